@@ -1,0 +1,131 @@
+/* nova_mi355x.h -- C ABI of libnova_mi355x.so: the MI355X (gfx950) commitment / MSM provider for Nova.
+ *
+ * Drop-in boundary.  Each entry point names the reference interface it replaces; paths are
+ * relative to the reference tree (microsoft/Nova, nova-snark 0.75.0).  The Rust-side binding a maintainer
+ * would add (an external `nova-mi355x-sys` shim crate, wired exactly where the optional CUDA `blitzar`
+ * backend is wired: src/provider/bn256_grumpkin.rs:43-78, src/provider/blitzar.rs:7-40) is in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every function returns 0 on success, a negative NMX_E_* otherwise, and
+ *     nmx_last_error() gives a thread-local message.  A failed call never writes a (possibly wrong) point.
+ *   - field elements: 32 bytes.  Default = canonical little-endian integer < modulus, i.e. the bytes of
+ *     `to_repr()` / `to_bytes()` (what blitzar.rs:10 sends).  With the *_MONT flags = the raw in-memory
+ *     4 x u64 Montgomery limbs (R = 2^256) of halo2curves (what `SerdeObject::write_raw` moves, ptau.rs:205).
+ *   - affine point: x || y, 64 bytes; the identity is the all-zero encoding in both forms
+ *     (src/provider/traits.rs:303-312 returns (0, 0, true)).
+ *   - results: affine canonical x || y plus an `is_inf` byte -- exactly `to_coordinates()`.
+ *   - all functions are thread-safe and re-entrant (the trait methods are static and are called from rayon
+ *     worker threads concurrently: src/r1cs/mod.rs:509-512, src/provider/hyperkzg.rs:1062-1065).
+ *   - inputs are borrowed for the duration of the call only.
+ */
+#ifndef NOVA_MI355X_H
+#define NOVA_MI355X_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* curve ids: src/provider/bn256_grumpkin.rs:26-33 (bn256, grumpkin), src/provider/pasta.rs:24-31 */
+enum { NMX_BN254_G1 = 0, NMX_GRUMPKIN = 1, NMX_PALLAS = 2, NMX_VESTA = 3, NMX_NUM_CURVES = 4 };
+
+/* flags */
+enum {
+  NMX_SCALARS_MONT = 1u << 0,   /* scalars are raw Montgomery limbs instead of canonical LE            */
+  NMX_BASES_MONT = 1u << 1,     /* base coordinates are raw Montgomery limbs instead of canonical LE     */
+  NMX_SCALARS_DEVICE = 1u << 2, /* `scalars` is a device (HBM) pointer on the library's device           */
+  NMX_BASES_DEVICE = 1u << 3,   /* `bases` is a device pointer (nmx_bases_register only)                 */
+  NMX_OUT_PARTIAL = 1u << 4     /* write a 128-byte (X,Y,ZZ,ZZZ) Montgomery partial sum instead of an     */
+                                /* affine point: the per-GPU result of a sharded MSM (nmx_point_sum)     */
+};
+
+/* error codes */
+enum {
+  NMX_OK = 0,
+  NMX_E_ARG = -1,          /* null pointer / bad curve id / bad flags / length mismatch                  */
+  NMX_E_NO_DEVICE = -2,    /* no usable HIP device: the library never falls back to a CPU path            */
+  NMX_E_HIP = -3,          /* a HIP runtime call failed (message has the hipError string)                 */
+  NMX_E_SCALAR_RANGE = -4, /* a canonical scalar >= modulus (from_repr would reject it)                   */
+  NMX_E_SMALL_RANGE = -5,  /* a small scalar >= 2^max_num_bits (msm.rs:543-552 would index out of bounds)  */
+  NMX_E_HANDLE = -6,       /* unknown / stale base handle, or offset + n beyond the registered key       */
+  NMX_E_TOO_LARGE = -7     /* n * windows >= 2^32                                                         */
+};
+
+/* ---- lifetime ------------------------------------------------------------------------------------- */
+/* Selects the HIP device for this process (one process per GPU) and creates the stream/workspace pool.
+ * Idempotent.  device < 0 => honour LOCAL_RANK, else device 0.  No reference counterpart (the reference is
+ * single-address-space); corresponds to blitzar's implicit backend init. */
+int nmx_init(int device);
+int nmx_shutdown(void);
+int nmx_device_count(void);
+const char* nmx_last_error(void);
+const char* nmx_version(void);
+
+/* ---- commitment-key residency ------------------------------------------------------------------------
+ * The reference passes bases as a prefix slice of a long-lived key (`&ck.ck[..v.len()]`,
+ * src/provider/pedersen.rs:267, src/provider/hyperkzg.rs:588).  Register the whole key once; every later
+ * call addresses bases[offset .. offset + n) of it in HBM.  `handle` 0 is never valid. */
+int nmx_bases_register(int curve, const void* bases_xy64, size_t n, uint32_t flags, uint64_t* handle);
+int nmx_bases_unregister(uint64_t handle);
+/* copies registered bases [offset, offset+n) back to the host as canonical x||y (test / key export helper) */
+int nmx_bases_read(uint64_t handle, size_t offset, size_t n, void* out_xy64);
+
+/* Synthetic key: P_i = (k0 + i) * G for i in [0, n), generated in HBM (the construction of
+ * src/provider/curve_property_tests.rs:186-194; plays the role of the test-utils `setup`,
+ * src/provider/hyperkzg.rs:357-376, whose real keys come from the host). */
+int nmx_bases_generate(int curve, uint64_t k0, size_t n, uint64_t* handle);
+
+/* ---- MSM ---------------------------------------------------------------------------------------------
+ * DlogGroupExt::vartime_multiscalar_mul (src/provider/traits.rs:79; impls src/provider/bn256_grumpkin.rs:45-47,
+ * src/provider/traits.rs:371-377) == msm() (src/provider/msm.rs:225-419):  out = sum_i scalars[i] * bases[i].
+ * n == 0 -> identity (msm.rs:228).  Identity bases and zero scalars contribute nothing (msm.rs:247-249). */
+int nmx_msm(int curve, const void* scalars, const void* bases_xy64, size_t n, uint32_t flags,
+            uint8_t* out, uint8_t* out_is_inf);
+/* same, bases taken from a registered key */
+int nmx_msm_handle(uint64_t handle, size_t offset, const void* scalars, size_t n, uint32_t flags,
+                   uint8_t* out, uint8_t* out_is_inf);
+
+/* DlogGroupExt::vartime_multiscalar_mul_small_with_max_num_bits (src/provider/traits.rs:99-106) ==
+ * msm_small_with_max_num_bits (src/provider/msm.rs:478-503): scalars are integers < 2^max_num_bits
+ * (u8..u64 widened by the caller, `Into<u64>`); max_num_bits == 0 -> identity (msm.rs:489).
+ * vartime_multiscalar_mul_small (traits.rs:93-96 / msm.rs:469-475) = this with max_num_bits = bit length of
+ * the largest scalar, which nmx_msm_u64 computes itself when max_num_bits == NMX_BITS_AUTO. */
+#define NMX_BITS_AUTO 0xffffffffu
+int nmx_msm_u64(int curve, const uint64_t* scalars, const void* bases_xy64, size_t n, uint32_t max_num_bits,
+                uint32_t flags, uint8_t* out, uint8_t* out_is_inf);
+int nmx_msm_u64_handle(uint64_t handle, size_t offset, const uint64_t* scalars, size_t n,
+                       uint32_t max_num_bits, uint32_t flags, uint8_t* out, uint8_t* out_is_inf);
+
+/* DlogGroupExt::batch_vartime_multiscalar_mul (src/provider/traits.rs:82-90; blitzar override
+ * src/provider/blitzar.rs:22-40): k MSMs over one base array, the j-th using bases[..lens[j]]
+ * (HyperKZG batch_commit, src/provider/hyperkzg.rs:593-612).  out = k x 64 bytes, out_is_inf = k bytes. */
+int nmx_msm_batch(int curve, const void* const* scalar_vecs, const size_t* lens, size_t k,
+                  const void* bases_xy64, size_t n_bases, uint32_t flags, uint8_t* out, uint8_t* out_is_inf);
+int nmx_msm_batch_handle(uint64_t handle, const void* const* scalar_vecs, const size_t* lens, size_t k,
+                         uint32_t flags, uint8_t* out, uint8_t* out_is_inf);
+
+/* CommitmentEngineTrait::commit (src/traits/commitment.rs:52-195; Pedersen src/provider/pedersen.rs:263-270,
+ * HyperKZG src/provider/hyperkzg.rs:584-591):  out = msm(v, ck[..n]) + h * r.  `h_xy64` / `r` follow the same
+ * flags as bases / scalars and are host pointers. */
+int nmx_commit(uint64_t ck_handle, const void* v, size_t n, const void* h_xy64, const void* r,
+               uint32_t flags, uint8_t* out, uint8_t* out_is_inf);
+
+/* Sum of `count` 128-byte partials (NMX_OUT_PARTIAL results gathered from the ranks of a sharded MSM) into one
+ * affine point: the G-term combine of SURVEY.md 8(e) (the reference's rayon `reduce(identity, +)`,
+ * src/provider/msm.rs:566-571,667-673). */
+int nmx_point_sum(int curve, const uint8_t* partials128, size_t count, uint8_t* out, uint8_t* out_is_inf);
+
+/* ---- measurement ------------------------------------------------------------------------------------
+ * With profiling on, every MSM brackets its stages with hipEvents on the stream the kernels run on;
+ * nmx_profile_last returns the last call's stage times in milliseconds (same thread).
+ * stage order: digits, sort, bounds+plan, accum, fold, reduce, tail(D2H+host Horner) ; returns #stages. */
+int nmx_set_profiling(int on);
+int nmx_profile_last(float* ms, int cap);
+/* forces the window width (0 = heuristic) -- tuning / tests only */
+int nmx_set_window_bits(uint32_t c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NOVA_MI355X_H */

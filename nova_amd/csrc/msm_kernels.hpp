@@ -1,0 +1,281 @@
+// msm_kernels.hpp -- the per-thread bodies of the Pippenger bucket-MSM kernels.
+//
+// Every kernel is a small functor with `operator()(uint32_t tid)`; msm_pipeline.hpp launches them through
+// one generic __global__ trampoline (device backend) -- or through a plain loop (tests/host_emul, g++ only,
+// used to debug indexing on machines without a GPU; never linked into libnova_mi355x.so).
+//
+// Replaces: /root/reference/src/provider/msm.rs:225-419 (`msm`), :478-503 (`msm_small_with_max_num_bits`)
+// and the third-party halo2curves::msm::msm_best they delegate to (msm.rs:411,500).
+//
+// Pipeline (N pairs, window width c, W = ceil((bits+1)/c) windows, M = 2^(c-1) buckets per window):
+//   1. DigitsFn      scalar -> W signed c-bit digits; emits (key = w*M + |d|-1, val = idx | sign<<31);
+//                    zero digits / zero scalars / identity bases (msm.rs:247-249) get the trash key W*M.
+//   2. radix sort    (key, val) pairs by key              [rocPRIM on the device backend]
+//   3. BoundsFn      bucket k -> [start, end) in the sorted array
+//   4. PlanFn        buckets longer than lmax are split into lmax-sized extra tasks (bounded work per lane
+//                    whatever the scalar distribution: all-equal scalars put N points in one bucket)
+//   5. AccumFn       one lane per (bucket | extra task): gather affine points, XYZZ mixed adds (msm.rs:129-165)
+//   6. FoldFn x3     strided folds of a heavy bucket's partial sums -> bucket
+//   7. ReduceFn...   per-window sum_k k*B_k by segmented running sums, log_m(M) levels (msm.rs:555-561,637-643
+//                    do this serially per thread; here it is a tree so 16 windows x 32768 buckets fill the chip)
+//   8. host tail     Horner over the W window sums (msm.rs:651-661), one inversion, canonical bytes.
+#pragma once
+#include "curve.hpp"
+
+namespace nmx {
+
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ uint32_t nmx_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
+__device__ __forceinline__ void nmx_atomic_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
+#else
+inline uint32_t nmx_atomic_add(uint32_t* p, uint32_t v) {
+  uint32_t o = *p;
+  *p = o + v;
+  return o;
+}
+inline void nmx_atomic_or(uint32_t* p, uint32_t v) { *p |= v; }
+#endif
+
+// error bits accumulated on the device
+enum : uint32_t { ERR_SCALAR_RANGE = 1u, ERR_SMALL_RANGE = 2u };
+
+struct MsmShape {
+  uint32_t n;         // pairs
+  uint32_t c;         // window width (bits)
+  uint32_t W;         // windows
+  uint32_t M;         // buckets per window = 2^(c-1)
+  uint32_t nbuckets;  // W*M ; key nbuckets is the trash bucket
+  uint32_t lmax;      // longest run one lane accumulates
+  uint32_t total;     // n*W sorted entries
+};
+
+// ----------------------------------------------------------------------------------------------------
+// 1. digits
+// ----------------------------------------------------------------------------------------------------
+// Signed-digit recoding: d_w in [-(2^(c-1) - 1), 2^(c-1)], sum_w d_w 2^(cw) = s.  With W*c >= bits + 1 the final
+// carry is always zero.
+template <int SFID> struct DigitsFn {
+  const uint32_t* scalars;  // n x 8 u32 (canonical or Montgomery), or n x 2 (u64 mode)
+  const uint32_t* bases;    // n x 16 u32: only tested for the all-zero identity encoding; may be null
+  uint32_t* keys;           // W x n
+  uint32_t* vals;           // W x n
+  uint32_t* err;
+  MsmShape sh;
+  uint32_t scalars_mont;  // 1: scalars are in Montgomery form
+  uint32_t u64_bits;      // 0: field scalars; >0: scalars are u64 and must be < 2^u64_bits
+
+  NMX_HD void operator()(uint32_t i) const {
+    uint32_t s[9];
+    bool skip = false;
+    if (u64_bits) {
+      s[0] = scalars[2 * (size_t)i];
+      s[1] = scalars[2 * (size_t)i + 1];
+#pragma unroll
+      for (int j = 2; j < 9; j++) s[j] = 0;
+      if (u64_bits < 64) {
+        uint64_t v = ((uint64_t)s[1] << 32) | s[0];
+        if (v >> u64_bits) {
+          nmx_atomic_or(err, ERR_SMALL_RANGE);
+          skip = true;
+        }
+      }
+    } else {
+      Fp<SFID> f;
+#pragma unroll
+      for (int j = 0; j < 8; j++) f.l[j] = scalars[8 * (size_t)i + j];
+      if (!f.lt_p()) {  // from_repr would have rejected it on the reference side
+        nmx_atomic_or(err, ERR_SCALAR_RANGE);
+        skip = true;
+      }
+      if (scalars_mont) f = f.from_mont();
+#pragma unroll
+      for (int j = 0; j < 8; j++) s[j] = f.l[j];
+      s[8] = 0;
+    }
+    if (bases) {  // identity base contributes nothing (msm.rs:247-249)
+      uint32_t o = 0;
+      const uint32_t* b = bases + 16 * (size_t)i;
+#pragma unroll
+      for (int j = 0; j < 16; j++) o |= b[j];
+      if (o == 0) skip = true;
+    }
+    uint32_t carry = 0;
+    const uint32_t mask = (1u << sh.c) - 1u;
+    const uint32_t half = sh.M;  // 2^(c-1)
+    for (uint32_t w = 0; w < sh.W; w++) {
+      uint32_t bit = w * sh.c;
+      uint32_t word = bit >> 5, off = bit & 31;
+      uint64_t two = (word < 8) ? (((uint64_t)s[word + 1] << 32) | s[word]) : 0;
+      uint32_t d = (uint32_t)((two >> off) & mask) + carry;
+      uint32_t neg = 0;
+      if (d > half) {
+        d = (1u << sh.c) - d;
+        neg = 1;
+        carry = 1;
+      } else {
+        carry = 0;
+      }
+      uint32_t key = (d == 0 || skip) ? sh.nbuckets : (w * sh.M + d - 1);
+      size_t o = (size_t)w * sh.n + i;
+      keys[o] = key;
+      vals[o] = i | (neg << 31);
+    }
+  }
+};
+
+// ----------------------------------------------------------------------------------------------------
+// 3. bucket boundaries in the sorted key array
+// ----------------------------------------------------------------------------------------------------
+struct BoundsFn {
+  const uint32_t* keys;  // sorted
+  uint32_t* start;       // nbuckets + 1, zero-initialised
+  uint32_t* end;         // nbuckets + 1, zero-initialised
+  uint32_t total;
+  NMX_HD void operator()(uint32_t j) const {
+    uint32_t k = keys[j];
+    if (j == 0 || keys[j - 1] != k) start[k] = j;
+    if (j + 1 == total || keys[j + 1] != k) end[k] = j + 1;
+  }
+};
+
+// ----------------------------------------------------------------------------------------------------
+// 4. plan: split over-long buckets
+// ----------------------------------------------------------------------------------------------------
+struct HeavyRec {
+  uint32_t bucket, off, cnt, pad;
+};
+struct TaskRec {
+  uint32_t start, len;
+};
+struct PlanFn {
+  const uint32_t* start;
+  const uint32_t* end;
+  uint32_t* counters;  // [0] = extra tasks used, [1] = heavy buckets
+  HeavyRec* heavy;
+  TaskRec* extra;
+  MsmShape sh;
+  NMX_HD void operator()(uint32_t k) const {
+    uint32_t s = end[k] - start[k];
+    if (s <= sh.lmax) return;
+    uint32_t nt = (s + sh.lmax - 1) / sh.lmax;
+    uint32_t off = nmx_atomic_add(&counters[0], nt);
+    uint32_t h = nmx_atomic_add(&counters[1], 1);
+    heavy[h] = HeavyRec{k, off, nt, 0};
+    for (uint32_t t = 0; t < nt; t++) {
+      uint32_t b = t * sh.lmax;
+      uint32_t len = s - b < sh.lmax ? s - b : sh.lmax;
+      extra[off + t] = TaskRec{start[k] + b, len};
+    }
+  }
+};
+
+// ----------------------------------------------------------------------------------------------------
+// 5. bucket accumulation (the dominant kernel)
+// ----------------------------------------------------------------------------------------------------
+template <int FID> struct AccumFn {
+  const Affine<FID>* bases;  // Montgomery form
+  const uint32_t* vals;      // sorted
+  const uint32_t* start;
+  const uint32_t* end;
+  const uint32_t* counters;
+  const TaskRec* extra;
+  XYZZ<FID>* buckets;   // nbuckets
+  XYZZ<FID>* partials;  // extra-task results
+  MsmShape sh;
+
+  NMX_HD XYZZ<FID> run(uint32_t b, uint32_t len) const {
+    XYZZ<FID> acc = XYZZ<FID>::identity();
+    for (uint32_t j = 0; j < len; j++) {
+      uint32_t v = vals[b + j];
+      Affine<FID> p = bases[v & 0x7fffffffu];
+      if (v >> 31) p.y = p.y.neg();
+      acc.add_affine(p.x, p.y);
+    }
+    return acc;
+  }
+  NMX_HD void operator()(uint32_t t) const {
+    if (t < sh.nbuckets) {
+      uint32_t b = start[t], s = end[t] - b;
+      if (s <= sh.lmax) buckets[t] = run(b, s);  // heavy buckets are written by the folds
+    } else {
+      uint32_t e = t - sh.nbuckets;
+      if (e >= counters[0]) return;
+      TaskRec r = extra[e];
+      partials[e] = run(r.start, r.len);
+    }
+  }
+};
+
+// ----------------------------------------------------------------------------------------------------
+// 6. strided fold of heavy buckets' partials.  Lane j of group g folds positions j, j+T, j+2T, ... < cnt
+//    into position j.  Applied with T = 256, 16, 1 (cnt = all, 256, 16); the last pass writes the bucket.
+// ----------------------------------------------------------------------------------------------------
+template <int FID> struct FoldFn {
+  const uint32_t* counters;
+  const HeavyRec* heavy;
+  XYZZ<FID>* partials;
+  XYZZ<FID>* buckets;
+  uint32_t T;       // lanes per heavy bucket in this pass
+  uint32_t cap;     // positions valid on entry = min(cnt, cap); cap = 0xffffffff for the first pass
+  uint32_t groups;  // grid = groups * T lanes; groups loop over the heavy list
+  NMX_HD void operator()(uint32_t tid) const {
+    uint32_t j = tid % T;
+    uint32_t nh = counters[1];
+    for (uint32_t h = tid / T; h < nh; h += groups) {
+      HeavyRec r = heavy[h];
+      uint32_t cnt = r.cnt < cap ? r.cnt : cap;
+      if (j >= cnt) continue;
+      XYZZ<FID> acc = partials[r.off + j];
+      for (uint32_t q = j + T; q < cnt; q += T) acc.add(partials[r.off + q]);
+      if (T == 1)
+        buckets[r.bucket] = acc;
+      else
+        partials[r.off + j] = acc;
+    }
+  }
+};
+
+// ----------------------------------------------------------------------------------------------------
+// 7. bucket reduction:  F = sum_{k=1..n} k * B_k  per window, as a tree.
+//    Invariant per window:  F = Sum(Y) + 2^ls * G(A),  G(X) = sum_{k=0..n-1} k * X_k.
+//    Start: A = Y = B, ls = 0 (F = G(B) + Sum(B)).  One level with segment length m:
+//      A'_u = sum_j A_{um+j};  g_u = sum_j j*A_{um+j};  Y'_u = sum_j Y_{um+j} + 2^ls * g_u;  ls' = ls + log2 m.
+// ----------------------------------------------------------------------------------------------------
+template <int FID> struct ReduceFn {
+  const XYZZ<FID>* A;
+  const XYZZ<FID>* Y;  // == A on the first level
+  XYZZ<FID>* A_out;
+  XYZZ<FID>* Y_out;
+  uint32_t n_in;   // elements per window on entry
+  uint32_t m;      // segment length (divides n_in)
+  uint32_t ls;     // log2 of the scale carried by G(A)
+  uint32_t first;  // 1: Y aliases A (first level)
+  NMX_HD void operator()(uint32_t tid) const {
+    uint32_t n_out = n_in / m;
+    uint32_t w = tid / n_out, u = tid % n_out;
+    size_t base = (size_t)w * n_in + (size_t)u * m;
+    XYZZ<FID> run = XYZZ<FID>::identity();  // running suffix sum of A
+    XYZZ<FID> g = XYZZ<FID>::identity();    // sum_j j*A_j (0-based)
+    for (uint32_t j = m - 1; j >= 1; j--) {
+      run.add(A[base + j]);
+      g.add(run);
+    }
+    XYZZ<FID> y;
+    if (first) {
+      // Y == A: Sum(Y seg) + g = sum_j (j+1) A_j = g + run + A_0
+      run.add(A[base]);
+      y = g;
+      y.add(run);
+    } else {
+      run.add(A[base]);
+      for (uint32_t q = 0; q < ls; q++) g.dbl_in_place();
+      y = g;
+      for (uint32_t j = 0; j < m; j++) y.add(Y[base + j]);
+    }
+    size_t o = (size_t)w * n_out + u;
+    A_out[o] = run;
+    Y_out[o] = y;
+  }
+};
+
+}  // namespace nmx

@@ -1,0 +1,130 @@
+// tests/host_emul/emul.cpp -- TEST-ONLY serial emulation of the HIP kernels (g++; never linked into the product).
+//
+// Runs the *same* functor bodies and the same msm_pipeline() orchestration as libnova_mi355x.so, with a backend
+// made of plain loops and std::stable_sort.  Purpose: catch indexing / recoding / edge-case bugs in the kernel
+// bodies on machines without a GPU (the build container), so GPU minutes are spent on parity and timing rather
+// than on debugging.  It is not an oracle (it shares code with the product) and not a fallback (the product
+// returns NMX_E_NO_DEVICE without a GPU); tests compare it against oracle/ like any other implementation.
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <numeric>
+#include <vector>
+
+#include "../../nova_amd/csrc/curves.hpp"
+#include "../../nova_amd/csrc/msm_pipeline.hpp"
+
+using namespace nmx;
+
+struct HostEmulBackend {
+  std::vector<void*> blocks;
+  ~HostEmulBackend() {
+    for (void* p : blocks) free(p);
+  }
+  template <class T> T* alloc(size_t count) {
+    void* p = calloc(count ? count : 1, sizeof(T));
+    blocks.push_back(p);
+    return (T*)p;
+  }
+  void memset0(void* p, size_t bytes) { memset(p, 0, bytes); }
+  template <class F> void launch(const F& f, uint32_t n) {
+    for (uint32_t t = 0; t < n; t++) f(t);
+  }
+  void sort_pairs(uint32_t* k_in, uint32_t* k_out, uint32_t* v_in, uint32_t* v_out, size_t total, uint32_t bits) {
+    std::vector<uint32_t> idx(total);
+    std::iota(idx.begin(), idx.end(), 0u);
+    uint32_t mask = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
+    std::stable_sort(idx.begin(), idx.end(),
+                     [&](uint32_t a, uint32_t b) { return (k_in[a] & mask) < (k_in[b] & mask); });
+    for (size_t i = 0; i < total; i++) {
+      k_out[i] = k_in[idx[i]];
+      v_out[i] = v_in[idx[i]];
+    }
+  }
+  void d2h(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); }
+  void sync() {}
+  void mark(const char*) {}
+};
+
+template <int CID>
+static int emul_msm_t(const uint8_t* scalars, const uint8_t* bases_xy64, size_t n, uint32_t u64_bits,
+                      uint32_t u64_mode, uint32_t scalars_mont, uint32_t force_c, uint8_t* out, uint8_t* inf) {
+  using C = CurveT<CID>;
+  constexpr int BF = C::BF, SF = C::SF;
+  XYZZ<BF> r = XYZZ<BF>::identity();
+  if (n != 0 && !(u64_mode && u64_bits == 0)) {
+    std::vector<Affine<BF>> b(n);
+    for (size_t i = 0; i < n; i++) {
+      b[i].x = fp_from_bytes<BF>(bases_xy64 + 64 * i).to_mont();
+      b[i].y = fp_from_bytes<BF>(bases_xy64 + 64 * i + 32).to_mont();
+    }
+    MsmArgs a;
+    a.scalars = (const uint32_t*)scalars;
+    a.bases = b.data();
+    a.n = (uint32_t)n;
+    a.scalars_mont = scalars_mont;
+    a.u64_bits = u64_mode ? u64_bits : 0;
+    a.force_c = force_c;
+    HostEmulBackend be;
+    XYZZ<BF> wsum[260];
+    uint32_t err = 0;
+    MsmShape sh = msm_pipeline<HostEmulBackend, BF, SF>(be, a, FpParams<SF>::BITS, wsum, &err);
+    if (err) return -(int)err - 100;
+    r = combine_windows<BF>(wsum, sh);
+  }
+  xyzz_to_xy64<BF>(r, out, inf);
+  return 0;
+}
+
+template <int FID> static void fp_op_t(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  Fp<FID> x = fp_from_bytes<FID>(a), y = fp_from_bytes<FID>(b), r;
+  switch (op) {
+    case 0: r = x * y; break;      // Montgomery product
+    case 1: r = x + y; break;
+    case 2: r = x - y; break;
+    case 3: r = x.to_mont(); break;
+    case 4: r = x.from_mont(); break;
+    case 5: r = x.inv(); break;    // Montgomery-domain inverse
+    case 6: r = x.neg(); break;
+    case 7: r = x.sqr(); break;
+    default: r = Fp<FID>::zero();
+  }
+  fp_to_bytes(r, out);
+}
+
+extern "C" {
+
+int emul_msm(int curve, const uint8_t* scalars, const uint8_t* bases_xy64, size_t n, uint32_t u64_bits,
+             uint32_t u64_mode, uint32_t scalars_mont, uint32_t force_c, uint8_t* out, uint8_t* inf) {
+  switch (curve) {
+    case 0: return emul_msm_t<0>(scalars, bases_xy64, n, u64_bits, u64_mode, scalars_mont, force_c, out, inf);
+    case 1: return emul_msm_t<1>(scalars, bases_xy64, n, u64_bits, u64_mode, scalars_mont, force_c, out, inf);
+    case 2: return emul_msm_t<2>(scalars, bases_xy64, n, u64_bits, u64_mode, scalars_mont, force_c, out, inf);
+    case 3: return emul_msm_t<3>(scalars, bases_xy64, n, u64_bits, u64_mode, scalars_mont, force_c, out, inf);
+  }
+  return -1;
+}
+
+int emul_fp_op(int fid, int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  switch (fid) {
+    case 0: fp_op_t<0>(op, a, b, out); return 0;
+    case 1: fp_op_t<1>(op, a, b, out); return 0;
+    case 2: fp_op_t<2>(op, a, b, out); return 0;
+    case 3: fp_op_t<3>(op, a, b, out); return 0;
+  }
+  return -1;
+}
+
+// generator of curve `cid` as canonical x||y (checks the constants in curves.hpp)
+int emul_generator(int curve, uint8_t* out) {
+  switch (curve) {
+    case 0: memcpy(out, CurveT<0>::GX, 32); memcpy(out + 32, CurveT<0>::GY, 32); return 0;
+    case 1: memcpy(out, CurveT<1>::GX, 32); memcpy(out + 32, CurveT<1>::GY, 32); return 0;
+    case 2: memcpy(out, CurveT<2>::GX, 32); memcpy(out + 32, CurveT<2>::GY, 32); return 0;
+    case 3: memcpy(out, CurveT<3>::GX, 32); memcpy(out + 32, CurveT<3>::GY, 32); return 0;
+  }
+  return -1;
+}
+}
