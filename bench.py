@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- BN254 MSM throughput (BASELINE.json metric: scalar-point pairs/s) on N MI355X GPUs of one node.
+
+A "step" is one pass of the hot path over one batch of synthetic input: one `CommitmentEngine::commit(ck, v, 0)`
+(= DlogGroupExt::vartime_multiscalar_mul, /root/reference benches/commit.rs:120-124) over 2^LOG2N uniformly random
+BN254 scalars per GPU, commitment key resident in HBM, scalars resident in HBM when the timed region starts.
+N > 1: every rank runs the full single-GPU MSM on its own contiguous shard of the (scalar, base) array (weak
+scaling: 2^LOG2N pairs per GPU), then the 128-byte partial sums are all-gathered over RCCL and combined
+(SURVEY.md 8(e)); value = pairs of all ranks / max-over-ranks time.
+
+  python bench.py                      # 1 GPU, 2^20 pairs, prints ONE JSON line
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus 8 --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+BYTES_PER_PAIR = 96            # 32 B scalar + 64 B affine base, each read once
+STAGES = ["digits", "sort", "bounds_plan", "accum", "fold", "reduce", "tail"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log2n", type=int, default=20, help="pairs per GPU = 2^log2n (BASELINE configs[1]: 20)")
+    ap.add_argument("--curve", type=int, default=0, help="0 bn254_g1 (headline), 1 grumpkin, 2 pallas, 3 vesta")
+    ap.add_argument("--dist", default="random", help="scalar distribution: random | u1 | u10 | u16 | u32 | u64")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--window-bits", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import nova_amd
+    from nova_amd import _lib
+    from tests import util
+    L = _lib.lib()
+    rc = L.nmx_init(local_rank)
+    assert rc == 0, L.nmx_last_error().decode()
+    if args.window_bits:
+        L.nmx_set_window_bits(args.window_bits)
+
+    n = 1 << args.log2n
+    cid = args.curve
+    ce = nova_amd.CommitmentEngine(cid)
+    group = ce.group
+    # shard `rank` of the key: bases P_i = (1 + rank*n + i) * G, generated in HBM
+    ck = nova_amd.CommitmentKey.generate(cid, n, k0=1 + rank * n)
+    # two scalar vectors per rank, alternated between steps, resident in HBM before timing starts
+    host_sc = [util.scalar_set(cid, n, args.dist, seed=util.SEED + 1000 * rank + j) for j in range(2)]
+    dev_sc = [torch.from_numpy(s.copy()).cuda() for s in host_sc]
+    from nova_amd.dist import sharded_msm
+
+    def step(j):
+        if world == 1:
+            return group.vartime_multiscalar_mul(dev_sc[j & 1], ck)
+        return sharded_msm(group, ck, dev_sc[j & 1])
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for j in range(args.warmup):
+        step(j)
+    L.nmx_set_profiling(1)
+    import ctypes
+    prof = (ctypes.c_float * 16)()
+    stage_sum = np.zeros(len(STAGES))
+    fence()
+    t0 = time.perf_counter()
+    result = None
+    for j in range(args.steps):
+        result = step(j)
+        k = L.nmx_profile_last(prof, 16)  # hipEvent times of this step's kernels, on the library's stream
+        stage_sum[:k] += np.array(prof[:k])
+    fence()
+    dt = time.perf_counter() - t0
+    L.nmx_set_profiling(0)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        stage_ms = stage_sum / max(args.steps, 1)
+        accum_ms = float(stage_ms[STAGES.index("accum")])
+        pairs = n * world * args.steps
+        achieved = BYTES_PER_PAIR * n / (accum_ms * 1e-3) / 1e9 if accum_ms > 0 else 0.0
+        out = {
+            "metric": "BN254 MSM scalar-point pairs/sec" if cid == 0 else f"{nova_amd.CURVE_NAMES[cid]} MSM scalar-point pairs/sec",
+            "value": pairs / dt,
+            "unit": "pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32x8 (256-bit modular integer, Montgomery)",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{nova_amd.CURVE_NAMES[cid]} Pippenger MSM 2^{args.log2n} pairs per GPU, {args.dist} scalars, "
+                            "bases+scalars resident in HBM (BASELINE.json configs[1])",
+                "pairs_per_gpu": n,
+                "parallelism": f"shard{world}" if world > 1 else "single",
+                "combine": "rccl all_gather of 128-byte partials + host point sum" if world > 1 else "none",
+            },
+            "stages_ms": {s: round(float(v), 4) for s, v in zip(STAGES, stage_ms)},
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_launch<AccumFn> (bucket accumulation)",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "note": "algorithmic bytes = 96 B/pair x pairs per launch / accum-kernel time (hipEvents on the "
+                        "library stream); the MSM is integer-VALU-bound, not HBM-bound (DESIGN.md)",
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cid, ck, host_sc[(args.steps - 1) & 1], n, result)
+        print(json.dumps(out), flush=True)
+    ck.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cid, ck, scalars, n, gpu_result):
+    """The oracle (C restatement of the reference's msm(), OpenMP over all host cores) timed on the same inputs,
+    bounded to ~10-30 s of CPU work; also cross-checks the GPU result when the sample is the whole workload."""
+    from oracle import cref
+    threads = os.cpu_count() or 1
+    cref.set_threads(threads)
+    sample = min(n, 1 << 20)
+    host = ck.read(0, sample)
+    prep = cref.Prepared(cid, host, sample)
+    sc = np.ascontiguousarray(scalars[:sample])
+    best = None
+    res = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        res = prep.msm(sc, sample)
+        t = time.perf_counter() - t0
+        best = t if best is None else min(best, t)
+    out = {
+        "value": sample / best,
+        "unit": "pairs/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"2^{sample.bit_length() - 1} pairs of the same workload, best of 2, oracle/nova_ref.c "
+                  "(C restatement of msm.rs + Pippenger in the msm_best role; the Rust reference cannot be built here)",
+        "seconds": best,
+    }
+    if sample == n and gpu_result is not None and len(gpu_result.xy) == 64:
+        out["gpu_matches_cpu"] = (gpu_result.xy, int(gpu_result.is_inf)) == res
+    return out
+
+
+if __name__ == "__main__":
+    main()

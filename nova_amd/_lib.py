@@ -1,0 +1,48 @@
+"""ctypes binding of include/nova_mi355x.h.  Fails loudly when the HIP library has not been built."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libnova_mi355x.so")
+
+# flags / error codes (include/nova_mi355x.h)
+SCALARS_MONT, BASES_MONT, SCALARS_DEVICE, BASES_DEVICE, OUT_PARTIAL = 1, 2, 4, 8, 16
+E_ARG, E_NO_DEVICE, E_HIP, E_SCALAR_RANGE, E_SMALL_RANGE, E_HANDLE, E_TOO_LARGE = -1, -2, -3, -4, -5, -6, -7
+BITS_AUTO = 0xFFFFFFFF
+
+_lib = None
+
+
+def lib():
+    """The loaded library.  No fallback: a missing .so is an error (run `python -c 'import __graft_entry__ as g; g.build()'`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError(
+            f"{SO_PATH} is missing: build the HIP extension first (__graft_entry__.build()); "
+            "nova_amd has no CPU fallback")
+    L = ctypes.CDLL(SO_PATH)
+    i, u32, u64, sz, vp = ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_size_t, ctypes.c_void_p
+    L.nmx_init.argtypes = [i]
+    L.nmx_shutdown.argtypes = []
+    L.nmx_device_count.argtypes = []
+    L.nmx_last_error.restype = ctypes.c_char_p
+    L.nmx_version.restype = ctypes.c_char_p
+    L.nmx_bases_register.argtypes = [i, vp, sz, u32, ctypes.POINTER(u64)]
+    L.nmx_bases_unregister.argtypes = [u64]
+    L.nmx_bases_read.argtypes = [u64, sz, sz, vp]
+    L.nmx_bases_generate.argtypes = [i, u64, sz, ctypes.POINTER(u64)]
+    L.nmx_msm.argtypes = [i, vp, vp, sz, u32, vp, vp]
+    L.nmx_msm_handle.argtypes = [u64, sz, vp, sz, u32, vp, vp]
+    L.nmx_msm_u64.argtypes = [i, vp, vp, sz, u32, u32, vp, vp]
+    L.nmx_msm_u64_handle.argtypes = [u64, sz, vp, sz, u32, u32, vp, vp]
+    L.nmx_msm_batch.argtypes = [i, vp, vp, sz, vp, sz, u32, vp, vp]
+    L.nmx_msm_batch_handle.argtypes = [u64, vp, vp, sz, u32, vp, vp]
+    L.nmx_commit.argtypes = [u64, vp, sz, vp, vp, u32, vp, vp]
+    L.nmx_point_sum.argtypes = [i, vp, sz, vp, vp]
+    L.nmx_set_profiling.argtypes = [i]
+    L.nmx_profile_last.argtypes = [ctypes.POINTER(ctypes.c_float), i]
+    L.nmx_set_window_bits.argtypes = [u32]
+    _lib = L
+    return L

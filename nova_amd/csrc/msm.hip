@@ -613,7 +613,6 @@ int nmx_commit(uint64_t ck_handle, const void* v, size_t n, const void* h_xy64, 
                uint32_t flags, uint8_t* out, uint8_t* out_is_inf) {
   return guarded([&] {
     require(out && (v || n == 0) && h_xy64 && r, NMX_E_ARG, "null argument");
-    require(!(flags & NMX_OUT_PARTIAL), NMX_E_ARG, "NMX_OUT_PARTIAL is not supported for commit");
     auto bs = lookup(ck_handle);
     require(n <= bs.n, NMX_E_HANDLE, "ck shorter than v");  // assert!(ck.ck.len() >= v.len()), pedersen.rs:264
     CtxLease L;

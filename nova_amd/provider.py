@@ -1,0 +1,225 @@
+"""Host-side mirror of the reference's provider interface for the commitment / MSM path.
+
+Same names, argument meaning and error behaviour as the reference (paths relative to /root/reference):
+  DlogGroupExt             src/provider/traits.rs:77-117   -> class DlogGroup
+  CommitmentEngineTrait    src/traits/commitment.rs:52-195 -> class CommitmentEngine
+  Pedersen / HyperKZG CE   src/provider/pedersen.rs:240-305, src/provider/hyperkzg.rs:584-645
+Every group operation happens inside libnova_mi355x.so; this module only marshals buffers.
+
+Buffers: scalars are (n, 32) uint8 -- canonical little-endian by default (`to_repr()`), raw Montgomery limbs
+with mont=True; small scalars are uint64 arrays; bases are (n, 64) uint8 x||y, identity = 64 zero bytes.
+A torch CUDA uint8 / int64 tensor may be passed for scalars: it is used in place (HBM-resident input).
+"""
+import ctypes
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib as L
+
+BN254_G1, GRUMPKIN, PALLAS, VESTA = 0, 1, 2, 3
+CURVE_NAMES = {0: "bn254_g1", 1: "grumpkin", 2: "pallas", 3: "vesta"}
+
+
+class NmxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"nmx error {code}: {msg}")
+        self.code = code
+
+
+def _check(rc):
+    if rc != 0:
+        raise NmxError(rc, L.lib().nmx_last_error().decode())
+
+
+def _is_device_tensor(x):
+    return hasattr(x, "data_ptr") and getattr(x, "is_cuda", False)
+
+
+def _host_u8(x, width):
+    """-> contiguous uint8 array with trailing dimension `width` (or empty)."""
+    if isinstance(x, (bytes, bytearray, memoryview)):
+        x = np.frombuffer(bytes(x), dtype=np.uint8)
+    a = np.ascontiguousarray(x, dtype=np.uint8).reshape(-1)
+    assert a.size % width == 0, f"buffer length {a.size} is not a multiple of {width}"
+    return a
+
+
+def _scalar_arg(s, width):
+    """-> (pointer, n, device_flag, keepalive)"""
+    if _is_device_tensor(s):
+        assert s.is_contiguous()
+        nbytes = s.numel() * s.element_size()
+        assert nbytes % width == 0
+        return s.data_ptr(), nbytes // width, L.SCALARS_DEVICE, s
+    if width == 8:
+        a = np.ascontiguousarray(s, dtype=np.uint64).reshape(-1)
+        return a.ctypes.data, a.size, 0, a
+    a = _host_u8(s, width)
+    return a.ctypes.data, a.size // width, 0, a
+
+
+@dataclass(frozen=True)
+class Commitment:
+    """Affine result, as `to_coordinates()` returns it (src/provider/traits.rs:303-312)."""
+    xy: bytes          # canonical x||y, 64 bytes; zeros for the identity
+    is_inf: bool
+
+    def to_coordinates(self):
+        return (int.from_bytes(self.xy[:32], "little"), int.from_bytes(self.xy[32:], "little"), self.is_inf)
+
+
+class _Out:
+    def __init__(self, k=1, partial=False):
+        self.w = 128 if partial else 64
+        self.buf = np.zeros(self.w * max(k, 1), dtype=np.uint8)
+        self.inf = np.zeros(max(k, 1), dtype=np.uint8)
+
+    @property
+    def p(self):
+        return self.buf.ctypes.data, self.inf.ctypes.data
+
+    def get(self, j=0):
+        return Commitment(self.buf[self.w * j: self.w * (j + 1)].tobytes(), bool(self.inf[j]))
+
+
+class CommitmentKey:
+    """A commitment key resident in HBM: `ck` bases + blinding generator `h`
+    (src/provider/pedersen.rs:33-45, src/provider/hyperkzg.rs:84-100).  The reference passes `&ck.ck[..n]`
+    slices; here the key is registered once (nmx_bases_register) and calls address a prefix of it."""
+
+    def __init__(self, curve, handle, n, h_xy64, mont=False):
+        self.curve, self.handle, self.n, self.mont = curve, handle, n, mont
+        self.h = bytes(h_xy64)
+
+    @classmethod
+    def from_host(cls, curve, ck_xy64, h_xy64=None, mont=False):
+        a = _host_u8(ck_xy64, 64)
+        n = a.size // 64
+        h = ctypes.c_uint64(0)
+        _check(L.lib().nmx_bases_register(curve, a.ctypes.data, n, L.BASES_MONT if mont else 0, ctypes.byref(h)))
+        return cls(curve, h.value, n, h_xy64 if h_xy64 is not None else bytes(64), mont)
+
+    @classmethod
+    def generate(cls, curve, n, k0=1):
+        """Synthetic key P_i = (k0 + i) * G built on the device (nmx_bases_generate); h = P_n."""
+        h = ctypes.c_uint64(0)
+        _check(L.lib().nmx_bases_generate(curve, k0, n + 1, ctypes.byref(h)))
+        key = cls(curve, h.value, n, bytes(64))
+        key.h = key.read(n, 1).tobytes()
+        return key
+
+    def read(self, offset, n):
+        out = np.zeros((n, 64), dtype=np.uint8)
+        _check(L.lib().nmx_bases_read(self.handle, offset, n, out.ctypes.data))
+        return out
+
+    def __len__(self):
+        return self.n
+
+    def close(self):
+        if self.handle:
+            _check(L.lib().nmx_bases_unregister(self.handle))
+            self.handle = 0
+
+
+class DlogGroup:
+    """`DlogGroupExt` for one curve (src/provider/traits.rs:77-117)."""
+
+    def __init__(self, curve):
+        assert curve in CURVE_NAMES
+        self.curve = curve
+
+    # -- vartime_multiscalar_mul (traits.rs:79; msm(), src/provider/msm.rs:225) -------------------------
+    def vartime_multiscalar_mul(self, scalars, bases, mont=False, partial=False):
+        sp, n, dev, _k = _scalar_arg(scalars, 32)
+        flags = dev | (L.SCALARS_MONT if mont else 0) | (L.OUT_PARTIAL if partial else 0)
+        out = _Out(partial=partial)
+        if isinstance(bases, CommitmentKey):
+            assert bases.curve == self.curve
+            assert n <= bases.n, "assert_eq!(coeffs.len(), bases.len()) / ck.len() >= v.len()"
+            _check(L.lib().nmx_msm_handle(bases.handle, 0, sp, n, flags, *out.p))
+        else:
+            b = _host_u8(bases, 64)
+            assert b.size // 64 == n, "assert_eq!(coeffs.len(), bases.len())  (msm.rs:226)"
+            _check(L.lib().nmx_msm(self.curve, sp, b.ctypes.data, n, flags | (L.BASES_MONT if mont else 0), *out.p))
+        return out.get()
+
+    # -- batch_vartime_multiscalar_mul (traits.rs:82-90; blitzar.rs:22-40) -----------------------------
+    def batch_vartime_multiscalar_mul(self, scalar_vecs, bases, mont=False):
+        k = len(scalar_vecs)
+        args = [_scalar_arg(v, 32) for v in scalar_vecs]
+        dev = {a[2] for a in args}
+        assert len(dev) <= 1, "all vectors must live on the same side"
+        flags = (dev.pop() if dev else 0) | (L.SCALARS_MONT if mont else 0)
+        ptrs = (ctypes.c_void_p * max(k, 1))(*[a[0] for a in args])
+        lens = (ctypes.c_size_t * max(k, 1))(*[a[1] for a in args])
+        out = _Out(k)
+        if isinstance(bases, CommitmentKey):
+            _check(L.lib().nmx_msm_batch_handle(bases.handle, ptrs, lens, k, flags, *out.p))
+        else:
+            b = _host_u8(bases, 64)
+            _check(L.lib().nmx_msm_batch(self.curve, ptrs, lens, k, b.ctypes.data, b.size // 64,
+                                         flags | (L.BASES_MONT if mont else 0), *out.p))
+        return [out.get(j) for j in range(k)]
+
+    # -- vartime_multiscalar_mul_small* (traits.rs:93-106; msm.rs:469-503) ---------------------------------
+    def vartime_multiscalar_mul_small(self, scalars, bases, partial=False):
+        return self.vartime_multiscalar_mul_small_with_max_num_bits(scalars, bases, None, partial)
+
+    def vartime_multiscalar_mul_small_with_max_num_bits(self, scalars, bases, max_num_bits, partial=False):
+        sp, n, dev, _k = _scalar_arg(scalars, 8)
+        bits = L.BITS_AUTO if max_num_bits is None else int(max_num_bits)
+        flags = dev | (L.OUT_PARTIAL if partial else 0)
+        out = _Out(partial=partial)
+        if isinstance(bases, CommitmentKey):
+            assert n <= bases.n
+            _check(L.lib().nmx_msm_u64_handle(bases.handle, 0, sp, n, bits, flags, *out.p))
+        else:
+            b = _host_u8(bases, 64)
+            assert b.size // 64 == n, "assert_eq!(bases.len(), scalars.len())  (msm.rs:486)"
+            _check(L.lib().nmx_msm_u64(self.curve, sp, b.ctypes.data, n, bits, flags, *out.p))
+        return out.get()
+
+    def point_sum(self, partials):
+        """Sum 128-byte partials (sharded MSM combine)."""
+        buf = np.frombuffer(b"".join(partials), dtype=np.uint8) if not isinstance(partials, np.ndarray) else partials
+        buf = np.ascontiguousarray(buf, dtype=np.uint8).reshape(-1)
+        out = _Out()
+        _check(L.lib().nmx_point_sum(self.curve, buf.ctypes.data, buf.size // 128, *out.p))
+        return out.get()
+
+
+class CommitmentEngine:
+    """`CommitmentEngineTrait` restricted to the hot path (src/traits/commitment.rs:52-195)."""
+
+    def __init__(self, curve):
+        self.group = DlogGroup(curve)
+
+    def setup_synthetic(self, n, k0=1):
+        return CommitmentKey.generate(self.group.curve, n, k0)
+
+    def commit(self, ck, v, r=None, mont=False, partial=False):
+        """msm(v, ck[..len v]) + h*r  (pedersen.rs:263-270, hyperkzg.rs:584-591)."""
+        sp, n, dev, _k = _scalar_arg(v, 32)
+        assert len(ck) >= n, "assert!(ck.ck.len() >= v.len())"
+        rr = _host_u8(bytes(32) if r is None else r, 32)
+        hh = _host_u8(ck.h, 64)
+        flags = dev | (L.SCALARS_MONT if mont else 0) | (L.BASES_MONT if ck.mont else 0) | (L.OUT_PARTIAL if partial else 0)
+        out = _Out(partial=partial)
+        _check(L.lib().nmx_commit(ck.handle, sp, n, hh.ctypes.data, rr.ctypes.data, flags, *out.p))
+        return out.get()
+
+    def batch_commit(self, ck, vs, rs=None, mont=False):
+        """hyperkzg.rs:593-612: batch MSM over ck[..max len], then + h*r_i each."""
+        rs = [None] * len(vs) if rs is None else rs
+        assert len(vs) == len(rs)
+        if all(r is None or bytes(r) == bytes(32) for r in rs):
+            return self.group.batch_vartime_multiscalar_mul(vs, ck, mont)
+        return [self.commit(ck, v, r, mont) for v, r in zip(vs, rs)]
+
+    def commit_small(self, ck, v_u64, r=None, mont=False):
+        """msm_small(v, ck[..len v]) + h*r  (pedersen.rs:272-283)."""
+        small = self.group.vartime_multiscalar_mul_small(v_u64, ck, partial=True)
+        blind = self.commit(ck, np.zeros((0, 32), np.uint8), r, mont, partial=True)
+        return self.group.point_sum([small.xy, blind.xy])

@@ -1,0 +1,169 @@
+"""ctypes loader for oracle/libnova_ref.so (tier-2 oracle, oracle/nova_ref.c).
+
+TEST INFRASTRUCTURE ONLY -- see the header of nova_ref.c.  Builds the library on first use if missing.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libnova_ref.so")
+_lib = None
+
+
+def build(force=False):
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "nova_ref.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libnova_ref.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_SO)
+        vp, sz, u8p, u64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_uint64
+        L.ref_set_threads.argtypes = [ctypes.c_int]
+        L.ref_get_threads.restype = ctypes.c_int
+        L.ref_bases_load.restype = vp
+        L.ref_bases_load.argtypes = [ctypes.c_int, vp, sz]
+        L.ref_bases_free.argtypes = [vp]
+        L.ref_msm_prepared.argtypes = [ctypes.c_int, vp, vp, sz, vp, vp]
+        L.ref_msm_best_prepared.argtypes = [ctypes.c_int, vp, vp, sz, vp, vp]
+        L.ref_msm.argtypes = [ctypes.c_int, vp, vp, sz, vp, vp]
+        L.ref_msm_u64_prepared.argtypes = [ctypes.c_int, vp, vp, sz, sz, vp, vp]
+        L.ref_msm_u64.argtypes = [ctypes.c_int, vp, vp, sz, sz, vp, vp]
+        L.ref_msm_batch.argtypes = [ctypes.c_int, vp, vp, sz, vp, sz, vp, vp]
+        L.ref_commit.argtypes = [ctypes.c_int, vp, vp, sz, vp, vp, vp, vp]
+        L.ref_batch_add.argtypes = [ctypes.c_int, vp, sz, vp, sz, vp, vp]
+        L.ref_sequential_bases.argtypes = [ctypes.c_int, vp, u64, sz, vp]
+        L.ref_field_axpy.argtypes = [ctypes.c_int, vp, vp, vp, sz, vp]
+        _lib = L
+    return _lib
+
+
+def _buf(a):
+    """numpy uint8/uint64 array or bytes -> (pointer, keepalive)"""
+    if isinstance(a, (bytes, bytearray)):
+        a = np.frombuffer(bytes(a), dtype=np.uint8)
+    a = np.ascontiguousarray(a)
+    return a.ctypes.data, a
+
+
+def _out():
+    out = np.zeros(64, dtype=np.uint8)
+    inf = np.zeros(1, dtype=np.uint8)
+    return out, inf
+
+
+def set_threads(t):
+    lib().ref_set_threads(int(t))
+
+
+def get_threads():
+    return lib().ref_get_threads()
+
+
+def msm(cid, scalars, bases, n):
+    """scalars: n x 32 canonical LE bytes; bases: n x 64 canonical x||y.  Returns (64 bytes, is_inf)."""
+    sp, _s = _buf(scalars)
+    bp, _b = _buf(bases)
+    out, inf = _out()
+    rc = lib().ref_msm(cid, sp, bp, n, out.ctypes.data, inf.ctypes.data)
+    if rc:
+        raise ValueError(f"ref_msm rc={rc}")
+    return out.tobytes(), int(inf[0])
+
+
+def msm_u64(cid, scalars_u64, bases, n, max_num_bits=None):
+    s = np.ascontiguousarray(scalars_u64, dtype=np.uint64)
+    bp, _b = _buf(bases)
+    out, inf = _out()
+    mb = (1 << 64) - 1 if max_num_bits is None else int(max_num_bits)
+    rc = lib().ref_msm_u64(cid, s.ctypes.data, bp, n, mb, out.ctypes.data, inf.ctypes.data)
+    if rc:
+        raise ValueError(f"ref_msm_u64 rc={rc}")
+    return out.tobytes(), int(inf[0])
+
+
+class Prepared:
+    """A host key converted once (what a `Vec<Affine>` already is on the reference side)."""
+
+    def __init__(self, cid, bases, n):
+        bp, _b = _buf(bases)
+        self.cid, self.n = cid, n
+        self.h = lib().ref_bases_load(cid, bp, n)
+
+    def msm(self, scalars, n, best_only=False):
+        sp, _s = _buf(scalars)
+        out, inf = _out()
+        fn = lib().ref_msm_best_prepared if best_only else lib().ref_msm_prepared
+        rc = fn(self.cid, sp, self.h, n, out.ctypes.data, inf.ctypes.data)
+        if rc:
+            raise ValueError(f"ref_msm_prepared rc={rc}")
+        return out.tobytes(), int(inf[0])
+
+    def msm_u64(self, scalars_u64, n, max_num_bits=None):
+        s = np.ascontiguousarray(scalars_u64, dtype=np.uint64)
+        out, inf = _out()
+        mb = (1 << 64) - 1 if max_num_bits is None else int(max_num_bits)
+        rc = lib().ref_msm_u64_prepared(self.cid, s.ctypes.data, self.h, n, mb, out.ctypes.data, inf.ctypes.data)
+        if rc:
+            raise ValueError(f"ref_msm_u64_prepared rc={rc}")
+        return out.tobytes(), int(inf[0])
+
+    def close(self):
+        if self.h:
+            lib().ref_bases_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+def msm_batch(cid, vecs, bases, n_bases):
+    k = len(vecs)
+    keep = [np.ascontiguousarray(np.frombuffer(bytes(v), dtype=np.uint8)) if len(v) else np.zeros(1, np.uint8) for v in vecs]
+    ptrs = (ctypes.c_void_p * k)(*[a.ctypes.data for a in keep])
+    lens = (ctypes.c_size_t * k)(*[len(v) // 32 for v in vecs])
+    bp, _b = _buf(bases)
+    out = np.zeros(64 * max(k, 1), dtype=np.uint8)
+    inf = np.zeros(max(k, 1), dtype=np.uint8)
+    rc = lib().ref_msm_batch(cid, ptrs, lens, k, bp, n_bases, out.ctypes.data, inf.ctypes.data)
+    if rc:
+        raise ValueError(f"ref_msm_batch rc={rc}")
+    return [(out[64 * j: 64 * j + 64].tobytes(), int(inf[j])) for j in range(k)]
+
+
+def commit(cid, v, ck, n, h, r):
+    vp_, _v = _buf(v)
+    cp, _c = _buf(ck)
+    hp, _h = _buf(h)
+    rp, _r = _buf(r)
+    out, inf = _out()
+    rc = lib().ref_commit(cid, vp_, cp, n, hp, rp, out.ctypes.data, inf.ctypes.data)
+    if rc:
+        raise ValueError(f"ref_commit rc={rc}")
+    return out.tobytes(), int(inf[0])
+
+
+def sequential_bases(curve, k0, n):
+    """P_i = (k0+i)*G as an (n, 64) uint8 array; `curve` is an oracle.pyref.Curve."""
+    from . import pyref
+    g = np.frombuffer(pyref.point_to_xy64((curve.gx, curve.gy)), dtype=np.uint8)
+    out = np.zeros((n, 64), dtype=np.uint8)
+    rc = lib().ref_sequential_bases(curve.cid, g.ctypes.data, k0, n, out.ctypes.data)
+    if rc:
+        raise ValueError(f"ref_sequential_bases rc={rc}")
+    return out
+
+
+def field_axpy(fid, a, b, r, n):
+    ap, _a = _buf(a)
+    bp, _b = _buf(b)
+    rp, _r = _buf(r)
+    out = np.zeros(32 * n, dtype=np.uint8)
+    lib().ref_field_axpy(fid, ap, bp, rp, n, out.ctypes.data)
+    return out.tobytes()

@@ -1,0 +1,702 @@
+/* oracle/nova_ref.c -- tier-2 oracle: CPU restatement of the reference's MSM provider, in plain C.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may load
+ * libnova_ref.so; nothing under nova_amd/ links or calls it.  It doubles as the timed CPU baseline
+ * (`cpu_baseline.kind = "port"`): the Rust reference (halo2curves asm + rayon) cannot be built in this
+ * environment (no cargo/rustc, crates not vendored -- SURVEY.md section 0).
+ *
+ * What is restated (paths relative to /root/reference):
+ *   src/provider/msm.rs:38-183    BucketXYZZ: zero / double_in_place (dbl-2008-s-1) / add_assign_bucket
+ *                                 (add-2008-s) / bucket_add_affine (madd-2008-s) incl. exceptional cases
+ *   src/provider/msm.rs:189-211   scalar_num_bits, repr_low_u64
+ *   src/provider/msm.rs:225-419   msm(): n == 0, n <= 16 -> msm_simple, zero/identity filtering, signed
+ *                                 classification into 11 bit-width groups, per-group algorithms, pos - neg
+ *   src/provider/msm.rs:432-454   accumulate_bases (chunked sum)
+ *   src/provider/msm.rs:478-503   msm_small_with_max_num_bits dispatch (0 / 1 / 2..=10 / 11..=32 / else)
+ *   src/provider/msm.rs:505-530   msm_binary        :533-575 msm_10        :577-677 msm_small_rest
+ *   src/provider/msm.rs:679-686   compute_ln        :689-708 batch_add
+ *   src/provider/traits.rs:82-90  batch_vartime_multiscalar_mul (bases[..len_j] per vector)
+ *   src/provider/pedersen.rs:263-270 / hyperkzg.rs:584-591  commit = msm + h*r
+ *   src/provider/traits.rs:303-312 to_coordinates(): identity -> (0, 0, true)
+ * Third-party piece: `halo2curves::msm::msm_best` (crate halo2curves = "0.9.0", Cargo.toml:36-41; called at
+ * msm.rs:411,500) is not in the tree.  Its published algorithm is a windowed Pippenger over rayon chunks
+ * (window c = 1 if n < 4, 3 if n < 32, else ceil(ln n); signed "Booth" digits; per-window buckets summed by a
+ * running sum; windows combined by c doublings); `best_msm()` below restates that.  Any correct MSM returns the
+ * same group element, so the internal strategy affects the baseline's speed only.
+ *
+ * Parity pinning: the reference stores no MSM output vectors (its tests assert msm == naive sum at run time:
+ * msm.rs:722-821, curve_property_tests.rs:180-218, blitzar.rs:48-214).  This file is pinned against
+ * oracle/pyref.py (big-int definition) on that same test matrix in tests/test_oracle.py.
+ *
+ * Threading: OpenMP, one chunk per thread + final sum -- the decomposition the reference uses with rayon
+ * (`par_chunks(len / num_threads)` + `reduce(identity, +)`, msm.rs:520-526,564-571,664-673).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef unsigned __int128 u128;
+typedef struct { uint64_t l[4]; } fe;
+
+typedef struct {
+  fe p;          /* modulus */
+  uint64_t ninv; /* -p^-1 mod 2^64 */
+  fe r1;         /* R mod p (Montgomery one) */
+  fe r2;         /* R^2 mod p */
+} field_t;
+
+typedef struct {
+  const field_t* base;   /* coordinate field */
+  const field_t* scalar; /* scalar field */
+} curve_t;
+
+/* moduli: bn256_grumpkin.rs:39-40, pasta.rs:37-38; Montgomery constants computed from them (tests re-derive) */
+static const field_t F_BN_Q = {
+    {{0x3c208c16d87cfd47ull, 0x97816a916871ca8dull, 0xb85045b68181585dull, 0x30644e72e131a029ull}},
+    0x87d20782e4866389ull,
+    {{0xd35d438dc58f0d9dull, 0x0a78eb28f5c70b3dull, 0x666ea36f7879462cull, 0x0e0a77c19a07df2full}},
+    {{0xf32cfc5b538afa89ull, 0xb5e71911d44501fbull, 0x47ab1eff0a417ff6ull, 0x06d89f71cab8351full}}};
+static const field_t F_BN_R = {
+    {{0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull}},
+    0xc2e1f593efffffffull,
+    {{0xac96341c4ffffffbull, 0x36fc76959f60cd29ull, 0x666ea36f7879462eull, 0x0e0a77c19a07df2full}},
+    {{0x1bb8e645ae216da7ull, 0x53fe3ab1e35c59e3ull, 0x8c49833d53bb8085ull, 0x0216d0b17f4e44a5ull}}};
+static const field_t F_PA_P = {
+    {{0x992d30ed00000001ull, 0x224698fc094cf91bull, 0x0000000000000000ull, 0x4000000000000000ull}},
+    0x992d30ecffffffffull,
+    {{0x34786d38fffffffdull, 0x992c350be41914adull, 0xffffffffffffffffull, 0x3fffffffffffffffull}},
+    {{0x8c78ecb30000000full, 0xd7d30dbd8b0de0e7ull, 0x7797a99bc3c95d18ull, 0x096d41af7b9cb714ull}}};
+static const field_t F_PA_Q = {
+    {{0x8c46eb2100000001ull, 0x224698fc0994a8ddull, 0x0000000000000000ull, 0x4000000000000000ull}},
+    0x8c46eb20ffffffffull,
+    {{0x5b2b3e9cfffffffdull, 0x992c350be3420567ull, 0xffffffffffffffffull, 0x3fffffffffffffffull}},
+    {{0xfc9678ff0000000full, 0x67bb433d891a16e3ull, 0x7fae231004ccf590ull, 0x096d41af7ccfdaa9ull}}};
+
+/* curve ids as include/nova_mi355x.h: 0 bn254 g1, 1 grumpkin, 2 pallas, 3 vesta */
+static const curve_t CURVES[4] = {{&F_BN_Q, &F_BN_R}, {&F_BN_R, &F_BN_Q}, {&F_PA_P, &F_PA_Q}, {&F_PA_Q, &F_PA_P}};
+
+/* ------------------------------------------------------------------ field ------------------------------ */
+static inline int fe_is_zero(const fe* a) { return (a->l[0] | a->l[1] | a->l[2] | a->l[3]) == 0; }
+static inline int fe_eq(const fe* a, const fe* b) {
+  return ((a->l[0] ^ b->l[0]) | (a->l[1] ^ b->l[1]) | (a->l[2] ^ b->l[2]) | (a->l[3] ^ b->l[3])) == 0;
+}
+static inline int fe_geq(const fe* a, const fe* b) {
+  for (int i = 3; i >= 0; i--) {
+    if (a->l[i] > b->l[i]) return 1;
+    if (a->l[i] < b->l[i]) return 0;
+  }
+  return 1;
+}
+static inline void fe_sub_raw(fe* r, const fe* a, const fe* b, uint64_t* borrow) {
+  u128 bw = 0;
+  for (int i = 0; i < 4; i++) {
+    u128 d = (u128)a->l[i] - b->l[i] - bw;
+    r->l[i] = (uint64_t)d;
+    bw = (d >> 64) & 1;
+  }
+  *borrow = (uint64_t)bw;
+}
+static inline void fe_add(const field_t* F, fe* r, const fe* a, const fe* b) {
+  u128 c = 0;
+  fe t;
+  for (int i = 0; i < 4; i++) {
+    c += (u128)a->l[i] + b->l[i];
+    t.l[i] = (uint64_t)c;
+    c >>= 64;
+  }
+  uint64_t bw;
+  fe u;
+  fe_sub_raw(&u, &t, &F->p, &bw);
+  *r = bw ? t : u; /* p < 2^255: no carry out of the top limb */
+}
+static inline void fe_sub(const field_t* F, fe* r, const fe* a, const fe* b) {
+  uint64_t bw;
+  fe t;
+  fe_sub_raw(&t, a, b, &bw);
+  if (bw) {
+    u128 c = 0;
+    for (int i = 0; i < 4; i++) {
+      c += (u128)t.l[i] + F->p.l[i];
+      t.l[i] = (uint64_t)c;
+      c >>= 64;
+    }
+  }
+  *r = t;
+}
+static inline void fe_neg(const field_t* F, fe* r, const fe* a) {
+  if (fe_is_zero(a)) { *r = *a; return; }
+  uint64_t bw;
+  fe_sub_raw(r, &F->p, a, &bw);
+}
+static inline void fe_dbl(const field_t* F, fe* r, const fe* a) { fe_add(F, r, a, a); }
+/* Montgomery product, CIOS with 64-bit limbs */
+static inline void fe_mul(const field_t* F, fe* r, const fe* a, const fe* b) {
+  uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; i++) {
+    u128 c = 0;
+    for (int j = 0; j < 4; j++) {
+      c += (u128)a->l[j] * b->l[i] + t[j];
+      t[j] = (uint64_t)c;
+      c >>= 64;
+    }
+    c += t[4];
+    t[4] = (uint64_t)c;
+    t[5] = (uint64_t)(c >> 64);
+    uint64_t m = t[0] * F->ninv;
+    c = (u128)m * F->p.l[0] + t[0];
+    c >>= 64;
+    for (int j = 1; j < 4; j++) {
+      c += (u128)m * F->p.l[j] + t[j];
+      t[j - 1] = (uint64_t)c;
+      c >>= 64;
+    }
+    c += t[4];
+    t[3] = (uint64_t)c;
+    t[4] = t[5] + (uint64_t)(c >> 64);
+  }
+  fe x = {{t[0], t[1], t[2], t[3]}};
+  uint64_t bw;
+  fe u;
+  fe_sub_raw(&u, &x, &F->p, &bw);
+  *r = (t[4] || !bw) ? u : x;
+}
+static inline void fe_sqr(const field_t* F, fe* r, const fe* a) { fe_mul(F, r, a, a); }
+static void fe_inv(const field_t* F, fe* r, const fe* a) { /* a^(p-2) */
+  fe e = F->p;
+  u128 bw = 2;
+  for (int i = 0; i < 4; i++) {
+    u128 d = (u128)e.l[i] - bw;
+    e.l[i] = (uint64_t)d;
+    bw = (d >> 64) & 1;
+  }
+  fe acc = F->r1;
+  for (int i = 255; i >= 0; i--) {
+    fe_sqr(F, &acc, &acc);
+    if ((e.l[i >> 6] >> (i & 63)) & 1) fe_mul(F, &acc, &acc, a);
+  }
+  *r = acc;
+}
+static inline void fe_to_mont(const field_t* F, fe* r, const fe* a) { fe_mul(F, r, a, &F->r2); }
+static inline void fe_from_mont(const field_t* F, fe* r, const fe* a) {
+  fe one = {{1, 0, 0, 0}};
+  fe_mul(F, r, a, &one);
+}
+
+/* ------------------------------------------------------------------ XYZZ (msm.rs:38-183) ---------------- */
+typedef struct { fe x, y; } aff;            /* identity = (0,0) */
+typedef struct { fe x, y, zz, zzz; } xyzz;  /* identity <=> zz == 0 (msm.rs:59-61) */
+
+static inline int aff_is_identity(const aff* p) { return fe_is_zero(&p->x) && fe_is_zero(&p->y); }
+static inline void xyzz_zero(const field_t* F, xyzz* b) { /* msm.rs:48-55 */
+  b->x = F->r1; b->y = F->r1;
+  memset(&b->zz, 0, sizeof(fe)); memset(&b->zzz, 0, sizeof(fe));
+}
+static inline int xyzz_is_zero(const xyzz* b) { return fe_is_zero(&b->zz); }
+
+static void xyzz_double(const field_t* F, xyzz* b) { /* msm.rs:65-88 */
+  if (xyzz_is_zero(b)) return;
+  fe u, v, w, s, xx, m, t, x3, y3;
+  fe_dbl(F, &u, &b->y);
+  fe_sqr(F, &v, &u);
+  fe_mul(F, &w, &u, &v);
+  fe_mul(F, &s, &b->x, &v);
+  fe_sqr(F, &xx, &b->x);
+  fe_dbl(F, &m, &xx); fe_add(F, &m, &m, &xx);
+  fe_sqr(F, &x3, &m); fe_dbl(F, &t, &s); fe_sub(F, &x3, &x3, &t);
+  fe_sub(F, &t, &s, &x3); fe_mul(F, &y3, &m, &t);
+  fe_mul(F, &t, &w, &b->y); fe_sub(F, &y3, &y3, &t);
+  b->x = x3; b->y = y3;
+  fe_mul(F, &b->zz, &b->zz, &v);
+  fe_mul(F, &b->zzz, &b->zzz, &w);
+}
+static void xyzz_add(const field_t* F, xyzz* a, const xyzz* o) { /* msm.rs:91-123 */
+  if (xyzz_is_zero(o)) return;
+  if (xyzz_is_zero(a)) { *a = *o; return; }
+  fe u1, u2, s1, s2;
+  fe_mul(F, &u1, &a->x, &o->zz);
+  fe_mul(F, &u2, &o->x, &a->zz);
+  fe_mul(F, &s1, &a->y, &o->zzz);
+  fe_mul(F, &s2, &o->y, &a->zzz);
+  if (fe_eq(&u1, &u2)) {
+    if (fe_eq(&s1, &s2)) xyzz_double(F, a); else xyzz_zero(F, a);
+    return;
+  }
+  fe p, r, pp, ppp, q, t, x3;
+  fe_sub(F, &p, &u2, &u1);
+  fe_sub(F, &r, &s2, &s1);
+  fe_sqr(F, &pp, &p);
+  fe_mul(F, &ppp, &p, &pp);
+  fe_mul(F, &q, &u1, &pp);
+  fe_sqr(F, &x3, &r); fe_sub(F, &x3, &x3, &ppp); fe_dbl(F, &t, &q); fe_sub(F, &x3, &x3, &t);
+  fe_sub(F, &t, &q, &x3); fe_mul(F, &t, &r, &t);
+  fe_mul(F, &s1, &s1, &ppp); fe_sub(F, &a->y, &t, &s1);
+  a->x = x3;
+  fe_mul(F, &a->zz, &a->zz, &o->zz); fe_mul(F, &a->zz, &a->zz, &pp);
+  fe_mul(F, &a->zzz, &a->zzz, &o->zzz); fe_mul(F, &a->zzz, &a->zzz, &ppp);
+}
+static void xyzz_add_affine(const field_t* F, xyzz* b, const aff* p) { /* msm.rs:129-165 */
+  if (aff_is_identity(p)) return;
+  if (xyzz_is_zero(b)) { b->x = p->x; b->y = p->y; b->zz = F->r1; b->zzz = F->r1; return; }
+  fe u2, s2;
+  fe_mul(F, &u2, &p->x, &b->zz);
+  fe_mul(F, &s2, &p->y, &b->zzz);
+  if (fe_eq(&b->x, &u2)) {
+    if (fe_eq(&b->y, &s2)) xyzz_double(F, b); else xyzz_zero(F, b);
+    return;
+  }
+  fe pv, r, pp, ppp, q, t, x3;
+  fe_sub(F, &pv, &u2, &b->x);
+  fe_sub(F, &r, &s2, &b->y);
+  fe_sqr(F, &pp, &pv);
+  fe_mul(F, &ppp, &pv, &pp);
+  fe_mul(F, &q, &b->x, &pp);
+  fe_sqr(F, &x3, &r); fe_sub(F, &x3, &x3, &ppp); fe_dbl(F, &t, &q); fe_sub(F, &x3, &x3, &t);
+  fe_sub(F, &t, &q, &x3); fe_mul(F, &t, &r, &t);
+  fe_mul(F, &q, &b->y, &ppp); fe_sub(F, &b->y, &t, &q);
+  b->x = x3;
+  fe_mul(F, &b->zz, &b->zz, &pp);
+  fe_mul(F, &b->zzz, &b->zzz, &ppp);
+}
+static void xyzz_neg(const field_t* F, xyzz* a) { fe_neg(F, &a->y, &a->y); }
+static void xyzz_sub(const field_t* F, xyzz* a, const xyzz* o) {
+  xyzz t = *o; xyzz_neg(F, &t); xyzz_add(F, a, &t);
+}
+static void xyzz_to_affine(const field_t* F, aff* r, const xyzz* b) { /* msm.rs:172-183 + traits.rs:303-312 */
+  if (xyzz_is_zero(b)) { memset(r, 0, sizeof(*r)); return; }
+  fe zi, zzi;
+  fe_inv(F, &zi, &b->zz);
+  fe_inv(F, &zzi, &b->zzz);
+  fe_mul(F, &r->x, &b->x, &zi);
+  fe_mul(F, &r->y, &b->y, &zzi);
+}
+/* k * P, k a canonical 256-bit integer (msm_simple's `*base * coeff`, msm.rs:422-429) */
+static void xyzz_scalar_mul(const field_t* F, xyzz* r, const aff* p, const fe* k) {
+  xyzz acc; xyzz_zero(F, &acc);
+  for (int i = 255; i >= 0; i--) {
+    xyzz_double(F, &acc);
+    if ((k->l[i >> 6] >> (i & 63)) & 1) xyzz_add_affine(F, &acc, p);
+  }
+  *r = acc;
+}
+
+/* ------------------------------------------------------------------ helpers ----------------------------- */
+static int g_threads = 0;
+static int nthreads(void) {
+  if (g_threads > 0) return g_threads;
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+static uint32_t scalar_num_bits(const fe* s) { /* msm.rs:191-200 (canonical integer) */
+  for (int i = 3; i >= 0; i--)
+    if (s->l[i]) return (uint32_t)(i * 64 + 64 - __builtin_clzll(s->l[i]));
+  return 0;
+}
+static size_t num_bits_usize(uint64_t n) { return n == 0 ? 0 : (size_t)(64 - __builtin_clzll(n)); } /* msm.rs:456-462 */
+static size_t compute_ln(size_t a) { return a == 0 ? 0 : (size_t)(63 - __builtin_clzll((uint64_t)a)) * 69 / 100; } /* msm.rs:679-686 */
+
+/* sum of chunk results: rayon `.reduce(identity, +)` */
+typedef void (*chunk_fn)(const curve_t* C, const void* scalars, const aff* bases, size_t lo, size_t hi, void* ctx,
+                         xyzz* out);
+static void par_chunks(const curve_t* C, const void* scalars, const aff* bases, size_t n, size_t chunk, chunk_fn fn,
+                       void* ctx, xyzz* out) {
+  const field_t* F = C->base;
+  size_t nchunks = (n + chunk - 1) / chunk;
+  xyzz* parts = (xyzz*)malloc(sizeof(xyzz) * (nchunks ? nchunks : 1));
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads())
+  for (long ci = 0; ci < (long)nchunks; ci++) {
+    size_t lo = (size_t)ci * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    fn(C, scalars, bases, lo, hi, ctx, &parts[ci]);
+  }
+  xyzz_zero(F, out);
+  for (size_t i = 0; i < nchunks; i++) xyzz_add(F, out, &parts[i]);
+  free(parts);
+}
+
+/* ------------------------------------------------------------------ small-scalar MSMs ------------------- */
+/* msm_binary (msm.rs:505-530): every non-zero scalar counts as 1 */
+static void binary_chunk(const curve_t* C, const void* sv, const aff* bases, size_t lo, size_t hi, void* ctx, xyzz* out) {
+  (void)ctx;
+  const uint64_t* s = (const uint64_t*)sv;
+  xyzz_zero(C->base, out);
+  for (size_t i = lo; i < hi; i++)
+    if (s[i] != 0) xyzz_add_affine(C->base, out, &bases[i]);
+}
+static void msm_binary(const curve_t* C, const uint64_t* s, const aff* bases, size_t n, xyzz* out) {
+  size_t nt = (size_t)nthreads();
+  if (n > nt) par_chunks(C, s, bases, n, n / nt, binary_chunk, NULL, out);
+  else binary_chunk(C, s, bases, 0, n, NULL, out);
+}
+/* msm_10 (msm.rs:533-575) */
+static void msm10_chunk(const curve_t* C, const void* sv, const aff* bases, size_t lo, size_t hi, void* ctx, xyzz* out) {
+  const field_t* F = C->base;
+  const uint64_t* s = (const uint64_t*)sv;
+  size_t max_num_bits = *(size_t*)ctx;
+  size_t nb = (size_t)1 << max_num_bits;
+  xyzz* buckets = (xyzz*)malloc(sizeof(xyzz) * nb);
+  for (size_t k = 0; k < nb; k++) xyzz_zero(F, &buckets[k]);
+  for (size_t i = lo; i < hi; i++)
+    if (s[i] != 0) xyzz_add_affine(F, &buckets[s[i]], &bases[i]); /* in-contract: s[i] < 2^max_num_bits */
+  xyzz result, running;
+  xyzz_zero(F, &result); xyzz_zero(F, &running);
+  for (size_t k = nb - 1; k >= 1; k--) { /* buckets.skip(1).rev() */
+    xyzz_add(F, &running, &buckets[k]);
+    xyzz_add(F, &result, &running);
+  }
+  free(buckets);
+  *out = result;
+}
+static void msm_10(const curve_t* C, const uint64_t* s, const aff* bases, size_t n, size_t max_num_bits, xyzz* out) {
+  size_t nt = (size_t)nthreads();
+  if (n > nt) par_chunks(C, s, bases, n, n / nt, msm10_chunk, &max_num_bits, out);
+  else msm10_chunk(C, s, bases, 0, n, &max_num_bits, out);
+}
+/* msm_small_rest (msm.rs:577-677) */
+static void rest_chunk(const curve_t* C, const void* sv, const aff* bases, size_t lo, size_t hi, void* ctx, xyzz* out) {
+  const field_t* F = C->base;
+  const uint64_t* s = (const uint64_t*)sv;
+  size_t max_num_bits = *(size_t*)ctx;
+  size_t len = hi - lo;
+  size_t c = len < 32 ? 3 : compute_ln(len) + 2;               /* msm.rs:587-591 */
+  if (max_num_bits == 32 || max_num_bits == 64) c = 8;         /* msm.rs:593-595 */
+  size_t nwin = (max_num_bits + c - 1) / c;                    /* (0..max_num_bits).step_by(c) */
+  size_t nb = ((size_t)1 << c) - 1;
+  xyzz* wsum = (xyzz*)malloc(sizeof(xyzz) * (nwin ? nwin : 1));
+  xyzz* buckets = (xyzz*)malloc(sizeof(xyzz) * nb);
+  for (size_t w = 0; w < nwin; w++) {
+    size_t w_start = w * c;
+    xyzz res; xyzz_zero(F, &res);
+    for (size_t k = 0; k < nb; k++) xyzz_zero(F, &buckets[k]);
+    for (size_t i = lo; i < hi; i++) {
+      uint64_t sc = s[i];
+      if (sc == 0) continue;
+      if (sc == 1) {                                           /* msm.rs:613-617 */
+        if (w_start == 0) xyzz_add_affine(F, &res, &bases[i]);
+      } else {
+        sc >>= w_start;
+        sc %= ((uint64_t)1 << c);
+        if (sc != 0) xyzz_add_affine(F, &buckets[sc - 1], &bases[i]);
+      }
+    }
+    xyzz running; xyzz_zero(F, &running);
+    for (size_t k = nb; k-- > 0;) {                            /* msm.rs:638-642 */
+      xyzz_add(F, &running, &buckets[k]);
+      xyzz_add(F, &res, &running);
+    }
+    wsum[w] = res;
+  }
+  /* lowest + fold(rev(window_sums[1..])) with c doublings (msm.rs:648-661) */
+  xyzz total; xyzz_zero(F, &total);
+  for (size_t w = nwin; w-- > 1;) {
+    xyzz_add(F, &total, &wsum[w]);
+    for (size_t q = 0; q < c; q++) xyzz_double(F, &total);
+  }
+  xyzz_add(F, &total, &wsum[0]);
+  free(buckets); free(wsum);
+  *out = total;
+}
+static void msm_small_rest(const curve_t* C, const uint64_t* s, const aff* bases, size_t n, size_t max_num_bits, xyzz* out) {
+  size_t nt = (size_t)nthreads();
+  if (n > nt) par_chunks(C, s, bases, n, n / nt, rest_chunk, &max_num_bits, out);
+  else rest_chunk(C, s, bases, 0, n, &max_num_bits, out);
+}
+
+/* ------------------------------------------------------------------ msm_best role ----------------------- */
+/* Windowed Pippenger with signed (Booth) digits over canonical 256-bit scalars; one serial instance per chunk. */
+static void best_chunk(const curve_t* C, const void* sv, const aff* bases, size_t lo, size_t hi, void* ctx, xyzz* out) {
+  (void)ctx;
+  const field_t* F = C->base;
+  const fe* s = (const fe*)sv;
+  size_t len = hi - lo;
+  size_t c;
+  if (len < 4) c = 1;
+  else if (len < 32) c = 3;
+  else c = (size_t)ceil(log((double)len));
+  size_t nwin = (256 + c - 1) / c + 1; /* +1: Booth carry */
+  size_t nb = (size_t)1 << (c - 1);
+  xyzz* buckets = (xyzz*)malloc(sizeof(xyzz) * nb);
+  xyzz acc; xyzz_zero(F, &acc);
+  for (size_t w = nwin; w-- > 0;) {
+    for (size_t q = 0; q < c; q++) xyzz_double(F, &acc);
+    for (size_t k = 0; k < nb; k++) xyzz_zero(F, &buckets[k]);
+    for (size_t i = lo; i < hi; i++) {
+      /* Booth digit of window w: bits [w*c - 1, w*c + c) of the scalar, d = ((v + 1) >> 1) - sign * 2^c */
+      size_t bit = w * c;
+      uint64_t v = 0;
+      for (size_t b = 0; b <= c; b++) {
+        long pos = (long)bit - 1 + (long)b;
+        uint64_t bv = (pos < 0 || pos >= 256) ? 0 : ((s[i].l[pos >> 6] >> (pos & 63)) & 1);
+        v |= bv << b;
+      }
+      int sign = (int)((v >> c) & 1);
+      long d = (long)((v + 1) >> 1);
+      if (sign) d -= (long)1 << c;
+      if (d == 0) continue;
+      aff p = bases[i];
+      if (aff_is_identity(&p)) continue;
+      if (d < 0) { fe_neg(F, &p.y, &p.y); d = -d; }
+      xyzz_add_affine(F, &buckets[d - 1], &p);
+    }
+    xyzz running, sum; xyzz_zero(F, &running); xyzz_zero(F, &sum);
+    for (size_t k = nb; k-- > 0;) {
+      xyzz_add(F, &running, &buckets[k]);
+      xyzz_add(F, &sum, &running);
+    }
+    xyzz_add(F, &acc, &sum);
+  }
+  free(buckets);
+  *out = acc;
+}
+static void best_msm(const curve_t* C, const fe* s, const aff* bases, size_t n, xyzz* out) {
+  size_t nt = (size_t)nthreads();
+  if (n == 0) { xyzz_zero(C->base, out); return; }
+  size_t chunk = (n + nt - 1) / nt;
+  par_chunks(C, s, bases, n, chunk, best_chunk, NULL, out);
+}
+
+/* msm_small_with_max_num_bits (msm.rs:478-503) */
+static void msm_small_bits(const curve_t* C, const uint64_t* s, const aff* bases, size_t n, size_t max_num_bits, xyzz* out) {
+  if (max_num_bits == 0) { xyzz_zero(C->base, out); return; }
+  if (max_num_bits == 1) { msm_binary(C, s, bases, n, out); return; }
+  if (max_num_bits <= 10) { msm_10(C, s, bases, n, max_num_bits, out); return; }
+  if (max_num_bits <= 32) { msm_small_rest(C, s, bases, n, max_num_bits, out); return; }
+  fe* fs = (fe*)calloc(n ? n : 1, sizeof(fe));                  /* Scalar::from(u64), kept canonical */
+  for (size_t i = 0; i < n; i++) fs[i].l[0] = s[i];
+  best_msm(C, fs, bases, n, out);
+  free(fs);
+}
+
+/* accumulate_bases (msm.rs:432-454) */
+static void accum_chunk(const curve_t* C, const void* sv, const aff* bases, size_t lo, size_t hi, void* ctx, xyzz* out) {
+  (void)sv; (void)ctx;
+  xyzz_zero(C->base, out);
+  for (size_t i = lo; i < hi; i++) xyzz_add_affine(C->base, out, &bases[i]);
+}
+static void accumulate_bases(const curve_t* C, const aff* bases, size_t n, xyzz* out) {
+  size_t nt = (size_t)nthreads();
+  if (n == 0) { xyzz_zero(C->base, out); return; }
+  if (n > nt) par_chunks(C, NULL, bases, n, (n + nt - 1) / nt, accum_chunk, NULL, out);
+  else accum_chunk(C, NULL, bases, 0, n, NULL, out);
+}
+
+/* ------------------------------------------------------------------ msm() (msm.rs:225-419) -------------- */
+static void msm_full(const curve_t* C, const fe* coeffs /* canonical */, const aff* bases /* Montgomery */, size_t n, xyzz* out) {
+  const field_t* F = C->base;
+  const field_t* S = C->scalar;
+  xyzz_zero(F, out);
+  if (n == 0) return;                                              /* :228 */
+  if (n <= 16) {                                                   /* :233 msm_simple */
+    for (size_t i = 0; i < n; i++) {
+      xyzz t; xyzz_scalar_mul(F, &t, &bases[i], &coeffs[i]);
+      xyzz_add(F, out, &t);
+    }
+    return;
+  }
+  /* Phase 1: classify (:243-279) */
+  uint8_t* group = (uint8_t*)malloc(n);
+  size_t counts[12]; memset(counts, 0, sizeof(counts));
+#pragma omp parallel for num_threads(nthreads())
+  for (long i = 0; i < (long)n; i++) {
+    const fe* s = &coeffs[i];
+    if (fe_is_zero(s) || aff_is_identity(&bases[i])) { group[i] = 255; continue; }
+    fe neg; uint64_t bw; fe_sub_raw(&neg, &S->p, s, &bw);          /* -s, canonical */
+    uint32_t bs = scalar_num_bits(s), bn = scalar_num_bits(&neg);
+    uint8_t g;
+    if (bs <= 1) g = 0; else if (bn <= 1) g = 1; else if (bs <= 8) g = 2; else if (bn <= 8) g = 3;
+    else if (bs <= 16) g = 4; else if (bn <= 16) g = 5; else if (bs <= 32) g = 6; else if (bn <= 32) g = 7;
+    else if (bs <= 64) g = 8; else if (bn <= 64) g = 9; else g = 10;
+    group[i] = g;
+  }
+  for (size_t i = 0; i < n; i++) if (group[i] != 255) counts[group[i]]++;
+  /* Phase 2: partition by group (:285-301; the sort key is the group only) */
+  size_t start[12]; start[0] = 0;
+  for (int g = 0; g < 11; g++) start[g + 1] = start[g] + counts[g];
+  size_t m = start[11];
+  if (m == 0) { free(group); return; }                              /* :281-283 */
+  aff* gb = (aff*)malloc(sizeof(aff) * m);
+  uint64_t* gs = (uint64_t*)malloc(sizeof(uint64_t) * m);
+  fe* gl = (fe*)malloc(sizeof(fe) * (counts[10] ? counts[10] : 1));
+  size_t pos[12]; memcpy(pos, start, sizeof(pos));
+  for (size_t i = 0; i < n; i++) {
+    uint8_t g = group[i];
+    if (g == 255) continue;
+    size_t o = pos[g]++;
+    gb[o] = bases[i];
+    if (g == 10) { gl[o - start[10]] = coeffs[i]; gs[o] = 0; }
+    else if (g & 1) { fe neg; uint64_t bw; fe_sub_raw(&neg, &S->p, &coeffs[i], &bw); gs[o] = neg.l[0]; } /* repr_low_u64(-s) */
+    else gs[o] = coeffs[i].l[0];
+  }
+  /* Phase 3 (:324-418) */
+  xyzz pos_r, neg_r, total; xyzz_zero(F, &total);
+  accumulate_bases(C, gb + start[0], counts[0], &pos_r);
+  accumulate_bases(C, gb + start[1], counts[1], &neg_r);
+  xyzz_sub(F, &pos_r, &neg_r); xyzz_add(F, &total, &pos_r);
+  static const size_t BITS[4] = {8, 16, 32, 64};
+  for (int k = 0; k < 4; k++) {
+    int gp = 2 + 2 * k, gn = gp + 1;
+    msm_small_bits(C, gs + start[gp], gb + start[gp], counts[gp], BITS[k], &pos_r);
+    msm_small_bits(C, gs + start[gn], gb + start[gn], counts[gn], BITS[k], &neg_r);
+    xyzz_sub(F, &pos_r, &neg_r); xyzz_add(F, &total, &pos_r);
+  }
+  if (counts[10]) { best_msm(C, gl, gb + start[10], counts[10], &pos_r); xyzz_add(F, &total, &pos_r); }
+  free(group); free(gb); free(gs); free(gl);
+  *out = total;
+}
+
+/* ------------------------------------------------------------------ marshalling + exported API ---------- */
+static void load_bases(const curve_t* C, const uint8_t* xy64, size_t n, aff* out) {
+#pragma omp parallel for num_threads(nthreads())
+  for (long i = 0; i < (long)n; i++) {
+    fe x, y;
+    memcpy(&x, xy64 + 64 * i, 32); memcpy(&y, xy64 + 64 * i + 32, 32);
+    fe_to_mont(C->base, &out[i].x, &x); fe_to_mont(C->base, &out[i].y, &y);
+  }
+}
+static void store_point(const curve_t* C, const xyzz* p, uint8_t* out, uint8_t* is_inf) {
+  aff a; xyzz_to_affine(C->base, &a, p);
+  if (xyzz_is_zero(p)) { memset(out, 0, 64); if (is_inf) *is_inf = 1; return; }
+  fe x, y; fe_from_mont(C->base, &x, &a.x); fe_from_mont(C->base, &y, &a.y);
+  memcpy(out, &x, 32); memcpy(out + 32, &y, 32);
+  if (is_inf) *is_inf = 0;
+}
+
+void ref_set_threads(int t) { g_threads = t; }
+int ref_get_threads(void) { return nthreads(); }
+
+/* Opaque prepared key: bases converted once to Montgomery form (a host `Vec<Affine>` already is) */
+void* ref_bases_load(int curve, const uint8_t* bases_xy64, size_t n) {
+  if (curve < 0 || curve > 3) return NULL;
+  aff* b = (aff*)malloc(sizeof(aff) * (n ? n : 1));
+  load_bases(&CURVES[curve], bases_xy64, n, b);
+  return b;
+}
+void ref_bases_free(void* h) { free(h); }
+
+/* msm() on a prepared key prefix; scalars canonical LE 32 bytes */
+int ref_msm_prepared(int curve, const uint8_t* scalars_le32, const void* prepared, size_t n, uint8_t* out, uint8_t* is_inf) {
+  if (curve < 0 || curve > 3) return -1;
+  const curve_t* C = &CURVES[curve];
+  for (size_t i = 0; i < n; i++) { /* from_repr would reject s >= r */
+    fe s; memcpy(&s, scalars_le32 + 32 * i, 32);
+    if (fe_geq(&s, &C->scalar->p)) return -4;
+  }
+  xyzz r; msm_full(C, (const fe*)scalars_le32, (const aff*)prepared, n, &r);
+  store_point(C, &r, out, is_inf);
+  return 0;
+}
+int ref_msm(int curve, const uint8_t* scalars_le32, const uint8_t* bases_xy64, size_t n, uint8_t* out, uint8_t* is_inf) {
+  void* b = ref_bases_load(curve, bases_xy64, n);
+  if (!b) return -1;
+  int rc = ref_msm_prepared(curve, scalars_le32, b, n, out, is_inf);
+  free(b);
+  return rc;
+}
+/* halo2curves::msm::msm_best role only (benches/commit.rs:115 times this directly) */
+int ref_msm_best_prepared(int curve, const uint8_t* scalars_le32, const void* prepared, size_t n, uint8_t* out, uint8_t* is_inf) {
+  if (curve < 0 || curve > 3) return -1;
+  const curve_t* C = &CURVES[curve];
+  xyzz r; best_msm(C, (const fe*)scalars_le32, (const aff*)prepared, n, &r);
+  store_point(C, &r, out, is_inf);
+  return 0;
+}
+/* msm_small_with_max_num_bits; max_num_bits == (size_t)-1 -> msm_small (msm.rs:469-475) */
+int ref_msm_u64_prepared(int curve, const uint64_t* s, const void* prepared, size_t n, size_t max_num_bits, uint8_t* out, uint8_t* is_inf) {
+  if (curve < 0 || curve > 3) return -1;
+  const curve_t* C = &CURVES[curve];
+  if (max_num_bits == (size_t)-1) {
+    uint64_t mx = 0; for (size_t i = 0; i < n; i++) if (s[i] > mx) mx = s[i];
+    max_num_bits = num_bits_usize(mx);
+  }
+  if (max_num_bits >= 2 && max_num_bits <= 10)
+    for (size_t i = 0; i < n; i++) if (s[i] >> max_num_bits) return -5; /* msm.rs:552 would index out of bounds */
+  xyzz r; msm_small_bits(C, s, (const aff*)prepared, n, max_num_bits, &r);
+  store_point(C, &r, out, is_inf);
+  return 0;
+}
+int ref_msm_u64(int curve, const uint64_t* s, const uint8_t* bases_xy64, size_t n, size_t max_num_bits, uint8_t* out, uint8_t* is_inf) {
+  void* b = ref_bases_load(curve, bases_xy64, n);
+  if (!b) return -1;
+  int rc = ref_msm_u64_prepared(curve, s, b, n, max_num_bits, out, is_inf);
+  free(b);
+  return rc;
+}
+/* batch_vartime_multiscalar_mul (traits.rs:82-90) */
+int ref_msm_batch(int curve, const uint8_t* const* vecs, const size_t* lens, size_t k, const uint8_t* bases_xy64, size_t n_bases,
+                  uint8_t* out, uint8_t* is_inf) {
+  void* b = ref_bases_load(curve, bases_xy64, n_bases);
+  if (!b) return -1;
+  int rc = 0;
+  for (size_t j = 0; j < k && rc == 0; j++) {
+    if (lens[j] > n_bases) { rc = -1; break; }
+    rc = ref_msm_prepared(curve, vecs[j], b, lens[j], out + 64 * j, is_inf ? is_inf + j : NULL);
+  }
+  free(b);
+  return rc;
+}
+/* commit = msm(v, ck[..n]) + h * r (pedersen.rs:263-270) */
+int ref_commit(int curve, const uint8_t* v_le32, const uint8_t* ck_xy64, size_t n, const uint8_t* h_xy64, const uint8_t* r_le32,
+               uint8_t* out, uint8_t* is_inf) {
+  if (curve < 0 || curve > 3) return -1;
+  const curve_t* C = &CURVES[curve];
+  aff* b = (aff*)ref_bases_load(curve, ck_xy64, n);
+  xyzz acc; msm_full(C, (const fe*)v_le32, b, n, &acc);
+  free(b);
+  aff h; load_bases(C, h_xy64, 1, &h);
+  fe r; memcpy(&r, r_le32, 32);
+  xyzz t; xyzz_scalar_mul(C->base, &t, &h, &r);
+  xyzz_add(C->base, &acc, &t);
+  store_point(C, &acc, out, is_inf);
+  return 0;
+}
+/* batch_add (msm.rs:689-708): sum of bases at the given indices */
+int ref_batch_add(int curve, const uint8_t* bases_xy64, size_t n_bases, const uint64_t* idx, size_t k, uint8_t* out, uint8_t* is_inf) {
+  if (curve < 0 || curve > 3) return -1;
+  const curve_t* C = &CURVES[curve];
+  aff* b = (aff*)ref_bases_load(curve, bases_xy64, n_bases);
+  xyzz acc; xyzz_zero(C->base, &acc);
+  for (size_t i = 0; i < k; i++) xyzz_add_affine(C->base, &acc, &b[idx[i]]);
+  free(b);
+  store_point(C, &acc, out, is_inf);
+  return 0;
+}
+/* P_i = (k0 + i) * G (curve_property_tests.rs:186-194); generator given by the caller as canonical x||y */
+int ref_sequential_bases(int curve, const uint8_t* gen_xy64, uint64_t k0, size_t n, uint8_t* out_xy64) {
+  if (curve < 0 || curve > 3) return -1;
+  const curve_t* C = &CURVES[curve];
+  aff g; load_bases(C, gen_xy64, 1, &g);
+  int nt = nthreads();
+  size_t chunk = (n + nt - 1) / (size_t)nt;
+#pragma omp parallel for num_threads(nt)
+  for (int t = 0; t < nt; t++) {
+    size_t lo = (size_t)t * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    if (lo >= hi) continue;
+    fe k = {{k0 + lo, 0, 0, 0}};
+    xyzz p; xyzz_scalar_mul(C->base, &p, &g, &k);
+    for (size_t i = lo; i < hi; i++) {
+      store_point(C, &p, out_xy64 + 64 * i, NULL);
+      xyzz_add_affine(C->base, &p, &g);
+    }
+  }
+  return 0;
+}
+/* field-vector kernels of the "next" rows, canonical in/out: out = a + r*b  (r1cs/mod.rs:1058-1067) */
+int ref_field_axpy(int field, const uint8_t* a, const uint8_t* b, const uint8_t* r, size_t n, uint8_t* out) {
+  static const field_t* FS[4] = {&F_BN_Q, &F_BN_R, &F_PA_P, &F_PA_Q};
+  if (field < 0 || field > 3) return -1;
+  const field_t* F = FS[field];
+  fe rr; memcpy(&rr, r, 32); fe_to_mont(F, &rr, &rr);
+#pragma omp parallel for num_threads(nthreads())
+  for (long i = 0; i < (long)n; i++) {
+    fe x, y; memcpy(&x, a + 32 * i, 32); memcpy(&y, b + 32 * i, 32);
+    fe_mul(F, &y, &y, &rr); /* (y * rR)/R = y*r, canonical */
+    fe_add(F, &x, &x, &y);
+    memcpy(out + 32 * i, &x, 32);
+  }
+  return 0;
+}

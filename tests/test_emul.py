@@ -1,0 +1,153 @@
+"""CPU-side check of the HIP kernel bodies (no GPU): tests/host_emul runs the same functors and the same
+msm_pipeline() as libnova_mi355x.so with a loop backend (see tests/host_emul/emul.cpp) and is compared against
+the oracle.  This exercises digit recoding, sorting/bounds, over-long bucket splitting + folds, the reduction tree
+and the host tail for every curve, window width and scalar distribution -- it is a debugging aid that saves GPU
+minutes, not a shipped path: the real parity gate is tests/test_gpu_parity.py through the C ABI.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import cref
+from oracle import pyref as R
+from tests import util
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "host_emul", "emul.cpp")
+SO = os.path.join(HERE, "host_emul", "libnmx_emul.so")
+CSRC = os.path.join(os.path.dirname(HERE), "nova_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def emul():
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("fp.hpp", "curve.hpp", "curves.hpp", "msm_kernels.hpp", "msm_pipeline.hpp")]
+    if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", SO, SRC])
+    L = ctypes.CDLL(SO)
+    L.emul_msm.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32,
+                           ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+    L.emul_fp_op.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
+    return L
+
+
+def run(L, cid, scalars, bases, n, force_c=0, u64_bits=None):
+    s = np.ascontiguousarray(scalars)
+    b = np.ascontiguousarray(bases)
+    out = np.zeros(64, np.uint8)
+    inf = np.zeros(1, np.uint8)
+    mode = 0 if u64_bits is None else 1
+    rc = L.emul_msm(cid, s.ctypes.data, b.ctypes.data, n, u64_bits or 0, mode, 0, force_c, out.ctypes.data, inf.ctypes.data)
+    return rc, out.tobytes(), int(inf[0])
+
+
+FIELDS = [R.BN254_Q, R.BN254_R, R.PALLAS_P, R.PALLAS_Q]
+
+
+@pytest.mark.parametrize("fid", range(4))
+def test_field_ops(emul, fid):
+    """fp.hpp (8 x 32-bit Montgomery) against big-int arithmetic, incl. boundary values."""
+    p = FIELDS[fid]
+    Rm = 1 << 256
+    Ri = pow(Rm, -1, p)
+    rng = np.random.Generator(np.random.PCG64(fid))
+
+    def op(o, a, b=0):
+        out = ctypes.create_string_buffer(32)
+        emul.emul_fp_op(fid, o, a.to_bytes(32, "little"), b.to_bytes(32, "little"), out)
+        return int.from_bytes(out.raw, "little")
+
+    vals = [0, 1, 2, p - 1, p - 2, (1 << 253) - 1, Rm % p] + [int.from_bytes(rng.bytes(32), "little") % p for _ in range(40)]
+    for a in vals:
+        for b in vals[:12]:
+            assert op(0, a, b) == a * b * Ri % p
+            assert op(1, a, b) == (a + b) % p
+            assert op(2, a, b) == (a - b) % p
+        assert op(3, a) == a * Rm % p
+        assert op(4, a) == a * Ri % p
+        assert op(6, a) == (-a) % p
+        assert op(7, a) == a * a * Ri % p
+    for a in vals[1:8]:
+        assert op(5, a * Rm % p) == pow(a, -1, p) * Rm % p
+    assert op(5, 0) == 0
+
+
+@pytest.mark.parametrize("c", list(R.CURVES.values()), ids=lambda c: c.name)
+@pytest.mark.parametrize("n", [1, 2, 16, 17, 100, 1000])
+def test_emul_msm_all_sets(emul, c, n):
+    bases = cref.sequential_bases(c, 1000 + n, n)
+    for kind in ["random", "equal", "zero_rm1", "pm_small", "u1", "u10"]:
+        sc = util.scalar_set(c.cid, n, kind)
+        rc, got, inf = run(emul, c.cid, sc, bases, n)
+        assert rc == 0
+        assert (got, inf) == cref.msm(c.cid, sc, bases, n), (c.name, n, kind)
+
+
+@pytest.mark.parametrize("force_c", [1, 2, 5, 9, 13, 16])
+def test_emul_window_widths(emul, force_c):
+    c = R.BN254_G1
+    n = 300
+    bases = cref.sequential_bases(c, 3, n)
+    for kind in ["random", "zero_rm1"]:
+        sc = util.scalar_set(c.cid, n, kind)
+        rc, got, inf = run(emul, c.cid, sc, bases, n, force_c=force_c)
+        assert rc == 0 and (got, inf) == cref.msm(c.cid, sc, bases, n), (force_c, kind)
+    c = R.PALLAS  # 255-bit scalars: top window carries
+    bases = cref.sequential_bases(c, 3, n)
+    sc = util.scalar_set(c.cid, n, "zero_rm1")
+    rc, got, inf = run(emul, c.cid, sc, bases, n, force_c=force_c)
+    assert rc == 0 and (got, inf) == cref.msm(c.cid, sc, bases, n)
+
+
+def test_emul_heavy_buckets_and_identity_bases(emul):
+    """All-equal scalars put every point of a window in one bucket: over-long buckets are split into extra tasks
+    and folded (PlanFn / FoldFn).  8200 > 256 * lmax exercises all three fold passes."""
+    c = R.BN254_G1
+    n = 8200
+    bases = cref.sequential_bases(c, 77, n).copy()
+    bases[5] = 0
+    bases[4000] = 0
+    for kind in ["equal", "zero_rm1", "random"]:
+        sc = util.scalar_set(c.cid, n, kind)
+        rc, got, inf = run(emul, c.cid, sc, bases, n)
+        assert rc == 0 and (got, inf) == cref.msm(c.cid, sc, bases, n), kind
+        if kind == "equal":  # c = 13 -> lmax = 32 -> 257 extra tasks per bucket: the T = 256 fold pass loops
+            rc, got, inf = run(emul, c.cid, sc, bases, n, force_c=13)
+            assert rc == 0 and (got, inf) == cref.msm(c.cid, sc, bases, n)
+    # duplicate bases: P + P inside a bucket takes the doubling branch, P + (-P) the cancellation branch
+    dup = np.repeat(bases[:1], 64, axis=0)
+    sc = util.scalar_set(c.cid, 64, "equal")
+    rc, got, inf = run(emul, c.cid, sc, dup, 64)
+    assert rc == 0 and (got, inf) == cref.msm(c.cid, sc, dup, 64)
+    sc = util.scalar_set(c.cid, 64, "zero_rm1").copy()
+    sc[0::2] = util.int_to_le32(1)  # 1*P + (r-1)*P + ... == identity
+    rc, got, inf = run(emul, c.cid, sc, dup, 64)
+    assert rc == 0 and (got, inf) == (bytes(64), 1)
+
+
+@pytest.mark.parametrize("bits", [1, 4, 8, 10, 16, 20, 32, 40, 64])
+def test_emul_small_scalars(emul, bits):
+    """msm_small_with_max_num_bits semantics (msm.rs:478-503) incl. the out-of-contract error."""
+    for c in (R.BN254_G1, R.VESTA):
+        n = 200
+        bases = cref.sequential_bases(c, 9, n)
+        s = util.small_scalars(n, bits)
+        rc, got, inf = run(emul, c.cid, s, bases, n, u64_bits=bits)
+        assert rc == 0 and (got, inf) == cref.msm_u64(c.cid, s, bases, n, bits)
+    if bits < 64:
+        s = s.copy()
+        s[7] = np.uint64(1) << np.uint64(bits)
+        rc, _, _ = run(emul, c.cid, s, bases, n, u64_bits=bits)
+        assert rc != 0  # ERR_SMALL_RANGE
+
+
+def test_emul_scalar_out_of_range(emul):
+    c = R.BN254_G1
+    n = 20
+    bases = cref.sequential_bases(c, 9, n)
+    sc = util.random_scalars(c.cid, n).copy()
+    sc[3] = util.int_to_le32(c.r)  # == modulus: from_repr rejects
+    rc, _, _ = run(emul, c.cid, sc, bases, n)
+    assert rc != 0
