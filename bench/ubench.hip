@@ -8,7 +8,7 @@
 #include <cstdlib>
 #include <vector>
 
-#include "../nova_amd/csrc/fp.hpp"
+#include "../nova_amd/csrc/curve.hpp"
 
 using namespace nmx;
 #define CHK(x)                                                                      \
@@ -76,160 +76,34 @@ __global__ __launch_bounds__(256) void k_dfma(double* out, double a, double b) {
   out[blockIdx.x * 256 + threadIdx.x] = x0 + x1 + x2 + x3;
 }
 
-// --- modmul variants -------------------------------------------------------------------------------
-// V0: fp.hpp as shipped (C++ 96-bit accumulator)
-__global__ __launch_bounds__(256) void k_modmul_v0(Fp<0>* io, int iters) {
+// --- shipped field / curve arithmetic (fp.hpp, curve.hpp) ---------------------------------------------
+// The saturated-32-bit-limb candidates this design was chosen against (C++ 96-bit accumulator 68 G/s, inline-asm
+// v_mad_u64_u32 + v_addc 119 G/s, CIOS 95 G/s, vs 9 x 29-bit 173 G/s) were measured with an earlier revision of
+// this file; their numbers are kept in profiles/r01_ubench_limb_formats.jsonl.
+template <int FID> __global__ __launch_bounds__(256) void k_modmul(uint32_t* io, int iters) {
   int t = blockIdx.x * 256 + threadIdx.x;
-  Fp<0> x = io[t], y = io[t + 1];
+  Fp<FID> x = Fp<FID>::from_words(io + 8 * t), y = Fp<FID>::from_words(io + 8 * t + 8);
   for (int i = 0; i < iters; i++) {
     x = x * y;
     y = y * x;
   }
-  io[t] = x + y;
+  (x + y).norm().canon().to_words(io + 8 * t);
 }
-
-// V1: asm mac (v_mad_u64_u32 carry-out -> v_addc), 2 wait states for the VCC hazard
-__device__ __forceinline__ void mac_asm(uint64_t& lo, uint32_t& hi, uint32_t x, uint32_t y) {
-  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
-      : "+v"(lo), "+v"(hi)
-      : "v"(x), "v"(y)
-      : "vcc");
-}
-__device__ __forceinline__ Fp<0> mul_v1(const Fp<0>& a, const Fp<0>& b) {
-  using PP = FpParams<0>;
-  uint64_t lo = 0;
-  uint32_t hi = 0;
-  uint32_t m[8];
-  Fp<0> r;
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-#pragma unroll
-    for (int i = 0; i <= k; i++) mac_asm(lo, hi, a.l[i], b.l[k - i]);
-#pragma unroll
-    for (int i = 0; i < k; i++) mac_asm(lo, hi, m[i], PP::P[k - i]);
-    m[k] = (uint32_t)lo * PP::NINV;
-    mac_asm(lo, hi, m[k], PP::P[0]);
-    lo = (lo >> 32) | ((uint64_t)hi << 32);
-    hi = 0;
-  }
-#pragma unroll
-  for (int k = 8; k < 16; k++) {
-#pragma unroll
-    for (int i = k - 7; i < 8; i++) mac_asm(lo, hi, a.l[i], b.l[k - i]);
-#pragma unroll
-    for (int i = k - 7; i < 8; i++) mac_asm(lo, hi, m[i], PP::P[k - i]);
-    r.l[k - 8] = (uint32_t)lo;
-    lo = (lo >> 32) | ((uint64_t)hi << 32);
-    hi = 0;
-  }
-  r.cond_sub_p();
-  return r;
-}
-__global__ __launch_bounds__(256) void k_modmul_v1(Fp<0>* io, int iters) {
+template <int FID> __global__ __launch_bounds__(256) void k_modsqr(uint32_t* io, int iters) {
   int t = blockIdx.x * 256 + threadIdx.x;
-  Fp<0> x = io[t], y = io[t + 1];
+  Fp<FID> x = Fp<FID>::from_words(io + 8 * t), y = Fp<FID>::from_words(io + 8 * t + 8);
   for (int i = 0; i < iters; i++) {
-    x = mul_v1(x, y);
-    y = mul_v1(y, x);
+    x = x.sqr();
+    y = y.sqr();
   }
-  io[t] = x + y;
+  (x + y).norm().canon().to_words(io + 8 * t);
 }
-
-// V2: 9 x 29-bit limbs, plain 64-bit column accumulators (no carry logic at all); throughput probe only
-struct F29 {
-  uint32_t l[9];
-};
-__device__ __forceinline__ F29 mul_v2(const F29& a, const F29& b, const F29& p, uint32_t ninv) {
-  const uint32_t mask = (1u << 29) - 1;
-  uint64_t acc = 0;
-  uint32_t m[9];
-  F29 r;
-#pragma unroll
-  for (int k = 0; k < 9; k++) {
-#pragma unroll
-    for (int i = 0; i <= k; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
-#pragma unroll
-    for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * p.l[k - i];
-    m[k] = ((uint32_t)acc * ninv) & mask;
-    acc += (uint64_t)m[k] * p.l[0];
-    acc >>= 29;
-  }
-#pragma unroll
-  for (int k = 9; k < 17; k++) {
-#pragma unroll
-    for (int i = k - 8; i < 9; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
-#pragma unroll
-    for (int i = k - 8; i < 9; i++) acc += (uint64_t)m[i] * p.l[k - i];
-    r.l[k - 9] = (uint32_t)acc & mask;
-    acc >>= 29;
-  }
-  r.l[8] = (uint32_t)acc;
-  return r;
-}
-__global__ __launch_bounds__(256) void k_modmul_v2(F29* io, int iters, F29 p, uint32_t ninv) {
+// mixed addition throughput: every lane adds the same stream of 64 points to its own accumulator
+template <int FID> __global__ __launch_bounds__(256) void k_madd(const AffineW* pts, XYZZW* out, int iters) {
   int t = blockIdx.x * 256 + threadIdx.x;
-  F29 x = io[t], y = io[t + 1];
-  for (int i = 0; i < iters; i++) {
-    x = mul_v2(x, y, p, ninv);
-    y = mul_v2(y, x, p, ninv);
-  }
-#pragma unroll
-  for (int j = 0; j < 9; j++) x.l[j] ^= y.l[j];
-  io[t] = x;
-}
-
-// V3: operand-scanning CIOS on 32-bit limbs, every step  a*b + t + c  (cannot overflow 64 bits: no carry flags)
-__device__ __forceinline__ Fp<0> mul_v3(const Fp<0>& a, const Fp<0>& b) {
-  using PP = FpParams<0>;
-  uint32_t t[9];
-#pragma unroll
-  for (int j = 0; j < 9; j++) t[j] = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    uint64_t c = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      c = (uint64_t)a.l[j] * b.l[i] + t[j] + c;
-      t[j] = (uint32_t)c;
-      c >>= 32;
-    }
-    uint32_t t8 = t[8] + (uint32_t)c;  // < 2^32 because P < 2^255
-    uint32_t m = t[0] * PP::NINV;
-    c = (uint64_t)m * PP::P[0] + t[0];
-    c >>= 32;
-#pragma unroll
-    for (int j = 1; j < 8; j++) {
-      c = (uint64_t)m * PP::P[j] + t[j] + c;
-      t[j - 1] = (uint32_t)c;
-      c >>= 32;
-    }
-    c += t8;
-    t[7] = (uint32_t)c;
-    t[8] = (uint32_t)(c >> 32);
-  }
-  Fp<0> r;
-#pragma unroll
-  for (int j = 0; j < 8; j++) r.l[j] = t[j];
-  r.cond_sub_p();
-  return r;
-}
-__global__ __launch_bounds__(256) void k_modmul_v3(Fp<0>* io, int iters) {
-  int t = blockIdx.x * 256 + threadIdx.x;
-  Fp<0> x = io[t], y = io[t + 1];
-  for (int i = 0; i < iters; i++) {
-    x = mul_v3(x, y);
-    y = mul_v3(y, x);
-  }
-  io[t] = x + y;
-}
-// correctness cross-check of V1/V3 against V0 on random inputs
-__global__ void k_check(const Fp<0>* in, uint32_t* bad, int n) {
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n) return;
-  Fp<0> a = in[t], b = in[t + 1];
-  Fp<0> r0 = a * b, r1 = mul_v1(a, b), r3 = mul_v3(a, b);
-  if (r0 != r1) atomicAdd(&bad[0], 1);
-  if (r0 != r3) atomicAdd(&bad[1], 1);
+  XYZZ<FID> acc = XYZZ<FID>::from_affine(Affine<FID>::load(pts[t & 63]));
+  for (int i = 0; i < iters; i++) acc.add_affine(Affine<FID>::load(pts[(t + i + 1) & 63]), (i & 1) != 0);
+  acc.store(out[t]);
 }
 
 template <class L> float time_ms(L&& launch, int reps = 5) {
@@ -273,7 +147,7 @@ int main() {
   ms = time_ms([&] { k_dfma<<<blocks, 256>>>((double*)buf, 1.0000001, 1e-9); });
   printf("{\"ubench\": \"v_fma_f64\", \"Gops\": %.1f}\n", lanes_ops / ms * 1e-6);
 
-  // random-ish field elements < P: clear the top 3 bits
+  // random-ish field elements < p: clear the top 3 bits
   {
     std::vector<uint32_t> h((size_t)(threads + 1) * 8);
     uint64_t s = 0x5EEDC0DE12345678ull;
@@ -284,26 +158,39 @@ int main() {
     for (size_t i = 0; i < (size_t)threads + 1; i++) h[i * 8 + 7] &= 0x1fffffffu;
     CHK(hipMemcpy(buf, h.data(), h.size() * 4, hipMemcpyHostToDevice));
   }
-  uint32_t* bad;
-  CHK(hipMalloc(&bad, 8));
-  CHK(hipMemset(bad, 0, 8));
-  k_check<<<(threads + 255) / 256, 256>>>((const Fp<0>*)buf, bad, threads);
-  uint32_t hbad[2];
-  CHK(hipMemcpy(hbad, bad, 8, hipMemcpyDeviceToHost));
-  printf("{\"check\": \"modmul variants vs v0\", \"v1_mismatch\": %u, \"v3_mismatch\": %u}\n", hbad[0], hbad[1]);
-
   const int it = 256;
   const double mm = (double)threads * it * 2;
-  ms = time_ms([&] { k_modmul_v0<<<blocks, 256>>>((Fp<0>*)buf, it); });
-  printf("{\"ubench\": \"modmul_v0_cpp96\", \"Gmodmul_s\": %.2f}\n", mm / ms * 1e-6);
-  ms = time_ms([&] { k_modmul_v1<<<blocks, 256>>>((Fp<0>*)buf, it); });
-  printf("{\"ubench\": \"modmul_v1_asm_mac\", \"Gmodmul_s\": %.2f}\n", mm / ms * 1e-6);
-  ms = time_ms([&] { k_modmul_v3<<<blocks, 256>>>((Fp<0>*)buf, it); });
-  printf("{\"ubench\": \"modmul_v3_cios\", \"Gmodmul_s\": %.2f}\n", mm / ms * 1e-6);
-  F29 p29;
-  for (int j = 0; j < 9; j++) p29.l[j] = 0x0fffffffu - j;
-  p29.l[0] |= 1;
-  ms = time_ms([&] { k_modmul_v2<<<blocks, 256>>>((F29*)buf, it, p29, 0x12345677u); });
-  printf("{\"ubench\": \"modmul_v2_29bit\", \"Gmodmul_s\": %.2f}\n", mm / ms * 1e-6);
+  ms = time_ms([&] { k_modmul<0><<<blocks, 256>>>((uint32_t*)buf, it); });
+  printf("{\"ubench\": \"modmul_9x29 bn254_fq\", \"Gmodmul_s\": %.2f}\n", mm / ms * 1e-6);
+  ms = time_ms([&] { k_modsqr<0><<<blocks, 256>>>((uint32_t*)buf, it); });
+  printf("{\"ubench\": \"modsqr_9x29 bn254_fq\", \"Gmodmul_s\": %.2f}\n", mm / ms * 1e-6);
+  ms = time_ms([&] { k_modmul<2><<<blocks, 256>>>((uint32_t*)buf, it); });
+  printf("{\"ubench\": \"modmul_9x29 pasta_fp\", \"Gmodmul_s\": %.2f}\n", mm / ms * 1e-6);
+  // 64 points on BN254: (1,2) is on the curve; use doublings of it computed on the host via the same header
+  {
+    std::vector<AffineW> pts(64);
+    uint32_t wx[8] = {1, 0, 0, 0, 0, 0, 0, 0}, wy[8] = {2, 0, 0, 0, 0, 0, 0, 0};
+    Affine<0> g;
+    g.x = Fp<0>::from_words(wx).to_internal().canon();
+    g.y = Fp<0>::from_words(wy).to_internal().canon();
+    XYZZ<0> acc = XYZZ<0>::from_affine(g);
+    for (int i = 0; i < 64; i++) {
+      acc.to_affine().store(pts[i]);
+      acc.add_affine(g);
+      acc.dbl_in_place();
+    }
+    AffineW* dp;
+    XYZZW* dout;
+    CHK(hipMalloc(&dp, 64 * sizeof(AffineW)));
+    CHK(hipMalloc(&dout, (size_t)threads * sizeof(XYZZW)));
+    CHK(hipMemcpy(dp, pts.data(), 64 * sizeof(AffineW), hipMemcpyHostToDevice));
+    const int mit = 64;
+    ms = time_ms([&] { k_madd<0><<<blocks, 256>>>(dp, dout, mit); });
+    printf("{\"ubench\": \"xyzz_madd bn254 (L1-resident operands)\", \"Gmadd_s\": %.3f, \"blocks_per_cu\": 8}\n",
+           (double)threads * mit / ms * 1e-6);
+    ms = time_ms([&] { k_madd<0><<<blocks / 2, 256>>>(dp, dout, mit); });
+    printf("{\"ubench\": \"xyzz_madd bn254 (L1-resident operands)\", \"Gmadd_s\": %.3f, \"blocks_per_cu\": 4}\n",
+           (double)threads / 2 * mit / ms * 1e-6);
+  }
   return 0;
 }

@@ -36,8 +36,11 @@ enum {
   NMX_BASES_MONT = 1u << 1,     /* base coordinates are raw Montgomery limbs instead of canonical LE     */
   NMX_SCALARS_DEVICE = 1u << 2, /* `scalars` is a device (HBM) pointer on the library's device           */
   NMX_BASES_DEVICE = 1u << 3,   /* `bases` is a device pointer (nmx_bases_register only)                 */
-  NMX_OUT_PARTIAL = 1u << 4     /* write a 128-byte (X,Y,ZZ,ZZZ) Montgomery partial sum instead of an     */
-                                /* affine point: the per-GPU result of a sharded MSM (nmx_point_sum)     */
+  NMX_OUT_PARTIAL = 1u << 4     /* write a 128-byte partial sum instead of an affine point: the per-GPU   */
+                                /* result of a sharded MSM, input of nmx_point_sum.  Format: extended     */
+                                /* Jacobian (X, Y, ZZ, ZZZ), x = X/ZZ, y = Y/ZZZ, each coordinate the     */
+                                /* 32-byte LE integer v * 2^261 mod p (the library's internal residue     */
+                                /* form), identity <=> ZZ == 0.                                           */
 };
 
 /* error codes */

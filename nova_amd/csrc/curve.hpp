@@ -1,21 +1,48 @@
 // curve.hpp -- extended-Jacobian (X, Y, ZZ, ZZZ) bucket arithmetic for a = 0 short-Weierstrass curves.
 //
 // Same coordinate system and EFD formula set the reference uses for its bucket loops
-// (/root/reference/src/provider/msm.rs:38-165: madd-2008-s, add-2008-s, dbl-2008-s-1), including its
-// explicit handling of the exceptional cases (empty bucket, P == Q -> double, P == -Q -> empty, identity
-// base skipped: msm.rs:92-113,130-155).  The formulas never use the curve constant b, so one instantiation
-// per base field serves both curves of a cycle.
+// (/root/reference/src/provider/msm.rs:38-165: madd-2008-s, add-2008-s, dbl-2008-s-1), including its explicit
+// handling of the exceptional cases (empty bucket, P == Q -> double, P == -Q -> empty, identity base skipped:
+// msm.rs:92-113,130-155).  The formulas never use the curve constant b, so one instantiation per base field
+// serves both curves of a cycle.
+//
+// Lazy-reduction discipline (fp.hpp): no conditional subtraction of p anywhere in the hot formulas.  In-register
+// invariants of an XYZZ accumulator, in multiples of p (asserted in the NMX_DEBUG_BOUNDS emulation build):
+//     x < 5.3      y < 3.5      zz, zzz < 1.2         every coordinate normalized
+// A product of operands bounded by a*p and b*p is < (1 + a*b/127) p; the bound of every intermediate is written
+// at the right of its line and stays below the 127 limit.  Points at rest in HBM are canonical (< p), packed
+// 8 x u32 per coordinate.
 #pragma once
 #include "fp.hpp"
 
 namespace nmx {
 
-template <int FID> struct Affine {  // 64 bytes; identity encoded as (0, 0) like halo2curves / traits.rs:303-312
-  Fp<FID> x, y;
-  NMX_HD bool is_identity() const { return x.is_zero() && y.is_zero(); }
+// 64 bytes in HBM: x || y, each the canonical internal-form residue packed in 8 x u32; identity = all zero
+// (like halo2curves / traits.rs:303-312; (0, 0) is not on any of the four curves).
+struct AffineW {
+  uint32_t w[16];
+};
+// 128 bytes in HBM: x, y, zz, zzz packed; identity <=> zz words all zero (msm.rs:59-61)
+struct XYZZW {
+  uint32_t w[32];
 };
 
-template <int FID> struct XYZZ {  // 128 bytes; identity <=> zz == 0 (msm.rs:59-61)
+template <int FID> struct Affine {
+  Fp<FID> x, y;  // canonical
+  static NMX_HD Affine load(const AffineW& m) {
+    Affine a;
+    a.x = Fp<FID>::from_words(m.w);
+    a.y = Fp<FID>::from_words(m.w + 8);
+    return a;
+  }
+  NMX_HD void store(AffineW& m) const {
+    x.to_words(m.w);
+    y.to_words(m.w + 8);
+  }
+  NMX_HD bool is_identity() const { return x.is_zero_limbs() && y.is_zero_limbs(); }
+};
+
+template <int FID> struct XYZZ {
   using F = Fp<FID>;
   F x, y, zz, zzz;
 
@@ -27,7 +54,30 @@ template <int FID> struct XYZZ {  // 128 bytes; identity <=> zz == 0 (msm.rs:59-
     r.zzz = F::zero();
     return r;
   }
-  NMX_HD bool is_identity() const { return zz.is_zero(); }
+  // Identity <=> zz is the literal zero: zz is only ever a product of non-zero residues, the constant one, or an
+  // explicit zero written by identity() -- and 0 * anything comes out of the Montgomery product as literal 0.
+  NMX_HD bool is_identity() const { return zz.is_zero_limbs(); }
+
+  static NMX_HD XYZZ load(const XYZZW& m) {
+    XYZZ r;
+    r.x = F::from_words(m.w);
+    r.y = F::from_words(m.w + 8);
+    r.zz = F::from_words(m.w + 16);
+    r.zzz = F::from_words(m.w + 24);
+    return r;
+  }
+  NMX_HD void store(XYZZW& m) const {  // canonicalises: at rest every coordinate is < p
+    x.canon().to_words(m.w);
+    y.canon().to_words(m.w + 8);
+    zz.canon().to_words(m.w + 16);
+    zzz.canon().to_words(m.w + 24);
+  }
+  NMX_HD void check() const {
+    x.check_below(5.3, "x");
+    y.check_below(3.5, "y");
+    zz.check_below(1.2, "zz");
+    zzz.check_below(1.2, "zzz");
+  }
 
   static NMX_HD XYZZ from_affine(const Affine<FID>& p) {
     if (p.is_identity()) return identity();
@@ -39,31 +89,37 @@ template <int FID> struct XYZZ {  // 128 bytes; identity <=> zz == 0 (msm.rs:59-
     return r;
   }
 
-  NMX_HD XYZZ neg() const {
+  NMX_HD XYZZ neg() const {  // rare (host tail)
     XYZZ r = *this;
-    r.y = y.neg();
+    r.y = F::sub2(F::zero(), y.canon()).norm();  // 2p - y in (p, 2p]
     return r;
   }
 
-  // dbl-2008-s-1 with a = 0: 2M + 5S ... (msm.rs:65-88)
+  // dbl-2008-s-1 with a = 0 (msm.rs:65-88).                                     bound (x p)
   NMX_HD void dbl_in_place() {
     if (is_identity()) return;
     // a point of order 2 (y == 0) cannot occur on these prime-order curves
-    F u = y.dbl();
-    F v = u.sqr();
-    F w = u * v;
-    F s = x * v;
-    F xx = x.sqr();
-    F m = xx.dbl() + xx;
-    F x3 = m.sqr() - s.dbl();
-    F y3 = m * (s - x3) - w * y;
+    F u = y.dbl().norm();                          //  7.0
+    F v = u.sqr();                                 //  1 + 49/127      < 1.39
+    F w = u * v;                                   //  1 + 9.8/127     < 1.08
+    F s = x * v;                                   //  1 + 7.4/127     < 1.06
+    F xx = x.sqr();                                //  1 + 28.1/127    < 1.23
+    F m = (xx.dbl() + xx).norm();                  //  3.69
+    F s2 = s.dbl().norm();                         //  2.12
+    F x3 = F::sub4(m.sqr(), s2).norm();            //  1.11 + 4        < 5.11
+    F e = F::sub8(s, x3).norm();                   //  1.06 + 8        < 9.06
+    F y3 = F::sub2(m * e, w * y).norm();           //  (1 + 33.5/127) + 2 < 3.27     [w*y < 1.03 < 2]
     x = x3;
     y = y3;
-    zz = zz * v;
-    zzz = zzz * w;
+    zz = zz * v;                                   //  1 + 1.67/127    < 1.02
+    zzz = zzz * w;                                 //  < 1.02
+#ifdef NMX_BOUND_CHECKS
+    check();
+#endif
   }
 
-  // madd-2008-s: this += (px, +-py), affine operand known non-identity by the caller when skip_check
+  // madd-2008-s (msm.rs:129-165): this += (px, py), the affine operand non-identity.
+  // px canonical (< p); py < 2p normalized (a canonical y, or 2p - y for a negated point).
   NMX_HD void add_affine(const F& px, const F& py) {
     if (is_identity()) {
       x = px;
@@ -72,64 +128,82 @@ template <int FID> struct XYZZ {  // 128 bytes; identity <=> zz == 0 (msm.rs:59-
       zzz = F::one();
       return;
     }
-    F u2 = px * zz;
-    F s2 = py * zzz;
-    if (u2 == x) {
-      if (s2 == y) {
-        dbl_in_place();
-      } else {
-        *this = identity();
+    F u2 = px * zz;                                //  1 + 1.2/127     < 1.01
+    F s2 = py * zzz;                               //  1 + 2.4/127     < 1.02
+    F d = F::sub8(u2, x).norm();                   //  in (2.7, 9.01)             [x < 5.3 < 8]
+    if (d.maybe_zero_mod_p()) {                    //  taken with probability 2^-29 unless u2 == x
+      if (F::eq_mod_p(u2, x)) {
+        if (F::eq_mod_p(s2, y))
+          dbl_in_place();                          //  P == Q   (msm.rs:148-150)
+        else
+          *this = identity();                      //  P == -Q  (msm.rs:151-153)
+        return;
       }
-      return;
     }
-    F p = u2 - x;
-    F r = s2 - y;
-    F pp = p.sqr();
-    F ppp = p * pp;
-    F q = x * pp;
-    F x3 = r.sqr() - ppp - q.dbl();
-    y = r * (q - x3) - y * ppp;
+    F r = F::sub4(s2, y).norm();                   //  1.02 + 4        < 5.02     [y < 3.5 < 4]
+    F pp = d.sqr();                                //  1 + 81.2/127    < 1.64
+    F ppp = d * pp;                                //  1 + 14.8/127    < 1.12
+    F q = x * pp;                                  //  1 + 8.7/127     < 1.07
+    F t = (ppp + q.dbl()).norm();                  //  3.26
+    F x3 = F::sub4(r.sqr(), t).norm();             //  (1 + 25.2/127) + 4 < 5.2
+    F e = F::sub8(q, x3).norm();                   //  1.07 + 8        < 9.07
+    F y3 = F::sub2(r * e, y * ppp).norm();         //  (1 + 45.6/127) + 2 < 3.36  [y*ppp < 1.04 < 2]
     x = x3;
-    zz = zz * pp;
-    zzz = zzz * ppp;
+    y = y3;
+    zz = zz * pp;                                  //  1 + 1.97/127    < 1.02
+    zzz = zzz * ppp;                               //  < 1.02
+#ifdef NMX_BOUND_CHECKS
+    check();
+#endif
   }
-  NMX_HD void add_affine(const Affine<FID>& p) {
+  // affine operand as loaded from HBM; negate = the sign of a signed window digit
+  NMX_HD void add_affine(const Affine<FID>& p, bool negate = false) {
     if (p.is_identity()) return;  // msm.rs:130-132
-    add_affine(p.x, p.y);
+    if (negate)
+      add_affine(p.x, F::sub2(F::zero(), p.y).norm());  // 2p - y in (p, 2p]
+    else
+      add_affine(p.x, p.y);
   }
 
-  // add-2008-s: this += o  (msm.rs:91-123)
+  // add-2008-s (msm.rs:91-123): this += o, both operands within the in-register invariants.
   NMX_HD void add(const XYZZ& o) {
     if (o.is_identity()) return;
     if (is_identity()) {
       *this = o;
       return;
     }
-    F u1 = x * o.zz;
-    F u2 = o.x * zz;
-    F s1 = y * o.zzz;
-    F s2 = o.y * zzz;
-    if (u1 == u2) {
-      if (s1 == s2) {
-        dbl_in_place();
-      } else {
-        *this = identity();
+    F u1 = x * o.zz;                               //  1 + 6.4/127     < 1.06
+    F u2 = o.x * zz;                               //  < 1.06
+    F s1 = y * o.zzz;                              //  1 + 4.2/127     < 1.04
+    F s2 = o.y * zzz;                              //  < 1.04
+    F d = F::sub2(u2, u1).norm();                  //  in (0.94, 3.06)
+    if (d.maybe_zero_mod_p()) {
+      if (F::eq_mod_p(u1, u2)) {
+        if (F::eq_mod_p(s1, s2))
+          dbl_in_place();                          //  msm.rs:106-108
+        else
+          *this = identity();                      //  msm.rs:109-111
+        return;
       }
-      return;
     }
-    F p = u2 - u1;
-    F r = s2 - s1;
-    F pp = p.sqr();
-    F ppp = p * pp;
-    F q = u1 * pp;
-    F x3 = r.sqr() - ppp - q.dbl();
-    y = r * (q - x3) - s1 * ppp;
+    F r = F::sub2(s2, s1).norm();                  //  3.04
+    F pp = d.sqr();                                //  1 + 9.4/127     < 1.08
+    F ppp = d * pp;                                //  < 1.03
+    F q = u1 * pp;                                 //  < 1.01
+    F t = (ppp + q.dbl()).norm();                  //  3.05
+    F x3 = F::sub4(r.sqr(), t).norm();             //  (1 + 9.3/127) + 4 < 5.08
+    F e = F::sub8(q, x3).norm();                   //  < 9.01
+    F y3 = F::sub2(r * e, s1 * ppp).norm();        //  (1 + 27.4/127) + 2 < 3.22
     x = x3;
-    zz = zz * o.zz * pp;
-    zzz = zzz * o.zzz * ppp;
+    y = y3;
+    zz = (zz * o.zz) * pp;                         //  < 1.02
+    zzz = (zzz * o.zzz) * ppp;                     //  < 1.02
+#ifdef NMX_BOUND_CHECKS
+    check();
+#endif
   }
 
-  // affine (x/zz, y/zzz); identity -> (0, 0)   (msm.rs:172-183 + traits.rs:303-312)
+  // affine (x/zz, y/zzz) canonical; identity -> (0, 0)   (msm.rs:172-183 + traits.rs:303-312)
   NMX_HD Affine<FID> to_affine() const {
     Affine<FID> r;
     if (is_identity()) {
@@ -139,8 +213,8 @@ template <int FID> struct XYZZ {  // 128 bytes; identity <=> zz == 0 (msm.rs:59-
     }
     // one inversion: (zz*zzz)^-1, then zz^-1 = inv*zzz, zzz^-1 = inv*zz
     F i = (zz * zzz).inv();
-    r.x = x * (i * zzz);
-    r.y = y * (i * zz);
+    r.x = (x * (i * zzz)).canon();
+    r.y = (y * (i * zz)).canon();
     return r;
   }
 };

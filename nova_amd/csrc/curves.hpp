@@ -35,28 +35,34 @@ template <> struct CurveT<3> {  // Vesta: y^2 = x^3 + 5, G = (-1, 2)
   static constexpr uint32_t GY[8] = {2, 0, 0, 0, 0, 0, 0, 0};
 };
 
-// ---- host-side byte marshalling (x86-64 is little-endian: limbs map 1:1 onto LE bytes) ------------------
+// ---- host-side byte marshalling (x86-64 is little-endian: 8 x u32 words map 1:1 onto 32 LE bytes) ---------
+// 32 bytes -> unpacked limbs, no reduction (the value is whatever integer the bytes spell)
 template <int FID> inline Fp<FID> fp_from_bytes(const uint8_t* b) {
-  Fp<FID> r;
-  memcpy(r.l, b, 32);
-  return r;
+  uint32_t w[8];
+  memcpy(w, b, 32);
+  return Fp<FID>::from_words(w);
 }
-template <int FID> inline void fp_to_bytes(const Fp<FID>& f, uint8_t* b) { memcpy(b, f.l, 32); }
+// normalized value < 2^256 -> 32 bytes
+template <int FID> inline void fp_to_bytes(const Fp<FID>& f, uint8_t* b) {
+  uint32_t w[8];
+  f.to_words(w);
+  memcpy(b, w, 32);
+}
 
-// XYZZ (Montgomery) -> canonical affine x||y + inf flag: `to_coordinates()` (traits.rs:303-312)
+// XYZZ (internal form) -> canonical affine x||y + inf flag: `to_coordinates()` (traits.rs:303-312)
 template <int FID> inline void xyzz_to_xy64(const XYZZ<FID>& p, uint8_t* out, uint8_t* is_inf) {
-  Affine<FID> a = p.to_affine();
   if (p.is_identity()) {
     memset(out, 0, 64);
     if (is_inf) *is_inf = 1;
     return;
   }
-  fp_to_bytes(a.x.from_mont(), out);
-  fp_to_bytes(a.y.from_mont(), out + 32);
+  Affine<FID> a = p.to_affine();
+  fp_to_bytes(a.x.to_canonical(), out);
+  fp_to_bytes(a.y.to_canonical(), out + 32);
   if (is_inf) *is_inf = 0;
 }
 
-// k * P for a canonical 256-bit integer k (host tail only: the h * r term of commit)
+// k * P for a canonical 256-bit integer k given as 8 x u32 (host tail only: the h * r term of commit)
 template <int FID> inline XYZZ<FID> scalar_mul(const XYZZ<FID>& p, const uint32_t k[8]) {
   XYZZ<FID> acc = XYZZ<FID>::identity();
   for (int i = 255; i >= 0; i--) {

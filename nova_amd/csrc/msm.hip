@@ -190,9 +190,15 @@ static void arena_reserve(Ctx& c, size_t bytes) {
 // ---------------------------------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------------------------------
-template <int FID> struct ToMontFn {  // canonical -> Montgomery, in place, one field element per lane
-  Fp<FID>* v;
-  NMX_HD void operator()(uint32_t i) const { v[i] = v[i].to_mont(); }
+template <int FID> struct ToInternalFn {  // ABI form -> internal form (canonical residue), in place, one element per lane
+  uint32_t* v;         // 8 words per element
+  uint32_t from_mont;  // 1: input is halo2curves Montgomery (x * 2^256); 0: canonical integer
+  NMX_HD void operator()(uint32_t i) const {
+    uint32_t* w = v + 8 * (size_t)i;
+    Fp<FID> f = Fp<FID>::from_words(w);
+    f = from_mont ? f.mont256_to_internal() : f.to_internal();
+    f.canon().to_words(w);  // 0 -> 0: the identity encoding (0, 0) is preserved
+  }
 };
 struct OrFn {  // OR of all u64 scalars -> bit length of the maximum
   const uint32_t* s;
@@ -204,24 +210,24 @@ struct OrFn {  // OR of all u64 scalars -> bit length of the maximum
 };
 template <int CID> struct GenFn {  // P_i = (k0 + i) * G
   using C = CurveT<CID>;
-  Affine<C::BF>* out;
+  AffineW* out;
   uint64_t k0;
   NMX_HD void operator()(uint32_t i) const {
-    Fp<C::BF> gx, gy;
+    uint32_t wx[8], wy[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-      gx.l[j] = C::GX[j];
-      gy.l[j] = C::GY[j];
+      wx[j] = C::GX[j];
+      wy[j] = C::GY[j];
     }
-    gx = gx.to_mont();
-    gy = gy.to_mont();
+    Fp<C::BF> gx = Fp<C::BF>::from_words(wx).to_internal().canon();
+    Fp<C::BF> gy = Fp<C::BF>::from_words(wy).to_internal().canon();
     uint64_t k = k0 + i;
     XYZZ<C::BF> acc = XYZZ<C::BF>::identity();
     for (int b = 63; b >= 0; b--) {
       acc.dbl_in_place();
       if ((k >> b) & 1u) acc.add_affine(gx, gy);
     }
-    out[i] = acc.to_affine();
+    acc.to_affine().store(out[i]);
   }
 };
 
@@ -258,7 +264,7 @@ static XYZZ<CurveT<CID>::BF> run_msm(Ctx& c, const void* d_bases, size_t n, cons
     require((uint64_t)n * sh.W < 0xffffffffull && n < 0x7fffffffull, NMX_E_TOO_LARGE,
             "n * windows must be < 2^32");
   }
-  XYZZ<BF> wsum[260];
+  XYZZW wsum[260];
   uint32_t err = 0;
   MsmShape sh{};
   const bool prof = G.profiling;
@@ -298,7 +304,9 @@ static XYZZ<CurveT<CID>::BF> run_msm(Ctx& c, const void* d_bases, size_t n, cons
 template <int CID> static void write_result(const XYZZ<CurveT<CID>::BF>& r, uint32_t flags, uint8_t* out,
                                             uint8_t* is_inf) {
   if (flags & NMX_OUT_PARTIAL) {
-    memcpy(out, &r, 128);
+    XYZZW w;
+    r.store(w);
+    memcpy(out, w.w, 128);
     if (is_inf) *is_inf = r.is_identity() ? 1 : 0;
   } else {
     xyzz_to_xy64<CurveT<CID>::BF>(r, out, is_inf);
@@ -315,9 +323,9 @@ template <int CID> static void* upload_bases(Ctx& c, const void* src, size_t n, 
     HIPCHK(hipMemcpyAsync(d, src, n * 64,
                           (flags & NMX_BASES_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                           c.stream));
-    if (!(flags & NMX_BASES_MONT)) {
+    {
       DeviceBackend be(c, false, false);
-      ToMontFn<BF> f{(Fp<BF>*)d};
+      ToInternalFn<BF> f{(uint32_t*)d, (flags & NMX_BASES_MONT) ? 1u : 0u};
       be.launch(f, (uint32_t)(2 * n));
     }
     HIPCHK(hipStreamSynchronize(c.stream));
@@ -486,7 +494,7 @@ int nmx_bases_read(uint64_t handle, size_t offset, size_t n, void* out_xy64) {
       constexpr int BF = CurveT<CID>::BF;
       for (size_t i = 0; i < 2 * n; i++) {
         Fp<BF> f = fp_from_bytes<BF>(o + 32 * i);
-        fp_to_bytes(f.from_mont(), o + 32 * i);
+        fp_to_bytes(f.to_canonical(), o + 32 * i);
       }
     });
   });
@@ -502,7 +510,7 @@ int nmx_bases_generate(int curve, uint64_t k0, size_t n, uint64_t* handle) {
     try {
       DeviceBackend be(*L.c, false, false);
       DISPATCH_CURVE(curve, {
-        GenFn<CID> f{(Affine<CurveT<CID>::BF>*)d, k0};
+        GenFn<CID> f{(AffineW*)d, k0};
         be.launch(f, (uint32_t)n);
       });
       HIPCHK(hipStreamSynchronize(L.c->stream));
@@ -620,18 +628,22 @@ int nmx_commit(uint64_t ck_handle, const void* v, size_t n, const void* h_xy64, 
     DISPATCH_CURVE(bs.curve, {
       constexpr int BF = CurveT<CID>::BF, SF = CurveT<CID>::SF;
       auto acc = run_msm<CID>(*L.c, bs.d, n, mc);
-      Fp<SF> rs = fp_from_bytes<SF>((const uint8_t*)r);
-      if (flags & NMX_SCALARS_MONT) rs = rs.from_mont();
-      require(rs.lt_p(), NMX_E_SCALAR_RANGE, "blinding scalar >= field modulus");
-      if (!rs.is_zero()) {
+      uint32_t rw[8];
+      memcpy(rw, r, 32);
+      require(Fp<SF>::words_lt_p(rw), NMX_E_SCALAR_RANGE, "blinding scalar >= field modulus");
+      if (flags & NMX_SCALARS_MONT) Fp<SF>::from_words(rw).mont256_to_canonical().to_words(rw);
+      uint32_t any = 0;
+      for (int i = 0; i < 8; i++) any |= rw[i];
+      if (any) {
         Affine<BF> h;
         h.x = fp_from_bytes<BF>((const uint8_t*)h_xy64);
         h.y = fp_from_bytes<BF>((const uint8_t*)h_xy64 + 32);
-        if (!(flags & NMX_BASES_MONT)) {
-          h.x = h.x.to_mont();
-          h.y = h.y.to_mont();
+        if (!h.is_identity()) {
+          const bool m = (flags & NMX_BASES_MONT) != 0;
+          h.x = (m ? h.x.mont256_to_internal() : h.x.to_internal()).canon();
+          h.y = (m ? h.y.mont256_to_internal() : h.y.to_internal()).canon();
         }
-        acc.add(scalar_mul<BF>(XYZZ<BF>::from_affine(h), rs.l));
+        acc.add(scalar_mul<BF>(XYZZ<BF>::from_affine(h), rw));
       }
       write_result<CID>(acc, flags, out, out_is_inf);
     });
@@ -645,9 +657,9 @@ int nmx_point_sum(int curve, const uint8_t* partials128, size_t count, uint8_t* 
       constexpr int BF = CurveT<CID>::BF;
       XYZZ<BF> acc = XYZZ<BF>::identity();
       for (size_t i = 0; i < count; i++) {
-        XYZZ<BF> p;
-        memcpy(&p, partials128 + 128 * i, 128);
-        acc.add(p);
+        XYZZW w;
+        memcpy(w.w, partials128 + 128 * i, 128);
+        acc.add(XYZZ<BF>::load(w));
       }
       xyzz_to_xy64<BF>(acc, out, out_is_inf);
     });

@@ -80,17 +80,14 @@ template <int SFID> struct DigitsFn {
         }
       }
     } else {
-      Fp<SFID> f;
 #pragma unroll
-      for (int j = 0; j < 8; j++) f.l[j] = scalars[8 * (size_t)i + j];
-      if (!f.lt_p()) {  // from_repr would have rejected it on the reference side
+      for (int j = 0; j < 8; j++) s[j] = scalars[8 * (size_t)i + j];
+      s[8] = 0;
+      if (!Fp<SFID>::words_lt_p(s)) {  // from_repr would have rejected it on the reference side
         nmx_atomic_or(err, ERR_SCALAR_RANGE);
         skip = true;
       }
-      if (scalars_mont) f = f.from_mont();
-#pragma unroll
-      for (int j = 0; j < 8; j++) s[j] = f.l[j];
-      s[8] = 0;
+      if (scalars_mont) Fp<SFID>::from_words(s).mont256_to_canonical().to_words(s);
     }
     if (bases) {  // identity base contributes nothing (msm.rs:247-249)
       uint32_t o = 0;
@@ -173,35 +170,34 @@ struct PlanFn {
 // 5. bucket accumulation (the dominant kernel)
 // ----------------------------------------------------------------------------------------------------
 template <int FID> struct AccumFn {
-  const Affine<FID>* bases;  // Montgomery form
+  const AffineW* bases;      // internal form, canonical, packed
   const uint32_t* vals;      // sorted
   const uint32_t* start;
   const uint32_t* end;
   const uint32_t* counters;
   const TaskRec* extra;
-  XYZZ<FID>* buckets;   // nbuckets
-  XYZZ<FID>* partials;  // extra-task results
+  XYZZW* buckets;   // nbuckets
+  XYZZW* partials;  // extra-task results
   MsmShape sh;
 
   NMX_HD XYZZ<FID> run(uint32_t b, uint32_t len) const {
     XYZZ<FID> acc = XYZZ<FID>::identity();
     for (uint32_t j = 0; j < len; j++) {
       uint32_t v = vals[b + j];
-      Affine<FID> p = bases[v & 0x7fffffffu];
-      if (v >> 31) p.y = p.y.neg();
-      acc.add_affine(p.x, p.y);
+      Affine<FID> p = Affine<FID>::load(bases[v & 0x7fffffffu]);
+      acc.add_affine(p, (v >> 31) != 0);  // identity bases never get here (trash key)
     }
     return acc;
   }
   NMX_HD void operator()(uint32_t t) const {
     if (t < sh.nbuckets) {
       uint32_t b = start[t], s = end[t] - b;
-      if (s <= sh.lmax) buckets[t] = run(b, s);  // heavy buckets are written by the folds
+      if (s <= sh.lmax) run(b, s).store(buckets[t]);  // heavy buckets are written by the folds
     } else {
       uint32_t e = t - sh.nbuckets;
       if (e >= counters[0]) return;
       TaskRec r = extra[e];
-      partials[e] = run(r.start, r.len);
+      run(r.start, r.len).store(partials[e]);
     }
   }
 };
@@ -213,8 +209,8 @@ template <int FID> struct AccumFn {
 template <int FID> struct FoldFn {
   const uint32_t* counters;
   const HeavyRec* heavy;
-  XYZZ<FID>* partials;
-  XYZZ<FID>* buckets;
+  XYZZW* partials;
+  XYZZW* buckets;
   uint32_t T;       // lanes per heavy bucket in this pass
   uint32_t cap;     // positions valid on entry = min(cnt, cap); cap = 0xffffffff for the first pass
   uint32_t groups;  // grid = groups * T lanes; groups loop over the heavy list
@@ -225,12 +221,12 @@ template <int FID> struct FoldFn {
       HeavyRec r = heavy[h];
       uint32_t cnt = r.cnt < cap ? r.cnt : cap;
       if (j >= cnt) continue;
-      XYZZ<FID> acc = partials[r.off + j];
-      for (uint32_t q = j + T; q < cnt; q += T) acc.add(partials[r.off + q]);
+      XYZZ<FID> acc = XYZZ<FID>::load(partials[r.off + j]);
+      for (uint32_t q = j + T; q < cnt; q += T) acc.add(XYZZ<FID>::load(partials[r.off + q]));
       if (T == 1)
-        buckets[r.bucket] = acc;
+        acc.store(buckets[r.bucket]);
       else
-        partials[r.off + j] = acc;
+        acc.store(partials[r.off + j]);
     }
   }
 };
@@ -242,10 +238,10 @@ template <int FID> struct FoldFn {
 //      A'_u = sum_j A_{um+j};  g_u = sum_j j*A_{um+j};  Y'_u = sum_j Y_{um+j} + 2^ls * g_u;  ls' = ls + log2 m.
 // ----------------------------------------------------------------------------------------------------
 template <int FID> struct ReduceFn {
-  const XYZZ<FID>* A;
-  const XYZZ<FID>* Y;  // == A on the first level
-  XYZZ<FID>* A_out;
-  XYZZ<FID>* Y_out;
+  const XYZZW* A;
+  const XYZZW* Y;  // == A on the first level
+  XYZZW* A_out;
+  XYZZW* Y_out;
   uint32_t n_in;   // elements per window on entry
   uint32_t m;      // segment length (divides n_in)
   uint32_t ls;     // log2 of the scale carried by G(A)
@@ -257,24 +253,24 @@ template <int FID> struct ReduceFn {
     XYZZ<FID> run = XYZZ<FID>::identity();  // running suffix sum of A
     XYZZ<FID> g = XYZZ<FID>::identity();    // sum_j j*A_j (0-based)
     for (uint32_t j = m - 1; j >= 1; j--) {
-      run.add(A[base + j]);
+      run.add(XYZZ<FID>::load(A[base + j]));
       g.add(run);
     }
     XYZZ<FID> y;
     if (first) {
       // Y == A: Sum(Y seg) + g = sum_j (j+1) A_j = g + run + A_0
-      run.add(A[base]);
+      run.add(XYZZ<FID>::load(A[base]));
       y = g;
       y.add(run);
     } else {
-      run.add(A[base]);
+      run.add(XYZZ<FID>::load(A[base]));
       for (uint32_t q = 0; q < ls; q++) g.dbl_in_place();
       y = g;
-      for (uint32_t j = 0; j < m; j++) y.add(Y[base + j]);
+      for (uint32_t j = 0; j < m; j++) y.add(XYZZ<FID>::load(Y[base + j]));
     }
     size_t o = (size_t)w * n_out + u;
-    A_out[o] = run;
-    Y_out[o] = y;
+    run.store(A_out[o]);
+    y.store(Y_out[o]);
   }
 };
 

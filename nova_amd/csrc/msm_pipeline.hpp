@@ -11,7 +11,7 @@ namespace nmx {
 
 struct MsmArgs {
   const uint32_t* scalars;  // backend-addressable: n x 8 u32 (field) or n x 2 u32 (u64 mode)
-  const void* bases;        // backend-addressable Affine<FID>[n], Montgomery form
+  const void* bases;        // backend-addressable AffineW[n]: internal form, canonical
   uint32_t n;
   uint32_t scalars_mont;
   uint32_t u64_bits;   // 0 => field scalars
@@ -53,7 +53,7 @@ static constexpr uint32_t kFoldGroups = 512;
 // Runs stages 1-7.  On return `wsum_host[0..W)` holds the per-window sums (XYZZ, Montgomery), and *err_host the
 // device error bits.  Returns the shape used.
 template <class BE, int FID, int SFID>
-MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZ<FID>* wsum_host,
+MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsum_host,
                       uint32_t* err_host) {
   const uint32_t bits = a.u64_bits ? a.u64_bits : scalar_bits;
   MsmShape sh = make_shape(a.n, bits, a.force_c);
@@ -70,8 +70,8 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZ<FID>*
   uint32_t* counters = end + sh.nbuckets + 1;  // [0] extra tasks, [1] heavy buckets, [2] error bits
   HeavyRec* heavy = be.template alloc<HeavyRec>(heavy_cap);
   TaskRec* extra = be.template alloc<TaskRec>(extra_cap);
-  XYZZ<FID>* buckets = be.template alloc<XYZZ<FID>>(sh.nbuckets);
-  XYZZ<FID>* partials = be.template alloc<XYZZ<FID>>(extra_cap);
+  XYZZW* buckets = be.template alloc<XYZZW>(sh.nbuckets);
+  XYZZW* partials = be.template alloc<XYZZW>(extra_cap);
 
   be.memset0(start, (2 * ((size_t)sh.nbuckets + 1) + 4) * sizeof(uint32_t));
 
@@ -104,7 +104,7 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZ<FID>*
   }
   be.mark("accum");
   {
-    AccumFn<FID> f{(const Affine<FID>*)a.bases, vals1, start, end, counters, extra, buckets, partials, sh};
+    AccumFn<FID> f{(const AffineW*)a.bases, vals1, start, end, counters, extra, buckets, partials, sh};
     be.launch(f, sh.nbuckets + extra_cap);
   }
   be.mark("fold");
@@ -119,8 +119,8 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZ<FID>*
     be.launch(f, kFoldGroups);
   }
   be.mark("reduce");
-  const XYZZ<FID>* A = buckets;
-  const XYZZ<FID>* Y = buckets;
+  const XYZZW* A = buckets;
+  const XYZZW* Y = buckets;
   uint32_t n_in = sh.M, ls = 0, first = 1;
   if (n_in == 1) {
     // c == 1: one bucket per window, weight 1: the bucket is the window sum
@@ -128,8 +128,8 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZ<FID>*
   while (n_in > 1) {
     uint32_t m = n_in < 16 ? n_in : 16;
     uint32_t n_out = n_in / m;
-    XYZZ<FID>* Ao = be.template alloc<XYZZ<FID>>((size_t)sh.W * n_out);
-    XYZZ<FID>* Yo = be.template alloc<XYZZ<FID>>((size_t)sh.W * n_out);
+    XYZZW* Ao = be.template alloc<XYZZW>((size_t)sh.W * n_out);
+    XYZZW* Yo = be.template alloc<XYZZW>((size_t)sh.W * n_out);
     ReduceFn<FID> f{A, Y, Ao, Yo, n_in, m, ls, first};
     be.launch(f, sh.W * n_out);
     A = Ao;
@@ -139,19 +139,19 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZ<FID>*
     first = 0;
   }
   be.mark("tail");
-  be.d2h(wsum_host, Y, sizeof(XYZZ<FID>) * sh.W);
+  be.d2h(wsum_host, Y, sizeof(XYZZW) * sh.W);
   be.d2h(err_host, counters + 2, sizeof(uint32_t));
-  be.sync();
   be.mark("end");
+  be.sync();
   return sh;
 }
 
 // Host tail: Horner over window sums, high to low (msm.rs:651-661).
-template <int FID> XYZZ<FID> combine_windows(const XYZZ<FID>* wsum, const MsmShape& sh) {
-  XYZZ<FID> acc = wsum[sh.W - 1];
+template <int FID> XYZZ<FID> combine_windows(const XYZZW* wsum, const MsmShape& sh) {
+  XYZZ<FID> acc = XYZZ<FID>::load(wsum[sh.W - 1]);
   for (int w = (int)sh.W - 2; w >= 0; w--) {
     for (uint32_t q = 0; q < sh.c; q++) acc.dbl_in_place();
-    acc.add(wsum[w]);
+    acc.add(XYZZ<FID>::load(wsum[w]));
   }
   return acc;
 }

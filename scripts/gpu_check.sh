@@ -15,6 +15,6 @@ timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -25 | tee "$OUT/pyt
 echo "== bench"
 timeout 600 python bench.py --steps 10 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err"; cat "$OUT/bench.json"; tail -5 "$OUT/bench.err"
 echo "== rocprof kernel trace"
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/$OUT/prof" -o msm -- python "$GRAFT_REPO_ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$GRAFT_REPO_ROOT/$OUT/prof_bench.json" 2> "$GRAFT_REPO_ROOT/$OUT/prof.err" )
-find "$OUT/prof" -name "*stats*" | head; f=$(find "$OUT/prof" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -20 "$f"
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$OUT/prof" -o msm -- python "$GRAFT_REPO_ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$GRAFT_REPO_ROOT/$OUT/prof_bench.json" 2> "$GRAFT_REPO_ROOT/$OUT/prof.err" )
+find "$OUT/prof" -name "*stats*" | head; f=$(find "$OUT/prof" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && column -s, -t "$f" | cut -c1-220 | head -24
 echo "== done"

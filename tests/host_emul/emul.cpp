@@ -55,10 +55,12 @@ static int emul_msm_t(const uint8_t* scalars, const uint8_t* bases_xy64, size_t 
   constexpr int BF = C::BF, SF = C::SF;
   XYZZ<BF> r = XYZZ<BF>::identity();
   if (n != 0 && !(u64_mode && u64_bits == 0)) {
-    std::vector<Affine<BF>> b(n);
+    std::vector<AffineW> b(n);
     for (size_t i = 0; i < n; i++) {
-      b[i].x = fp_from_bytes<BF>(bases_xy64 + 64 * i).to_mont();
-      b[i].y = fp_from_bytes<BF>(bases_xy64 + 64 * i + 32).to_mont();
+      Affine<BF> a;
+      a.x = fp_from_bytes<BF>(bases_xy64 + 64 * i).to_internal().canon();
+      a.y = fp_from_bytes<BF>(bases_xy64 + 64 * i + 32).to_internal().canon();
+      a.store(b[i]);
     }
     MsmArgs a;
     a.scalars = (const uint32_t*)scalars;
@@ -68,7 +70,7 @@ static int emul_msm_t(const uint8_t* scalars, const uint8_t* bases_xy64, size_t 
     a.u64_bits = u64_mode ? u64_bits : 0;
     a.force_c = force_c;
     HostEmulBackend be;
-    XYZZ<BF> wsum[260];
+    XYZZW wsum[260];
     uint32_t err = 0;
     MsmShape sh = msm_pipeline<HostEmulBackend, BF, SF>(be, a, FpParams<SF>::BITS, wsum, &err);
     if (err) return -(int)err - 100;
@@ -78,18 +80,25 @@ static int emul_msm_t(const uint8_t* scalars, const uint8_t* bases_xy64, size_t 
   return 0;
 }
 
+// inputs: 256-bit integers (any value the test wants, e.g. up to 8p); outputs canonicalised
 template <int FID> static void fp_op_t(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
-  Fp<FID> x = fp_from_bytes<FID>(a), y = fp_from_bytes<FID>(b), r;
+  using F = Fp<FID>;
+  F x = fp_from_bytes<FID>(a), y = fp_from_bytes<FID>(b), r;
   switch (op) {
-    case 0: r = x * y; break;      // Montgomery product
-    case 1: r = x + y; break;
-    case 2: r = x - y; break;
-    case 3: r = x.to_mont(); break;
-    case 4: r = x.from_mont(); break;
-    case 5: r = x.inv(); break;    // Montgomery-domain inverse
-    case 6: r = x.neg(); break;
-    case 7: r = x.sqr(); break;
-    default: r = Fp<FID>::zero();
+    case 0: r = (x * y).canon(); break;                 // x*y*2^-261
+    case 1: r = (x + y).norm().canon(); break;          // lazy add
+    case 2: r = F::sub2(x, y).norm().canon(); break;    // x - y + 2p   (y < 2p)
+    case 3: r = x.to_internal().canon(); break;         // x*2^261
+    case 4: r = x.to_canonical(); break;                // x*2^-261
+    case 5: r = x.inv().canon(); break;                 // internal-form inverse
+    case 6: r = F::sub8(x, y).norm().canon(); break;    // x - y + 8p   (y < 8p)
+    case 7: r = x.sqr().canon(); break;
+    case 8: r = x.mont256_to_internal().canon(); break; // x*2^5 (halo2 Montgomery -> internal)
+    case 9: r = x.mont256_to_canonical(); break;        // x*2^-256
+    case 10: r = F::sub4(x, y).norm().canon(); break;
+    case 11: r = x.canon(); break;
+    case 12: { r = F::zero(); r.l[0] = x.norm().maybe_zero_mod_p() ? 1u : 0u; } break;
+    default: r = F::zero();
   }
   fp_to_bytes(r, out);
 }

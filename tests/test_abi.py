@@ -72,15 +72,10 @@ def test_point_sum_is_host_side_and_matches_oracle(L):
         n = 24
         bases = cref.sequential_bases(c, 11, n)
         sc = util.random_scalars(c.cid, n)
-        Rm = 1 << 256
         parts = []
         for lo, hi in ((0, 7), (7, 7), (7, 24)):  # includes an empty shard -> identity partial
             xy, inf = cref.msm(c.cid, sc[lo:hi], bases[lo:hi], hi - lo)
-            if inf:
-                parts.append(R.fe_to_le32(Rm % c.p) * 2 + bytes(64))
-            else:
-                x, y = R.xy64_to_point(xy)
-                parts.append(b"".join(R.fe_to_le32(v * Rm % c.p) for v in (x, y, 1, 1)))
+            parts.append(util.affine_to_partial(c.p, xy, inf))
         buf = np.frombuffer(b"".join(parts), dtype=np.uint8)
         out = np.zeros(64, np.uint8)
         inf = np.zeros(1, np.uint8)

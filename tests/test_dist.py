@@ -36,12 +36,7 @@ def _worker(rank, world, port, n, cid, q):
     sc = util.random_scalars(cid, n, seed=3)
     lo, hi = shard_range(n, rank, world)
     xy, inf = cref.msm(cid, sc[lo:hi], bases[lo:hi], hi - lo)
-    Rm = 1 << 256
-    if inf:
-        part = R.fe_to_le32(Rm % c.p) * 2 + bytes(64)
-    else:
-        x, y = R.xy64_to_point(xy)
-        part = b"".join(R.fe_to_le32(v * Rm % c.p) for v in (x, y, 1, 1))
+    part = util.affine_to_partial(c.p, xy, inf)
     got = combine_partials(DlogGroup(cid), part)
     exp = cref.msm(cid, sc, bases, n)
     q.put((rank, (got.xy, int(got.is_inf)) == exp))

@@ -25,7 +25,7 @@ CSRC = os.path.join(os.path.dirname(HERE), "nova_amd", "csrc")
 def emul():
     deps = [SRC] + [os.path.join(CSRC, f) for f in ("fp.hpp", "curve.hpp", "curves.hpp", "msm_kernels.hpp", "msm_pipeline.hpp")]
     if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(d) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", SO, SRC])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-DNMX_DEBUG_BOUNDS", "-shared", "-fPIC", "-o", SO, SRC])
     L = ctypes.CDLL(SO)
     L.emul_msm.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32,
                            ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
@@ -47,10 +47,44 @@ FIELDS = [R.BN254_Q, R.BN254_R, R.PALLAS_P, R.PALLAS_Q]
 
 
 @pytest.mark.parametrize("fid", range(4))
-def test_field_ops(emul, fid):
-    """fp.hpp (8 x 32-bit Montgomery) against big-int arithmetic, incl. boundary values."""
+def test_field_constants(fid):
+    """Every generated constant in fp.hpp (9 x 29-bit limbs) re-derived from the modulus."""
+    import re
     p = FIELDS[fid]
-    Rm = 1 << 256
+    src = open(os.path.join(CSRC, "fp.hpp")).read()
+    name = ["F_BN254_FQ", "F_BN254_FR", "F_PASTA_FP", "F_PASTA_FQ"][fid]
+    blk = src[src.index(f"struct FpParams<{name}>"):]
+    blk = blk[:blk.index("\n};") + 3]
+
+    def arr(nm):
+        m = re.search(r"uint32_t %s\[\d\] = \{([^}]*)\}" % nm, blk)
+        return [int(x.strip().rstrip("u"), 16) for x in m.group(1).split(",")]
+
+    def val29(l):
+        return sum(v << (29 * i) for i, v in enumerate(l))
+
+    assert val29(arr("P")) == p and all(v < 1 << 29 for v in arr("P")[:8])
+    assert sum(v << (32 * i) for i, v in enumerate(arr("PW"))) == p
+    assert val29(arr("ONE")) == (1 << 261) % p
+    assert val29(arr("R2")) == (1 << 522) % p
+    assert val29(arr("C266")) == (1 << 266) % p
+    ninv = int(re.search(r"NINV = (0x[0-9a-f]+)u", blk).group(1), 16)
+    assert (ninv * p + 1) % (1 << 29) == 0
+    for k, nm in ((2, "K2P"), (4, "K4P"), (8, "K8P")):
+        K = arr(nm)
+        assert val29(K) == k * p
+        assert all(v >= (1 << 29) - 1 for v in K[:8])          # dominates every normalized limb
+        assert K[8] >= ((k * p - (1 << 233)) >> 232)             # and the top limb of anything < kp - 2^233
+        assert all(v + (1 << 30) < 1 << 32 for v in K)           # a + K - b cannot wrap
+    assert (1 << 261) // p >= 127
+
+
+@pytest.mark.parametrize("fid", range(4))
+def test_field_ops(emul, fid):
+    """fp.hpp (9 x 29-bit limbs, R' = 2^261, lazy reduction) against big-int arithmetic, incl. operands at the
+    edges of the stated bounds (multiples of p up to 8p - 1, all-ones limbs)."""
+    p = FIELDS[fid]
+    Rm = 1 << 261
     Ri = pow(Rm, -1, p)
     rng = np.random.Generator(np.random.PCG64(fid))
 
@@ -59,19 +93,38 @@ def test_field_ops(emul, fid):
         emul.emul_fp_op(fid, o, a.to_bytes(32, "little"), b.to_bytes(32, "little"), out)
         return int.from_bytes(out.raw, "little")
 
-    vals = [0, 1, 2, p - 1, p - 2, (1 << 253) - 1, Rm % p] + [int.from_bytes(rng.bytes(32), "little") % p for _ in range(40)]
-    for a in vals:
-        for b in vals[:12]:
-            assert op(0, a, b) == a * b * Ri % p
-            assert op(1, a, b) == (a + b) % p
-            assert op(2, a, b) == (a - b) % p
-        assert op(3, a) == a * Rm % p
+    rnd = [int.from_bytes(rng.bytes(32), "little") % p for _ in range(30)]
+    edge = [0, 1, 2, p - 1, p - 2, (1 << 253) - 1, Rm % p, (1 << 232) - 1, ((1 << 29) - 1) * sum(1 << (29 * i) for i in range(8))]
+    wide = [p, p + 1, 2 * p - 1, 2 * p, 3 * p + 5, 4 * p - 1]  # weakly reduced operands (still < 2^256)
+    wide = [v for v in wide if v < 1 << 256]
+    for a in edge + rnd:
+        for b in edge + rnd[:6] + wide:
+            if (a // p + 1) * (b // p + 1) < 127:
+                assert op(0, a, b) == a * b * Ri % p
+            assert op(1, a, b % (1 << 255)) == (a + b % (1 << 255)) % p
+            if b < 2 * p - (1 << 233):
+                assert op(2, a, b) == (a - b) % p
+            if b < 4 * p - (1 << 233):
+                assert op(10, a, b) == (a - b) % p
+            assert op(6, a, b) == (a - b) % p          # 8p spread covers everything < 2^256 ... < 8p - 2^233
+        assert op(3, a % p) == a * Rm % p
         assert op(4, a) == a * Ri % p
-        assert op(6, a) == (-a) % p
         assert op(7, a) == a * a * Ri % p
-    for a in vals[1:8]:
+        assert op(8, a % p) == (a % p) * 32 % p
+        assert op(9, a % p) == (a % p) * pow(1 << 256, -1, p) % p
+        assert op(11, a) == a % p
+    for a in wide + [5 * p + 7, 7 * p + 123] if 8 * p < 1 << 256 else wide:
+        if a < 1 << 256:
+            assert op(11, a) == a % p
+            assert op(7, a) == a * a * Ri % p
+    for a in rnd[:6] + [1, p - 1]:
         assert op(5, a * Rm % p) == pow(a, -1, p) * Rm % p
     assert op(5, 0) == 0
+    # the cheap divisibility filter never misses a true multiple of p
+    for k in range(0, 4):
+        if k * p < 1 << 256:
+            assert op(12, k * p) == 1
+    assert sum(op(12, v) for v in rnd) == 0  # 2^-29 false-positive rate: none expected on 30 samples
 
 
 @pytest.mark.parametrize("c", list(R.CURVES.values()), ids=lambda c: c.name)

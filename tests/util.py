@@ -101,3 +101,17 @@ def scalar_set(cid, n, kind, seed=SEED):
     if kind.startswith("u"):
         return u64_to_le32(small_scalars(n, int(kind[1:]), seed))
     raise ValueError(kind)
+
+
+R_INTERNAL = 1 << 261  # Montgomery radix of the library's internal residue form (nova_amd/csrc/fp.hpp)
+
+
+def affine_to_partial(p_mod, xy64, is_inf):
+    """Canonical affine bytes -> the 128-byte partial format of NMX_OUT_PARTIAL / nmx_point_sum:
+    (X, Y, ZZ, ZZZ) = (x, y, 1, 1) * 2^261 mod p, each a 32-byte LE integer; identity <=> ZZ == 0."""
+    one = R_INTERNAL % p_mod
+    if is_inf:
+        return one.to_bytes(32, "little") * 2 + bytes(64)
+    x = int.from_bytes(xy64[:32], "little")
+    y = int.from_bytes(xy64[32:64], "little")
+    return b"".join((v * R_INTERNAL % p_mod).to_bytes(32, "little") for v in (x, y, 1, 1))
