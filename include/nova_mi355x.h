@@ -36,6 +36,9 @@ enum {
   NMX_BASES_MONT = 1u << 1,     /* base coordinates are raw Montgomery limbs instead of canonical LE     */
   NMX_SCALARS_DEVICE = 1u << 2, /* `scalars` is a device (HBM) pointer on the library's device           */
   NMX_BASES_DEVICE = 1u << 3,   /* `bases` is a device pointer (nmx_bases_register only)                 */
+  NMX_BASES_PRECOMPUTE = 1u << 5, /* nmx_bases_register / nmx_bases_generate: also build the window tables          */
+                                /* 2^(c*w) * P_i in HBM (W x the key size; c = 16, W = 16 for keys >= 2^20).    */
+                                /* MSMs over >= 4096 points of such a key run all windows into one bucket set. */
   NMX_OUT_PARTIAL = 1u << 4     /* write a 128-byte partial sum instead of an affine point: the per-GPU   */
                                 /* result of a sharded MSM, input of nmx_point_sum.  Format: extended     */
                                 /* Jacobian (X, Y, ZZ, ZZZ), x = X/ZZ, y = Y/ZZZ, each coordinate the     */
@@ -77,7 +80,7 @@ int nmx_bases_read(uint64_t handle, size_t offset, size_t n, void* out_xy64);
 /* Synthetic key: P_i = (k0 + i) * G for i in [0, n), generated in HBM (the construction of
  * src/provider/curve_property_tests.rs:186-194; plays the role of the test-utils `setup`,
  * src/provider/hyperkzg.rs:357-376, whose real keys come from the host). */
-int nmx_bases_generate(int curve, uint64_t k0, size_t n, uint64_t* handle);
+int nmx_bases_generate(int curve, uint64_t k0, size_t n, uint32_t flags, uint64_t* handle);
 
 /* ---- MSM ---------------------------------------------------------------------------------------------
  * DlogGroupExt::vartime_multiscalar_mul (src/provider/traits.rs:79; impls src/provider/bn256_grumpkin.rs:45-47,

@@ -1,0 +1,375 @@
+// capi.hip -- the C ABI of include/nova_mi355x.h: global state, context pool, key registry, dispatch to the
+// per-curve operation tables (curve_*.hip).  No group arithmetic and no CPU fallback in this file.
+#include "runtime.hpp"
+
+namespace nmx {
+
+Global G;
+static thread_local std::string t_err;
+static thread_local float t_prof[kMaxMarks];
+static thread_local int t_prof_n = 0;
+
+void prof_store(const float* ms, int n) {
+  t_prof_n = n < kMaxMarks ? n : kMaxMarks;
+  for (int i = 0; i < t_prof_n; i++) t_prof[i] = ms[i];
+}
+void prof_add_tail(float ms) {
+  if (t_prof_n > 0) t_prof[t_prof_n - 1] += ms;
+}
+
+void arena_reserve(Ctx& c, size_t bytes) {
+  if (bytes <= c.cap) return;
+  if (c.arena) HIPCHK(hipFree(c.arena));
+  c.arena = nullptr;
+  c.cap = 0;
+  size_t want = bytes + bytes / 8 + (1u << 20);
+  HIPCHK(hipMalloc((void**)&c.arena, want));
+  c.cap = want;
+}
+
+static void ensure_init() {
+  std::lock_guard<std::mutex> lk(G.mu);
+  if (G.inited) return;
+  int cnt = 0;
+  hipError_t e = hipGetDeviceCount(&cnt);
+  if (e != hipSuccess || cnt <= 0)
+    throw Fail{NMX_E_NO_DEVICE, "no HIP device visible (libnova_mi355x has no CPU fallback)"};
+  int dev = G.device;
+  if (dev < 0) {
+    const char* lr = getenv("LOCAL_RANK");
+    dev = lr ? atoi(lr) % cnt : 0;
+  }
+  if (dev >= cnt) throw Fail{NMX_E_ARG, "device index out of range"};
+  G.device = dev;
+  HIPCHK(hipSetDevice(dev));
+  G.inited = true;
+}
+
+// One context per in-flight call: concurrent callers (rayon workers on the reference side) never share a stream
+// or a workspace, so a small MSM does not queue behind a 2^20 one.
+struct CtxLease {
+  Ctx* c;
+  CtxLease() {
+    ensure_init();
+    HIPCHK(hipSetDevice(G.device));
+    {
+      std::lock_guard<std::mutex> lk(G.mu);
+      if (!G.free_ctx.empty()) {
+        c = G.free_ctx.back();
+        G.free_ctx.pop_back();
+        return;
+      }
+    }
+    c = new Ctx();
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    std::lock_guard<std::mutex> lk(G.mu);
+    G.all_ctx.push_back(c);
+  }
+  ~CtxLease() {
+    std::lock_guard<std::mutex> lk(G.mu);
+    G.free_ctx.push_back(c);
+  }
+};
+
+static const CurveOps& ops(int curve) {
+  switch (curve) {
+    case NMX_BN254_G1: return curve_ops_bn254_g1();
+    case NMX_GRUMPKIN: return curve_ops_grumpkin();
+    case NMX_PALLAS: return curve_ops_pallas();
+    case NMX_VESTA: return curve_ops_vesta();
+  }
+  throw Fail{NMX_E_ARG, "bad curve id"};
+}
+
+static BaseSet lookup(uint64_t h) {
+  std::lock_guard<std::mutex> lk(G.mu);
+  auto it = G.bases.find(h);
+  if (it == G.bases.end()) throw Fail{NMX_E_HANDLE, "unknown base handle"};
+  return it->second;
+}
+static uint64_t publish(const BaseSet& bs) {
+  std::lock_guard<std::mutex> lk(G.mu);
+  uint64_t h = G.next_handle++;
+  G.bases[h] = bs;
+  return h;
+}
+
+struct OrFn {  // OR of all u64 scalars -> bit length of the maximum
+  const uint32_t* s;
+  uint32_t* out;
+  NMX_HD void operator()(uint32_t i) const {
+    if (s[2 * (size_t)i]) nmx_atomic_or(out, s[2 * (size_t)i]);
+    if (s[2 * (size_t)i + 1]) nmx_atomic_or(out + 1, s[2 * (size_t)i + 1]);
+  }
+};
+static uint32_t resolve_u64_bits(Ctx& c, const uint64_t* s, size_t n, bool dev, uint32_t max_bits) {
+  if (max_bits != NMX_BITS_AUTO) {
+    require(max_bits <= 64, NMX_E_ARG, "max_num_bits must be <= 64");
+    return max_bits;
+  }
+  if (n == 0) return 0;
+  uint64_t orv = 0;
+  if (!dev) {
+    for (size_t i = 0; i < n; i++) orv |= s[i];
+  } else {
+    arena_reserve(c, 256);
+    HIPCHK(hipMemsetAsync(c.arena, 0, 8, c.stream));
+    DeviceBackend be(c, false, false);
+    OrFn f{(const uint32_t*)s, (uint32_t*)c.arena};
+    be.launch(f, (uint32_t)n);
+    HIPCHK(hipMemcpyAsync(&orv, c.arena, 8, hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+  }
+  uint32_t b = 0;
+  while (orv) {
+    b++;
+    orv >>= 1;
+  }
+  return b;  // num_bits(max) as msm.rs:456-462,473
+}
+
+template <class Fn> static int guarded(Fn&& fn) {
+  try {
+    fn();
+    return NMX_OK;
+  } catch (const Fail& f) {
+    t_err = f.msg;
+    return f.code;
+  } catch (const std::exception& e) {
+    t_err = e.what();
+    return NMX_E_HIP;
+  }
+}
+
+struct TempBases {  // RAII for one-shot uploads
+  void* d = nullptr;
+  ~TempBases() {
+    if (d) (void)hipFree(d);
+  }
+};
+
+static MsmCall field_call(const void* scalars, uint32_t flags) {
+  return MsmCall{scalars, (flags & NMX_SCALARS_DEVICE) != 0, (flags & NMX_SCALARS_MONT) != 0, 0, false};
+}
+
+}  // namespace nmx
+
+using namespace nmx;
+
+extern "C" {
+
+int nmx_init(int device) {
+  return guarded([&] {
+    {
+      std::lock_guard<std::mutex> lk(G.mu);
+      if (!G.inited) G.device = device;
+    }
+    ensure_init();
+  });
+}
+
+int nmx_shutdown(void) {
+  return guarded([&] {
+    std::lock_guard<std::mutex> lk(G.mu);
+    if (!G.inited) return;
+    (void)hipSetDevice(G.device);
+    for (auto& kv : G.bases)
+      if (kv.second.d) (void)hipFree(kv.second.d);
+    G.bases.clear();
+    for (Ctx* c : G.all_ctx) {
+      if (c->arena) (void)hipFree(c->arena);
+      if (c->have_ev)
+        for (int i = 0; i < kMaxMarks; i++) (void)hipEventDestroy(c->ev[i]);
+      if (c->stream) (void)hipStreamDestroy(c->stream);
+      delete c;
+    }
+    G.all_ctx.clear();
+    G.free_ctx.clear();
+    G.inited = false;
+  });
+}
+
+int nmx_device_count(void) {
+  int cnt = 0;
+  if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
+  return cnt;
+}
+
+const char* nmx_last_error(void) { return t_err.c_str(); }
+const char* nmx_version(void) { return "nova-mi355x 0.1.0 (gfx950)"; }
+
+int nmx_bases_register(int curve, const void* bases, size_t n, uint32_t flags, uint64_t* handle) {
+  return guarded([&] {
+    require(handle && (bases || n == 0), NMX_E_ARG, "null argument");
+    const CurveOps& o = ops(curve);
+    CtxLease L;
+    BaseSet bs{curve, n, nullptr, 0, 0};
+    bs.d = o.upload(*L.c, bases, n, flags, &bs.pre_c, &bs.pre_W);
+    *handle = publish(bs);
+  });
+}
+
+int nmx_bases_unregister(uint64_t handle) {
+  return guarded([&] {
+    ensure_init();
+    BaseSet bs;
+    {
+      std::lock_guard<std::mutex> lk(G.mu);
+      auto it = G.bases.find(handle);
+      if (it == G.bases.end()) throw Fail{NMX_E_HANDLE, "unknown base handle"};
+      bs = it->second;
+      G.bases.erase(it);
+    }
+    HIPCHK(hipSetDevice(G.device));
+    if (bs.d) HIPCHK(hipFree(bs.d));
+  });
+}
+
+int nmx_bases_read(uint64_t handle, size_t offset, size_t n, void* out_xy64) {
+  return guarded([&] {
+    require(out_xy64 || n == 0, NMX_E_ARG, "null argument");
+    auto bs = lookup(handle);
+    require(offset + n <= bs.n, NMX_E_HANDLE, "offset + n beyond the registered key");
+    CtxLease L;
+    HIPCHK(hipMemcpyAsync(out_xy64, (const char*)bs.d + offset * 64, n * 64, hipMemcpyDeviceToHost,
+                          L.c->stream));
+    HIPCHK(hipStreamSynchronize(L.c->stream));
+    ops(bs.curve).internal_to_canonical((uint8_t*)out_xy64, 2 * n);
+  });
+}
+
+int nmx_bases_generate(int curve, uint64_t k0, size_t n, uint32_t flags, uint64_t* handle) {
+  return guarded([&] {
+    require(handle != nullptr, NMX_E_ARG, "null argument");
+    require(n < (1ull << 31) && k0 < (1ull << 62), NMX_E_ARG, "k0 / n out of range");
+    const CurveOps& o = ops(curve);
+    CtxLease L;
+    BaseSet bs{curve, n, nullptr, 0, 0};
+    bs.d = o.generate(*L.c, k0, n, flags, &bs.pre_c, &bs.pre_W);
+    *handle = publish(bs);
+  });
+}
+
+int nmx_msm_handle(uint64_t handle, size_t offset, const void* scalars, size_t n, uint32_t flags,
+                   uint8_t* out, uint8_t* out_is_inf) {
+  return guarded([&] {
+    require(out && (scalars || n == 0), NMX_E_ARG, "null argument");
+    auto bs = lookup(handle);
+    require(offset + n <= bs.n, NMX_E_HANDLE, "offset + n beyond the registered key");
+    CtxLease L;
+    ops(bs.curve).msm_key(*L.c, bs, offset, n, field_call(scalars, flags), flags, out, out_is_inf);
+  });
+}
+
+int nmx_msm(int curve, const void* scalars, const void* bases, size_t n, uint32_t flags, uint8_t* out,
+            uint8_t* out_is_inf) {
+  return guarded([&] {
+    require(out && ((scalars && bases) || n == 0), NMX_E_ARG, "null argument");
+    const CurveOps& o = ops(curve);
+    CtxLease L;
+    TempBases tb;
+    uint32_t pc, pw;
+    tb.d = o.upload(*L.c, bases, n, flags & ~(uint32_t)NMX_BASES_PRECOMPUTE, &pc, &pw);
+    o.msm_plain(*L.c, tb.d, n, field_call(scalars, flags), flags, out, out_is_inf);
+  });
+}
+
+int nmx_msm_u64_handle(uint64_t handle, size_t offset, const uint64_t* scalars, size_t n,
+                       uint32_t max_num_bits, uint32_t flags, uint8_t* out, uint8_t* out_is_inf) {
+  return guarded([&] {
+    require(out && (scalars || n == 0), NMX_E_ARG, "null argument");
+    auto bs = lookup(handle);
+    require(offset + n <= bs.n, NMX_E_HANDLE, "offset + n beyond the registered key");
+    CtxLease L;
+    bool dev = (flags & NMX_SCALARS_DEVICE) != 0;
+    uint32_t bits = resolve_u64_bits(*L.c, scalars, n, dev, max_num_bits);
+    MsmCall mc{scalars, dev, false, bits, true};
+    ops(bs.curve).msm_key(*L.c, bs, offset, n, mc, flags, out, out_is_inf);
+  });
+}
+
+int nmx_msm_u64(int curve, const uint64_t* scalars, const void* bases, size_t n, uint32_t max_num_bits,
+                uint32_t flags, uint8_t* out, uint8_t* out_is_inf) {
+  return guarded([&] {
+    require(out && ((scalars && bases) || n == 0), NMX_E_ARG, "null argument");
+    const CurveOps& o = ops(curve);
+    CtxLease L;
+    TempBases tb;
+    bool dev = (flags & NMX_SCALARS_DEVICE) != 0;
+    uint32_t bits = resolve_u64_bits(*L.c, scalars, n, dev, max_num_bits);
+    MsmCall mc{scalars, dev, false, bits, true};
+    uint32_t pc, pw;
+    tb.d = o.upload(*L.c, bases, n, flags & ~(uint32_t)NMX_BASES_PRECOMPUTE, &pc, &pw);
+    o.msm_plain(*L.c, tb.d, n, mc, flags, out, out_is_inf);
+  });
+}
+
+static void batch_impl(const BaseSet& bs, const void* const* vecs, const size_t* lens, size_t k, uint32_t flags,
+                       uint8_t* out, uint8_t* out_is_inf, Ctx& c) {
+  require((vecs && lens && out) || k == 0, NMX_E_ARG, "null argument");
+  require(!(flags & NMX_OUT_PARTIAL), NMX_E_ARG, "NMX_OUT_PARTIAL is not supported for batches");
+  const CurveOps& o = ops(bs.curve);
+  for (size_t j = 0; j < k; j++) {
+    require(lens[j] <= bs.n, NMX_E_ARG, "vector longer than the base array");  // traits.rs:88 slices bases[..len]
+    require(vecs[j] || lens[j] == 0, NMX_E_ARG, "null scalar vector");
+    o.msm_key(c, bs, 0, lens[j], field_call(vecs[j], flags), flags, out + 64 * j,
+              out_is_inf ? out_is_inf + j : nullptr);
+  }
+}
+
+int nmx_msm_batch_handle(uint64_t handle, const void* const* scalar_vecs, const size_t* lens, size_t k,
+                         uint32_t flags, uint8_t* out, uint8_t* out_is_inf) {
+  return guarded([&] {
+    auto bs = lookup(handle);
+    CtxLease L;
+    batch_impl(bs, scalar_vecs, lens, k, flags, out, out_is_inf, *L.c);
+  });
+}
+
+int nmx_msm_batch(int curve, const void* const* scalar_vecs, const size_t* lens, size_t k,
+                  const void* bases, size_t n_bases, uint32_t flags, uint8_t* out, uint8_t* out_is_inf) {
+  return guarded([&] {
+    require(bases || n_bases == 0, NMX_E_ARG, "null argument");
+    const CurveOps& o = ops(curve);
+    CtxLease L;
+    TempBases tb;
+    uint32_t pc, pw;
+    tb.d = o.upload(*L.c, bases, n_bases, flags & ~(uint32_t)NMX_BASES_PRECOMPUTE, &pc, &pw);
+    batch_impl(BaseSet{curve, n_bases, tb.d, 0, 0}, scalar_vecs, lens, k, flags, out, out_is_inf, *L.c);
+  });
+}
+
+int nmx_commit(uint64_t ck_handle, const void* v, size_t n, const void* h_xy64, const void* r,
+               uint32_t flags, uint8_t* out, uint8_t* out_is_inf) {
+  return guarded([&] {
+    require(out && (v || n == 0) && h_xy64 && r, NMX_E_ARG, "null argument");
+    auto bs = lookup(ck_handle);
+    require(n <= bs.n, NMX_E_HANDLE, "ck shorter than v");  // assert!(ck.ck.len() >= v.len()), pedersen.rs:264
+    CtxLease L;
+    ops(bs.curve).commit(*L.c, bs, n, field_call(v, flags), h_xy64, r, flags, out, out_is_inf);
+  });
+}
+
+int nmx_point_sum(int curve, const uint8_t* partials128, size_t count, uint8_t* out, uint8_t* out_is_inf) {
+  return guarded([&] {
+    require(out && (partials128 || count == 0), NMX_E_ARG, "null argument");
+    ops(curve).point_sum(partials128, count, out, out_is_inf);
+  });
+}
+
+int nmx_set_profiling(int on) {
+  G.profiling = on != 0;
+  return NMX_OK;
+}
+int nmx_profile_last(float* ms, int cap) {
+  int n = t_prof_n < cap ? t_prof_n : cap;
+  for (int i = 0; i < n; i++) ms[i] = t_prof[i];
+  return t_prof_n;
+}
+int nmx_set_window_bits(uint32_t c) {
+  if (c > 24) return NMX_E_ARG;
+  G.force_c = c;
+  return NMX_OK;
+}
+
+}  // extern "C"

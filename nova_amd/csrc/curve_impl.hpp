@@ -1,0 +1,272 @@
+// curve_impl.hpp -- everything that is instantiated per curve; included by the four curve_*.hip TUs only.
+//
+// Replaces, behind the reference's DlogGroupExt / CommitmentEngineTrait seam:
+//   /root/reference/src/provider/msm.rs:225-419,469-503  (msm, msm_small, msm_small_with_max_num_bits)
+//   halo2curves::msm::msm_best (called at msm.rs:411,500)
+//   /root/reference/src/provider/pedersen.rs:263-270, hyperkzg.rs:584-591 (commit = msm + h*r)
+#pragma once
+#include "runtime.hpp"
+
+namespace nmx {
+
+// ---------------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------------
+template <int FID> struct ToInternalFn {  // ABI form -> internal form (canonical residue), in place, one element per lane
+  uint32_t* v;         // 8 words per element
+  uint32_t from_mont;  // 1: input is halo2curves Montgomery (x * 2^256); 0: canonical integer
+  NMX_HD void operator()(uint32_t i) const {
+    uint32_t* w = v + 8 * (size_t)i;
+    Fp<FID> f = Fp<FID>::from_words(w);
+    f = from_mont ? f.mont256_to_internal() : f.to_internal();
+    f.canon().to_words(w);  // 0 -> 0: the identity encoding (0, 0) is preserved
+  }
+};
+template <int CID> struct GenFn {  // P_i = (k0 + i) * G
+  using C = CurveT<CID>;
+  AffineW* out;
+  uint64_t k0;
+  NMX_HD void operator()(uint32_t i) const {
+    uint32_t wx[8], wy[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      wx[j] = C::GX[j];
+      wy[j] = C::GY[j];
+    }
+    Fp<C::BF> gx = Fp<C::BF>::from_words(wx).to_internal().canon();
+    Fp<C::BF> gy = Fp<C::BF>::from_words(wy).to_internal().canon();
+    uint64_t k = k0 + i;
+    XYZZ<C::BF> acc = XYZZ<C::BF>::identity();
+    for (int b = 63; b >= 0; b--) {
+      acc.dbl_in_place();
+      if ((k >> b) & 1u) acc.add_affine(gx, gy);
+    }
+    acc.to_affine().store(out[i]);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// one MSM on the device
+// ---------------------------------------------------------------------------------------------------
+template <int CID>
+static XYZZ<CurveT<CID>::BF> run_msm(Ctx& c, const void* d_bases, size_t n, const MsmCall& mc) {
+  using C = CurveT<CID>;
+  constexpr int BF = C::BF, SF = C::SF;
+  XYZZ<BF> ident = XYZZ<BF>::identity();
+  if (n == 0) return ident;                       // msm.rs:228
+  if (mc.u64_mode && mc.u64_bits == 0) return ident;  // msm.rs:489
+  const uint32_t sbits = FpParams<SF>::BITS;
+  const size_t sbytes = mc.u64_mode ? 8 : 32;
+
+  MsmArgs a;
+  a.bases = d_bases;
+  a.n = (uint32_t)n;
+  a.scalars_mont = mc.scalars_mont ? 1u : 0u;
+  a.u64_bits = mc.u64_mode ? mc.u64_bits : 0u;
+  a.force_c = G.force_c;
+  a.pre_stride = mc.pre_stride;
+  a.pre_offset = mc.pre_offset;
+  a.pre_c = mc.pre_c;
+  {
+    uint32_t bits = a.u64_bits ? a.u64_bits : sbits;
+    MsmShape sh = make_shape(a.n, bits, a.force_c, a.pre_stride ? a.pre_c : 0);
+    require((uint64_t)n * sh.W < 0xffffffffull && n < 0x7fffffffull, NMX_E_TOO_LARGE,
+            "n * windows must be < 2^32");
+  }
+  XYZZW wsum[260];
+  uint32_t err = 0;
+  MsmShape sh{};
+  const bool prof = G.profiling;
+  for (int pass = 0; pass < 2; pass++) {
+    DeviceBackend be(c, pass == 0, prof);
+    if (mc.scalars_device) {
+      a.scalars = (const uint32_t*)mc.scalars;
+    } else {
+      uint32_t* d_s = be.alloc<uint32_t>(n * sbytes / 4);
+      a.scalars = d_s;
+      if (pass == 1)
+        HIPCHK(hipMemcpyAsync(d_s, mc.scalars, n * sbytes, hipMemcpyHostToDevice, c.stream));
+    }
+    sh = msm_pipeline<DeviceBackend, BF, SF>(be, a, sbits, wsum, &err);
+    if (pass == 0) {
+      arena_reserve(c, be.used);
+    } else if (prof) {
+      float st[kMaxMarks];
+      int ns = 0;
+      for (int i = 0; i + 1 < be.nmarks; i++) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, c.ev[i], c.ev[i + 1]));
+        st[ns++] = ms;
+      }
+      prof_store(st, ns);
+    }
+  }
+  require(!(err & ERR_SCALAR_RANGE), NMX_E_SCALAR_RANGE, "scalar >= field modulus");
+  require(!(err & ERR_SMALL_RANGE), NMX_E_SMALL_RANGE, "small scalar >= 2^max_num_bits");
+  auto t0 = std::chrono::steady_clock::now();
+  XYZZ<BF> r = combine_windows<BF>(wsum, sh);
+  if (prof) {
+    auto t1 = std::chrono::steady_clock::now();
+    prof_add_tail(std::chrono::duration<float, std::milli>(t1 - t0).count());
+  }
+  return r;
+}
+
+template <int CID> static void write_result(const XYZZ<CurveT<CID>::BF>& r, uint32_t flags, uint8_t* out,
+                                            uint8_t* is_inf) {
+  if (flags & NMX_OUT_PARTIAL) {
+    XYZZW w;
+    r.store(w);
+    memcpy(out, w.w, 128);
+    if (is_inf) *is_inf = r.is_identity() ? 1 : 0;
+  } else {
+    xyzz_to_xy64<CurveT<CID>::BF>(r, out, is_inf);
+  }
+}
+
+// upload (or adopt) a base array, returning a Montgomery-form device copy owned by the caller
+// number of tables / window width for a key of n points (0 tables = no precomputation)
+template <int CID> static void table_shape(size_t n, uint32_t flags, uint32_t* pre_c, uint32_t* pre_W) {
+  *pre_c = 0;
+  *pre_W = 0;
+  if (!(flags & NMX_BASES_PRECOMPUTE) || n < kPrecompMinN) return;
+  uint32_t c = G.force_c ? G.force_c : choose_c_precomp((uint32_t)n);
+  uint32_t W = (FpParams<CurveT<CID>::SF>::BITS + 1 + c - 1) / c;
+  if ((uint64_t)W * n >= (1ull << 31)) return;  // table index must fit 31 bits
+  *pre_c = c;
+  *pre_W = W;
+}
+template <int CID> static void build_tables(Ctx& c, void* d, size_t n, uint32_t pre_c, uint32_t pre_W) {
+  if (!pre_W) return;
+  DeviceBackend be(c, false, false);
+  PrecompFn<CurveT<CID>::BF> f{(AffineW*)d, (uint32_t)n, pre_c, pre_W};
+  be.launch(f, (uint32_t)n);
+}
+
+template <int CID>
+static void* upload_bases(Ctx& c, const void* src, size_t n, uint32_t flags, uint32_t* pre_c, uint32_t* pre_W) {
+  constexpr int BF = CurveT<CID>::BF;
+  void* d = nullptr;
+  table_shape<CID>(n, flags, pre_c, pre_W);
+  if (n == 0) return nullptr;
+  HIPCHK(hipMalloc(&d, n * 64 * (*pre_W ? *pre_W : 1)));
+  try {
+    HIPCHK(hipMemcpyAsync(d, src, n * 64,
+                          (flags & NMX_BASES_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                          c.stream));
+    {
+      DeviceBackend be(c, false, false);
+      ToInternalFn<BF> f{(uint32_t*)d, (flags & NMX_BASES_MONT) ? 1u : 0u};
+      be.launch(f, (uint32_t)(2 * n));
+    }
+    build_tables<CID>(c, d, n, *pre_c, *pre_W);
+    HIPCHK(hipStreamSynchronize(c.stream));
+  } catch (...) {
+    (void)hipFree(d);
+    throw;
+  }
+  return d;
+}
+
+template <int CID>
+static void msm_entry(const void* d_bases, size_t n, const MsmCall& mc, uint32_t flags, uint8_t* out,
+                      uint8_t* is_inf, Ctx& c) {
+  auto r = run_msm<CID>(c, d_bases, n, mc);
+  write_result<CID>(r, flags, out, is_inf);
+}
+// MSM over bs[offset, offset + n): through the key's window tables when it has them and n is large enough
+template <int CID>
+static XYZZ<CurveT<CID>::BF> run_msm_key(Ctx& c, const BaseSet& bs, size_t offset, size_t n, MsmCall mc) {
+  if (bs.pre_W && n >= kPrecompMinN && (G.force_c == 0 || G.force_c == bs.pre_c)) {
+    mc.pre_stride = (uint32_t)bs.n;
+    mc.pre_offset = (uint32_t)offset;
+    mc.pre_c = bs.pre_c;
+    return run_msm<CID>(c, bs.d, n, mc);
+  }
+  return run_msm<CID>(c, (const char*)bs.d + offset * 64, n, mc);
+}
+template <int CID>
+static void msm_key_entry(const BaseSet& bs, size_t offset, size_t n, const MsmCall& mc, uint32_t flags,
+                          uint8_t* out, uint8_t* is_inf, Ctx& c) {
+  auto r = run_msm_key<CID>(c, bs, offset, n, mc);
+  write_result<CID>(r, flags, out, is_inf);
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// type-erased table
+// ---------------------------------------------------------------------------------------------------
+template <int CID> struct CurveImpl {
+  using C = CurveT<CID>;
+  static constexpr int BF = C::BF, SF = C::SF;
+
+  static void msm_plain(Ctx& c, const void* d_bases, size_t n, const MsmCall& mc, uint32_t flags, uint8_t* out,
+                        uint8_t* inf) {
+    msm_entry<CID>(d_bases, n, mc, flags, out, inf, c);
+  }
+  static void msm_key(Ctx& c, const BaseSet& bs, size_t offset, size_t n, const MsmCall& mc, uint32_t flags,
+                      uint8_t* out, uint8_t* inf) {
+    msm_key_entry<CID>(bs, offset, n, mc, flags, out, inf, c);
+  }
+  static void commit(Ctx& c, const BaseSet& bs, size_t n, const MsmCall& mc, const void* h_xy64, const void* r,
+                     uint32_t flags, uint8_t* out, uint8_t* inf) {
+    auto acc = run_msm_key<CID>(c, bs, 0, n, mc);
+    uint32_t rw[8];
+    memcpy(rw, r, 32);
+    require(Fp<SF>::words_lt_p(rw), NMX_E_SCALAR_RANGE, "blinding scalar >= field modulus");
+    if (flags & NMX_SCALARS_MONT) Fp<SF>::from_words(rw).mont256_to_canonical().to_words(rw);
+    uint32_t any = 0;
+    for (int i = 0; i < 8; i++) any |= rw[i];
+    if (any) {
+      Affine<BF> h;
+      h.x = fp_from_bytes<BF>((const uint8_t*)h_xy64);
+      h.y = fp_from_bytes<BF>((const uint8_t*)h_xy64 + 32);
+      if (!h.is_identity()) {
+        const bool m = (flags & NMX_BASES_MONT) != 0;
+        h.x = (m ? h.x.mont256_to_internal() : h.x.to_internal()).canon();
+        h.y = (m ? h.y.mont256_to_internal() : h.y.to_internal()).canon();
+      }
+      acc.add(scalar_mul<BF>(XYZZ<BF>::from_affine(h), rw));
+    }
+    write_result<CID>(acc, flags, out, inf);
+  }
+  static void* upload(Ctx& c, const void* src, size_t n, uint32_t flags, uint32_t* pc, uint32_t* pw) {
+    return upload_bases<CID>(c, src, n, flags, pc, pw);
+  }
+  static void* generate(Ctx& c, uint64_t k0, size_t n, uint32_t flags, uint32_t* pc, uint32_t* pw) {
+    void* d = nullptr;
+    table_shape<CID>(n, flags, pc, pw);
+    if (n) HIPCHK(hipMalloc(&d, n * 64 * (*pw ? *pw : 1)));
+    try {
+      DeviceBackend be(c, false, false);
+      GenFn<CID> f{(AffineW*)d, k0};
+      be.launch(f, (uint32_t)n);
+      build_tables<CID>(c, d, n, *pc, *pw);
+      HIPCHK(hipStreamSynchronize(c.stream));
+    } catch (...) {
+      if (d) (void)hipFree(d);
+      throw;
+    }
+    return d;
+  }
+  static void internal_to_canonical(uint8_t* e, size_t count) {
+    for (size_t i = 0; i < count; i++) {
+      Fp<BF> f = fp_from_bytes<BF>(e + 32 * i);
+      fp_to_bytes(f.to_canonical(), e + 32 * i);
+    }
+  }
+  static void point_sum(const uint8_t* partials128, size_t count, uint8_t* out, uint8_t* inf) {
+    XYZZ<BF> acc = XYZZ<BF>::identity();
+    for (size_t i = 0; i < count; i++) {
+      XYZZW w;
+      memcpy(w.w, partials128 + 128 * i, 128);
+      acc.add(XYZZ<BF>::load(w));
+    }
+    xyzz_to_xy64<BF>(acc, out, inf);
+  }
+  static CurveOps ops() {
+    return CurveOps{&msm_plain, &msm_key, &commit, &upload, &generate, &internal_to_canonical, &point_sum};
+  }
+};
+
+}  // namespace nmx

@@ -15,9 +15,9 @@
 //   4. PlanFn        buckets longer than lmax are split into lmax-sized extra tasks (bounded work per lane
 //                    whatever the scalar distribution: all-equal scalars put N points in one bucket)
 //   5. AccumFn       one lane per (bucket | extra task): gather affine points, XYZZ mixed adds (msm.rs:129-165)
-//   6. FoldFn x3     strided folds of a heavy bucket's partial sums -> bucket
-//   7. ReduceFn...   per-window sum_k k*B_k by segmented running sums, log_m(M) levels (msm.rs:555-561,637-643
-//                    do this serially per thread; here it is a tree so 16 windows x 32768 buckets fill the chip)
+//   6. FoldFn x4     strided folds of a heavy bucket's partial sums -> bucket
+//   7. ReducePairFn  per-window sum_k k*B_k as a binary tree, log2(M) levels, two dependent additions per level
+//                    (msm.rs:555-561,637-643 do this sum serially per thread)
 //   8. host tail     Horner over the W window sums (msm.rs:651-661), one inversion, canonical bytes.
 #pragma once
 #include "curve.hpp"
@@ -42,9 +42,11 @@ enum : uint32_t { ERR_SCALAR_RANGE = 1u, ERR_SMALL_RANGE = 2u };
 struct MsmShape {
   uint32_t n;         // pairs
   uint32_t c;         // window width (bits)
-  uint32_t W;         // windows
-  uint32_t M;         // buckets per window = 2^(c-1)
-  uint32_t nbuckets;  // W*M ; key nbuckets is the trash bucket
+  uint32_t W;         // digit windows
+  uint32_t WB;        // bucket sets: W, or 1 when window w reads the precomputed table 2^(cw) * P (all windows share
+                      // one bucket set and no window combination is needed)
+  uint32_t M;         // buckets per set = 2^(c-1)
+  uint32_t nbuckets;  // WB*M ; key nbuckets is the trash bucket
   uint32_t lmax;      // longest run one lane accumulates
   uint32_t total;     // n*W sorted entries
 };
@@ -63,6 +65,8 @@ template <int SFID> struct DigitsFn {
   MsmShape sh;
   uint32_t scalars_mont;  // 1: scalars are in Montgomery form
   uint32_t u64_bits;      // 0: field scalars; >0: scalars are u64 and must be < 2^u64_bits
+  uint32_t pre_stride;    // 0: plain bases[i]; else window w uses table entry w*pre_stride + pre_offset + i
+  uint32_t pre_offset;
 
   NMX_HD void operator()(uint32_t i) const {
     uint32_t s[9];
@@ -91,7 +95,7 @@ template <int SFID> struct DigitsFn {
     }
     if (bases) {  // identity base contributes nothing (msm.rs:247-249)
       uint32_t o = 0;
-      const uint32_t* b = bases + 16 * (size_t)i;
+      const uint32_t* b = bases + 16 * ((size_t)pre_offset + i);
 #pragma unroll
       for (int j = 0; j < 16; j++) o |= b[j];
       if (o == 0) skip = true;
@@ -112,10 +116,10 @@ template <int SFID> struct DigitsFn {
       } else {
         carry = 0;
       }
-      uint32_t key = (d == 0 || skip) ? sh.nbuckets : (w * sh.M + d - 1);
+      uint32_t key = (d == 0 || skip) ? sh.nbuckets : ((pre_stride ? 0u : w * sh.M) + d - 1);
       size_t o = (size_t)w * sh.n + i;
       keys[o] = key;
-      vals[o] = i | (neg << 31);
+      vals[o] = (pre_stride ? w * pre_stride + pre_offset + i : i) | (neg << 31);
     }
   }
 };
@@ -204,7 +208,7 @@ template <int FID> struct AccumFn {
 
 // ----------------------------------------------------------------------------------------------------
 // 6. strided fold of heavy buckets' partials.  Lane j of group g folds positions j, j+T, j+2T, ... < cnt
-//    into position j.  Applied with T = 256, 16, 1 (cnt = all, 256, 16); the last pass writes the bucket.
+//    into position j.  Applied with T = 256, 32, 4, 1 (cnt = all, 256, 32, 4); the last pass writes the bucket.
 // ----------------------------------------------------------------------------------------------------
 template <int FID> struct FoldFn {
   const uint32_t* counters;
@@ -221,6 +225,7 @@ template <int FID> struct FoldFn {
       HeavyRec r = heavy[h];
       uint32_t cnt = r.cnt < cap ? r.cnt : cap;
       if (j >= cnt) continue;
+      if (T != 1 && j + T >= cnt) continue;  // nothing to add: position j already holds its sum
       XYZZ<FID> acc = XYZZ<FID>::load(partials[r.off + j]);
       for (uint32_t q = j + T; q < cnt; q += T) acc.add(XYZZ<FID>::load(partials[r.off + q]));
       if (T == 1)
@@ -232,45 +237,74 @@ template <int FID> struct FoldFn {
 };
 
 // ----------------------------------------------------------------------------------------------------
-// 7. bucket reduction:  F = sum_{k=1..n} k * B_k  per window, as a tree.
-//    Invariant per window:  F = Sum(Y) + 2^ls * G(A),  G(X) = sum_{k=0..n-1} k * X_k.
-//    Start: A = Y = B, ls = 0 (F = G(B) + Sum(B)).  One level with segment length m:
-//      A'_u = sum_j A_{um+j};  g_u = sum_j j*A_{um+j};  Y'_u = sum_j Y_{um+j} + 2^ls * g_u;  ls' = ls + log2 m.
+// Key registration: tables T_w[i] = 2^(c*w) * P_i, w = 1..W-1 (T_0 = the key itself).  288 GB of HBM per GPU makes
+// W = 16 copies of a commitment key cheap (1 GiB for 2^20 BN254 points); in exchange every window of an MSM drops
+// into ONE set of 2^(c-1) buckets: the bucket reduction shrinks W-fold and the host-side window combination
+// (msm.rs:651-661) disappears.  Commitment keys are long-lived in Nova (created once by `setup`,
+// src/provider/pedersen.rs:249-259), so this is paid once per key.
 // ----------------------------------------------------------------------------------------------------
-template <int FID> struct ReduceFn {
-  const XYZZW* A;
-  const XYZZW* Y;  // == A on the first level
-  XYZZW* A_out;
+template <int FID> struct PrecompFn {
+  AffineW* tables;  // W x n
+  uint32_t n, c, W;
+  NMX_HD void operator()(uint32_t i) const {
+    Affine<FID> a = Affine<FID>::load(tables[i]);
+    XYZZ<FID> p = XYZZ<FID>::from_affine(a);
+    for (uint32_t w = 1; w < W; w++) {
+      for (uint32_t q = 0; q < c; q++) p.dbl_in_place();
+      a = p.to_affine();
+      a.store(tables[(size_t)w * n + i]);
+      p = XYZZ<FID>::from_affine(a);  // back to zz = zzz = 1: keeps the next doublings cheap and bounded
+    }
+  }
+};
+
+// ----------------------------------------------------------------------------------------------------
+// 7. bucket reduction:  F = sum_{b=0..n-1} (b+1) * B_b  per window, as a binary tree that is shallow in
+//    *dependent point additions* (the lower levels have fewer lanes than the chip has SIMDs, so their cost is
+//    latency, not throughput: ~7 us per dependent XYZZ addition).
+//    Invariant per window:  F = Sum(Y) + G(D),  G(X) = sum_j j * X_j (0-based).  Start: Y = D = B.
+//    One level:   D'_j = 2 * (D_2j + D_2j+1)          (keeps G's weights: 2j*D_2j + (2j+1)*D_2j+1 = j*D'_j + D_2j+1)
+//                 Y'_j = Y_2j + Y_2j+1 + D_2j+1
+//    After log2(n) levels n = 1, G = 0 and F = Y_0.  The two outputs of a pair are computed by different waves
+//    (role 0 / role 1), so a level is two dependent additions deep whatever n is.  The reference does this sum
+//    serially per thread (msm.rs:555-561,637-643).
+// ----------------------------------------------------------------------------------------------------
+template <int FID> struct ReducePairFn {
+  const XYZZW* D;
+  const XYZZW* Y;  // == D on the first level (Y = D = B)
+  XYZZW* D_out;
   XYZZW* Y_out;
-  uint32_t n_in;   // elements per window on entry
-  uint32_t m;      // segment length (divides n_in)
-  uint32_t ls;     // log2 of the scale carried by G(A)
-  uint32_t first;  // 1: Y aliases A (first level)
+  uint32_t n_in;          // elements per window on entry (a power of two >= 2)
+  uint32_t pairs;         // W * n_in / 2
+  uint32_t pairs_padded;  // pairs rounded up to a multiple of 64: roles never share a wave
+  uint32_t first;
   NMX_HD void operator()(uint32_t tid) const {
-    uint32_t n_out = n_in / m;
-    uint32_t w = tid / n_out, u = tid % n_out;
-    size_t base = (size_t)w * n_in + (size_t)u * m;
-    XYZZ<FID> run = XYZZ<FID>::identity();  // running suffix sum of A
-    XYZZ<FID> g = XYZZ<FID>::identity();    // sum_j j*A_j (0-based)
-    for (uint32_t j = m - 1; j >= 1; j--) {
-      run.add(XYZZ<FID>::load(A[base + j]));
-      g.add(run);
-    }
-    XYZZ<FID> y;
-    if (first) {
-      // Y == A: Sum(Y seg) + g = sum_j (j+1) A_j = g + run + A_0
-      run.add(XYZZ<FID>::load(A[base]));
-      y = g;
-      y.add(run);
+    const uint32_t role = tid >= pairs_padded ? 1u : 0u;
+    const uint32_t j = tid - role * pairs_padded;
+    if (j >= pairs) return;
+    const uint32_t half = n_in >> 1;
+    const uint32_t w = j / half, u = j - w * half;
+    const size_t base = (size_t)w * n_in + 2 * (size_t)u;
+    const size_t o = (size_t)w * half + u;
+    if (role == 0) {
+      if (n_in == 2) return;  // last level: only Y_0 is needed
+      XYZZ<FID> d = XYZZ<FID>::load(D[base]);
+      d.add(XYZZ<FID>::load(D[base + 1]));
+      d.dbl_in_place();
+      d.store(D_out[o]);
     } else {
-      run.add(XYZZ<FID>::load(A[base]));
-      for (uint32_t q = 0; q < ls; q++) g.dbl_in_place();
-      y = g;
-      for (uint32_t j = 0; j < m; j++) y.add(XYZZ<FID>::load(Y[base + j]));
+      XYZZ<FID> y;
+      if (first) {  // Y = D = B:  B_2j + 2 * B_2j+1
+        y = XYZZ<FID>::load(D[base + 1]);
+        y.dbl_in_place();
+        y.add(XYZZ<FID>::load(D[base]));
+      } else {
+        y = XYZZ<FID>::load(Y[base + 1]);
+        y.add(XYZZ<FID>::load(D[base + 1]));
+        y.add(XYZZ<FID>::load(Y[base]));
+      }
+      y.store(Y_out[o]);
     }
-    size_t o = (size_t)w * n_out + u;
-    run.store(A_out[o]);
-    y.store(Y_out[o]);
   }
 };
 

@@ -16,6 +16,9 @@ struct MsmArgs {
   uint32_t scalars_mont;
   uint32_t u64_bits;   // 0 => field scalars
   uint32_t force_c;    // 0 => heuristic
+  // precomputed-table mode (key registered with NMX_BASES_PRECOMPUTE): `bases` points at T_0[0], tables are
+  // pre_stride apart, this call uses entries [pre_offset, pre_offset + n) of each, window width pre_c
+  uint32_t pre_stride = 0, pre_offset = 0, pre_c = 0;
 };
 
 inline uint32_t ilog2_u32(uint32_t v) {
@@ -35,28 +38,40 @@ inline uint32_t choose_c(uint32_t n, uint32_t bits) {
   return (uint32_t)c;
 }
 
-inline MsmShape make_shape(uint32_t n, uint32_t bits, uint32_t force_c) {
+// Window width of the precomputed tables of a key of n_key points.
+inline uint32_t choose_c_precomp(uint32_t n_key) {
+  uint32_t lg = ilog2_u32(n_key < 2 ? 2 : n_key);
+  int c = (int)lg - 4;
+  if (c < 8) c = 8;
+  if (c > 16) c = 16;
+  return (uint32_t)c;
+}
+
+inline MsmShape make_shape(uint32_t n, uint32_t bits, uint32_t force_c, uint32_t pre_c = 0) {
   MsmShape sh;
   sh.n = n;
-  sh.c = force_c ? force_c : choose_c(n, bits);
+  sh.c = pre_c ? pre_c : (force_c ? force_c : choose_c(n, bits));
   sh.W = (bits + 1 + sh.c - 1) / sh.c;
+  sh.WB = pre_c ? 1 : sh.W;
   sh.M = 1u << (sh.c - 1);
-  sh.nbuckets = sh.W * sh.M;
-  uint32_t avg = n / sh.M;
-  sh.lmax = 4 * avg < 32 ? 32 : 4 * avg;
+  sh.nbuckets = sh.WB * sh.M;
   sh.total = n * sh.W;
+  if (pre_c) {
+    sh.lmax = 32;  // every bucket collects ~W*n/M points: equal 32-point tasks, perfectly balanced lanes
+  } else {
+    uint32_t avg = n / sh.M;
+    sh.lmax = 4 * avg < 32 ? 32 : 4 * avg;
+  }
   return sh;
 }
 
-static constexpr uint32_t kFoldGroups = 512;
-
-// Runs stages 1-7.  On return `wsum_host[0..W)` holds the per-window sums (XYZZ, Montgomery), and *err_host the
+// Runs stages 1-7.  On return `wsum_host[0..WB)` holds the per-window sums (XYZZ, Montgomery), and *err_host the
 // device error bits.  Returns the shape used.
 template <class BE, int FID, int SFID>
 MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsum_host,
                       uint32_t* err_host) {
   const uint32_t bits = a.u64_bits ? a.u64_bits : scalar_bits;
-  MsmShape sh = make_shape(a.n, bits, a.force_c);
+  MsmShape sh = make_shape(a.n, bits, a.force_c, a.pre_stride ? a.pre_c : 0);
   const size_t total = sh.total;
   const uint32_t heavy_cap = (uint32_t)(total / sh.lmax) + 1;
   const uint32_t extra_cap = 2 * heavy_cap;
@@ -86,6 +101,8 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
     f.sh = sh;
     f.scalars_mont = a.scalars_mont;
     f.u64_bits = a.u64_bits;
+    f.pre_stride = a.pre_stride;
+    f.pre_offset = a.pre_offset;
     be.launch(f, sh.n);
   }
   be.mark("sort");
@@ -109,37 +126,41 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
   }
   be.mark("fold");
   {
-    FoldFn<FID> f{counters, heavy, partials, buckets, 256, 0xffffffffu, kFoldGroups};
-    be.launch(f, kFoldGroups * 256);
-    f.T = 16;
+    const uint32_t hb = heavy_cap < sh.nbuckets ? heavy_cap : sh.nbuckets;  // upper bound on heavy buckets
+    const uint32_t g256 = hb < 4096 ? hb : 4096;
+    FoldFn<FID> f{counters, heavy, partials, buckets, 256, 0xffffffffu, g256};
+    be.launch(f, g256 * 256);
+    f.T = 32;
     f.cap = 256;
-    be.launch(f, kFoldGroups * 16);
+    f.groups = hb < 32768 ? hb : 32768;
+    be.launch(f, f.groups * 32);
+    f.T = 4;
+    f.cap = 32;
+    f.groups = hb;
+    be.launch(f, f.groups * 4);
     f.T = 1;
-    f.cap = 16;
-    be.launch(f, kFoldGroups);
+    f.cap = 4;
+    be.launch(f, f.groups);
   }
   be.mark("reduce");
-  const XYZZW* A = buckets;
+  const XYZZW* D = buckets;
   const XYZZW* Y = buckets;
-  uint32_t n_in = sh.M, ls = 0, first = 1;
-  if (n_in == 1) {
-    // c == 1: one bucket per window, weight 1: the bucket is the window sum
-  }
+  uint32_t n_in = sh.M, first = 1;  // M == 1 (c == 1): the bucket is the window sum
   while (n_in > 1) {
-    uint32_t m = n_in < 16 ? n_in : 16;
-    uint32_t n_out = n_in / m;
-    XYZZW* Ao = be.template alloc<XYZZW>((size_t)sh.W * n_out);
-    XYZZW* Yo = be.template alloc<XYZZW>((size_t)sh.W * n_out);
-    ReduceFn<FID> f{A, Y, Ao, Yo, n_in, m, ls, first};
-    be.launch(f, sh.W * n_out);
-    A = Ao;
+    const uint32_t half = n_in / 2;
+    XYZZW* Do = be.template alloc<XYZZW>((size_t)sh.WB * half);
+    XYZZW* Yo = be.template alloc<XYZZW>((size_t)sh.WB * half);
+    const uint32_t pairs = sh.WB * half;
+    const uint32_t padded = (pairs + 63u) & ~63u;
+    ReducePairFn<FID> f{D, Y, Do, Yo, n_in, pairs, padded, first};
+    be.launch(f, 2 * padded);
+    D = Do;
     Y = Yo;
-    ls += ilog2_u32(m);
-    n_in = n_out;
+    n_in = half;
     first = 0;
   }
   be.mark("tail");
-  be.d2h(wsum_host, Y, sizeof(XYZZW) * sh.W);
+  be.d2h(wsum_host, Y, sizeof(XYZZW) * sh.WB);
   be.d2h(err_host, counters + 2, sizeof(uint32_t));
   be.mark("end");
   be.sync();
@@ -148,8 +169,8 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
 
 // Host tail: Horner over window sums, high to low (msm.rs:651-661).
 template <int FID> XYZZ<FID> combine_windows(const XYZZW* wsum, const MsmShape& sh) {
-  XYZZ<FID> acc = XYZZ<FID>::load(wsum[sh.W - 1]);
-  for (int w = (int)sh.W - 2; w >= 0; w--) {
+  XYZZ<FID> acc = XYZZ<FID>::load(wsum[sh.WB - 1]);
+  for (int w = (int)sh.WB - 2; w >= 0; w--) {  // WB == 1 (precomputed tables): nothing to combine
     for (uint32_t q = 0; q < sh.c; q++) acc.dbl_in_place();
     acc.add(XYZZ<FID>::load(wsum[w]));
   }

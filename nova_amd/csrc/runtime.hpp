@@ -1,0 +1,171 @@
+// runtime.hpp -- device runtime shared by every translation unit of libnova_mi355x.so: error plumbing, the generic
+// launch trampoline, the per-call context (HIP stream + workspace arena + profiling events), the key registry
+// and the per-curve operation table.  The library is split into one TU per curve (compile time), one for the
+// rocPRIM sort and one for the C ABI (capi.hip).  There is no CPU fallback anywhere: without a HIP device every
+// entry point returns NMX_E_NO_DEVICE.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/nova_mi355x.h"
+#include "curves.hpp"
+#include "msm_pipeline.hpp"
+
+namespace nmx {
+
+// ---------------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------------
+struct Fail {
+  int code;
+  std::string msg;
+};
+#define HIPCHK(x)                                                                                  \
+  do {                                                                                             \
+    hipError_t e_ = (x);                                                                           \
+    if (e_ != hipSuccess)                                                                          \
+      throw ::nmx::Fail{NMX_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)};                \
+  } while (0)
+static inline void require(bool ok, int code, const char* msg) {
+  if (!ok) throw Fail{code, msg};
+}
+
+// ---------------------------------------------------------------------------------------------------
+// generic launch trampoline: one lane per tid
+// ---------------------------------------------------------------------------------------------------
+template <class F> __global__ __launch_bounds__(256) void k_launch(F f, uint32_t n) {
+  uint32_t tid = blockIdx.x * 256u + threadIdx.x;
+  if (tid < n) f(tid);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// per-call context: stream + workspace arena + profiling events
+// ---------------------------------------------------------------------------------------------------
+static constexpr int kMaxMarks = 12;
+struct Ctx {
+  hipStream_t stream = nullptr;
+  char* arena = nullptr;
+  size_t cap = 0;
+  hipEvent_t ev[kMaxMarks];
+  bool have_ev = false;
+};
+
+struct BaseSet {
+  int curve;
+  size_t n;
+  void* d;             // AffineW[pre_W ? pre_W * n : n]: the key (internal form), then its window tables
+  uint32_t pre_c = 0;  // window width of the tables (0: none)
+  uint32_t pre_W = 0;
+};
+
+struct Global {
+  std::mutex mu;
+  bool inited = false;
+  int device = 0;
+  std::vector<Ctx*> free_ctx;
+  std::vector<Ctx*> all_ctx;
+  std::unordered_map<uint64_t, BaseSet> bases;
+  uint64_t next_handle = 1;
+  bool profiling = false;
+  uint32_t force_c = 0;
+};
+extern Global G;                 // capi.hip
+void prof_store(const float* ms, int n);   // last call's stage times of this thread (capi.hip)
+void prof_add_tail(float ms);
+void arena_reserve(Ctx& c, size_t bytes);  // capi.hip
+// rocPRIM radix sort of (key, value) pairs, its own TU (sort.hip).  tmp == nullptr: size query.
+void device_sort_pairs(void* tmp, size_t& tmp_bytes, uint32_t* k_in, uint32_t* k_out, uint32_t* v_in,
+                       uint32_t* v_out, size_t total, uint32_t bits, hipStream_t stream);
+
+struct DeviceBackend {
+  Ctx& c;
+  bool dry;
+  size_t used = 0;
+  int nmarks = 0;
+  bool prof;
+  explicit DeviceBackend(Ctx& ctx, bool dry_, bool prof_) : c(ctx), dry(dry_), prof(prof_) {}
+
+  template <class T> T* alloc(size_t count) {
+    size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+    T* p = (T*)(c.arena + used);
+    used += bytes;
+    if (!dry) require(used <= c.cap, NMX_E_HIP, "workspace arena overflow");
+    return p;
+  }
+  void memset0(void* p, size_t bytes) {
+    if (dry) return;
+    HIPCHK(hipMemsetAsync(p, 0, bytes, c.stream));
+  }
+  template <class F> void launch(const F& f, uint32_t n) {
+    if (dry || n == 0) return;
+    hipLaunchKernelGGL((k_launch<F>), dim3((n + 255) / 256), dim3(256), 0, c.stream, f, n);
+    HIPCHK(hipGetLastError());
+  }
+  void sort_pairs(uint32_t* k_in, uint32_t* k_out, uint32_t* v_in, uint32_t* v_out, size_t total,
+                  uint32_t bits) {
+    size_t tmp_bytes = 0;
+    device_sort_pairs(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, total, bits, c.stream);
+    char* tmp = alloc<char>(tmp_bytes ? tmp_bytes : 1);
+    if (dry) return;
+    device_sort_pairs(tmp, tmp_bytes, k_in, k_out, v_in, v_out, total, bits, c.stream);
+  }
+  void d2h(void* dst, const void* src, size_t bytes) {
+    if (dry) return;
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c.stream));
+  }
+  void sync() {
+    if (dry) return;
+    HIPCHK(hipStreamSynchronize(c.stream));
+  }
+  void mark(const char*) {
+    if (dry || !prof) return;
+    if (!c.have_ev) {
+      for (int i = 0; i < kMaxMarks; i++) HIPCHK(hipEventCreate(&c.ev[i]));
+      c.have_ev = true;
+    }
+    if (nmarks < kMaxMarks) HIPCHK(hipEventRecord(c.ev[nmarks++], c.stream));
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// one MSM request, and the per-curve operation table (each curve is instantiated in its own TU)
+// ---------------------------------------------------------------------------------------------------
+struct MsmCall {
+  const void* scalars;  // host or device
+  bool scalars_device;
+  bool scalars_mont;
+  uint32_t u64_bits;  // 0 => field scalars; NMX_BITS_AUTO resolved by the caller
+  bool u64_mode;
+  // precomputed tables of the registered key (0 = none / not used for this call)
+  uint32_t pre_stride = 0, pre_offset = 0, pre_c = 0;
+};
+static constexpr size_t kPrecompMinN = 4096;  // below this the plain path with a narrow window is faster
+
+struct CurveOps {
+  // out = sum scalars[i] * bases[i] over device-resident internal-form bases
+  void (*msm_plain)(Ctx&, const void* d_bases, size_t n, const MsmCall&, uint32_t flags, uint8_t* out, uint8_t* inf);
+  // same over key[offset, offset+n), through the key's window tables when it has them
+  void (*msm_key)(Ctx&, const BaseSet&, size_t offset, size_t n, const MsmCall&, uint32_t flags, uint8_t* out,
+                  uint8_t* inf);
+  // msm_key(v) + h * r
+  void (*commit)(Ctx&, const BaseSet&, size_t n, const MsmCall&, const void* h_xy64, const void* r, uint32_t flags,
+                 uint8_t* out, uint8_t* inf);
+  void* (*upload)(Ctx&, const void* src, size_t n, uint32_t flags, uint32_t* pre_c, uint32_t* pre_W);
+  void* (*generate)(Ctx&, uint64_t k0, size_t n, uint32_t flags, uint32_t* pre_c, uint32_t* pre_W);
+  void (*internal_to_canonical)(uint8_t* elems32, size_t count);  // host, in place
+  void (*point_sum)(const uint8_t* partials128, size_t count, uint8_t* out, uint8_t* inf);  // host
+};
+const CurveOps& curve_ops_bn254_g1();
+const CurveOps& curve_ops_grumpkin();
+const CurveOps& curve_ops_pallas();
+const CurveOps& curve_ops_vesta();
+
+}  // namespace nmx

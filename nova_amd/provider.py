@@ -93,18 +93,21 @@ class CommitmentKey:
         self.h = bytes(h_xy64)
 
     @classmethod
-    def from_host(cls, curve, ck_xy64, h_xy64=None, mont=False):
+    def from_host(cls, curve, ck_xy64, h_xy64=None, mont=False, precompute=True):
+        """Register a host key.  precompute=True also builds the window tables 2^(cw) * P_i in HBM (16x the key for
+        c = 16): commitment keys are long-lived, so every later MSM runs all windows into one bucket set."""
         a = _host_u8(ck_xy64, 64)
         n = a.size // 64
         h = ctypes.c_uint64(0)
-        _check(L.lib().nmx_bases_register(curve, a.ctypes.data, n, L.BASES_MONT if mont else 0, ctypes.byref(h)))
+        flags = (L.BASES_MONT if mont else 0) | (L.BASES_PRECOMPUTE if precompute else 0)
+        _check(L.lib().nmx_bases_register(curve, a.ctypes.data, n, flags, ctypes.byref(h)))
         return cls(curve, h.value, n, h_xy64 if h_xy64 is not None else bytes(64), mont)
 
     @classmethod
-    def generate(cls, curve, n, k0=1):
+    def generate(cls, curve, n, k0=1, precompute=True):
         """Synthetic key P_i = (k0 + i) * G built on the device (nmx_bases_generate); h = P_n."""
         h = ctypes.c_uint64(0)
-        _check(L.lib().nmx_bases_generate(curve, k0, n + 1, ctypes.byref(h)))
+        _check(L.lib().nmx_bases_generate(curve, k0, n + 1, L.BASES_PRECOMPUTE if precompute else 0, ctypes.byref(h)))
         key = cls(curve, h.value, n, bytes(64))
         key.h = key.read(n, 1).tobytes()
         return key

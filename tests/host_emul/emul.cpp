@@ -50,19 +50,31 @@ struct HostEmulBackend {
 
 template <int CID>
 static int emul_msm_t(const uint8_t* scalars, const uint8_t* bases_xy64, size_t n, uint32_t u64_bits,
-                      uint32_t u64_mode, uint32_t scalars_mont, uint32_t force_c, uint8_t* out, uint8_t* inf) {
+                      uint32_t u64_mode, uint32_t scalars_mont, uint32_t force_c, uint8_t* out, uint8_t* inf,
+                      uint32_t pre_c = 0, size_t n_key = 0, size_t pre_offset = 0) {
   using C = CurveT<CID>;
   constexpr int BF = C::BF, SF = C::SF;
   XYZZ<BF> r = XYZZ<BF>::identity();
   if (n != 0 && !(u64_mode && u64_bits == 0)) {
-    std::vector<AffineW> b(n);
-    for (size_t i = 0; i < n; i++) {
+    // precomputed-table mode: bases_xy64 holds the whole key (n_key points); the MSM uses [pre_offset, +n)
+    const size_t nb = pre_c ? n_key : n;
+    const uint32_t Wt = pre_c ? (FpParams<SF>::BITS + 1 + pre_c - 1) / pre_c : 1;
+    std::vector<AffineW> b(nb * Wt);
+    for (size_t i = 0; i < nb; i++) {
       Affine<BF> a;
       a.x = fp_from_bytes<BF>(bases_xy64 + 64 * i).to_internal().canon();
       a.y = fp_from_bytes<BF>(bases_xy64 + 64 * i + 32).to_internal().canon();
       a.store(b[i]);
     }
     MsmArgs a;
+    if (pre_c) {
+      HostEmulBackend pb;
+      PrecompFn<BF> pf{b.data(), (uint32_t)nb, pre_c, Wt};
+      pb.launch(pf, (uint32_t)nb);
+      a.pre_stride = (uint32_t)nb;
+      a.pre_offset = (uint32_t)pre_offset;
+      a.pre_c = pre_c;
+    }
     a.scalars = (const uint32_t*)scalars;
     a.bases = b.data();
     a.n = (uint32_t)n;
@@ -112,6 +124,18 @@ int emul_msm(int curve, const uint8_t* scalars, const uint8_t* bases_xy64, size_
     case 1: return emul_msm_t<1>(scalars, bases_xy64, n, u64_bits, u64_mode, scalars_mont, force_c, out, inf);
     case 2: return emul_msm_t<2>(scalars, bases_xy64, n, u64_bits, u64_mode, scalars_mont, force_c, out, inf);
     case 3: return emul_msm_t<3>(scalars, bases_xy64, n, u64_bits, u64_mode, scalars_mont, force_c, out, inf);
+  }
+  return -1;
+}
+
+// precomputed-table mode over a key of n_key points, MSM over key[offset .. offset+n)
+int emul_msm_precomp(int curve, const uint8_t* scalars, const uint8_t* key_xy64, size_t n_key, size_t offset, size_t n,
+                     uint32_t u64_bits, uint32_t u64_mode, uint32_t pre_c, uint8_t* out, uint8_t* inf) {
+  switch (curve) {
+    case 0: return emul_msm_t<0>(scalars, key_xy64, n, u64_bits, u64_mode, 0, 0, out, inf, pre_c, n_key, offset);
+    case 1: return emul_msm_t<1>(scalars, key_xy64, n, u64_bits, u64_mode, 0, 0, out, inf, pre_c, n_key, offset);
+    case 2: return emul_msm_t<2>(scalars, key_xy64, n, u64_bits, u64_mode, 0, 0, out, inf, pre_c, n_key, offset);
+    case 3: return emul_msm_t<3>(scalars, key_xy64, n, u64_bits, u64_mode, 0, 0, out, inf, pre_c, n_key, offset);
   }
   return -1;
 }

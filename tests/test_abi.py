@@ -59,7 +59,7 @@ def test_no_cpu_fallback_without_device(L):
     assert b"no HIP device" in L.nmx_last_error()
     assert not out.any()  # a failed call never writes a point
     h = ctypes.c_uint64(0)
-    assert L.nmx_bases_generate(0, 1, 8, ctypes.byref(h)) == _lib.E_NO_DEVICE
+    assert L.nmx_bases_generate(0, 1, 8, 0, ctypes.byref(h)) == _lib.E_NO_DEVICE
     assert L.nmx_init(0) == _lib.E_NO_DEVICE
 
 

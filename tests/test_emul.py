@@ -29,6 +29,9 @@ def emul():
     L = ctypes.CDLL(SO)
     L.emul_msm.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32,
                            ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+    L.emul_msm_precomp.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t,
+                                   ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p,
+                                   ctypes.c_void_p]
     L.emul_fp_op.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
     return L
 
@@ -204,3 +207,33 @@ def test_emul_scalar_out_of_range(emul):
     sc[3] = util.int_to_le32(c.r)  # == modulus: from_repr rejects
     rc, _, _ = run(emul, c.cid, sc, bases, n)
     assert rc != 0
+
+
+def run_pre(L, cid, scalars, key, n_key, offset, n, pre_c, u64_bits=None):
+    s = np.ascontiguousarray(scalars)
+    k = np.ascontiguousarray(key)
+    out = np.zeros(64, np.uint8)
+    inf = np.zeros(1, np.uint8)
+    mode = 0 if u64_bits is None else 1
+    rc = L.emul_msm_precomp(cid, s.ctypes.data, k.ctypes.data, n_key, offset, n, u64_bits or 0, mode, pre_c,
+                            out.ctypes.data, inf.ctypes.data)
+    return rc, out.tobytes(), int(inf[0])
+
+
+@pytest.mark.parametrize("c", list(R.CURVES.values()), ids=lambda c: c.name)
+def test_emul_precomputed_tables(emul, c):
+    """Registered-key mode: window w reads table 2^(cw)*P, all windows share one bucket set (PrecompFn +
+    pre_stride digits); prefixes and interior slices of the key; every scalar set; small-scalar mode."""
+    n_key = 160
+    key = cref.sequential_bases(c, 21, n_key).copy()
+    key[13] = 0  # an identity point inside the key
+    cases = [(8, 0, n_key, "random"), (8, 0, 77, "equal"), (8, 30, 100, "zero_rm1"), (8, 13, 1, "random"),
+             (11, 0, n_key, "pm_small"), (16, 5, 150, "random")]
+    for pre_c, off, n, kind in cases:
+        sc = util.scalar_set(c.cid, n, kind)
+        rc, got, inf = run_pre(emul, c.cid, sc, key, n_key, off, n, pre_c)
+        assert rc == 0 and (got, inf) == cref.msm(c.cid, sc, key[off:off + n], n), (pre_c, off, n, kind)
+    for bits in (1, 33, 64):
+        s = util.small_scalars(n_key, bits)
+        rc, got, inf = run_pre(emul, c.cid, s, key, n_key, 0, n_key, 9, u64_bits=bits)
+        assert rc == 0 and (got, inf) == cref.msm_u64(c.cid, s, key, n_key, bits)

@@ -160,14 +160,48 @@ def test_commit_engine(nmx, c):
     ck.close()
 
 
-@pytest.mark.parametrize("logn", [16, 20])
-def test_bn254_baseline_sizes(nmx, logn):
+@pytest.mark.parametrize("c", ALL, ids=lambda c: c.name)
+def test_precomputed_tables_vs_plain(nmx, c):
+    """A key registered with window tables (NMX_BASES_PRECOMPUTE) and the same key without them give the oracle's
+    result on every scalar set, for prefixes and interior slices, field and small scalars."""
+    import ctypes
+    from nova_amd import _lib
+    L = _lib.lib()
+    n_key = 9000
+    host = cref.sequential_bases(c, 77, n_key).copy()
+    host[4500] = 0  # identity point inside the key
+    g = nmx.DlogGroup(c.cid)
+    prep = cref.Prepared(c.cid, host, n_key)
+    keys = [nmx.CommitmentKey.from_host(c.cid, host, precompute=p) for p in (True, False)]
+    for kind in ["random", "equal", "zero_rm1", "pm_small", "u1", "u16"]:
+        sc = util.scalar_set(c.cid, n_key, kind)
+        exp = prep.msm(sc, n_key)
+        for ck in keys:
+            assert as_pair(g.vartime_multiscalar_mul(sc, ck)) == exp, kind
+    out = np.zeros(64, np.uint8)
+    inf = np.zeros(1, np.uint8)
+    for off, n in ((0, 5000), (1234, 7000), (4000, 4096), (8000, 1000)):
+        sc = np.ascontiguousarray(util.random_scalars(c.cid, n, seed=off))
+        exp = cref.msm(c.cid, sc, host[off:off + n], n)
+        for ck in keys:
+            assert L.nmx_msm_handle(ck.handle, off, sc.ctypes.data, n, 0, out.ctypes.data, inf.ctypes.data) == 0
+            assert (out.tobytes(), int(inf[0])) == exp, (off, n)
+    for bits in (1, 10, 33, 64):
+        s = util.small_scalars(n_key, bits)
+        exp = prep.msm_u64(s, n_key, bits)
+        for ck in keys:
+            assert as_pair(g.vartime_multiscalar_mul_small_with_max_num_bits(s, ck, bits)) == exp
+    [ck.close() for ck in keys]
+
+
+@pytest.mark.parametrize("logn,precompute", [(16, False), (16, True), (20, True), (20, False)])
+def test_bn254_baseline_sizes(nmx, logn, precompute):
     """BASELINE.json configs: BN254 MSM at 2^16 and 2^20, random scalars, bit-exact vs the oracle; plus
     size-independent properties at full size: shard additivity and linearity."""
     c = R.BN254_G1
     n = 1 << logn
     g = nmx.DlogGroup(c.cid)
-    ck = nmx.CommitmentKey.generate(c.cid, n, k0=1)
+    ck = nmx.CommitmentKey.generate(c.cid, n, k0=1, precompute=precompute)
     host = ck.read(0, n)
     s = util.random_scalars(c.cid, n, seed=1)
     t = util.random_scalars(c.cid, n, seed=2)
