@@ -41,6 +41,7 @@ static void ensure_init() {
   }
   if (dev >= cnt) throw Fail{NMX_E_ARG, "device index out of range"};
   G.device = dev;
+  if (const char* t = getenv("NMX_TUNE_LMAX")) G.force_lmax = (uint32_t)atoi(t);
   HIPCHK(hipSetDevice(dev));
   G.inited = true;
 }

@@ -19,11 +19,11 @@ namespace nmx {
 
 // 64 bytes in HBM: x || y, each the canonical internal-form residue packed in 8 x u32; identity = all zero
 // (like halo2curves / traits.rs:303-312; (0, 0) is not on any of the four curves).
-struct AffineW {
+struct alignas(16) AffineW {  // 16-byte alignment: one point is four global_load_dwordx4
   uint32_t w[16];
 };
 // 128 bytes in HBM: x, y, zz, zzz packed; identity <=> zz words all zero (msm.rs:59-61)
-struct XYZZW {
+struct alignas(16) XYZZW {
   uint32_t w[32];
 };
 
@@ -157,12 +157,15 @@ template <int FID> struct XYZZ {
 #endif
   }
   // affine operand as loaded from HBM; negate = the sign of a signed window digit
+  // The sign is applied with a per-limb select, NOT a branch: lanes of one wave carry digits of both signs, and
+  // two call sites of the (fully inlined) addition would make every wave execute it twice.
   NMX_HD void add_affine(const Affine<FID>& p, bool negate = false) {
     if (p.is_identity()) return;  // msm.rs:130-132
-    if (negate)
-      add_affine(p.x, F::sub2(F::zero(), p.y).norm());  // 2p - y in (p, 2p]
-    else
-      add_affine(p.x, p.y);
+    F ny = F::sub2(F::zero(), p.y).norm();  // 2p - y in (p, 2p]
+    F y;
+#pragma unroll
+    for (int i = 0; i < 9; i++) y.l[i] = negate ? ny.l[i] : p.y.l[i];
+    add_affine(p.x, y);
   }
 
   // add-2008-s (msm.rs:91-123): this += o, both operands within the in-register invariants.

@@ -27,7 +27,11 @@ namespace nmx {
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ uint32_t nmx_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 __device__ __forceinline__ void nmx_atomic_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
+__device__ __forceinline__ void nmx_atomic_max(uint32_t* p, uint32_t v) { atomicMax(p, v); }
 #else
+inline void nmx_atomic_max(uint32_t* p, uint32_t v) {
+  if (v > *p) *p = v;
+}
 inline uint32_t nmx_atomic_add(uint32_t* p, uint32_t v) {
   uint32_t o = *p;
   *p = o + v;
@@ -151,7 +155,7 @@ struct TaskRec {
 struct PlanFn {
   const uint32_t* start;
   const uint32_t* end;
-  uint32_t* counters;  // [0] = extra tasks used, [1] = heavy buckets
+  uint32_t* counters;  // [0] = extra tasks used, [1] = heavy buckets, [3] = most tasks in one bucket
   HeavyRec* heavy;
   TaskRec* extra;
   MsmShape sh;
@@ -159,6 +163,7 @@ struct PlanFn {
     uint32_t s = end[k] - start[k];
     if (s <= sh.lmax) return;
     uint32_t nt = (s + sh.lmax - 1) / sh.lmax;
+    nmx_atomic_max(&counters[3], nt);
     uint32_t off = nmx_atomic_add(&counters[0], nt);
     uint32_t h = nmx_atomic_add(&counters[1], 1);
     heavy[h] = HeavyRec{k, off, nt, 0};
@@ -186,10 +191,21 @@ template <int FID> struct AccumFn {
 
   NMX_HD XYZZ<FID> run(uint32_t b, uint32_t len) const {
     XYZZ<FID> acc = XYZZ<FID>::identity();
+    if (len == 0) return acc;
+    // software pipeline: the gather of point j+1 (64 B from a random row of a table that can be GiBs) is in
+    // flight while point j is being added (~6000 VALU cycles)
+    uint32_t v = vals[b];
+    AffineW cur = bases[v & 0x7fffffffu];
     for (uint32_t j = 0; j < len; j++) {
-      uint32_t v = vals[b + j];
-      Affine<FID> p = Affine<FID>::load(bases[v & 0x7fffffffu]);
-      acc.add_affine(p, (v >> 31) != 0);  // identity bases never get here (trash key)
+      uint32_t vn = v;
+      AffineW nxt = cur;
+      if (j + 1 < len) {
+        vn = vals[b + j + 1];
+        nxt = bases[vn & 0x7fffffffu];
+      }
+      acc.add_affine(Affine<FID>::load(cur), (v >> 31) != 0);  // identity bases never get here (trash key)
+      cur = nxt;
+      v = vn;
     }
     return acc;
   }
@@ -219,6 +235,7 @@ template <int FID> struct FoldFn {
   uint32_t cap;     // positions valid on entry = min(cnt, cap); cap = 0xffffffff for the first pass
   uint32_t groups;  // grid = groups * T lanes; groups loop over the heavy list
   NMX_HD void operator()(uint32_t tid) const {
+    if (T != 1 && counters[3] <= T) return;  // no bucket has more than T partials: this pass has nothing to fold
     uint32_t j = tid % T;
     uint32_t nh = counters[1];
     for (uint32_t h = tid / T; h < nh; h += groups) {

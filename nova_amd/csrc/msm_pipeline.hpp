@@ -16,6 +16,7 @@ struct MsmArgs {
   uint32_t scalars_mont;
   uint32_t u64_bits;   // 0 => field scalars
   uint32_t force_c;    // 0 => heuristic
+  uint32_t force_lmax = 0;  // 0 => heuristic (tuning knob: NMX_TUNE_LMAX)
   // precomputed-table mode (key registered with NMX_BASES_PRECOMPUTE): `bases` points at T_0[0], tables are
   // pre_stride apart, this call uses entries [pre_offset, pre_offset + n) of each, window width pre_c
   uint32_t pre_stride = 0, pre_offset = 0, pre_c = 0;
@@ -72,6 +73,7 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
                       uint32_t* err_host) {
   const uint32_t bits = a.u64_bits ? a.u64_bits : scalar_bits;
   MsmShape sh = make_shape(a.n, bits, a.force_c, a.pre_stride ? a.pre_c : 0);
+  if (a.force_lmax) sh.lmax = a.force_lmax;
   const size_t total = sh.total;
   const uint32_t heavy_cap = (uint32_t)(total / sh.lmax) + 1;
   const uint32_t extra_cap = 2 * heavy_cap;
@@ -82,7 +84,7 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
   uint32_t* vals1 = be.template alloc<uint32_t>(total);
   uint32_t* start = be.template alloc<uint32_t>(2 * ((size_t)sh.nbuckets + 1) + 4);
   uint32_t* end = start + sh.nbuckets + 1;
-  uint32_t* counters = end + sh.nbuckets + 1;  // [0] extra tasks, [1] heavy buckets, [2] error bits
+  uint32_t* counters = end + sh.nbuckets + 1;  // [0] extra tasks, [1] heavy buckets, [2] error bits, [3] max tasks
   HeavyRec* heavy = be.template alloc<HeavyRec>(heavy_cap);
   TaskRec* extra = be.template alloc<TaskRec>(extra_cap);
   XYZZW* buckets = be.template alloc<XYZZW>(sh.nbuckets);

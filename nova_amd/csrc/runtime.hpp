@@ -76,6 +76,7 @@ struct Global {
   uint64_t next_handle = 1;
   bool profiling = false;
   uint32_t force_c = 0;
+  uint32_t force_lmax = 0;  // env NMX_TUNE_LMAX (tuning only)
 };
 extern Global G;                 // capi.hip
 void prof_store(const float* ms, int n);   // last call's stage times of this thread (capi.hip)
