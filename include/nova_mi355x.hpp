@@ -1,0 +1,140 @@
+// nova_mi355x.hpp -- header-only C++ host mirror of the reference's provider interface for the commitment / MSM
+// path, on top of the C ABI (nova_mi355x.h).  Same names, argument meaning and error behaviour as the reference:
+//   DlogGroupExt            /root/reference/src/provider/traits.rs:77-117
+//   CommitmentEngineTrait   /root/reference/src/traits/commitment.rs:52-195
+//   Pedersen / HyperKZG CE  /root/reference/src/provider/pedersen.rs:240-305, src/provider/hyperkzg.rs:584-645
+// No group arithmetic here: every operation is a call into libnova_mi355x.so.  Precondition violations that are
+// `assert!` panics in the reference throw std::invalid_argument; library errors throw nova::provider::Error.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "nova_mi355x.h"
+
+namespace nova {
+namespace provider {
+
+using Scalar = std::array<uint8_t, 32>;  // canonical little-endian (`to_repr()`), or raw Montgomery with mont = true
+using Affine = std::array<uint8_t, 64>;  // x || y, identity = all zero (`to_coordinates()`, traits.rs:303-312)
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string& m) : std::runtime_error("nmx error " + std::to_string(c) + ": " + m), code(c) {}
+};
+inline void check(int rc) {
+  if (rc != NMX_OK) throw Error(rc, nmx_last_error());
+}
+
+struct Point {  // result of an MSM / commit, as `to_coordinates()` returns it
+  Affine xy{};
+  bool is_inf = true;
+  bool operator==(const Point& o) const { return xy == o.xy && is_inf == o.is_inf; }
+};
+
+// A commitment key resident in HBM (`CommitmentKey { ck, h }`, pedersen.rs:33-45 / hyperkzg.rs:84-100).
+class CommitmentKey {
+ public:
+  CommitmentKey(int curve, const std::vector<Affine>& ck, const Affine& h, bool mont = false, bool precompute = true)
+      : curve_(curve), n_(ck.size()), h_(h), mont_(mont) {
+    uint32_t flags = (mont ? NMX_BASES_MONT : 0u) | (precompute ? NMX_BASES_PRECOMPUTE : 0u);
+    check(nmx_bases_register(curve, ck.data(), ck.size(), flags, &handle_));
+  }
+  CommitmentKey(const CommitmentKey&) = delete;
+  CommitmentKey& operator=(const CommitmentKey&) = delete;
+  ~CommitmentKey() {
+    if (handle_) nmx_bases_unregister(handle_);
+  }
+  size_t len() const { return n_; }
+  int curve() const { return curve_; }
+  uint64_t handle() const { return handle_; }
+  const Affine& h() const { return h_; }
+  bool mont() const { return mont_; }
+
+ private:
+  int curve_;
+  size_t n_;
+  Affine h_;
+  bool mont_;
+  uint64_t handle_ = 0;
+};
+
+// `DlogGroupExt` for one curve id (NMX_BN254_G1 / NMX_GRUMPKIN / NMX_PALLAS / NMX_VESTA).
+template <int CURVE> struct DlogGroupExt {
+  // traits.rs:79 == msm() (msm.rs:225): assert_eq!(coeffs.len(), bases.len())
+  static Point vartime_multiscalar_mul(const std::vector<Scalar>& scalars, const std::vector<Affine>& bases,
+                                       bool mont = false) {
+    if (scalars.size() != bases.size()) throw std::invalid_argument("assert_eq!(coeffs.len(), bases.len())");
+    Point p;
+    uint8_t inf = 0;
+    uint32_t flags = mont ? (NMX_SCALARS_MONT | NMX_BASES_MONT) : 0u;
+    check(nmx_msm(CURVE, scalars.data(), bases.data(), scalars.size(), flags, p.xy.data(), &inf));
+    p.is_inf = inf != 0;
+    return p;
+  }
+  // same over a registered key prefix (`&ck.ck[..v.len()]`)
+  static Point vartime_multiscalar_mul(const std::vector<Scalar>& scalars, const CommitmentKey& ck, bool mont = false) {
+    if (scalars.size() > ck.len()) throw std::invalid_argument("assert!(ck.ck.len() >= v.len())");
+    Point p;
+    uint8_t inf = 0;
+    check(nmx_msm_handle(ck.handle(), 0, scalars.data(), scalars.size(), mont ? NMX_SCALARS_MONT : 0u,
+                         p.xy.data(), &inf));
+    p.is_inf = inf != 0;
+    return p;
+  }
+  // traits.rs:82-90: the j-th vector uses bases[..len_j]
+  static std::vector<Point> batch_vartime_multiscalar_mul(const std::vector<std::vector<Scalar>>& scalars,
+                                                          const CommitmentKey& ck, bool mont = false) {
+    std::vector<const void*> ptrs;
+    std::vector<size_t> lens;
+    for (auto& v : scalars) {
+      ptrs.push_back(v.data());
+      lens.push_back(v.size());
+    }
+    std::vector<uint8_t> out(64 * scalars.size() + 1), inf(scalars.size() + 1);
+    check(nmx_msm_batch_handle(ck.handle(), ptrs.data(), lens.data(), scalars.size(), mont ? NMX_SCALARS_MONT : 0u,
+                               out.data(), inf.data()));
+    std::vector<Point> r(scalars.size());
+    for (size_t j = 0; j < scalars.size(); j++) {
+      std::copy(out.begin() + 64 * j, out.begin() + 64 * j + 64, r[j].xy.begin());
+      r[j].is_inf = inf[j] != 0;
+    }
+    return r;
+  }
+  // traits.rs:93-106 (`T: Into<u64>`: widen to u64 before the call)
+  static Point vartime_multiscalar_mul_small(const std::vector<uint64_t>& scalars, const CommitmentKey& ck) {
+    return vartime_multiscalar_mul_small_with_max_num_bits(scalars, ck, NMX_BITS_AUTO);
+  }
+  static Point vartime_multiscalar_mul_small_with_max_num_bits(const std::vector<uint64_t>& scalars,
+                                                               const CommitmentKey& ck, uint32_t max_num_bits) {
+    if (scalars.size() > ck.len()) throw std::invalid_argument("assert_eq!(bases.len(), scalars.len())");
+    Point p;
+    uint8_t inf = 0;
+    check(nmx_msm_u64_handle(ck.handle(), 0, scalars.data(), scalars.size(), max_num_bits, 0, p.xy.data(), &inf));
+    p.is_inf = inf != 0;
+    return p;
+  }
+};
+
+// `CommitmentEngineTrait` restricted to the hot path.
+template <int CURVE> struct CommitmentEngine {
+  // pedersen.rs:263-270 / hyperkzg.rs:584-591:  msm(v, ck[..len v]) + h * r
+  static Point commit(const CommitmentKey& ck, const std::vector<Scalar>& v, const Scalar& r, bool mont = false) {
+    if (ck.len() < v.size()) throw std::invalid_argument("assert!(ck.ck.len() >= v.len())");
+    Point p;
+    uint8_t inf = 0;
+    uint32_t flags = (mont ? NMX_SCALARS_MONT : 0u) | (ck.mont() ? NMX_BASES_MONT : 0u);
+    check(nmx_commit(ck.handle(), v.data(), v.size(), ck.h().data(), r.data(), flags, p.xy.data(), &inf));
+    p.is_inf = inf != 0;
+    return p;
+  }
+  // hyperkzg.rs:593-612 with r_i = 0 (the HyperKZG prover's use)
+  static std::vector<Point> batch_commit(const CommitmentKey& ck, const std::vector<std::vector<Scalar>>& v) {
+    return DlogGroupExt<CURVE>::batch_vartime_multiscalar_mul(v, ck);
+  }
+};
+
+}  // namespace provider
+}  // namespace nova

@@ -1,0 +1,38 @@
+"""include/nova_mi355x.hpp (the C++ host mirror of DlogGroupExt / CommitmentEngine) compiled with g++ and run against
+the oracle.  Without a GPU the binary must stop with NMX_E_NO_DEVICE (exit 3); on the GPU box it must pass."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "cpp", "host_mirror_test.cpp")
+BIN = os.path.join(ROOT, "tests", "cpp", "host_mirror_test.bin")
+
+
+def build():
+    import __graft_entry__
+    __graft_entry__.build()
+    deps = [SRC, os.path.join(ROOT, "include", "nova_mi355x.hpp"), os.path.join(ROOT, "include", "nova_mi355x.h")]
+    if not os.path.exists(BIN) or os.path.getmtime(BIN) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", BIN, SRC,
+                               "-L" + os.path.join(ROOT, "nova_amd"), "-lnova_mi355x",
+                               "-L" + os.path.join(ROOT, "oracle"), "-lnova_ref",
+                               "-Wl,-rpath," + os.path.join(ROOT, "nova_amd"), "-Wl,-rpath," + os.path.join(ROOT, "oracle"),
+                               "-Wl,-rpath,/opt/rocm/lib"])
+    return BIN
+
+
+def test_cpp_mirror_compiles_and_refuses_without_gpu():
+    from nova_amd import _lib
+    if _lib.lib().nmx_device_count() > 0:
+        pytest.skip("a HIP device is visible")
+    r = subprocess.run([build()], capture_output=True, text=True)
+    assert r.returncode == 3, (r.returncode, r.stderr)
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_on_gpu():
+    b = BIN if os.path.exists(BIN) else build()
+    r = subprocess.run([b], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
