@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--dist", default="random", help="scalar distribution: random | u1 | u10 | u16 | u32 | u64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--window-bits", type=int, default=0)
+    ap.add_argument("--workload", default="msm", choices=["msm", "axpy", "cross_term", "bind"],
+                    help="msm = the headline (default); the others time one HBM-bound field-vector kernel of "
+                         "SURVEY.md 8(f) at 2^log2n elements per GPU")
     args = ap.parse_args()
 
     import torch
@@ -60,6 +63,9 @@ def main():
     assert rc == 0, L.nmx_last_error().decode()
     if args.window_bits:
         L.nmx_set_window_bits(args.window_bits)
+
+    if args.workload != "msm":
+        return field_workload(args, world, rank, L, torch, dist)
 
     n = 1 << args.log2n
     cid = args.curve
@@ -146,6 +152,92 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cid, ck, host_sc[(args.steps - 1) & 1], n, result)
         print(json.dumps(out), flush=True)
     ck.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def field_workload(args, world, rank, L, torch, dist):
+    """One HBM-bound field-vector kernel per step on HBM-resident vectors (BN254 scalar field unless --curve):
+    axpy = NIFS witness fold (r1cs/mod.rs:1058-1067), cross_term = commit_T's T (r1cs/mod.rs:614-620),
+    bind = MLE bind_poly_var_top (spartan/polys/multilinear.rs:65-84).  Ranks are independent replicas."""
+    import ctypes
+    from nova_amd import fieldvec as fv
+    from tests import util
+    n = 1 << args.log2n
+    cid = args.curve
+    fid = fv.SCALAR_FIELD_OF_CURVE[cid]
+    nvec = {"axpy": 2, "cross_term": 4, "bind": 1}[args.workload]
+    host = [util.random_scalars(cid, n, seed=util.SEED + 7 * j + rank) for j in range(nvec)]
+    dev = [torch.from_numpy(h).cuda() for h in host]
+    r = util.random_scalars(cid, 1, seed=99)
+    bytes_per_elem = {"axpy": 96, "cross_term": 160, "bind": 48}[args.workload]  # reads + writes per element
+
+    def step():
+        if args.workload == "axpy":
+            return fv.axpy(fid, dev[0], dev[1], r)
+        if args.workload == "cross_term":
+            return fv.cross_term(fid, dev[0], dev[1], dev[2], dev[3], r)
+        return fv.bind_poly_var_top(fid, dev[0], r)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    L.nmx_set_profiling(1)
+    prof = (ctypes.c_float * 4)()
+    ksum = 0.0
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+        L.nmx_profile_last(prof, 4)
+        ksum += prof[0]
+    fence()
+    dt = time.perf_counter() - t0
+    L.nmx_set_profiling(0)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank == 0:
+        kms = ksum / args.steps
+        achieved = bytes_per_elem * n / (kms * 1e-3) / 1e9
+        res = {
+            "metric": f"field elements/sec ({args.workload})", "value": n * world * args.steps / dt, "unit": "elements/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32x8 (256-bit modular integer)", "data": "synthetic",
+            "config": {"workload": f"{args.workload} over 2^{args.log2n} {['bn254_fq','bn254_fr','pasta_fp','pasta_fq'][fid]} "
+                                   "elements per GPU, HBM-resident (SURVEY.md 8(f))", "parallelism": f"replicas{world}"},
+            "kernel_ms": kms,
+            "roofline": {"bound": "hbm", "kernel": f"k_launch<{args.workload}>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "note": f"{bytes_per_elem} algorithmic bytes per element / kernel time from hipEvents on the library stream"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import cref
+            threads = os.cpu_count() or 1
+            cref.set_threads(threads)
+            m = min(n, 1 << 22)
+            t1 = time.perf_counter()
+            if args.workload == "axpy":
+                exp = cref.field_axpy(fid, host[0][:m], host[1][:m], r, m)
+            elif args.workload == "cross_term":
+                exp = cref.field_cross_term(fid, host[0][:m], host[1][:m], host[2][:m], host[3][:m], r, m)
+            else:
+                exp = cref.field_bind(fid, host[0], 0, n // 2, 1, r, min(m, n // 2))
+            t = time.perf_counter() - t1
+            cnt = m if args.workload != "bind" else min(m, n // 2)
+            got = out.cpu().numpy().reshape(-1)[: 32 * cnt].tobytes()
+            res["cpu_baseline"] = {"value": cnt / t, "unit": "elements/s", "cores": threads, "kind": "port",
+                                   "sample": f"first {cnt} elements, one pass, oracle/nova_ref.c (OpenMP)",
+                                   "gpu_matches_cpu": got == exp[: 32 * cnt]}
+        print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

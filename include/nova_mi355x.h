@@ -122,6 +122,28 @@ int nmx_commit(uint64_t ck_handle, const void* v, size_t n, const void* h_xy64, 
  * src/provider/msm.rs:566-571,667-673). */
 int nmx_point_sum(int curve, const uint8_t* partials128, size_t count, uint8_t* out, uint8_t* out_is_inf);
 
+/* ---- field-vector kernels either side of the MSM -------------------------------
+ * field ids: 0 = BN254 Fq (Grumpkin scalars), 1 = BN254 Fr (BN254 scalars), 2 = Pasta Fp (Vesta scalars),
+ * 3 = Pasta Fq (Pallas scalars).  Vectors are n x 32 bytes; flags: NMX_SCALARS_MONT (vectors and the challenge
+ * are raw Montgomery limbs), NMX_SCALARS_DEVICE (every vector pointer incl. `out` is an HBM pointer -- results
+ * then stay resident for the next nmx_msm_handle(..., NMX_SCALARS_DEVICE)); the challenge is always a host pointer. */
+enum { NMX_F_BN254_FQ = 0, NMX_F_BN254_FR = 1, NMX_F_PASTA_FP = 2, NMX_F_PASTA_FQ = 3 };
+/* out = a + r*b : RelaxedR1CSWitness::fold, W = W1 + r*W2 and E = E1 + r*T (src/r1cs/mod.rs:1058-1067) */
+int nmx_field_axpy(int field, const void* a, const void* b, const void* r, size_t n, uint32_t flags, void* out);
+/* out = a + r*b + r^2*c : fold_relaxed's E (src/r1cs/mod.rs:1096-1101) */
+int nmx_field_axpy2(int field, const void* a, const void* b, const void* c, const void* r, size_t n, uint32_t flags,
+                    void* out);
+/* out = az*bz - u*cz - e : the cross term T of commit_T (src/r1cs/mod.rs:614-620) */
+int nmx_field_cross_term(int field, const void* az, const void* bz, const void* cz, const void* e, const void* u,
+                         size_t n, uint32_t flags, void* out);
+/* out = a + b : Z = Z1 + Z2 (src/r1cs/mod.rs:590-609) */
+int nmx_field_vec_add(int field, const void* a, const void* b, size_t n, uint32_t flags, void* out);
+/* MultilinearPolynomial::bind_poly_var_top (src/spartan/polys/multilinear.rs:65-84):
+ * out[i] = z[i] + r*(z[i + len/2] - z[i]), i < len/2.  `out` may equal `z` (in place, as the reference does). */
+int nmx_mle_bind_top(int field, const void* z, size_t len, const void* r, uint32_t flags, void* out);
+/* HyperKZG fold step (src/provider/hyperkzg.rs:1085-1095): out[j] = p[2j] + x*(p[2j+1] - p[2j]), j < len/2 */
+int nmx_poly_fold_pairs(int field, const void* p, size_t len, const void* x, uint32_t flags, void* out);
+
 /* ---- measurement ------------------------------------------------------------------------------------
  * With profiling on, every MSM brackets its stages with hipEvents on the stream the kernels run on;
  * nmx_profile_last returns the last call's stage times in milliseconds (same thread).

@@ -41,6 +41,12 @@ def lib():
     L.nmx_msm_batch_handle.argtypes = [u64, vp, vp, sz, u32, vp, vp]
     L.nmx_commit.argtypes = [u64, vp, sz, vp, vp, u32, vp, vp]
     L.nmx_point_sum.argtypes = [i, vp, sz, vp, vp]
+    L.nmx_field_axpy.argtypes = [i, vp, vp, vp, sz, u32, vp]
+    L.nmx_field_axpy2.argtypes = [i, vp, vp, vp, vp, sz, u32, vp]
+    L.nmx_field_cross_term.argtypes = [i, vp, vp, vp, vp, vp, sz, u32, vp]
+    L.nmx_field_vec_add.argtypes = [i, vp, vp, sz, u32, vp]
+    L.nmx_mle_bind_top.argtypes = [i, vp, sz, vp, u32, vp]
+    L.nmx_poly_fold_pairs.argtypes = [i, vp, sz, vp, u32, vp]
     L.nmx_set_profiling.argtypes = [i]
     L.nmx_profile_last.argtypes = [ctypes.POINTER(ctypes.c_float), i]
     L.nmx_set_window_bits.argtypes = [u32]

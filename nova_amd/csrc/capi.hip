@@ -358,6 +358,62 @@ int nmx_point_sum(int curve, const uint8_t* partials128, size_t count, uint8_t* 
   });
 }
 
+// ---- field-vector kernels -------------------------------------------------------
+int nmx_field_axpy(int field, const void* a, const void* b, const void* r, size_t n, uint32_t flags, void* out) {
+  return guarded([&] {
+    require((a && b && out) || n == 0, NMX_E_ARG, "null argument");
+    require(r != nullptr, NMX_E_ARG, "null argument");
+    if (n == 0) return;
+    CtxLease L;
+    fv_axpy(*L.c, field, a, b, r, n, flags, out);
+  });
+}
+int nmx_field_axpy2(int field, const void* a, const void* b, const void* c, const void* r, size_t n, uint32_t flags,
+                    void* out) {
+  return guarded([&] {
+    require((a && b && c && out) || n == 0, NMX_E_ARG, "null argument");
+    require(r != nullptr, NMX_E_ARG, "null argument");
+    if (n == 0) return;
+    CtxLease L;
+    fv_axpy2(*L.c, field, a, b, c, r, n, flags, out);
+  });
+}
+int nmx_field_cross_term(int field, const void* az, const void* bz, const void* cz, const void* e, const void* u,
+                         size_t n, uint32_t flags, void* out) {
+  return guarded([&] {
+    require((az && bz && cz && e && out) || n == 0, NMX_E_ARG, "null argument");
+    require(u != nullptr, NMX_E_ARG, "null argument");
+    if (n == 0) return;
+    CtxLease L;
+    fv_cross_term(*L.c, field, az, bz, cz, e, u, n, flags, out);
+  });
+}
+int nmx_field_vec_add(int field, const void* a, const void* b, size_t n, uint32_t flags, void* out) {
+  return guarded([&] {
+    require((a && b && out) || n == 0, NMX_E_ARG, "null argument");
+    if (n == 0) return;
+    CtxLease L;
+    fv_vec_add(*L.c, field, a, b, n, flags, out);
+  });
+}
+int nmx_mle_bind_top(int field, const void* z, size_t len, const void* r, uint32_t flags, void* out) {
+  return guarded([&] {
+    require(z && out && r, NMX_E_ARG, "null argument");
+    require(len >= 2 && (len & 1) == 0, NMX_E_ARG, "len must be even and >= 2");  // assert!(self.num_vars > 0)
+    CtxLease L;
+    fv_bind(*L.c, field, z, len, 0, len / 2, 1, r, len / 2, flags, out);
+  });
+}
+int nmx_poly_fold_pairs(int field, const void* p, size_t len, const void* x, uint32_t flags, void* out) {
+  return guarded([&] {
+    require(p && out && x, NMX_E_ARG, "null argument");
+    require(len >= 2 && (len & 1) == 0, NMX_E_ARG, "len must be even and >= 2");
+    require(!((flags & NMX_SCALARS_DEVICE) && out == p), NMX_E_ARG, "pairwise fold cannot run in place");
+    CtxLease L;
+    fv_bind(*L.c, field, p, len, 0, 1, 2, x, len / 2, flags, out);
+  });
+}
+
 int nmx_set_profiling(int on) {
   G.profiling = on != 0;
   return NMX_OK;

@@ -164,6 +164,16 @@ struct CurveOps {
   void (*internal_to_canonical)(uint8_t* elems32, size_t count);  // host, in place
   void (*point_sum)(const uint8_t* partials128, size_t count, uint8_t* out, uint8_t* inf);  // host
 };
+// field-vector kernels (fieldvec.hip)
+void fv_axpy(Ctx&, int field, const void* a, const void* b, const void* r, size_t n, uint32_t flags, void* out);
+void fv_axpy2(Ctx&, int field, const void* a, const void* b, const void* c, const void* r, size_t n, uint32_t flags,
+              void* out);
+void fv_cross_term(Ctx&, int field, const void* az, const void* bz, const void* cz, const void* e, const void* u,
+                   size_t n, uint32_t flags, void* out);
+void fv_vec_add(Ctx&, int field, const void* a, const void* b, size_t n, uint32_t flags, void* out);
+void fv_bind(Ctx&, int field, const void* z, size_t z_len, size_t lo_off, size_t hi_off, size_t stride, const void* r,
+             size_t n_out, uint32_t flags, void* out);
+
 const CurveOps& curve_ops_bn254_g1();
 const CurveOps& curve_ops_grumpkin();
 const CurveOps& curve_ops_pallas();

@@ -1,0 +1,111 @@
+"""Field-vector kernels either side of the MSM: thin marshalling over the C ABI.
+
+Reference sites (relative to /root/reference):
+  axpy        W = W1 + r*W2, E = E1 + r*T           src/r1cs/mod.rs:1058-1067   (RelaxedR1CSWitness::fold)
+  axpy2       E = E1 + r*T + r^2*E2                 src/r1cs/mod.rs:1096-1101   (fold_relaxed)
+  cross_term  T = AZ o BZ - u*CZ - E                src/r1cs/mod.rs:614-620     (commit_T)
+  vec_add     Z = Z1 + Z2                           src/r1cs/mod.rs:590-609
+  bind_poly_var_top                                 src/spartan/polys/multilinear.rs:65-84
+  fold_pairs  Pi[j] = P[2j] + x*(P[2j+1] - P[2j])   src/provider/hyperkzg.rs:1085-1095
+Vectors: (n, 32) uint8 numpy arrays (host) or torch CUDA uint8 tensors (HBM-resident; the result is then a CUDA
+tensor too and can be passed straight to DlogGroup.vartime_multiscalar_mul).  Field ids as include/nova_mi355x.h.
+"""
+import numpy as np
+
+from . import _lib as L
+from .provider import _check, _host_u8, _is_device_tensor
+
+BN254_FQ, BN254_FR, PASTA_FP, PASTA_FQ = 0, 1, 2, 3
+SCALAR_FIELD_OF_CURVE = {0: BN254_FR, 1: BN254_FQ, 2: PASTA_FQ, 3: PASTA_FP}
+
+
+def _vec(x):
+    if _is_device_tensor(x):
+        assert x.is_contiguous() and x.numel() * x.element_size() % 32 == 0
+        return x.data_ptr(), x.numel() * x.element_size() // 32, True, x
+    a = _host_u8(x, 32)
+    return a.ctypes.data, a.size // 32, False, a
+
+
+def _out_like(dev, n, ref):
+    if dev:
+        import torch
+        o = torch.empty((n, 32), dtype=torch.uint8, device=ref.device)
+        return o.data_ptr(), o
+    o = np.zeros((n, 32), dtype=np.uint8)
+    return o.ctypes.data, o
+
+
+def _chal(r):
+    a = _host_u8(r, 32)
+    assert a.size == 32
+    return a
+
+
+def _flags(dev, mont):
+    return (L.SCALARS_DEVICE if dev else 0) | (L.SCALARS_MONT if mont else 0)
+
+
+def axpy(field, a, b, r, mont=False):
+    pa, n, dev, _ka = _vec(a)
+    pb, nb, devb, _kb = _vec(b)
+    assert n == nb and dev == devb, "InvalidWitnessLength (r1cs/mod.rs:1054-1056)"
+    po, out = _out_like(dev, n, a)
+    rr = _chal(r)
+    _check(L.lib().nmx_field_axpy(field, pa, pb, rr.ctypes.data, n, _flags(dev, mont), po))
+    return out
+
+
+def axpy2(field, a, b, c, r, mont=False):
+    pa, n, dev, _ka = _vec(a)
+    pb, nb, _d1, _kb = _vec(b)
+    pc, nc, _d2, _kc = _vec(c)
+    assert n == nb == nc
+    po, out = _out_like(dev, n, a)
+    rr = _chal(r)
+    _check(L.lib().nmx_field_axpy2(field, pa, pb, pc, rr.ctypes.data, n, _flags(dev, mont), po))
+    return out
+
+
+def cross_term(field, az, bz, cz, e, u, mont=False):
+    p1, n, dev, _k1 = _vec(az)
+    p2, n2, _d2, _k2 = _vec(bz)
+    p3, n3, _d3, _k3 = _vec(cz)
+    p4, n4, _d4, _k4 = _vec(e)
+    assert n == n2 == n3 == n4
+    po, out = _out_like(dev, n, az)
+    uu = _chal(u)
+    _check(L.lib().nmx_field_cross_term(field, p1, p2, p3, p4, uu.ctypes.data, n, _flags(dev, mont), po))
+    return out
+
+
+def vec_add(field, a, b, mont=False):
+    pa, n, dev, _ka = _vec(a)
+    pb, nb, _d, _kb = _vec(b)
+    assert n == nb
+    po, out = _out_like(dev, n, a)
+    _check(L.lib().nmx_field_vec_add(field, pa, pb, n, _flags(dev, mont), po))
+    return out
+
+
+def bind_poly_var_top(field, z, r, mont=False, in_place=False):
+    """Returns the bound polynomial (len/2 evaluations).  in_place (device tensors only) overwrites z[:len/2]."""
+    pz, n, dev, _kz = _vec(z)
+    assert n >= 2 and n % 2 == 0, "assert!(self.num_vars > 0)"
+    rr = _chal(r)
+    if in_place:
+        assert dev
+        _check(L.lib().nmx_mle_bind_top(field, pz, n, rr.ctypes.data, _flags(dev, mont), pz))
+        return z.view(-1)[: (n // 2) * 32].view(n // 2, 32)
+    po, out = _out_like(dev, n // 2, z)
+    _check(L.lib().nmx_mle_bind_top(field, pz, n, rr.ctypes.data, _flags(dev, mont), po))
+    return out
+
+
+def fold_pairs(field, p, x, mont=False):
+    pp, n, dev, _kp = _vec(p)
+    assert n >= 2 and n % 2 == 0
+    xx = _chal(x)
+    po, out = _out_like(dev, n // 2, p)
+    _check(L.lib().nmx_poly_fold_pairs(field, pp, n, xx.ctypes.data, _flags(dev, mont), po))
+    return out

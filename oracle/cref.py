@@ -40,6 +40,9 @@ def lib():
         L.ref_batch_add.argtypes = [ctypes.c_int, vp, sz, vp, sz, vp, vp]
         L.ref_sequential_bases.argtypes = [ctypes.c_int, vp, u64, sz, vp]
         L.ref_field_axpy.argtypes = [ctypes.c_int, vp, vp, vp, sz, vp]
+        L.ref_field_axpy2.argtypes = [ctypes.c_int, vp, vp, vp, vp, sz, vp]
+        L.ref_field_cross_term.argtypes = [ctypes.c_int, vp, vp, vp, vp, vp, sz, vp]
+        L.ref_field_bind.argtypes = [ctypes.c_int, vp, sz, sz, sz, vp, sz, vp]
         _lib = L
     return _lib
 
@@ -166,4 +169,26 @@ def field_axpy(fid, a, b, r, n):
     rp, _r = _buf(r)
     out = np.zeros(32 * n, dtype=np.uint8)
     lib().ref_field_axpy(fid, ap, bp, rp, n, out.ctypes.data)
+    return out.tobytes()
+
+
+def field_axpy2(fid, a, b, c, r, n):
+    ps = [_buf(x) for x in (a, b, c, r)]
+    out = np.zeros(32 * n, dtype=np.uint8)
+    lib().ref_field_axpy2(fid, ps[0][0], ps[1][0], ps[2][0], ps[3][0], n, out.ctypes.data)
+    return out.tobytes()
+
+
+def field_cross_term(fid, az, bz, cz, e, u, n):
+    ps = [_buf(x) for x in (az, bz, cz, e, u)]
+    out = np.zeros(32 * n, dtype=np.uint8)
+    lib().ref_field_cross_term(fid, ps[0][0], ps[1][0], ps[2][0], ps[3][0], ps[4][0], n, out.ctypes.data)
+    return out.tobytes()
+
+
+def field_bind(fid, z, lo, hi, stride, r, n_out):
+    pz, _z = _buf(z)
+    pr, _r = _buf(r)
+    out = np.zeros(32 * n_out, dtype=np.uint8)
+    lib().ref_field_bind(fid, pz, lo, hi, stride, pr, n_out, out.ctypes.data)
     return out.tobytes()

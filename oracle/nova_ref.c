@@ -700,3 +700,50 @@ int ref_field_axpy(int field, const uint8_t* a, const uint8_t* b, const uint8_t*
   }
   return 0;
 }
+
+/* ---- remaining field-vector restatements, canonical in/out ---------------------------- */
+static const field_t* field_by_id(int f) {
+  static const field_t* FS[4] = {&F_BN_Q, &F_BN_R, &F_PA_P, &F_PA_Q};
+  return (f < 0 || f > 3) ? NULL : FS[f];
+}
+static inline void ld_mont(const field_t* F, fe* r, const uint8_t* p) { fe t; memcpy(&t, p, 32); fe_to_mont(F, r, &t); }
+static inline void st_canon(const field_t* F, uint8_t* p, const fe* v) { fe t; fe_from_mont(F, &t, v); memcpy(p, &t, 32); }
+/* E = E1 + r*T + r^2*E2 (r1cs/mod.rs:1096-1101) */
+int ref_field_axpy2(int field, const uint8_t* a, const uint8_t* b, const uint8_t* c, const uint8_t* r, size_t n, uint8_t* out) {
+  const field_t* F = field_by_id(field); if (!F) return -1;
+  fe rr, rr2; ld_mont(F, &rr, r); fe_mul(F, &rr2, &rr, &rr);
+#pragma omp parallel for num_threads(nthreads())
+  for (long i = 0; i < (long)n; i++) {
+    fe x, y, z, t; ld_mont(F, &x, a + 32 * i); ld_mont(F, &y, b + 32 * i); ld_mont(F, &z, c + 32 * i);
+    fe_mul(F, &t, &rr, &y); fe_add(F, &x, &x, &t); fe_mul(F, &t, &rr2, &z); fe_add(F, &x, &x, &t);
+    st_canon(F, out + 32 * i, &x);
+  }
+  return 0;
+}
+/* T = az*bz - u*cz - e (r1cs/mod.rs:614-620) */
+int ref_field_cross_term(int field, const uint8_t* az, const uint8_t* bz, const uint8_t* cz, const uint8_t* e, const uint8_t* u,
+                         size_t n, uint8_t* out) {
+  const field_t* F = field_by_id(field); if (!F) return -1;
+  fe uu; ld_mont(F, &uu, u);
+#pragma omp parallel for num_threads(nthreads())
+  for (long i = 0; i < (long)n; i++) {
+    fe a, b, c, ee, t; ld_mont(F, &a, az + 32 * i); ld_mont(F, &b, bz + 32 * i); ld_mont(F, &c, cz + 32 * i); ld_mont(F, &ee, e + 32 * i);
+    fe_mul(F, &a, &a, &b); fe_mul(F, &t, &uu, &c); fe_sub(F, &a, &a, &t); fe_sub(F, &a, &a, &ee);
+    st_canon(F, out + 32 * i, &a);
+  }
+  return 0;
+}
+/* out[i] = z[lo + i*stride] + r*(z[hi + i*stride] - z[lo + i*stride]):
+ * bind_poly_var_top (multilinear.rs:65-84: lo = 0, hi = len/2, stride 1) and the HyperKZG halving
+ * (hyperkzg.rs:1085-1095: lo = 0, hi = 1, stride 2) */
+int ref_field_bind(int field, const uint8_t* z, size_t lo, size_t hi, size_t stride, const uint8_t* r, size_t n_out, uint8_t* out) {
+  const field_t* F = field_by_id(field); if (!F) return -1;
+  fe rr; ld_mont(F, &rr, r);
+#pragma omp parallel for num_threads(nthreads())
+  for (long i = 0; i < (long)n_out; i++) {
+    fe a, b, t; ld_mont(F, &a, z + 32 * (lo + i * stride)); ld_mont(F, &b, z + 32 * (hi + i * stride));
+    fe_sub(F, &t, &b, &a); fe_mul(F, &t, &rr, &t); fe_add(F, &a, &a, &t);
+    st_canon(F, out + 32 * i, &a);
+  }
+  return 0;
+}

@@ -207,3 +207,18 @@ def bind_poly_var_top(p, Z, r):
     """Z[i] = Z[i] + r*(Z[i+n] - Z[i]), n = len/2 (src/spartan/polys/multilinear.rs:65-84)."""
     n = len(Z) // 2
     return [(Z[i] + r * (Z[i + n] - Z[i])) % p for i in range(n)]
+
+
+def axpy2(p, a, b, c, r):
+    """E = E1 + r*T + r^2*E2 (src/r1cs/mod.rs:1096-1101)."""
+    return [(x + r * y + r * r * z) % p for x, y, z in zip(a, b, c)]
+
+
+def cross_term(p, az, bz, cz, e, u):
+    """T = AZ o BZ - u*CZ - E (src/r1cs/mod.rs:614-620)."""
+    return [(a * b - u * c - ee) % p for a, b, c, ee in zip(az, bz, cz, e)]
+
+
+def fold_pairs(p, P, x):
+    """Pi[j] = P[2j] + x*(P[2j+1] - P[2j]) (src/provider/hyperkzg.rs:1085-1095)."""
+    return [(P[2 * j] + x * (P[2 * j + 1] - P[2 * j])) % p for j in range(len(P) // 2)]

@@ -1,0 +1,38 @@
+"""CPU: pins the oracle's field-vector restatements (oracle/nova_ref.c) against the big-int definitions and the
+reference's known-answer tests (tests/golden/field_kats.json)."""
+import pytest
+
+from oracle import cref
+from oracle import pyref as R
+from tests import fv_common as C
+
+
+def test_oracle_kats():
+    C.check_kats(lambda fid, p, x: cref.field_bind(fid, p, 0, 1, 2, x, len(p) // 2),
+                 lambda fid, z, r: cref.field_bind(fid, z, 0, len(z) // 2, 1, r, len(z) // 2))
+    # the definitions themselves
+    for case in C.KATS["hyperkzg_fold_eval"]["cases"]:
+        cur = case["poly"]
+        for x in reversed(case["point"]):
+            cur = R.fold_pairs(R.BN254_R, cur, x)
+        assert cur == [case["eval"]]
+    for case in C.KATS["mle_bind_top_eval"]["cases"]:
+        cur = case["evals"]
+        for r in case["point"]:
+            cur = R.bind_poly_var_top(R.BN254_R, cur, r)
+        assert cur == [case["eval"]]
+
+
+@pytest.mark.parametrize("fid", range(4))
+def test_oracle_field_vectors(fid):
+    p = C.FIELDS[fid]
+    n = 64
+    a, b, c, e = (C.edge_vectors(fid, n, s) for s in (1, 2, 3, 4))
+    r = C.rand_vec(fid, 1, 9)
+    ri = C.ints(r)[0]
+    enc = lambda xs: b"".join(R.fe_to_le32(x) for x in xs)
+    assert cref.field_axpy(fid, a, b, r, n) == enc(R.axpy(p, C.ints(a), C.ints(b), ri))
+    assert cref.field_axpy2(fid, a, b, c, r, n) == enc(R.axpy2(p, C.ints(a), C.ints(b), C.ints(c), ri))
+    assert cref.field_cross_term(fid, a, b, c, e, r, n) == enc(R.cross_term(p, C.ints(a), C.ints(b), C.ints(c), C.ints(e), ri))
+    assert cref.field_bind(fid, a, 0, n // 2, 1, r, n // 2) == enc(R.bind_poly_var_top(p, C.ints(a), ri))
+    assert cref.field_bind(fid, a, 0, 1, 2, r, n // 2) == enc(R.fold_pairs(p, C.ints(a), ri))
