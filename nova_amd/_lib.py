@@ -22,6 +22,13 @@ def lib():
         raise RuntimeError(
             f"{SO_PATH} is missing: build the HIP extension first (__graft_entry__.build()); "
             "nova_amd has no CPU fallback")
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.  If this library pulled in
+    # /opt/rocm's copy first, a later `import torch` would bring up a second runtime that cannot see the GPU
+    # ("No HIP GPUs are available").  Loading torch first makes both share torch's copy.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(SO_PATH)
     i, u32, u64, sz, vp = ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_size_t, ctypes.c_void_p
     L.nmx_init.argtypes = [i]
