@@ -39,7 +39,8 @@ def main():
     ap.add_argument("--dist", default="random", help="scalar distribution: random | u1 | u10 | u16 | u32 | u64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--window-bits", type=int, default=0)
-    ap.add_argument("--workload", default="msm", choices=["msm", "axpy", "cross_term", "bind"],
+    ap.add_argument("--iters", type=int, default=65536, help="prove_step_replay: MinRoot iterations per step")
+    ap.add_argument("--workload", default="msm", choices=["msm", "axpy", "cross_term", "bind", "prove_step_replay"],
                     help="msm = the headline (default); the others time one HBM-bound field-vector kernel of "
                          "SURVEY.md 8(f) at 2^log2n elements per GPU")
     args = ap.parse_args()
@@ -64,6 +65,8 @@ def main():
     if args.window_bits:
         L.nmx_set_window_bits(args.window_bits)
 
+    if args.workload == "prove_step_replay":
+        return prove_step_replay(args, world, rank, L, torch, dist)
     if args.workload != "msm":
         return field_workload(args, world, rank, L, torch, dist)
 
@@ -157,6 +160,128 @@ def main():
         dist.destroy_process_group()
 
 
+def witness_like(cid, n, seed):
+    """Scalars shaped like an R1CS witness: half zeros, a quarter small (< 2^16), a quarter full-width
+    (why msm() partitions by bit width, src/provider/msm.rs:237-279)."""
+    from tests import util
+    v = util.random_scalars(cid, n, seed=seed).copy()
+    rng = np.random.Generator(np.random.PCG64(seed))
+    kind = rng.integers(0, 4, size=n)
+    v[kind < 2] = 0
+    small = util.u64_to_le32(util.small_scalars(n, 16, seed=seed))
+    v[kind == 2] = small[kind == 2]
+    return v
+
+
+def prove_step_replay(args, world, rank, L, torch, dist):
+    """REPLAY of the provider calls of one RecursiveSNARK::prove_step (src/nova/mod.rs:456-541, SURVEY.md 3(B)) on the
+    MinRoot step circuit (examples/minroot.rs: 3 constraints per iteration + the 9 986-constraint augmented circuit
+    on BN254, 10 538 on Grumpkin): 4 MSMs + 2 cross terms + 4 AXPY folds, vectors resident in HBM, commitments
+    returned to the host after each MSM (they feed the Poseidon RO challenge on the reference side).  NOT replayed:
+    witness synthesis, Poseidon hashing and the sparse matrix-vector products (CPU side of the reference; SpMV is
+    SURVEY 8(f) row 3, not built yet).  This is a replay, not prove_step: the Rust reference cannot be built here."""
+    import nova_amd
+    from nova_amd import fieldvec as fv
+    from tests import util
+    assert world == 1, "prove_step is sequential: replicas only"
+    N = 3 * args.iters + 9986          # primary (BN254) witness / constraint count
+    n2 = 10538                         # secondary (Grumpkin)
+    cur = {"P": (0, fv.SCALAR_FIELD_OF_CURVE[0], N), "S": (1, fv.SCALAR_FIELD_OF_CURVE[1], n2)}
+    ce = {k: nova_amd.CommitmentEngine(c[0]) for k, c in cur.items()}
+    ck = {k: ce[k].setup_synthetic(c[2], k0=3) for k, c in cur.items()}
+    host, dev = {}, {}
+    for k, (cid, fid, n) in cur.items():
+        host[k] = {"W": witness_like(cid, n, 11), "W1": util.random_scalars(cid, n, seed=12),
+                   "E1": util.random_scalars(cid, n, seed=13)}
+        for j, nm in enumerate(("AZ", "BZ", "CZ")):
+            host[k][nm] = util.random_scalars(cid, n, seed=20 + j)
+        dev[k] = {nm: torch.from_numpy(v).cuda() for nm, v in host[k].items()}
+    u = util.random_scalars(0, 1, seed=31)
+    r = {k: util.random_scalars(c[0], 1, seed=32) for k, c in cur.items()}
+    rT = {k: util.random_scalars(c[0], 1, seed=33) for k, c in cur.items()}
+    uS = util.random_scalars(1, 1, seed=34)
+
+    def nifs(k, uu):
+        cid, fid, n = cur[k]
+        d = dev[k]
+        T = fv.cross_term(fid, d["AZ"], d["BZ"], d["CZ"], d["E1"], uu)     # r1cs/mod.rs:614-620
+        comT = ce[k].commit(ck[k], T, rT[k])                                  # r1cs/mod.rs:622
+        W = fv.axpy(fid, d["W1"], d["W"], r[k])                               # r1cs/mod.rs:1058-1062
+        E = fv.axpy(fid, d["E1"], T, r[k])                                    # r1cs/mod.rs:1063-1067
+        return comT, W, E
+
+    def step():
+        out = []
+        out.append(nifs("S", uS)[0])                                          # nova/mod.rs:464  NIFS on the secondary
+        out.append(ce["P"].commit(ck["P"], dev["P"]["W"]))                    # nova/mod.rs:477-496 primary witness commit
+        out.append(nifs("P", u)[0])                                           # nova/mod.rs:502  NIFS on the primary
+        out.append(ce["S"].commit(ck["S"], dev["S"]["W"]))                    # nova/mod.rs:515-541 secondary witness commit
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    outj = {
+        "metric": "RecursiveSNARK prove_step provider-call REPLAY ms (minroot, BN254/Grumpkin)", "value": dt * 1e3, "unit": "ms",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": False,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (256-bit modular integer)", "data": "synthetic",
+        "config": {"workload": f"prove_step replay: minroot {args.iters} iterations/step -> primary N={N} (BN254), secondary n={n2} "
+                               "(Grumpkin); 4 MSMs + 2 cross terms + 4 folds; no SpMV / synthesis / Poseidon (BASELINE.json configs[3])"},
+        "roofline": None,
+    }
+    if not args.no_cpu_baseline:
+        from oracle import cref
+        threads = effective_cpus()
+        cref.set_threads(threads)
+        keys = {k: ck[k].read(0, cur[k][2]) for k in cur}
+        prep = {k: cref.Prepared(cur[k][0], keys[k], cur[k][2]) for k in cur}
+        t1 = time.perf_counter()
+        exp = []
+        for k, uu in (("S", uS), ("P", u)):
+            cid, fid, n = cur[k]
+            h = host[k]
+            T = cref.field_cross_term(fid, h["AZ"], h["BZ"], h["CZ"], h["E1"], uu, n)
+            comT = cref.commit(cid, T, keys[k], n, ck[k].h, rT[k])
+            cref.field_axpy(fid, h["W1"], h["W"], r[k], n)
+            cref.field_axpy(fid, h["E1"], T, r[k], n)
+            comW = prep[k].msm(h["W"], n)
+            exp.append((comT, comW))
+        t_cpu = time.perf_counter() - t1
+        ok = [(res[0].xy, int(res[0].is_inf)) == exp[0][0], (res[1].xy, int(res[1].is_inf)) == exp[1][1],
+              (res[2].xy, int(res[2].is_inf)) == exp[1][0], (res[3].xy, int(res[3].is_inf)) == exp[0][1]]
+        outj["cpu_baseline"] = {"value": t_cpu * 1e3, "unit": "ms", "cores": threads, "kind": "port",
+                                "sample": "the same call sequence once through oracle/nova_ref.c (commit re-loads the key "
+                                          "each call, as a fresh Vec<Affine> would not)", "gpu_matches_cpu": all(ok)}
+    print(json.dumps(outj), flush=True)
+    for k in ck:
+        ck[k].close()
+
+
+def effective_cpus():
+    """Host cores this process may actually use: min(affinity, cgroup CPU quota).  The GPU boxes expose 256
+    hardware threads but a 16-CPU cgroup quota; oversubscribing it makes the OpenMP baseline 4x slower
+    (profiles/r01_msm_2p20/cpu_baseline_thread_scaling.txt)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def field_workload(args, world, rank, L, torch, dist):
     """One HBM-bound field-vector kernel per step on HBM-resident vectors (BN254 scalar field unless --curve):
     axpy = NIFS witness fold (r1cs/mod.rs:1058-1067), cross_term = commit_T's T (r1cs/mod.rs:614-620),
@@ -221,7 +346,7 @@ def field_workload(args, world, rank, L, torch, dist):
         }
         if world == 1 and not args.no_cpu_baseline:
             from oracle import cref
-            threads = os.cpu_count() or 1
+            threads = effective_cpus()
             cref.set_threads(threads)
             m = min(n, 1 << 22)
             t1 = time.perf_counter()
@@ -247,7 +372,7 @@ def cpu_baseline(cid, ck, scalars, n, gpu_result):
     """The oracle (C restatement of the reference's msm(), OpenMP over all host cores) timed on the same inputs,
     bounded to ~10-30 s of CPU work; also cross-checks the GPU result when the sample is the whole workload."""
     from oracle import cref
-    threads = os.cpu_count() or 1
+    threads = effective_cpus()
     cref.set_threads(threads)
     sample = min(n, 1 << 20)
     host = ck.read(0, sample)

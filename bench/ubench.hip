@@ -76,6 +76,55 @@ __global__ __launch_bounds__(256) void k_dfma(double* out, double a, double b) {
   out[blockIdx.x * 256 + threadIdx.x] = x0 + x1 + x2 + x3;
 }
 
+__global__ __launch_bounds__(256) void k_shr64_only(uint64_t* out, uint32_t a) {
+  uint64_t x0 = threadIdx.x * 0x9E3779B97F4A7C15ull + a, x1 = x0 * 3, x2 = x0 * 5, x3 = x0 * 7;
+  for (int i = 0; i < ITERS; i++) {
+    asm volatile("v_lshrrev_b64 %0, 1, %0\n\tv_lshrrev_b64 %1, 1, %1\n\tv_lshrrev_b64 %2, 1, %2\n\tv_lshrrev_b64 %3, 1, %3"
+                 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = x0 ^ x1 ^ x2 ^ x3;
+}
+__global__ __launch_bounds__(256) void k_add64(uint64_t* out, uint32_t a) {
+  uint64_t x0 = threadIdx.x + a, x1 = x0 * 3, x2 = x0 * 5, x3 = x0 * 7;
+  for (int i = 0; i < ITERS; i++) {
+    asm volatile("v_lshl_add_u64 %0, %1, 0, %0\n\tv_lshl_add_u64 %1, %2, 0, %1\n\tv_lshl_add_u64 %2, %3, 0, %2\n\tv_lshl_add_u64 %3, %0, 0, %3"
+                 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = x0 ^ x1 ^ x2 ^ x3;
+}
+__global__ __launch_bounds__(256) void k_alignbit(uint32_t* out, uint32_t a) {
+  uint32_t x0 = threadIdx.x + a, x1 = x0 * 3, x2 = x0 * 5, x3 = x0 * 7;
+  for (int i = 0; i < ITERS; i++) {
+    asm volatile("v_alignbit_b32 %0, %1, %0, 29\n\tv_alignbit_b32 %1, %2, %1, 29\n\tv_alignbit_b32 %2, %3, %2, 29\n\tv_alignbit_b32 %3, %0, %3, 29"
+                 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = x0 ^ x1 ^ x2 ^ x3;
+}
+__global__ __launch_bounds__(256) void k_mad24(uint32_t* out, uint32_t a) {
+  uint32_t x0 = threadIdx.x + a, x1 = x0 * 3, x2 = x0 * 5, x3 = x0 * 7;
+  for (int i = 0; i < ITERS; i++) {
+    asm volatile("v_mad_u32_u24 %0, %1, %2, %0\n\tv_mad_u32_u24 %1, %2, %3, %1\n\tv_mad_u32_u24 %2, %3, %0, %2\n\tv_mad_u32_u24 %3, %0, %1, %3"
+                 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = x0 ^ x1 ^ x2 ^ x3;
+}
+__global__ __launch_bounds__(256) void k_mulhi24(uint32_t* out, uint32_t a) {
+  uint32_t x0 = threadIdx.x + a, x1 = x0 * 3, x2 = x0 * 5, x3 = x0 * 7;
+  for (int i = 0; i < ITERS; i++) {
+    asm volatile("v_mul_hi_u32_u24 %0, %1, %0\n\tv_mul_hi_u32_u24 %1, %2, %1\n\tv_mul_hi_u32_u24 %2, %3, %2\n\tv_mul_hi_u32_u24 %3, %0, %3"
+                 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = x0 ^ x1 ^ x2 ^ x3;
+}
+__global__ __launch_bounds__(256) void k_add3(uint32_t* out, uint32_t a) {
+  uint32_t x0 = threadIdx.x + a, x1 = x0 * 3, x2 = x0 * 5, x3 = x0 * 7;
+  for (int i = 0; i < ITERS; i++) {
+    asm volatile("v_add3_u32 %0, %1, %2, %0\n\tv_add3_u32 %1, %2, %3, %1\n\tv_add3_u32 %2, %3, %0, %2\n\tv_add3_u32 %3, %0, %1, %3"
+                 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = x0 ^ x1 ^ x2 ^ x3;
+}
+
 // --- shipped field / curve arithmetic (fp.hpp, curve.hpp) ---------------------------------------------
 // The saturated-32-bit-limb candidates this design was chosen against (C++ 96-bit accumulator 68 G/s, inline-asm
 // v_mad_u64_u32 + v_addc 119 G/s, CIOS 95 G/s, vs 9 x 29-bit 173 G/s) were measured with an earlier revision of
@@ -146,6 +195,19 @@ int main() {
   printf("{\"ubench\": \"v_add_u32+v_xor\", \"Gops\": %.1f}\n", 2 * lanes_ops / ms * 1e-6);
   ms = time_ms([&] { k_dfma<<<blocks, 256>>>((double*)buf, 1.0000001, 1e-9); });
   printf("{\"ubench\": \"v_fma_f64\", \"Gops\": %.1f}\n", lanes_ops / ms * 1e-6);
+
+  ms = time_ms([&] { k_shr64_only<<<blocks, 256>>>((uint64_t*)buf, 3u); });
+  printf("{\"ubench\": \"v_lshrrev_b64\", \"Gops\": %.1f}\n", lanes_ops / ms * 1e-6);
+  ms = time_ms([&] { k_add64<<<blocks, 256>>>((uint64_t*)buf, 3u); });
+  printf("{\"ubench\": \"v_lshl_add_u64\", \"Gops\": %.1f}\n", lanes_ops / ms * 1e-6);
+  ms = time_ms([&] { k_alignbit<<<blocks, 256>>>((uint32_t*)buf, 3u); });
+  printf("{\"ubench\": \"v_alignbit_b32\", \"Gops\": %.1f}\n", lanes_ops / ms * 1e-6);
+  ms = time_ms([&] { k_mad24<<<blocks, 256>>>((uint32_t*)buf, 3u); });
+  printf("{\"ubench\": \"v_mad_u32_u24\", \"Gops\": %.1f}\n", lanes_ops / ms * 1e-6);
+  ms = time_ms([&] { k_mulhi24<<<blocks, 256>>>((uint32_t*)buf, 3u); });
+  printf("{\"ubench\": \"v_mul_hi_u32_u24\", \"Gops\": %.1f}\n", lanes_ops / ms * 1e-6);
+  ms = time_ms([&] { k_add3<<<blocks, 256>>>((uint32_t*)buf, 3u); });
+  printf("{\"ubench\": \"v_add3_u32\", \"Gops\": %.1f}\n", lanes_ops / ms * 1e-6);
 
   // random-ish field elements < p: clear the top 3 bits
   {
