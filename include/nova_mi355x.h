@@ -144,6 +144,17 @@ int nmx_mle_bind_top(int field, const void* z, size_t len, const void* r, uint32
 /* HyperKZG fold step (src/provider/hyperkzg.rs:1085-1095): out[j] = p[2j] + x*(p[2j+1] - p[2j]), j < len/2 */
 int nmx_poly_fold_pairs(int field, const void* p, size_t len, const void* x, uint32_t flags, void* out);
 
+/* The N-scaling sums of one eq-factored sum-check round (src/spartan/sumcheck.rs:900-1075), over id in [0, len/2)
+ * with x0 = X[id], x1 = X[id + len/2] and factor = eqL[id >> shift] * eqR[id & (2^shift - 1)] (first-half rounds,
+ * sumcheck.rs:1233-1247) or factor = eqR[id] when eqL == NULL (last half, sumcheck.rs:1249-1251):
+ *   mode 3 (A, B, C): out = (sum (a0*b0 - c0)*factor, sum (a1-a0)*(b1-b0)*factor)    cubic_with_three_inputs
+ *   mode 2 (A, B):    out = (sum (a0*b0 - 1)*factor,  sum (a1-a0)*(b1-b0)*factor)    cubic_with_two_inputs
+ *   mode 1 (A):       out = (sum a0*factor, 0)                                        quadratic_with_one_input
+ * out64 = two field elements in the vectors' own form (host pointer).  The O(1) derivation of the round polynomial
+ * from these sums and the claim stays on the caller's side (sumcheck.rs:686-753). */
+int nmx_sumcheck_eq_sums(int field, int mode, const void* A, const void* B, const void* C, size_t len, const void* eqL,
+                         size_t n_eqL, const void* eqR, size_t n_eqR, uint32_t shift, uint32_t flags, uint8_t* out64);
+
 /* ---- measurement ------------------------------------------------------------------------------------
  * With profiling on, every MSM brackets its stages with hipEvents on the stream the kernels run on;
  * nmx_profile_last returns the last call's stage times in milliseconds (same thread).

@@ -54,6 +54,7 @@ def lib():
     L.nmx_field_vec_add.argtypes = [i, vp, vp, sz, u32, vp]
     L.nmx_mle_bind_top.argtypes = [i, vp, sz, vp, u32, vp]
     L.nmx_poly_fold_pairs.argtypes = [i, vp, sz, vp, u32, vp]
+    L.nmx_sumcheck_eq_sums.argtypes = [i, i, vp, vp, vp, sz, vp, sz, vp, sz, u32, u32, vp]
     L.nmx_set_profiling.argtypes = [i]
     L.nmx_profile_last.argtypes = [ctypes.POINTER(ctypes.c_float), i]
     L.nmx_set_window_bits.argtypes = [u32]

@@ -414,6 +414,24 @@ int nmx_poly_fold_pairs(int field, const void* p, size_t len, const void* x, uin
   });
 }
 
+int nmx_sumcheck_eq_sums(int field, int mode, const void* A, const void* B, const void* C, size_t len, const void* eqL,
+                         size_t n_eqL, const void* eqR, size_t n_eqR, uint32_t shift, uint32_t flags, uint8_t* out64) {
+  return guarded([&] {
+    require(A && eqR && out64, NMX_E_ARG, "null argument");
+    require(mode >= 1 && mode <= 3 && (mode < 2 || B) && (mode < 3 || C), NMX_E_ARG, "missing input polynomial");
+    require(len >= 2 && (len & 1) == 0 && len / 2 < (1ull << 31), NMX_E_ARG, "len must be even");
+    const size_t h = len / 2;
+    if (eqL) {
+      require(shift < 32 && n_eqR == ((size_t)1 << shift) && ((h - 1) >> shift) < n_eqL, NMX_E_ARG,
+              "eq tables do not cover the index range");  // poly_eq_right.len() == 1 << second_half (sumcheck.rs:1238)
+    } else {
+      require(n_eqR >= h, NMX_E_ARG, "eq table shorter than the half length");
+    }
+    CtxLease L;
+    fv_eq_sums(*L.c, field, mode, A, B, C, len, eqL, n_eqL, eqR, n_eqR, shift, flags, out64);
+  });
+}
+
 int nmx_set_profiling(int on) {
   G.profiling = on != 0;
   return NMX_OK;

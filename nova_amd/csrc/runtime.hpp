@@ -174,6 +174,9 @@ void fv_vec_add(Ctx&, int field, const void* a, const void* b, size_t n, uint32_
 void fv_bind(Ctx&, int field, const void* z, size_t z_len, size_t lo_off, size_t hi_off, size_t stride, const void* r,
              size_t n_out, uint32_t flags, void* out);
 
+void fv_eq_sums(Ctx&, int field, int mode, const void* A, const void* B, const void* C, size_t len, const void* eqL,
+                size_t nL, const void* eqR, size_t nR, uint32_t shift, uint32_t flags, uint8_t* out);  // sumcheck.hip
+
 const CurveOps& curve_ops_bn254_g1();
 const CurveOps& curve_ops_grumpkin();
 const CurveOps& curve_ops_pallas();

@@ -1,0 +1,200 @@
+// sumcheck.hip -- the N-scaling sums of Spartan's eq-factored sum-check rounds.
+//
+// One launch computes, over id in [0, h) with (x0, x1) = (X[id], X[id + h]) and
+// factor(id) = eqL[id >> shift] * eqR[id & mask]   (first-half rounds; eqL == nullptr: factor = eqR[id], last half),
+//   mode 3  t_0 = sum (a0*b0 - c0) * factor,  t_inf = sum (a1-a0)*(b1-b0) * factor
+//           EqSumCheckInstance::evaluation_points_cubic_with_three_inputs, /root/reference/src/spartan/sumcheck.rs:900-958
+//   mode 2  t_0 = sum (a0*b0 - 1) * factor,   t_inf as above      ..._cubic_with_two_inputs, sumcheck.rs:972-1037
+//   mode 1  t_0 = sum a0 * factor                                 ..._quadratic_with_one_input, sumcheck.rs:1039-1075
+// The O(1) derivation of the round polynomial from (t_0, t_inf, claim) (sumcheck.rs:686-753), the eq tables
+// (O(sqrt n), sumcheck.rs:608-660) and the transcript stay on the host side of the reference.
+//
+// HBM-bound: 160 B (mode 3) / 128 B (mode 2) / 32 B (mode 1) per index against 6 / 5 / 2 modmuls.  Lanes read
+// consecutive elements (32 B per lane, coalesced); per-lane partial sums are combined by an LDS tree per block and a
+// second one-block launch.  Vectors are processed in the form they arrive in (canonical or R = 2^256 Montgomery):
+// every term carries the same power of the form factor, fixed by one constant multiplication on the host.
+#include "runtime.hpp"
+
+namespace nmx {
+
+template <int FID> __device__ __forceinline__ Fp<FID> ldw(const uint32_t* p, size_t i) {
+  return Fp<FID>::from_words(p + 8 * i);
+}
+
+// tree-reduce `v` over the 256 lanes of a block; result valid in lane 0.  Values < 2p on entry.
+template <int FID> __device__ __forceinline__ Fp<FID> block_sum(Fp<FID> v, uint32_t* lds /* 256 x 9 */) {
+  const uint32_t t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 9; i++) lds[i * 256 + t] = v.l[i];  // limb-major: conflict-free
+  __syncthreads();
+  for (uint32_t s = 128; s >= 1; s >>= 1) {
+    if (t < s) {
+      Fp<FID> o;
+#pragma unroll
+      for (int i = 0; i < 9; i++) o.l[i] = lds[i * 256 + t + s];
+      v = (v + o).norm().canon();  // < 4p -> < p
+#pragma unroll
+      for (int i = 0; i < 9; i++) lds[i * 256 + t] = v.l[i];
+    }
+    __syncthreads();
+  }
+  return v;
+}
+
+template <int FID, int MODE>
+__global__ __launch_bounds__(256) void k_eq_sums(const uint32_t* A, const uint32_t* B, const uint32_t* C,
+                                                 const uint32_t* eqL, const uint32_t* eqR, uint32_t shift, uint32_t mask,
+                                                 uint32_t h, Fp<FID> fconst, uint32_t* partial) {
+  using F = Fp<FID>;
+  __shared__ uint32_t lds[9 * 256];
+  F s0 = F::zero(), s1 = F::zero();
+  for (uint32_t id = blockIdx.x * 256u + threadIdx.x; id < h; id += gridDim.x * 256u) {
+    F fac = ldw<FID>(eqR, eqL ? (id & mask) : id);
+    if (eqL) fac = ldw<FID>(eqL, id >> shift) * fac;
+    F a0 = ldw<FID>(A, id);
+    if (MODE == 1) {
+      s0 = (s0 + a0 * fac).norm().canon();
+    } else {
+      F a1 = ldw<FID>(A, (size_t)id + h), b0 = ldw<FID>(B, id), b1 = ldw<FID>(B, (size_t)id + h);
+      // the subtrahend at the scale of a product (x * Fm^2 / R'): c0 * fconst (MODE 3), or the constant itself (MODE 2)
+      F c = MODE == 3 ? ldw<FID>(C, id) * fconst : fconst;
+      F e0 = F::sub2(a0 * b0, c).norm();                                    // < 3.1 p
+      F q = F::sub2(a1, a0).norm() * F::sub2(b1, b0).norm();                // operands < 3 p
+      s0 = (s0 + e0 * fac).norm().canon();
+      s1 = (s1 + q * fac).norm().canon();
+    }
+  }
+  s0 = block_sum<FID>(s0, lds);
+  if (MODE != 1) {
+    __syncthreads();
+    s1 = block_sum<FID>(s1, lds);
+  }
+  if (threadIdx.x == 0) {
+    s0.to_words(partial + 16 * blockIdx.x);
+    s1.to_words(partial + 16 * blockIdx.x + 8);
+  }
+}
+
+template <int FID> __global__ __launch_bounds__(256) void k_sum_partials(const uint32_t* partial, uint32_t nparts, uint32_t* out) {
+  using F = Fp<FID>;
+  __shared__ uint32_t lds[9 * 256];
+  F s0 = F::zero(), s1 = F::zero();
+  for (uint32_t i = threadIdx.x; i < nparts; i += 256) {
+    s0 = (s0 + ldw<FID>(partial, 2 * (size_t)i)).norm().canon();
+    s1 = (s1 + ldw<FID>(partial, 2 * (size_t)i + 1)).norm().canon();
+  }
+  s0 = block_sum<FID>(s0, lds);
+  __syncthreads();
+  s1 = block_sum<FID>(s1, lds);
+  if (threadIdx.x == 0) {
+    s0.to_words(out);
+    s1.to_words(out + 8);
+  }
+}
+
+// 2^e mod p as a plain integer in limbs (host)
+template <int FID> static Fp<FID> pow2_plain(uint32_t e) {
+  using F = Fp<FID>;
+  F two = F::zero();
+  two.l[0] = 2;
+  F base = two.to_internal().canon(), acc = F::one();
+  for (int i = 31; i >= 0; i--) {
+    acc = acc.sqr();
+    if ((e >> i) & 1u) acc = acc * base;
+  }
+  return acc.to_canonical();
+}
+
+template <int FID, int MODE>
+static void eq_sums_t(Ctx& c, const void* A, const void* B, const void* C, size_t len, const void* eqL, size_t nL,
+                      const void* eqR, size_t nR, uint32_t shift, uint32_t flags, uint8_t* out) {
+  using F = Fp<FID>;
+  const bool mont = flags & NMX_SCALARS_MONT, dev = flags & NMX_SCALARS_DEVICE;
+  const uint32_t h = (uint32_t)(len / 2);
+  const uint32_t blocks = h < 256 * 2048 ? (h + 255) / 256 : 2048;
+  // staging (host operands) + partials + result
+  size_t need = (size_t)blocks * 64 + 64 + 512;
+  auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  if (!dev) need += pad(len * 32) * (MODE == 3 ? 3 : MODE == 2 ? 2 : 1) + pad(nL * 32) + pad(nR * 32);
+  arena_reserve(c, need);
+  size_t used = 0;
+  auto stage = [&](const void* p, size_t elems) -> const uint32_t* {
+    if (!p) return nullptr;
+    if (dev) return (const uint32_t*)p;
+    char* d = c.arena + used;
+    used += pad(elems * 32);
+    HIPCHK(hipMemcpyAsync(d, p, elems * 32, hipMemcpyHostToDevice, c.stream));
+    return (const uint32_t*)d;
+  };
+  const uint32_t* dA = stage(A, len);
+  const uint32_t* dB = MODE >= 2 ? stage(B, len) : nullptr;
+  const uint32_t* dC = MODE == 3 ? stage(C, len) : nullptr;
+  const uint32_t* dL = stage(eqL, nL);
+  const uint32_t* dR = stage(eqR, nR);
+  uint32_t* partial = (uint32_t*)(c.arena + used);
+  used += pad((size_t)blocks * 64);
+  uint32_t* dout = (uint32_t*)(c.arena + used);
+  // Form factor Fm = 1 (canonical) or 2^256 (Montgomery); R' = 2^261; a product of two stored elements comes out
+  // as x*y * Fm^2 / R'.  MODE 3 brings c0*Fm to that scale with the plain constant Fm; MODE 2 subtracts the
+  // constant 1 * Fm^2 / R' directly.
+  F fconst = F::zero();
+  if (MODE == 3) {
+    if (mont) fconst = pow2_plain<FID>(256);
+    else fconst.l[0] = 1;
+  } else if (MODE == 2) {
+    F one_plain = F::zero();
+    one_plain.l[0] = 1;
+    fconst = mont ? pow2_plain<FID>(512 - 261) : one_plain.to_canonical();  // 2^251, or 2^-261 mod p
+  }
+  const bool prof = G.profiling;
+  DeviceBackend be(c, false, prof);
+  be.mark("k");
+  const uint32_t mask = shift >= 32 ? 0xffffffffu : ((1u << shift) - 1u);
+  hipLaunchKernelGGL((k_eq_sums<FID, MODE>), dim3(blocks), dim3(256), 0, c.stream, dA, dB, dC, dL, dR, shift, mask, h,
+                     fconst, partial);
+  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL((k_sum_partials<FID>), dim3(1), dim3(256), 0, c.stream, partial, blocks, dout);
+  HIPCHK(hipGetLastError());
+  be.mark("end");
+  uint32_t res[16];
+  HIPCHK(hipMemcpyAsync(res, dout, 64, hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipStreamSynchronize(c.stream));
+  if (prof && be.nmarks == 2) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
+    prof_store(&ms, 1);
+  }
+  // sums carry x * Fm^k / R'^(k-1) with k = 4 (modes 2, 3: two data factors + two eq factors) or, without eqL, k = 3;
+  // mode 1: k = 3 / 2.  Bring them back to the vectors' own form x * Fm:  multiply by R'^(k-1) / Fm^(k-1)
+  // (one more Montgomery product => the plain constant is R'^k / Fm^(k-1)).
+  const uint32_t k = (MODE == 1 ? 2u : 3u) + (eqL ? 1u : 0u);
+  const uint32_t e = 261u * k - (mont ? 256u * (k - 1) : 0u);
+  F corr = pow2_plain<FID>(e);
+  for (int j = 0; j < 2; j++) {
+    F v = F::from_words(res + 8 * j) * corr;
+    uint32_t w[8];
+    v.canon().to_words(w);
+    memcpy(out + 32 * j, w, 32);
+  }
+}
+
+void fv_eq_sums(Ctx& c, int field, int mode, const void* A, const void* B, const void* C, size_t len, const void* eqL,
+                size_t nL, const void* eqR, size_t nR, uint32_t shift, uint32_t flags, uint8_t* out) {
+#define EQS(FID)                                                                                        \
+  switch (mode) {                                                                                       \
+    case 1: eq_sums_t<FID, 1>(c, A, B, C, len, eqL, nL, eqR, nR, shift, flags, out); return;            \
+    case 2: eq_sums_t<FID, 2>(c, A, B, C, len, eqL, nL, eqR, nR, shift, flags, out); return;            \
+    case 3: eq_sums_t<FID, 3>(c, A, B, C, len, eqL, nL, eqR, nR, shift, flags, out); return;            \
+    default: throw Fail{NMX_E_ARG, "bad sum-check mode"};                                               \
+  }
+  switch (field) {
+    case 0: EQS(0)
+    case 1: EQS(1)
+    case 2: EQS(2)
+    case 3: EQS(3)
+    default: throw Fail{NMX_E_ARG, "bad field id"};
+  }
+#undef EQS
+}
+
+}  // namespace nmx

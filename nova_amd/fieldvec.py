@@ -109,3 +109,28 @@ def fold_pairs(field, p, x, mont=False):
     po, out = _out_like(dev, n // 2, p)
     _check(L.lib().nmx_poly_fold_pairs(field, pp, n, xx.ctypes.data, _flags(dev, mont), po))
     return out
+
+
+def sumcheck_eq_sums(field, mode, A, B, C, eq_right, eq_left=None, shift=0, mont=False):
+    """(t_0, t_inf) of EqSumCheckInstance::evaluation_points_{quadratic_with_one_input (mode 1),
+    cubic_with_two_inputs (2), cubic_with_three_inputs (3)} (src/spartan/sumcheck.rs:900-1075) as two 32-byte field
+    elements.  eq_left given: first-half rounds, factor = eq_left[id >> shift] * eq_right[id & (2^shift - 1)]."""
+    pa, n, dev, _ka = _vec(A)
+    pb = pc = None
+    keep = []
+    if mode >= 2:
+        pb, nb, _d, kb = _vec(B)
+        assert nb == n
+        keep.append(kb)
+    if mode >= 3:
+        pc, nc, _d, kc = _vec(C)
+        assert nc == n
+        keep.append(kc)
+    pr, nr, _d, kr = _vec(eq_right)
+    pl, nl = None, 0
+    if eq_left is not None:
+        pl, nl, _d, kl = _vec(eq_left)
+        keep.append(kl)
+    out = np.zeros(64, dtype=np.uint8)
+    _check(L.lib().nmx_sumcheck_eq_sums(field, mode, pa, pb, pc, n, pl, nl, pr, nr, shift, _flags(dev, mont), out.ctypes.data))
+    return out[:32].tobytes(), out[32:].tobytes()

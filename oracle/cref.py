@@ -43,6 +43,7 @@ def lib():
         L.ref_field_axpy2.argtypes = [ctypes.c_int, vp, vp, vp, vp, sz, vp]
         L.ref_field_cross_term.argtypes = [ctypes.c_int, vp, vp, vp, vp, vp, sz, vp]
         L.ref_field_bind.argtypes = [ctypes.c_int, vp, sz, sz, sz, vp, sz, vp]
+        L.ref_sumcheck_eq_sums.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, sz, vp, vp, ctypes.c_uint, vp]
         _lib = L
     return _lib
 
@@ -192,3 +193,11 @@ def field_bind(fid, z, lo, hi, stride, r, n_out):
     out = np.zeros(32 * n_out, dtype=np.uint8)
     lib().ref_field_bind(fid, pz, lo, hi, stride, pr, n_out, out.ctypes.data)
     return out.tobytes()
+
+
+def sumcheck_eq_sums(fid, mode, A, B, C, n, eq_right, eq_left=None, shift=0):
+    ps = [_buf(x) if x is not None else (None, None) for x in (A, B, C, eq_left, eq_right)]
+    out = np.zeros(64, dtype=np.uint8)
+    rc = lib().ref_sumcheck_eq_sums(fid, mode, ps[0][0], ps[1][0], ps[2][0], n, ps[3][0], ps[4][0], shift, out.ctypes.data)
+    assert rc == 0
+    return out[:32].tobytes(), out[32:].tobytes()

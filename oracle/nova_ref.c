@@ -747,3 +747,27 @@ int ref_field_bind(int field, const uint8_t* z, size_t lo, size_t hi, size_t str
   }
   return 0;
 }
+
+/* (t_0, t_inf) of the eq-factored sum-check rounds (src/spartan/sumcheck.rs:900-958 mode 3, :972-1037 mode 2,
+ * :1039-1075 mode 1); eqL == NULL selects the last-half form (factor = eqR[id]).  Canonical in/out. */
+int ref_sumcheck_eq_sums(int field, int mode, const uint8_t* A, const uint8_t* B, const uint8_t* C, size_t len, const uint8_t* eqL,
+                         const uint8_t* eqR, unsigned shift, uint8_t* out64) {
+  const field_t* F = field_by_id(field); if (!F) return -1;
+  size_t h = len / 2, mask = ((size_t)1 << shift) - 1;
+  fe s0, s1; memset(&s0, 0, sizeof s0); memset(&s1, 0, sizeof s1);
+  for (size_t id = 0; id < h; id++) {
+    fe fac, t; ld_mont(F, &fac, eqR + 32 * (eqL ? (id & mask) : id));
+    if (eqL) { ld_mont(F, &t, eqL + 32 * (id >> shift)); fe_mul(F, &fac, &t, &fac); }
+    fe a0; ld_mont(F, &a0, A + 32 * id);
+    if (mode == 1) { fe_mul(F, &t, &a0, &fac); fe_add(F, &s0, &s0, &t); continue; }
+    fe a1, b0, b1, e0, q, c;
+    ld_mont(F, &a1, A + 32 * (id + h)); ld_mont(F, &b0, B + 32 * id); ld_mont(F, &b1, B + 32 * (id + h));
+    if (mode == 3) ld_mont(F, &c, C + 32 * id); else c = F->r1;
+    fe_mul(F, &e0, &a0, &b0); fe_sub(F, &e0, &e0, &c);
+    fe_sub(F, &a1, &a1, &a0); fe_sub(F, &b1, &b1, &b0); fe_mul(F, &q, &a1, &b1);
+    fe_mul(F, &t, &e0, &fac); fe_add(F, &s0, &s0, &t);
+    fe_mul(F, &t, &q, &fac); fe_add(F, &s1, &s1, &t);
+  }
+  st_canon(F, out64, &s0); st_canon(F, out64 + 32, &s1);
+  return 0;
+}

@@ -222,3 +222,18 @@ def cross_term(p, az, bz, cz, e, u):
 def fold_pairs(p, P, x):
     """Pi[j] = P[2j] + x*(P[2j+1] - P[2j]) (src/provider/hyperkzg.rs:1085-1095)."""
     return [(P[2 * j] + x * (P[2 * j + 1] - P[2 * j])) % p for j in range(len(P) // 2)]
+
+
+def sumcheck_eq_sums(p, mode, A, B, C, eq_right, eq_left=None, shift=0):
+    """(t_0, t_inf) of the eq-factored sum-check rounds (src/spartan/sumcheck.rs:900-1075)."""
+    h = len(A) // 2
+    t0 = tinf = 0
+    for i in range(h):
+        fac = eq_right[i & ((1 << shift) - 1)] * eq_left[i >> shift] if eq_left is not None else eq_right[i]
+        if mode == 1:
+            t0 += A[i] * fac
+            continue
+        c0 = C[i] if mode == 3 else 1
+        t0 += (A[i] * B[i] - c0) * fac
+        tinf += (A[i + h] - A[i]) * (B[i + h] - B[i]) * fac
+    return t0 % p, tinf % p

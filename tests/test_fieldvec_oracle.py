@@ -36,3 +36,18 @@ def test_oracle_field_vectors(fid):
     assert cref.field_cross_term(fid, a, b, c, e, r, n) == enc(R.cross_term(p, C.ints(a), C.ints(b), C.ints(c), C.ints(e), ri))
     assert cref.field_bind(fid, a, 0, n // 2, 1, r, n // 2) == enc(R.bind_poly_var_top(p, C.ints(a), ri))
     assert cref.field_bind(fid, a, 0, 1, 2, r, n // 2) == enc(R.fold_pairs(p, C.ints(a), ri))
+
+
+@pytest.mark.parametrize("fid", range(4))
+def test_oracle_sumcheck_eq_sums(fid):
+    """sumcheck.rs:900-1075: C restatement == big-int definition, first-half (eqL x eqR) and last-half forms."""
+    p = C.FIELDS[fid]
+    n, shift = 64, 3
+    A, B, Cc = (C.edge_vectors(fid, n, s) for s in (1, 2, 3))
+    eqR, eqL, eqF = C.rand_vec(fid, 1 << shift, 5), C.rand_vec(fid, (n // 2) >> shift, 6), C.rand_vec(fid, n // 2, 7)
+    enc = lambda t: tuple(R.fe_to_le32(x) for x in t)
+    for mode in (1, 2, 3):
+        got = cref.sumcheck_eq_sums(fid, mode, A, B, Cc, n, eqR, eqL, shift)
+        assert got == enc(R.sumcheck_eq_sums(p, mode, C.ints(A), C.ints(B), C.ints(Cc), C.ints(eqR), C.ints(eqL), shift))
+        got = cref.sumcheck_eq_sums(fid, mode, A, B, Cc, n, eqF)
+        assert got == enc(R.sumcheck_eq_sums(p, mode, C.ints(A), C.ints(B), C.ints(Cc), C.ints(eqF)))

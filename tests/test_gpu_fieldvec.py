@@ -81,3 +81,36 @@ def test_commit_T_flow_stays_on_device(nmx):
     assert (com.xy, int(com.is_inf)) == cref.commit(c.cid, T_ref, host_key, n, ck.h, r_T)
     assert E2.cpu().numpy().tobytes() == cref.field_axpy(fid, e, T_ref, r, n)
     ck.close()
+
+
+@pytest.mark.parametrize("fid", range(4))
+@pytest.mark.parametrize("logn", [1, 6, 12, 18])
+def test_sumcheck_eq_sums(nmx, fid, logn):
+    """evaluation_points_* N-scaling sums (sumcheck.rs:900-1075): all three modes, first- and last-half factor forms,
+    host / device operands, canonical / Montgomery layouts."""
+    import torch
+    from nova_amd import fieldvec as fv
+    p = C.FIELDS[fid]
+    n = 1 << logn
+    h = n // 2
+    shift = max(0, (logn - 1) // 2)
+    A, B, Cc = (C.edge_vectors(fid, n, s) for s in (1, 2, 3))
+    eqR, eqL, eqF = C.rand_vec(fid, 1 << shift, 5), C.rand_vec(fid, max(1, h >> shift), 6), C.rand_vec(fid, h, 7)
+    for mode in (1, 2, 3):
+        exp1 = cref.sumcheck_eq_sums(fid, mode, A, B, Cc, n, eqR, eqL, shift)
+        exp2 = cref.sumcheck_eq_sums(fid, mode, A, B, Cc, n, eqF)
+        assert fv.sumcheck_eq_sums(fid, mode, A, B, Cc, eqR, eqL, shift) == exp1, (mode, "first half")
+        assert fv.sumcheck_eq_sums(fid, mode, A, B, Cc, eqF) == exp2, (mode, "last half")
+    if logn == 12:
+        d = [torch.from_numpy(x.copy()).cuda() for x in (A, B, Cc, eqR, eqL)]
+        assert fv.sumcheck_eq_sums(fid, 3, d[0], d[1], d[2], d[3], d[4], shift) == cref.sumcheck_eq_sums(fid, 3, A, B, Cc, n, eqR, eqL, shift)
+        Rm = 1 << 256
+        to_m = lambda v: C.vec([x * Rm % p for x in C.ints(v)])
+        for mode in (1, 2, 3):
+            got = fv.sumcheck_eq_sums(fid, mode, to_m(A), to_m(B), to_m(Cc), to_m(eqR), to_m(eqL), shift, mont=True)
+            exp = cref.sumcheck_eq_sums(fid, mode, A, B, Cc, n, eqR, eqL, shift)
+            assert tuple(C.ints(C.vec([int.from_bytes(g, "little") * pow(Rm, -1, p) % p]))[0] for g in got) == \
+                tuple(int.from_bytes(e, "little") for e in exp), mode
+            got = fv.sumcheck_eq_sums(fid, mode, to_m(A), to_m(B), to_m(Cc), to_m(eqF), mont=True)
+            exp = cref.sumcheck_eq_sums(fid, mode, A, B, Cc, n, eqF)
+            assert tuple(int.from_bytes(g, "little") * pow(Rm, -1, p) % p for g in got) == tuple(int.from_bytes(e, "little") for e in exp)
