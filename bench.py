@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--iters", type=int, default=65536, help="prove_step_replay: MinRoot iterations per step")
-    ap.add_argument("--workload", default="msm", choices=["msm", "axpy", "cross_term", "bind", "prove_step_replay"],
+    ap.add_argument("--workload", default="msm", choices=["msm", "axpy", "cross_term", "bind", "sumcheck3", "prove_step_replay"],
                     help="msm = the headline (default); the others time one HBM-bound field-vector kernel of "
                          "SURVEY.md 8(f) at 2^log2n elements per GPU")
     args = ap.parse_args()
@@ -292,17 +292,24 @@ def field_workload(args, world, rank, L, torch, dist):
     n = 1 << args.log2n
     cid = args.curve
     fid = fv.SCALAR_FIELD_OF_CURVE[cid]
-    nvec = {"axpy": 2, "cross_term": 4, "bind": 1}[args.workload]
+    nvec = {"axpy": 2, "cross_term": 4, "bind": 1, "sumcheck3": 3}[args.workload]
     host = [util.random_scalars(cid, n, seed=util.SEED + 7 * j + rank) for j in range(nvec)]
     dev = [torch.from_numpy(h).cuda() for h in host]
     r = util.random_scalars(cid, 1, seed=99)
-    bytes_per_elem = {"axpy": 96, "cross_term": 160, "bind": 48}[args.workload]  # reads + writes per element
+    # reads + writes per element of the input vectors (sumcheck3: a0,a1,b0,b1,c0 per index = 80 B per element)
+    bytes_per_elem = {"axpy": 96, "cross_term": 160, "bind": 48, "sumcheck3": 80}[args.workload]
+    shift = (args.log2n - 1) // 2
+    if args.workload == "sumcheck3":
+        eqR = torch.from_numpy(util.random_scalars(cid, 1 << shift, seed=5)).cuda()
+        eqL = torch.from_numpy(util.random_scalars(cid, (n // 2) >> shift, seed=6)).cuda()
 
     def step():
         if args.workload == "axpy":
             return fv.axpy(fid, dev[0], dev[1], r)
         if args.workload == "cross_term":
             return fv.cross_term(fid, dev[0], dev[1], dev[2], dev[3], r)
+        if args.workload == "sumcheck3":  # one outer sum-check round's N-scaling sums (sumcheck.rs:900-958)
+            return fv.sumcheck_eq_sums(fid, 3, dev[0], dev[1], dev[2], eqR, eqL, shift)
         return fv.bind_poly_var_top(fid, dev[0], r)
 
     def fence():
@@ -354,12 +361,20 @@ def field_workload(args, world, rank, L, torch, dist):
                 exp = cref.field_axpy(fid, host[0][:m], host[1][:m], r, m)
             elif args.workload == "cross_term":
                 exp = cref.field_cross_term(fid, host[0][:m], host[1][:m], host[2][:m], host[3][:m], r, m)
+            elif args.workload == "sumcheck3":
+                m = n
+                exp = cref.sumcheck_eq_sums(fid, 3, host[0], host[1], host[2], n, eqR.cpu().numpy(), eqL.cpu().numpy(), shift)
             else:
                 exp = cref.field_bind(fid, host[0], 0, n // 2, 1, r, min(m, n // 2))
             t = time.perf_counter() - t1
             cnt = m if args.workload != "bind" else min(m, n // 2)
-            got = out.cpu().numpy().reshape(-1)[: 32 * cnt].tobytes()
-            res["cpu_baseline"] = {"value": cnt / t, "unit": "elements/s", "cores": threads, "kind": "port",
+            if args.workload == "sumcheck3":
+                got, exp = b"".join(out), b"".join(exp)
+                cnt = 2
+            else:
+                got = out.cpu().numpy().reshape(-1)[: 32 * cnt].tobytes()
+            cnt_rate = n if args.workload == "sumcheck3" else cnt
+            res["cpu_baseline"] = {"value": cnt_rate / t, "unit": "elements/s", "cores": threads, "kind": "port",
                                    "sample": f"first {cnt} elements, one pass, oracle/nova_ref.c (OpenMP)",
                                    "gpu_matches_cpu": got == exp[: 32 * cnt]}
         print(json.dumps(res), flush=True)

@@ -155,6 +155,19 @@ int nmx_poly_fold_pairs(int field, const void* p, size_t len, const void* x, uin
 int nmx_sumcheck_eq_sums(int field, int mode, const void* A, const void* B, const void* C, size_t len, const void* eqL,
                          size_t n_eqL, const void* eqR, size_t n_eqR, uint32_t shift, uint32_t flags, uint8_t* out64);
 
+/* EqPolynomial::evals_from_points (src/spartan/polys/eq.rs:54-73): out[2^ell] = eq(r, x) for x in {0,1}^ell, r[0] the
+ * most significant variable.  r: ell x 32 bytes, host.  out: host, or HBM with NMX_SCALARS_DEVICE. */
+int nmx_eq_evals_from_points(int field, const void* r, size_t ell, uint32_t flags, void* out);
+/* MultilinearPolynomial::evaluate / evaluate_with (src/spartan/polys/multilinear.rs:88-129): Z(r), len == 2^ell. */
+int nmx_mle_evaluate(int field, const void* z, size_t len, const void* r, size_t ell, uint32_t flags, uint8_t* out32);
+/* SparseMatrix (CSR, scipy naming: data / indices / indptr, src/r1cs/sparse.rs:232-260) resident in HBM, and
+ * SparseMatrix::multiply_vec (sparse.rs:201-229): out[rows] = M * z.  indptr / indices are `usize` on the reference
+ * side, hence uint64_t here.  R1CS matrices are fixed per circuit: register once, apply every step. */
+int nmx_spmv_register(int field, const uint64_t* indptr, const uint64_t* indices, const void* data, size_t rows,
+                      size_t cols, uint32_t flags, uint64_t* handle);
+int nmx_spmv_unregister(uint64_t handle);
+int nmx_spmv_apply(uint64_t handle, const void* z, size_t z_len, uint32_t flags, void* out);
+
 /* ---- measurement ------------------------------------------------------------------------------------
  * With profiling on, every MSM brackets its stages with hipEvents on the stream the kernels run on;
  * nmx_profile_last returns the last call's stage times in milliseconds (same thread).

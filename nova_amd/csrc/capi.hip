@@ -177,6 +177,12 @@ int nmx_shutdown(void) {
     for (auto& kv : G.bases)
       if (kv.second.d) (void)hipFree(kv.second.d);
     G.bases.clear();
+    for (auto& kv : G.sparse) {
+      (void)hipFree(kv.second.indptr);
+      (void)hipFree(kv.second.indices);
+      (void)hipFree(kv.second.data);
+    }
+    G.sparse.clear();
     for (Ctx* c : G.all_ctx) {
       if (c->arena) (void)hipFree(c->arena);
       if (c->have_ev)
@@ -429,6 +435,123 @@ int nmx_sumcheck_eq_sums(int field, int mode, const void* A, const void* B, cons
     }
     CtxLease L;
     fv_eq_sums(*L.c, field, mode, A, B, C, len, eqL, n_eqL, eqR, n_eqR, shift, flags, out64);
+  });
+}
+
+struct DevBuf {  // RAII device allocation
+  void* p = nullptr;
+  explicit DevBuf(size_t bytes) { HIPCHK(hipMalloc(&p, bytes ? bytes : 1)); }
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+};
+
+int nmx_eq_evals_from_points(int field, const void* r, size_t ell, uint32_t flags, void* out) {
+  return guarded([&] {
+    require((r || ell == 0) && out, NMX_E_ARG, "null argument");
+    require(ell < 31, NMX_E_ARG, "too many variables");
+    CtxLease L;
+    const size_t n = (size_t)1 << ell;
+    if (flags & NMX_SCALARS_DEVICE) {
+      fv_eq_evals(*L.c, field, r, (uint32_t)ell, flags, (uint32_t*)out);
+      HIPCHK(hipStreamSynchronize(L.c->stream));
+    } else {
+      DevBuf d(n * 32);
+      fv_eq_evals(*L.c, field, r, (uint32_t)ell, flags, (uint32_t*)d.p);
+      HIPCHK(hipMemcpyAsync(out, d.p, n * 32, hipMemcpyDeviceToHost, L.c->stream));
+      HIPCHK(hipStreamSynchronize(L.c->stream));
+    }
+  });
+}
+
+int nmx_mle_evaluate(int field, const void* z, size_t len, const void* r, size_t ell, uint32_t flags, uint8_t* out32) {
+  return guarded([&] {
+    require(z && (r || ell == 0) && out32, NMX_E_ARG, "null argument");
+    require(ell < 31 && len == ((size_t)1 << ell), NMX_E_ARG, "assert_eq!(r.len(), self.get_num_vars())");
+    CtxLease L;
+    // sqrt decomposition of MultilinearPolynomial::evaluate_with (multilinear.rs:98-129)
+    const size_t s_right = ell / 2, s_left = ell - s_right;
+    DevBuf eqL(((size_t)1 << s_left) * 32), eqR(((size_t)1 << s_right) * 32);
+    fv_eq_evals(*L.c, field, r, (uint32_t)s_left, flags, (uint32_t*)eqL.p);
+    fv_eq_evals(*L.c, field, (const uint8_t*)r + 32 * s_left, (uint32_t)s_right, flags, (uint32_t*)eqR.p);
+    const void* dz = z;
+    DevBuf* up = nullptr;
+    DevBuf zbuf((flags & NMX_SCALARS_DEVICE) ? 1 : len * 32);
+    if (!(flags & NMX_SCALARS_DEVICE)) {
+      HIPCHK(hipMemcpyAsync(zbuf.p, z, len * 32, hipMemcpyHostToDevice, L.c->stream));
+      dz = zbuf.p;
+    }
+    (void)up;
+    uint8_t two[64];
+    // sum_id z[id] * eqL[id >> s_right] * eqR[id & (2^s_right - 1)]: the mode-1 sum over "half" = len
+    fv_eq_sums(*L.c, field, 1, dz, nullptr, nullptr, 2 * len, eqL.p, (size_t)1 << s_left, eqR.p, (size_t)1 << s_right,
+               (uint32_t)s_right, flags | NMX_SCALARS_DEVICE, two);
+    memcpy(out32, two, 32);
+  });
+}
+
+int nmx_spmv_register(int field, const uint64_t* indptr, const uint64_t* indices, const void* data, size_t rows,
+                      size_t cols, uint32_t flags, uint64_t* handle) {
+  return guarded([&] {
+    require(indptr && handle && field >= 0 && field < 4, NMX_E_ARG, "bad argument");
+    const size_t nnz = (size_t)indptr[rows];
+    require((indices && data) || nnz == 0, NMX_E_ARG, "null argument");
+    require(rows < (1ull << 31) && cols < (1ull << 31) && nnz < (1ull << 31), NMX_E_TOO_LARGE, "matrix too large");
+    std::vector<uint32_t> ip(rows + 1), ix(nnz ? nnz : 1);
+    for (size_t i = 0; i <= rows; i++) {
+      require(indptr[i] <= nnz && (i == 0 || indptr[i] >= indptr[i - 1]), NMX_E_ARG, "indptr not monotone");
+      ip[i] = (uint32_t)indptr[i];
+    }
+    for (size_t k = 0; k < nnz; k++) {
+      require(indices[k] < cols, NMX_E_ARG, "column index out of range");
+      ix[k] = (uint32_t)indices[k];
+    }
+    CtxLease L;
+    Global::SparseSet ss{field, rows, cols, nnz, nullptr, nullptr, nullptr};
+    HIPCHK(hipMalloc((void**)&ss.indptr, (rows + 1) * 4));
+    HIPCHK(hipMalloc((void**)&ss.indices, (nnz ? nnz : 1) * 4));
+    HIPCHK(hipMalloc((void**)&ss.data, (nnz ? nnz : 1) * 32));
+    HIPCHK(hipMemcpyAsync(ss.indptr, ip.data(), (rows + 1) * 4, hipMemcpyHostToDevice, L.c->stream));
+    HIPCHK(hipMemcpyAsync(ss.indices, ix.data(), nnz * 4, hipMemcpyHostToDevice, L.c->stream));
+    HIPCHK(hipMemcpyAsync(ss.data, data, nnz * 32, hipMemcpyHostToDevice, L.c->stream));
+    fv_spmv_convert(*L.c, field, ss.data, nnz, flags);
+    HIPCHK(hipStreamSynchronize(L.c->stream));
+    std::lock_guard<std::mutex> lk(G.mu);
+    uint64_t h = G.next_handle++;
+    G.sparse[h] = ss;
+    *handle = h;
+  });
+}
+int nmx_spmv_unregister(uint64_t handle) {
+  return guarded([&] {
+    Global::SparseSet ss;
+    {
+      std::lock_guard<std::mutex> lk(G.mu);
+      auto it = G.sparse.find(handle);
+      if (it == G.sparse.end()) throw Fail{NMX_E_HANDLE, "unknown matrix handle"};
+      ss = it->second;
+      G.sparse.erase(it);
+    }
+    HIPCHK(hipSetDevice(G.device));
+    (void)hipFree(ss.indptr);
+    (void)hipFree(ss.indices);
+    (void)hipFree(ss.data);
+  });
+}
+int nmx_spmv_apply(uint64_t handle, const void* z, size_t z_len, uint32_t flags, void* out) {
+  return guarded([&] {
+    require(z && out, NMX_E_ARG, "null argument");
+    Global::SparseSet ss;
+    {
+      std::lock_guard<std::mutex> lk(G.mu);
+      auto it = G.sparse.find(handle);
+      if (it == G.sparse.end()) throw Fail{NMX_E_HANDLE, "unknown matrix handle"};
+      ss = it->second;
+    }
+    require(z_len == ss.cols, NMX_E_ARG, "invalid shape");  // assert_eq!(self.cols, vector.len(), "invalid shape")
+    if (ss.rows == 0) return;
+    CtxLease L;
+    fv_spmv_apply(*L.c, ss.field, ss.indptr, ss.indices, ss.data, ss.rows, ss.cols, z, flags, out);
   });
 }
 

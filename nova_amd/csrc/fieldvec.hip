@@ -66,6 +66,45 @@ template <int FID> struct BindTopFn {
   }
 };
 
+// EqPolynomial::evals_from_points, one doubling step (/root/reference/src/spartan/polys/eq.rs:54-73):
+//   y = x[i] * r;  x[i + size] = y;  x[i] -= y        for i < size
+template <int FID> struct EqStepFn {
+  uint32_t* buf;
+  Fp<FID> r;  // r * 2^261
+  uint32_t size;
+  NMX_HD void operator()(uint32_t i) const {
+    using F = Fp<FID>;
+    F x = ld<FID>(buf, i);
+    F y = r * x;                                   // < 1.01 p
+    st<FID>(buf, (size_t)i + size, y);
+    st<FID>(buf, i, F::sub2(x, y).norm());         // x - y + 2p
+  }
+};
+
+// CSR sparse matrix x vector, one row per lane (/root/reference/src/r1cs/sparse.rs:201-229, SparseMatrix::multiply_vec;
+// the reference's +-1 / small-coefficient fast paths are a CPU optimisation of the same product).  Matrix values are
+// stored in internal form at registration, so data * z comes out in z's own form with no correction.
+template <int FID> struct SpmvFn {
+  const uint32_t* indptr;   // rows + 1
+  const uint32_t* indices;  // nnz
+  const uint32_t* data;     // nnz x 8, internal form
+  const uint32_t* z;        // cols x 8
+  uint32_t* out;            // rows x 8
+  NMX_HD void operator()(uint32_t row) const {
+    using F = Fp<FID>;
+    F acc = F::zero();
+    uint32_t pending = 0;
+    for (uint32_t k = indptr[row]; k < indptr[row + 1]; k++) {
+      acc = acc + ld<FID>(data, k) * ld<FID>(z, indices[k]);
+      if (++pending == 6) {
+        acc = acc.norm().canon();
+        pending = 0;
+      }
+    }
+    st<FID>(out, row, acc.norm());
+  }
+};
+
 // ---- host side ---------------------------------------------------------------------------------------
 // launch one functor over n lanes; with profiling on, bracket it with hipEvents on the context's stream
 struct VecIO;
@@ -167,6 +206,86 @@ template <int FID> struct FieldImpl {
     timed_launch(c, f, n_out, &io);
   }
 };
+
+// builds eq(r, .) over {0,1}^ell into the device buffer d_out (2^ell elements, the vectors' form)
+template <int FID> static void eq_evals_t(Ctx& c, const void* r_host, uint32_t ell, uint32_t flags, uint32_t* d_out) {
+  using F = Fp<FID>;
+  const bool mont = flags & NMX_SCALARS_MONT;
+  // evals[0] = ONE in the vectors' form: 1, or 2^256 mod p
+  F one = F::zero();
+  one.l[0] = 1;
+  uint32_t w[8];
+  if (mont) {
+    // 2^256 mod p as a plain integer = the internal form (x * 2^261) of x = 1/32
+    F two5 = F::zero();
+    two5.l[0] = 32;
+    F inv32 = two5.to_internal().canon().inv();  // (1/32) * 2^261 = 2^256 mod p
+    inv32.canon().to_words(w);
+  } else {
+    one.to_words(w);
+  }
+  HIPCHK(hipMemcpyAsync(d_out, w, 32, hipMemcpyHostToDevice, c.stream));
+  HIPCHK(hipStreamSynchronize(c.stream));  // w is a stack buffer
+  DeviceBackend be(c, false, false);
+  uint32_t size = 1;
+  for (int j = (int)ell - 1; j >= 0; j--) {  // for r in r.iter().rev()
+    EqStepFn<FID> f{d_out, challenge<FID>((const uint8_t*)r_host + 32 * j, mont), size};
+    be.launch(f, size);
+    size *= 2;
+  }
+}
+
+template <int FID> static void spmv_convert_t(Ctx& c, uint32_t* d_data, size_t nnz, uint32_t flags) {
+  DeviceBackend be(c, false, false);
+  struct Conv {
+    uint32_t* v;
+    uint32_t from_mont;
+    NMX_HD void operator()(uint32_t i) const {
+      Fp<FID> f = Fp<FID>::from_words(v + 8 * (size_t)i);
+      (from_mont ? f.mont256_to_internal() : f.to_internal()).canon().to_words(v + 8 * (size_t)i);
+    }
+  };
+  Conv f{d_data, (flags & NMX_SCALARS_MONT) ? 1u : 0u};
+  be.launch(f, (uint32_t)nnz);
+}
+template <int FID>
+static void spmv_apply_t(Ctx& c, const uint32_t* indptr, const uint32_t* indices, const uint32_t* data, size_t rows,
+                         size_t cols, const void* z, uint32_t flags, void* out) {
+  VecIO io(c, flags & NMX_SCALARS_DEVICE, rows + cols, 2);
+  const uint32_t* dz = io.in(z, cols);
+  uint32_t* dout = io.out(out, rows);
+  SpmvFn<FID> f{indptr, indices, data, dz, dout};
+  timed_launch(c, f, rows, &io);
+}
+
+void fv_eq_evals(Ctx& c, int field, const void* r_host, uint32_t ell, uint32_t flags, uint32_t* d_out) {
+  switch (field) {
+    case 0: eq_evals_t<0>(c, r_host, ell, flags, d_out); break;
+    case 1: eq_evals_t<1>(c, r_host, ell, flags, d_out); break;
+    case 2: eq_evals_t<2>(c, r_host, ell, flags, d_out); break;
+    case 3: eq_evals_t<3>(c, r_host, ell, flags, d_out); break;
+    default: throw Fail{NMX_E_ARG, "bad field id"};
+  }
+}
+void fv_spmv_convert(Ctx& c, int field, uint32_t* d_data, size_t nnz, uint32_t flags) {
+  switch (field) {
+    case 0: spmv_convert_t<0>(c, d_data, nnz, flags); break;
+    case 1: spmv_convert_t<1>(c, d_data, nnz, flags); break;
+    case 2: spmv_convert_t<2>(c, d_data, nnz, flags); break;
+    case 3: spmv_convert_t<3>(c, d_data, nnz, flags); break;
+    default: throw Fail{NMX_E_ARG, "bad field id"};
+  }
+}
+void fv_spmv_apply(Ctx& c, int field, const uint32_t* indptr, const uint32_t* indices, const uint32_t* data, size_t rows,
+                   size_t cols, const void* z, uint32_t flags, void* out) {
+  switch (field) {
+    case 0: spmv_apply_t<0>(c, indptr, indices, data, rows, cols, z, flags, out); break;
+    case 1: spmv_apply_t<1>(c, indptr, indices, data, rows, cols, z, flags, out); break;
+    case 2: spmv_apply_t<2>(c, indptr, indices, data, rows, cols, z, flags, out); break;
+    case 3: spmv_apply_t<3>(c, indptr, indices, data, rows, cols, z, flags, out); break;
+    default: throw Fail{NMX_E_ARG, "bad field id"};
+  }
+}
 
 #define FIELD_SWITCH(field, CALL)                                        \
   switch (field) {                                                       \

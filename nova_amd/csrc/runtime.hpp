@@ -73,6 +73,12 @@ struct Global {
   std::vector<Ctx*> free_ctx;
   std::vector<Ctx*> all_ctx;
   std::unordered_map<uint64_t, BaseSet> bases;
+  struct SparseSet {  // a CSR matrix resident in HBM (R1CS matrices are fixed per circuit: upload once)
+    int field;
+    size_t rows, cols, nnz;
+    uint32_t *indptr, *indices, *data;
+  };
+  std::unordered_map<uint64_t, SparseSet> sparse;
   uint64_t next_handle = 1;
   bool profiling = false;
   uint32_t force_c = 0;
@@ -174,6 +180,10 @@ void fv_vec_add(Ctx&, int field, const void* a, const void* b, size_t n, uint32_
 void fv_bind(Ctx&, int field, const void* z, size_t z_len, size_t lo_off, size_t hi_off, size_t stride, const void* r,
              size_t n_out, uint32_t flags, void* out);
 
+void fv_eq_evals(Ctx&, int field, const void* r_host, uint32_t ell, uint32_t flags, uint32_t* d_out);
+void fv_spmv_convert(Ctx&, int field, uint32_t* d_data, size_t nnz, uint32_t flags);
+void fv_spmv_apply(Ctx&, int field, const uint32_t* indptr, const uint32_t* indices, const uint32_t* data, size_t rows,
+                   size_t cols, const void* z, uint32_t flags, void* out);
 void fv_eq_sums(Ctx&, int field, int mode, const void* A, const void* B, const void* C, size_t len, const void* eqL,
                 size_t nL, const void* eqR, size_t nR, uint32_t shift, uint32_t flags, uint8_t* out);  // sumcheck.hip
 

@@ -48,22 +48,30 @@ __global__ __launch_bounds__(256) void k_eq_sums(const uint32_t* A, const uint32
   using F = Fp<FID>;
   __shared__ uint32_t lds[9 * 256];
   F s0 = F::zero(), s1 = F::zero();
+  uint32_t pending = 0;  // lazily added terms since the last canonicalisation (each < 1.1 p, limbs < 2^29)
   for (uint32_t id = blockIdx.x * 256u + threadIdx.x; id < h; id += gridDim.x * 256u) {
     F fac = ldw<FID>(eqR, eqL ? (id & mask) : id);
     if (eqL) fac = ldw<FID>(eqL, id >> shift) * fac;
     F a0 = ldw<FID>(A, id);
     if (MODE == 1) {
-      s0 = (s0 + a0 * fac).norm().canon();
+      s0 = s0 + a0 * fac;
     } else {
       F a1 = ldw<FID>(A, (size_t)id + h), b0 = ldw<FID>(B, id), b1 = ldw<FID>(B, (size_t)id + h);
       // the subtrahend at the scale of a product (x * Fm^2 / R'): c0 * fconst (MODE 3), or the constant itself (MODE 2)
       F c = MODE == 3 ? ldw<FID>(C, id) * fconst : fconst;
       F e0 = F::sub2(a0 * b0, c).norm();                                    // < 3.1 p
       F q = F::sub2(a1, a0).norm() * F::sub2(b1, b0).norm();                // operands < 3 p
-      s0 = (s0 + e0 * fac).norm().canon();
-      s1 = (s1 + q * fac).norm().canon();
+      s0 = s0 + e0 * fac;
+      s1 = s1 + q * fac;
+    }
+    if (++pending == 6) {  // 1 canonical + 6 fresh terms: value < 8 p, limbs < 7 * 2^29 -- then back to < p
+      s0 = s0.norm().canon();
+      s1 = s1.norm().canon();
+      pending = 0;
     }
   }
+  s0 = s0.norm().canon();
+  s1 = s1.norm().canon();
   s0 = block_sum<FID>(s0, lds);
   if (MODE != 1) {
     __syncthreads();
@@ -111,7 +119,9 @@ static void eq_sums_t(Ctx& c, const void* A, const void* B, const void* C, size_
   using F = Fp<FID>;
   const bool mont = flags & NMX_SCALARS_MONT, dev = flags & NMX_SCALARS_DEVICE;
   const uint32_t h = (uint32_t)(len / 2);
-  const uint32_t blocks = h < 256 * 2048 ? (h + 255) / 256 : 2048;
+  // >= 8 indices per lane before the (comparatively expensive) LDS tree, at most 2048 blocks
+  const uint32_t want = (h + 256 * 8 - 1) / (256 * 8);
+  const uint32_t blocks = want < 1 ? 1 : (want > 2048 ? 2048 : want);
   // staging (host operands) + partials + result
   size_t need = (size_t)blocks * 64 + 64 + 512;
   auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };

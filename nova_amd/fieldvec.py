@@ -134,3 +134,48 @@ def sumcheck_eq_sums(field, mode, A, B, C, eq_right, eq_left=None, shift=0, mont
     out = np.zeros(64, dtype=np.uint8)
     _check(L.lib().nmx_sumcheck_eq_sums(field, mode, pa, pb, pc, n, pl, nl, pr, nr, shift, _flags(dev, mont), out.ctypes.data))
     return out[:32].tobytes(), out[32:].tobytes()
+
+
+def eq_evals_from_points(field, r, mont=False):
+    """EqPolynomial::evals_from_points (src/spartan/polys/eq.rs:54-73): (2^ell, 32) table, r[0] most significant."""
+    rr = _host_u8(r, 32)
+    ell = rr.size // 32
+    out = np.zeros((1 << ell, 32), dtype=np.uint8)
+    _check(L.lib().nmx_eq_evals_from_points(field, rr.ctypes.data, ell, L.SCALARS_MONT if mont else 0, out.ctypes.data))
+    return out
+
+
+def mle_evaluate(field, z, r, mont=False):
+    """MultilinearPolynomial::evaluate (src/spartan/polys/multilinear.rs:88-129)."""
+    pz, n, dev, _kz = _vec(z)
+    rr = _host_u8(r, 32)
+    out = np.zeros(32, dtype=np.uint8)
+    _check(L.lib().nmx_mle_evaluate(field, pz, n, rr.ctypes.data, rr.size // 32, _flags(dev, mont), out.ctypes.data))
+    return out.tobytes()
+
+
+class SparseMatrix:
+    """CSR matrix resident in HBM (src/r1cs/sparse.rs:232-260); multiply_vec = sparse.rs:201-229."""
+
+    def __init__(self, field, indptr, indices, data, cols, mont=False):
+        import ctypes
+        ip = np.ascontiguousarray(indptr, dtype=np.uint64)
+        ix = np.ascontiguousarray(indices, dtype=np.uint64)
+        d = _host_u8(data, 32)
+        self.rows, self.cols, self.field = len(ip) - 1, cols, field
+        h = ctypes.c_uint64(0)
+        _check(L.lib().nmx_spmv_register(field, ip.ctypes.data, ix.ctypes.data, d.ctypes.data, self.rows, cols,
+                                         L.SCALARS_MONT if mont else 0, ctypes.byref(h)))
+        self.handle = h.value
+
+    def multiply_vec(self, z, mont=False):
+        pz, n, dev, _kz = _vec(z)
+        assert n == self.cols, "invalid shape"
+        po, out = _out_like(dev, self.rows, z)
+        _check(L.lib().nmx_spmv_apply(self.handle, pz, n, _flags(dev, mont), po))
+        return out
+
+    def close(self):
+        if self.handle:
+            _check(L.lib().nmx_spmv_unregister(self.handle))
+            self.handle = 0

@@ -43,6 +43,9 @@ def lib():
         L.ref_field_axpy2.argtypes = [ctypes.c_int, vp, vp, vp, vp, sz, vp]
         L.ref_field_cross_term.argtypes = [ctypes.c_int, vp, vp, vp, vp, vp, sz, vp]
         L.ref_field_bind.argtypes = [ctypes.c_int, vp, sz, sz, sz, vp, sz, vp]
+        L.ref_eq_evals.argtypes = [ctypes.c_int, vp, sz, vp]
+        L.ref_mle_evaluate.argtypes = [ctypes.c_int, vp, sz, vp, vp]
+        L.ref_spmv.argtypes = [ctypes.c_int, vp, vp, vp, sz, vp, vp]
         L.ref_sumcheck_eq_sums.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, sz, vp, vp, ctypes.c_uint, vp]
         _lib = L
     return _lib
@@ -201,3 +204,28 @@ def sumcheck_eq_sums(fid, mode, A, B, C, n, eq_right, eq_left=None, shift=0):
     rc = lib().ref_sumcheck_eq_sums(fid, mode, ps[0][0], ps[1][0], ps[2][0], n, ps[3][0], ps[4][0], shift, out.ctypes.data)
     assert rc == 0
     return out[:32].tobytes(), out[32:].tobytes()
+
+
+def eq_evals(fid, r, ell):
+    pr, _r = _buf(r)
+    out = np.zeros(32 << ell, dtype=np.uint8)
+    lib().ref_eq_evals(fid, pr, ell, out.ctypes.data)
+    return out.tobytes()
+
+
+def mle_evaluate(fid, z, ell, r):
+    pz, _z = _buf(z)
+    pr, _r = _buf(r)
+    out = np.zeros(32, dtype=np.uint8)
+    lib().ref_mle_evaluate(fid, pz, ell, pr, out.ctypes.data)
+    return out.tobytes()
+
+
+def spmv(fid, indptr, indices, data, rows, z):
+    ip = np.ascontiguousarray(indptr, dtype=np.uint64)
+    ix = np.ascontiguousarray(indices, dtype=np.uint64)
+    pd, _d = _buf(data)
+    pz, _z = _buf(z)
+    out = np.zeros(32 * rows, dtype=np.uint8)
+    lib().ref_spmv(fid, ip.ctypes.data, ix.ctypes.data, pd, rows, pz, out.ctypes.data)
+    return out.tobytes()

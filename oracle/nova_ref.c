@@ -771,3 +771,57 @@ int ref_sumcheck_eq_sums(int field, int mode, const uint8_t* A, const uint8_t* B
   st_canon(F, out64, &s0); st_canon(F, out64 + 32, &s1);
   return 0;
 }
+
+/* EqPolynomial::evals_from_points (src/spartan/polys/eq.rs:54-73), canonical in/out */
+int ref_eq_evals(int field, const uint8_t* r, size_t ell, uint8_t* out) {
+  const field_t* F = field_by_id(field); if (!F) return -1;
+  size_t n = (size_t)1 << ell;
+  fe* ev = (fe*)calloc(n, sizeof(fe));
+  ev[0] = F->r1;
+  size_t size = 1;
+  for (size_t j = ell; j-- > 0;) {           /* for r in r.iter().rev() */
+    fe rr; ld_mont(F, &rr, r + 32 * j);
+    for (size_t i = 0; i < size; i++) {
+      fe y; fe_mul(F, &y, &ev[i], &rr);       /* *y = *x * r */
+      ev[i + size] = y;
+      fe_sub(F, &ev[i], &ev[i], &y);          /* *x -= *y */
+    }
+    size *= 2;
+  }
+  for (size_t i = 0; i < n; i++) st_canon(F, out + 32 * i, &ev[i]);
+  free(ev);
+  return 0;
+}
+/* MultilinearPolynomial::evaluate_with (src/spartan/polys/multilinear.rs:98-129): sqrt decomposition */
+int ref_mle_evaluate(int field, const uint8_t* z, size_t ell, const uint8_t* r, uint8_t* out32) {
+  const field_t* F = field_by_id(field); if (!F) return -1;
+  size_t s_right = ell / 2, s_left = ell - s_right, n_left = (size_t)1 << s_left, n_right = (size_t)1 << s_right;
+  uint8_t* el = (uint8_t*)malloc(32 * n_left); uint8_t* er = (uint8_t*)malloc(32 * n_right);
+  ref_eq_evals(field, r, s_left, el); ref_eq_evals(field, r + 32 * s_left, s_right, er);
+  fe acc; memset(&acc, 0, sizeof acc);
+  for (size_t i = 0; i < n_left; i++) {
+    fe red; memset(&red, 0, sizeof red);
+    for (size_t j = 0; j < n_right; j++) {
+      fe zz, e, t; ld_mont(F, &zz, z + 32 * (i * n_right + j)); ld_mont(F, &e, er + 32 * j);
+      fe_mul(F, &t, &zz, &e); fe_add(F, &red, &red, &t);
+    }
+    fe e, t; ld_mont(F, &e, el + 32 * i); fe_mul(F, &t, &e, &red); fe_add(F, &acc, &acc, &t);
+  }
+  st_canon(F, out32, &acc);
+  free(el); free(er);
+  return 0;
+}
+/* SparseMatrix::multiply_vec (src/r1cs/sparse.rs:201-229), CSR with usize indices */
+int ref_spmv(int field, const uint64_t* indptr, const uint64_t* indices, const uint8_t* data, size_t rows, const uint8_t* z, uint8_t* out) {
+  const field_t* F = field_by_id(field); if (!F) return -1;
+#pragma omp parallel for num_threads(nthreads())
+  for (long rw = 0; rw < (long)rows; rw++) {
+    fe acc; memset(&acc, 0, sizeof acc);
+    for (uint64_t k = indptr[rw]; k < indptr[rw + 1]; k++) {
+      fe d, v, t; ld_mont(F, &d, data + 32 * k); ld_mont(F, &v, z + 32 * indices[k]);
+      fe_mul(F, &t, &d, &v); fe_add(F, &acc, &acc, &t);
+    }
+    st_canon(F, out + 32 * rw, &acc);
+  }
+  return 0;
+}

@@ -237,3 +237,26 @@ def sumcheck_eq_sums(p, mode, A, B, C, eq_right, eq_left=None, shift=0):
         t0 += (A[i] * B[i] - c0) * fac
         tinf += (A[i + h] - A[i]) * (B[i + h] - B[i]) * fac
     return t0 % p, tinf % p
+
+
+def eq_evals(p, r):
+    """eq(r, x) for x in {0,1}^ell, x read MSB-first against r[0] (src/spartan/polys/eq.rs:29-41,54-73)."""
+    ell = len(r)
+    out = []
+    for x in range(1 << ell):
+        v = 1
+        for i in range(ell):
+            bit = (x >> (ell - 1 - i)) & 1
+            v = v * (r[i] if bit else (1 - r[i])) % p
+        out.append(v)
+    return out
+
+
+def mle_evaluate(p, Z, r):
+    """Z(r) = sum_x Z[x] * eq(r, x) (src/spartan/polys/multilinear.rs:88-129)."""
+    return sum(z * e for z, e in zip(Z, eq_evals(p, r))) % p
+
+
+def spmv(p, indptr, indices, data, z):
+    """CSR M*z (src/r1cs/sparse.rs:201-229)."""
+    return [sum(data[k] * z[indices[k]] for k in range(indptr[r], indptr[r + 1])) % p for r in range(len(indptr) - 1)]

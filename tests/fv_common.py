@@ -28,6 +28,32 @@ def to_bytes(x):
     return bytes(x) if isinstance(x, (bytes, bytearray)) else np.asarray(x).tobytes()
 
 
+def check_kats2(eq_evals, mle_evaluate, spmv):
+    """eq_evals(fid, r_vec) -> bytes; mle_evaluate(fid, z_vec, r_vec) -> bytes; spmv(fid, indptr, indices, data_vec, cols, z_vec) -> bytes"""
+    for fid in FIELDS:
+        for case in KATS["eq_evals"]["cases"]:
+            assert ints(np.frombuffer(to_bytes(eq_evals(fid, vec(case["r"]))), np.uint8)) == case["evals"]
+        for case in KATS["mle_bind_top_eval"]["cases"]:
+            assert ints(np.frombuffer(to_bytes(mle_evaluate(fid, vec(case["evals"]), vec(case["point"]))), np.uint8)) == [case["eval"]]
+        for case in KATS["spmv"]["cases"]:
+            got = spmv(fid, case["indptr"], case["indices"], vec(case["data"]), case["cols"], vec(case["z"]))
+            assert ints(np.frombuffer(to_bytes(got), np.uint8)) == case["out"]
+
+
+def random_csr(fid, rows, cols, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    counts = rng.integers(0, 9, size=rows)
+    counts[rows // 2] = 40  # one long row
+    indptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    nnz = int(indptr[-1])
+    indices = rng.integers(0, cols, size=nnz).astype(np.uint64)
+    data = rand_vec(fid, nnz, seed + 1).copy()
+    p = FIELDS[fid]
+    for i, x in enumerate([1, p - 1, 2, p - 7, 0]):  # the reference special-cases +-1 and small coefficients
+        data[(5 * i) % nnz] = util.int_to_le32(x)
+    return indptr, indices, data
+
+
 def check_kats(fold_pairs, bind_top):
     """fold_pairs(fid, poly_vec, x_vec) / bind_top(fid, evals_vec, r_vec) -> bytes; all four fields."""
     for fid in FIELDS:

@@ -51,3 +51,23 @@ def test_oracle_sumcheck_eq_sums(fid):
         assert got == enc(R.sumcheck_eq_sums(p, mode, C.ints(A), C.ints(B), C.ints(Cc), C.ints(eqR), C.ints(eqL), shift))
         got = cref.sumcheck_eq_sums(fid, mode, A, B, Cc, n, eqF)
         assert got == enc(R.sumcheck_eq_sums(p, mode, C.ints(A), C.ints(B), C.ints(Cc), C.ints(eqF)))
+
+
+def test_oracle_kats_eq_mle_spmv():
+    C.check_kats2(lambda fid, r: cref.eq_evals(fid, r, len(r)),
+                  lambda fid, z, r: cref.mle_evaluate(fid, z, len(r), r),
+                  lambda fid, ip, ix, d, cols, z: cref.spmv(fid, ip, ix, d, len(ip) - 1, z))
+
+
+@pytest.mark.parametrize("fid", range(4))
+def test_oracle_eq_mle_spmv_vs_definition(fid):
+    p = C.FIELDS[fid]
+    enc = lambda xs: b"".join(R.fe_to_le32(x) for x in xs)
+    for ell in (0, 1, 4, 7):
+        r = C.rand_vec(fid, max(ell, 1), 3)[:ell]
+        assert cref.eq_evals(fid, r, ell) == enc(R.eq_evals(p, C.ints(r)))
+        z = C.edge_vectors(fid, 1 << ell, 5) if ell else C.rand_vec(fid, 1, 5)
+        assert cref.mle_evaluate(fid, z, ell, r) == enc([R.mle_evaluate(p, C.ints(z), C.ints(r))])
+    ip, ix, d = C.random_csr(fid, 50, 30, 9)
+    z = C.rand_vec(fid, 30, 10)
+    assert cref.spmv(fid, ip, ix, d, 50, z) == enc(R.spmv(p, [int(x) for x in ip], [int(x) for x in ix], C.ints(d), C.ints(z)))

@@ -114,3 +114,36 @@ def test_sumcheck_eq_sums(nmx, fid, logn):
             got = fv.sumcheck_eq_sums(fid, mode, to_m(A), to_m(B), to_m(Cc), to_m(eqF), mont=True)
             exp = cref.sumcheck_eq_sums(fid, mode, A, B, Cc, n, eqF)
             assert tuple(int.from_bytes(g, "little") * pow(Rm, -1, p) % p for g in got) == tuple(int.from_bytes(e, "little") for e in exp)
+
+
+def test_reference_kats_eq_mle_spmv(nmx):
+    from nova_amd import fieldvec as fv
+
+    def spmv(fid, ip, ix, d, cols, z):
+        m = fv.SparseMatrix(fid, ip, ix, d, cols)
+        out = m.multiply_vec(z)
+        m.close()
+        return out
+
+    C.check_kats2(lambda fid, r: fv.eq_evals_from_points(fid, r), lambda fid, z, r: fv.mle_evaluate(fid, z, r), spmv)
+
+
+@pytest.mark.parametrize("fid", range(4))
+def test_eq_mle_spmv_vs_oracle(nmx, fid):
+    import torch
+    from nova_amd import fieldvec as fv
+    for ell in (0, 1, 5, 12, 17):
+        r = C.rand_vec(fid, max(ell, 1), 3)[:ell]
+        assert fv.eq_evals_from_points(fid, r).tobytes() == cref.eq_evals(fid, r, ell)
+        z = C.edge_vectors(fid, 1 << ell, 5) if ell else C.rand_vec(fid, 1, 5)
+        assert fv.mle_evaluate(fid, z, r) == cref.mle_evaluate(fid, z, ell, r)
+        if ell == 12:
+            assert fv.mle_evaluate(fid, torch.from_numpy(z.copy()).cuda(), r) == cref.mle_evaluate(fid, z, ell, r)
+    for rows, cols in ((50, 30), (20000, 15000)):
+        ip, ix, d = C.random_csr(fid, rows, cols, 9)
+        z = C.rand_vec(fid, cols, 10)
+        m = fv.SparseMatrix(fid, ip, ix, d, cols)
+        exp = cref.spmv(fid, ip, ix, d, rows, z)
+        assert m.multiply_vec(z).tobytes() == exp
+        assert m.multiply_vec(torch.from_numpy(z.copy()).cuda()).cpu().numpy().tobytes() == exp
+        m.close()
