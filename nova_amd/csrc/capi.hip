@@ -475,13 +475,11 @@ int nmx_mle_evaluate(int field, const void* z, size_t len, const void* r, size_t
     fv_eq_evals(*L.c, field, r, (uint32_t)s_left, flags, (uint32_t*)eqL.p);
     fv_eq_evals(*L.c, field, (const uint8_t*)r + 32 * s_left, (uint32_t)s_right, flags, (uint32_t*)eqR.p);
     const void* dz = z;
-    DevBuf* up = nullptr;
     DevBuf zbuf((flags & NMX_SCALARS_DEVICE) ? 1 : len * 32);
     if (!(flags & NMX_SCALARS_DEVICE)) {
       HIPCHK(hipMemcpyAsync(zbuf.p, z, len * 32, hipMemcpyHostToDevice, L.c->stream));
       dz = zbuf.p;
     }
-    (void)up;
     uint8_t two[64];
     // sum_id z[id] * eqL[id >> s_right] * eqR[id & (2^s_right - 1)]: the mode-1 sum over "half" = len
     fv_eq_sums(*L.c, field, 1, dz, nullptr, nullptr, 2 * len, eqL.p, (size_t)1 << s_left, eqR.p, (size_t)1 << s_right,
