@@ -108,7 +108,8 @@ template <int FID> struct XYZZ {
     F s2 = s.dbl().norm();                         //  2.12
     F x3 = F::sub4(m.sqr(), s2).norm();            //  1.11 + 4        < 5.11
     F e = F::sub8(s, x3).norm();                   //  1.06 + 8        < 9.06
-    F y3 = F::sub2(m * e, w * y).norm();           //  (1 + 33.5/127) + 2 < 3.27     [w*y < 1.03 < 2]
+    F ny = F::sub4(F::zero(), y);                  //  4p - y in (0.5, 4], limbs < 2^31 (left un-normalized)
+    F y3 = F::mul_add(m, e, w, ny);                //  m*e - w*y:  1 + (33.5 + 4.4)/127 < 1.3   [one reduction]
     x = x3;
     y = y3;
     zz = zz * v;                                   //  1 + 1.67/127    < 1.02
@@ -147,7 +148,8 @@ template <int FID> struct XYZZ {
     F t = (ppp + q.dbl()).norm();                  //  3.26
     F x3 = F::sub4(r.sqr(), t).norm();             //  (1 + 25.2/127) + 4 < 5.2
     F e = F::sub8(q, x3).norm();                   //  1.07 + 8        < 9.07
-    F y3 = F::sub2(r * e, y * ppp).norm();         //  (1 + 45.6/127) + 2 < 3.36  [y*ppp < 1.04 < 2]
+    F ny = F::sub4(F::zero(), y);                  //  4p - y in (0.5, 4], limbs < 2^31 (left un-normalized)
+    F y3 = F::mul_add(r, e, ppp, ny);              //  r*e - y*ppp:  1 + (45.6 + 4.5)/127 < 1.4  [one reduction]
     x = x3;
     y = y3;
     zz = zz * pp;                                  //  1 + 1.97/127    < 1.02
@@ -196,7 +198,8 @@ template <int FID> struct XYZZ {
     F t = (ppp + q.dbl()).norm();                  //  3.05
     F x3 = F::sub4(r.sqr(), t).norm();             //  (1 + 9.3/127) + 4 < 5.08
     F e = F::sub8(q, x3).norm();                   //  < 9.01
-    F y3 = F::sub2(r * e, s1 * ppp).norm();        //  (1 + 27.4/127) + 2 < 3.22
+    F ns1 = F::sub2(F::zero(), s1);                //  2p - s1 in (0.9, 2], limbs < 2^31 (left un-normalized)
+    F y3 = F::mul_add(r, e, ppp, ns1);             //  r*e - s1*ppp:  1 + (27.4 + 2.1)/127 < 1.24 [one reduction]
     x = x3;
     y = y3;
     zz = (zz * o.zz) * pp;                         //  < 1.02

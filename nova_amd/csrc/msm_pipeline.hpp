@@ -58,7 +58,8 @@ inline MsmShape make_shape(uint32_t n, uint32_t bits, uint32_t force_c, uint32_t
   sh.nbuckets = sh.WB * sh.M;
   sh.total = n * sh.W;
   if (pre_c) {
-    sh.lmax = 32;  // every bucket collects ~W*n/M points: equal 32-point tasks, perfectly balanced lanes
+    sh.lmax = 24;  // every bucket collects ~W*n/M points: equal 24-point tasks, perfectly balanced lanes
+                   // (measured sweep 16..64 at 2^20: 24 is the minimum of accumulate + fold)
   } else {
     uint32_t avg = n / sh.M;
     sh.lmax = 4 * avg < 32 ? 32 : 4 * avg;
