@@ -45,6 +45,9 @@ def main():
                          "SURVEY.md 8(f) at 2^log2n elements per GPU")
     args = ap.parse_args()
 
+    # RCCL prints a version banner on stdout when NCCL_DEBUG is VERSION/INFO; stdout must carry ONE JSON line
+    if os.environ.get("NCCL_DEBUG", "").upper() in ("VERSION", "INFO", "TRACE", ""):
+        os.environ["NCCL_DEBUG"] = "WARN"
     import torch
     import torch.distributed as dist
 
@@ -53,8 +56,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    # NMX_BENCH_FORCE_DIST=1 exercises the RCCL exchange path with a single rank (1-GPU boxes)
+    force_dist = os.environ.get("NMX_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
+        if force_dist and world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import nova_amd
     from nova_amd import _lib
@@ -82,7 +92,7 @@ def main():
     from nova_amd.dist import sharded_msm
 
     def step(j):
-        if world == 1:
+        if world == 1 and not force_dist:
             return group.vartime_multiscalar_mul(dev_sc[j & 1], ck)
         return sharded_msm(group, ck, dev_sc[j & 1])
 
@@ -113,6 +123,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    out = None
     if rank == 0:
         stage_ms = stage_sum / max(args.steps, 1)
         accum_ms = float(stage_ms[STAGES.index("accum")])
@@ -153,11 +164,24 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cid, ck, host_sc[(args.steps - 1) & 1], n, result)
-        print(json.dumps(out), flush=True)
     ck.close()
-    if world > 1:
+    emit(out if rank == 0 else None, world > 1 or force_dist, dist)
+
+
+def emit(result, world_or_dist, dist):
+    """Tear the process group down first, flush every C stdio buffer (library banners), then print the one JSON
+    line as the very last thing on rank 0's stdout."""
+    import ctypes
+    if world_or_dist:
         dist.barrier()
         dist.destroy_process_group()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    sys.stdout.flush()
+    if result is not None:
+        print(json.dumps(result), flush=True)
 
 
 def witness_like(cid, n, seed):
@@ -336,6 +360,7 @@ def field_workload(args, world, rank, L, torch, dist):
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    res = None
     if rank == 0:
         kms = ksum / args.steps
         achieved = bytes_per_elem * n / (kms * 1e-3) / 1e9
@@ -377,10 +402,7 @@ def field_workload(args, world, rank, L, torch, dist):
             res["cpu_baseline"] = {"value": cnt_rate / t, "unit": "elements/s", "cores": threads, "kind": "port",
                                    "sample": f"first {cnt} elements, one pass, oracle/nova_ref.c (OpenMP)",
                                    "gpu_matches_cpu": got == exp[: 32 * cnt]}
-        print(json.dumps(res), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    emit(res if rank == 0 else None, world > 1, dist)
 
 
 def cpu_baseline(cid, ck, scalars, n, gpu_result):
