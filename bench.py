@@ -45,9 +45,9 @@ def main():
                          "SURVEY.md 8(f) at 2^log2n elements per GPU")
     args = ap.parse_args()
 
-    # RCCL prints a version banner on stdout when NCCL_DEBUG is VERSION/INFO; stdout must carry ONE JSON line
-    if os.environ.get("NCCL_DEBUG", "").upper() in ("VERSION", "INFO", "TRACE", ""):
-        os.environ["NCCL_DEBUG"] = "WARN"
+    # RCCL writes its version banner / warnings to stdout; stdout must end with ONE JSON line: send RCCL's log to
+    # stderr and (see emit()) print the JSON only after the process group is gone and C stdio is flushed.
+    os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
     import torch
     import torch.distributed as dist
 
