@@ -131,7 +131,7 @@ template <int CID> static void table_shape(size_t n, uint32_t flags, uint32_t* p
   *pre_c = 0;
   *pre_W = 0;
   if (!(flags & NMX_BASES_PRECOMPUTE) || n < kPrecompMinN) return;
-  uint32_t c = G.force_c ? G.force_c : choose_c_precomp((uint32_t)n);
+  uint32_t c = G.force_c ? G.force_c : choose_c_precomp((uint32_t)n, FpParams<CurveT<CID>::SF>::BITS);
   uint32_t W = (FpParams<CurveT<CID>::SF>::BITS + 1 + c - 1) / c;
   if ((uint64_t)W * n >= (1ull << 31)) return;  // table index must fit 31 bits
   *pre_c = c;

@@ -157,7 +157,6 @@ struct PlanFn {
   const uint32_t* end;
   uint32_t* counters;  // [0] = extra tasks used, [1] = heavy buckets, [3] = most tasks in one bucket
   HeavyRec* heavy;
-  TaskRec* extra;
   MsmShape sh;
   NMX_HD void operator()(uint32_t k) const {
     uint32_t s = end[k] - start[k];
@@ -167,10 +166,27 @@ struct PlanFn {
     uint32_t off = nmx_atomic_add(&counters[0], nt);
     uint32_t h = nmx_atomic_add(&counters[1], 1);
     heavy[h] = HeavyRec{k, off, nt, 0};
-    for (uint32_t t = 0; t < nt; t++) {
-      uint32_t b = t * sh.lmax;
-      uint32_t len = s - b < sh.lmax ? s - b : sh.lmax;
-      extra[off + t] = TaskRec{start[k] + b, len};
+  }
+};
+// Task records of the over-long buckets, `lanes` lanes per bucket.  (A single lane per bucket would serialise
+// N/lmax writes when one bucket holds a whole window -- all-equal or 0/1 scalars, or a nearly empty top window.)
+struct ExpandFn {
+  const uint32_t* start;
+  const uint32_t* end;
+  const uint32_t* counters;
+  const HeavyRec* heavy;
+  TaskRec* extra;
+  MsmShape sh;
+  uint32_t lanes, groups;
+  NMX_HD void operator()(uint32_t tid) const {
+    const uint32_t j = tid % lanes, nh = counters[1];
+    for (uint32_t h = tid / lanes; h < nh; h += groups) {
+      const HeavyRec r = heavy[h];
+      const uint32_t b0 = start[r.bucket], s = end[r.bucket] - b0;
+      for (uint32_t t = j; t < r.cnt; t += lanes) {
+        const uint32_t b = t * sh.lmax;
+        extra[r.off + t] = TaskRec{b0 + b, s - b < sh.lmax ? s - b : sh.lmax};
+      }
     }
   }
 };

@@ -30,22 +30,42 @@ inline uint32_t ilog2_u32(uint32_t v) {
 
 // Window width.  Buckets cost ~2 full adds each in the reduction tree, points cost one mixed add per window:
 // the optimum grows like log2(n) - O(1); 16 keeps keys in 20 bits and the bucket array in L2-friendly sizes.
+// Among c0-1, c0, c0+1 prefer the width whose TOP window is well populated: a top window of t bits sends every
+// point into 2^(t-1) buckets, and with t of 2 or 3 those buckets each collect a large share of all points.
+inline uint32_t settle_c(int c0, int lo, int hi, uint32_t bits) {
+  int best = c0, best_score = -1;
+  for (int c = c0 - 1; c <= c0 + 1; c++) {
+    if (c < lo || c > hi) continue;
+    int W = ((int)bits + 1 + c - 1) / c;
+    int top = (int)bits + 1 - (W - 1) * c;           // bits carried by the top window
+    int score = (top * 2 >= c ? 1000 : top * 10) - (c == c0 ? 0 : 1);
+    if (score > best_score) {
+      best_score = score;
+      best = c;
+    }
+  }
+  return (uint32_t)best;
+}
 inline uint32_t choose_c(uint32_t n, uint32_t bits) {
   uint32_t lg = ilog2_u32(n < 2 ? 2 : n);
   int c = (int)lg - 4;
   if (c < 3) c = 3;
   if (c > 16) c = 16;
   if ((uint32_t)c > bits + 1) c = bits + 1;
+  if (c >= 6 && bits > 64) c = (int)settle_c(c, 5, 16, bits);
   return (uint32_t)c;
 }
 
 // Window width of the precomputed tables of a key of n_key points.
-inline uint32_t choose_c_precomp(uint32_t n_key) {
+// Measured (profiles/r01_msm_2p20/window_width_sweep.txt): 16 is best up to 2^21 points, 20 from 2^22 on
+// (13 windows instead of 16: -19 % mixed additions; 2^19 buckets are amortised only by that many points).
+inline uint32_t choose_c_precomp(uint32_t n_key, uint32_t bits) {
   uint32_t lg = ilog2_u32(n_key < 2 ? 2 : n_key);
+  if (lg >= 22) return 20;
   int c = (int)lg - 4;
   if (c < 8) c = 8;
   if (c > 16) c = 16;
-  return (uint32_t)c;
+  return settle_c(c, 8, 16, bits);
 }
 
 inline MsmShape make_shape(uint32_t n, uint32_t bits, uint32_t force_c, uint32_t pre_c = 0) {
@@ -119,8 +139,11 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
     be.launch(f, (uint32_t)total);
   }
   {
-    PlanFn f{start, end, counters, heavy, extra, sh};
+    PlanFn f{start, end, counters, heavy, sh};
     be.launch(f, sh.nbuckets);
+    const uint32_t hb = heavy_cap < sh.nbuckets ? heavy_cap : sh.nbuckets;
+    ExpandFn e{start, end, counters, heavy, extra, sh, 64, hb < 16384 ? hb : 16384};
+    be.launch(e, e.groups * e.lanes);
   }
   be.mark("accum");
   {
