@@ -15,7 +15,7 @@
 //   4. PlanFn        buckets longer than lmax are split into lmax-sized extra tasks (bounded work per lane
 //                    whatever the scalar distribution: all-equal scalars put N points in one bucket)
 //   5. AccumFn       one lane per (bucket | extra task): gather affine points, XYZZ mixed adds (msm.rs:129-165)
-//   6. FoldFn x4     strided folds of a heavy bucket's partial sums -> bucket
+//   6. FoldFn x<=6   strided folds of a heavy bucket's partial sums -> bucket
 //   7. ReducePairFn  per-window sum_k k*B_k as a binary tree, log2(M) levels, two dependent additions per level
 //                    (msm.rs:555-561,637-643 do this sum serially per thread)
 //   8. host tail     Horner over the W window sums (msm.rs:651-661), one inversion, canonical bytes.
@@ -240,7 +240,7 @@ template <int FID> struct AccumFn {
 
 // ----------------------------------------------------------------------------------------------------
 // 6. strided fold of heavy buckets' partials.  Lane j of group g folds positions j, j+T, j+2T, ... < cnt
-//    into position j.  Applied with T = 256, 32, 4, 1 (cnt = all, 256, 32, 4); the last pass writes the bucket.
+//    into position j.  Applied with T = 32768, 4096, 512, 64, 8, 1; the last pass writes the bucket.
 // ----------------------------------------------------------------------------------------------------
 template <int FID> struct FoldFn {
   const uint32_t* counters;

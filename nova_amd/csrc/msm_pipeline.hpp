@@ -152,21 +152,25 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
   }
   be.mark("fold");
   {
+    // Every pass shrinks a bucket's partial count by at most 8x (<= 7 dependent additions per lane); passes that no
+    // bucket needs exit at once (max task count is on the device).  One bucket holding a whole window (all-equal or
+    // 0/1 scalars) therefore costs ~35 dependent additions instead of N / (lmax * 256).
     const uint32_t hb = heavy_cap < sh.nbuckets ? heavy_cap : sh.nbuckets;  // upper bound on heavy buckets
-    const uint32_t g256 = hb < 4096 ? hb : 4096;
-    FoldFn<FID> f{counters, heavy, partials, buckets, 256, 0xffffffffu, g256};
-    be.launch(f, g256 * 256);
-    f.T = 32;
-    f.cap = 256;
-    f.groups = hb < 32768 ? hb : 32768;
-    be.launch(f, f.groups * 32);
-    f.T = 4;
-    f.cap = 32;
-    f.groups = hb;
-    be.launch(f, f.groups * 4);
-    f.T = 1;
-    f.cap = 4;
-    be.launch(f, f.groups);
+    // typical task count per bucket decides the last split: ~22 partials fold fastest as 4 lanes x 6 then 1 x 4
+    const uint32_t typical = (uint32_t)(total / ((size_t)sh.nbuckets * sh.lmax));
+    const uint32_t Ts[6] = {32768, 4096, 512, 64, typical > 32 ? 8u : 4u, 1};
+    for (int p = 0; p < 6; p++) {
+      const uint32_t T = Ts[p];
+      const uint32_t cap = p == 0 ? 0xffffffffu : Ts[p - 1];
+      if ((uint64_t)T * sh.lmax > total && T != 1) continue;  // no bucket can have more than T tasks
+      // buckets with more than T tasks number at most total / (T * lmax): ~2^18 lanes per pass cover them in a few
+      // sweeps, and a pass nobody needs costs one small empty launch
+      uint32_t groups = T == 1 ? hb : (1u << 18) / T;
+      if (groups > hb) groups = hb;
+      if (groups < 1) groups = 1;
+      FoldFn<FID> f{counters, heavy, partials, buckets, T, cap, groups};
+      be.launch(f, groups * T);
+    }
   }
   be.mark("reduce");
   const XYZZW* D = buckets;
