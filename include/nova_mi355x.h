@@ -103,6 +103,13 @@ int nmx_msm_u64(int curve, const uint64_t* scalars, const void* bases_xy64, size
 int nmx_msm_u64_handle(uint64_t handle, size_t offset, const uint64_t* scalars, size_t n,
                        uint32_t max_num_bits, uint32_t flags, uint8_t* out, uint8_t* out_is_inf);
 
+/* Sparse commitments over a registered key (src/provider/pedersen.rs:395-427, src/provider/hyperkzg.rs:751-790):
+ *   scalars != NULL: commit_sparse's MSM   out = sum_j scalars[j] * ck[indices[j]]
+ *   scalars == NULL: commit_sparse_binary / batch_add (src/provider/msm.rs:689-708)   out = sum_j ck[indices[j]]
+ * indices are `usize` on the reference side (host pointer); an index >= the key length is NMX_E_HANDLE. */
+int nmx_msm_sparse_handle(uint64_t handle, const uint64_t* indices, const void* scalars, size_t k, uint32_t flags,
+                          uint8_t* out, uint8_t* out_is_inf);
+
 /* DlogGroupExt::batch_vartime_multiscalar_mul (src/provider/traits.rs:82-90; blitzar override
  * src/provider/blitzar.rs:22-40): k MSMs over one base array, the j-th using bases[..lens[j]]
  * (HyperKZG batch_commit, src/provider/hyperkzg.rs:593-612).  out = k x 64 bytes, out_is_inf = k bytes. */

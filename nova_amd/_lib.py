@@ -44,6 +44,7 @@ def lib():
     L.nmx_msm_handle.argtypes = [u64, sz, vp, sz, u32, vp, vp]
     L.nmx_msm_u64.argtypes = [i, vp, vp, sz, u32, u32, vp, vp]
     L.nmx_msm_u64_handle.argtypes = [u64, sz, vp, sz, u32, u32, vp, vp]
+    L.nmx_msm_sparse_handle.argtypes = [u64, vp, vp, sz, u32, vp, vp]
     L.nmx_msm_batch.argtypes = [i, vp, vp, sz, vp, sz, u32, vp, vp]
     L.nmx_msm_batch_handle.argtypes = [u64, vp, vp, sz, u32, vp, vp]
     L.nmx_commit.argtypes = [u64, vp, sz, vp, vp, u32, vp, vp]

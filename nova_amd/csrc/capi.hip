@@ -311,6 +311,25 @@ int nmx_msm_u64(int curve, const uint64_t* scalars, const void* bases, size_t n,
   });
 }
 
+int nmx_msm_sparse_handle(uint64_t handle, const uint64_t* indices, const void* scalars, size_t k, uint32_t flags,
+                          uint8_t* out, uint8_t* out_is_inf) {
+  return guarded([&] {
+    require(out && (indices || k == 0), NMX_E_ARG, "null argument");
+    require(!(flags & NMX_SCALARS_DEVICE) || scalars, NMX_E_ARG, "device flag without scalars");
+    auto bs = lookup(handle);
+    std::vector<uint32_t> idx(k ? k : 1);
+    for (size_t i = 0; i < k; i++) {
+      require(indices[i] < bs.n, NMX_E_HANDLE, "index beyond the registered key");  // ck.ck[i] would panic
+      idx[i] = (uint32_t)indices[i];
+    }
+    CtxLease L;
+    MsmCall mc = scalars ? field_call(scalars, flags) : MsmCall{nullptr, false, false, 1, true};
+    mc.gather_host = idx.data();
+    mc.all_ones = scalars == nullptr;
+    ops(bs.curve).msm_key(*L.c, bs, 0, k, mc, flags, out, out_is_inf);
+  });
+}
+
 static void batch_impl(const BaseSet& bs, const void* const* vecs, const size_t* lens, size_t k, uint32_t flags,
                        uint8_t* out, uint8_t* out_is_inf, Ctx& c) {
   require((vecs && lens && out) || k == 0, NMX_E_ARG, "null argument");

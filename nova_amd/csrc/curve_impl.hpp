@@ -80,7 +80,15 @@ static XYZZ<CurveT<CID>::BF> run_msm(Ctx& c, const void* d_bases, size_t n, cons
   const bool prof = G.profiling;
   for (int pass = 0; pass < 2; pass++) {
     DeviceBackend be(c, pass == 0, prof);
-    if (mc.scalars_device) {
+    if (mc.gather_host) {
+      uint32_t* d_g = be.alloc<uint32_t>(n);
+      a.gather = d_g;
+      if (pass == 1) HIPCHK(hipMemcpyAsync(d_g, mc.gather_host, n * 4, hipMemcpyHostToDevice, c.stream));
+    }
+    a.all_ones = mc.all_ones ? 1u : 0u;
+    if (mc.all_ones) {
+      a.scalars = nullptr;
+    } else if (mc.scalars_device) {
       a.scalars = (const uint32_t*)mc.scalars;
     } else {
       uint32_t* d_s = be.alloc<uint32_t>(n * sbytes / 4);

@@ -71,13 +71,16 @@ template <int SFID> struct DigitsFn {
   uint32_t u64_bits;      // 0: field scalars; >0: scalars are u64 and must be < 2^u64_bits
   uint32_t pre_stride;    // 0: plain bases[i]; else window w uses table entry w*pre_stride + pre_offset + i
   uint32_t pre_offset;
+  const uint32_t* gather;  // non-null: pair i uses base index gather[i] (commit_sparse / batch_add, pedersen.rs:395-427)
+  uint32_t all_ones;       // 1: every scalar is 1 (commit_sparse_binary); `scalars` is not read
 
   NMX_HD void operator()(uint32_t i) const {
     uint32_t s[9];
     bool skip = false;
+    const uint32_t bi = (gather ? gather[i] : i) + pre_offset;  // index of this pair's base in the key
     if (u64_bits) {
-      s[0] = scalars[2 * (size_t)i];
-      s[1] = scalars[2 * (size_t)i + 1];
+      s[0] = all_ones ? 1u : scalars[2 * (size_t)i];
+      s[1] = all_ones ? 0u : scalars[2 * (size_t)i + 1];
 #pragma unroll
       for (int j = 2; j < 9; j++) s[j] = 0;
       if (u64_bits < 64) {
@@ -99,7 +102,7 @@ template <int SFID> struct DigitsFn {
     }
     if (bases) {  // identity base contributes nothing (msm.rs:247-249)
       uint32_t o = 0;
-      const uint32_t* b = bases + 16 * ((size_t)pre_offset + i);
+      const uint32_t* b = bases + 16 * (size_t)bi;
 #pragma unroll
       for (int j = 0; j < 16; j++) o |= b[j];
       if (o == 0) skip = true;
@@ -123,7 +126,7 @@ template <int SFID> struct DigitsFn {
       uint32_t key = (d == 0 || skip) ? sh.nbuckets : ((pre_stride ? 0u : w * sh.M) + d - 1);
       size_t o = (size_t)w * sh.n + i;
       keys[o] = key;
-      vals[o] = (pre_stride ? w * pre_stride + pre_offset + i : i) | (neg << 31);
+      vals[o] = (w * pre_stride + bi) | (neg << 31);
     }
   }
 };

@@ -20,6 +20,9 @@ struct MsmArgs {
   // precomputed-table mode (key registered with NMX_BASES_PRECOMPUTE): `bases` points at T_0[0], tables are
   // pre_stride apart, this call uses entries [pre_offset, pre_offset + n) of each, window width pre_c
   uint32_t pre_stride = 0, pre_offset = 0, pre_c = 0;
+  // sparse forms (commit_sparse / commit_sparse_binary): pair i uses base gather[i]; all_ones: scalars are all 1
+  const uint32_t* gather = nullptr;
+  uint32_t all_ones = 0;
 };
 
 inline uint32_t ilog2_u32(uint32_t v) {
@@ -126,6 +129,8 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
     f.u64_bits = a.u64_bits;
     f.pre_stride = a.pre_stride;
     f.pre_offset = a.pre_offset;
+    f.gather = a.gather;
+    f.all_ones = a.all_ones;
     be.launch(f, sh.n);
   }
   be.mark("sort");

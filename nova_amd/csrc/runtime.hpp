@@ -153,6 +153,9 @@ struct MsmCall {
   bool u64_mode;
   // precomputed tables of the registered key (0 = none / not used for this call)
   uint32_t pre_stride = 0, pre_offset = 0, pre_c = 0;
+  // sparse forms: host base indices (validated < key length by the caller), and "all scalars are 1"
+  const uint32_t* gather_host = nullptr;
+  bool all_ones = false;
 };
 static constexpr size_t kPrecompMinN = 4096;  // below this the plain path with a narrow window is faster
 

@@ -221,6 +221,47 @@ class CommitmentEngine:
             return self.group.batch_vartime_multiscalar_mul(vs, ck, mont)
         return [self.commit(ck, v, r, mont) for v, r in zip(vs, rs)]
 
+    def _blind(self, ck, point, r, mont):
+        """point + h*r through the ABI: both as partials, summed by nmx_point_sum."""
+        if r is None or bytes(_host_u8(r, 32)) == bytes(32):
+            return self.group.point_sum([point.xy])
+        blind = self.commit(ck, np.zeros((0, 32), np.uint8), r, mont, partial=True)
+        return self.group.point_sum([point.xy, blind.xy])
+
+    def _sparse(self, ck, indices, scalars, mont):
+        idx = np.ascontiguousarray(indices, dtype=np.uint64)
+        out = _Out(partial=True)
+        if scalars is None:
+            sp, flags = None, 0
+        else:
+            sp, n, dev, _k = _scalar_arg(scalars, 32)
+            assert n == len(idx), "assert_eq!(indices.len(), scalars.len())  (pedersen.rs:416)"
+            flags = dev | (L.SCALARS_MONT if mont else 0)
+        _check(L.lib().nmx_msm_sparse_handle(ck.handle, idx.ctypes.data, sp, len(idx), flags | L.OUT_PARTIAL, *out.p))
+        return out.get()
+
+    def commit_sparse_binary(self, ck, non_zero_indices, r=None, mont=False):
+        """batch_add(&ck.ck, indices) + h*r  (pedersen.rs:395-408, msm.rs:689-708)."""
+        return self._blind(ck, self._sparse(ck, non_zero_indices, None, mont), r, mont)
+
+    def commit_sparse(self, ck, indices, scalars, r=None, mont=False):
+        """msm(scalars, ck[indices]) + h*r  (pedersen.rs:410-427)."""
+        return self._blind(ck, self._sparse(ck, indices, scalars, mont), r, mont)
+
+    def commit_small_range(self, ck, v_u64, r, start, stop, max_num_bits, mont=False):
+        """msm_small_with_max_num_bits(v[range], ck[range]) + h*r  (pedersen.rs:285-305)."""
+        v = np.ascontiguousarray(v_u64, dtype=np.uint64)[start:stop]
+        out = _Out(partial=True)
+        assert stop <= len(ck), "assert!(bases.len() == scalars.len())"
+        _check(L.lib().nmx_msm_u64_handle(ck.handle, start, v.ctypes.data, len(v), int(max_num_bits), L.OUT_PARTIAL, *out.p))
+        return self._blind(ck, out.get(), r, mont)
+
+    def batch_commit_small(self, ck, vs, rs=None, mont=False):
+        """commitment.rs:139-150 / hyperkzg.rs:626-645: commit_small per vector."""
+        rs = [None] * len(vs) if rs is None else rs
+        assert len(vs) == len(rs)
+        return [self.commit_small(ck, v, r, mont) for v, r in zip(vs, rs)]
+
     def commit_small(self, ck, v_u64, r=None, mont=False):
         """msm_small(v, ck[..len v]) + h*r  (pedersen.rs:272-283)."""
         small = self.group.vartime_multiscalar_mul_small(v_u64, ck, partial=True)

@@ -160,6 +160,43 @@ def test_commit_engine(nmx, c):
     ck.close()
 
 
+@pytest.mark.parametrize("c", [R.BN254_G1, R.VESTA], ids=lambda c: c.name)
+@pytest.mark.parametrize("precompute", [True, False])
+def test_sparse_commitments(nmx, c, precompute):
+    """commit_sparse_binary / commit_sparse / commit_small_range / batch_commit_small
+    (src/provider/pedersen.rs:285-305,395-427) against the oracle on gathered bases."""
+    ce = nmx.CommitmentEngine(c.cid)
+    n_key = 6000
+    host = cref.sequential_bases(c, 41, n_key + 1).copy()
+    host[17] = 0
+    ck = nmx.CommitmentKey.from_host(c.cid, host[:n_key], host[n_key].tobytes(), precompute=precompute)
+    rng = np.random.Generator(np.random.PCG64(5))
+    r = util.random_scalars(c.cid, 1, seed=9)
+    for k in (0, 1, 300, 5000):
+        idx = rng.integers(0, n_key, size=k).astype(np.uint64)  # with repeats: a base may appear several times
+        if k >= 300:
+            idx[3] = 17  # the identity point
+        gathered = host[idx.astype(np.int64)] if k else np.zeros((0, 64), np.uint8)
+        ones = util.u64_to_le32(np.ones(k, np.uint64))
+        assert as_pair(ce.commit_sparse_binary(ck, idx)) == cref.msm(c.cid, ones, gathered, k)
+        assert as_pair(ce.commit_sparse_binary(ck, idx, r)) == cref.commit(c.cid, ones, gathered, k, host[n_key], r)
+        sc = util.scalar_set(c.cid, k, "pm_small") if k else np.zeros((0, 32), np.uint8)
+        assert as_pair(ce.commit_sparse(ck, idx, sc)) == cref.msm(c.cid, sc, gathered, k)
+        assert as_pair(ce.commit_sparse(ck, idx, sc, r)) == cref.commit(c.cid, sc, gathered, k, host[n_key], r)
+    from nova_amd import _lib
+    with pytest.raises(nmx.NmxError) as e:
+        ce.commit_sparse_binary(ck, np.array([n_key], np.uint64))
+    assert e.value.code == _lib.E_HANDLE
+    v = util.small_scalars(n_key, 12)
+    exp = cref.commit(c.cid, util.u64_to_le32(v[100:5100]), host[100:5100], 5000, host[n_key], r)
+    assert as_pair(ce.commit_small_range(ck, v, r, 100, 5100, 12)) == exp
+    vs = [util.small_scalars(L, 9, seed=L) for L in (10, 4500)]
+    got = [as_pair(x) for x in ce.batch_commit_small(ck, vs, [r, None])]
+    assert got[0] == cref.commit(c.cid, util.u64_to_le32(vs[0]), host[:10], 10, host[n_key], r)
+    assert got[1] == cref.msm(c.cid, util.u64_to_le32(vs[1]), host[:4500], 4500)
+    ck.close()
+
+
 @pytest.mark.parametrize("c", ALL, ids=lambda c: c.name)
 def test_precomputed_tables_vs_plain(nmx, c):
     """A key registered with window tables (NMX_BASES_PRECOMPUTE) and the same key without them give the oracle's
