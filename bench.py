@@ -27,6 +27,27 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 BYTES_PER_PAIR = 96            # 32 B scalar + 64 B affine base, each read once
 STAGES = ["digits", "sort", "bounds_plan", "accum", "fold", "reduce", "tail"]
+MAD_PEAK_T = 28.8              # measured v_mad_u64_u32 rate, T/s (bench/ubench.hip)
+MADS_PER_MADD = 1305           # 6 x 162 + 2 x 126 + 243 multiply-adds per XYZZ mixed addition (curve.hpp)
+
+
+def madds_per_launch(n, args):
+    """Mixed additions of one accumulate launch on uniformly random scalars: one per (pair, window)."""
+    bits = {0: 254, 1: 254, 2: 255, 3: 255}[args.curve]
+    c = args.window_bits or (20 if args.log2n >= 22 else 16)
+    return n * (-(-(bits + 1) // c))
+
+
+def pmc_traffic(args, world):
+    """HBM bytes per accumulate launch from the committed PMC summary -- only for the exact configuration it was
+    collected on (BN254, 2^20, random scalars, one GPU); everything else reports null."""
+    if not (world == 1 and args.curve == 0 and args.log2n == 20 and args.dist == "random" and not args.window_bits):
+        return None
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_msm_2p20", "pmc_traffic.json")))["accum"]
+        return d["hbm_read_bytes_corrected"] + d["hbm_write_bytes"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def main():
@@ -157,9 +178,15 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic(args, world),
                 "note": "algorithmic bytes = 96 B/pair x pairs per launch / accum-kernel time (hipEvents on the "
-                        "library stream); the MSM is integer-VALU-bound, not HBM-bound (DESIGN.md)",
+                        "library stream); the MSM is integer-VALU-bound, not HBM-bound (DESIGN.md). traffic = HBM bytes "
+                        "per launch from the separate rocprofv3 --pmc passes in profiles/ (null for other configs).",
+                # the roofline that actually binds this kernel: 32x32+64 multiply-adds against the measured
+                # v_mad_u64_u32 rate (profiles/r01_ubench_instruction_rates.jsonl)
+                "valu_mad": {"achieved_T_per_s": MADS_PER_MADD * madds_per_launch(n, args) / (accum_ms * 1e-3) / 1e12 if accum_ms > 0 else 0.0,
+                             "peak_T_per_s": MAD_PEAK_T, "frac": (MADS_PER_MADD * madds_per_launch(n, args) / (accum_ms * 1e-3) / 1e12) / MAD_PEAK_T if accum_ms > 0 else 0.0,
+                             "mads_per_mixed_add": MADS_PER_MADD},
             },
         }
         if world == 1 and not args.no_cpu_baseline:
