@@ -173,8 +173,7 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
       uint32_t groups = T == 1 ? hb : (1u << 18) / T;
       if (groups > hb) groups = hb;
       if (groups < 1) groups = 1;
-      FoldFn<FID> f{counters, heavy, partials, buckets, T, cap, groups};
-      be.launch(f, groups * T);
+      be.template launch_fold<FID>(counters, heavy, partials, buckets, T, cap, groups);
     }
   }
   be.mark("reduce");
@@ -186,9 +185,7 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
     XYZZW* Do = be.template alloc<XYZZW>((size_t)sh.WB * half);
     XYZZW* Yo = be.template alloc<XYZZW>((size_t)sh.WB * half);
     const uint32_t pairs = sh.WB * half;
-    const uint32_t padded = (pairs + 63u) & ~63u;
-    ReducePairFn<FID> f{D, Y, Do, Yo, n_in, pairs, padded, first};
-    be.launch(f, 2 * padded);
+    be.template launch_reduce_pair<FID>(D, Y, Do, Yo, n_in, pairs, first);
     D = Do;
     Y = Yo;
     n_in = half;

@@ -18,6 +18,7 @@
 #include "../../include/nova_mi355x.h"
 #include "curves.hpp"
 #include "msm_pipeline.hpp"
+#include "curve_quad.hpp"
 
 namespace nmx {
 
@@ -115,6 +116,20 @@ struct DeviceBackend {
     if (dry || n == 0) return;
     hipLaunchKernelGGL((k_launch<F>), dim3((n + 255) / 256), dim3(256), 0, c.stream, f, n);
     HIPCHK(hipGetLastError());
+  }
+  // the latency-bound stages run with four cooperating lanes per point addition (curve_quad.hpp)
+  template <int FID>
+  void launch_fold(const uint32_t* counters, const HeavyRec* heavy, XYZZW* partials, XYZZW* buckets, uint32_t T,
+                   uint32_t cap, uint32_t groups) {
+    FoldQuadFn<FID> f{counters, heavy, partials, buckets, T, cap, groups};
+    launch(f, groups * T * 4);
+  }
+  template <int FID>
+  void launch_reduce_pair(const XYZZW* D, const XYZZW* Y, XYZZW* Do, XYZZW* Yo, uint32_t n_in, uint32_t pairs,
+                          uint32_t first) {
+    const uint32_t padded = (pairs + 15u) & ~15u;  // 16 quads = one wave: roles never share a wave
+    ReducePairQuadFn<FID> f{D, Y, Do, Yo, n_in, pairs, padded, first};
+    launch(f, 2 * padded * 4);
   }
   void sort_pairs(uint32_t* k_in, uint32_t* k_out, uint32_t* v_in, uint32_t* v_out, size_t total,
                   uint32_t bits) {

@@ -32,6 +32,19 @@ struct HostEmulBackend {
   template <class F> void launch(const F& f, uint32_t n) {
     for (uint32_t t = 0; t < n; t++) f(t);
   }
+  template <int FID>
+  void launch_fold(const uint32_t* counters, const HeavyRec* heavy, XYZZW* partials, XYZZW* buckets, uint32_t T,
+                   uint32_t cap, uint32_t groups) {
+    FoldFn<FID> f{counters, heavy, partials, buckets, T, cap, groups};
+    launch(f, groups * T);
+  }
+  template <int FID>
+  void launch_reduce_pair(const XYZZW* D, const XYZZW* Y, XYZZW* Do, XYZZW* Yo, uint32_t n_in, uint32_t pairs,
+                          uint32_t first) {
+    const uint32_t padded = (pairs + 63u) & ~63u;
+    ReducePairFn<FID> f{D, Y, Do, Yo, n_in, pairs, padded, first};
+    launch(f, 2 * padded);
+  }
   void sort_pairs(uint32_t* k_in, uint32_t* k_out, uint32_t* v_in, uint32_t* v_out, size_t total, uint32_t bits) {
     std::vector<uint32_t> idx(total);
     std::iota(idx.begin(), idx.end(), 0u);
