@@ -127,7 +127,7 @@ template <int FID> struct FoldQuadFn {
   XYZZW* partials;
   XYZZW* buckets;
   uint32_t T, cap, groups;
-  __device__ void operator()(uint32_t tid) const {
+  __device__ __forceinline__ void operator()(uint32_t tid) const {
     if (T != 1 && counters[3] <= T) return;
     const uint32_t q = tid & 3u, item = tid >> 2;
     const uint32_t j = item % T, nh = counters[1];
@@ -149,7 +149,7 @@ template <int FID> struct ReducePairQuadFn {
   XYZZW* D_out;
   XYZZW* Y_out;
   uint32_t n_in, pairs, pairs_padded /* multiple of 16: roles never share a wave */, first;
-  __device__ void operator()(uint32_t tid) const {
+  __device__ __forceinline__ void operator()(uint32_t tid) const {
     const uint32_t q = tid & 3u, item = tid >> 2;
     const uint32_t role = item >= pairs_padded ? 1u : 0u;
     const uint32_t j = item - role * pairs_padded;
