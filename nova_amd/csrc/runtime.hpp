@@ -117,19 +117,34 @@ struct DeviceBackend {
     hipLaunchKernelGGL((k_launch<F>), dim3((n + 255) / 256), dim3(256), 0, c.stream, f, n);
     HIPCHK(hipGetLastError());
   }
-  // the latency-bound stages run with four cooperating lanes per point addition (curve_quad.hpp)
+  // Fold / reduction passes with fewer work items than the chip has lanes are bound by the latency of a point
+  // addition: they run with four cooperating lanes per addition (curve_quad.hpp, ~3x shorter latency, ~1.3x the
+  // lane-cycles).  Passes with enough items to be throughput-bound keep one lane per addition.
+  static constexpr uint32_t kQuadBelowItems = 65536;  // 256 CUs x 4 SIMDs x 64 lanes
   template <int FID>
   void launch_fold(const uint32_t* counters, const HeavyRec* heavy, XYZZW* partials, XYZZW* buckets, uint32_t T,
                    uint32_t cap, uint32_t groups) {
-    FoldQuadFn<FID> f{counters, heavy, partials, buckets, T, cap, groups};
-    launch(f, groups * T * 4);
+    // T >= 64 passes only ever touch the few buckets that hold a large share of all points
+    if (T >= 64 || groups * T < kQuadBelowItems) {
+      FoldQuadFn<FID> f{counters, heavy, partials, buckets, T, cap, groups};
+      launch(f, groups * T * 4);
+    } else {
+      FoldFn<FID> f{counters, heavy, partials, buckets, T, cap, groups};
+      launch(f, groups * T);
+    }
   }
   template <int FID>
   void launch_reduce_pair(const XYZZW* D, const XYZZW* Y, XYZZW* Do, XYZZW* Yo, uint32_t n_in, uint32_t pairs,
                           uint32_t first) {
-    const uint32_t padded = (pairs + 15u) & ~15u;  // 16 quads = one wave: roles never share a wave
-    ReducePairQuadFn<FID> f{D, Y, Do, Yo, n_in, pairs, padded, first};
-    launch(f, 2 * padded * 4);
+    if (2 * pairs < kQuadBelowItems) {
+      const uint32_t padded = (pairs + 15u) & ~15u;  // 16 quads = one wave: roles never share a wave
+      ReducePairQuadFn<FID> f{D, Y, Do, Yo, n_in, pairs, padded, first};
+      launch(f, 2 * padded * 4);
+    } else {
+      const uint32_t padded = (pairs + 63u) & ~63u;
+      ReducePairFn<FID> f{D, Y, Do, Yo, n_in, pairs, padded, first};
+      launch(f, 2 * padded);
+    }
   }
   void sort_pairs(uint32_t* k_in, uint32_t* k_out, uint32_t* v_in, uint32_t* v_out, size_t total,
                   uint32_t bits) {
