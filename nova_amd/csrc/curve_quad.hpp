@@ -130,7 +130,7 @@ template <int FID> struct FoldQuadFn {
   __device__ __forceinline__ void operator()(uint32_t tid) const {
     if (T != 1 && counters[3] <= T) return;
     const uint32_t q = tid & 3u, item = tid >> 2;
-    const uint32_t j = item % T, nh = counters[1];
+    const uint32_t j = item % T, nh = counters[T >= 64 ? 4 : 1];
     for (uint32_t h = item / T; h < nh; h += groups) {
       const HeavyRec r = heavy[h];
       const uint32_t cnt = r.cnt < cap ? r.cnt : cap;

@@ -158,8 +158,9 @@ struct TaskRec {
 struct PlanFn {
   const uint32_t* start;
   const uint32_t* end;
-  uint32_t* counters;  // [0] = extra tasks used, [1] = heavy buckets, [3] = most tasks in one bucket
+  uint32_t* counters;  // [0] = extra tasks used, [1] = heavy buckets, [3] = most tasks in one bucket, [4] = big ones
   HeavyRec* heavy;
+  HeavyRec* big;  // the buckets split into more than 64 tasks (at most total / (64 * lmax) of them)
   MsmShape sh;
   NMX_HD void operator()(uint32_t k) const {
     uint32_t s = end[k] - start[k];
@@ -169,6 +170,7 @@ struct PlanFn {
     uint32_t off = nmx_atomic_add(&counters[0], nt);
     uint32_t h = nmx_atomic_add(&counters[1], 1);
     heavy[h] = HeavyRec{k, off, nt, 0};
+    if (nt > 64) big[nmx_atomic_add(&counters[4], 1)] = HeavyRec{k, off, nt, 0};  // see FoldFn: passes with T >= 64
   }
 };
 // Task records of the over-long buckets, `lanes` lanes per bucket.  (A single lane per bucket would serialise
@@ -247,7 +249,7 @@ template <int FID> struct AccumFn {
 // ----------------------------------------------------------------------------------------------------
 template <int FID> struct FoldFn {
   const uint32_t* counters;
-  const HeavyRec* heavy;
+  const HeavyRec* heavy;  // the list this pass walks: all split buckets (T < 64) or only the big ones (T >= 64)
   XYZZW* partials;
   XYZZW* buckets;
   uint32_t T;       // lanes per heavy bucket in this pass
@@ -256,7 +258,7 @@ template <int FID> struct FoldFn {
   NMX_HD void operator()(uint32_t tid) const {
     if (T != 1 && counters[3] <= T) return;  // no bucket has more than T partials: this pass has nothing to fold
     uint32_t j = tid % T;
-    uint32_t nh = counters[1];
+    uint32_t nh = counters[T >= 64 ? 4 : 1];
     for (uint32_t h = tid / T; h < nh; h += groups) {
       HeavyRec r = heavy[h];
       uint32_t cnt = r.cnt < cap ? r.cnt : cap;

@@ -106,15 +106,17 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
   uint32_t* vals0 = be.template alloc<uint32_t>(total);
   uint32_t* keys1 = be.template alloc<uint32_t>(total);
   uint32_t* vals1 = be.template alloc<uint32_t>(total);
-  uint32_t* start = be.template alloc<uint32_t>(2 * ((size_t)sh.nbuckets + 1) + 4);
+  uint32_t* start = be.template alloc<uint32_t>(2 * ((size_t)sh.nbuckets + 1) + 8);
   uint32_t* end = start + sh.nbuckets + 1;
-  uint32_t* counters = end + sh.nbuckets + 1;  // [0] extra tasks, [1] heavy buckets, [2] error bits, [3] max tasks
+  uint32_t* counters = end + sh.nbuckets + 1;  // [0] extra tasks, [1] split buckets, [2] error bits, [3] max tasks, [4] big
   HeavyRec* heavy = be.template alloc<HeavyRec>(heavy_cap);
+  const uint32_t big_cap = (uint32_t)(total / ((size_t)64 * sh.lmax)) + 1;
+  HeavyRec* big = be.template alloc<HeavyRec>(big_cap);
   TaskRec* extra = be.template alloc<TaskRec>(extra_cap);
   XYZZW* buckets = be.template alloc<XYZZW>(sh.nbuckets);
   XYZZW* partials = be.template alloc<XYZZW>(extra_cap);
 
-  be.memset0(start, (2 * ((size_t)sh.nbuckets + 1) + 4) * sizeof(uint32_t));
+  be.memset0(start, (2 * ((size_t)sh.nbuckets + 1) + 8) * sizeof(uint32_t));
 
   be.mark("digits");
   {
@@ -144,7 +146,7 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
     be.launch(f, (uint32_t)total);
   }
   {
-    PlanFn f{start, end, counters, heavy, sh};
+    PlanFn f{start, end, counters, heavy, big, sh};
     be.launch(f, sh.nbuckets);
     const uint32_t hb = heavy_cap < sh.nbuckets ? heavy_cap : sh.nbuckets;
     ExpandFn e{start, end, counters, heavy, extra, sh, 64, hb < 16384 ? hb : 16384};
@@ -170,10 +172,12 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
       if ((uint64_t)T * sh.lmax > total && T != 1) continue;  // no bucket can have more than T tasks
       // buckets with more than T tasks number at most total / (T * lmax): ~2^18 lanes per pass cover them in a few
       // sweeps, and a pass nobody needs costs one small empty launch
-      uint32_t groups = T == 1 ? hb : (1u << 18) / T;
-      if (groups > hb) groups = hb;
+      // T >= 64 passes walk the short list of big buckets; the last two walk every split bucket, one group each
+      const uint32_t bound = T >= 64 ? (big_cap < hb ? big_cap : hb) : hb;
+      uint32_t groups = T >= 64 ? (1u << 18) / T : bound;
+      if (groups > bound) groups = bound;
       if (groups < 1) groups = 1;
-      be.template launch_fold<FID>(counters, heavy, partials, buckets, T, cap, groups);
+      be.template launch_fold<FID>(counters, T >= 64 ? big : heavy, partials, buckets, T, cap, groups);
     }
   }
   be.mark("reduce");
