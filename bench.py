@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--iters", type=int, default=65536, help="prove_step_replay: MinRoot iterations per step")
-    ap.add_argument("--workload", default="msm", choices=["msm", "axpy", "cross_term", "bind", "sumcheck3", "prove_step_replay"],
+    ap.add_argument("--workload", default="msm", choices=["msm", "axpy", "cross_term", "bind", "sumcheck3", "prove_step_replay", "hyperkzg_replay"],
                     help="msm = the headline (default); the others time one HBM-bound field-vector kernel of "
                          "SURVEY.md 8(f) at 2^log2n elements per GPU")
     args = ap.parse_args()
@@ -98,6 +98,8 @@ def main():
 
     if args.workload == "prove_step_replay":
         return prove_step_replay(args, world, rank, L, torch, dist)
+    if args.workload == "hyperkzg_replay":
+        return hyperkzg_replay(args, world, rank, L, torch, dist)
     if args.workload != "msm":
         return field_workload(args, world, rank, L, torch, dist)
 
@@ -311,6 +313,76 @@ def prove_step_replay(args, world, rank, L, torch, dist):
     print(json.dumps(outj), flush=True)
     for k in ck:
         ck[k].close()
+
+
+def hyperkzg_replay(args, world, rank, L, torch, dist):
+    """REPLAY of the provider-side work of one HyperKZG `prove` (src/provider/hyperkzg.rs:926-1110) for
+    n = 2^log2n on BN254: ell-1 pair folds Pi[j] = P[2j] + x*(P[2j+1]-P[2j]) (hyperkzg.rs:1085-1095), `batch_commit` of
+    the folded polynomials of lengths n/2 ... 2 (hyperkzg.rs:1100), and the three length-n MSMs of `kzg_open`
+    (hyperkzg.rs:1002-1004,1062-1065).  Everything stays in HBM; commitments return to the host.  NOT replayed: the
+    transcript, the 3*ell Horner evaluations and `div_by_monomial` (hyperkzg.rs:961-1056; not built yet), so the
+    kzg_open MSMs run on stand-in random quotient polynomials.  A replay, not `prove`: no Rust toolchain here."""
+    import nova_amd
+    from nova_amd import fieldvec as fv
+    from tests import util
+    assert world == 1
+    ell = args.log2n
+    n = 1 << ell
+    cid = 0
+    fid = fv.SCALAR_FIELD_OF_CURVE[cid]
+    ce = nova_amd.CommitmentEngine(cid)
+    ck = ce.setup_synthetic(n, k0=5)
+    hP = util.random_scalars(cid, n, seed=41)
+    hQ = [util.random_scalars(cid, n, seed=50 + j) for j in range(3)]
+    xs = util.random_scalars(cid, ell, seed=42)
+    dP = torch.from_numpy(hP).cuda()
+    dQ = [torch.from_numpy(q).cuda() for q in hQ]
+
+    def step():
+        polys, cur = [], dP
+        for i in range(ell - 1):
+            cur = fv.fold_pairs(fid, cur, xs[ell - i - 1])
+            polys.append(cur)
+        coms = ce.batch_commit(ck, polys)
+        opens = [ce.commit(ck, q) for q in dQ]
+        return coms, opens
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        coms, opens = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    outj = {
+        "metric": "HyperKZG prove provider-call REPLAY ms (BN254)", "value": dt * 1e3, "unit": "ms", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": False, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u32x8 (256-bit modular integer)", "data": "synthetic",
+        "config": {"workload": f"HyperKZG prove replay, n = 2^{ell}: {ell - 1} pair folds, batch_commit of lengths n/2..2, 3 MSMs of n "
+                               "(BASELINE.json configs[4]); no transcript / Horner / div_by_monomial"},
+        "roofline": None,
+    }
+    if not args.no_cpu_baseline:
+        from oracle import cref
+        threads = effective_cpus()
+        cref.set_threads(threads)
+        key = ck.read(0, n)
+        prep = cref.Prepared(cid, key, n)
+        t1 = time.perf_counter()
+        cur, hp = hP, []
+        for i in range(ell - 1):
+            m = len(cur) // 2
+            cur = np.frombuffer(cref.field_bind(fid, cur, 0, 1, 2, xs[ell - i - 1], m), np.uint8).reshape(m, 32)
+            hp.append(cur)
+        ecoms = [prep.msm(p_, len(p_)) for p_ in hp]
+        eopens = [prep.msm(q, n) for q in hQ]
+        t_cpu = time.perf_counter() - t1
+        ok = [(c.xy, int(c.is_inf)) for c in coms] == ecoms and [(c.xy, int(c.is_inf)) for c in opens] == eopens
+        outj["cpu_baseline"] = {"value": t_cpu * 1e3, "unit": "ms", "cores": threads, "kind": "port",
+                                "sample": "the same call sequence once through oracle/nova_ref.c", "gpu_matches_cpu": ok}
+    print(json.dumps(outj), flush=True)
+    ck.close()
 
 
 def effective_cpus():
