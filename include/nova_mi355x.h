@@ -162,6 +162,10 @@ int nmx_poly_fold_pairs(int field, const void* p, size_t len, const void* x, uin
 int nmx_sumcheck_eq_sums(int field, int mode, const void* A, const void* B, const void* C, size_t len, const void* eqL,
                          size_t n_eqL, const void* eqR, size_t n_eqR, uint32_t shift, uint32_t flags, uint8_t* out64);
 
+/* out[i] = sum_{k >= i} f[k] * u^(k-i), i < n (coefficient form).  out[0] is `poly_eval(f, u)` (Horner,
+ * src/provider/hyperkzg.rs:1011-1020); out[1..n) is the quotient h of `div_by_monomial(f, u)`
+ * (src/provider/hyperkzg.rs:961-999, h[i-1] = f[i] + h[i]*u) that kzg_open commits to. */
+int nmx_poly_suffix_horner(int field, const void* f, size_t n, const void* u, uint32_t flags, void* out);
 /* EqPolynomial::evals_from_points (src/spartan/polys/eq.rs:54-73): out[2^ell] = eq(r, x) for x in {0,1}^ell, r[0] the
  * most significant variable.  r: ell x 32 bytes, host.  out: host, or HBM with NMX_SCALARS_DEVICE. */
 int nmx_eq_evals_from_points(int field, const void* r, size_t ell, uint32_t flags, void* out);

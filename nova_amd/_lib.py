@@ -56,6 +56,7 @@ def lib():
     L.nmx_mle_bind_top.argtypes = [i, vp, sz, vp, u32, vp]
     L.nmx_poly_fold_pairs.argtypes = [i, vp, sz, vp, u32, vp]
     L.nmx_sumcheck_eq_sums.argtypes = [i, i, vp, vp, vp, sz, vp, sz, vp, sz, u32, u32, vp]
+    L.nmx_poly_suffix_horner.argtypes = [i, vp, sz, vp, u32, vp]
     L.nmx_eq_evals_from_points.argtypes = [i, vp, sz, u32, vp]
     L.nmx_mle_evaluate.argtypes = [i, vp, sz, vp, sz, u32, vp]
     L.nmx_spmv_register.argtypes = [i, vp, vp, vp, sz, sz, u32, ctypes.POINTER(u64)]

@@ -518,6 +518,16 @@ struct DevBuf {  // RAII device allocation
   }
 };
 
+int nmx_poly_suffix_horner(int field, const void* f, size_t n, const void* u, uint32_t flags, void* out) {
+  return guarded([&] {
+    require(f && u && out, NMX_E_ARG, "null argument");
+    require(n >= 1 && n < (1ull << 31), NMX_E_ARG, "assert!(!f.is_empty())");
+    require(!((flags & NMX_SCALARS_DEVICE) && out == f), NMX_E_ARG, "cannot run in place");
+    CtxLease L;
+    fv_suffix_horner(*L.c, field, f, n, u, flags, out);
+  });
+}
+
 int nmx_eq_evals_from_points(int field, const void* r, size_t ell, uint32_t flags, void* out) {
   return guarded([&] {
     require((r || ell == 0) && out, NMX_E_ARG, "null argument");

@@ -105,6 +105,43 @@ template <int FID> struct SpmvFn {
   }
 };
 
+// Suffix Horner  out[i] = sum_{k >= i} f[k] * u^(k-i):  out[0] is `poly_eval(f, u)` (hyperkzg.rs:1011-1020) and out[1..]
+// is the quotient of `div_by_monomial` (hyperkzg.rs:961-999: h[i-1] = f[i] + h[i]*u).  Same three phases as the
+// reference's chunked version -- chunk-local recurrences, carries between chunks with u^chunk, fix-up -- with
+// 64-element chunks (one lane each) and the carry phase applied recursively.
+static constexpr uint32_t kHornerChunk = 64;
+template <int FID> struct HornerLocalFn {
+  const uint32_t* f;
+  uint32_t* out;    // local suffix values
+  uint32_t* heads;  // heads[c] = local value at the first element of chunk c
+  Fp<FID> u;        // u * 2^261
+  uint32_t n;
+  NMX_HD void operator()(uint32_t c) const {
+    using F = Fp<FID>;
+    const uint32_t lo = c * kHornerChunk, hi = lo + kHornerChunk < n ? lo + kHornerChunk : n;
+    F t = F::zero();
+    for (uint32_t i = hi; i-- > lo;) {
+      t = (ld<FID>(f, i) + u * t).norm().canon();
+      t.to_words(out + 8 * (size_t)i);
+    }
+    t.to_words(heads + 8 * (size_t)c);
+  }
+};
+template <int FID> struct HornerFixFn {
+  uint32_t* out;
+  const uint32_t* carries;  // carries[c] = global suffix value at the start of chunk c
+  const uint32_t* pw;       // pw[k] = u^k * 2^261, k = 0..64
+  uint32_t n;
+  NMX_HD void operator()(uint32_t i) const {
+    using F = Fp<FID>;
+    const uint32_t c = i / kHornerChunk, nc = (n + kHornerChunk - 1) / kHornerChunk;
+    if (c + 1 >= nc) return;  // last chunk: local values are already global
+    const uint32_t dist = (c + 1) * kHornerChunk - i;  // 1..64
+    F v = ld<FID>(out, i) + ld<FID>(pw, dist) * ld<FID>(carries, c + 1);
+    st<FID>(out, i, v.norm());
+  }
+};
+
 // ---- host side ---------------------------------------------------------------------------------------
 // launch one functor over n lanes; with profiling on, bracket it with hipEvents on the context's stream
 struct VecIO;
@@ -256,6 +293,73 @@ static void spmv_apply_t(Ctx& c, const uint32_t* indptr, const uint32_t* indices
   uint32_t* dout = io.out(out, rows);
   SpmvFn<FID> f{indptr, indices, data, dz, dout};
   timed_launch(c, f, rows, &io);
+}
+
+// out (device, n elements) <- suffix Horner of f (device) at the challenge whose internal residue is `ui`
+template <int FID> static void horner_dev(Ctx& c, const uint32_t* f, uint32_t n, Fp<FID> ui, uint32_t* out,
+                                          std::vector<void*>& tmp) {
+  using F = Fp<FID>;
+  DeviceBackend be(c, false, false);
+  const uint32_t nc = (n + kHornerChunk - 1) / kHornerChunk;
+  uint32_t* heads = nullptr;
+  HIPCHK(hipMalloc((void**)&heads, (size_t)nc * 32));
+  tmp.push_back(heads);
+  HornerLocalFn<FID> lf{f, out, heads, ui, n};
+  be.launch(lf, nc);
+  if (nc == 1) return;
+  // powers u^0 .. u^64 (internal form), 64 host multiplications
+  std::vector<uint32_t> pwh(8 * (kHornerChunk + 1));
+  F p = F::one();
+  for (uint32_t k = 0; k <= kHornerChunk; k++) {
+    p.canon().to_words(pwh.data() + 8 * k);
+    p = (p * ui).canon();
+  }
+  F uc = F::from_words(pwh.data() + 8 * kHornerChunk);  // u^64
+  uint32_t *pw = nullptr, *carries = nullptr;
+  HIPCHK(hipMalloc((void**)&pw, pwh.size() * 4));
+  tmp.push_back(pw);
+  HIPCHK(hipMalloc((void**)&carries, (size_t)nc * 32));
+  tmp.push_back(carries);
+  HIPCHK(hipMemcpyAsync(pw, pwh.data(), pwh.size() * 4, hipMemcpyHostToDevice, c.stream));
+  HIPCHK(hipStreamSynchronize(c.stream));  // pwh is a local buffer
+  horner_dev<FID>(c, heads, nc, uc, carries, tmp);
+  HornerFixFn<FID> ff{out, carries, pw, n};
+  be.launch(ff, n);
+}
+template <int FID>
+static void horner_t(Ctx& c, const void* f, size_t n, const void* u, uint32_t flags, void* out) {
+  const bool dev = flags & NMX_SCALARS_DEVICE;
+  std::vector<void*> tmp;
+  struct Free {
+    std::vector<void*>& v;
+    ~Free() {
+      for (void* p : v) (void)hipFree(p);
+    }
+  } guard{tmp};
+  const uint32_t* df = (const uint32_t*)f;
+  uint32_t* dout = (uint32_t*)out;
+  if (!dev) {
+    void *a = nullptr, *b = nullptr;
+    HIPCHK(hipMalloc(&a, n * 32));
+    tmp.push_back(a);
+    HIPCHK(hipMalloc(&b, n * 32));
+    tmp.push_back(b);
+    HIPCHK(hipMemcpyAsync(a, f, n * 32, hipMemcpyHostToDevice, c.stream));
+    df = (const uint32_t*)a;
+    dout = (uint32_t*)b;
+  }
+  horner_dev<FID>(c, df, (uint32_t)n, challenge<FID>(u, flags & NMX_SCALARS_MONT), dout, tmp);
+  if (!dev) HIPCHK(hipMemcpyAsync(out, dout, n * 32, hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipStreamSynchronize(c.stream));
+}
+void fv_suffix_horner(Ctx& c, int field, const void* f, size_t n, const void* u, uint32_t flags, void* out) {
+  switch (field) {
+    case 0: horner_t<0>(c, f, n, u, flags, out); break;
+    case 1: horner_t<1>(c, f, n, u, flags, out); break;
+    case 2: horner_t<2>(c, f, n, u, flags, out); break;
+    case 3: horner_t<3>(c, f, n, u, flags, out); break;
+    default: throw Fail{NMX_E_ARG, "bad field id"};
+  }
 }
 
 void fv_eq_evals(Ctx& c, int field, const void* r_host, uint32_t ell, uint32_t flags, uint32_t* d_out) {

@@ -213,6 +213,7 @@ void fv_vec_add(Ctx&, int field, const void* a, const void* b, size_t n, uint32_
 void fv_bind(Ctx&, int field, const void* z, size_t z_len, size_t lo_off, size_t hi_off, size_t stride, const void* r,
              size_t n_out, uint32_t flags, void* out);
 
+void fv_suffix_horner(Ctx&, int field, const void* f, size_t n, const void* u, uint32_t flags, void* out);
 void fv_eq_evals(Ctx&, int field, const void* r_host, uint32_t ell, uint32_t flags, uint32_t* d_out);
 void fv_spmv_convert(Ctx&, int field, uint32_t* d_data, size_t nnz, uint32_t flags);
 void fv_spmv_apply(Ctx&, int field, const uint32_t* indptr, const uint32_t* indices, const uint32_t* data, size_t rows,

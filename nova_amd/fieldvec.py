@@ -179,3 +179,22 @@ class SparseMatrix:
         if self.handle:
             _check(L.lib().nmx_spmv_unregister(self.handle))
             self.handle = 0
+
+
+def suffix_horner(field, f, u, mont=False):
+    """out[i] = sum_{k>=i} f[k] u^(k-i): out[0] = poly_eval(f, u) (hyperkzg.rs:1011-1020), out[1:] = the quotient of
+    div_by_monomial(f, u) (hyperkzg.rs:961-999)."""
+    pf, n, dev, _kf = _vec(f)
+    uu = _chal(u)
+    po, out = _out_like(dev, n, f)
+    _check(L.lib().nmx_poly_suffix_horner(field, pf, n, uu.ctypes.data, _flags(dev, mont), po))
+    return out
+
+
+def poly_eval(field, f, u, mont=False):
+    out = suffix_horner(field, f, u, mont)
+    return (out[0].cpu().numpy() if _is_device_tensor(out) else out[0]).tobytes()
+
+
+def div_by_monomial(field, f, u, mont=False):
+    return suffix_horner(field, f, u, mont)[1:]

@@ -43,6 +43,7 @@ def lib():
         L.ref_field_axpy2.argtypes = [ctypes.c_int, vp, vp, vp, vp, sz, vp]
         L.ref_field_cross_term.argtypes = [ctypes.c_int, vp, vp, vp, vp, vp, sz, vp]
         L.ref_field_bind.argtypes = [ctypes.c_int, vp, sz, sz, sz, vp, sz, vp]
+        L.ref_poly_suffix_horner.argtypes = [ctypes.c_int, vp, sz, vp, vp]
         L.ref_eq_evals.argtypes = [ctypes.c_int, vp, sz, vp]
         L.ref_mle_evaluate.argtypes = [ctypes.c_int, vp, sz, vp, vp]
         L.ref_spmv.argtypes = [ctypes.c_int, vp, vp, vp, sz, vp, vp]
@@ -228,4 +229,12 @@ def spmv(fid, indptr, indices, data, rows, z):
     pz, _z = _buf(z)
     out = np.zeros(32 * rows, dtype=np.uint8)
     lib().ref_spmv(fid, ip.ctypes.data, ix.ctypes.data, pd, rows, pz, out.ctypes.data)
+    return out.tobytes()
+
+
+def suffix_horner(fid, f, n, u):
+    pf, _f = _buf(f)
+    pu, _u = _buf(u)
+    out = np.zeros(32 * n, dtype=np.uint8)
+    lib().ref_poly_suffix_horner(fid, pf, n, pu, out.ctypes.data)
     return out.tobytes()

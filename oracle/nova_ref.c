@@ -825,3 +825,16 @@ int ref_spmv(int field, const uint64_t* indptr, const uint64_t* indices, const u
   }
   return 0;
 }
+
+/* div_by_monomial (src/provider/hyperkzg.rs:946-999: h[i-1] = f[i] + h[i]*u, chunked in the reference, serial here)
+ * and Horner poly_eval (hyperkzg.rs:1011-1020) in one pass: out[i] = sum_{k>=i} f[k] u^(k-i). */
+int ref_poly_suffix_horner(int field, const uint8_t* f, size_t n, const uint8_t* u, uint8_t* out) {
+  const field_t* F = field_by_id(field); if (!F) return -1;
+  fe uu, acc; ld_mont(F, &uu, u); memset(&acc, 0, sizeof acc);
+  for (size_t i = n; i-- > 0;) {
+    fe fi; ld_mont(F, &fi, f + 32 * i);
+    fe_mul(F, &acc, &acc, &uu); fe_add(F, &acc, &acc, &fi);   /* acc = acc * u + fi */
+    st_canon(F, out + 32 * i, &acc);
+  }
+  return 0;
+}

@@ -260,3 +260,21 @@ def mle_evaluate(p, Z, r):
 def spmv(p, indptr, indices, data, z):
     """CSR M*z (src/r1cs/sparse.rs:201-229)."""
     return [sum(data[k] * z[indices[k]] for k in range(indptr[r], indptr[r + 1])) % p for r in range(len(indptr) - 1)]
+
+
+def poly_eval(p, f, u):
+    """Horner (src/provider/hyperkzg.rs:1011-1020): coefficients low to high."""
+    acc = 0
+    for c in reversed(f):
+        acc = (acc * u + c) % p
+    return acc
+
+
+def div_by_monomial(p, f, u):
+    """h with f(x) = h(x) (x - u) + f(u): h[i-1] = f[i] + h[i]*u (src/provider/hyperkzg.rs:946-999)."""
+    h = [0] * (len(f) - 1)
+    nxt = 0
+    for i in range(len(f) - 1, 0, -1):
+        nxt = (f[i] + nxt * u) % p
+        h[i - 1] = nxt
+    return h

@@ -71,3 +71,23 @@ def test_oracle_eq_mle_spmv_vs_definition(fid):
     ip, ix, d = C.random_csr(fid, 50, 30, 9)
     z = C.rand_vec(fid, 30, 10)
     assert cref.spmv(fid, ip, ix, d, 50, z) == enc(R.spmv(p, [int(x) for x in ip], [int(x) for x in ix], C.ints(d), C.ints(z)))
+
+
+@pytest.mark.parametrize("fid", range(4))
+def test_oracle_horner_and_div_by_monomial(fid):
+    """hyperkzg.rs:946-1020: the quotient really divides (f(x) = h(x)(x-u) + f(u)) and the C pass matches."""
+    p = C.FIELDS[fid]
+    for n in (1, 2, 7, 200):
+        f = C.edge_vectors(fid, n, 3) if n > 5 else C.rand_vec(fid, n, 3)
+        u = C.rand_vec(fid, 1, 4)
+        fi, ui = C.ints(f), C.ints(u)[0]
+        h, ev = R.div_by_monomial(p, fi, ui), R.poly_eval(p, fi, ui)
+        # multiply back: h(x)(x-u) + ev == f(x)
+        back = [0] * n
+        for i, c in enumerate(h):
+            back[i + 1] = (back[i + 1] + c) % p
+            back[i] = (back[i] - c * ui) % p
+        back[0] = (back[0] + ev) % p
+        assert back == fi
+        got = cref.suffix_horner(fid, f, n, u)
+        assert got == b"".join(R.fe_to_le32(x) for x in [ev] + h)

@@ -147,3 +147,22 @@ def test_eq_mle_spmv_vs_oracle(nmx, fid):
         assert m.multiply_vec(z).tobytes() == exp
         assert m.multiply_vec(torch.from_numpy(z.copy()).cuda()).cpu().numpy().tobytes() == exp
         m.close()
+
+
+@pytest.mark.parametrize("fid", range(4))
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 4096, 4097, 300000])
+def test_horner_and_div_by_monomial(nmx, fid, n):
+    """poly_eval + div_by_monomial (hyperkzg.rs:946-1020) as one suffix-Horner pass; chunk boundaries and recursion."""
+    import torch
+    from nova_amd import fieldvec as fv
+    f = C.edge_vectors(fid, n, 3) if n > 5 else C.rand_vec(fid, n, 3)
+    u = C.rand_vec(fid, 1, 4)
+    exp = cref.suffix_horner(fid, f, n, u)
+    assert fv.suffix_horner(fid, f, u).tobytes() == exp
+    assert fv.poly_eval(fid, f, u) == exp[:32]
+    if n in (65, 300000):
+        d = torch.from_numpy(f.copy()).cuda()
+        assert fv.div_by_monomial(fid, d, u).cpu().numpy().tobytes() == exp[32:]
+    for special in (0, 1):
+        us = util.int_to_le32(special)
+        assert fv.suffix_horner(fid, f, us).tobytes() == cref.suffix_horner(fid, f, n, us)
