@@ -317,11 +317,13 @@ def prove_step_replay(args, world, rank, L, torch, dist):
 
 def hyperkzg_replay(args, world, rank, L, torch, dist):
     """REPLAY of the provider-side work of one HyperKZG `prove` (src/provider/hyperkzg.rs:926-1110) for
-    n = 2^log2n on BN254: ell-1 pair folds Pi[j] = P[2j] + x*(P[2j+1]-P[2j]) (hyperkzg.rs:1085-1095), `batch_commit` of
-    the folded polynomials of lengths n/2 ... 2 (hyperkzg.rs:1100), and the three length-n MSMs of `kzg_open`
-    (hyperkzg.rs:1002-1004,1062-1065).  Everything stays in HBM; commitments return to the host.  NOT replayed: the
-    transcript, the 3*ell Horner evaluations and `div_by_monomial` (hyperkzg.rs:961-1056; not built yet), so the
-    kzg_open MSMs run on stand-in random quotient polynomials.  A replay, not `prove`: no Rust toolchain here."""
+    n = 2^log2n on BN254, everything resident in HBM, commitments / evaluations returned to the host:
+      ell-1 pair folds Pi[j] = P[2j] + x*(P[2j+1]-P[2j])                      (hyperkzg.rs:1085-1095)
+      batch_commit of the folded polynomials, lengths n/2 ... 2               (hyperkzg.rs:1100)
+      3*ell Horner evaluations f_i(u_j)                                       (hyperkzg.rs:1011-1020,1049-1056)
+      B = sum q^i f_i                                                         (hyperkzg.rs:1028-1040)
+      3 x kzg_open: h = div_by_monomial(B, u_j), commit(h)                    (hyperkzg.rs:961-1004,1062-1065)
+    NOT replayed: the Keccak transcript (challenges are fixed random scalars).  A replay, not `prove`."""
     import nova_amd
     from nova_amd import fieldvec as fv
     from tests import util
@@ -333,34 +335,39 @@ def hyperkzg_replay(args, world, rank, L, torch, dist):
     ce = nova_amd.CommitmentEngine(cid)
     ck = ce.setup_synthetic(n, k0=5)
     hP = util.random_scalars(cid, n, seed=41)
-    hQ = [util.random_scalars(cid, n, seed=50 + j) for j in range(3)]
     xs = util.random_scalars(cid, ell, seed=42)
+    us = util.random_scalars(cid, 3, seed=43)
+    qs = util.random_scalars(cid, ell, seed=44)
     dP = torch.from_numpy(hP).cuda()
-    dQ = [torch.from_numpy(q).cuda() for q in hQ]
 
     def step():
-        polys, cur = [], dP
+        polys, cur = [dP], dP
         for i in range(ell - 1):
             cur = fv.fold_pairs(fid, cur, xs[ell - i - 1])
             polys.append(cur)
-        coms = ce.batch_commit(ck, polys)
-        opens = [ce.commit(ck, q) for q in dQ]
-        return coms, opens
+        coms = ce.batch_commit(ck, polys[1:])
+        evals = [[fv.poly_eval(fid, f, us[j]) for j in range(3)] for f in polys]
+        B = polys[0].clone()
+        for i in range(1, ell):
+            m = polys[i].shape[0]
+            B[:m] = fv.axpy(fid, B[:m].contiguous(), polys[i], qs[i])
+        opens = [ce.commit(ck, fv.div_by_monomial(fid, B, us[j]).contiguous()) for j in range(3)]
+        return coms, evals, opens
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        coms, opens = step()
+        coms, evals, opens = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     outj = {
         "metric": "HyperKZG prove provider-call REPLAY ms (BN254)", "value": dt * 1e3, "unit": "ms", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": False, "scaling": "weak",
         "vs_baseline": None, "dtype": "u32x8 (256-bit modular integer)", "data": "synthetic",
-        "config": {"workload": f"HyperKZG prove replay, n = 2^{ell}: {ell - 1} pair folds, batch_commit of lengths n/2..2, 3 MSMs of n "
-                               "(BASELINE.json configs[4]); no transcript / Horner / div_by_monomial"},
+        "config": {"workload": f"HyperKZG prove replay, n = 2^{ell}: {ell - 1} pair folds, batch_commit of lengths n/2..2, {3 * ell} Horner "
+                               "evaluations, batch polynomial, 3 x (div_by_monomial + MSM of n-1) (BASELINE.json configs[4]); no transcript"},
         "roofline": None,
     }
     if not args.no_cpu_baseline:
@@ -370,17 +377,27 @@ def hyperkzg_replay(args, world, rank, L, torch, dist):
         key = ck.read(0, n)
         prep = cref.Prepared(cid, key, n)
         t1 = time.perf_counter()
-        cur, hp = hP, []
+        cur, hp = hP, [hP]
         for i in range(ell - 1):
             m = len(cur) // 2
             cur = np.frombuffer(cref.field_bind(fid, cur, 0, 1, 2, xs[ell - i - 1], m), np.uint8).reshape(m, 32)
             hp.append(cur)
-        ecoms = [prep.msm(p_, len(p_)) for p_ in hp]
-        eopens = [prep.msm(q, n) for q in hQ]
+        ecoms = [prep.msm(p_, len(p_)) for p_ in hp[1:]]
+        eevals = [[cref.suffix_horner(fid, f, len(f), us[j])[:32] for j in range(3)] for f in hp]
+        Bh = hP.copy()
+        for i in range(1, ell):
+            m = len(hp[i])
+            Bh[:m] = np.frombuffer(cref.field_axpy(fid, Bh[:m], hp[i], qs[i], m), np.uint8).reshape(m, 32)
+        eopens = []
+        for j in range(3):
+            h = np.frombuffer(cref.suffix_horner(fid, Bh, n, us[j]), np.uint8).reshape(n, 32)[1:]
+            eopens.append(prep.msm(np.ascontiguousarray(h), n - 1))
         t_cpu = time.perf_counter() - t1
-        ok = [(c.xy, int(c.is_inf)) for c in coms] == ecoms and [(c.xy, int(c.is_inf)) for c in opens] == eopens
+        ok = ([(c.xy, int(c.is_inf)) for c in coms] == ecoms and evals == eevals
+              and [(c.xy, int(c.is_inf)) for c in opens] == eopens)
         outj["cpu_baseline"] = {"value": t_cpu * 1e3, "unit": "ms", "cores": threads, "kind": "port",
-                                "sample": "the same call sequence once through oracle/nova_ref.c", "gpu_matches_cpu": ok}
+                                "sample": "the same call sequence once through oracle/nova_ref.c (Horner / division passes are "
+                                          "single-threaded there)", "gpu_matches_cpu": ok}
     print(json.dumps(outj), flush=True)
     ck.close()
 
