@@ -134,8 +134,11 @@ def main():
     fence()
     t0 = time.perf_counter()
     result = None
+    per_call = []
     for j in range(args.steps):
-        result = step(j)
+        tj = time.perf_counter()
+        result = step(j)  # returns the point: every call ends with its own device->host copy, so this is a full latency
+        per_call.append(time.perf_counter() - tj)
         k = L.nmx_profile_last(prof, 16)  # hipEvent times of this step's kernels, on the library's stream
         stage_sum[:k] += np.array(prof[:k])
     fence()
@@ -173,6 +176,8 @@ def main():
                 "combine": "rccl all_gather of 128-byte partials + host point sum" if world > 1 else "none",
             },
             "stages_ms": {s: round(float(v), 4) for s, v in zip(STAGES, stage_ms)},
+            # median and min of the timed calls (rank 0's own calls; `value` uses the whole region)
+            "per_call_ms": {"median": round(float(np.median(per_call)) * 1e3, 4), "min": round(min(per_call) * 1e3, 4)},
             "roofline": {
                 "bound": "hbm",
                 "kernel": "k_launch<AccumFn> (bucket accumulation)",

@@ -161,6 +161,19 @@ int nmx_poly_fold_pairs(int field, const void* p, size_t len, const void* x, uin
  * from these sums and the claim stays on the caller's side (sumcheck.rs:686-753). */
 int nmx_sumcheck_eq_sums(int field, int mode, const void* A, const void* B, const void* C, size_t len, const void* eqL,
                          size_t n_eqL, const void* eqR, size_t n_eqR, uint32_t shift, uint32_t flags, uint8_t* out64);
+/* The sums of one round of the sum-checks WITHOUT an eq factor, over id in [0, len/2), dX = x1 - x0, X(-1) = 2*x0 - x1:
+ *   kind 1 (A, B)    quad_prod  out = (sum a0*b0,    sum dA*dB)                  src/spartan/sumcheck.rs:163-186
+ *   kind 2 (A, B)    linear     out = (sum a0 - b0,  sum A(-1) - B(-1))          src/spartan/sumcheck.rs:353-378
+ *   kind 3 (A, B)    quadratic  out = (sum a0*b0,    sum A(-1)*B(-1))            src/spartan/sumcheck.rs:380-405
+ *   kind 4 (A, B, C) cubic      out = (sum a0*b0*c0, sum dA*dB*dC, sum A(-1)*B(-1)*C(-1))   sumcheck.rs:407-443
+ * out96 = three field elements (the third is zero for kinds 1-3), host pointer, in the vectors' own form. */
+int nmx_sumcheck_plain_sums(int field, int kind, const void* A, const void* B, const void* C, size_t len, uint32_t flags,
+                            uint8_t* out96);
+/* PolyEvalWitness::batch / batch_diff_size (src/spartan/mod.rs:165-277): out[i] = sum_j s^j * vecs[j][i], i < n_out,
+ * vectors shorter than n_out read as zero-padded; every lens[j] <= n_out.  `vecs`, `lens`, `s` are host arrays; the
+ * vectors themselves and `out` follow NMX_SCALARS_DEVICE. */
+int nmx_field_lincomb_powers(int field, const void* const* vecs, const size_t* lens, size_t k, const void* s, size_t n_out,
+                             uint32_t flags, void* out);
 
 /* out[i] = sum_{k >= i} f[k] * u^(k-i), i < n (coefficient form).  out[0] is `poly_eval(f, u)` (Horner,
  * src/provider/hyperkzg.rs:1011-1020); out[1..n) is the quotient h of `div_by_monomial(f, u)`
@@ -171,6 +184,10 @@ int nmx_poly_suffix_horner(int field, const void* f, size_t n, const void* u, ui
 int nmx_eq_evals_from_points(int field, const void* r, size_t ell, uint32_t flags, void* out);
 /* MultilinearPolynomial::evaluate / evaluate_with (src/spartan/polys/multilinear.rs:88-129): Z(r), len == 2^ell. */
 int nmx_mle_evaluate(int field, const void* z, size_t len, const void* r, size_t ell, uint32_t flags, uint8_t* out32);
+/* MultilinearPolynomial::multi_evaluate_with (src/spartan/polys/multilinear.rs:131-180): k polynomials of the same
+ * length 2^ell at one point; the eq tables are built once.  out = k x 32 bytes (host). */
+int nmx_mle_multi_evaluate(int field, const void* const* zs, size_t k, size_t len, const void* r, size_t ell,
+                           uint32_t flags, uint8_t* out);
 /* SparseMatrix (CSR, scipy naming: data / indices / indptr, src/r1cs/sparse.rs:232-260) resident in HBM, and
  * SparseMatrix::multiply_vec (sparse.rs:201-229): out[rows] = M * z.  indptr / indices are `usize` on the reference
  * side, hence uint64_t here.  R1CS matrices are fixed per circuit: register once, apply every step. */
@@ -178,6 +195,9 @@ int nmx_spmv_register(int field, const uint64_t* indptr, const uint64_t* indices
                       size_t cols, uint32_t flags, uint64_t* handle);
 int nmx_spmv_unregister(uint64_t handle);
 int nmx_spmv_apply(uint64_t handle, const void* z, size_t z_len, uint32_t flags, void* out);
+/* (M*z1, M*z2) in one pass over the matrix: PrecomputedSparseMatrix::multiply_vec_pair (src/r1cs/sparse.rs:215-229) */
+int nmx_spmv_apply_pair(uint64_t handle, const void* z1, const void* z2, size_t z_len, uint32_t flags, void* out1,
+                        void* out2);
 
 /* ---- measurement ------------------------------------------------------------------------------------
  * With profiling on, every MSM brackets its stages with hipEvents on the stream the kernels run on;

@@ -62,6 +62,10 @@ def lib():
     L.nmx_spmv_register.argtypes = [i, vp, vp, vp, sz, sz, u32, ctypes.POINTER(u64)]
     L.nmx_spmv_unregister.argtypes = [u64]
     L.nmx_spmv_apply.argtypes = [u64, vp, sz, u32, vp]
+    L.nmx_spmv_apply_pair.argtypes = [u64, vp, vp, sz, u32, vp, vp]
+    L.nmx_sumcheck_plain_sums.argtypes = [i, i, vp, vp, vp, sz, u32, vp]
+    L.nmx_field_lincomb_powers.argtypes = [i, vp, vp, sz, vp, sz, u32, vp]
+    L.nmx_mle_multi_evaluate.argtypes = [i, vp, sz, sz, vp, sz, u32, vp]
     L.nmx_set_profiling.argtypes = [i]
     L.nmx_profile_last.argtypes = [ctypes.POINTER(ctypes.c_float), i]
     L.nmx_set_window_bits.argtypes = [u32]

@@ -510,6 +510,34 @@ int nmx_sumcheck_eq_sums(int field, int mode, const void* A, const void* B, cons
   });
 }
 
+int nmx_sumcheck_plain_sums(int field, int kind, const void* A, const void* B, const void* C, size_t len, uint32_t flags,
+                            uint8_t* out96) {
+  return guarded([&] {
+    require(A && B && out96, NMX_E_ARG, "null argument");
+    require(kind >= 1 && kind <= 4 && (kind < 4 || C), NMX_E_ARG, "missing input polynomial");
+    require(len >= 2 && (len & 1) == 0 && len / 2 < (1ull << 31), NMX_E_ARG, "len must be even");
+    CtxLease L;
+    uint8_t three[96] = {0};
+    fv_plain_sums(*L.c, field, kind, A, B, C, len, flags, three);
+    memcpy(out96, three, 96);
+  });
+}
+
+int nmx_field_lincomb_powers(int field, const void* const* vecs, const size_t* lens, size_t k, const void* s, size_t n_out,
+                             uint32_t flags, void* out) {
+  return guarded([&] {
+    require(s && (out || n_out == 0) && (k == 0 || (vecs && lens)), NMX_E_ARG, "null argument");
+    require(k <= 4096 && n_out < (1ull << 31), NMX_E_TOO_LARGE, "too many / too long vectors");
+    for (size_t j = 0; j < k; j++) {
+      require(lens[j] <= n_out, NMX_E_ARG, "output shorter than an input polynomial");
+      require(vecs[j] || lens[j] == 0, NMX_E_ARG, "null vector");
+    }
+    if (n_out == 0) return;
+    CtxLease L;
+    fv_lincomb(*L.c, field, vecs, lens, k, s, n_out, flags, out);
+  });
+}
+
 struct DevBuf {  // RAII device allocation
   void* p = nullptr;
   explicit DevBuf(size_t bytes) { HIPCHK(hipMalloc(&p, bytes ? bytes : 1)); }
@@ -567,6 +595,35 @@ int nmx_mle_evaluate(int field, const void* z, size_t len, const void* r, size_t
     fv_eq_sums(*L.c, field, 1, dz, nullptr, nullptr, 2 * len, eqL.p, (size_t)1 << s_left, eqR.p, (size_t)1 << s_right,
                (uint32_t)s_right, flags | NMX_SCALARS_DEVICE, two);
     memcpy(out32, two, 32);
+  });
+}
+
+int nmx_mle_multi_evaluate(int field, const void* const* zs, size_t k, size_t len, const void* r, size_t ell,
+                           uint32_t flags, uint8_t* out) {
+  return guarded([&] {
+    require((zs || k == 0) && (r || ell == 0) && (out || k == 0), NMX_E_ARG, "null argument");
+    require(ell < 31 && len == ((size_t)1 << ell), NMX_E_ARG, "assert!(Zs.iter().all(|z| z.len() == n))");
+    if (k == 0) return;  // multilinear.rs:133-135
+    for (size_t j = 0; j < k; j++) require(zs[j], NMX_E_ARG, "null polynomial");
+    CtxLease L;
+    // the two sqrt-size eq tables are built once and shared by all k polynomials (multilinear.rs:141-147)
+    const size_t s_right = ell / 2, s_left = ell - s_right;
+    DevBuf eqL(((size_t)1 << s_left) * 32), eqR(((size_t)1 << s_right) * 32);
+    fv_eq_evals(*L.c, field, r, (uint32_t)s_left, flags, (uint32_t*)eqL.p);
+    fv_eq_evals(*L.c, field, (const uint8_t*)r + 32 * s_left, (uint32_t)s_right, flags, (uint32_t*)eqR.p);
+    const bool dev = flags & NMX_SCALARS_DEVICE;
+    DevBuf zbuf(dev ? 1 : len * 32);
+    for (size_t j = 0; j < k; j++) {
+      const void* dz = zs[j];
+      if (!dev) {
+        HIPCHK(hipMemcpyAsync(zbuf.p, zs[j], len * 32, hipMemcpyHostToDevice, L.c->stream));
+        dz = zbuf.p;
+      }
+      uint8_t two[64];
+      fv_eq_sums(*L.c, field, 1, dz, nullptr, nullptr, 2 * len, eqL.p, (size_t)1 << s_left, eqR.p,
+                 (size_t)1 << s_right, (uint32_t)s_right, flags | NMX_SCALARS_DEVICE, two);
+      memcpy(out + 32 * j, two, 32);
+    }
   });
 }
 
@@ -632,6 +689,24 @@ int nmx_spmv_apply(uint64_t handle, const void* z, size_t z_len, uint32_t flags,
     if (ss.rows == 0) return;
     CtxLease L;
     fv_spmv_apply(*L.c, ss.field, ss.indptr, ss.indices, ss.data, ss.rows, ss.cols, z, flags, out);
+  });
+}
+
+int nmx_spmv_apply_pair(uint64_t handle, const void* z1, const void* z2, size_t z_len, uint32_t flags, void* out1,
+                        void* out2) {
+  return guarded([&] {
+    require(z1 && z2 && out1 && out2, NMX_E_ARG, "null argument");
+    Global::SparseSet ss;
+    {
+      std::lock_guard<std::mutex> lk(G.mu);
+      auto it = G.sparse.find(handle);
+      if (it == G.sparse.end()) throw Fail{NMX_E_HANDLE, "unknown matrix handle"};
+      ss = it->second;
+    }
+    require(z_len == ss.cols, NMX_E_ARG, "invalid shape for v1 / v2");  // sparse.rs:217-218
+    if (ss.rows == 0) return;
+    CtxLease L;
+    fv_spmv_apply_pair(*L.c, ss.field, ss.indptr, ss.indices, ss.data, ss.rows, ss.cols, z1, z2, flags, out1, out2);
   });
 }
 

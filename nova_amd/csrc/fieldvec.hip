@@ -105,6 +105,58 @@ template <int FID> struct SpmvFn {
   }
 };
 
+// (M*z1, M*z2) in one pass over the matrix (sparse.rs:215-229, multiply_vec_pair: AZ/BZ/CZ of two instances at once)
+template <int FID> struct SpmvPairFn {
+  const uint32_t* indptr;
+  const uint32_t* indices;
+  const uint32_t* data;
+  const uint32_t *z1, *z2;
+  uint32_t *out1, *out2;
+  NMX_HD void operator()(uint32_t row) const {
+    using F = Fp<FID>;
+    F a1 = F::zero(), a2 = F::zero();
+    uint32_t pending = 0;
+    for (uint32_t k = indptr[row]; k < indptr[row + 1]; k++) {
+      const F m = ld<FID>(data, k);
+      const uint32_t col = indices[k];
+      a1 = a1 + m * ld<FID>(z1, col);
+      a2 = a2 + m * ld<FID>(z2, col);
+      if (++pending == 6) {
+        a1 = a1.norm().canon();
+        a2 = a2.norm().canon();
+        pending = 0;
+      }
+    }
+    st<FID>(out1, row, a1.norm());
+    st<FID>(out2, row, a2.norm());
+  }
+};
+
+// out[i] = sum_j w[j] * v_j[i], vectors shorter than the output read as zero-padded: PolyEvalWitness::batch and
+// batch_diff_size with w[j] = s^j (/root/reference/src/spartan/mod.rs:165-277), the random linear combination in
+// front of the batched PCS opening.  (k + 1) x 32 B per element against k modmuls: HBM-bound for every k.
+template <int FID> struct LinCombFn {
+  const uint64_t* vecs;  // k device addresses
+  const uint64_t* lens;  // k element counts
+  const uint32_t* w;     // k x 8, internal form (s^j * 2^261), canonical
+  uint32_t* out;
+  uint32_t k;
+  NMX_HD void operator()(uint32_t i) const {
+    using F = Fp<FID>;
+    F acc = F::zero();
+    uint32_t pending = 0;
+    for (uint32_t j = 0; j < k; j++) {
+      if (i >= lens[j]) continue;
+      acc = acc + ld<FID>(w, j) * ld<FID>((const uint32_t*)(uintptr_t)vecs[j], i);
+      if (++pending == 6) {
+        acc = acc.norm().canon();
+        pending = 0;
+      }
+    }
+    st<FID>(out, i, acc.norm());
+  }
+};
+
 // Suffix Horner  out[i] = sum_{k >= i} f[k] * u^(k-i):  out[0] is `poly_eval(f, u)` (hyperkzg.rs:1011-1020) and out[1..]
 // is the quotient of `div_by_monomial` (hyperkzg.rs:961-999: h[i-1] = f[i] + h[i]*u).  Same three phases as the
 // reference's chunked version -- chunk-local recurrences, carries between chunks with u^chunk, fix-up -- with
@@ -295,6 +347,75 @@ static void spmv_apply_t(Ctx& c, const uint32_t* indptr, const uint32_t* indices
   timed_launch(c, f, rows, &io);
 }
 
+template <int FID>
+static void spmv_apply_pair_t(Ctx& c, const uint32_t* indptr, const uint32_t* indices, const uint32_t* data, size_t rows,
+                              size_t cols, const void* z1, const void* z2, uint32_t flags, void* out1, void* out2) {
+  VecIO io(c, flags & NMX_SCALARS_DEVICE, rows + cols, 4);
+  const uint32_t* d1 = io.in(z1, cols);
+  const uint32_t* d2 = io.in(z2, cols);
+  uint32_t* o1 = io.out(out1, rows);
+  uint32_t* o2 = io.out(out2, rows);
+  SpmvPairFn<FID> f{indptr, indices, data, d1, d2, o1, o2};
+  timed_launch(c, f, rows, &io);
+}
+
+template <int FID>
+static void lincomb_t(Ctx& c, const void* const* vecs, const size_t* lens, size_t k, const void* s, size_t n_out,
+                      uint32_t flags, void* out) {
+  using F = Fp<FID>;
+  const bool mont = flags & NMX_SCALARS_MONT, dev = flags & NMX_SCALARS_DEVICE;
+  auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  size_t need = pad(k * 8) * 2 + pad(k * 32) + 256;
+  if (!dev) {
+    for (size_t j = 0; j < k; j++) need += pad(lens[j] * 32);
+    need += pad(n_out * 32);
+  }
+  arena_reserve(c, need);
+  size_t used = 0;
+  auto take = [&](size_t bytes) {
+    char* d = c.arena + used;
+    used += pad(bytes);
+    return d;
+  };
+  std::vector<uint64_t> addr(k), ln(k);
+  std::vector<uint32_t> w(8 * k);
+  // powers::<E>(&s, k) = [1, s, s^2, ...] (spartan/mod.rs:130-137), in internal form
+  const F si = challenge<FID>(s, mont);
+  F pw = F::one();
+  for (size_t j = 0; j < k; j++) {
+    pw.canon().to_words(w.data() + 8 * j);
+    pw = (pw * si).canon();
+    ln[j] = lens[j];
+    if (dev) {
+      addr[j] = (uint64_t)(uintptr_t)vecs[j];
+    } else {
+      char* d = take(lens[j] * 32);
+      if (lens[j]) HIPCHK(hipMemcpyAsync(d, vecs[j], lens[j] * 32, hipMemcpyHostToDevice, c.stream));
+      addr[j] = (uint64_t)(uintptr_t)d;
+    }
+  }
+  uint64_t* d_addr = (uint64_t*)take(k * 8);
+  uint64_t* d_len = (uint64_t*)take(k * 8);
+  uint32_t* d_w = (uint32_t*)take(k * 32);
+  HIPCHK(hipMemcpyAsync(d_addr, addr.data(), k * 8, hipMemcpyHostToDevice, c.stream));
+  HIPCHK(hipMemcpyAsync(d_len, ln.data(), k * 8, hipMemcpyHostToDevice, c.stream));
+  HIPCHK(hipMemcpyAsync(d_w, w.data(), k * 32, hipMemcpyHostToDevice, c.stream));
+  uint32_t* d_out = dev ? (uint32_t*)out : (uint32_t*)take(n_out * 32);
+  LinCombFn<FID> f{d_addr, d_len, d_w, d_out, (uint32_t)k};
+  const bool prof = G.profiling;
+  DeviceBackend be(c, false, prof);
+  be.mark("kernel");
+  be.launch(f, (uint32_t)n_out);
+  be.mark("end");
+  if (!dev) HIPCHK(hipMemcpyAsync(out, d_out, n_out * 32, hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipStreamSynchronize(c.stream));  // also: addr / ln / w are stack-owned
+  if (prof && be.nmarks == 2) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
+    prof_store(&ms, 1);
+  }
+}
+
 // out (device, n elements) <- suffix Horner of f (device) at the challenge whose internal residue is `ui`
 template <int FID> static void horner_dev(Ctx& c, const uint32_t* f, uint32_t n, Fp<FID> ui, uint32_t* out,
                                           std::vector<void*>& tmp) {
@@ -387,6 +508,27 @@ void fv_spmv_apply(Ctx& c, int field, const uint32_t* indptr, const uint32_t* in
     case 1: spmv_apply_t<1>(c, indptr, indices, data, rows, cols, z, flags, out); break;
     case 2: spmv_apply_t<2>(c, indptr, indices, data, rows, cols, z, flags, out); break;
     case 3: spmv_apply_t<3>(c, indptr, indices, data, rows, cols, z, flags, out); break;
+    default: throw Fail{NMX_E_ARG, "bad field id"};
+  }
+}
+
+void fv_spmv_apply_pair(Ctx& c, int field, const uint32_t* indptr, const uint32_t* indices, const uint32_t* data,
+                        size_t rows, size_t cols, const void* z1, const void* z2, uint32_t flags, void* out1, void* out2) {
+  switch (field) {
+    case 0: spmv_apply_pair_t<0>(c, indptr, indices, data, rows, cols, z1, z2, flags, out1, out2); break;
+    case 1: spmv_apply_pair_t<1>(c, indptr, indices, data, rows, cols, z1, z2, flags, out1, out2); break;
+    case 2: spmv_apply_pair_t<2>(c, indptr, indices, data, rows, cols, z1, z2, flags, out1, out2); break;
+    case 3: spmv_apply_pair_t<3>(c, indptr, indices, data, rows, cols, z1, z2, flags, out1, out2); break;
+    default: throw Fail{NMX_E_ARG, "bad field id"};
+  }
+}
+void fv_lincomb(Ctx& c, int field, const void* const* vecs, const size_t* lens, size_t k, const void* s, size_t n_out,
+                uint32_t flags, void* out) {
+  switch (field) {
+    case 0: lincomb_t<0>(c, vecs, lens, k, s, n_out, flags, out); break;
+    case 1: lincomb_t<1>(c, vecs, lens, k, s, n_out, flags, out); break;
+    case 2: lincomb_t<2>(c, vecs, lens, k, s, n_out, flags, out); break;
+    case 3: lincomb_t<3>(c, vecs, lens, k, s, n_out, flags, out); break;
     default: throw Fail{NMX_E_ARG, "bad field id"};
   }
 }

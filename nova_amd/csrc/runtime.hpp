@@ -218,6 +218,12 @@ void fv_eq_evals(Ctx&, int field, const void* r_host, uint32_t ell, uint32_t fla
 void fv_spmv_convert(Ctx&, int field, uint32_t* d_data, size_t nnz, uint32_t flags);
 void fv_spmv_apply(Ctx&, int field, const uint32_t* indptr, const uint32_t* indices, const uint32_t* data, size_t rows,
                    size_t cols, const void* z, uint32_t flags, void* out);
+void fv_spmv_apply_pair(Ctx&, int field, const uint32_t* indptr, const uint32_t* indices, const uint32_t* data,
+                        size_t rows, size_t cols, const void* z1, const void* z2, uint32_t flags, void* out1, void* out2);
+void fv_lincomb(Ctx&, int field, const void* const* vecs, const size_t* lens, size_t k, const void* s, size_t n_out,
+                uint32_t flags, void* out);
+void fv_plain_sums(Ctx&, int field, int kind, const void* A, const void* B, const void* C, size_t len, uint32_t flags,
+                   uint8_t* out);  // sumcheck.hip
 void fv_eq_sums(Ctx&, int field, int mode, const void* A, const void* B, const void* C, size_t len, const void* eqL,
                 size_t nL, const void* eqR, size_t nR, uint32_t shift, uint32_t flags, uint8_t* out);  // sumcheck.hip
 

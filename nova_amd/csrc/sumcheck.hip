@@ -188,6 +188,143 @@ static void eq_sums_t(Ctx& c, const void* A, const void* B, const void* C, size_
   }
 }
 
+// ---- sums without an eq factor (the classic sum-check rounds) ------------------------------------------------------
+//   kind 1  quad_prod   (sum a0*b0,        sum dA*dB)                          sumcheck.rs:163-186
+//   kind 2  linear      (sum a0-b0,        sum A(-1)-B(-1))                    sumcheck.rs:353-378
+//   kind 3  quadratic   (sum a0*b0,        sum A(-1)*B(-1))                    sumcheck.rs:380-405
+//   kind 4  cubic       (sum a0*b0*c0,     sum dA*dB*dC,   sum A(-1)B(-1)C(-1)) sumcheck.rs:407-443
+// with dX = x1 - x0 and X(-1) = 2*x0 - x1.  64 B (two vectors) or 96 B (three) per index against 2-7 modmuls: HBM-bound.
+template <int FID, int KIND>
+__global__ __launch_bounds__(256) void k_plain_sums(const uint32_t* A, const uint32_t* B, const uint32_t* C, uint32_t h,
+                                                    uint32_t* partial /* 32 words per block */) {
+  using F = Fp<FID>;
+  __shared__ uint32_t lds[9 * 256];
+  F s0 = F::zero(), s1 = F::zero(), s2 = F::zero();
+  uint32_t pending = 0;
+  for (uint32_t id = blockIdx.x * 256u + threadIdx.x; id < h; id += gridDim.x * 256u) {
+    const F a0 = ldw<FID>(A, id), a1 = ldw<FID>(A, (size_t)id + h);
+    const F b0 = ldw<FID>(B, id), b1 = ldw<FID>(B, (size_t)id + h);
+    if (KIND == 1) {
+      s0 = s0 + a0 * b0;
+      s1 = s1 + F::sub2(a1, a0).norm() * F::sub2(b1, b0).norm();          // operands < 3 p -> < 1.08 p
+    } else if (KIND == 2) {
+      s0 = s0 + F::sub2(a0, b0);                                          // < 3 p
+      s1 = s1 + F::sub4(F::sub2(a0.dbl(), a1).norm(), F::sub2(b0.dbl(), b1).norm());  // < 4p + 4p
+    } else if (KIND == 3) {
+      s0 = s0 + a0 * b0;
+      s1 = s1 + F::sub2(a0.dbl(), a1).norm() * F::sub2(b0.dbl(), b1).norm();  // operands < 4 p -> < 1.13 p
+    } else {
+      const F c0 = ldw<FID>(C, id), c1 = ldw<FID>(C, (size_t)id + h);
+      s0 = s0 + (a0 * b0) * c0;
+      s1 = s1 + (F::sub2(a1, a0).norm() * F::sub2(b1, b0).norm()) * F::sub2(c1, c0).norm();
+      s2 = s2 + (F::sub2(a0.dbl(), a1).norm() * F::sub2(b0.dbl(), b1).norm()) * F::sub2(c0.dbl(), c1).norm();
+    }
+    // kind 2 adds up to 8 p per term (limbs < 2^31): canonicalise every term; products add < 1.2 p (limbs < 2^29)
+    if (KIND == 2 || ++pending == 6) {
+      s0 = s0.norm().canon();
+      s1 = s1.norm().canon();
+      if (KIND == 4) s2 = s2.norm().canon();
+      pending = 0;
+    }
+  }
+  s0 = block_sum<FID>(s0.norm().canon(), lds);
+  __syncthreads();
+  s1 = block_sum<FID>(s1.norm().canon(), lds);
+  if (KIND == 4) {
+    __syncthreads();
+    s2 = block_sum<FID>(s2.norm().canon(), lds);
+  }
+  if (threadIdx.x == 0) {
+    s0.to_words(partial + 32 * blockIdx.x);
+    s1.to_words(partial + 32 * blockIdx.x + 8);
+    s2.to_words(partial + 32 * blockIdx.x + 16);
+  }
+}
+
+template <int FID> __global__ __launch_bounds__(256) void k_sum_partials3(const uint32_t* partial, uint32_t nparts, uint32_t* out) {
+  using F = Fp<FID>;
+  __shared__ uint32_t lds[9 * 256];
+  for (int j = 0; j < 3; j++) {
+    F s = F::zero();
+    for (uint32_t i = threadIdx.x; i < nparts; i += 256) s = (s + ldw<FID>(partial, 4 * (size_t)i + j)).norm().canon();
+    s = block_sum<FID>(s, lds);
+    if (threadIdx.x == 0) s.to_words(out + 8 * j);
+    __syncthreads();
+  }
+}
+
+template <int FID, int KIND>
+static void plain_sums_t(Ctx& c, const void* A, const void* B, const void* C, size_t len, uint32_t flags, uint8_t* out) {
+  using F = Fp<FID>;
+  const bool mont = flags & NMX_SCALARS_MONT, dev = flags & NMX_SCALARS_DEVICE;
+  const uint32_t h = (uint32_t)(len / 2);
+  const uint32_t want = (h + 256 * 8 - 1) / (256 * 8);
+  const uint32_t blocks = want < 1 ? 1 : (want > 2048 ? 2048 : want);
+  auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  size_t need = (size_t)blocks * 128 + 128 + 512;
+  if (!dev) need += pad(len * 32) * (KIND == 4 ? 3 : 2);
+  arena_reserve(c, need);
+  size_t used = 0;
+  auto stage = [&](const void* p, size_t elems) -> const uint32_t* {
+    if (dev) return (const uint32_t*)p;
+    char* d = c.arena + used;
+    used += pad(elems * 32);
+    HIPCHK(hipMemcpyAsync(d, p, elems * 32, hipMemcpyHostToDevice, c.stream));
+    return (const uint32_t*)d;
+  };
+  const uint32_t* dA = stage(A, len);
+  const uint32_t* dB = stage(B, len);
+  const uint32_t* dC = KIND == 4 ? stage(C, len) : nullptr;
+  uint32_t* partial = (uint32_t*)(c.arena + used);
+  used += pad((size_t)blocks * 128);
+  uint32_t* dout = (uint32_t*)(c.arena + used);
+  const bool prof = G.profiling;
+  DeviceBackend be(c, false, prof);
+  be.mark("k");
+  hipLaunchKernelGGL((k_plain_sums<FID, KIND>), dim3(blocks), dim3(256), 0, c.stream, dA, dB, dC, h, partial);
+  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL((k_sum_partials3<FID>), dim3(1), dim3(256), 0, c.stream, partial, blocks, dout);
+  HIPCHK(hipGetLastError());
+  be.mark("end");
+  uint32_t res[24];
+  HIPCHK(hipMemcpyAsync(res, dout, 96, hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipStreamSynchronize(c.stream));
+  if (prof && be.nmarks == 2) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
+    prof_store(&ms, 1);
+  }
+  // a product of k stored elements (k - 1 Montgomery products) is x * Fm^k / R'^(k-1); see eq_sums_t
+  const uint32_t k = KIND == 2 ? 1u : KIND == 4 ? 3u : 2u;
+  F corr = pow2_plain<FID>(261u * k - (mont ? 256u * (k - 1) : 0u));
+  for (int j = 0; j < (KIND == 4 ? 3 : 2); j++) {
+    F v = F::from_words(res + 8 * j) * corr;
+    uint32_t w[8];
+    v.canon().to_words(w);
+    memcpy(out + 32 * j, w, 32);
+  }
+}
+
+void fv_plain_sums(Ctx& c, int field, int kind, const void* A, const void* B, const void* C, size_t len, uint32_t flags,
+                   uint8_t* out) {
+#define PLS(FID)                                                                  \
+  switch (kind) {                                                                 \
+    case 1: plain_sums_t<FID, 1>(c, A, B, C, len, flags, out); return;            \
+    case 2: plain_sums_t<FID, 2>(c, A, B, C, len, flags, out); return;            \
+    case 3: plain_sums_t<FID, 3>(c, A, B, C, len, flags, out); return;            \
+    case 4: plain_sums_t<FID, 4>(c, A, B, C, len, flags, out); return;            \
+    default: throw Fail{NMX_E_ARG, "bad sum-check kind"};                         \
+  }
+  switch (field) {
+    case 0: PLS(0)
+    case 1: PLS(1)
+    case 2: PLS(2)
+    case 3: PLS(3)
+    default: throw Fail{NMX_E_ARG, "bad field id"};
+  }
+#undef PLS
+}
+
 void fv_eq_sums(Ctx& c, int field, int mode, const void* A, const void* B, const void* C, size_t len, const void* eqL,
                 size_t nL, const void* eqR, size_t nR, uint32_t shift, uint32_t flags, uint8_t* out) {
 #define EQS(FID)                                                                                        \

@@ -136,6 +136,41 @@ def sumcheck_eq_sums(field, mode, A, B, C, eq_right, eq_left=None, shift=0, mont
     return out[:32].tobytes(), out[32:].tobytes()
 
 
+def sumcheck_plain_sums(field, kind, A, B, C=None, mont=False):
+    """Round sums of the sum-checks without an eq factor (src/spartan/sumcheck.rs): kind 1 compute_eval_points_quad_prod
+    (:163-186), 2 ..._linear (:353-378), 3 ..._quadratic (:380-405), 4 ..._cubic (:407-443).  Returns a tuple of two
+    (kinds 1-3) or three (kind 4) 32-byte field elements."""
+    pa, n, dev, _ka = _vec(A)
+    pb, nb, _d, _kb = _vec(B)
+    assert nb == n
+    pc = None
+    if kind == 4:
+        pc, nc, _d, _kc = _vec(C)
+        assert nc == n
+    out = np.zeros(96, dtype=np.uint8)
+    _check(L.lib().nmx_sumcheck_plain_sums(field, kind, pa, pb, pc, n, _flags(dev, mont), out.ctypes.data))
+    t = (out[:32].tobytes(), out[32:64].tobytes(), out[64:].tobytes())
+    return t if kind == 4 else t[:2]
+
+
+def lincomb_powers(field, vecs, s, n_out=None, mont=False):
+    """PolyEvalWitness::batch / batch_diff_size (src/spartan/mod.rs:165-277): sum_j s^j * vecs[j], shorter vectors
+    zero-padded to the longest (or to n_out)."""
+    import ctypes
+    k = len(vecs)
+    parts = [_vec(v) for v in vecs]
+    dev = bool(parts) and parts[0][2]
+    assert all(pt[2] == dev for pt in parts)
+    lens = [pt[1] for pt in parts]
+    n = max(lens, default=0) if n_out is None else n_out
+    ptrs = (ctypes.c_void_p * max(k, 1))(*[pt[0] for pt in parts])
+    ln = (ctypes.c_size_t * max(k, 1))(*lens)
+    po, out = _out_like(dev, n, vecs[0] if k else None)
+    ss = _chal(s)
+    _check(L.lib().nmx_field_lincomb_powers(field, ptrs, ln, k, ss.ctypes.data, n, _flags(dev, mont), po))
+    return out
+
+
 def eq_evals_from_points(field, r, mont=False):
     """EqPolynomial::evals_from_points (src/spartan/polys/eq.rs:54-73): (2^ell, 32) table, r[0] most significant."""
     rr = _host_u8(r, 32)
@@ -152,6 +187,23 @@ def mle_evaluate(field, z, r, mont=False):
     out = np.zeros(32, dtype=np.uint8)
     _check(L.lib().nmx_mle_evaluate(field, pz, n, rr.ctypes.data, rr.size // 32, _flags(dev, mont), out.ctypes.data))
     return out.tobytes()
+
+
+def mle_multi_evaluate(field, zs, r, mont=False):
+    """MultilinearPolynomial::multi_evaluate_with (src/spartan/polys/multilinear.rs:131-180): list of 32-byte values."""
+    import ctypes
+    k = len(zs)
+    if k == 0:
+        return []
+    parts = [_vec(z) for z in zs]
+    dev = parts[0][2]
+    n = parts[0][1]
+    assert all(pt[1] == n and pt[2] == dev for pt in parts), "assert!(Zs.iter().all(|z| z.len() == n))"
+    rr = _host_u8(r, 32)
+    ptrs = (ctypes.c_void_p * k)(*[pt[0] for pt in parts])
+    out = np.zeros(32 * k, dtype=np.uint8)
+    _check(L.lib().nmx_mle_multi_evaluate(field, ptrs, k, n, rr.ctypes.data, rr.size // 32, _flags(dev, mont), out.ctypes.data))
+    return [out[32 * j: 32 * j + 32].tobytes() for j in range(k)]
 
 
 class SparseMatrix:
@@ -174,6 +226,16 @@ class SparseMatrix:
         po, out = _out_like(dev, self.rows, z)
         _check(L.lib().nmx_spmv_apply(self.handle, pz, n, _flags(dev, mont), po))
         return out
+
+    def multiply_vec_pair(self, z1, z2, mont=False):
+        """(M*z1, M*z2) in one pass (sparse.rs:215-229)."""
+        p1, n1, dev, _k1 = _vec(z1)
+        p2, n2, dev2, _k2 = _vec(z2)
+        assert n1 == self.cols and n2 == self.cols and dev == dev2, "invalid shape"
+        po1, out1 = _out_like(dev, self.rows, z1)
+        po2, out2 = _out_like(dev, self.rows, z1)
+        _check(L.lib().nmx_spmv_apply_pair(self.handle, p1, p2, n1, _flags(dev, mont), po1, po2))
+        return out1, out2
 
     def close(self):
         if self.handle:

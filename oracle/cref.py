@@ -48,6 +48,10 @@ def lib():
         L.ref_mle_evaluate.argtypes = [ctypes.c_int, vp, sz, vp, vp]
         L.ref_spmv.argtypes = [ctypes.c_int, vp, vp, vp, sz, vp, vp]
         L.ref_sumcheck_eq_sums.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, sz, vp, vp, ctypes.c_uint, vp]
+        L.ref_spmv_pair.argtypes = [ctypes.c_int, vp, vp, vp, sz, vp, vp, vp, vp]
+        L.ref_sumcheck_plain_sums.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, sz, vp]
+        L.ref_lincomb_powers.argtypes = [ctypes.c_int, vp, vp, sz, vp, sz, vp]
+        L.ref_mle_multi_evaluate.argtypes = [ctypes.c_int, vp, sz, sz, vp, vp]
         _lib = L
     return _lib
 
@@ -238,3 +242,48 @@ def suffix_horner(fid, f, n, u):
     out = np.zeros(32 * n, dtype=np.uint8)
     lib().ref_poly_suffix_horner(fid, pf, n, pu, out.ctypes.data)
     return out.tobytes()
+
+
+def spmv_pair(fid, indptr, indices, data, rows, z1, z2):
+    ip = np.ascontiguousarray(indptr, dtype=np.uint64)
+    ix = np.ascontiguousarray(indices, dtype=np.uint64)
+    pd, _d = _buf(data)
+    p1, _1 = _buf(z1)
+    p2, _2 = _buf(z2)
+    o1 = np.zeros(32 * rows, dtype=np.uint8)
+    o2 = np.zeros(32 * rows, dtype=np.uint8)
+    lib().ref_spmv_pair(fid, ip.ctypes.data, ix.ctypes.data, pd, rows, p1, p2, o1.ctypes.data, o2.ctypes.data)
+    return o1.tobytes(), o2.tobytes()
+
+
+def sumcheck_plain_sums(fid, kind, A, B, C, n):
+    ps = [_buf(x) if x is not None else (None, None) for x in (A, B, C)]
+    out = np.zeros(96, dtype=np.uint8)
+    rc = lib().ref_sumcheck_plain_sums(fid, kind, ps[0][0], ps[1][0], ps[2][0], n, out.ctypes.data)
+    assert rc == 0
+    return out[:32].tobytes(), out[32:64].tobytes(), out[64:].tobytes()
+
+
+def _ptr_table(vecs):
+    keep = [np.ascontiguousarray(np.frombuffer(bytes(v), dtype=np.uint8)) if len(v) else np.zeros(1, np.uint8) for v in vecs]
+    ptrs = (ctypes.c_void_p * max(len(vecs), 1))(*[a.ctypes.data for a in keep])
+    return ptrs, keep
+
+
+def lincomb_powers(fid, vecs, s, n_out):
+    k = len(vecs)
+    ptrs, _keep = _ptr_table(vecs)
+    lens = (ctypes.c_size_t * max(k, 1))(*[len(v) // 32 for v in vecs])
+    ps, _s = _buf(s)
+    out = np.zeros(32 * max(n_out, 1), dtype=np.uint8)
+    lib().ref_lincomb_powers(fid, ptrs, lens, k, ps, n_out, out.ctypes.data)
+    return out[: 32 * n_out].tobytes()
+
+
+def mle_multi_evaluate(fid, zs, ell, r):
+    k = len(zs)
+    ptrs, _keep = _ptr_table(zs)
+    pr, _r = _buf(r) if len(r) else (None, None)
+    out = np.zeros(32 * max(k, 1), dtype=np.uint8)
+    lib().ref_mle_multi_evaluate(fid, ptrs, k, ell, pr, out.ctypes.data)
+    return [out[32 * j: 32 * j + 32].tobytes() for j in range(k)]

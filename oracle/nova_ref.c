@@ -826,6 +826,102 @@ int ref_spmv(int field, const uint64_t* indptr, const uint64_t* indices, const u
   return 0;
 }
 
+/* PrecomputedSparseMatrix::multiply_vec_pair (src/r1cs/sparse.rs:215-229): (M*v1, M*v2), one pass over the rows */
+int ref_spmv_pair(int field, const uint64_t* indptr, const uint64_t* indices, const uint8_t* data, size_t rows,
+                  const uint8_t* z1, const uint8_t* z2, uint8_t* out1, uint8_t* out2) {
+  const field_t* F = field_by_id(field); if (!F) return -1;
+  for (size_t rw = 0; rw < rows; rw++) {
+    fe a1, a2; memset(&a1, 0, sizeof a1); memset(&a2, 0, sizeof a2);
+    for (uint64_t k = indptr[rw]; k < indptr[rw + 1]; k++) {
+      fe d, v, t; ld_mont(F, &d, data + 32 * k);
+      ld_mont(F, &v, z1 + 32 * indices[k]); fe_mul(F, &t, &d, &v); fe_add(F, &a1, &a1, &t);
+      ld_mont(F, &v, z2 + 32 * indices[k]); fe_mul(F, &t, &d, &v); fe_add(F, &a2, &a2, &t);
+    }
+    st_canon(F, out1 + 32 * rw, &a1); st_canon(F, out2 + 32 * rw, &a2);
+  }
+  return 0;
+}
+
+/* The sum-check round sums without an eq factor (src/spartan/sumcheck.rs): kind 1 compute_eval_points_quad_prod
+ * (:163-186), 2 compute_eval_points_linear (:353-378), 3 compute_eval_points_quadratic (:380-405),
+ * 4 compute_eval_points_cubic (:407-443).  out96 = three canonical elements (third zero for kinds 1-3). */
+int ref_sumcheck_plain_sums(int field, int kind, const uint8_t* A, const uint8_t* B, const uint8_t* C, size_t len, uint8_t* out96) {
+  const field_t* F = field_by_id(field); if (!F) return -1;
+  size_t h = len / 2;
+  fe s0, s1, s2; memset(&s0, 0, sizeof s0); memset(&s1, 0, sizeof s1); memset(&s2, 0, sizeof s2);
+  for (size_t i = 0; i < h; i++) {
+    fe a0, a1, b0, b1, c0, c1, t, u, dA, dB, dC, am, bm, cm;
+    ld_mont(F, &a0, A + 32 * i); ld_mont(F, &a1, A + 32 * (i + h));
+    ld_mont(F, &b0, B + 32 * i); ld_mont(F, &b1, B + 32 * (i + h));
+    fe_sub(F, &dA, &a1, &a0); fe_sub(F, &dB, &b1, &b0);
+    fe_add(F, &am, &a0, &a0); fe_sub(F, &am, &am, &a1);      /* A(-1) = a0 + a0 - a1 */
+    fe_add(F, &bm, &b0, &b0); fe_sub(F, &bm, &bm, &b1);
+    switch (kind) {
+      case 1: fe_mul(F, &t, &a0, &b0); fe_add(F, &s0, &s0, &t); fe_mul(F, &t, &dA, &dB); fe_add(F, &s1, &s1, &t); break;
+      case 2: fe_sub(F, &t, &a0, &b0); fe_add(F, &s0, &s0, &t); fe_sub(F, &t, &am, &bm); fe_add(F, &s1, &s1, &t); break;
+      case 3: fe_mul(F, &t, &a0, &b0); fe_add(F, &s0, &s0, &t); fe_mul(F, &t, &am, &bm); fe_add(F, &s1, &s1, &t); break;
+      case 4:
+        ld_mont(F, &c0, C + 32 * i); ld_mont(F, &c1, C + 32 * (i + h));
+        fe_sub(F, &dC, &c1, &c0);
+        fe_sub(F, &am, &a0, &dA); fe_sub(F, &bm, &b0, &dB); fe_sub(F, &cm, &c0, &dC);   /* (poly[i] - d), :432 */
+        fe_mul(F, &t, &a0, &b0); fe_mul(F, &t, &t, &c0); fe_add(F, &s0, &s0, &t);
+        fe_mul(F, &u, &dA, &dB); fe_mul(F, &u, &u, &dC); fe_add(F, &s1, &s1, &u);
+        fe_mul(F, &t, &am, &bm); fe_mul(F, &t, &t, &cm); fe_add(F, &s2, &s2, &t);
+        break;
+      default: return -1;
+    }
+  }
+  st_canon(F, out96, &s0); st_canon(F, out96 + 32, &s1); st_canon(F, out96 + 64, &s2);
+  return 0;
+}
+
+/* PolyEvalWitness::batch / batch_diff_size (src/spartan/mod.rs:165-277): out[i] = sum_j s^j * vecs[j][i], shorter
+ * vectors zero-padded; powers::<E>(s, k) = [1, s, s^2, ...] (:130-137) */
+int ref_lincomb_powers(int field, const uint8_t* const* vecs, const size_t* lens, size_t k, const uint8_t* s, size_t n_out, uint8_t* out) {
+  const field_t* F = field_by_id(field); if (!F) return -1;
+  fe sm; ld_mont(F, &sm, s);
+  fe* acc = (fe*)calloc(n_out ? n_out : 1, sizeof(fe));
+  fe pw = F->r1;
+  for (size_t j = 0; j < k; j++) {
+    for (size_t i = 0; i < lens[j]; i++) {
+      fe v, t; ld_mont(F, &v, vecs[j] + 32 * i);
+      fe_mul(F, &t, &pw, &v); fe_add(F, &acc[i], &acc[i], &t);
+    }
+    fe_mul(F, &pw, &pw, &sm);
+  }
+  for (size_t i = 0; i < n_out; i++) st_canon(F, out + 32 * i, &acc[i]);
+  free(acc);
+  return 0;
+}
+
+/* MultilinearPolynomial::multi_evaluate_with (src/spartan/polys/multilinear.rs:131-180): row sums of all k
+ * polynomials against eq_right, then a dot with eq_left */
+int ref_mle_multi_evaluate(int field, const uint8_t* const* zs, size_t k, size_t ell, const uint8_t* r, uint8_t* out) {
+  const field_t* F = field_by_id(field); if (!F) return -1;
+  if (k == 0) return 0;
+  size_t s_right = ell / 2, s_left = ell - s_right, n_left = (size_t)1 << s_left, n_right = (size_t)1 << s_right;
+  uint8_t* el = (uint8_t*)malloc(32 * n_left); uint8_t* er = (uint8_t*)malloc(32 * n_right);
+  ref_eq_evals(field, r, s_left, el); ref_eq_evals(field, r + 32 * s_left, s_right, er);
+  fe* red = (fe*)calloc(n_left * k, sizeof(fe));
+  for (size_t i = 0; i < n_left; i++)
+    for (size_t j = 0; j < n_right; j++) {
+      fe e; ld_mont(F, &e, er + 32 * j);
+      for (size_t p = 0; p < k; p++) {
+        fe zz, t; ld_mont(F, &zz, zs[p] + 32 * (i * n_right + j));
+        fe_mul(F, &t, &zz, &e); fe_add(F, &red[i * k + p], &red[i * k + p], &t);
+      }
+    }
+  for (size_t p = 0; p < k; p++) {
+    fe acc; memset(&acc, 0, sizeof acc);
+    for (size_t i = 0; i < n_left; i++) {
+      fe e, t; ld_mont(F, &e, el + 32 * i); fe_mul(F, &t, &e, &red[i * k + p]); fe_add(F, &acc, &acc, &t);
+    }
+    st_canon(F, out + 32 * p, &acc);
+  }
+  free(el); free(er); free(red);
+  return 0;
+}
+
 /* div_by_monomial (src/provider/hyperkzg.rs:946-999: h[i-1] = f[i] + h[i]*u, chunked in the reference, serial here)
  * and Horner poly_eval (hyperkzg.rs:1011-1020) in one pass: out[i] = sum_{k>=i} f[k] u^(k-i). */
 int ref_poly_suffix_horner(int field, const uint8_t* f, size_t n, const uint8_t* u, uint8_t* out) {

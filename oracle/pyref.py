@@ -278,3 +278,40 @@ def div_by_monomial(p, f, u):
         nxt = (f[i] + nxt * u) % p
         h[i - 1] = nxt
     return h
+
+
+def sumcheck_plain_sums(p, kind, A, B, C=None):
+    """Round sums without an eq factor (src/spartan/sumcheck.rs:163-186, 353-443); kinds as in nova_mi355x.h."""
+    h = len(A) // 2
+    s0 = s1 = s2 = 0
+    for i in range(h):
+        a0, a1, b0, b1 = A[i], A[i + h], B[i], B[i + h]
+        dA, dB = a1 - a0, b1 - b0
+        am, bm = 2 * a0 - a1, 2 * b0 - b1
+        if kind == 1:
+            s0 += a0 * b0
+            s1 += dA * dB
+        elif kind == 2:
+            s0 += a0 - b0
+            s1 += am - bm
+        elif kind == 3:
+            s0 += a0 * b0
+            s1 += am * bm
+        else:
+            c0, c1 = C[i], C[i + h]
+            dC = c1 - c0
+            s0 += a0 * b0 * c0
+            s1 += dA * dB * dC
+            s2 += (a0 - dA) * (b0 - dB) * (c0 - dC)
+    return s0 % p, s1 % p, s2 % p
+
+
+def lincomb_powers(p, vecs, s, n_out):
+    """PolyEvalWitness::batch / batch_diff_size: sum_j s^j * P_j, zero-padded (src/spartan/mod.rs:165-277)."""
+    out = [0] * n_out
+    pw = 1
+    for v in vecs:
+        for i, x in enumerate(v):
+            out[i] = (out[i] + pw * x) % p
+        pw = pw * s % p
+    return out

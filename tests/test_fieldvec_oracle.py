@@ -91,3 +91,53 @@ def test_oracle_horner_and_div_by_monomial(fid):
         assert back == fi
         got = cref.suffix_horner(fid, f, n, u)
         assert got == b"".join(R.fe_to_le32(x) for x in [ev] + h)
+
+
+@pytest.mark.parametrize("fid", range(4))
+def test_oracle_plain_sums_lincomb_multi_eval_pair(fid):
+    """sumcheck.rs:163-186,353-443; spartan/mod.rs:165-277; multilinear.rs:131-180; sparse.rs:215-229:
+    C restatements == big-int definitions."""
+    p = C.FIELDS[fid]
+    enc1 = R.fe_to_le32
+    n = 64
+    A, B, Cc = (C.edge_vectors(fid, n, s) for s in (1, 2, 3))
+    for kind in (1, 2, 3, 4):
+        got = cref.sumcheck_plain_sums(fid, kind, A, B, Cc if kind == 4 else None, n)
+        exp = R.sumcheck_plain_sums(p, kind, C.ints(A), C.ints(B), C.ints(Cc))
+        assert got == tuple(enc1(x) for x in exp), kind
+    # quad_prod consistency with the round polynomial: s0 + (s0 + s_quad + linear) = claim is the caller's algebra;
+    # here: kind 3's A(-1)B(-1) relates to kind 1 by  S(-1) = S(0) - (S(1) - S(0) - q) + q  with q the dA*dB sum
+    s0, q, _ = R.sumcheck_plain_sums(p, 1, C.ints(A), C.ints(B))
+    _, sm1, _ = R.sumcheck_plain_sums(p, 3, C.ints(A), C.ints(B))
+    s1 = sum(a * b for a, b in zip(C.ints(A)[n // 2:], C.ints(B)[n // 2:])) % p
+    assert sm1 == (2 * s0 - s1 + 2 * q) % p
+    # random linear combination, ragged lengths
+    vecs = [C.edge_vectors(fid, m, 10 + m) for m in (64, 17, 64, 1)] + [C.rand_vec(fid, 1, 3)[:0]]
+    s = C.rand_vec(fid, 1, 77)
+    exp = b"".join(enc1(x) for x in R.lincomb_powers(p, [C.ints(v) for v in vecs], C.ints(s)[0], 64))
+    assert cref.lincomb_powers(fid, [v.tobytes() for v in vecs], s, 64) == exp
+    one = C.vec([1])
+    assert cref.lincomb_powers(fid, [vecs[0].tobytes(), vecs[2].tobytes()], one, 64) == \
+        cref.field_axpy(fid, vecs[0], vecs[2], one, 64)
+    # multi_evaluate_with == evaluate_with per polynomial (multilinear.rs:414-439)
+    for ell in (0, 1, 5, 6):
+        r = C.rand_vec(fid, max(ell, 1), 3)[:ell]
+        zs = [C.edge_vectors(fid, 1 << ell, 20 + j) if ell > 2 else C.rand_vec(fid, 1 << ell, 20 + j) for j in range(3)]
+        assert cref.mle_multi_evaluate(fid, [z.tobytes() for z in zs], ell, r) == [cref.mle_evaluate(fid, z, ell, r) for z in zs]
+    assert cref.mle_multi_evaluate(fid, [], 3, C.rand_vec(fid, 3, 1)) == []
+    # multiply_vec_pair == two multiply_vec (sparse.rs:531-544)
+    ip, ix, d = C.random_csr(fid, 50, 30, 9)
+    z1, z2 = C.rand_vec(fid, 30, 10), C.edge_vectors(fid, 30, 11)
+    assert cref.spmv_pair(fid, ip, ix, d, 50, z1, z2) == (cref.spmv(fid, ip, ix, d, 50, z1), cref.spmv(fid, ip, ix, d, 50, z2))
+
+
+def test_oracle_multi_evaluate_known_values():
+    """The reference's stored known-answer case (multilinear.rs:456-485): p(x1,x2,x3) = (x1 + x2) * x3, evaluations
+    indexed x1-MSB = [0,0,0,1,0,1,0,2], and the constant polynomial 5, at (1,1,1) -> [2, 5]; plus (2,3,4) -> 20."""
+    for fid in range(4):
+        z1 = C.vec([0, 0, 0, 1, 0, 1, 0, 2])
+        z2 = C.vec([5] * 8)
+        got = cref.mle_multi_evaluate(fid, [z1.tobytes(), z2.tobytes()], 3, C.vec([1, 1, 1]))
+        assert [int.from_bytes(g, "little") for g in got] == [2, 5]
+        got = cref.mle_multi_evaluate(fid, [z1.tobytes(), z2.tobytes()], 3, C.vec([2, 3, 4]))
+        assert [int.from_bytes(g, "little") for g in got] == [20, 5]

@@ -166,3 +166,85 @@ def test_horner_and_div_by_monomial(nmx, fid, n):
     for special in (0, 1):
         us = util.int_to_le32(special)
         assert fv.suffix_horner(fid, f, us).tobytes() == cref.suffix_horner(fid, f, n, us)
+
+
+@pytest.mark.parametrize("fid", range(4))
+@pytest.mark.parametrize("logn", [1, 6, 13, 18])
+def test_sumcheck_plain_sums(nmx, fid, logn):
+    """compute_eval_points_{quad_prod, linear, quadratic, cubic} (sumcheck.rs:163-186, 353-443): host / device
+    operands, canonical / Montgomery layouts."""
+    import torch
+    from nova_amd import fieldvec as fv
+    p = C.FIELDS[fid]
+    n = 1 << logn
+    A, B, Cc = (C.edge_vectors(fid, n, s) for s in (1, 2, 3))
+    for kind in (1, 2, 3, 4):
+        exp = cref.sumcheck_plain_sums(fid, kind, A, B, Cc if kind == 4 else None, n)
+        exp = exp if kind == 4 else exp[:2]
+        assert fv.sumcheck_plain_sums(fid, kind, A, B, Cc if kind == 4 else None) == exp, kind
+        if logn == 13:
+            d = [torch.from_numpy(x.copy()).cuda() for x in (A, B, Cc)]
+            assert fv.sumcheck_plain_sums(fid, kind, d[0], d[1], d[2] if kind == 4 else None) == exp, kind
+            Rm = 1 << 256
+            to_m = lambda v: C.vec([x * Rm % p for x in C.ints(v)])
+            got = fv.sumcheck_plain_sums(fid, kind, to_m(A), to_m(B), to_m(Cc) if kind == 4 else None, mont=True)
+            assert tuple(int.from_bytes(g, "little") * pow(Rm, -1, p) % p for g in got) == \
+                tuple(int.from_bytes(e, "little") for e in exp), kind
+    # worst-case operands for the lazy bounds: all p-1 against all 0 / all p-1
+    hi, lo = C.vec([p - 1] * n), C.vec([0] * n)
+    mix = np.concatenate([hi[: n // 2], lo[: n // 2]]) if n > 1 else hi
+    for kind in (1, 2, 3, 4):
+        for X, Y, Z in ((hi, hi, hi), (mix, lo, mix), (lo, mix, hi), (mix, mix, mix)):
+            exp = cref.sumcheck_plain_sums(fid, kind, X, Y, Z if kind == 4 else None, n)
+            assert fv.sumcheck_plain_sums(fid, kind, X, Y, Z if kind == 4 else None) == (exp if kind == 4 else exp[:2])
+
+
+@pytest.mark.parametrize("fid", range(4))
+def test_lincomb_multi_evaluate_spmv_pair(nmx, fid):
+    """PolyEvalWitness::batch / batch_diff_size (spartan/mod.rs:165-277), multi_evaluate_with (multilinear.rs:131-180),
+    multiply_vec_pair (sparse.rs:215-229)."""
+    import torch
+    from nova_amd import fieldvec as fv
+    p = C.FIELDS[fid]
+    s = C.rand_vec(fid, 1, 77)
+    for lens in ((64, 17, 64, 1, 0), (1 << 16, 1 << 15, 1 << 16, 1000, 1 << 16, 3, 1 << 14, 1 << 16), (5,)):
+        vecs = [C.edge_vectors(fid, m, 10 + j) if m > 8 else C.rand_vec(fid, max(m, 1), 10 + j)[:m] for j, m in enumerate(lens)]
+        exp = cref.lincomb_powers(fid, [v.tobytes() for v in vecs], s, max(lens))
+        assert fv.lincomb_powers(fid, vecs, s).tobytes() == exp, lens
+        if 0 not in lens:
+            d = [torch.from_numpy(v.copy()).cuda() for v in vecs]
+            out = fv.lincomb_powers(fid, d, s)
+            assert out.is_cuda and out.cpu().numpy().tobytes() == exp
+    # s = 1 and s = 0 (the reference special-cases coefficient ONE)
+    vecs = [C.edge_vectors(fid, 300, 1), C.edge_vectors(fid, 300, 2)]
+    for sv in (0, 1, p - 1):
+        assert fv.lincomb_powers(fid, vecs, C.vec([sv])).tobytes() == cref.lincomb_powers(fid, [v.tobytes() for v in vecs], C.vec([sv]), 300)
+    Rm = 1 << 256
+    to_m = lambda v: C.vec([x * Rm % p for x in C.ints(v)])
+    got = fv.lincomb_powers(fid, [to_m(v) for v in vecs], to_m(s), mont=True)
+    assert C.vec([x * pow(Rm, -1, p) % p for x in C.ints(got)]).tobytes() == cref.lincomb_powers(fid, [v.tobytes() for v in vecs], s, 300)
+
+    # the reference's stored known-answer case (multilinear.rs:456-485)
+    z1, z2 = C.vec([0, 0, 0, 1, 0, 1, 0, 2]), C.vec([5] * 8)
+    assert [int.from_bytes(g, "little") for g in fv.mle_multi_evaluate(fid, [z1, z2], C.vec([1, 1, 1]))] == [2, 5]
+    assert fv.mle_multi_evaluate(fid, [], C.vec([1, 1, 1])) == []
+    for ell in (0, 1, 6, 13):
+        r = C.rand_vec(fid, max(ell, 1), 3)[:ell]
+        zs = [C.edge_vectors(fid, 1 << ell, 20 + j) if ell > 2 else C.rand_vec(fid, 1 << ell, 20 + j) for j in range(3)]
+        exp = cref.mle_multi_evaluate(fid, [z.tobytes() for z in zs], ell, r)
+        assert fv.mle_multi_evaluate(fid, zs, r) == exp
+        assert exp == [fv.mle_evaluate(fid, z, r) for z in zs]  # multilinear.rs:414-439
+        if ell == 13:
+            assert fv.mle_multi_evaluate(fid, [torch.from_numpy(z.copy()).cuda() for z in zs], r) == exp
+
+    for rows, cols in ((50, 30), (20000, 15000)):
+        ip, ix, d = C.random_csr(fid, rows, cols, 9)
+        z1, z2 = C.rand_vec(fid, cols, 10), C.edge_vectors(fid, cols, 11)
+        m = fv.SparseMatrix(fid, ip, ix, d, cols)
+        e1, e2 = cref.spmv_pair(fid, ip, ix, d, rows, z1, z2)
+        o1, o2 = m.multiply_vec_pair(z1, z2)
+        assert (o1.tobytes(), o2.tobytes()) == (e1, e2)
+        o1, o2 = m.multiply_vec_pair(torch.from_numpy(z1.copy()).cuda(), torch.from_numpy(z2.copy()).cuda())
+        assert (o1.cpu().numpy().tobytes(), o2.cpu().numpy().tobytes()) == (e1, e2)
+        assert m.multiply_vec(z1).tobytes() == e1
+        m.close()
