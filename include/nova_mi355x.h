@@ -37,6 +37,9 @@ enum {
   NMX_SCALARS_DEVICE = 1u << 2, /* `scalars` is a device (HBM) pointer on the library's device           */
   NMX_BASES_DEVICE = 1u << 3,   /* `bases` is a device pointer (nmx_bases_register only)                 */
   NMX_BASES_PRECOMPUTE = 1u << 5, /* nmx_bases_register / nmx_bases_generate: also build the window tables          */
+  NMX_BASES_VALIDATE = 1u << 6,   /* nmx_bases_register*: reject coordinates >= p and points off the curve with
+                                     NMX_E_POINT (identity (0,0) passes) -- what read_points enforces on loaded
+                                     keys, /root/reference/src/provider/ptau.rs:372-391                            */
                                 /* 2^(c*w) * P_i in HBM (W x the key size; c = 16, W = 16 for keys >= 2^20).    */
                                 /* MSMs over >= 4096 points of such a key run all windows into one bucket set. */
   NMX_OUT_PARTIAL = 1u << 4     /* write a 128-byte partial sum instead of an affine point: the per-GPU   */
@@ -55,7 +58,11 @@ enum {
   NMX_E_SCALAR_RANGE = -4, /* a canonical scalar >= modulus (from_repr would reject it)                   */
   NMX_E_SMALL_RANGE = -5,  /* a small scalar >= 2^max_num_bits (msm.rs:543-552 would index out of bounds)  */
   NMX_E_HANDLE = -6,       /* unknown / stale base handle, or offset + n beyond the registered key       */
-  NMX_E_TOO_LARGE = -7     /* n * windows >= 2^32                                                         */
+  NMX_E_TOO_LARGE = -7,    /* n * windows >= 2^32                                                         */
+  NMX_E_IO = -8,           /* key file cannot be opened / read (PtauFileError::IoError)                    */
+  NMX_E_FORMAT = -9,       /* key file header rejected (InvalidHead, UnsupportedVersion, InvalidNumSections,
+                              InvalidPrime, InsufficientPowerForG1/G2; ptau.rs:104-151)                    */
+  NMX_E_POINT = -10        /* a loaded point is not canonical or not on the curve (PointNotOnCurve)        */
 };
 
 /* ---- lifetime ------------------------------------------------------------------------------------- */
@@ -73,6 +80,20 @@ const char* nmx_version(void);
  * src/provider/pedersen.rs:267, src/provider/hyperkzg.rs:588).  Register the whole key once; every later
  * call addresses bases[offset .. offset + n) of it in HBM.  `handle` 0 is never valid. */
 int nmx_bases_register(int curve, const void* bases_xy64, size_t n, uint32_t flags, uint64_t* handle);
+/* On-disk keys.  Points in both formats are halo2curves `write_raw` records: x || y as raw
+ * R = 2^256 Montgomery limbs, 64 bytes -- the layout NMX_BASES_MONT takes, so the file is streamed to HBM through
+ * pinned staging buffers and converted / validated there; NMX_BASES_VALIDATE is always applied (read_points does).
+ *  - nmx_bases_register_ptau: HyperKZG `load_setup` (src/provider/hyperkzg.rs:658-674) -> `read_ptau`
+ *    (src/provider/ptau.rs:270-436): "ptau" magic, version 1, 11 or 3 sections, header section (n8, prime == base
+ *    modulus of `curve`, power with num_g1 <= 2^(power+1) - 1 and num_g2 <= 2^power), then the first num_g1 points
+ *    of section 2 become the key.  Section 3 (G2) is left to the host: pairings are outside this library.
+ *  - nmx_bases_register_keyfile: Pedersen `load_setup` (src/provider/pedersen.rs:318-340): 12-byte head
+ *    "PEDERSEN_KEY", then h, then ck[0 .. n) (the caller passes n already rounded with next_power_of_two as the
+ *    reference does); h comes back as canonical x || y in h_xy64.
+ * flags: NMX_BASES_PRECOMPUTE. */
+int nmx_bases_register_ptau(int curve, const char* path, size_t num_g1, size_t num_g2, uint32_t flags, uint64_t* handle);
+int nmx_bases_register_keyfile(int curve, const char* path, size_t n, uint32_t flags, uint64_t* handle,
+                               uint8_t* h_xy64);
 int nmx_bases_unregister(uint64_t handle);
 /* copies registered bases [offset, offset+n) back to the host as canonical x||y (test / key export helper) */
 int nmx_bases_read(uint64_t handle, size_t offset, size_t n, void* out_xy64);

@@ -6,8 +6,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libnova_mi355x.so")
 
 # flags / error codes (include/nova_mi355x.h)
-SCALARS_MONT, BASES_MONT, SCALARS_DEVICE, BASES_DEVICE, OUT_PARTIAL, BASES_PRECOMPUTE = 1, 2, 4, 8, 16, 32
+SCALARS_MONT, BASES_MONT, SCALARS_DEVICE, BASES_DEVICE, OUT_PARTIAL, BASES_PRECOMPUTE, BASES_VALIDATE = 1, 2, 4, 8, 16, 32, 64
 E_ARG, E_NO_DEVICE, E_HIP, E_SCALAR_RANGE, E_SMALL_RANGE, E_HANDLE, E_TOO_LARGE = -1, -2, -3, -4, -5, -6, -7
+E_IO, E_FORMAT, E_POINT = -8, -9, -10
 BITS_AUTO = 0xFFFFFFFF
 
 _lib = None
@@ -40,6 +41,8 @@ def lib():
     L.nmx_bases_unregister.argtypes = [u64]
     L.nmx_bases_read.argtypes = [u64, sz, sz, vp]
     L.nmx_bases_generate.argtypes = [i, u64, sz, u32, ctypes.POINTER(u64)]
+    L.nmx_bases_register_ptau.argtypes = [i, ctypes.c_char_p, sz, sz, u32, ctypes.POINTER(u64)]
+    L.nmx_bases_register_keyfile.argtypes = [i, ctypes.c_char_p, sz, u32, ctypes.POINTER(u64), vp]
     L.nmx_msm.argtypes = [i, vp, vp, sz, u32, vp, vp]
     L.nmx_msm_handle.argtypes = [u64, sz, vp, sz, u32, vp, vp]
     L.nmx_msm_u64.argtypes = [i, vp, vp, sz, u32, u32, vp, vp]

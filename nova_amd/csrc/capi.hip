@@ -159,6 +159,8 @@ static MsmCall field_call(const void* scalars, uint32_t flags) {
 
 }  // namespace nmx
 
+#include "keyfile.hpp"
+
 using namespace nmx;
 
 extern "C" {
@@ -215,7 +217,54 @@ int nmx_bases_register(int curve, const void* bases, size_t n, uint32_t flags, u
     const CurveOps& o = ops(curve);
     CtxLease L;
     BaseSet bs{curve, n, nullptr, 0, 0};
-    bs.d = o.upload(*L.c, bases, n, flags, &bs.pre_c, &bs.pre_W);
+    bs.d = o.upload(*L.c, bases, n, flags, &bs.pre_c, &bs.pre_W, nullptr);
+    *handle = publish(bs);
+  });
+}
+
+int nmx_bases_register_ptau(int curve, const char* path, size_t num_g1, size_t num_g2, uint32_t flags, uint64_t* handle) {
+  return guarded([&] {
+    require(path && handle, NMX_E_ARG, "null argument");
+    require(num_g1 < (1ull << 31), NMX_E_TOO_LARGE, "key too large");
+    const CurveOps& o = ops(curve);
+    FileCloser fc{fopen(path, "rb")};
+    if (!fc.f) throw Fail{NMX_E_IO, std::string("IoError: cannot open ") + path};
+    // read_ptau (ptau.rs:399-436): meta data, header checks, then the first num_g1 points of section 2
+    const PtauMeta meta = ptau_read_meta(fc.f);
+    seek_to(fc.f, meta.pos_header);
+    ptau_read_header(fc.f, o.base_modulus_words, num_g1, num_g2);
+    seek_to(fc.f, meta.pos_tau_g1);
+    CtxLease L;
+    BaseSet bs{curve, num_g1, nullptr, 0, 0};
+    const BaseFill fill = file_fill(fc.f, num_g1);
+    const uint32_t fl = (flags & NMX_BASES_PRECOMPUTE) | NMX_BASES_MONT | NMX_BASES_VALIDATE;
+    bs.d = o.upload(*L.c, nullptr, num_g1, fl, &bs.pre_c, &bs.pre_W, &fill);
+    *handle = publish(bs);
+  });
+}
+
+int nmx_bases_register_keyfile(int curve, const char* path, size_t n, uint32_t flags, uint64_t* handle,
+                               uint8_t* h_xy64) {
+  return guarded([&] {
+    require(path && handle && h_xy64, NMX_E_ARG, "null argument");
+    require(n < (1ull << 31), NMX_E_TOO_LARGE, "key too large");
+    const CurveOps& o = ops(curve);
+    FileCloser fc{fopen(path, "rb")};
+    if (!fc.f) throw Fail{NMX_E_IO, std::string("IoError: cannot open ") + path};
+    char head[12];
+    read_exact(fc.f, head, 12, "head");
+    require(memcmp(head, "PEDERSEN_KEY", 12) == 0, NMX_E_FORMAT, "InvalidHead");  // pedersen.rs:324-330
+    // points[0] = h, points[1..] = ck (pedersen.rs:332-339)
+    uint8_t h_raw[64], h_canon[64];
+    read_exact(fc.f, h_raw, 64, "h");
+    require(o.check_point_host(h_raw, NMX_BASES_MONT, h_canon), NMX_E_POINT,
+            "PointNotOnCurve: h is not canonical or not on the curve");
+    CtxLease L;
+    BaseSet bs{curve, n, nullptr, 0, 0};
+    const BaseFill fill = file_fill(fc.f, n);
+    const uint32_t fl = (flags & NMX_BASES_PRECOMPUTE) | NMX_BASES_MONT | NMX_BASES_VALIDATE;
+    bs.d = o.upload(*L.c, nullptr, n, fl, &bs.pre_c, &bs.pre_W, &fill);
+    memcpy(h_xy64, h_canon, 64);
     *handle = publish(bs);
   });
 }
@@ -280,7 +329,7 @@ int nmx_msm(int curve, const void* scalars, const void* bases, size_t n, uint32_
     CtxLease L;
     TempBases tb;
     uint32_t pc, pw;
-    tb.d = o.upload(*L.c, bases, n, flags & ~(uint32_t)NMX_BASES_PRECOMPUTE, &pc, &pw);
+    tb.d = o.upload(*L.c, bases, n, flags & ~(uint32_t)NMX_BASES_PRECOMPUTE, &pc, &pw, nullptr);
     o.msm_plain(*L.c, tb.d, n, field_call(scalars, flags), flags, out, out_is_inf);
   });
 }
@@ -310,7 +359,7 @@ int nmx_msm_u64(int curve, const uint64_t* scalars, const void* bases, size_t n,
     uint32_t bits = resolve_u64_bits(*L.c, scalars, n, dev, max_num_bits);
     MsmCall mc{scalars, dev, false, bits, true};
     uint32_t pc, pw;
-    tb.d = o.upload(*L.c, bases, n, flags & ~(uint32_t)NMX_BASES_PRECOMPUTE, &pc, &pw);
+    tb.d = o.upload(*L.c, bases, n, flags & ~(uint32_t)NMX_BASES_PRECOMPUTE, &pc, &pw, nullptr);
     o.msm_plain(*L.c, tb.d, n, mc, flags, out, out_is_inf);
   });
 }
@@ -413,7 +462,7 @@ int nmx_msm_batch(int curve, const void* const* scalar_vecs, const size_t* lens,
     CtxLease L;
     TempBases tb;
     uint32_t pc, pw;
-    tb.d = o.upload(*L.c, bases, n_bases, flags & ~(uint32_t)NMX_BASES_PRECOMPUTE, &pc, &pw);
+    tb.d = o.upload(*L.c, bases, n_bases, flags & ~(uint32_t)NMX_BASES_PRECOMPUTE, &pc, &pw, nullptr);
     batch_impl(BaseSet{curve, n_bases, tb.d, 0, 0}, scalar_vecs, lens, k, flags, out, out_is_inf, *L.c);
   });
 }

@@ -22,6 +22,35 @@ template <int FID> struct ToInternalFn {  // ABI form -> internal form (canonica
     f.canon().to_words(w);  // 0 -> 0: the identity encoding (0, 0) is preserved
   }
 };
+// NMX_BASES_VALIDATE: raw ABI-form point i -> error bit if a coordinate is >= p or y^2 != x^3 + b (read_points,
+// /root/reference/src/provider/ptau.rs:372-391: read_raw rejects non-canonical coordinates, then is_on_curve; the
+// identity (0, 0) passes is_on_curve).  Runs BEFORE the in-place conversion.
+template <int CID> struct ValidateFn {
+  using C = CurveT<CID>;
+  const uint32_t* v;  // n x 16 words
+  uint32_t from_mont;
+  uint32_t* err;
+  NMX_HD void operator()(uint32_t i) const {
+    using F = Fp<C::BF>;
+    const uint32_t* w = v + 16 * (size_t)i;
+    uint32_t any = 0;
+    for (int j = 0; j < 16; j++) any |= w[j];
+    if (!any) return;
+    bool ok = F::words_lt_p(w) && F::words_lt_p(w + 8);
+    if (ok) {
+      F x = F::from_words(w), y = F::from_words(w + 8);
+      x = (from_mont ? x.mont256_to_internal() : x.to_internal());
+      y = (from_mont ? y.mont256_to_internal() : y.to_internal());
+      uint32_t bw[8];
+      for (int j = 0; j < 8; j++) bw[j] = C::B[j];
+      F b = F::from_words(bw).to_internal();
+      F lhs = y.sqr();
+      F rhs = (x.sqr() * x + b).norm();
+      ok = F::eq_mod_p(lhs, rhs);
+    }
+    if (!ok) nmx_atomic_or(err, 1u);
+  }
+};
 template <int CID> struct GenFn {  // P_i = (k0 + i) * G
   using C = CurveT<CID>;
   AffineW* out;
@@ -153,16 +182,31 @@ template <int CID> static void build_tables(Ctx& c, void* d, size_t n, uint32_t 
 }
 
 template <int CID>
-static void* upload_bases(Ctx& c, const void* src, size_t n, uint32_t flags, uint32_t* pre_c, uint32_t* pre_W) {
+static void* upload_bases(Ctx& c, const void* src, size_t n, uint32_t flags, uint32_t* pre_c, uint32_t* pre_W,
+                          const BaseFill* fill) {
   constexpr int BF = CurveT<CID>::BF;
   void* d = nullptr;
   table_shape<CID>(n, flags, pre_c, pre_W);
   if (n == 0) return nullptr;
   HIPCHK(hipMalloc(&d, n * 64 * (*pre_W ? *pre_W : 1)));
   try {
-    HIPCHK(hipMemcpyAsync(d, src, n * 64,
-                          (flags & NMX_BASES_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
-                          c.stream));
+    if (fill) (*fill)(d, c.stream);
+    else
+      HIPCHK(hipMemcpyAsync(d, src, n * 64,
+                            (flags & NMX_BASES_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                            c.stream));
+    if (flags & NMX_BASES_VALIDATE) {
+      arena_reserve(c, 256);
+      uint32_t* derr = (uint32_t*)c.arena;
+      HIPCHK(hipMemsetAsync(derr, 0, 4, c.stream));
+      DeviceBackend be(c, false, false);
+      ValidateFn<CID> f{(const uint32_t*)d, (flags & NMX_BASES_MONT) ? 1u : 0u, derr};
+      be.launch(f, (uint32_t)n);
+      uint32_t herr = 0;
+      HIPCHK(hipMemcpyAsync(&herr, derr, 4, hipMemcpyDeviceToHost, c.stream));
+      HIPCHK(hipStreamSynchronize(c.stream));
+      require(herr == 0, NMX_E_POINT, "PointNotOnCurve: a loaded point is not canonical or not on the curve");
+    }
     {
       DeviceBackend be(c, false, false);
       ToInternalFn<BF> f{(uint32_t*)d, (flags & NMX_BASES_MONT) ? 1u : 0u};
@@ -239,8 +283,21 @@ template <int CID> struct CurveImpl {
     }
     write_result<CID>(acc, flags, out, inf);
   }
-  static void* upload(Ctx& c, const void* src, size_t n, uint32_t flags, uint32_t* pc, uint32_t* pw) {
-    return upload_bases<CID>(c, src, n, flags, pc, pw);
+  static void* upload(Ctx& c, const void* src, size_t n, uint32_t flags, uint32_t* pc, uint32_t* pw,
+                      const BaseFill* fill) {
+    return upload_bases<CID>(c, src, n, flags, pc, pw, fill);
+  }
+  static bool check_point_host(const uint8_t* xy64, uint32_t flags, uint8_t* out) {
+    uint32_t w[16], err = 0;
+    memcpy(w, xy64, 64);
+    ValidateFn<CID> f{w, (flags & NMX_BASES_MONT) ? 1u : 0u, &err};
+    f(0);
+    if (err) return false;
+    for (int k = 0; k < 2; k++) {
+      Fp<BF> v = Fp<BF>::from_words(w + 8 * k);
+      fp_to_bytes((flags & NMX_BASES_MONT) ? v.mont256_to_canonical() : v.canon(), out + 32 * k);
+    }
+    return true;
   }
   static void* generate(Ctx& c, uint64_t k0, size_t n, uint32_t flags, uint32_t* pc, uint32_t* pw) {
     void* d = nullptr;
@@ -274,7 +331,8 @@ template <int CID> struct CurveImpl {
     xyzz_to_xy64<BF>(acc, out, inf);
   }
   static CurveOps ops() {
-    return CurveOps{&msm_plain, &msm_key, &commit, &upload, &generate, &internal_to_canonical, &point_sum};
+    return CurveOps{&msm_plain, &msm_key, &commit, &upload, &check_point_host, FpParams<BF>::PW,
+                    &generate, &internal_to_canonical, &point_sum};
   }
 };
 

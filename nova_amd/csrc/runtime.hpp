@@ -4,6 +4,7 @@
 // rocPRIM sort and one for the C ABI (capi.hip).  There is no CPU fallback anywhere: without a HIP device every
 // entry point returns NMX_E_NO_DEVICE.
 #pragma once
+#include <functional>
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -189,6 +190,10 @@ struct MsmCall {
 };
 static constexpr size_t kPrecompMinN = 4096;  // below this the plain path with a narrow window is faster
 
+// Fills the freshly allocated device key (n x 64 raw bytes) -- nullptr: one hipMemcpy from `src`; key files stream
+// through pinned staging buffers (keyfile.hip)
+using BaseFill = std::function<void(void* d_dst, hipStream_t stream)>;
+
 struct CurveOps {
   // out = sum scalars[i] * bases[i] over device-resident internal-form bases
   void (*msm_plain)(Ctx&, const void* d_bases, size_t n, const MsmCall&, uint32_t flags, uint8_t* out, uint8_t* inf);
@@ -198,7 +203,10 @@ struct CurveOps {
   // msm_key(v) + h * r
   void (*commit)(Ctx&, const BaseSet&, size_t n, const MsmCall&, const void* h_xy64, const void* r, uint32_t flags,
                  uint8_t* out, uint8_t* inf);
-  void* (*upload)(Ctx&, const void* src, size_t n, uint32_t flags, uint32_t* pre_c, uint32_t* pre_W);
+  void* (*upload)(Ctx&, const void* src, size_t n, uint32_t flags, uint32_t* pre_c, uint32_t* pre_W, const BaseFill* fill);
+  // host: one point in the ABI form (flags & NMX_BASES_MONT) -> canonical x||y; false if not canonical / off the curve
+  bool (*check_point_host)(const uint8_t* xy64, uint32_t flags, uint8_t* out_canonical_xy64);
+  const uint32_t* base_modulus_words;  // 8 x u32
   void* (*generate)(Ctx&, uint64_t k0, size_t n, uint32_t flags, uint32_t* pre_c, uint32_t* pre_W);
   void (*internal_to_canonical)(uint8_t* elems32, size_t count);  // host, in place
   void (*point_sum)(const uint8_t* partials128, size_t count, uint8_t* out, uint8_t* inf);  // host

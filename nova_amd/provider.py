@@ -104,6 +104,36 @@ class CommitmentKey:
         return cls(curve, h.value, n, h_xy64 if h_xy64 is not None else bytes(64), mont)
 
     @classmethod
+    def from_host_validated(cls, curve, ck_xy64, h_xy64=None, mont=False, precompute=True):
+        """from_host + the checks `read_points` applies to loaded keys (ptau.rs:372-391): NmxError(E_POINT) on a
+        non-canonical coordinate or an off-curve point."""
+        a = _host_u8(ck_xy64, 64)
+        h = ctypes.c_uint64(0)
+        flags = (L.BASES_MONT if mont else 0) | (L.BASES_PRECOMPUTE if precompute else 0) | L.BASES_VALIDATE
+        _check(L.lib().nmx_bases_register(curve, a.ctypes.data, a.size // 64, flags, ctypes.byref(h)))
+        return cls(curve, h.value, a.size // 64, h_xy64 if h_xy64 is not None else bytes(64), mont)
+
+    @classmethod
+    def load_ptau(cls, curve, path, n, h_xy64=None, precompute=True):
+        """HyperKZG `load_setup` (src/provider/hyperkzg.rs:658-674): ck = the first n.next_power_of_two() tauG1 points of
+        a .ptau file, streamed to HBM.  `h` (from_label on the reference side) and tau_H (G2) stay with the host."""
+        num = 1 if n <= 1 else 1 << (n - 1).bit_length()
+        h = ctypes.c_uint64(0)
+        _check(L.lib().nmx_bases_register_ptau(curve, str(path).encode(), num, 2, L.BASES_PRECOMPUTE if precompute else 0,
+                                               ctypes.byref(h)))
+        return cls(curve, h.value, num, h_xy64 if h_xy64 is not None else bytes(64))
+
+    @classmethod
+    def load_keyfile(cls, curve, path, n, precompute=True):
+        """Pedersen `load_setup` (src/provider/pedersen.rs:318-340): "PEDERSEN_KEY" | h | ck[0..n.next_power_of_two())."""
+        num = 1 if n <= 1 else 1 << (n - 1).bit_length()
+        h = ctypes.c_uint64(0)
+        hxy = np.zeros(64, dtype=np.uint8)
+        _check(L.lib().nmx_bases_register_keyfile(curve, str(path).encode(), num, L.BASES_PRECOMPUTE if precompute else 0,
+                                                  ctypes.byref(h), hxy.ctypes.data))
+        return cls(curve, h.value, num, hxy.tobytes())
+
+    @classmethod
     def generate(cls, curve, n, k0=1, precompute=True):
         """Synthetic key P_i = (k0 + i) * G built on the device (nmx_bases_generate); h = P_n."""
         h = ctypes.c_uint64(0)
