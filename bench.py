@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--iters", type=int, default=65536, help="prove_step_replay: MinRoot iterations per step")
-    ap.add_argument("--workload", default="msm", choices=["msm", "axpy", "cross_term", "bind", "sumcheck3", "prove_step_replay", "hyperkzg_replay"],
+    ap.add_argument("--workload", default="msm", choices=["msm", "axpy", "cross_term", "bind", "sumcheck3", "quad_prod", "lincomb8", "horner", "mle_eval", "spmv", "prove_step_replay", "hyperkzg_replay"],
                     help="msm = the headline (default); the others time one HBM-bound field-vector kernel of "
                          "SURVEY.md 8(f) at 2^log2n elements per GPU")
     args = ap.parse_args()
@@ -428,34 +428,89 @@ def effective_cpus():
 
 
 def field_workload(args, world, rank, L, torch, dist):
-    """One HBM-bound field-vector kernel per step on HBM-resident vectors (BN254 scalar field unless --curve):
-    axpy = NIFS witness fold (r1cs/mod.rs:1058-1067), cross_term = commit_T's T (r1cs/mod.rs:614-620),
-    bind = MLE bind_poly_var_top (spartan/polys/multilinear.rs:65-84).  Ranks are independent replicas."""
+    """One field-vector kernel per step on HBM-resident vectors (BN254 scalar field unless --curve); ranks are
+    independent replicas.  Workloads and the reference loops they replace:
+      axpy        NIFS witness fold                      r1cs/mod.rs:1058-1067
+      cross_term  commit_T's T                           r1cs/mod.rs:614-620
+      bind        MLE bind_poly_var_top                  spartan/polys/multilinear.rs:65-84
+      sumcheck3   eq-factored cubic round sums           spartan/sumcheck.rs:900-958
+      quad_prod   plain quadratic round sums             spartan/sumcheck.rs:163-186
+      lincomb8    PolyEvalWitness::batch of 8 polys      spartan/mod.rs:223-277
+      horner      poly_eval + div_by_monomial            provider/hyperkzg.rs:946-1020
+      mle_eval    MultilinearPolynomial::evaluate_with   spartan/polys/multilinear.rs:98-129
+      spmv        R1CS A*z, 3 non-zeros per row average  r1cs/sparse.rs:201-229"""
     import ctypes
     from nova_amd import fieldvec as fv
+    from oracle import cref
     from tests import util
     n = 1 << args.log2n
     cid = args.curve
     fid = fv.SCALAR_FIELD_OF_CURVE[cid]
-    nvec = {"axpy": 2, "cross_term": 4, "bind": 1, "sumcheck3": 3}[args.workload]
+    wl = args.workload
+    nvec = {"axpy": 2, "cross_term": 4, "bind": 1, "sumcheck3": 3, "quad_prod": 2, "lincomb8": 8, "horner": 1,
+            "mle_eval": 1, "spmv": 1}[wl]
     host = [util.random_scalars(cid, n, seed=util.SEED + 7 * j + rank) for j in range(nvec)]
     dev = [torch.from_numpy(h).cuda() for h in host]
     r = util.random_scalars(cid, 1, seed=99)
-    # reads + writes per element of the input vectors (sumcheck3: a0,a1,b0,b1,c0 per index = 80 B per element)
-    bytes_per_elem = {"axpy": 96, "cross_term": 160, "bind": 48, "sumcheck3": 80}[args.workload]
+    # algorithmic reads + writes per element of the input vectors (sumcheck3: a0,a1,b0,b1,c0 per index = 80 B per
+    # element; quad_prod: a0,a1,b0,b1 per index = 64 B per element; horner: read f, write out = 64 B;
+    # lincomb8: 8 reads + 1 write; mle_eval: one read; spmv: per row 3 x (32 B value + 4 B index + 32 B gathered z)
+    # + 8 B indptr + 32 B result)
+    bytes_per_elem = {"axpy": 96, "cross_term": 160, "bind": 48, "sumcheck3": 80, "quad_prod": 64, "lincomb8": 288,
+                      "horner": 64, "mle_eval": 32, "spmv": 3 * 68 + 40}[wl]
     shift = (args.log2n - 1) // 2
-    if args.workload == "sumcheck3":
+    eqR = eqL = mat = csr = None
+    if wl == "sumcheck3":
         eqR = torch.from_numpy(util.random_scalars(cid, 1 << shift, seed=5)).cuda()
         eqL = torch.from_numpy(util.random_scalars(cid, (n // 2) >> shift, seed=6)).cuda()
+    if wl == "mle_eval":
+        point = util.random_scalars(cid, args.log2n, seed=8)
+    if wl == "spmv":  # n rows x n columns, 3 random non-zeros per row (the minroot shape: 3 constraints per iteration)
+        rng = np.random.Generator(np.random.PCG64(5))
+        indptr = np.arange(0, 3 * n + 1, 3, dtype=np.uint64)
+        indices = rng.integers(0, n, size=3 * n).astype(np.uint64)
+        data = util.random_scalars(cid, 3 * n, seed=4)
+        csr = (indptr, indices, data)
+        mat = fv.SparseMatrix(fid, indptr, indices, data, n)
 
     def step():
-        if args.workload == "axpy":
+        if wl == "axpy":
             return fv.axpy(fid, dev[0], dev[1], r)
-        if args.workload == "cross_term":
+        if wl == "cross_term":
             return fv.cross_term(fid, dev[0], dev[1], dev[2], dev[3], r)
-        if args.workload == "sumcheck3":  # one outer sum-check round's N-scaling sums (sumcheck.rs:900-958)
+        if wl == "sumcheck3":
             return fv.sumcheck_eq_sums(fid, 3, dev[0], dev[1], dev[2], eqR, eqL, shift)
+        if wl == "quad_prod":
+            return fv.sumcheck_plain_sums(fid, 1, dev[0], dev[1])
+        if wl == "lincomb8":
+            return fv.lincomb_powers(fid, dev, r)
+        if wl == "horner":
+            return fv.suffix_horner(fid, dev[0], r)
+        if wl == "mle_eval":
+            return fv.mle_evaluate(fid, dev[0], point)
+        if wl == "spmv":
+            return mat.multiply_vec(dev[0])
         return fv.bind_poly_var_top(fid, dev[0], r)
+
+    def cpu(m):
+        """the oracle on the first m elements -> (bytes to compare, number of elements the time covers)"""
+        if wl == "axpy":
+            return cref.field_axpy(fid, host[0][:m], host[1][:m], r, m), m
+        if wl == "cross_term":
+            return cref.field_cross_term(fid, host[0][:m], host[1][:m], host[2][:m], host[3][:m], r, m), m
+        if wl == "sumcheck3":
+            return b"".join(cref.sumcheck_eq_sums(fid, 3, host[0], host[1], host[2], n, eqR.cpu().numpy(), eqL.cpu().numpy(), shift)), n
+        if wl == "quad_prod":
+            return b"".join(cref.sumcheck_plain_sums(fid, 1, host[0], host[1], None, n)[:2]), n
+        if wl == "lincomb8":
+            return cref.lincomb_powers(fid, [h[:m].tobytes() for h in host], r, m), m
+        if wl == "horner":
+            return cref.suffix_horner(fid, host[0], n, r), n
+        if wl == "mle_eval":
+            return cref.mle_evaluate(fid, host[0], args.log2n, point), n
+        if wl == "spmv":
+            return cref.spmv(fid, csr[0][: m + 1], csr[1], csr[2], m, host[0]), m
+        return cref.field_bind(fid, host[0], 0, n // 2, 1, r, min(m, n // 2)), min(m, n // 2)
 
     def fence():
         torch.cuda.synchronize()
@@ -486,43 +541,34 @@ def field_workload(args, world, rank, L, torch, dist):
         kms = ksum / args.steps
         achieved = bytes_per_elem * n / (kms * 1e-3) / 1e9
         res = {
-            "metric": f"field elements/sec ({args.workload})", "value": n * world * args.steps / dt, "unit": "elements/s",
+            "metric": f"field elements/sec ({wl})", "value": n * world * args.steps / dt, "unit": "elements/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32x8 (256-bit modular integer)", "data": "synthetic",
-            "config": {"workload": f"{args.workload} over 2^{args.log2n} {['bn254_fq','bn254_fr','pasta_fp','pasta_fq'][fid]} "
+            "config": {"workload": f"{wl} over 2^{args.log2n} {['bn254_fq','bn254_fr','pasta_fp','pasta_fq'][fid]} "
                                    "elements per GPU, HBM-resident (SURVEY.md 8(f))", "parallelism": f"replicas{world}"},
             "kernel_ms": kms,
-            "roofline": {"bound": "hbm", "kernel": f"k_launch<{args.workload}>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": f"k_launch<{wl}>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "note": f"{bytes_per_elem} algorithmic bytes per element / kernel time from hipEvents on the library stream"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            from oracle import cref
             threads = effective_cpus()
             cref.set_threads(threads)
-            m = min(n, 1 << 22)
             t1 = time.perf_counter()
-            if args.workload == "axpy":
-                exp = cref.field_axpy(fid, host[0][:m], host[1][:m], r, m)
-            elif args.workload == "cross_term":
-                exp = cref.field_cross_term(fid, host[0][:m], host[1][:m], host[2][:m], host[3][:m], r, m)
-            elif args.workload == "sumcheck3":
-                m = n
-                exp = cref.sumcheck_eq_sums(fid, 3, host[0], host[1], host[2], n, eqR.cpu().numpy(), eqL.cpu().numpy(), shift)
-            else:
-                exp = cref.field_bind(fid, host[0], 0, n // 2, 1, r, min(m, n // 2))
+            exp, cnt = cpu(min(n, 1 << 22))
             t = time.perf_counter() - t1
-            cnt = m if args.workload != "bind" else min(m, n // 2)
-            if args.workload == "sumcheck3":
-                got, exp = b"".join(out), b"".join(exp)
-                cnt = 2
+            if isinstance(out, tuple):
+                got = b"".join(out)
+            elif isinstance(out, bytes):
+                got = out
             else:
-                got = out.cpu().numpy().reshape(-1)[: 32 * cnt].tobytes()
-            cnt_rate = n if args.workload == "sumcheck3" else cnt
-            res["cpu_baseline"] = {"value": cnt_rate / t, "unit": "elements/s", "cores": threads, "kind": "port",
-                                   "sample": f"first {cnt} elements, one pass, oracle/nova_ref.c (OpenMP)",
-                                   "gpu_matches_cpu": got == exp[: 32 * cnt]}
+                got = out.cpu().numpy().reshape(-1).tobytes()
+            res["cpu_baseline"] = {"value": cnt / t, "unit": "elements/s", "cores": threads, "kind": "port",
+                                   "sample": f"{cnt} elements, one pass, oracle/nova_ref.c",
+                                   "gpu_matches_cpu": got[: len(exp)] == exp}
+    if mat is not None:
+        mat.close()
     emit(res if rank == 0 else None, world > 1, dist)
 
 

@@ -128,7 +128,7 @@ template <int FID> struct FoldQuadFn {
   XYZZW* buckets;
   uint32_t T, cap, groups;
   __device__ __forceinline__ void operator()(uint32_t tid) const {
-    if (T != 1 && counters[3] <= T) return;
+    if (T >= 64 && counters[3] <= T) return;
     const uint32_t q = tid & 3u, item = tid >> 2;
     const uint32_t j = item % T, nh = counters[T >= 64 ? 4 : 1];
     for (uint32_t h = item / T; h < nh; h += groups) {

@@ -416,15 +416,35 @@ static void lincomb_t(Ctx& c, const void* const* vecs, const size_t* lens, size_
   }
 }
 
+// Workspace of one suffix-Horner call, carved from the context arena (no allocation on the call path once the arena
+// has grown): per recursion level the chunk heads and carries, plus one 65-entry power table.
+struct HornerArena {
+  char* base;
+  size_t used = 0;
+  static size_t pad(size_t b) { return (b + 255) & ~(size_t)255; }
+  static size_t need(size_t n) {
+    size_t total = 0;
+    for (size_t m = n; m > 1;) {
+      const size_t nc = (m + kHornerChunk - 1) / kHornerChunk;
+      total += 2 * pad(nc * 32) + pad((kHornerChunk + 1) * 32);
+      m = nc;
+    }
+    return total + pad(32) + 256;
+  }
+  void* take(size_t bytes) {
+    void* p = base + used;
+    used += pad(bytes);
+    return p;
+  }
+};
+
 // out (device, n elements) <- suffix Horner of f (device) at the challenge whose internal residue is `ui`
 template <int FID> static void horner_dev(Ctx& c, const uint32_t* f, uint32_t n, Fp<FID> ui, uint32_t* out,
-                                          std::vector<void*>& tmp) {
+                                          HornerArena& ws) {
   using F = Fp<FID>;
   DeviceBackend be(c, false, false);
   const uint32_t nc = (n + kHornerChunk - 1) / kHornerChunk;
-  uint32_t* heads = nullptr;
-  HIPCHK(hipMalloc((void**)&heads, (size_t)nc * 32));
-  tmp.push_back(heads);
+  uint32_t* heads = (uint32_t*)ws.take((size_t)nc * 32);
   HornerLocalFn<FID> lf{f, out, heads, ui, n};
   be.launch(lf, nc);
   if (nc == 1) return;
@@ -436,42 +456,39 @@ template <int FID> static void horner_dev(Ctx& c, const uint32_t* f, uint32_t n,
     p = (p * ui).canon();
   }
   F uc = F::from_words(pwh.data() + 8 * kHornerChunk);  // u^64
-  uint32_t *pw = nullptr, *carries = nullptr;
-  HIPCHK(hipMalloc((void**)&pw, pwh.size() * 4));
-  tmp.push_back(pw);
-  HIPCHK(hipMalloc((void**)&carries, (size_t)nc * 32));
-  tmp.push_back(carries);
+  uint32_t* pw = (uint32_t*)ws.take(pwh.size() * 4);
+  uint32_t* carries = (uint32_t*)ws.take((size_t)nc * 32);
   HIPCHK(hipMemcpyAsync(pw, pwh.data(), pwh.size() * 4, hipMemcpyHostToDevice, c.stream));
   HIPCHK(hipStreamSynchronize(c.stream));  // pwh is a local buffer
-  horner_dev<FID>(c, heads, nc, uc, carries, tmp);
+  horner_dev<FID>(c, heads, nc, uc, carries, ws);
   HornerFixFn<FID> ff{out, carries, pw, n};
   be.launch(ff, n);
 }
 template <int FID>
 static void horner_t(Ctx& c, const void* f, size_t n, const void* u, uint32_t flags, void* out) {
   const bool dev = flags & NMX_SCALARS_DEVICE;
-  std::vector<void*> tmp;
-  struct Free {
-    std::vector<void*>& v;
-    ~Free() {
-      for (void* p : v) (void)hipFree(p);
-    }
-  } guard{tmp};
+  arena_reserve(c, HornerArena::need(n) + (dev ? 0 : 2 * HornerArena::pad(n * 32)));
+  HornerArena ws{c.arena};
   const uint32_t* df = (const uint32_t*)f;
   uint32_t* dout = (uint32_t*)out;
   if (!dev) {
-    void *a = nullptr, *b = nullptr;
-    HIPCHK(hipMalloc(&a, n * 32));
-    tmp.push_back(a);
-    HIPCHK(hipMalloc(&b, n * 32));
-    tmp.push_back(b);
+    void* a = ws.take(n * 32);
+    dout = (uint32_t*)ws.take(n * 32);
     HIPCHK(hipMemcpyAsync(a, f, n * 32, hipMemcpyHostToDevice, c.stream));
     df = (const uint32_t*)a;
-    dout = (uint32_t*)b;
   }
-  horner_dev<FID>(c, df, (uint32_t)n, challenge<FID>(u, flags & NMX_SCALARS_MONT), dout, tmp);
+  const bool prof = G.profiling;
+  DeviceBackend be(c, false, prof);
+  be.mark("kernel");
+  horner_dev<FID>(c, df, (uint32_t)n, challenge<FID>(u, flags & NMX_SCALARS_MONT), dout, ws);
+  be.mark("end");
   if (!dev) HIPCHK(hipMemcpyAsync(out, dout, n * 32, hipMemcpyDeviceToHost, c.stream));
   HIPCHK(hipStreamSynchronize(c.stream));
+  if (prof && be.nmarks == 2) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
+    prof_store(&ms, 1);
+  }
 }
 void fv_suffix_horner(Ctx& c, int field, const void* f, size_t n, const void* u, uint32_t flags, void* out) {
   switch (field) {

@@ -156,21 +156,62 @@ struct TaskRec {
   uint32_t start, len;
 };
 struct PlanFn {
+  // Appends to the split-bucket list.  In table mode EVERY bucket is split (n*W/M points against lmax = 24), and
+  // appends through same-address atomics are bound by the atomic unit (~8 ns each: 0.28 ms for the 2^19 buckets
+  // of a 2^22-pair MSM even with one atomic per wave).  So: every lane of a wave is alive (lanes past n come
+  // with valid = false), a lane plans kPerLane consecutive buckets, and the wave reserves its list slots and task
+  // slots with ONE 64-bit atomic; the two rarely-needed statistics are only touched by buckets with > 64 tasks.
+  static constexpr bool kFullWaves = true;
+  static constexpr uint32_t kPerLane = 4;
   const uint32_t* start;
   const uint32_t* end;
-  uint32_t* counters;  // [0] = extra tasks used, [1] = heavy buckets, [3] = most tasks in one bucket, [4] = big ones
+  uint32_t* counters;  // [0] = extra tasks used, [1] = split buckets (one u64: [1]:[0]), [3] = most tasks in one big
+                       // bucket, [4] = big buckets
   HeavyRec* heavy;
   HeavyRec* big;  // the buckets split into more than 64 tasks (at most total / (64 * lmax) of them)
   MsmShape sh;
-  NMX_HD void operator()(uint32_t k) const {
-    uint32_t s = end[k] - start[k];
-    if (s <= sh.lmax) return;
-    uint32_t nt = (s + sh.lmax - 1) / sh.lmax;
-    nmx_atomic_max(&counters[3], nt);
-    uint32_t off = nmx_atomic_add(&counters[0], nt);
-    uint32_t h = nmx_atomic_add(&counters[1], 1);
-    heavy[h] = HeavyRec{k, off, nt, 0};
-    if (nt > 64) big[nmx_atomic_add(&counters[4], 1)] = HeavyRec{k, off, nt, 0};  // see FoldFn: passes with T >= 64
+  NMX_HD void operator()(uint32_t q) const { (*this)(q, true); }
+  NMX_HD void operator()(uint32_t q, bool valid) const {
+    uint32_t nt[kPerLane];
+    uint64_t mine = 0;  // hi: split buckets, lo: tasks
+#pragma unroll
+    for (uint32_t u = 0; u < kPerLane; u++) {
+      const uint32_t k = q * kPerLane + u;
+      const uint32_t s = (valid && k < sh.nbuckets) ? end[k] - start[k] : 0;
+      nt[u] = s > sh.lmax ? (s + sh.lmax - 1) / sh.lmax : 0;
+      if (nt[u]) mine += (1ull << 32) | nt[u];
+    }
+    uint64_t base;  // list / task slots of this lane's first split bucket
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__ballot(mine != 0) == 0) return;  // wave-uniform
+    const uint32_t lane = __lane_id();
+    unsigned long long inc = mine;  // inclusive scan over the wave (neither half can carry into the other)
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned long long t = __shfl_up(inc, d);
+      if (lane >= (uint32_t)d) inc += t;
+    }
+    const unsigned long long total = __shfl(inc, 63);
+    unsigned long long wave_base = 0;
+    if (lane == 0) wave_base = atomicAdd((unsigned long long*)counters, total);
+    wave_base = __shfl(wave_base, 0);
+    base = wave_base + inc - mine;
+#else
+    base = ((uint64_t)counters[1] << 32) | counters[0];
+    counters[0] += (uint32_t)mine;
+    counters[1] += (uint32_t)(mine >> 32);
+#endif
+    uint32_t h = (uint32_t)(base >> 32), off = (uint32_t)base;
+#pragma unroll
+    for (uint32_t u = 0; u < kPerLane; u++) {
+      if (!nt[u]) continue;
+      const HeavyRec r{q * kPerLane + u, off, nt[u], 0};
+      heavy[h++] = r;
+      off += nt[u];
+      if (nt[u] > 64) {  // see FoldFn: passes with T >= 64
+        nmx_atomic_max(&counters[3], nt[u]);
+        big[nmx_atomic_add(&counters[4], 1)] = r;
+      }
+    }
   }
 };
 // Task records of the over-long buckets, `lanes` lanes per bucket.  (A single lane per bucket would serialise
@@ -256,7 +297,7 @@ template <int FID> struct FoldFn {
   uint32_t cap;     // positions valid on entry = min(cnt, cap); cap = 0xffffffff for the first pass
   uint32_t groups;  // grid = groups * T lanes; groups loop over the heavy list
   NMX_HD void operator()(uint32_t tid) const {
-    if (T != 1 && counters[3] <= T) return;  // no bucket has more than T partials: this pass has nothing to fold
+    if (T >= 64 && counters[3] <= T) return;  // no big bucket has more than T partials: nothing to fold here
     uint32_t j = tid % T;
     uint32_t nh = counters[T >= 64 ? 4 : 1];
     for (uint32_t h = tid / T; h < nh; h += groups) {

@@ -5,6 +5,7 @@
 // entry point returns NMX_E_NO_DEVICE.
 #pragma once
 #include <functional>
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -43,9 +44,14 @@ static inline void require(bool ok, int code, const char* msg) {
 // ---------------------------------------------------------------------------------------------------
 // generic launch trampoline: one lane per tid
 // ---------------------------------------------------------------------------------------------------
+// functors with `static constexpr bool kFullWaves` use wave-wide operations: every lane of the block calls them,
+// lanes past n with valid = false
+template <class F, class = void> struct wants_full_waves : std::false_type {};
+template <class F> struct wants_full_waves<F, std::void_t<decltype(F::kFullWaves)>> : std::true_type {};
 template <class F> __global__ __launch_bounds__(256) void k_launch(F f, uint32_t n) {
   uint32_t tid = blockIdx.x * 256u + threadIdx.x;
-  if (tid < n) f(tid);
+  if constexpr (wants_full_waves<F>::value) f(tid, tid < n);
+  else if (tid < n) f(tid);
 }
 
 // ---------------------------------------------------------------------------------------------------
