@@ -134,15 +134,37 @@ template <int SFID> struct DigitsFn {
 // ----------------------------------------------------------------------------------------------------
 // 3. bucket boundaries in the sorted key array
 // ----------------------------------------------------------------------------------------------------
+struct alignas(16) KeyQuad {
+  uint32_t x, y, z, w;
+};
 struct BoundsFn {
-  const uint32_t* keys;  // sorted
+  static constexpr uint32_t kPerLane = 4;  // one 16-byte load per lane
+  const uint32_t* keys;  // sorted, 16-byte aligned
   uint32_t* start;       // nbuckets + 1, zero-initialised
   uint32_t* end;         // nbuckets + 1, zero-initialised
   uint32_t total;
-  NMX_HD void operator()(uint32_t j) const {
-    uint32_t k = keys[j];
-    if (j == 0 || keys[j - 1] != k) start[k] = j;
-    if (j + 1 == total || keys[j + 1] != k) end[k] = j + 1;
+  NMX_HD void operator()(uint32_t q) const {
+    const uint32_t j0 = q * kPerLane;
+    uint32_t k[kPerLane + 2];  // k[0] = the key before the group, k[5] = the key after it
+    if (j0 + kPerLane <= total) {
+      const KeyQuad v = *reinterpret_cast<const KeyQuad*>(keys + j0);
+      k[1] = v.x;
+      k[2] = v.y;
+      k[3] = v.z;
+      k[4] = v.w;
+    } else {
+#pragma unroll
+      for (uint32_t u = 0; u < kPerLane; u++) k[1 + u] = j0 + u < total ? keys[j0 + u] : 0;
+    }
+    k[0] = j0 ? keys[j0 - 1] : 0;
+    k[kPerLane + 1] = j0 + kPerLane < total ? keys[j0 + kPerLane] : 0;
+#pragma unroll
+    for (uint32_t u = 0; u < kPerLane; u++) {
+      const uint32_t j = j0 + u;
+      if (j >= total) break;
+      if (j == 0 || k[u] != k[u + 1]) start[k[u + 1]] = j;
+      if (j + 1 == total || k[u + 2] != k[u + 1]) end[k[u + 1]] = j + 1;
+    }
   }
 };
 

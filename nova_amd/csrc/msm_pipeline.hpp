@@ -143,7 +143,7 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
   be.mark("bounds");
   {
     BoundsFn f{keys1, start, end, (uint32_t)total};
-    be.launch(f, (uint32_t)total);
+    be.launch(f, (uint32_t)((total + BoundsFn::kPerLane - 1) / BoundsFn::kPerLane));
   }
   {
     PlanFn f{start, end, counters, heavy, big, sh};
