@@ -56,6 +56,10 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(v0, hv.data(), n * 4, hipMemcpyHostToDevice));
   using namespace rocprim;
   if (run<default_config>("default", k0, k1, v0, v1, n, bits, hk)) return 1;
+#ifdef NOMERGE
+  using CN = radix_sort_config<default_config, default_config, default_config, NOMERGE>;
+  if (run<CN>("onesweep below 1M (limit " "NOMERGE" ")", k0, k1, v0, v1, n, bits, hk)) return 1;
+#endif
 #ifdef WIDE
   using C10 = radix_sort_config<default_config, default_config,
                                 radix_sort_onesweep_config<kernel_config<512, 32>, kernel_config<WIDE_BS, WIDE_IPT>, WIDE, block_radix_rank_algorithm::match>>;

@@ -113,6 +113,39 @@ template <int FID> __device__ __forceinline__ Fp<FID> quad_add(const Fp<FID>& c1
   return q == 0 ? x3 : q == 2 ? t3 : t4;
 }
 
+// madd-2008-s (curve.hpp add_affine): (c coordinates) += the affine point whose halves the quad holds in `o`
+// (even lanes: x canonical; odd lanes: y < 2p normalized, sign already applied).  Four multiplication steps:
+//     step 1   [      -      |      -       | u2 = x2*zz1 | s2 = y2*zzz1 ]
+//     step 2   [ pp = p*p    | rr = r*r     | pp          | pp           ]        p = u2-x1, r = s2-y1
+//     step 3   [ q = x1*pp   |      -       | zz3 = zz1*pp| ppp = p*pp   ]
+//     step 4   [      -      | y3 = r*e - y1*ppp (one reduction) | - | zzz3 = zzz1*ppp ]   x3 = rr-ppp-2q, e = q-x3
+// against 9 dependent multiplications on one lane.  r carries +8p instead of curve.hpp's +4p (one subtraction
+// constant for both lanes): y3 < p * (1 + (9.02*9.07 + 4.5)/127) < 1.7p, inside the y < 3.5p invariant.
+template <int FID> __device__ __forceinline__ Fp<FID> quad_madd(const Fp<FID>& c, const Fp<FID>& o, uint32_t q) {
+  using F = Fp<FID>;
+  if (qperm_u32<QP_L2>(c.is_zero_limbs() ? 1u : 0u)) return q < 2 ? o : F::one();  // identity += P  (msm.rs:133-139)
+  const F t1 = o * c;                              //  l2: u2 < 1.01 ; l3: s2 < 1.02
+  const F a = qperm<QP_SWAP2>(t1);                 //  l0: u2 ; l1: s2
+  const F d = F::sub8(a, c).norm();                //  l0: p in (2.7, 9.01) ; l1: r < 9.02
+  if (qperm_u32<QP_L0>(d.maybe_zero_mod_p() ? 1u : 0u)) {
+    // P == +-Q, or a 2^-29 false alarm: single-lane formulas on gathered operands
+    XYZZ<FID> A = quad_gather<FID>(c);
+    A.add_affine(qperm<QP_L0>(o), qperm<QP_L1>(o));
+    return quad_pick<FID>(A, q);
+  }
+  const F p = qperm<QP_L0>(d);
+  const F t2 = fsel(q == 1, d, p).sqr();           //  l1: rr < 1.65 ; others: pp < 1.64
+  const F t3 = fsel(q == 3, p, c) * t2;            //  l0: q < 1.07 ; l2: zz3 < 1.02 ; l3: ppp < 1.12
+  const F rr = qperm<QP_L1>(t2), ppp = qperm<QP_L3>(t3), qq = qperm<QP_L0>(t3);
+  const F tt = (ppp + qq.dbl()).norm();            //  3.26
+  const F x3 = F::sub4(rr, tt).norm();             //  < 5.65 ... rr < 1.65: (1.65 + 4) within the x < 8 bound of sub8
+  const F e = F::sub8(qq, x3).norm();              //  < 9.07
+  const F ny = F::sub4(F::zero(), c);              //  l1: 4p - y1, limbs < 2^31
+  const F t4 = F::mul_add(fsel(q == 3, c, d), fsel(q == 3, t3, e), ppp, fsel(q == 3, F::zero(), ny));
+  //                                                   l1: y3 = r*e - y1*ppp ; l3: zzz3 = zzz1*ppp
+  return q == 0 ? x3 : q == 2 ? t3 : t4;
+}
+
 }  // namespace nmx
 #endif  // __HIPCC__
 
@@ -139,6 +172,53 @@ template <int FID> struct FoldQuadFn {
       Fp<FID> acc = quad_load<FID>(partials[r.off + j], q);
       for (uint32_t k = j + T; k < cnt; k += T) acc = quad_add<FID>(acc, quad_load<FID>(partials[r.off + k], q), q);
       quad_store<FID>(T == 1 ? buckets[r.bucket] : partials[r.off + j], q, acc);
+    }
+  }
+};
+
+// AccumFn (msm_kernels.hpp) with one quad per task: for MSMs whose task count is below the chip's lane count the
+// accumulate kernel is a chain of `lmax` dependent mixed additions per lane, i.e. latency-bound.
+template <int FID> struct AccumQuadFn {
+  const AffineW* bases;
+  const uint32_t* vals;
+  const uint32_t* start;
+  const uint32_t* end;
+  const uint32_t* counters;
+  const TaskRec* extra;
+  XYZZW* buckets;
+  XYZZW* partials;
+  MsmShape sh;
+
+  // this lane's half of base v (even lanes x, odd lanes y with the digit's sign applied)
+  __device__ __forceinline__ Fp<FID> half(uint32_t v, uint32_t q) const {
+    using F = Fp<FID>;
+    const F h = F::from_words(bases[v & 0x7fffffffu].w + 8 * (q & 1u));
+    const F nh = F::sub2(F::zero(), h).norm();  // 2p - y
+    return fsel((q & 1u) && (v >> 31), nh, h);
+  }
+  __device__ __forceinline__ Fp<FID> run(uint32_t b, uint32_t len, uint32_t q) const {
+    using F = Fp<FID>;
+    F acc = F::zero();
+    if (len == 0) return acc;
+    F cur = half(vals[b], q);
+    for (uint32_t j = 0; j < len; j++) {
+      F nxt = cur;
+      if (j + 1 < len) nxt = half(vals[b + j + 1], q);  // in flight during the addition
+      acc = quad_madd<FID>(acc, cur, q);
+      cur = nxt;
+    }
+    return acc;
+  }
+  __device__ __forceinline__ void operator()(uint32_t tid) const {
+    const uint32_t q = tid & 3u, t = tid >> 2;
+    if (t < sh.nbuckets) {
+      const uint32_t b = start[t], s = end[t] - b;
+      if (s <= sh.lmax) quad_store<FID>(buckets[t], q, run(b, s, q));  // split buckets are written by the folds
+    } else {
+      const uint32_t e = t - sh.nbuckets;
+      if (e >= counters[0]) return;
+      const TaskRec r = extra[e];
+      quad_store<FID>(partials[e], q, run(r.start, r.len, q));
     }
   }
 };

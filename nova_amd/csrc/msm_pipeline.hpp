@@ -154,8 +154,8 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
   }
   be.mark("accum");
   {
-    AccumFn<FID> f{(const AffineW*)a.bases, vals1, start, end, counters, extra, buckets, partials, sh};
-    be.launch(f, sh.nbuckets + extra_cap);
+    be.template launch_accum<FID>((const AffineW*)a.bases, vals1, start, end, counters, extra, buckets, partials, sh,
+                                  sh.nbuckets + extra_cap, (uint64_t)sh.nbuckets + total / sh.lmax);
   }
   be.mark("fold");
   {

@@ -91,6 +91,7 @@ struct Global {
   bool profiling = false;
   uint32_t force_c = 0;
   uint32_t force_lmax = 0;  // env NMX_TUNE_LMAX (tuning only)
+  uint32_t no_quad_accum = 0;  // env NMX_TUNE_NO_QUAD_ACCUM (tuning only)
 };
 extern Global G;                 // capi.hip
 void prof_store(const float* ms, int n);   // last call's stage times of this thread (capi.hip)
@@ -138,6 +139,21 @@ struct DeviceBackend {
     } else {
       FoldFn<FID> f{counters, heavy, partials, buckets, T, cap, groups};
       launch(f, groups * T);
+    }
+  }
+  // accumulate: `tasks` = buckets + split tasks that actually exist (estimate), `slots` = lanes to launch for them
+  template <int FID>
+  void launch_accum(const AffineW* bases, const uint32_t* vals, const uint32_t* start, const uint32_t* end,
+                    const uint32_t* counters, const TaskRec* extra, XYZZW* buckets, XYZZW* partials, const MsmShape& sh,
+                    uint32_t slots, uint64_t tasks) {
+    // a quad per task pays while 4 x tasks still fits the chip's 65536 lanes once over (measured: 2^13 pairs
+    // 0.139 -> 0.085 ms, 2^14 0.141 -> 0.127, but 2^16 -- 59 k tasks -- 0.148 -> 0.233)
+    if (4 * tasks <= kQuadBelowItems && !G.no_quad_accum) {
+      AccumQuadFn<FID> f{bases, vals, start, end, counters, extra, buckets, partials, sh};
+      launch(f, slots * 4);
+    } else {
+      AccumFn<FID> f{bases, vals, start, end, counters, extra, buckets, partials, sh};
+      launch(f, slots);
     }
   }
   template <int FID>

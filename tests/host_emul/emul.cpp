@@ -33,6 +33,13 @@ struct HostEmulBackend {
     for (uint32_t t = 0; t < n; t++) f(t);
   }
   template <int FID>
+  void launch_accum(const AffineW* bases, const uint32_t* vals, const uint32_t* start, const uint32_t* end,
+                    const uint32_t* counters, const TaskRec* extra, XYZZW* buckets, XYZZW* partials, const MsmShape& sh,
+                    uint32_t slots, uint64_t) {
+    AccumFn<FID> f{bases, vals, start, end, counters, extra, buckets, partials, sh};
+    launch(f, slots);
+  }
+  template <int FID>
   void launch_fold(const uint32_t* counters, const HeavyRec* heavy, XYZZW* partials, XYZZW* buckets, uint32_t T,
                    uint32_t cap, uint32_t groups) {
     FoldFn<FID> f{counters, heavy, partials, buckets, T, cap, groups};
