@@ -59,15 +59,16 @@ inline uint32_t choose_c(uint32_t n, uint32_t bits) {
   return (uint32_t)c;
 }
 
-// Window width of the precomputed tables of a key of n_key points.
-// Measured (profiles/r01_msm_2p20/window_width_sweep.txt): 16 is best up to 2^21 points, 20 from 2^22 on
-// (13 windows instead of 16: -19 % mixed additions; 2^19 buckets are amortised only by that many points).
+// Window width of the precomputed tables of a key of n_key points, from two measured sweeps
+// (profiles/r01_msm_2p20/window_width_sweep.txt, window_width_sweep_small.txt):
+//   >= 2^22 points  c = 20   13 windows instead of 16: -19 % mixed additions; 2^19 buckets need that many points
+//   >= 2^18         c = 16   16-bit sort keys (two radix passes), 2^15 buckets
+//   >= 2^16         c = 15   one level less in the (latency-bound) bucket reduction tree
+//   below           c = 8    8-bit keys sort in ONE radix pass and the tree has 7 levels; these MSMs are pure latency
 inline uint32_t choose_c_precomp(uint32_t n_key, uint32_t bits) {
   uint32_t lg = ilog2_u32(n_key < 2 ? 2 : n_key);
   if (lg >= 22) return 20;
-  int c = (int)lg - 4;
-  if (c < 8) c = 8;
-  if (c > 16) c = 16;
+  const int c = lg >= 18 ? 16 : lg >= 16 ? 15 : 8;
   return settle_c(c, 8, 16, bits);
 }
 

@@ -146,9 +146,9 @@ struct DeviceBackend {
   void launch_accum(const AffineW* bases, const uint32_t* vals, const uint32_t* start, const uint32_t* end,
                     const uint32_t* counters, const TaskRec* extra, XYZZW* buckets, XYZZW* partials, const MsmShape& sh,
                     uint32_t slots, uint64_t tasks) {
-    // a quad per task pays while 4 x tasks still fits the chip's 65536 lanes once over (measured: 2^13 pairs
-    // 0.139 -> 0.085 ms, 2^14 0.141 -> 0.127, but 2^16 -- 59 k tasks -- 0.148 -> 0.233)
-    if (4 * tasks <= kQuadBelowItems && !G.no_quad_accum) {
+    // a quad per task pays while 4 x tasks is about the chip's 65536 lanes (measured: 10 k tasks 0.139 -> 0.085 ms,
+    // 17 k tasks 0.141 -> 0.127, but 59 k tasks 0.148 -> 0.233)
+    if (4 * tasks <= kQuadBelowItems + kQuadBelowItems / 2 && !G.no_quad_accum) {
       AccumQuadFn<FID> f{bases, vals, start, end, counters, extra, buckets, partials, sh};
       launch(f, slots * 4);
     } else {
