@@ -31,6 +31,15 @@ void arena_reserve(Ctx& c, size_t bytes) {
   c.cap = want;
 }
 
+void aux_reserve(Ctx& c, size_t bytes) {
+  if (bytes <= c.aux_cap) return;
+  if (c.aux) HIPCHK(hipFree(c.aux));
+  c.aux = nullptr;
+  c.aux_cap = 0;
+  HIPCHK(hipMalloc((void**)&c.aux, bytes + (1u << 16)));
+  c.aux_cap = bytes + (1u << 16);
+}
+
 static void ensure_init() {
   std::lock_guard<std::mutex> lk(G.mu);
   if (G.inited) return;
@@ -192,6 +201,7 @@ int nmx_shutdown(void) {
     G.sparse.clear();
     for (Ctx* c : G.all_ctx) {
       if (c->arena) (void)hipFree(c->arena);
+      if (c->aux) (void)hipFree(c->aux);
       if (c->have_ev)
         for (int i = 0; i < kMaxMarks; i++) (void)hipEventDestroy(c->ev[i]);
       if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -588,11 +598,36 @@ int nmx_field_lincomb_powers(int field, const void* const* vecs, const size_t* l
   });
 }
 
-struct DevBuf {  // RAII device allocation
-  void* p = nullptr;
-  explicit DevBuf(size_t bytes) { HIPCHK(hipMalloc(&p, bytes ? bytes : 1)); }
-  ~DevBuf() {
-    if (p) (void)hipFree(p);
+// The two sqrt-size eq tables of evaluate_with (multilinear.rs:98-129) and the staging copy of a host polynomial,
+// carved from the context's aux arena (the main arena is re-carved by fv_eq_sums)
+struct EvalScratch {
+  uint32_t *eqL, *eqR;
+  void* z;
+  size_t s_left, s_right;
+  EvalScratch(Ctx& c, int field, const void* r, size_t ell, size_t len, uint32_t flags) {
+    s_right = ell / 2;
+    s_left = ell - s_right;
+    auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t bl = pad(((size_t)1 << s_left) * 32), br = pad(((size_t)1 << s_right) * 32);
+    const size_t bz = (flags & NMX_SCALARS_DEVICE) ? 0 : pad(len * 32);
+    aux_reserve(c, bl + br + bz);
+    eqL = (uint32_t*)c.aux;
+    eqR = (uint32_t*)(c.aux + bl);
+    z = bz ? c.aux + bl + br : nullptr;
+    fv_eq_evals(c, field, r, (uint32_t)s_left, flags, eqL);
+    fv_eq_evals(c, field, (const uint8_t*)r + 32 * s_left, (uint32_t)s_right, flags, eqR);
+  }
+  // sum_id z[id] * eqL[id >> s_right] * eqR[id & (2^s_right - 1)]: the mode-1 sum over "half" = len
+  void evaluate(Ctx& c, int field, const void* zp, size_t len, uint32_t flags, uint8_t* out32) {
+    const void* dz = zp;
+    if (z) {
+      HIPCHK(hipMemcpyAsync(z, zp, len * 32, hipMemcpyHostToDevice, c.stream));
+      dz = z;
+    }
+    uint8_t two[64];
+    fv_eq_sums(c, field, 1, dz, nullptr, nullptr, 2 * len, eqL, (size_t)1 << s_left, eqR, (size_t)1 << s_right,
+               (uint32_t)s_right, flags | NMX_SCALARS_DEVICE, two);
+    memcpy(out32, two, 32);
   }
 };
 
@@ -616,9 +651,9 @@ int nmx_eq_evals_from_points(int field, const void* r, size_t ell, uint32_t flag
       fv_eq_evals(*L.c, field, r, (uint32_t)ell, flags, (uint32_t*)out);
       HIPCHK(hipStreamSynchronize(L.c->stream));
     } else {
-      DevBuf d(n * 32);
-      fv_eq_evals(*L.c, field, r, (uint32_t)ell, flags, (uint32_t*)d.p);
-      HIPCHK(hipMemcpyAsync(out, d.p, n * 32, hipMemcpyDeviceToHost, L.c->stream));
+      aux_reserve(*L.c, n * 32);
+      fv_eq_evals(*L.c, field, r, (uint32_t)ell, flags, (uint32_t*)L.c->aux);
+      HIPCHK(hipMemcpyAsync(out, L.c->aux, n * 32, hipMemcpyDeviceToHost, L.c->stream));
       HIPCHK(hipStreamSynchronize(L.c->stream));
     }
   });
@@ -629,22 +664,8 @@ int nmx_mle_evaluate(int field, const void* z, size_t len, const void* r, size_t
     require(z && (r || ell == 0) && out32, NMX_E_ARG, "null argument");
     require(ell < 31 && len == ((size_t)1 << ell), NMX_E_ARG, "assert_eq!(r.len(), self.get_num_vars())");
     CtxLease L;
-    // sqrt decomposition of MultilinearPolynomial::evaluate_with (multilinear.rs:98-129)
-    const size_t s_right = ell / 2, s_left = ell - s_right;
-    DevBuf eqL(((size_t)1 << s_left) * 32), eqR(((size_t)1 << s_right) * 32);
-    fv_eq_evals(*L.c, field, r, (uint32_t)s_left, flags, (uint32_t*)eqL.p);
-    fv_eq_evals(*L.c, field, (const uint8_t*)r + 32 * s_left, (uint32_t)s_right, flags, (uint32_t*)eqR.p);
-    const void* dz = z;
-    DevBuf zbuf((flags & NMX_SCALARS_DEVICE) ? 1 : len * 32);
-    if (!(flags & NMX_SCALARS_DEVICE)) {
-      HIPCHK(hipMemcpyAsync(zbuf.p, z, len * 32, hipMemcpyHostToDevice, L.c->stream));
-      dz = zbuf.p;
-    }
-    uint8_t two[64];
-    // sum_id z[id] * eqL[id >> s_right] * eqR[id & (2^s_right - 1)]: the mode-1 sum over "half" = len
-    fv_eq_sums(*L.c, field, 1, dz, nullptr, nullptr, 2 * len, eqL.p, (size_t)1 << s_left, eqR.p, (size_t)1 << s_right,
-               (uint32_t)s_right, flags | NMX_SCALARS_DEVICE, two);
-    memcpy(out32, two, 32);
+    EvalScratch es(*L.c, field, r, ell, len, flags);
+    es.evaluate(*L.c, field, z, len, flags, out32);
   });
 }
 
@@ -657,23 +678,8 @@ int nmx_mle_multi_evaluate(int field, const void* const* zs, size_t k, size_t le
     for (size_t j = 0; j < k; j++) require(zs[j], NMX_E_ARG, "null polynomial");
     CtxLease L;
     // the two sqrt-size eq tables are built once and shared by all k polynomials (multilinear.rs:141-147)
-    const size_t s_right = ell / 2, s_left = ell - s_right;
-    DevBuf eqL(((size_t)1 << s_left) * 32), eqR(((size_t)1 << s_right) * 32);
-    fv_eq_evals(*L.c, field, r, (uint32_t)s_left, flags, (uint32_t*)eqL.p);
-    fv_eq_evals(*L.c, field, (const uint8_t*)r + 32 * s_left, (uint32_t)s_right, flags, (uint32_t*)eqR.p);
-    const bool dev = flags & NMX_SCALARS_DEVICE;
-    DevBuf zbuf(dev ? 1 : len * 32);
-    for (size_t j = 0; j < k; j++) {
-      const void* dz = zs[j];
-      if (!dev) {
-        HIPCHK(hipMemcpyAsync(zbuf.p, zs[j], len * 32, hipMemcpyHostToDevice, L.c->stream));
-        dz = zbuf.p;
-      }
-      uint8_t two[64];
-      fv_eq_sums(*L.c, field, 1, dz, nullptr, nullptr, 2 * len, eqL.p, (size_t)1 << s_left, eqR.p,
-                 (size_t)1 << s_right, (uint32_t)s_right, flags | NMX_SCALARS_DEVICE, two);
-      memcpy(out + 32 * j, two, 32);
-    }
+    EvalScratch es(*L.c, field, r, ell, len, flags);
+    for (size_t j = 0; j < k; j++) es.evaluate(*L.c, field, zs[j], len, flags, out + 32 * j);
   });
 }
 

@@ -62,6 +62,8 @@ struct Ctx {
   hipStream_t stream = nullptr;
   char* arena = nullptr;
   size_t cap = 0;
+  char* aux = nullptr;  // second, small arena: data that must outlive calls which re-carve `arena` (eq tables)
+  size_t aux_cap = 0;
   hipEvent_t ev[kMaxMarks];
   bool have_ev = false;
 };
@@ -97,6 +99,7 @@ extern Global G;                 // capi.hip
 void prof_store(const float* ms, int n);   // last call's stage times of this thread (capi.hip)
 void prof_add_tail(float ms);
 void arena_reserve(Ctx& c, size_t bytes);  // capi.hip
+void aux_reserve(Ctx& c, size_t bytes);    // capi.hip
 // rocPRIM radix sort of (key, value) pairs, its own TU (sort.hip).  tmp == nullptr: size query.
 void device_sort_pairs(void* tmp, size_t& tmp_bytes, uint32_t* k_in, uint32_t* k_out, uint32_t* v_in,
                        uint32_t* v_out, size_t total, uint32_t bits, hipStream_t stream);
