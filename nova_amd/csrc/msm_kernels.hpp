@@ -276,20 +276,21 @@ template <int FID> struct AccumFn {
   NMX_HD XYZZ<FID> run(uint32_t b, uint32_t len) const {
     XYZZ<FID> acc = XYZZ<FID>::identity();
     if (len == 0) return acc;
-    // software pipeline: the gather of point j+1 (64 B from a random row of a table that can be GiBs) is in
-    // flight while point j is being added (~6000 VALU cycles)
+    // software pipeline, two stages: the index of point j+2 and the gather of point j+1 (64 B from a random row of a
+    // table that can be GiBs) are in flight while point j is being added (~6000 VALU cycles); the gather never
+    // waits for its own index load
     uint32_t v = vals[b];
+    uint32_t vn = len > 1 ? vals[b + 1] : v;
     AffineW cur = bases[v & 0x7fffffffu];
     for (uint32_t j = 0; j < len; j++) {
-      uint32_t vn = v;
+      uint32_t vnn = vn;
       AffineW nxt = cur;
-      if (j + 1 < len) {
-        vn = vals[b + j + 1];
-        nxt = bases[vn & 0x7fffffffu];
-      }
+      if (j + 1 < len) nxt = bases[vn & 0x7fffffffu];
+      if (j + 2 < len) vnn = vals[b + j + 2];
       acc.add_affine(Affine<FID>::load(cur), (v >> 31) != 0);  // identity bases never get here (trash key)
       cur = nxt;
       v = vn;
+      vn = vnn;
     }
     return acc;
   }
