@@ -251,9 +251,10 @@ struct ExpandFn {
     for (uint32_t h = tid / lanes; h < nh; h += groups) {
       const HeavyRec r = heavy[h];
       const uint32_t b0 = start[r.bucket], s = end[r.bucket] - b0;
+      // equal shares, not lmax-sized chunks plus a short remainder: the lanes of a wave finish together
       for (uint32_t t = j; t < r.cnt; t += lanes) {
-        const uint32_t b = t * sh.lmax;
-        extra[r.off + t] = TaskRec{b0 + b, s - b < sh.lmax ? s - b : sh.lmax};
+        const uint32_t lo = (uint32_t)(((uint64_t)t * s) / r.cnt), hi = (uint32_t)(((uint64_t)(t + 1) * s) / r.cnt);
+        extra[r.off + t] = TaskRec{b0 + lo, hi - lo};
       }
     }
   }
