@@ -28,7 +28,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 
 BYTES_PER_PAIR = 96            # 32 B scalar + 64 B affine base, each read once
 STAGES = ["digits", "sort", "bounds_plan", "accum", "fold", "reduce", "tail"]
 MAD_PEAK_T = 28.8              # measured v_mad_u64_u32 rate, T/s (bench/ubench.hip)
-MADS_PER_MADD = 1305           # 6 x 162 + 2 x 126 + 243 multiply-adds per XYZZ mixed addition (curve.hpp)
+# multiply-adds per XYZZ mixed addition (curve.hpp add_affine: 5 products, 2 squarings, 1 two-product sum) by base
+# field: BN254 Fq / Fr 5 x 162 + 2 x 126 + 243; the Pasta moduli have three zero limbs of nine, whose reduction
+# terms are dropped at compile time: 5 x 135 + 2 x 99 + 216
+MADS_PER_MADD_BY_CURVE = {0: 1305, 1: 1305, 2: 1089, 3: 1089}
 
 
 def madds_per_launch(n, args):
@@ -150,6 +153,7 @@ def main():
         dt = float(tmax.item())
 
     out = None
+    MADS_PER_MADD = MADS_PER_MADD_BY_CURVE[cid]
     if rank == 0:
         stage_ms = stage_sum / max(args.steps, 1)
         accum_ms = float(stage_ms[STAGES.index("accum")])

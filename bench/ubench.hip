@@ -138,16 +138,6 @@ template <int FID> __global__ __launch_bounds__(256) void k_modmul(uint32_t* io,
   }
   (x + y).norm().canon().to_words(io + 8 * t);
 }
-// the chained-asm form used by the mixed addition (fp.hpp mulc)
-template <int FID> __global__ __launch_bounds__(256) void k_modmulc(uint32_t* io, int iters) {
-  int t = blockIdx.x * 256 + threadIdx.x;
-  Fp<FID> x = Fp<FID>::from_words(io + 8 * t), y = Fp<FID>::from_words(io + 8 * t + 8);
-  for (int i = 0; i < iters; i++) {
-    x = Fp<FID>::mulc(x, y);
-    y = Fp<FID>::mulc(y, x);
-  }
-  (x + y).norm().canon().to_words(io + 8 * t);
-}
 template <int FID> __global__ __launch_bounds__(256) void k_modsqr(uint32_t* io, int iters) {
   int t = blockIdx.x * 256 + threadIdx.x;
   Fp<FID> x = Fp<FID>::from_words(io + 8 * t), y = Fp<FID>::from_words(io + 8 * t + 8);
@@ -234,10 +224,6 @@ int main() {
   const double mm = (double)threads * it * 2;
   ms = time_ms([&] { k_modmul<0><<<blocks, 256>>>((uint32_t*)buf, it); });
   printf("{\"ubench\": \"modmul_9x29 bn254_fq\", \"Gmodmul_s\": %.2f}\n", mm / ms * 1e-6);
-  ms = time_ms([&] { k_modmulc<0><<<blocks, 256>>>((uint32_t*)buf, it); });
-  printf("{\"ubench\": \"modmul_9x29 bn254_fq, chained asm\", \"Gmodmul_s\": %.2f}\n", mm / ms * 1e-6);
-  ms = time_ms([&] { k_modmulc<2><<<blocks, 256>>>((uint32_t*)buf, it); });
-  printf("{\"ubench\": \"modmul_9x29 pasta_fp, chained asm\", \"Gmodmul_s\": %.2f}\n", mm / ms * 1e-6);
   ms = time_ms([&] { k_modsqr<0><<<blocks, 256>>>((uint32_t*)buf, it); });
   printf("{\"ubench\": \"modsqr_9x29 bn254_fq\", \"Gmodmul_s\": %.2f}\n", mm / ms * 1e-6);
   ms = time_ms([&] { k_modmul<2><<<blocks, 256>>>((uint32_t*)buf, it); });

@@ -119,8 +119,7 @@ template <int FID> struct XYZZ {
 #endif
   }
 
-  // madd-2008-s (msm.rs:129-165): this += (px, py), the affine operand non-identity.  The accumulate kernel's inner
-  // loop: products in their chained form (fp.hpp mad_vv).
+  // madd-2008-s (msm.rs:129-165): this += (px, py), the affine operand non-identity.
   // px canonical (< p); py < 2p normalized (a canonical y, or 2p - y for a negated point).
   NMX_HD void add_affine(const F& px, const F& py) {
     if (is_identity()) {
@@ -130,8 +129,8 @@ template <int FID> struct XYZZ {
       zzz = F::one();
       return;
     }
-    F u2 = F::mulc(px, zz);                        //  1 + 1.2/127     < 1.01
-    F s2 = F::mulc(py, zzz);                       //  1 + 2.4/127     < 1.02
+    F u2 = px * zz;                                //  1 + 1.2/127     < 1.01
+    F s2 = py * zzz;                               //  1 + 2.4/127     < 1.02
     F d = F::sub8(u2, x).norm();                   //  in (2.7, 9.01)             [x < 5.3 < 8]
     if (d.maybe_zero_mod_p()) {                    //  taken with probability 2^-29 unless u2 == x
       if (F::eq_mod_p(u2, x)) {
@@ -143,18 +142,18 @@ template <int FID> struct XYZZ {
       }
     }
     F r = F::sub4(s2, y).norm();                   //  1.02 + 4        < 5.02     [y < 3.5 < 4]
-    F pp = d.sqrc();                               //  1 + 81.2/127    < 1.64
-    F ppp = F::mulc(d, pp);                        //  1 + 14.8/127    < 1.12
-    F q = F::mulc(x, pp);                          //  1 + 8.7/127     < 1.07
+    F pp = d.sqr();                                //  1 + 81.2/127    < 1.64
+    F ppp = d * pp;                                //  1 + 14.8/127    < 1.12
+    F q = x * pp;                                  //  1 + 8.7/127     < 1.07
     F t = (ppp + q.dbl()).norm();                  //  3.26
-    F x3 = F::sub4(r.sqrc(), t).norm();            //  (1 + 25.2/127) + 4 < 5.2
+    F x3 = F::sub4(r.sqr(), t).norm();             //  (1 + 25.2/127) + 4 < 5.2
     F e = F::sub8(q, x3).norm();                   //  1.07 + 8        < 9.07
     F ny = F::sub4(F::zero(), y);                  //  4p - y in (0.5, 4], limbs < 2^31 (left un-normalized)
-    F y3 = F::mul_addc(r, e, ppp, ny);             //  r*e - y*ppp:  1 + (45.6 + 4.5)/127 < 1.4  [one reduction]
+    F y3 = F::mul_add(r, e, ppp, ny);              //  r*e - y*ppp:  1 + (45.6 + 4.5)/127 < 1.4  [one reduction]
     x = x3;
     y = y3;
-    zz = F::mulc(zz, pp);                          //  1 + 1.97/127    < 1.02
-    zzz = F::mulc(zzz, ppp);                       //  < 1.02
+    zz = zz * pp;                                  //  1 + 1.97/127    < 1.02
+    zzz = zzz * ppp;                               //  < 1.02
 #ifdef NMX_BOUND_CHECKS
     check();
 #endif
