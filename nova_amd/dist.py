@@ -15,19 +15,30 @@ def shard_range(n, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+_BUFFERS = {}  # (device, world) -> (send, recv): the exchange happens once per MSM, so its buffers are kept
+
+
 def combine_partials(group, partial128, pg=None, device=None):
     """all_gather this rank's 128-byte partial (an NMX_OUT_PARTIAL result) and sum all of them.
     Works on any torch.distributed backend: 'nccl' (= RCCL, CUDA tensors) or 'gloo' (CPU tensors, tests)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(pg)
+    nccl = dist.get_backend(pg) == "nccl"
     if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(pg) == "nccl" else torch.device("cpu")
-    mine = torch.frombuffer(bytearray(partial128), dtype=torch.uint8).to(device)
-    assert mine.numel() == 128
-    gathered = [torch.zeros(128, dtype=torch.uint8, device=device) for _ in range(world)]
-    dist.all_gather(gathered, mine, group=pg)
-    return group.point_sum(np.ascontiguousarray(torch.stack(gathered).cpu().numpy()))
+        device = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
+    assert len(partial128) == 128
+    key = (str(device), world)
+    if key not in _BUFFERS:
+        _BUFFERS[key] = (torch.zeros(128, dtype=torch.uint8, device=device),
+                         torch.zeros(128 * world, dtype=torch.uint8, device=device))
+    send, recv = _BUFFERS[key]
+    send.copy_(torch.frombuffer(bytearray(partial128), dtype=torch.uint8))
+    if nccl:
+        dist.all_gather_into_tensor(recv, send, group=pg)  # one RCCL call on one flat buffer
+    else:
+        dist.all_gather(list(recv.view(world, 128).unbind(0)), send, group=pg)
+    return group.point_sum(np.ascontiguousarray(recv.cpu().numpy().reshape(world, 128)))
 
 
 def sharded_msm(group, ck_shard, scalars_shard, pg=None, mont=False):
