@@ -82,8 +82,11 @@ inline MsmShape make_shape(uint32_t n, uint32_t bits, uint32_t force_c, uint32_t
   sh.nbuckets = sh.WB * sh.M;
   sh.total = n * sh.W;
   if (pre_c) {
-    sh.lmax = 24;  // every bucket collects ~W*n/M points: equal 24-point tasks, perfectly balanced lanes
-                   // (measured sweep 16..64 at 2^20: 24 is the minimum of accumulate + fold)
+    // every bucket collects ~W*n/M points, split into equal tasks: shorter tasks make the accumulate kernel faster
+    // (more, shorter waves: smaller tails) and the folds slower.  Measured sweeps 10..64
+    // (profiles/r01_msm_2p20/lmax_sweep.txt): 24 is the minimum of accumulate + fold for the c <= 16 tables
+    // (512 points per bucket at 2^20), 16 for the c = 20 tables (~100 points per bucket)
+    sh.lmax = pre_c >= 18 ? 16 : 24;
   } else {
     uint32_t avg = n / sh.M;
     sh.lmax = 4 * avg < 32 ? 32 : 4 * avg;
