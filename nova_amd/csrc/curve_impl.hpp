@@ -94,6 +94,7 @@ static XYZZ<CurveT<CID>::BF> run_msm(Ctx& c, const void* d_bases, size_t n, cons
   a.u64_bits = mc.u64_mode ? mc.u64_bits : 0u;
   a.force_c = G.force_c;
   a.force_lmax = G.force_lmax;
+  a.force_fold_t = G.force_fold_t;
   a.pre_stride = mc.pre_stride;
   a.pre_offset = mc.pre_offset;
   a.pre_c = mc.pre_c;

@@ -17,6 +17,7 @@ struct MsmArgs {
   uint32_t u64_bits;   // 0 => field scalars
   uint32_t force_c;    // 0 => heuristic
   uint32_t force_lmax = 0;  // 0 => heuristic (tuning knob: NMX_TUNE_LMAX)
+  uint32_t force_fold_t = 0;  // 0 => heuristic (tuning knob: NMX_TUNE_FOLD_T; 1 = no middle fold pass)
   // precomputed-table mode (key registered with NMX_BASES_PRECOMPUTE): `bases` points at T_0[0], tables are
   // pre_stride apart, this call uses entries [pre_offset, pre_offset + n) of each, window width pre_c
   uint32_t pre_stride = 0, pre_offset = 0, pre_c = 0;
@@ -169,10 +170,13 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
     const uint32_t hb = heavy_cap < sh.nbuckets ? heavy_cap : sh.nbuckets;  // upper bound on heavy buckets
     // typical task count per bucket decides the last split: ~22 partials fold fastest as 4 lanes x 6 then 1 x 4
     const uint32_t typical = (uint32_t)(total / ((size_t)sh.nbuckets * sh.lmax));
-    const uint32_t Ts[6] = {32768, 4096, 512, 64, typical > 32 ? 8u : 4u, 1};
+    uint32_t mid = typical > 32 ? 8u : 4u;
+    if (a.force_fold_t) mid = a.force_fold_t == 1 ? 64 : a.force_fold_t;  // tuning: 1 = no middle pass
+    const uint32_t Ts[6] = {32768, 4096, 512, 64, mid, 1};
     for (int p = 0; p < 6; p++) {
       const uint32_t T = Ts[p];
       const uint32_t cap = p == 0 ? 0xffffffffu : Ts[p - 1];
+      if (p == 4 && T == 64) continue;
       if ((uint64_t)T * sh.lmax > total && T != 1) continue;  // no bucket can have more than T tasks
       // buckets with more than T tasks number at most total / (T * lmax): ~2^18 lanes per pass cover them in a few
       // sweeps, and a pass nobody needs costs one small empty launch

@@ -93,6 +93,7 @@ struct Global {
   bool profiling = false;
   uint32_t force_c = 0;
   uint32_t force_lmax = 0;  // env NMX_TUNE_LMAX (tuning only)
+  uint32_t force_fold_t = 0;  // env NMX_TUNE_FOLD_T (tuning only)
   uint32_t no_quad_accum = 0;  // env NMX_TUNE_NO_QUAD_ACCUM (tuning only)
 };
 extern Global G;                 // capi.hip

@@ -75,6 +75,32 @@ def test_identity_bases_and_duplicates(nmx, c):
     assert as_pair(g.vartime_multiscalar_mul(sc, dup)) == (bytes(64), 1)
 
 
+@pytest.mark.parametrize("n", [65, 6001, 100001])
+def test_cancelling_pairs_on_repeated_bases(nmx, n):
+    """Every bucket branch of msm.rs:106-113,148-155 at once, in the quad accumulate (small n), the table path and
+    the plain accumulate: three distinct points repeated, consecutive pairs (k, P), (r - k, P) cancel (P == -Q), equal
+    scalars on the same point double (P == Q); one unpaired term keeps the result off the identity."""
+    c = R.BN254_G1
+    g = nmx.DlogGroup(c.cid)
+    pts = cref.sequential_bases(c, 9, 3)
+    idx = (np.arange(n) // 2) % 3
+    bases = np.ascontiguousarray(pts[idx])
+    k = util.random_scalars(c.cid, n, seed=5).copy()
+    ki = [int.from_bytes(bytes(row), "little") for row in k]
+    for i in range(1, n - 1, 2):
+        k[i] = util.int_to_le32((c.r - ki[i - 1]) % c.r)
+    exp = cref.msm(c.cid, k, bases, n)
+    assert exp[1] == 0
+    assert as_pair(g.vartime_multiscalar_mul(k, bases)) == exp
+    ck = nmx.CommitmentKey.from_host(c.cid, bases)            # registered: window tables when n >= 4096
+    assert as_pair(g.vartime_multiscalar_mul(k, ck)) == exp
+    k[n - 1] = util.int_to_le32(0)                             # now everything cancels
+    assert as_pair(g.vartime_multiscalar_mul(k, ck)) == (bytes(64), 1)
+    same = np.repeat(k[:1], n, axis=0)                         # one scalar on three repeated points: doublings
+    assert as_pair(g.vartime_multiscalar_mul(same, ck)) == cref.msm(c.cid, same, bases, n)
+    ck.close()
+
+
 @pytest.mark.parametrize("bits", [0, 1, 4, 8, 10, 16, 20, 32, 40, 64])
 def test_msm_small(nmx, bits):
     """msm.rs:751-784 (test_msm_ux) through vartime_multiscalar_mul_small[_with_max_num_bits]."""
