@@ -42,6 +42,24 @@ class CommitmentKey {
     uint32_t flags = (mont ? NMX_BASES_MONT : 0u) | (precompute ? NMX_BASES_PRECOMPUTE : 0u);
     check(nmx_bases_register(curve, ck.data(), ck.size(), flags, &handle_));
   }
+  // `CommitmentEngineTrait::load_setup` (src/traits/commitment.rs:64-76).  HyperKZG (hyperkzg.rs:658-674): the first
+  // n.next_power_of_two() tauG1 points of a .ptau file; `h` is derived from the label on the reference side and tau_H
+  // (G2) stays with the host, so the caller supplies h.  Pedersen (pedersen.rs:318-340): "PEDERSEN_KEY" | h | ck.
+  // Points are validated as `read_points` does (ptau.rs:372-391); errors throw Error with NMX_E_IO / _FORMAT / _POINT.
+  static CommitmentKey load_ptau(int curve, const std::string& path, size_t n, const Affine& h, bool precompute = true) {
+    CommitmentKey k(curve, next_power_of_two(n), h);
+    check(nmx_bases_register_ptau(curve, path.c_str(), k.n_, 2, precompute ? NMX_BASES_PRECOMPUTE : 0u, &k.handle_));
+    return k;
+  }
+  static CommitmentKey load_keyfile(int curve, const std::string& path, size_t n, bool precompute = true) {
+    CommitmentKey k(curve, next_power_of_two(n), Affine{});
+    check(nmx_bases_register_keyfile(curve, path.c_str(), k.n_, precompute ? NMX_BASES_PRECOMPUTE : 0u, &k.handle_,
+                                     k.h_.data()));
+    return k;
+  }
+  CommitmentKey(CommitmentKey&& o) noexcept : curve_(o.curve_), n_(o.n_), h_(o.h_), mont_(o.mont_), handle_(o.handle_) {
+    o.handle_ = 0;
+  }
   CommitmentKey(const CommitmentKey&) = delete;
   CommitmentKey& operator=(const CommitmentKey&) = delete;
   ~CommitmentKey() {
@@ -54,6 +72,12 @@ class CommitmentKey {
   bool mont() const { return mont_; }
 
  private:
+  CommitmentKey(int curve, size_t n, const Affine& h) : curve_(curve), n_(n), h_(h), mont_(false) {}
+  static size_t next_power_of_two(size_t n) {
+    size_t p = 1;
+    while (p < n) p <<= 1;
+    return p;
+  }
   int curve_;
   size_t n_;
   Affine h_;

@@ -2,8 +2,10 @@
 // CommitmentEngine) against the oracle (libnova_ref.so).  Reads like the reference's blitzar tests
 // (/root/reference/src/provider/blitzar.rs:48-214).  Exit code 0 = pass, 3 = no GPU (NMX_E_NO_DEVICE raised), else fail.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <random>
+#include <string>
 
 #include "../../include/nova_mi355x.hpp"
 
@@ -52,6 +54,18 @@ template <int CURVE> static int run(const uint8_t gen[64], int topmask) {
     ref_msm(CURVE, sc[0].data(), bases[0].data(), vs[j].size(), exp.xy.data(), &inf);
     exp.is_inf = inf;
     if (!(res[j] == exp)) return 1;
+  }
+  // load_setup from a PEDERSEN_KEY file written by the harness: h = bases[n], ck = the same sequence (pedersen.rs:318-340)
+  if (const char* dir = getenv("NMX_TEST_KEYDIR")) {
+    CommitmentKey fk = CommitmentKey::load_keyfile(CURVE, std::string(dir) + "/curve" + std::to_string(CURVE) + ".key", n);
+    if (fk.len() != 128 || !(fk.h() == bases[n])) return 1;
+    if (!(CommitmentEngine<CURVE>::commit(fk, sc, r) == got)) return 1;
+    try {
+      CommitmentKey::load_keyfile(CURVE, std::string(dir) + "/missing.key", n);
+      return 1;
+    } catch (const Error& e) {
+      if (e.code != NMX_E_IO) return 1;
+    }
   }
   // assert!(ck.ck.len() >= v.len())
   try {

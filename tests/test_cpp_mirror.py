@@ -32,7 +32,13 @@ def test_cpp_mirror_compiles_and_refuses_without_gpu():
 
 
 @pytest.mark.gpu
-def test_cpp_mirror_on_gpu():
+def test_cpp_mirror_on_gpu(tmp_path):
+    from oracle import keyfiles as K
+    from oracle import pyref as R
     b = BIN if os.path.exists(BIN) else build()
-    r = subprocess.run([b], capture_output=True, text=True)
+    # key files for the load_setup part of the test: ck = P_{12345 + i}, i < 128, h = P_{12345 + 100}
+    for c in (R.BN254_G1, R.PALLAS):
+        pts = R.sequential_bases(c, 12345, 128)
+        (tmp_path / f"curve{c.cid}.key").write_bytes(K.write_pedersen_key(c, pts[100], pts))
+    r = subprocess.run([b], capture_output=True, text=True, env=dict(os.environ, NMX_TEST_KEYDIR=str(tmp_path)))
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
