@@ -164,14 +164,15 @@ class DlogGroup:
         self.curve = curve
 
     # -- vartime_multiscalar_mul (traits.rs:79; msm(), src/provider/msm.rs:225) -------------------------
-    def vartime_multiscalar_mul(self, scalars, bases, mont=False, partial=False):
+    def vartime_multiscalar_mul(self, scalars, bases, mont=False, partial=False, offset=0):
+        """offset: with a CommitmentKey, use bases[offset .. offset + n) of it (`&ck.ck[offset..][..n]`)."""
         sp, n, dev, _k = _scalar_arg(scalars, 32)
         flags = dev | (L.SCALARS_MONT if mont else 0) | (L.OUT_PARTIAL if partial else 0)
         out = _Out(partial=partial)
         if isinstance(bases, CommitmentKey):
             assert bases.curve == self.curve
-            assert n <= bases.n, "assert_eq!(coeffs.len(), bases.len()) / ck.len() >= v.len()"
-            _check(L.lib().nmx_msm_handle(bases.handle, 0, sp, n, flags, *out.p))
+            assert offset + n <= bases.n, "assert_eq!(coeffs.len(), bases.len()) / ck.len() >= v.len()"
+            _check(L.lib().nmx_msm_handle(bases.handle, offset, sp, n, flags, *out.p))
         else:
             b = _host_u8(bases, 64)
             assert b.size // 64 == n, "assert_eq!(coeffs.len(), bases.len())  (msm.rs:226)"
