@@ -248,3 +248,59 @@ def test_lincomb_multi_evaluate_spmv_pair(nmx, fid):
         assert (o1.cpu().numpy().tobytes(), o2.cpu().numpy().tobytes()) == (e1, e2)
         assert m.multiply_vec(z1).tobytes() == e1
         m.close()
+
+
+def test_concurrent_callers_mixed_entry_points(nmx):
+    """The reference calls these loops from rayon workers: every entry point must be re-entrant (one context --
+    stream, workspace, aux arena -- per in-flight call).  Six threads interleave MSMs and field-vector calls."""
+    import threading
+    import nova_amd
+    from nova_amd import fieldvec as fv
+    fid, cid = 1, 0
+    n, ell = 1 << 13, 13
+    a, b = C.edge_vectors(fid, n, 1), C.edge_vectors(fid, n, 2)
+    r = C.rand_vec(fid, 1, 9)
+    pt = C.rand_vec(fid, ell, 3)
+    ip, ix, d = C.random_csr(fid, 3000, n, 9)
+    mat = fv.SparseMatrix(fid, ip, ix, d, n)
+    ck = nova_amd.CommitmentKey.generate(cid, n, k0=3)
+    key = ck.read(0, n)
+    g = nova_amd.DlogGroup(cid)
+    exp = {
+        "axpy": cref.field_axpy(fid, a, b, r, n),
+        "mle": cref.mle_evaluate(fid, a, ell, pt),
+        "horner": cref.suffix_horner(fid, b, n, r),
+        "spmv": cref.spmv(fid, ip, ix, d, 3000, a),
+        "lin": cref.lincomb_powers(fid, [a.tobytes(), b.tobytes(), a[:100].tobytes()], r, n),
+        "sums": cref.sumcheck_plain_sums(fid, 4, a, b, a, n),
+        "msm": cref.msm(cid, a, key, n),
+    }
+    calls = {
+        "axpy": lambda: fv.axpy(fid, a, b, r).tobytes(),
+        "mle": lambda: fv.mle_evaluate(fid, a, pt),
+        "horner": lambda: fv.suffix_horner(fid, b, r).tobytes(),
+        "spmv": lambda: mat.multiply_vec(a).tobytes(),
+        "lin": lambda: fv.lincomb_powers(fid, [a, b, a[:100]], r).tobytes(),
+        "sums": lambda: fv.sumcheck_plain_sums(fid, 4, a, b, a),
+        "msm": lambda: (lambda p: (p.xy, int(p.is_inf)))(g.vartime_multiscalar_mul(a, ck)),
+    }
+    errors = []
+
+    def worker(seed):
+        names = list(calls)
+        for it in range(12):
+            nm = names[(seed * 5 + it * 3) % len(names)]
+            try:
+                if calls[nm]() != exp[nm]:
+                    errors.append((seed, it, nm, "mismatch"))
+            except Exception as e:  # noqa: BLE001
+                errors.append((seed, it, nm, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(s,)) for s in range(6)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    mat.close()
+    ck.close()
+    assert not errors, errors[:5]
