@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--iters", type=int, default=65536, help="prove_step_replay: MinRoot iterations per step")
-    ap.add_argument("--workload", default="msm", choices=["msm", "axpy", "cross_term", "bind", "sumcheck3", "quad_prod", "lincomb8", "horner", "mle_eval", "spmv", "prove_step_replay", "hyperkzg_replay"],
+    ap.add_argument("--workload", default="msm", choices=["msm", "axpy", "cross_term", "bind", "sumcheck3", "round3", "quad_prod", "lincomb8", "horner", "mle_eval", "spmv", "prove_step_replay", "hyperkzg_replay"],
                     help="msm = the headline (default); the others time one HBM-bound field-vector kernel of "
                          "SURVEY.md 8(f) at 2^log2n elements per GPU")
     args = ap.parse_args()
@@ -438,6 +438,8 @@ def field_workload(args, world, rank, L, torch, dist):
       cross_term  commit_T's T                           r1cs/mod.rs:614-620
       bind        MLE bind_poly_var_top                  spartan/polys/multilinear.rs:65-84
       sumcheck3   eq-factored cubic round sums           spartan/sumcheck.rs:900-958
+      round3      one whole cubic round fused: bind A, B, C with the challenge + the next round's sums
+                  (nmx_sumcheck_bind_eq_sums; the reference: sumcheck.rs:535-545 then :900-958)
       quad_prod   plain quadratic round sums             spartan/sumcheck.rs:163-186
       lincomb8    PolyEvalWitness::batch of 8 polys      spartan/mod.rs:223-277
       horner      poly_eval + div_by_monomial            provider/hyperkzg.rs:946-1020
@@ -451,7 +453,7 @@ def field_workload(args, world, rank, L, torch, dist):
     cid = args.curve
     fid = fv.SCALAR_FIELD_OF_CURVE[cid]
     wl = args.workload
-    nvec = {"axpy": 2, "cross_term": 4, "bind": 1, "sumcheck3": 3, "quad_prod": 2, "lincomb8": 8, "horner": 1,
+    nvec = {"axpy": 2, "cross_term": 4, "bind": 1, "sumcheck3": 3, "round3": 3, "quad_prod": 2, "lincomb8": 8, "horner": 1,
             "mle_eval": 1, "spmv": 1}[wl]
     host = [util.random_scalars(cid, n, seed=util.SEED + 7 * j + rank) for j in range(nvec)]
     dev = [torch.from_numpy(h).cuda() for h in host]
@@ -460,13 +462,19 @@ def field_workload(args, world, rank, L, torch, dist):
     # element; quad_prod: a0,a1,b0,b1 per index = 64 B per element; horner: read f, write out = 64 B;
     # lincomb8: 8 reads + 1 write; mle_eval: one read; spmv: per row 3 x (32 B value + 4 B index + 32 B gathered z)
     # + 8 B indptr + 32 B result)
-    bytes_per_elem = {"axpy": 96, "cross_term": 160, "bind": 48, "sumcheck3": 80, "quad_prod": 64, "lincomb8": 288,
+    # round3: three tables read once (96 B per element) and their bound halves written (48 B)
+    bytes_per_elem = {"axpy": 96, "cross_term": 160, "bind": 48, "sumcheck3": 80, "round3": 144, "quad_prod": 64, "lincomb8": 288,
                       "horner": 64, "mle_eval": 32, "spmv": 3 * 68 + 40}[wl]
     shift = (args.log2n - 1) // 2
     eqR = eqL = mat = csr = None
     if wl == "sumcheck3":
         eqR = torch.from_numpy(util.random_scalars(cid, 1 << shift, seed=5)).cuda()
         eqL = torch.from_numpy(util.random_scalars(cid, (n // 2) >> shift, seed=6)).cuda()
+    if wl == "round3":  # the eq tables of the NEXT round (half length n / 4)
+        shift = (args.log2n - 2) // 2
+        eqR = torch.from_numpy(util.random_scalars(cid, 1 << shift, seed=5)).cuda()
+        eqL = torch.from_numpy(util.random_scalars(cid, (n // 4) >> shift, seed=6)).cuda()
+        work = [torch.empty_like(t) for t in dev]
     if wl == "mle_eval":
         point = util.random_scalars(cid, args.log2n, seed=8)
     if wl == "spmv":  # n rows x n columns, 3 random non-zeros per row (the minroot shape: 3 constraints per iteration)
@@ -484,6 +492,11 @@ def field_workload(args, world, rank, L, torch, dist):
             return fv.cross_term(fid, dev[0], dev[1], dev[2], dev[3], r)
         if wl == "sumcheck3":
             return fv.sumcheck_eq_sums(fid, 3, dev[0], dev[1], dev[2], eqR, eqL, shift)
+        if wl == "round3":  # binds in place: work on copies refreshed outside the kernel timing (hipEvents bracket the kernel)
+            for w, t in zip(work, dev):
+                w.copy_(t)
+            torch.cuda.synchronize()
+            return fv.sumcheck_bind_eq_sums(fid, 3, work[0], work[1], work[2], r, eqR, eqL, shift)[3]
         if wl == "quad_prod":
             return fv.sumcheck_plain_sums(fid, 1, dev[0], dev[1])
         if wl == "lincomb8":
@@ -504,6 +517,10 @@ def field_workload(args, world, rank, L, torch, dist):
             return cref.field_cross_term(fid, host[0][:m], host[1][:m], host[2][:m], host[3][:m], r, m), m
         if wl == "sumcheck3":
             return b"".join(cref.sumcheck_eq_sums(fid, 3, host[0], host[1], host[2], n, eqR.cpu().numpy(), eqL.cpu().numpy(), shift)), n
+        if wl == "round3":
+            bound = [cref.field_bind(fid, h, 0, n // 2, 1, r, n // 2) for h in host]
+            return b"".join(cref.sumcheck_eq_sums(fid, 3, bound[0], bound[1], bound[2], n // 2, eqR.cpu().numpy(),
+                                                  eqL.cpu().numpy(), shift)), n
         if wl == "quad_prod":
             return b"".join(cref.sumcheck_plain_sums(fid, 1, host[0], host[1], None, n)[:2]), n
         if wl == "lincomb8":

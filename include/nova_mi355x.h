@@ -182,6 +182,14 @@ int nmx_poly_fold_pairs(int field, const void* p, size_t len, const void* x, uin
  * from these sums and the claim stays on the caller's side (sumcheck.rs:686-753). */
 int nmx_sumcheck_eq_sums(int field, int mode, const void* A, const void* B, const void* C, size_t len, const void* eqL,
                          size_t n_eqL, const void* eqR, size_t n_eqR, uint32_t shift, uint32_t flags, uint8_t* out64);
+/* One whole prover round in a single pass over HBM-resident tables (NMX_SCALARS_DEVICE required): bind A, B, C with
+ * the round challenge r (bind_poly_var_top, src/spartan/polys/multilinear.rs:65-84, called at
+ * src/spartan/sumcheck.rs:535-545) AND return the NEXT round's sums (t_0, t_inf) over the bound tables, exactly what
+ * nmx_mle_bind_top x3 followed by nmx_sumcheck_eq_sums(mode, outA, outB, outC, len/2, ...) would give; the eq tables
+ * are the next round's.  outX may equal X (in place, as the reference binds).  len % 4 == 0. */
+int nmx_sumcheck_bind_eq_sums(int field, int mode, const void* A, const void* B, const void* C, size_t len, const void* r,
+                              const void* eqL, size_t n_eqL, const void* eqR, size_t n_eqR, uint32_t shift,
+                              uint32_t flags, void* outA, void* outB, void* outC, uint8_t* out64);
 /* The sums of one round of the sum-checks WITHOUT an eq factor, over id in [0, len/2), dX = x1 - x0, X(-1) = 2*x0 - x1:
  *   kind 1 (A, B)    quad_prod  out = (sum a0*b0,    sum dA*dB)                  src/spartan/sumcheck.rs:163-186
  *   kind 2 (A, B)    linear     out = (sum a0 - b0,  sum A(-1) - B(-1))          src/spartan/sumcheck.rs:353-378

@@ -571,6 +571,27 @@ int nmx_sumcheck_eq_sums(int field, int mode, const void* A, const void* B, cons
   });
 }
 
+int nmx_sumcheck_bind_eq_sums(int field, int mode, const void* A, const void* B, const void* C, size_t len, const void* r,
+                              const void* eqL, size_t n_eqL, const void* eqR, size_t n_eqR, uint32_t shift,
+                              uint32_t flags, void* outA, void* outB, void* outC, uint8_t* out64) {
+  return guarded([&] {
+    require(A && outA && r && eqR && out64, NMX_E_ARG, "null argument");
+    require(mode >= 1 && mode <= 3 && (mode < 2 || (B && outB)) && (mode < 3 || (C && outC)), NMX_E_ARG,
+            "missing input / output polynomial");
+    require(flags & NMX_SCALARS_DEVICE, NMX_E_ARG, "the fused round works on HBM-resident tables only");
+    require(len >= 4 && (len & 3) == 0 && len / 4 < (1ull << 31), NMX_E_ARG, "len must be a multiple of 4");
+    const size_t hq = len / 4;  // the next round's half length
+    if (eqL) {
+      require(shift < 32 && n_eqR == ((size_t)1 << shift) && ((hq - 1) >> shift) < n_eqL, NMX_E_ARG,
+              "eq tables do not cover the next round's index range");
+    } else {
+      require(n_eqR >= hq, NMX_E_ARG, "eq table shorter than the next round's half length");
+    }
+    CtxLease L;
+    fv_bind_eq_sums(*L.c, field, mode, A, B, C, len, r, eqL, n_eqL, eqR, n_eqR, shift, flags, outA, outB, outC, out64);
+  });
+}
+
 int nmx_sumcheck_plain_sums(int field, int kind, const void* A, const void* B, const void* C, size_t len, uint32_t flags,
                             uint8_t* out96) {
   return guarded([&] {

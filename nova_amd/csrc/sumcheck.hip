@@ -188,6 +188,147 @@ static void eq_sums_t(Ctx& c, const void* A, const void* B, const void* C, size_
   }
 }
 
+// ---- one whole prover round in one pass: bind with the challenge AND the next round's eq-factored sums --------------
+// The reference binds A, B, C with the round challenge (bind_poly_var_top, multilinear.rs:65-84, via
+// sumcheck.rs:535-545) and then, at the top of the next round, streams the bound tables again for the evaluation
+// points (sumcheck.rs:900-1075).  The bound values a lane has just computed ARE the next round's operands: with
+// hq = len/4, lane id binds X[id], X[id + hq] (from X[id + 2hq], X[id + 3hq]) and these are (x0, x1) of next-round
+// index id.  One pass reads every table once and writes the bound halves: 576 B per index for three tables instead
+// of 576 B (three binds) + 320 B (sums) -- the sums ride along on the multiplier while the pass waits for HBM.
+// Binding in place is safe: a lane reads exactly the two low-half elements it overwrites.
+template <int FID, int MODE>
+__global__ __launch_bounds__(256) void k_bind_eq_sums(const uint32_t* A, const uint32_t* B, const uint32_t* C,
+                                                      uint32_t* oA, uint32_t* oB, uint32_t* oC, Fp<FID> r,
+                                                      const uint32_t* eqL, const uint32_t* eqR, uint32_t shift,
+                                                      uint32_t mask, uint32_t hq, Fp<FID> fconst, uint32_t* partial) {
+  using F = Fp<FID>;
+  __shared__ uint32_t lds[9 * 256];
+  F s0 = F::zero(), s1 = F::zero();
+  uint32_t pending = 0;
+  auto bind2 = [&](const uint32_t* X, uint32_t* oX, uint32_t id, F& y0, F& y1) {
+    const F x00 = ldw<FID>(X, id), x01 = ldw<FID>(X, (size_t)id + hq);
+    const F x10 = ldw<FID>(X, (size_t)id + 2 * (size_t)hq), x11 = ldw<FID>(X, (size_t)id + 3 * (size_t)hq);
+    y0 = (x00 + r * F::sub2(x10, x00).norm()).norm().canon();   // lo + r * (hi - lo), as BindTopFn
+    y1 = (x01 + r * F::sub2(x11, x01).norm()).norm().canon();
+    y0.to_words(oX + 8 * (size_t)id);
+    y1.to_words(oX + 8 * ((size_t)id + hq));
+  };
+  for (uint32_t id = blockIdx.x * 256u + threadIdx.x; id < hq; id += gridDim.x * 256u) {
+    F a0, a1, b0, b1, c0, c1;
+    bind2(A, oA, id, a0, a1);
+    if (MODE >= 2) bind2(B, oB, id, b0, b1);
+    if (MODE == 3) bind2(C, oC, id, c0, c1);
+    F fac = ldw<FID>(eqR, eqL ? (id & mask) : id);
+    if (eqL) fac = ldw<FID>(eqL, id >> shift) * fac;
+    if (MODE == 1) {
+      s0 = s0 + a0 * fac;
+    } else {
+      const F c = MODE == 3 ? c0 * fconst : fconst;
+      const F e0 = F::sub2(a0 * b0, c).norm();
+      const F q = F::sub2(a1, a0).norm() * F::sub2(b1, b0).norm();
+      s0 = s0 + e0 * fac;
+      s1 = s1 + q * fac;
+    }
+    if (++pending == 6) {
+      s0 = s0.norm().canon();
+      s1 = s1.norm().canon();
+      pending = 0;
+    }
+  }
+  s0 = block_sum<FID>(s0.norm().canon(), lds);
+  if (MODE != 1) {
+    __syncthreads();
+    s1 = block_sum<FID>(s1.norm().canon(), lds);
+  }
+  if (threadIdx.x == 0) {
+    s0.to_words(partial + 16 * blockIdx.x);
+    s1.to_words(partial + 16 * blockIdx.x + 8);
+  }
+}
+
+template <int FID> static Fp<FID> challenge_internal(const void* r, bool mont) {
+  uint32_t w[8];
+  memcpy(w, r, 32);
+  require(Fp<FID>::words_lt_p(w), NMX_E_SCALAR_RANGE, "challenge >= field modulus");
+  Fp<FID> f = Fp<FID>::from_words(w);
+  return (mont ? f.mont256_to_internal() : f.to_internal()).canon();
+}
+
+template <int FID, int MODE>
+static void bind_eq_sums_t(Ctx& c, const void* A, const void* B, const void* C, size_t len, const void* r, const void* eqL,
+                           size_t nL, const void* eqR, size_t nR, uint32_t shift, uint32_t flags, void* oA, void* oB,
+                           void* oC, uint8_t* out) {
+  using F = Fp<FID>;
+  const bool mont = flags & NMX_SCALARS_MONT;
+  const uint32_t hq = (uint32_t)(len / 4);
+  const uint32_t want = (hq + 256 * 4 - 1) / (256 * 4);
+  const uint32_t blocks = want < 1 ? 1 : (want > 4096 ? 4096 : want);
+  auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  arena_reserve(c, pad((size_t)blocks * 64) + 64 + 512);
+  uint32_t* partial = (uint32_t*)c.arena;
+  uint32_t* dout = (uint32_t*)(c.arena + pad((size_t)blocks * 64));
+  F fconst = F::zero();
+  if (MODE == 3) {
+    if (mont) fconst = pow2_plain<FID>(256);
+    else fconst.l[0] = 1;
+  } else if (MODE == 2) {
+    F one_plain = F::zero();
+    one_plain.l[0] = 1;
+    fconst = mont ? pow2_plain<FID>(512 - 261) : one_plain.to_canonical();
+  }
+  const F ri = challenge_internal<FID>(r, mont);
+  const bool prof = G.profiling;
+  DeviceBackend be(c, false, prof);
+  be.mark("k");
+  const uint32_t mask = shift >= 32 ? 0xffffffffu : ((1u << shift) - 1u);
+  hipLaunchKernelGGL((k_bind_eq_sums<FID, MODE>), dim3(blocks), dim3(256), 0, c.stream, (const uint32_t*)A,
+                     (const uint32_t*)B, (const uint32_t*)C, (uint32_t*)oA, (uint32_t*)oB, (uint32_t*)oC, ri,
+                     (const uint32_t*)eqL, (const uint32_t*)eqR, shift, mask, hq, fconst, partial);
+  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL((k_sum_partials<FID>), dim3(1), dim3(256), 0, c.stream, partial, blocks, dout);
+  HIPCHK(hipGetLastError());
+  be.mark("end");
+  uint32_t res[16];
+  HIPCHK(hipMemcpyAsync(res, dout, 64, hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipStreamSynchronize(c.stream));
+  if (prof && be.nmarks == 2) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
+    prof_store(&ms, 1);
+  }
+  const uint32_t k = (MODE == 1 ? 2u : 3u) + (eqL ? 1u : 0u);  // as eq_sums_t
+  const uint32_t e = 261u * k - (mont ? 256u * (k - 1) : 0u);
+  F corr = pow2_plain<FID>(e);
+  for (int j = 0; j < 2; j++) {
+    F v = F::from_words(res + 8 * j) * corr;
+    uint32_t w[8];
+    v.canon().to_words(w);
+    memcpy(out + 32 * j, w, 32);
+  }
+  (void)nL;
+  (void)nR;
+}
+
+void fv_bind_eq_sums(Ctx& c, int field, int mode, const void* A, const void* B, const void* C, size_t len, const void* r,
+                     const void* eqL, size_t nL, const void* eqR, size_t nR, uint32_t shift, uint32_t flags, void* oA,
+                     void* oB, void* oC, uint8_t* out) {
+#define BES(FID)                                                                                                    \
+  switch (mode) {                                                                                                   \
+    case 1: bind_eq_sums_t<FID, 1>(c, A, B, C, len, r, eqL, nL, eqR, nR, shift, flags, oA, oB, oC, out); return;    \
+    case 2: bind_eq_sums_t<FID, 2>(c, A, B, C, len, r, eqL, nL, eqR, nR, shift, flags, oA, oB, oC, out); return;    \
+    case 3: bind_eq_sums_t<FID, 3>(c, A, B, C, len, r, eqL, nL, eqR, nR, shift, flags, oA, oB, oC, out); return;    \
+    default: throw Fail{NMX_E_ARG, "bad sum-check mode"};                                                           \
+  }
+  switch (field) {
+    case 0: BES(0)
+    case 1: BES(1)
+    case 2: BES(2)
+    case 3: BES(3)
+    default: throw Fail{NMX_E_ARG, "bad field id"};
+  }
+#undef BES
+}
+
 // ---- sums without an eq factor (the classic sum-check rounds) ------------------------------------------------------
 //   kind 1  quad_prod   (sum a0*b0,        sum dA*dB)                          sumcheck.rs:163-186
 //   kind 2  linear      (sum a0-b0,        sum A(-1)-B(-1))                    sumcheck.rs:353-378

@@ -136,6 +136,26 @@ def sumcheck_eq_sums(field, mode, A, B, C, eq_right, eq_left=None, shift=0, mont
     return out[:32].tobytes(), out[32:].tobytes()
 
 
+def sumcheck_bind_eq_sums(field, mode, A, B, C, r, eq_right, eq_left=None, shift=0, mont=False):
+    """One prover round fused (nmx_sumcheck_bind_eq_sums): binds the HBM-resident tables A, B, C IN PLACE with the
+    challenge r and returns (A', B', C', (t_0, t_inf)) where the sums are the next round's, over the bound tables."""
+    parts = [_vec(x) if x is not None else (None, 0, True, None) for x in (A, B, C)]
+    n = parts[0][1]
+    assert all(pt[2] for pt in parts), "HBM-resident tables only"
+    assert n >= 4 and n % 4 == 0
+    pr, nr, _d, _kr = _vec(eq_right)
+    pl, nl = None, 0
+    if eq_left is not None:
+        pl, nl, _d, _kl = _vec(eq_left)
+    rr = _chal(r)
+    out = np.zeros(64, dtype=np.uint8)
+    _check(L.lib().nmx_sumcheck_bind_eq_sums(field, mode, parts[0][0], parts[1][0], parts[2][0], n, rr.ctypes.data, pl, nl,
+                                               pr, nr, shift, _flags(True, mont), parts[0][0], parts[1][0], parts[2][0],
+                                               out.ctypes.data))
+    half = lambda x: None if x is None else x.view(-1)[: (n // 2) * 32].view(n // 2, 32)
+    return half(A), half(B), half(C), (out[:32].tobytes(), out[32:].tobytes())
+
+
 def sumcheck_plain_sums(field, kind, A, B, C=None, mont=False):
     """Round sums of the sum-checks without an eq factor (src/spartan/sumcheck.rs): kind 1 compute_eval_points_quad_prod
     (:163-186), 2 ..._linear (:353-378), 3 ..._quadratic (:380-405), 4 ..._cubic (:407-443).  Returns a tuple of two

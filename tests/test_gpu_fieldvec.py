@@ -304,3 +304,57 @@ def test_concurrent_callers_mixed_entry_points(nmx):
     mat.close()
     ck.close()
     assert not errors, errors[:5]
+
+
+@pytest.mark.parametrize("fid", range(4))
+@pytest.mark.parametrize("logn", [2, 7, 13, 18])
+def test_sumcheck_fused_round(nmx, fid, logn):
+    """nmx_sumcheck_bind_eq_sums == bind_poly_var_top on A, B, C (multilinear.rs:65-84) followed by the next round's
+    evaluation_points_* sums (sumcheck.rs:900-1075): bound tables byte-equal, sums equal, all three modes, first- and
+    last-half eq forms, Montgomery layout; then a whole sum-check (every round fused) against the oracle's rounds."""
+    import torch
+    from nova_amd import fieldvec as fv
+    p = C.FIELDS[fid]
+    n = 1 << logn
+    hq = n // 4
+    shift = max(0, (logn - 2) // 2)
+    A, B, Cc = (C.edge_vectors(fid, n, s) if n > 8 else C.rand_vec(fid, n, s) for s in (1, 2, 3))
+    r = C.rand_vec(fid, 1, 9)
+    eqR, eqL, eqF = C.rand_vec(fid, 1 << shift, 5), C.rand_vec(fid, max(1, hq >> shift), 6), C.rand_vec(fid, hq, 7)
+    bound = [cref.field_bind(fid, X, 0, n // 2, 1, r, n // 2) for X in (A, B, Cc)]
+    for mode in (1, 2, 3):
+        for el, er, sh in ((eqL, eqR, shift), (None, eqF, 0)):
+            d = [torch.from_numpy(X.copy()).cuda() for X in (A, B, Cc)]
+            args = [d[0], d[1] if mode >= 2 else None, d[2] if mode == 3 else None]
+            oa, ob, oc, sums = fv.sumcheck_bind_eq_sums(fid, mode, args[0], args[1], args[2], r,
+                                                        torch.from_numpy(er).cuda(), None if el is None else torch.from_numpy(el).cuda(), sh)
+            outs = [oa, ob, oc]
+            for j in range(mode):
+                assert outs[j].cpu().numpy().tobytes() == bound[j], (mode, j)
+            exp = cref.sumcheck_eq_sums(fid, mode, bound[0], bound[1], bound[2], n // 2, er, el, sh)
+            assert sums == exp, (mode, el is None)
+    if logn == 13:
+        Rm = 1 << 256
+        to_m = lambda v: C.vec([x * Rm % p for x in C.ints(v)])
+        d = [torch.from_numpy(to_m(X)).cuda() for X in (A, B, Cc)]
+        oa, ob, oc, sums = fv.sumcheck_bind_eq_sums(fid, 3, d[0], d[1], d[2], to_m(r), torch.from_numpy(to_m(eqR)).cuda(),
+                                                    torch.from_numpy(to_m(eqL)).cuda(), shift, mont=True)
+        assert C.vec([x * pow(Rm, -1, p) % p for x in C.ints(oa.cpu().numpy())]).tobytes() == bound[0]
+        exp = cref.sumcheck_eq_sums(fid, 3, bound[0], bound[1], bound[2], n // 2, eqR, eqL, shift)
+        assert tuple(int.from_bytes(g, "little") * pow(Rm, -1, p) % p for g in sums) == tuple(int.from_bytes(e, "little") for e in exp)
+    if logn == 7:
+        # every round of a sum-check fused: tables shrink n -> 2, sums of each round equal the oracle's on its own tables
+        d = [torch.from_numpy(X.copy()).cuda() for X in (A, B, Cc)]
+        host = [A, B, Cc]
+        m = n
+        rnd = 0
+        while m >= 4:
+            rr = C.rand_vec(fid, 1, 100 + rnd)
+            eq = C.rand_vec(fid, m // 4, 200 + rnd)
+            d[0], d[1], d[2], sums = fv.sumcheck_bind_eq_sums(fid, 3, d[0], d[1], d[2], rr, torch.from_numpy(eq).cuda())
+            host = [np.frombuffer(cref.field_bind(fid, X, 0, m // 2, 1, rr, m // 2), np.uint8).reshape(-1, 32) for X in host]
+            assert sums == cref.sumcheck_eq_sums(fid, 3, host[0], host[1], host[2], m // 2, eq)
+            d = [x.contiguous() for x in d]
+            m //= 2
+            rnd += 1
+        assert [x.cpu().numpy().tobytes() for x in d] == [h.tobytes() for h in host]
