@@ -41,34 +41,57 @@ template <int FID> __device__ __forceinline__ Fp<FID> block_sum(Fp<FID> v, uint3
   return v;
 }
 
+// The terms of one index: e0 = a0*b0 - c0 (at product scale) and q = (a1-a0)*(b1-b0), with the eq factor.
+template <int FID, int MODE> struct EqTerm {
+  Fp<FID> e0, q, fac;
+};
+template <int FID, int MODE>
+__device__ __forceinline__ EqTerm<FID, MODE> eq_term(const uint32_t* A, const uint32_t* B, const uint32_t* C,
+                                                     const uint32_t* eqL, const uint32_t* eqR, uint32_t shift,
+                                                     uint32_t mask, uint32_t h, const Fp<FID>& nk, uint32_t id) {
+  using F = Fp<FID>;
+  EqTerm<FID, MODE> t;
+  t.fac = ldw<FID>(eqR, eqL ? (id & mask) : id);
+  if (eqL) t.fac = ldw<FID>(eqL, id >> shift) * t.fac;
+  const F a0 = ldw<FID>(A, id);
+  if (MODE == 1) {
+    t.e0 = a0;
+    t.q = F::zero();
+  } else {
+    const F a1 = ldw<FID>(A, (size_t)id + h), b0 = ldw<FID>(B, id), b1 = ldw<FID>(B, (size_t)id + h);
+    // a0*b0 - c0*k in ONE reduction: nk = p - k (k brings c0 to the scale of a product; MODE 2: c0 = 1 folded into nk)
+    t.e0 = MODE == 3 ? F::mul_add(a0, b0, ldw<FID>(C, id), nk) : (a0 * b0 + nk).norm();   // < 1.02 p / < 2.01 p
+    t.q = F::sub2(a1, a0).norm() * F::sub2(b1, b0).norm();                                 // operands < 3 p
+  }
+  return t;
+}
+
 template <int FID, int MODE>
 __global__ __launch_bounds__(256) void k_eq_sums(const uint32_t* A, const uint32_t* B, const uint32_t* C,
                                                  const uint32_t* eqL, const uint32_t* eqR, uint32_t shift, uint32_t mask,
-                                                 uint32_t h, Fp<FID> fconst, uint32_t* partial) {
+                                                 uint32_t h, Fp<FID> nk, uint32_t* partial) {
   using F = Fp<FID>;
   __shared__ uint32_t lds[9 * 256];
   F s0 = F::zero(), s1 = F::zero();
   uint32_t pending = 0;  // lazily added terms since the last canonicalisation (each < 1.1 p, limbs < 2^29)
-  for (uint32_t id = blockIdx.x * 256u + threadIdx.x; id < h; id += gridDim.x * 256u) {
-    F fac = ldw<FID>(eqR, eqL ? (id & mask) : id);
-    if (eqL) fac = ldw<FID>(eqL, id >> shift) * fac;
-    F a0 = ldw<FID>(A, id);
-    if (MODE == 1) {
-      s0 = s0 + a0 * fac;
-    } else {
-      F a1 = ldw<FID>(A, (size_t)id + h), b0 = ldw<FID>(B, id), b1 = ldw<FID>(B, (size_t)id + h);
-      // the subtrahend at the scale of a product (x * Fm^2 / R'): c0 * fconst (MODE 3), or the constant itself (MODE 2)
-      F c = MODE == 3 ? ldw<FID>(C, id) * fconst : fconst;
-      F e0 = F::sub2(a0 * b0, c).norm();                                    // < 3.1 p
-      F q = F::sub2(a1, a0).norm() * F::sub2(b1, b0).norm();                // operands < 3 p
-      s0 = s0 + e0 * fac;
-      s1 = s1 + q * fac;
-    }
+  const uint32_t stride = gridDim.x * 256u;
+  uint32_t id = blockIdx.x * 256u + threadIdx.x;
+  // two indices per iteration: s += e_i * f_i + e_j * f_j is one reduction for two products
+  for (; id + stride < h; id += 2 * stride) {
+    const EqTerm<FID, MODE> x = eq_term<FID, MODE>(A, B, C, eqL, eqR, shift, mask, h, nk, id);
+    const EqTerm<FID, MODE> y = eq_term<FID, MODE>(A, B, C, eqL, eqR, shift, mask, h, nk, id + stride);
+    s0 = s0 + F::mul_add(x.e0, x.fac, y.e0, y.fac);            // < p (1 + 2 * 2.1 * 1.1 / 127)
+    if (MODE != 1) s1 = s1 + F::mul_add(x.q, x.fac, y.q, y.fac);
     if (++pending == 6) {  // 1 canonical + 6 fresh terms: value < 8 p, limbs < 7 * 2^29 -- then back to < p
       s0 = s0.norm().canon();
       s1 = s1.norm().canon();
       pending = 0;
     }
+  }
+  if (id < h) {
+    const EqTerm<FID, MODE> x = eq_term<FID, MODE>(A, B, C, eqL, eqR, shift, mask, h, nk, id);
+    s0 = s0 + x.e0 * x.fac;
+    if (MODE != 1) s1 = s1 + x.q * x.fac;
   }
   s0 = s0.norm().canon();
   s1 = s1.norm().canon();
@@ -156,12 +179,14 @@ static void eq_sums_t(Ctx& c, const void* A, const void* B, const void* C, size_
     one_plain.l[0] = 1;
     fconst = mont ? pow2_plain<FID>(512 - 261) : one_plain.to_canonical();  // 2^251, or 2^-261 mod p
   }
+  // the kernels add nk = p - fconst (the subtrahend's negative, a canonical field element)
+  const F nk = MODE == 1 ? F::zero() : F::sub2(F::zero(), fconst.canon()).norm().canon();
   const bool prof = G.profiling;
   DeviceBackend be(c, false, prof);
   be.mark("k");
   const uint32_t mask = shift >= 32 ? 0xffffffffu : ((1u << shift) - 1u);
   hipLaunchKernelGGL((k_eq_sums<FID, MODE>), dim3(blocks), dim3(256), 0, c.stream, dA, dB, dC, dL, dR, shift, mask, h,
-                     fconst, partial);
+                     nk, partial);
   HIPCHK(hipGetLastError());
   hipLaunchKernelGGL((k_sum_partials<FID>), dim3(1), dim3(256), 0, c.stream, partial, blocks, dout);
   HIPCHK(hipGetLastError());
@@ -200,7 +225,7 @@ template <int FID, int MODE>
 __global__ __launch_bounds__(256) void k_bind_eq_sums(const uint32_t* A, const uint32_t* B, const uint32_t* C,
                                                       uint32_t* oA, uint32_t* oB, uint32_t* oC, Fp<FID> r,
                                                       const uint32_t* eqL, const uint32_t* eqR, uint32_t shift,
-                                                      uint32_t mask, uint32_t hq, Fp<FID> fconst, uint32_t* partial) {
+                                                      uint32_t mask, uint32_t hq, Fp<FID> nk, uint32_t* partial) {
   using F = Fp<FID>;
   __shared__ uint32_t lds[9 * 256];
   F s0 = F::zero(), s1 = F::zero();
@@ -223,8 +248,7 @@ __global__ __launch_bounds__(256) void k_bind_eq_sums(const uint32_t* A, const u
     if (MODE == 1) {
       s0 = s0 + a0 * fac;
     } else {
-      const F c = MODE == 3 ? c0 * fconst : fconst;
-      const F e0 = F::sub2(a0 * b0, c).norm();
+      const F e0 = MODE == 3 ? F::mul_add(a0, b0, c0, nk) : (a0 * b0 + nk).norm();  // a0*b0 - c0*k, one reduction
       const F q = F::sub2(a1, a0).norm() * F::sub2(b1, b0).norm();
       s0 = s0 + e0 * fac;
       s1 = s1 + q * fac;
@@ -276,6 +300,7 @@ static void bind_eq_sums_t(Ctx& c, const void* A, const void* B, const void* C, 
     one_plain.l[0] = 1;
     fconst = mont ? pow2_plain<FID>(512 - 261) : one_plain.to_canonical();
   }
+  const F nk = MODE == 1 ? F::zero() : F::sub2(F::zero(), fconst.canon()).norm().canon();  // p - fconst, as eq_sums_t
   const F ri = challenge_internal<FID>(r, mont);
   const bool prof = G.profiling;
   DeviceBackend be(c, false, prof);
@@ -283,7 +308,7 @@ static void bind_eq_sums_t(Ctx& c, const void* A, const void* B, const void* C, 
   const uint32_t mask = shift >= 32 ? 0xffffffffu : ((1u << shift) - 1u);
   hipLaunchKernelGGL((k_bind_eq_sums<FID, MODE>), dim3(blocks), dim3(256), 0, c.stream, (const uint32_t*)A,
                      (const uint32_t*)B, (const uint32_t*)C, (uint32_t*)oA, (uint32_t*)oB, (uint32_t*)oC, ri,
-                     (const uint32_t*)eqL, (const uint32_t*)eqR, shift, mask, hq, fconst, partial);
+                     (const uint32_t*)eqL, (const uint32_t*)eqR, shift, mask, hq, nk, partial);
   HIPCHK(hipGetLastError());
   hipLaunchKernelGGL((k_sum_partials<FID>), dim3(1), dim3(256), 0, c.stream, partial, blocks, dout);
   HIPCHK(hipGetLastError());
