@@ -16,6 +16,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -355,12 +356,22 @@ def hyperkzg_replay(args, world, rank, L, torch, dist):
             cur = fv.fold_pairs(fid, cur, xs[ell - i - 1])
             polys.append(cur)
         coms = ce.batch_commit(ck, polys[1:])
-        evals = [[fv.poly_eval(fid, f, us[j]) for j in range(3)] for f in polys]
-        B = polys[0].clone()
-        for i in range(1, ell):
-            m = polys[i].shape[0]
-            B[:m] = fv.axpy(fid, B[:m].contiguous(), polys[i], qs[i])
-        opens = [ce.commit(ck, fv.div_by_monomial(fid, B, us[j]).contiguous()) for j in range(3)]
+        evals = fv.poly_eval_multi(fid, polys, us)   # the whole v matrix (hyperkzg.rs:1049-1056) in one launch
+        B = fv.lincomb_powers(fid, polys, qs[0])     # B = sum_i q^i f_i (kzg_compute_batch_polynomial, hyperkzg.rs:1028-1040)
+        # the three openings run in parallel in the reference too (`u.into_par_iter()`, hyperkzg.rs:1062-1065)
+        opens = [None] * 3
+
+        def open_at(j):
+            opens[j] = ce.commit(ck, fv.div_by_monomial(fid, B, us[j]).contiguous())
+        if os.environ.get("NMX_REPLAY_SERIAL_OPENS"):
+            for j in range(3):
+                open_at(j)
+        else:
+            ths = [threading.Thread(target=open_at, args=(j,)) for j in range(3)]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
         return coms, evals, opens
 
     for _ in range(args.warmup):
@@ -376,7 +387,7 @@ def hyperkzg_replay(args, world, rank, L, torch, dist):
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": False, "scaling": "weak",
         "vs_baseline": None, "dtype": "u32x8 (256-bit modular integer)", "data": "synthetic",
         "config": {"workload": f"HyperKZG prove replay, n = 2^{ell}: {ell - 1} pair folds, batch_commit of lengths n/2..2, {3 * ell} Horner "
-                               "evaluations, batch polynomial, 3 x (div_by_monomial + MSM of n-1) (BASELINE.json configs[4]); no transcript"},
+                               "evaluations (one launch), batch polynomial (one launch), 3 x (div_by_monomial + MSM of n-1) (BASELINE.json configs[4]); no transcript"},
         "roofline": None,
     }
     if not args.no_cpu_baseline:
@@ -393,10 +404,7 @@ def hyperkzg_replay(args, world, rank, L, torch, dist):
             hp.append(cur)
         ecoms = [prep.msm(p_, len(p_)) for p_ in hp[1:]]
         eevals = [[cref.suffix_horner(fid, f, len(f), us[j])[:32] for j in range(3)] for f in hp]
-        Bh = hP.copy()
-        for i in range(1, ell):
-            m = len(hp[i])
-            Bh[:m] = np.frombuffer(cref.field_axpy(fid, Bh[:m], hp[i], qs[i], m), np.uint8).reshape(m, 32)
+        Bh = np.frombuffer(cref.lincomb_powers(fid, [h.tobytes() for h in hp], qs[0], n), np.uint8).reshape(n, 32)
         eopens = []
         for j in range(3):
             h = np.frombuffer(cref.suffix_horner(fid, Bh, n, us[j]), np.uint8).reshape(n, 32)[1:]

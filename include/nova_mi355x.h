@@ -208,6 +208,12 @@ int nmx_field_lincomb_powers(int field, const void* const* vecs, const size_t* l
  * src/provider/hyperkzg.rs:1011-1020); out[1..n) is the quotient h of `div_by_monomial(f, u)`
  * (src/provider/hyperkzg.rs:961-999, h[i-1] = f[i] + h[i]*u) that kzg_open commits to. */
 int nmx_poly_suffix_horner(int field, const void* f, size_t n, const void* u, uint32_t flags, void* out);
+/* HyperKZG's evaluation matrix (src/provider/hyperkzg.rs:1011-1020 `poly_eval`, called for every folded polynomial at
+ * the three points r, -r, r^2, :1049-1056): out[i * m + j] = polys[i](points[j]) for k polynomials of any lengths
+ * (coefficients low to high; an empty polynomial evaluates to 0) at m <= 4 points, all in one launch.  `polys`, `lens`,
+ * `points` and `out` are host arrays; the coefficient vectors follow NMX_SCALARS_DEVICE. */
+int nmx_poly_eval_multi(int field, const void* const* polys, const size_t* lens, size_t k, const void* points, size_t m,
+                        uint32_t flags, uint8_t* out);
 /* EqPolynomial::evals_from_points (src/spartan/polys/eq.rs:54-73): out[2^ell] = eq(r, x) for x in {0,1}^ell, r[0] the
  * most significant variable.  r: ell x 32 bytes, host.  out: host, or HBM with NMX_SCALARS_DEVICE. */
 int nmx_eq_evals_from_points(int field, const void* r, size_t ell, uint32_t flags, void* out);

@@ -67,6 +67,7 @@ def lib():
     L.nmx_spmv_apply.argtypes = [u64, vp, sz, u32, vp]
     L.nmx_spmv_apply_pair.argtypes = [u64, vp, vp, sz, u32, vp, vp]
     L.nmx_sumcheck_plain_sums.argtypes = [i, i, vp, vp, vp, sz, u32, vp]
+    L.nmx_poly_eval_multi.argtypes = [i, vp, vp, sz, vp, sz, u32, vp]
     L.nmx_sumcheck_bind_eq_sums.argtypes = [i, i, vp, vp, vp, sz, vp, vp, sz, vp, sz, u32, u32, vp, vp, vp, vp]
     L.nmx_field_lincomb_powers.argtypes = [i, vp, vp, sz, vp, sz, u32, vp]
     L.nmx_mle_multi_evaluate.argtypes = [i, vp, sz, sz, vp, sz, u32, vp]

@@ -663,6 +663,21 @@ int nmx_poly_suffix_horner(int field, const void* f, size_t n, const void* u, ui
   });
 }
 
+int nmx_poly_eval_multi(int field, const void* const* polys, const size_t* lens, size_t k, const void* points, size_t m,
+                        uint32_t flags, uint8_t* out) {
+  return guarded([&] {
+    require((k == 0 || (polys && lens)) && (m == 0 || points) && (out || k * m == 0), NMX_E_ARG, "null argument");
+    require(m <= 4 && k <= 4096, NMX_E_TOO_LARGE, "at most 4 points and 4096 polynomials per call");
+    for (size_t i = 0; i < k; i++) {
+      require(polys[i] || lens[i] == 0, NMX_E_ARG, "null polynomial");
+      require(lens[i] < (1ull << 31), NMX_E_TOO_LARGE, "polynomial too long");
+    }
+    if (k == 0 || m == 0) return;
+    CtxLease L;
+    fv_eval_multi(*L.c, field, polys, lens, k, points, m, flags, out);
+  });
+}
+
 int nmx_eq_evals_from_points(int field, const void* r, size_t ell, uint32_t flags, void* out) {
   return guarded([&] {
     require((r || ell == 0) && out, NMX_E_ARG, "null argument");

@@ -258,6 +258,8 @@ void fv_lincomb(Ctx&, int field, const void* const* vecs, const size_t* lens, si
                 uint32_t flags, void* out);
 void fv_plain_sums(Ctx&, int field, int kind, const void* A, const void* B, const void* C, size_t len, uint32_t flags,
                    uint8_t* out);  // sumcheck.hip
+void fv_eval_multi(Ctx&, int field, const void* const* polys, const size_t* lens, size_t k, const void* points, size_t m,
+                   uint32_t flags, uint8_t* out);  // sumcheck.hip
 void fv_bind_eq_sums(Ctx&, int field, int mode, const void* A, const void* B, const void* C, size_t len, const void* r,
                      const void* eqL, size_t nL, const void* eqR, size_t nR, uint32_t shift, uint32_t flags, void* oA,
                      void* oB, void* oC, uint8_t* out);  // sumcheck.hip

@@ -123,6 +123,14 @@ template <int FID> __global__ __launch_bounds__(256) void k_sum_partials(const u
   }
 }
 
+template <int FID> static Fp<FID> challenge_internal(const void* r, bool mont) {
+  uint32_t w[8];
+  memcpy(w, r, 32);
+  require(Fp<FID>::words_lt_p(w), NMX_E_SCALAR_RANGE, "challenge >= field modulus");
+  Fp<FID> f = Fp<FID>::from_words(w);
+  return (mont ? f.mont256_to_internal() : f.to_internal()).canon();
+}
+
 // 2^e mod p as a plain integer in limbs (host)
 template <int FID> static Fp<FID> pow2_plain(uint32_t e) {
   using F = Fp<FID>;
@@ -270,13 +278,6 @@ __global__ __launch_bounds__(256) void k_bind_eq_sums(const uint32_t* A, const u
   }
 }
 
-template <int FID> static Fp<FID> challenge_internal(const void* r, bool mont) {
-  uint32_t w[8];
-  memcpy(w, r, 32);
-  require(Fp<FID>::words_lt_p(w), NMX_E_SCALAR_RANGE, "challenge >= field modulus");
-  Fp<FID> f = Fp<FID>::from_words(w);
-  return (mont ? f.mont256_to_internal() : f.to_internal()).canon();
-}
 
 template <int FID, int MODE>
 static void bind_eq_sums_t(Ctx& c, const void* A, const void* B, const void* C, size_t len, const void* r, const void* eqL,
@@ -352,6 +353,175 @@ void fv_bind_eq_sums(Ctx& c, int field, int mode, const void* A, const void* B, 
     default: throw Fail{NMX_E_ARG, "bad field id"};
   }
 #undef BES
+}
+
+// ---- k polynomials evaluated at m points in one launch ------------------------------------------------------------
+// HyperKZG's evaluation matrix v[j][i] = f_i(u_j) (/root/reference/src/provider/hyperkzg.rs:1011-1020, 1049-1056):
+// ell polynomials of lengths n, n/2, ..., 2 at the three points r, -r, r^2.  One Horner pass per (polynomial, point)
+// is 3*ell launches each bound by a 64-step dependent chain; here a lane evaluates a 16-coefficient chunk at all m
+// points (coefficients read once), scales by u^(16 * lane) from a table, the block sums over its 256 chunks, and
+// thread 0 applies the block's own power u^(4096 * block).  A polynomial owns whole blocks.
+static constexpr uint32_t kEvalChunk = 16, kEvalMaxPts = 4;
+struct EvalPoly {
+  const uint32_t* f;
+  uint32_t len, first_block, nblocks;
+};
+template <int FID>
+__global__ __launch_bounds__(256) void k_eval_multi(const EvalPoly* polys, uint32_t k, uint32_t m,
+                                                    const uint32_t* pts /* m x 8, internal form */,
+                                                    const uint32_t* pw16 /* m x 256 x 8: u^(16 t) */,
+                                                    const uint32_t* pw4096 /* m x 20 x 8: u^(4096 * 2^s) */,
+                                                    uint32_t* partial /* blocks x kEvalMaxPts x 8 */) {
+  using F = Fp<FID>;
+  __shared__ uint32_t lds[9 * 256];
+  __shared__ uint32_t s_poly;
+  if (threadIdx.x == 0) {
+    uint32_t p = 0;
+    while (p + 1 < k && polys[p + 1].first_block <= blockIdx.x) p++;
+    s_poly = p;
+  }
+  __syncthreads();
+  const EvalPoly P = polys[s_poly];
+  const uint32_t lb = blockIdx.x - P.first_block;                     // block within the polynomial
+  const uint32_t lo = (lb * 256u + threadIdx.x) * kEvalChunk;          // this lane's first coefficient
+  F h[kEvalMaxPts];
+#pragma unroll
+  for (uint32_t j = 0; j < kEvalMaxPts; j++) h[j] = F::zero();
+  if (lo < P.len) {
+    const uint32_t hi = lo + kEvalChunk < P.len ? lo + kEvalChunk : P.len;
+    F u[kEvalMaxPts];
+#pragma unroll
+    for (uint32_t j = 0; j < kEvalMaxPts; j++) u[j] = j < m ? ldw<FID>(pts, j) : F::zero();
+    for (uint32_t i = hi; i-- > lo;) {
+      const F c = ldw<FID>(P.f, i);
+#pragma unroll
+      for (uint32_t j = 0; j < kEvalMaxPts; j++)
+        if (j < m) h[j] = (c + u[j] * h[j]).norm();                    // < 2.1 p, normalized
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < kEvalMaxPts; j++)
+      if (j < m) h[j] = (h[j] * ldw<FID>(pw16, (size_t)j * 256 + threadIdx.x)).canon();
+  }
+  for (uint32_t j = 0; j < m; j++) {
+    F sum = block_sum<FID>(h[j], lds);
+    if (threadIdx.x == 0) {
+      // times u^(4096 * lb): product over the set bits of lb
+      for (uint32_t sft = 0; sft < 20; sft++)
+        if ((lb >> sft) & 1u) sum = (sum * ldw<FID>(pw4096, (size_t)j * 20 + sft)).canon();
+      sum.to_words(partial + ((size_t)blockIdx.x * kEvalMaxPts + j) * 8);
+    }
+    __syncthreads();
+  }
+}
+// out[p][j] = sum over the polynomial's blocks
+template <int FID>
+__global__ __launch_bounds__(256) void k_eval_finish(const EvalPoly* polys, uint32_t m, const uint32_t* partial,
+                                                     uint32_t* out /* k x m x 8 */) {
+  using F = Fp<FID>;
+  __shared__ uint32_t lds[9 * 256];
+  const EvalPoly P = polys[blockIdx.x];
+  for (uint32_t j = 0; j < m; j++) {
+    F s = F::zero();
+    for (uint32_t b = threadIdx.x; b < P.nblocks; b += 256)
+      s = (s + ldw<FID>(partial, ((size_t)(P.first_block + b) * kEvalMaxPts + j))).norm().canon();
+    s = block_sum<FID>(s, lds);
+    if (threadIdx.x == 0) s.to_words(out + ((size_t)blockIdx.x * m + j) * 8);
+    __syncthreads();
+  }
+}
+
+template <int FID>
+static void eval_multi_t(Ctx& c, const void* const* polys, const size_t* lens, size_t k, const void* points, size_t m,
+                         uint32_t flags, uint8_t* out) {
+  using F = Fp<FID>;
+  const bool mont = flags & NMX_SCALARS_MONT, dev = flags & NMX_SCALARS_DEVICE;
+  auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  std::vector<EvalPoly> desc(k);
+  uint32_t blocks = 0;
+  size_t stage_bytes = 0;
+  for (size_t i = 0; i < k; i++) {
+    const uint32_t nb = (uint32_t)((lens[i] + 256 * kEvalChunk - 1) / (256 * kEvalChunk));
+    desc[i] = EvalPoly{nullptr, (uint32_t)lens[i], blocks, nb ? nb : 1};
+    blocks += desc[i].nblocks;
+    if (!dev) stage_bytes += pad(lens[i] * 32);
+  }
+  const size_t tab_bytes = pad(m * 32) + pad(m * 256 * 32) + pad(m * 20 * 32);
+  const size_t need = stage_bytes + pad(k * sizeof(EvalPoly)) + tab_bytes + pad((size_t)blocks * kEvalMaxPts * 32) +
+                      pad(k * m * 32) + 512;
+  arena_reserve(c, need);
+  size_t used = 0;
+  auto take = [&](size_t bytes) {
+    char* d = c.arena + used;
+    used += pad(bytes);
+    return d;
+  };
+  for (size_t i = 0; i < k; i++) {
+    if (dev) {
+      desc[i].f = (const uint32_t*)polys[i];
+    } else {
+      char* d = take(lens[i] * 32);
+      if (lens[i]) HIPCHK(hipMemcpyAsync(d, polys[i], lens[i] * 32, hipMemcpyHostToDevice, c.stream));
+      desc[i].f = (const uint32_t*)d;
+    }
+  }
+  // tables on the host: a few hundred multiplications per point
+  std::vector<uint32_t> hpts(8 * m), h16(8 * 256 * m), h4096(8 * 20 * m);
+  for (size_t j = 0; j < m; j++) {
+    const F u = challenge_internal<FID>((const uint8_t*)points + 32 * j, mont);
+    u.to_words(hpts.data() + 8 * j);
+    F u16 = u;
+    for (int q = 0; q < 4; q++) u16 = u16.sqr().canon();   // u^16
+    F pw = F::one();
+    for (int t = 0; t < 256; t++) {
+      pw.canon().to_words(h16.data() + 8 * (j * 256 + t));
+      pw = (pw * u16).canon();
+    }
+    F big = pw;  // u^(16 * 256) = u^4096
+    for (int sft = 0; sft < 20; sft++) {
+      big.canon().to_words(h4096.data() + 8 * (j * 20 + sft));
+      big = big.sqr().canon();
+    }
+  }
+  EvalPoly* d_desc = (EvalPoly*)take(k * sizeof(EvalPoly));
+  uint32_t* d_pts = (uint32_t*)take(m * 32);
+  uint32_t* d_16 = (uint32_t*)take(m * 256 * 32);
+  uint32_t* d_4096 = (uint32_t*)take(m * 20 * 32);
+  uint32_t* d_part = (uint32_t*)take((size_t)blocks * kEvalMaxPts * 32);
+  uint32_t* d_out = (uint32_t*)take(k * m * 32);
+  HIPCHK(hipMemcpyAsync(d_desc, desc.data(), k * sizeof(EvalPoly), hipMemcpyHostToDevice, c.stream));
+  HIPCHK(hipMemcpyAsync(d_pts, hpts.data(), m * 32, hipMemcpyHostToDevice, c.stream));
+  HIPCHK(hipMemcpyAsync(d_16, h16.data(), m * 256 * 32, hipMemcpyHostToDevice, c.stream));
+  HIPCHK(hipMemcpyAsync(d_4096, h4096.data(), m * 20 * 32, hipMemcpyHostToDevice, c.stream));
+  const bool prof = G.profiling;
+  DeviceBackend be(c, false, prof);
+  be.mark("k");
+  hipLaunchKernelGGL((k_eval_multi<FID>), dim3(blocks), dim3(256), 0, c.stream, d_desc, (uint32_t)k, (uint32_t)m, d_pts,
+                     d_16, d_4096, d_part);
+  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL((k_eval_finish<FID>), dim3((uint32_t)k), dim3(256), 0, c.stream, d_desc, (uint32_t)m, d_part, d_out);
+  HIPCHK(hipGetLastError());
+  be.mark("end");
+  std::vector<uint32_t> res(8 * k * m);
+  HIPCHK(hipMemcpyAsync(res.data(), d_out, k * m * 32, hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipStreamSynchronize(c.stream));
+  if (prof && be.nmarks == 2) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
+    prof_store(&ms, 1);
+  }
+  // the sums carry f * Fm (the coefficients' own form): nothing to correct -- every product had one internal-form factor
+  memcpy(out, res.data(), k * m * 32);
+}
+
+void fv_eval_multi(Ctx& c, int field, const void* const* polys, const size_t* lens, size_t k, const void* points, size_t m,
+                   uint32_t flags, uint8_t* out) {
+  switch (field) {
+    case 0: eval_multi_t<0>(c, polys, lens, k, points, m, flags, out); break;
+    case 1: eval_multi_t<1>(c, polys, lens, k, points, m, flags, out); break;
+    case 2: eval_multi_t<2>(c, polys, lens, k, points, m, flags, out); break;
+    case 3: eval_multi_t<3>(c, polys, lens, k, points, m, flags, out); break;
+    default: throw Fail{NMX_E_ARG, "bad field id"};
+  }
 }
 
 // ---- sums without an eq factor (the classic sum-check rounds) ------------------------------------------------------

@@ -273,6 +273,25 @@ def suffix_horner(field, f, u, mont=False):
     return out
 
 
+def poly_eval_multi(field, polys, points, mont=False):
+    """[[f_i(u_j) for j] for i] in one launch (nmx_poly_eval_multi): HyperKZG's v matrix, hyperkzg.rs:1049-1056."""
+    import ctypes
+    k = len(polys)
+    pts = _host_u8(points, 32)
+    m = pts.size // 32
+    if k == 0 or m == 0:
+        return [[] for _ in range(k)]
+    parts = [_vec(f) if len(f) else (None, 0, None, None) for f in polys]
+    devs = {pt[2] for pt in parts if pt[2] is not None}
+    assert len(devs) <= 1
+    dev = bool(devs) and devs.pop()
+    ptrs = (ctypes.c_void_p * k)(*[pt[0] for pt in parts])
+    lens = (ctypes.c_size_t * k)(*[pt[1] for pt in parts])
+    out = np.zeros(32 * k * m, dtype=np.uint8)
+    _check(L.lib().nmx_poly_eval_multi(field, ptrs, lens, k, pts.ctypes.data, m, _flags(dev, mont), out.ctypes.data))
+    return [[out[32 * (i * m + j): 32 * (i * m + j) + 32].tobytes() for j in range(m)] for i in range(k)]
+
+
 def poly_eval(field, f, u, mont=False):
     out = suffix_horner(field, f, u, mont)
     return (out[0].cpu().numpy() if _is_device_tensor(out) else out[0]).tobytes()

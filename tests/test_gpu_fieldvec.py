@@ -358,3 +358,28 @@ def test_sumcheck_fused_round(nmx, fid, logn):
             m //= 2
             rnd += 1
         assert [x.cpu().numpy().tobytes() for x in d] == [h.tobytes() for h in host]
+
+
+@pytest.mark.parametrize("fid", range(4))
+def test_poly_eval_multi(nmx, fid):
+    """nmx_poly_eval_multi == poly_eval per (polynomial, point) (hyperkzg.rs:1011-1020): the HyperKZG shape (lengths
+    n, n/2, ..., 2 at three points), ragged / empty / single-coefficient polynomials, lengths around the 16-coefficient
+    chunk and the 4096-coefficient block, special points 0, 1, -1, device operands, Montgomery layout."""
+    import torch
+    from nova_amd import fieldvec as fv
+    p = C.FIELDS[fid]
+    pts = np.concatenate([C.rand_vec(fid, 2, 5), C.vec([p - 1])])
+    polys = [C.edge_vectors(fid, 1 << e, 30 + e) if e > 3 else C.rand_vec(fid, 1 << e, 30 + e) for e in range(14, 0, -1)]
+    exp = [[cref.suffix_horner(fid, f, len(f), pts[j])[:32] for j in range(3)] for f in polys]
+    assert fv.poly_eval_multi(fid, polys, pts) == exp
+    assert fv.poly_eval_multi(fid, [torch.from_numpy(f.copy()).cuda() for f in polys], pts) == exp
+    odd = [C.rand_vec(fid, m, 50 + m) for m in (1, 15, 16, 17, 4095, 4096, 4097, 70001)] + [C.rand_vec(fid, 1, 1)[:0]]
+    sp = np.concatenate([C.vec([0]), C.vec([1]), C.rand_vec(fid, 1, 8), C.vec([2])])
+    exp = [[cref.suffix_horner(fid, f, len(f), sp[j])[:32] if len(f) else bytes(32) for j in range(4)] for f in odd]
+    assert fv.poly_eval_multi(fid, odd, sp) == exp
+    assert fv.poly_eval_multi(fid, odd[:3], sp[:1]) == [e[:1] for e in exp[:3]]
+    Rm = 1 << 256
+    to_m = lambda v: C.vec([x * Rm % p for x in C.ints(v)])
+    got = fv.poly_eval_multi(fid, [to_m(f) for f in polys[6:]], to_m(pts), mont=True)
+    want = [[cref.suffix_horner(fid, f, len(f), pts[j])[:32] for j in range(3)] for f in polys[6:]]
+    assert [[(int.from_bytes(g, "little") * pow(Rm, -1, p) % p).to_bytes(32, "little") for g in row] for row in got] == want
