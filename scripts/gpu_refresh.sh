@@ -9,7 +9,7 @@ for it in 1024 65536; do b --workload prove_step_replay --iters $it --steps 20 >
 for l in 14 16 20; do b --workload hyperkzg_replay --log2n $l --steps 5 > $O/hkzg_$l.json; done
 for c in 1 2 3; do b --curve $c --no-cpu-baseline --steps 20 > $O/bench_curve$c.json; done
 mkdir -p $O/fv
-for w in axpy cross_term bind sumcheck3 quad_prod lincomb8 horner mle_eval spmv; do for l in 20 24; do
+for w in axpy cross_term bind sumcheck3 round3 quad_prod lincomb8 horner mle_eval spmv; do for l in 20 24; do
   [ $w = spmv -a $l = 24 ] && l=22; [ $w = lincomb8 -a $l = 24 ] && l=22
   b --workload $w --log2n $l --steps 10 > $O/fv/bench_${w}_$l.json; done; done
 python - <<'PY'
