@@ -160,8 +160,9 @@ template <int FID> struct LinCombFn {
 // Suffix Horner  out[i] = sum_{k >= i} f[k] * u^(k-i):  out[0] is `poly_eval(f, u)` (hyperkzg.rs:1011-1020) and out[1..]
 // is the quotient of `div_by_monomial` (hyperkzg.rs:961-999: h[i-1] = f[i] + h[i]*u).  Same three phases as the
 // reference's chunked version -- chunk-local recurrences, carries between chunks with u^chunk, fix-up -- with
-// 64-element chunks (one lane each) and the carry phase applied recursively.
-static constexpr uint32_t kHornerChunk = 64;
+// 16-element chunks (one lane each: the chains are pure latency, so they are short -- 64-element chunks took 0.20 ms
+// for 2^20 coefficients, 16-element ones 0.12 ms) and the carry phase applied recursively.
+static constexpr uint32_t kHornerChunk = 16;
 template <int FID> struct HornerLocalFn {
   const uint32_t* f;
   uint32_t* out;    // local suffix values
@@ -182,13 +183,13 @@ template <int FID> struct HornerLocalFn {
 template <int FID> struct HornerFixFn {
   uint32_t* out;
   const uint32_t* carries;  // carries[c] = global suffix value at the start of chunk c
-  const uint32_t* pw;       // pw[k] = u^k * 2^261, k = 0..64
+  const uint32_t* pw;       // pw[k] = u^k * 2^261, k = 0..16
   uint32_t n;
   NMX_HD void operator()(uint32_t i) const {
     using F = Fp<FID>;
     const uint32_t c = i / kHornerChunk, nc = (n + kHornerChunk - 1) / kHornerChunk;
     if (c + 1 >= nc) return;  // last chunk: local values are already global
-    const uint32_t dist = (c + 1) * kHornerChunk - i;  // 1..64
+    const uint32_t dist = (c + 1) * kHornerChunk - i;  // 1..16
     F v = ld<FID>(out, i) + ld<FID>(pw, dist) * ld<FID>(carries, c + 1);
     st<FID>(out, i, v.norm());
   }
@@ -438,37 +439,48 @@ struct HornerArena {
   }
 };
 
-// out (device, n elements) <- suffix Horner of f (device) at the challenge whose internal residue is `ui`
-template <int FID> static void horner_dev(Ctx& c, const uint32_t* f, uint32_t n, Fp<FID> ui, uint32_t* out,
-                                          HornerArena& ws) {
-  using F = Fp<FID>;
+// out (device, n elements) <- suffix Horner of f (device); level `lvl` of the recursion evaluates at u^(16^lvl), whose
+// power table pw_all[lvl] (u_l^0 .. u_l^16, internal form) was uploaded before the first launch: no host round trip
+// between the levels.
+template <int FID> static void horner_dev(Ctx& c, const uint32_t* f, uint32_t n, const std::vector<Fp<FID>>& u_lvl,
+                                          const uint32_t* pw_all, uint32_t lvl, uint32_t* out, HornerArena& ws) {
   DeviceBackend be(c, false, false);
   const uint32_t nc = (n + kHornerChunk - 1) / kHornerChunk;
   uint32_t* heads = (uint32_t*)ws.take((size_t)nc * 32);
-  HornerLocalFn<FID> lf{f, out, heads, ui, n};
+  HornerLocalFn<FID> lf{f, out, heads, u_lvl[lvl], n};
   be.launch(lf, nc);
   if (nc == 1) return;
-  // powers u^0 .. u^64 (internal form), 64 host multiplications
-  std::vector<uint32_t> pwh(8 * (kHornerChunk + 1));
-  F p = F::one();
-  for (uint32_t k = 0; k <= kHornerChunk; k++) {
-    p.canon().to_words(pwh.data() + 8 * k);
-    p = (p * ui).canon();
-  }
-  F uc = F::from_words(pwh.data() + 8 * kHornerChunk);  // u^64
-  uint32_t* pw = (uint32_t*)ws.take(pwh.size() * 4);
   uint32_t* carries = (uint32_t*)ws.take((size_t)nc * 32);
-  HIPCHK(hipMemcpyAsync(pw, pwh.data(), pwh.size() * 4, hipMemcpyHostToDevice, c.stream));
-  HIPCHK(hipStreamSynchronize(c.stream));  // pwh is a local buffer
-  horner_dev<FID>(c, heads, nc, uc, carries, ws);
-  HornerFixFn<FID> ff{out, carries, pw, n};
+  horner_dev<FID>(c, heads, nc, u_lvl, pw_all, lvl + 1, carries, ws);
+  HornerFixFn<FID> ff{out, carries, pw_all + (size_t)lvl * (kHornerChunk + 1) * 8, n};
   be.launch(ff, n);
 }
 template <int FID>
 static void horner_t(Ctx& c, const void* f, size_t n, const void* u, uint32_t flags, void* out) {
+  using F = Fp<FID>;
   const bool dev = flags & NMX_SCALARS_DEVICE;
-  arena_reserve(c, HornerArena::need(n) + (dev ? 0 : 2 * HornerArena::pad(n * 32)));
+  // per level: u_l = u^(16^l) and its powers 0..16 -- 16 host multiplications per level, at most 8 levels
+  std::vector<F> u_lvl;
+  std::vector<uint32_t> pwh;
+  {
+    F ul = challenge<FID>(u, flags & NMX_SCALARS_MONT);
+    for (size_t m = n;; m = (m + kHornerChunk - 1) / kHornerChunk) {
+      u_lvl.push_back(ul);
+      F p = F::one();
+      for (uint32_t k = 0; k <= kHornerChunk; k++) {
+        uint32_t w[8];
+        p.canon().to_words(w);
+        pwh.insert(pwh.end(), w, w + 8);
+        if (k < kHornerChunk) p = (p * ul).canon();
+      }
+      ul = p;  // u_l^16
+      if (m <= kHornerChunk) break;
+    }
+  }
+  arena_reserve(c, HornerArena::need(n) + HornerArena::pad(pwh.size() * 4) + (dev ? 0 : 2 * HornerArena::pad(n * 32)));
   HornerArena ws{c.arena};
+  uint32_t* d_pw = (uint32_t*)ws.take(pwh.size() * 4);
+  HIPCHK(hipMemcpyAsync(d_pw, pwh.data(), pwh.size() * 4, hipMemcpyHostToDevice, c.stream));  // pwh lives to the sync below
   const uint32_t* df = (const uint32_t*)f;
   uint32_t* dout = (uint32_t*)out;
   if (!dev) {
@@ -480,7 +492,7 @@ static void horner_t(Ctx& c, const void* f, size_t n, const void* u, uint32_t fl
   const bool prof = G.profiling;
   DeviceBackend be(c, false, prof);
   be.mark("kernel");
-  horner_dev<FID>(c, df, (uint32_t)n, challenge<FID>(u, flags & NMX_SCALARS_MONT), dout, ws);
+  horner_dev<FID>(c, df, (uint32_t)n, u_lvl, d_pw, 0, dout, ws);
   be.mark("end");
   if (!dev) HIPCHK(hipMemcpyAsync(out, dout, n * 32, hipMemcpyDeviceToHost, c.stream));
   HIPCHK(hipStreamSynchronize(c.stream));
