@@ -55,6 +55,7 @@ static void ensure_init() {
   if (dev >= cnt) throw Fail{NMX_E_ARG, "device index out of range"};
   G.device = dev;
   if (const char* t = getenv("NMX_TUNE_LMAX")) G.force_lmax = (uint32_t)atoi(t);
+  if (const char* t = getenv("NMX_TUNE_PRECOMP_MIN_N")) G.precomp_min_n = (size_t)atoll(t);
   if (const char* t = getenv("NMX_TUNE_FOLD_T")) G.force_fold_t = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_NO_QUAD_ACCUM")) G.no_quad_accum = (uint32_t)atoi(t);
   HIPCHK(hipSetDevice(dev));

@@ -168,7 +168,7 @@ template <int CID> static void write_result(const XYZZ<CurveT<CID>::BF>& r, uint
 template <int CID> static void table_shape(size_t n, uint32_t flags, uint32_t* pre_c, uint32_t* pre_W) {
   *pre_c = 0;
   *pre_W = 0;
-  if (!(flags & NMX_BASES_PRECOMPUTE) || n < kPrecompMinN) return;
+  if (!(flags & NMX_BASES_PRECOMPUTE) || n < G.precomp_min_n) return;
   uint32_t c = G.force_c ? G.force_c : choose_c_precomp((uint32_t)n, FpParams<CurveT<CID>::SF>::BITS);
   uint32_t W = (FpParams<CurveT<CID>::SF>::BITS + 1 + c - 1) / c;
   if ((uint64_t)W * n >= (1ull << 31)) return;  // table index must fit 31 bits
@@ -231,7 +231,7 @@ static void msm_entry(const void* d_bases, size_t n, const MsmCall& mc, uint32_t
 // MSM over bs[offset, offset + n): through the key's window tables when it has them and n is large enough
 template <int CID>
 static XYZZ<CurveT<CID>::BF> run_msm_key(Ctx& c, const BaseSet& bs, size_t offset, size_t n, MsmCall mc) {
-  if (bs.pre_W && n >= kPrecompMinN && (G.force_c == 0 || G.force_c == bs.pre_c)) {
+  if (bs.pre_W && n >= G.precomp_min_n && (G.force_c == 0 || G.force_c == bs.pre_c)) {
     mc.pre_stride = (uint32_t)bs.n;
     mc.pre_offset = (uint32_t)offset;
     mc.pre_c = bs.pre_c;

@@ -76,6 +76,10 @@ struct BaseSet {
   uint32_t pre_W = 0;
 };
 
+// A registered key gets window tables from this many points on, and MSMs over it use them from this many pairs on:
+// everything but the trivial sizes.  (4096 until the small sizes were measured, scripts/gpu_smallmsm.py: with tables a
+// 2^11-pair MSM takes 0.29 ms instead of 0.98 -- one bucket set instead of 37, no 250-doubling Horner on the host.)
+static constexpr size_t kPrecompMinN = 2;  // default of Global::precomp_min_n
 struct Global {
   std::mutex mu;
   bool inited = false;
@@ -93,6 +97,7 @@ struct Global {
   bool profiling = false;
   uint32_t force_c = 0;
   uint32_t force_lmax = 0;  // env NMX_TUNE_LMAX (tuning only)
+  size_t precomp_min_n = kPrecompMinN;  // env NMX_TUNE_PRECOMP_MIN_N (tuning only)
   uint32_t force_fold_t = 0;  // env NMX_TUNE_FOLD_T (tuning only)
   uint32_t no_quad_accum = 0;  // env NMX_TUNE_NO_QUAD_ACCUM (tuning only)
 };
@@ -214,7 +219,6 @@ struct MsmCall {
   const uint32_t* gather_host = nullptr;
   bool all_ones = false;
 };
-static constexpr size_t kPrecompMinN = 4096;  // below this the plain path with a narrow window is faster
 
 // Fills the freshly allocated device key (n x 64 raw bytes) -- nullptr: one hipMemcpy from `src`; key files stream
 // through pinned staging buffers (keyfile.hip)

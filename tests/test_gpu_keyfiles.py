@@ -21,7 +21,7 @@ def _xy(points):
 @pytest.mark.parametrize("c", [R.BN254_G1, R.VESTA], ids=lambda c: c.name)
 def test_ptau_to_hbm_and_commit(nmx, tmp_path, c):
     import nova_amd
-    n = 5000   # > kPrecompMinN: the loaded key gets window tables
+    n = 5000   # the loaded key gets window tables (every registered key with NMX_BASES_PRECOMPUTE does)
     key = cref.sequential_bases(c, 11, 8192)
     pts = [R.xy64_to_point(bytes(row)) for row in key]
     pts[7] = R.INF                                   # an identity base survives the file
