@@ -120,9 +120,17 @@ def test_field_ops(emul, fid):
         if a < 1 << 256:
             assert op(11, a) == a % p
             assert op(7, a) == a * a * Ri % p
-    for a in rnd[:6] + [1, p - 1]:
-        assert op(5, a * Rm % p) == pow(a, -1, p) * Rm % p
-    assert op(5, 0) == 0
+    # inversion (host: binary extended Euclid on 4 x u64; also on weakly reduced inputs r + k*p)
+    more = [int.from_bytes(rng.bytes(32), "little") % p for _ in range(200)]
+    for a in rnd + more + [1, 2, p - 1, p - 2, (p + 1) // 2, 1 << 200, (1 << 253) % p]:
+        if a % p == 0:
+            continue
+        r = a * Rm % p
+        assert op(5, r) == pow(a, -1, p) * Rm % p
+        for k in (1, 3):
+            if r + k * p < 1 << 256:
+                assert op(5, r + k * p) == pow(a, -1, p) * Rm % p
+    assert op(5, 0) == 0 and op(5, p) == 0
     # the cheap divisibility filter never misses a true multiple of p
     for k in range(0, 4):
         if k * p < 1 << 256:
