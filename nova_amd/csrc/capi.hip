@@ -204,6 +204,7 @@ int nmx_shutdown(void) {
     for (Ctx* c : G.all_ctx) {
       if (c->arena) (void)hipFree(c->arena);
       if (c->aux) (void)hipFree(c->aux);
+      if (c->pinned) (void)hipHostFree(c->pinned);
       if (c->have_ev)
         for (int i = 0; i < kMaxMarks; i++) (void)hipEventDestroy(c->ev[i]);
       if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -62,6 +62,7 @@ struct Ctx {
   hipStream_t stream = nullptr;
   char* arena = nullptr;
   size_t cap = 0;
+  char* pinned = nullptr;  // 64 KiB of pinned host memory: landing zone of the small device->host result copies
   char* aux = nullptr;  // second, small arena: data that must outlive calls which re-carve `arena` (eq tables)
   size_t aux_cap = 0;
   hipEvent_t ev[kMaxMarks];
@@ -186,13 +187,32 @@ struct DeviceBackend {
     if (dry) return;
     device_sort_pairs(tmp, tmp_bytes, k_in, k_out, v_in, v_out, total, bits, c.stream);
   }
+  // Small results (window sums, error word) land in the context's pinned buffer and are copied to `dst` after the
+  // stream sync: a pageable destination would make hipMemcpyAsync stage the copy synchronously.
+  static constexpr size_t kPinnedBytes = 64 << 10;
+  struct Landing {
+    void* dst;
+    size_t off, bytes;
+  };
+  std::vector<Landing> landings;
+  size_t pinned_used = 0;
   void d2h(void* dst, const void* src, size_t bytes) {
     if (dry) return;
-    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c.stream));
+    if (!c.pinned) HIPCHK(hipHostMalloc((void**)&c.pinned, kPinnedBytes, hipHostMallocDefault));
+    if (pinned_used + bytes <= kPinnedBytes) {
+      HIPCHK(hipMemcpyAsync(c.pinned + pinned_used, src, bytes, hipMemcpyDeviceToHost, c.stream));
+      landings.push_back({dst, pinned_used, bytes});
+      pinned_used += (bytes + 63) & ~(size_t)63;
+    } else {
+      HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c.stream));
+    }
   }
   void sync() {
     if (dry) return;
     HIPCHK(hipStreamSynchronize(c.stream));
+    for (const Landing& l : landings) memcpy(l.dst, c.pinned + l.off, l.bytes);
+    landings.clear();
+    pinned_used = 0;
   }
   void mark(const char*) {
     if (dry || !prof) return;

@@ -200,8 +200,8 @@ static void eq_sums_t(Ctx& c, const void* A, const void* B, const void* C, size_
   HIPCHK(hipGetLastError());
   be.mark("end");
   uint32_t res[16];
-  HIPCHK(hipMemcpyAsync(res, dout, 64, hipMemcpyDeviceToHost, c.stream));
-  HIPCHK(hipStreamSynchronize(c.stream));
+  be.d2h(res, dout, 64);  // through the context's pinned landing buffer
+  be.sync();
   if (prof && be.nmarks == 2) {
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
@@ -315,8 +315,8 @@ static void bind_eq_sums_t(Ctx& c, const void* A, const void* B, const void* C, 
   HIPCHK(hipGetLastError());
   be.mark("end");
   uint32_t res[16];
-  HIPCHK(hipMemcpyAsync(res, dout, 64, hipMemcpyDeviceToHost, c.stream));
-  HIPCHK(hipStreamSynchronize(c.stream));
+  be.d2h(res, dout, 64);  // through the context's pinned landing buffer
+  be.sync();
   if (prof && be.nmarks == 2) {
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
@@ -502,8 +502,8 @@ static void eval_multi_t(Ctx& c, const void* const* polys, const size_t* lens, s
   HIPCHK(hipGetLastError());
   be.mark("end");
   std::vector<uint32_t> res(8 * k * m);
-  HIPCHK(hipMemcpyAsync(res.data(), d_out, k * m * 32, hipMemcpyDeviceToHost, c.stream));
-  HIPCHK(hipStreamSynchronize(c.stream));
+  be.d2h(res.data(), d_out, k * m * 32);
+  be.sync();
   if (prof && be.nmarks == 2) {
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
@@ -623,8 +623,8 @@ static void plain_sums_t(Ctx& c, const void* A, const void* B, const void* C, si
   HIPCHK(hipGetLastError());
   be.mark("end");
   uint32_t res[24];
-  HIPCHK(hipMemcpyAsync(res, dout, 96, hipMemcpyDeviceToHost, c.stream));
-  HIPCHK(hipStreamSynchronize(c.stream));
+  be.d2h(res, dout, 96);
+  be.sync();
   if (prof && be.nmarks == 2) {
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
