@@ -81,6 +81,22 @@ template <int FID> struct EqStepFn {
   }
 };
 
+// Small eq tables in ONE launch: out[x] = prod_i (x_i ? r_i : 1 - r_i), x_0 the most significant bit, ell <= 12
+// (the sqrt-size tables of evaluate_with: ell doubling launches are ~10 us each, this is one).  ell modmuls per entry
+// instead of one -- irrelevant at <= 4096 entries.
+template <int FID> struct EqDirectFn {
+  static constexpr uint32_t kMaxEll = 12;
+  uint32_t* out;
+  Fp<FID> r[kMaxEll], nr[kMaxEll];  // r_i * 2^261 and (1 - r_i) * 2^261, canonical
+  Fp<FID> one;                      // ONE in the vectors' form (1 or 2^256 mod p), as a plain residue
+  uint32_t ell;
+  NMX_HD void operator()(uint32_t x) const {
+    Fp<FID> acc = one;
+    for (uint32_t i = 0; i < ell; i++) acc = acc * (((x >> (ell - 1 - i)) & 1u) ? r[i] : nr[i]);
+    st<FID>(out, x, acc);
+  }
+};
+
 // CSR sparse matrix x vector, one row per lane (/root/reference/src/r1cs/sparse.rs:201-229, SparseMatrix::multiply_vec;
 // the reference's +-1 / small-coefficient fast paths are a CPU optimisation of the same product).  Matrix values are
 // stored in internal form at registration, so data * z comes out in z's own form with no correction.
@@ -314,9 +330,23 @@ template <int FID> static void eq_evals_t(Ctx& c, const void* r_host, uint32_t e
   } else {
     one.to_words(w);
   }
+  DeviceBackend be(c, false, false);
+  if (ell <= EqDirectFn<FID>::kMaxEll) {
+    EqDirectFn<FID> f;
+    f.out = d_out;
+    f.ell = ell;
+    f.one = F::from_words(w);
+    const F one_i = F::one();
+    for (uint32_t i = 0; i < ell; i++) {
+      f.r[i] = challenge<FID>((const uint8_t*)r_host + 32 * i, mont);
+      f.nr[i] = F::sub2(one_i, f.r[i]).norm().canon();
+    }
+    for (uint32_t i = ell; i < EqDirectFn<FID>::kMaxEll; i++) f.r[i] = f.nr[i] = F::zero();
+    be.launch(f, 1u << ell);
+    return;
+  }
   HIPCHK(hipMemcpyAsync(d_out, w, 32, hipMemcpyHostToDevice, c.stream));
   HIPCHK(hipStreamSynchronize(c.stream));  // w is a stack buffer
-  DeviceBackend be(c, false, false);
   uint32_t size = 1;
   for (int j = (int)ell - 1; j >= 0; j--) {  // for r in r.iter().rev()
     EqStepFn<FID> f{d_out, challenge<FID>((const uint8_t*)r_host + 32 * j, mont), size};
