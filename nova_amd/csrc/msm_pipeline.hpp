@@ -87,7 +87,9 @@ inline MsmShape make_shape(uint32_t n, uint32_t bits, uint32_t force_c, uint32_t
     // (more, shorter waves: smaller tails) and the folds slower.  Measured sweeps 10..64
     // (profiles/r01_msm_2p20/lmax_sweep.txt): 24 is the minimum of accumulate + fold for the c <= 16 tables
     // (512 points per bucket at 2^20), 16 for the c = 20 tables (~100 points per bucket)
-    sh.lmax = pre_c >= 18 ? 16 : 24;
+    // Below 2^18 pairs the kernel is a handful of waves per SIMD and its time is the length of the task chain: 8
+    // (n < 2^15) and 12 (n < 2^18) measured best there (2^13: 0.341 -> 0.312 ms, 2^14: 0.380 -> 0.337, 2^17: 0.555 -> 0.521)
+    sh.lmax = n < (1u << 15) ? 8 : n < (1u << 18) ? 12 : pre_c >= 18 ? 16 : 24;
   } else {
     uint32_t avg = n / sh.M;
     sh.lmax = 4 * avg < 32 ? 32 : 4 * avg;
