@@ -5,6 +5,9 @@
 //   halo2curves::msm::msm_best (called at msm.rs:411,500)
 //   /root/reference/src/provider/pedersen.rs:263-270, hyperkzg.rs:584-591 (commit = msm + h*r)
 #pragma once
+#include <array>
+#include <future>
+
 #include "runtime.hpp"
 
 namespace nmx {
@@ -264,13 +267,15 @@ template <int CID> struct CurveImpl {
   }
   static void commit(Ctx& c, const BaseSet& bs, size_t n, const MsmCall& mc, const void* h_xy64, const void* r,
                      uint32_t flags, uint8_t* out, uint8_t* inf) {
-    auto acc = run_msm_key<CID>(c, bs, 0, n, mc);
+    // the blinding term h * r is ~380 host point operations (0.1-0.2 ms): computed on a second host thread while the
+    // GPU runs the MSM, so a blinded commit costs what an unblinded one does
     uint32_t rw[8];
     memcpy(rw, r, 32);
     require(Fp<SF>::words_lt_p(rw), NMX_E_SCALAR_RANGE, "blinding scalar >= field modulus");
     if (flags & NMX_SCALARS_MONT) Fp<SF>::from_words(rw).mont256_to_canonical().to_words(rw);
     uint32_t any = 0;
     for (int i = 0; i < 8; i++) any |= rw[i];
+    std::future<XYZZ<BF>> hr;
     if (any) {
       Affine<BF> h;
       h.x = fp_from_bytes<BF>((const uint8_t*)h_xy64);
@@ -280,8 +285,12 @@ template <int CID> struct CurveImpl {
         h.x = (m ? h.x.mont256_to_internal() : h.x.to_internal()).canon();
         h.y = (m ? h.y.mont256_to_internal() : h.y.to_internal()).canon();
       }
-      acc.add(scalar_mul<BF>(XYZZ<BF>::from_affine(h), rw));
+      std::array<uint32_t, 8> k;
+      memcpy(k.data(), rw, 32);
+      hr = std::async(std::launch::async, [h, k] { return scalar_mul<BF>(XYZZ<BF>::from_affine(h), k.data()); });
     }
+    auto acc = run_msm_key<CID>(c, bs, 0, n, mc);  // a failure here unwinds through hr's destructor, which joins
+    if (any) acc.add(hr.get());
     write_result<CID>(acc, flags, out, inf);
   }
   static void* upload(Ctx& c, const void* src, size_t n, uint32_t flags, uint32_t* pc, uint32_t* pw,
