@@ -117,3 +117,17 @@ def test_large_file_streams_through_both_staging_buffers(nmx, tmp_path):
     ck = nova_amd.CommitmentKey(c.cid, h.value, n, bytes(64))
     assert ck.read(0, n).tobytes() == xy.tobytes()
     ck.close()
+
+
+def test_committed_key_files_to_hbm(nmx):
+    """The committed fixtures (tests/golden/keys) through the product loaders."""
+    import os
+    import nova_amd
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "keys")
+    ck = nova_amd.CommitmentKey.load_ptau(R.BN254_G1.cid, os.path.join(d, "tiny_bn254.ptau"), 4)
+    assert ck.read(0, 4).tobytes() == _xy(R.sequential_bases(R.BN254_G1, 7, 4)).tobytes()
+    ck.close()
+    pts = R.sequential_bases(R.PALLAS, 5, 5)
+    ck = nova_amd.CommitmentKey.load_keyfile(R.PALLAS.cid, os.path.join(d, "tiny_pallas.key"), 4)
+    assert ck.h == R.point_to_xy64(pts[0]) and ck.read(0, 4).tobytes() == _xy(pts[1:]).tobytes()
+    ck.close()

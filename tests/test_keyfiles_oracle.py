@@ -71,3 +71,15 @@ def test_pedersen_key_roundtrip(c):
         K.read_pedersen_key(c, b"PEDERSEN_KEX" + data[12:], 8)
     with pytest.raises(K.PtauFileError, match="IoError"):
         K.read_pedersen_key(c, data, 9)       # needs 16 + 1 points
+
+
+def test_committed_key_files():
+    """tests/golden/keys/* (made by tests/golden/make_key_files.py) read back to the points they were written from."""
+    import os
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "keys")
+    data = open(os.path.join(d, "tiny_bn254.ptau"), "rb").read()
+    assert len(data) == 4 + 8 + 12 + 40 + 8 * 12 + 12 + 4 * 64 + 12 + 128
+    assert K.read_ptau_g1(R.BN254_G1, data, 4, 2) == R.sequential_bases(R.BN254_G1, 7, 4)
+    data = open(os.path.join(d, "tiny_pallas.key"), "rb").read()
+    pts = R.sequential_bases(R.PALLAS, 5, 5)
+    assert K.read_pedersen_key(R.PALLAS, data, 4) == (pts[0], pts[1:])
