@@ -42,6 +42,8 @@ enum {
                                      keys, /root/reference/src/provider/ptau.rs:372-391                            */
                                 /* 2^(c*w) * P_i in HBM (W x the key size; c = 16, W = 16 for keys >= 2^20).    */
                                 /* MSMs over >= 4096 points of such a key run all windows into one bucket set. */
+  NMX_BASES_NOCACHE = 1u << 7,  /* slice-form calls (nmx_msm, nmx_msm_u64, nmx_msm_batch): do not look the base  */
+                                /* array up in / insert it into the slice cache (one-shot arrays)               */
   NMX_OUT_PARTIAL = 1u << 4     /* write a 128-byte partial sum instead of an affine point: the per-GPU   */
                                 /* result of a sharded MSM, input of nmx_point_sum.  Format: extended     */
                                 /* Jacobian (X, Y, ZZ, ZZZ), x = X/ZZ, y = Y/ZZZ, each coordinate the     */
@@ -106,9 +108,51 @@ int nmx_bases_generate(int curve, uint64_t k0, size_t n, uint32_t flags, uint64_
 /* ---- MSM ---------------------------------------------------------------------------------------------
  * DlogGroupExt::vartime_multiscalar_mul (src/provider/traits.rs:79; impls src/provider/bn256_grumpkin.rs:45-47,
  * src/provider/traits.rs:371-377) == msm() (src/provider/msm.rs:225-419):  out = sum_i scalars[i] * bases[i].
- * n == 0 -> identity (msm.rs:228).  Identity bases and zero scalars contribute nothing (msm.rs:247-249). */
+ * n == 0 -> identity (msm.rs:228).  Identity bases and zero scalars contribute nothing (msm.rs:247-249).
+ *
+ * Slice form = the trait's own signature: the reference passes `&ck.ck[..n]` and no handle (pedersen.rs:263-270,
+ * hyperkzg.rs:584-591, blitzar.rs:7-20).  The library therefore keeps a SLICE CACHE of resident keys: a call whose
+ * `bases_xy64` pointer is the first element of (or lies inside) an array it has seen before runs over the resident
+ * copy, window tables included, exactly like nmx_msm_handle -- no upload, no conversion.  Identity of an array =
+ * (curve, layout flag, host address) confirmed on every call by 64-bit content fingerprints read from the caller's
+ * slice (valid for the duration of the call): every point for arrays up to 2048 points, otherwise the first and last
+ * point used plus eight probes of a <= 4096-point grid that move from call to call; a longer prefix of the
+ * same array re-registers it at the new length, so one resident copy serves `&ck[..n]` for every n.  Arrays are
+ * assumed immutable while cached (Nova's commitment keys are: created once by `setup`, pedersen.rs:249-259); a caller
+ * that rewrites one in place must call nmx_cache_invalidate.  Arrays shorter than the cache's min_n (default 128
+ * points) and calls with NMX_BASES_NOCACHE are uploaded for the call only.  LRU eviction under a byte budget
+ * (default: a quarter of the device's HBM); evicted or invalidated keys stay alive until the calls using them return. */
 int nmx_msm(int curve, const void* scalars, const void* bases_xy64, size_t n, uint32_t flags,
             uint8_t* out, uint8_t* out_is_inf);
+/* Slice-cache control.  nmx_cache_configure: max_bytes / min_n / max_entries, 0 = leave unchanged. */
+int nmx_cache_clear(void);
+int nmx_cache_invalidate(const void* bases_xy64);
+int nmx_cache_configure(size_t max_bytes, size_t min_n, size_t max_entries);
+/* Smallest n for which the shim should send an MSM to the GPU at all (below it: stay on the CPU `msm()`).  The
+ * reference issues thousands of tiny MSMs through this same trait -- IPA's CommitmentKeyExtTrait::fold is n/2
+ * two-point MSMs per round (src/provider/pedersen.rs:484-497), msm() itself switches to msm_simple for n <= 16
+ * (src/provider/msm.rs:233-235) -- and one GPU MSM costs 0.2-0.3 ms whatever its size.  Default 128 (measured
+ * cross-over against the CPU oracle), env NMX_MIN_N overrides.  The library itself accepts any n. */
+size_t nmx_min_gpu_n(int curve);
+/* One-time self-check for the zero-copy layouts (NMX_BASES_MONT / NMX_SCALARS_MONT): the shim passes the raw
+ * in-memory bytes of the curve's standard generator (`G1Affine::generator()`, 64 bytes) and of the scalar
+ * `Scalar::from(value)` (32 bytes); returns NMX_OK iff they are x*2^256 mod p little-endian limbs as the *_MONT
+ * flags assume (halo2curves does not promise repr(C)), NMX_E_FORMAT otherwise.  Pure host code. */
+int nmx_check_layout(int curve, const void* generator_raw64, const void* scalar_raw32, uint64_t value);
+/* Monotonic counters of this process (cap >= NMX_STAT_COUNT entries are written; returns NMX_STAT_COUNT). */
+enum {
+  NMX_STAT_CACHE_HITS = 0,    /* slice-form calls served by a resident key                                   */
+  NMX_STAT_CACHE_UPLOADS = 1, /* keys uploaded into the slice cache (first sight, or fingerprint mismatch)    */
+  NMX_STAT_CACHE_REGROWS = 2, /* of those: re-registrations because a longer prefix of a known array arrived  */
+  NMX_STAT_CACHE_EVICTIONS = 3,
+  NMX_STAT_CACHE_ENTRIES = 4, /* current                                                                      */
+  NMX_STAT_CACHE_BYTES = 5,   /* current HBM bytes held by the slice cache (keys + tables)                    */
+  NMX_STAT_UNCACHED_CALLS = 6,/* slice-form calls that uploaded their bases for the call only                 */
+  NMX_STAT_BASE_BYTES_H2D = 7,/* bytes of base points copied host -> device by slice-form calls               */
+  NMX_STAT_MSM_CALLS = 8,     /* MSMs run (every entry point; a batch counts each vector)                     */
+  NMX_STAT_COUNT = 9
+};
+int nmx_stats(uint64_t* out, int cap);
 /* same, bases taken from a registered key */
 int nmx_msm_handle(uint64_t handle, size_t offset, const void* scalars, size_t n, uint32_t flags,
                    uint8_t* out, uint8_t* out_is_inf);

@@ -87,7 +87,10 @@ class CommitmentKey {
 
 // `DlogGroupExt` for one curve id (NMX_BN254_G1 / NMX_GRUMPKIN / NMX_PALLAS / NMX_VESTA).
 template <int CURVE> struct DlogGroupExt {
-  // traits.rs:79 == msm() (msm.rs:225): assert_eq!(coeffs.len(), bases.len())
+  // Smallest n worth sending to the GPU; below it the shim keeps the CPU msm() (pedersen.rs:484-497, msm.rs:233)
+  static size_t min_gpu_n() { return nmx_min_gpu_n(CURVE); }
+  // traits.rs:79 == msm() (msm.rs:225): assert_eq!(coeffs.len(), bases.len()).  Slice form: the library's slice cache
+  // keeps `bases` resident (window tables included) keyed by bases.data(); a prefix of the same vector hits it.
   static Point vartime_multiscalar_mul(const std::vector<Scalar>& scalars, const std::vector<Affine>& bases,
                                        bool mont = false) {
     if (scalars.size() != bases.size()) throw std::invalid_argument("assert_eq!(coeffs.len(), bases.len())");

@@ -7,6 +7,10 @@ SO_PATH = os.path.join(_HERE, "libnova_mi355x.so")
 
 # flags / error codes (include/nova_mi355x.h)
 SCALARS_MONT, BASES_MONT, SCALARS_DEVICE, BASES_DEVICE, OUT_PARTIAL, BASES_PRECOMPUTE, BASES_VALIDATE = 1, 2, 4, 8, 16, 32, 64
+BASES_NOCACHE = 128
+# nmx_stats indices
+(STAT_CACHE_HITS, STAT_CACHE_UPLOADS, STAT_CACHE_REGROWS, STAT_CACHE_EVICTIONS, STAT_CACHE_ENTRIES, STAT_CACHE_BYTES,
+ STAT_UNCACHED_CALLS, STAT_BASE_BYTES_H2D, STAT_MSM_CALLS, STAT_COUNT) = range(10)
 E_ARG, E_NO_DEVICE, E_HIP, E_SCALAR_RANGE, E_SMALL_RANGE, E_HANDLE, E_TOO_LARGE = -1, -2, -3, -4, -5, -6, -7
 E_IO, E_FORMAT, E_POINT = -8, -9, -10
 BITS_AUTO = 0xFFFFFFFF
@@ -74,5 +78,19 @@ def lib():
     L.nmx_set_profiling.argtypes = [i]
     L.nmx_profile_last.argtypes = [ctypes.POINTER(ctypes.c_float), i]
     L.nmx_set_window_bits.argtypes = [u32]
+    L.nmx_cache_clear.argtypes = []
+    L.nmx_cache_invalidate.argtypes = [vp]
+    L.nmx_cache_configure.argtypes = [sz, sz, sz]
+    L.nmx_min_gpu_n.argtypes = [i]
+    L.nmx_min_gpu_n.restype = sz
+    L.nmx_check_layout.argtypes = [i, vp, vp, u64]
+    L.nmx_stats.argtypes = [ctypes.POINTER(u64), i]
     _lib = L
     return L
+
+
+def stats():
+    """nmx_stats as a list indexed by the STAT_* constants."""
+    buf = (ctypes.c_uint64 * STAT_COUNT)()
+    lib().nmx_stats(buf, STAT_COUNT)
+    return list(buf)

@@ -2,6 +2,7 @@
 // per-curve operation tables (curve_*.hip).  No group arithmetic and no CPU fallback in this file.
 #include <algorithm>
 #include <atomic>
+#include <list>
 #include <thread>
 
 #include "runtime.hpp"
@@ -9,6 +10,21 @@
 namespace nmx {
 
 Global G;
+static std::atomic<uint64_t> g_stats[NMX_STAT_COUNT];
+static inline void stat_add(int k, uint64_t v = 1) { g_stats[k].fetch_add(v, std::memory_order_relaxed); }
+
+BaseSet::~BaseSet() {
+  if (d && owns) {
+    (void)hipSetDevice(G.device);
+    (void)hipFree(d);
+  }
+}
+Global::SparseSet::~SparseSet() {
+  if (indptr || indices || data) (void)hipSetDevice(G.device);
+  if (indptr) (void)hipFree(indptr);
+  if (indices) (void)hipFree(indices);
+  if (data) (void)hipFree(data);
+}
 static thread_local std::string t_err;
 static thread_local float t_prof[kMaxMarks];
 static thread_local int t_prof_n = 0;
@@ -40,6 +56,7 @@ void aux_reserve(Ctx& c, size_t bytes) {
   c.aux_cap = bytes + (1u << 16);
 }
 
+static void cache_init_defaults();  // slice-cache budget from the device's HBM size / the environment (below)
 static void ensure_init() {
   std::lock_guard<std::mutex> lk(G.mu);
   if (G.inited) return;
@@ -56,9 +73,15 @@ static void ensure_init() {
   G.device = dev;
   if (const char* t = getenv("NMX_TUNE_LMAX")) G.force_lmax = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_PRECOMP_MIN_N")) G.precomp_min_n = (size_t)atoll(t);
-  if (const char* t = getenv("NMX_TUNE_FOLD_T")) G.force_fold_t = (uint32_t)atoi(t);
+  if (const char* t = getenv("NMX_TUNE_FOLD_T")) {
+    // the middle fold pass takes 2..63 lanes per bucket (1 = no middle pass); anything else would make the last
+    // pass re-add positions the 64-lane pass already folded -- a tuning knob must not change results
+    const int v = atoi(t);
+    G.force_fold_t = v < 1 ? 0u : v > 63 ? 63u : (uint32_t)v;
+  }
   if (const char* t = getenv("NMX_TUNE_NO_QUAD_ACCUM")) G.no_quad_accum = (uint32_t)atoi(t);
   HIPCHK(hipSetDevice(dev));
+  cache_init_defaults();
   G.inited = true;
 }
 
@@ -98,17 +121,28 @@ static const CurveOps& ops(int curve) {
   throw Fail{NMX_E_ARG, "bad curve id"};
 }
 
-static BaseSet lookup(uint64_t h) {
+// A reference to the key: the caller's copy keeps the HBM allocation alive for the duration of its call even if
+// another thread unregisters the handle meanwhile.
+static BaseRef lookup(uint64_t h) {
   std::lock_guard<std::mutex> lk(G.mu);
   auto it = G.bases.find(h);
   if (it == G.bases.end()) throw Fail{NMX_E_HANDLE, "unknown base handle"};
   return it->second;
 }
-static uint64_t publish(const BaseSet& bs) {
+static uint64_t publish(std::shared_ptr<BaseSet> bs) {
   std::lock_guard<std::mutex> lk(G.mu);
   uint64_t h = G.next_handle++;
-  G.bases[h] = bs;
+  G.bases[h] = std::move(bs);
   return h;
+}
+// key[offset, offset + n) inside the registered key?  Written so that offset + n cannot wrap (the Rust slice would
+// have panicked; a C caller must get an error, not an out-of-bounds HBM read).
+static inline bool slice_ok(const BaseSet& bs, size_t offset, size_t n) { return offset <= bs.n && n <= bs.n - offset; }
+// upload / generate a key and wrap it
+template <class Make> static std::shared_ptr<BaseSet> make_key(int curve, size_t n, Make&& make) {
+  auto bs = std::make_shared<BaseSet>(curve, n);
+  bs->d = make(&bs->pre_c, &bs->pre_W);
+  return bs;
 }
 
 struct OrFn {  // OR of all u64 scalars -> bit length of the maximum
@@ -158,15 +192,190 @@ template <class Fn> static int guarded(Fn&& fn) {
   }
 }
 
-struct TempBases {  // RAII for one-shot uploads
-  void* d = nullptr;
-  ~TempBases() {
-    if (d) (void)hipFree(d);
-  }
-};
-
 static MsmCall field_call(const void* scalars, uint32_t flags) {
   return MsmCall{scalars, (flags & NMX_SCALARS_DEVICE) != 0, (flags & NMX_SCALARS_MONT) != 0, 0, false};
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Slice cache: device residency for the trait's slice-form calls (include/nova_mi355x.h, "Slice form").
+// The reference passes `&ck.ck[..n]` (pedersen.rs:267, hyperkzg.rs:588) -- the address of element 0 of one long-lived
+// Vec for every n -- so (curve, layout, address) names the key and sampled content fingerprints confirm it.
+// ---------------------------------------------------------------------------------------------------
+static inline uint64_t point_hash(const void* p64) {
+  uint64_t w[8], h = 0x9e3779b97f4a7c15ull;
+  memcpy(w, p64, 64);
+  for (int i = 0; i < 8; i++) {
+    h = (h ^ w[i]) * 0xff51afd7ed558ccdull;
+    h ^= h >> 29;
+  }
+  return h;
+}
+// Arrays up to this many points are verified in full on every call (stride-1 grid); longer ones by sampling.
+static constexpr size_t kFullVerifyBelow = 2048;
+struct SliceEntry {
+  int curve;
+  uint32_t mont;
+  const uint8_t* host;  // address of element 0 (identity only; dereferenced solely through a live caller slice)
+  size_t n;
+  size_t stride;             // fingerprint grid: hashes of points 0, stride, 2*stride, ... and of point n - 1
+  std::vector<uint64_t> fp;  // fp[k] = hash(point k * stride); fp.back() = hash(point n - 1)
+  std::shared_ptr<BaseSet> bs;
+  uint64_t tick = 0, probes = 0;
+  size_t grid() const { return fp.size() - 1; }
+  void fingerprint() {
+    stride = n <= 4096 ? 1 : (n + 4095) / 4096;
+    const size_t g = (n + stride - 1) / stride;
+    fp.resize(g + 1);
+    for (size_t k = 0; k < g; k++) fp[k] = point_hash(host + 64 * k * stride);
+    fp[g] = point_hash(host + 64 * (n - 1));
+  }
+  // Do the caller's bytes for points [off, off + m) still match?  First and last grid point inside the range, the
+  // very last point when the whole array is used, and six grid points that move from call to call.
+  bool matches(const uint8_t* slice, size_t off, size_t m) {
+    if (m == 0) return true;
+    const size_t g = grid();
+    if (n <= kFullVerifyBelow) {  // short arrays (<= 128 KiB): every point, ~10 us
+      for (size_t i = 0; i < m; i++)
+        if (point_hash(slice + 64 * i) != fp[off + i]) return false;
+      return true;
+    }
+    const size_t k_lo = (off + stride - 1) / stride, k_hi = (off + m - 1) / stride;  // grid points in range: [k_lo, k_hi]
+    if (off + m == n && point_hash(slice + 64 * (m - 1)) != fp[g]) return false;
+    if (k_lo > k_hi) return true;  // no grid point inside a very short interior slice
+    auto ok = [&](size_t k) { return point_hash(slice + 64 * (k * stride - off)) == fp[k]; };
+    if (!ok(k_lo) || !ok(k_hi)) return false;  // k_hi * stride <= off + m - 1 <= n - 1: always a grid point
+    const size_t span = k_hi - k_lo + 1;
+    uint64_t x = 0x2545f4914f6cdd1dull * (++probes);
+    for (int j = 0; j < 6; j++) {
+      x ^= x >> 12, x ^= x << 25, x ^= x >> 27;
+      if (!ok(k_lo + (size_t)((x * 0x2545f4914f6cdd1dull) >> 33) % span)) return false;
+    }
+    return true;
+  }
+};
+static struct SliceCache {
+  std::mutex mu;         // entries, budget
+  std::mutex upload_mu;  // one miss at a time: two rayon workers committing to the same key upload it once
+  std::list<SliceEntry> entries;
+  size_t bytes = 0, max_bytes = 0, min_n = 128, max_entries = 32;
+  uint64_t clock = 0;
+} SC;
+
+static void cache_init_defaults() {
+  std::lock_guard<std::mutex> ck(SC.mu);
+  if (SC.max_bytes == 0) {
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    SC.max_bytes = total_b / 4;
+  }
+  if (const char* t = getenv("NMX_CACHE_BYTES")) SC.max_bytes = (size_t)atoll(t);
+  if (const char* t = getenv("NMX_CACHE_MIN_N")) SC.min_n = (size_t)atoll(t);
+}
+static void cache_publish_gauges() {  // SC.mu held
+  g_stats[NMX_STAT_CACHE_ENTRIES].store(SC.entries.size(), std::memory_order_relaxed);
+  g_stats[NMX_STAT_CACHE_BYTES].store(SC.bytes, std::memory_order_relaxed);
+}
+static void cache_erase(std::list<SliceEntry>::iterator it) {  // SC.mu held; in-flight users keep the BaseSet alive
+  SC.bytes -= it->bs->bytes();
+  SC.entries.erase(it);
+}
+struct SliceKey {
+  BaseRef bs;  // null: not cacheable, upload for this call only
+  size_t offset = 0;
+};
+// hit: the resident key and the offset of `bases` inside it
+static bool cache_find(int curve, uint32_t mont, const uint8_t* bases, size_t n, SliceKey* out, bool* grow) {
+  std::lock_guard<std::mutex> lk(SC.mu);
+  *grow = false;
+  for (auto it = SC.entries.begin(); it != SC.entries.end(); ++it) {
+    SliceEntry& e = *it;
+    if (e.curve != curve || e.mont != mont) continue;
+    if (bases < e.host || bases >= e.host + 64 * e.n || ((size_t)(bases - e.host) & 63)) continue;
+    const size_t off = (size_t)(bases - e.host) / 64;
+    if (n > e.n - off) {  // reaches past the resident part
+      if (off == 0) {     // a longer prefix of a known array: re-register at the new length
+        *grow = e.matches(bases, 0, e.n);
+        cache_erase(it);
+        cache_publish_gauges();
+        return false;
+      }
+      continue;
+    }
+    if (!e.matches(bases, off, n)) {  // same address, different content: the array was freed and reused
+      cache_erase(it);
+      cache_publish_gauges();
+      return false;
+    }
+    e.tick = ++SC.clock;
+    out->bs = e.bs;
+    out->offset = off;
+    return true;
+  }
+  return false;
+}
+static SliceKey slice_key(Ctx& c, const CurveOps& o, int curve, const void* bases, size_t n, uint32_t flags) {
+  SliceKey k;
+  if ((flags & (NMX_BASES_NOCACHE | NMX_BASES_DEVICE)) || n == 0) return k;
+  const uint32_t mont = (flags & NMX_BASES_MONT) ? 1u : 0u;
+  const uint8_t* b = (const uint8_t*)bases;
+  bool grow = false;
+  if (cache_find(curve, mont, b, n, &k, &grow)) {
+    stat_add(NMX_STAT_CACHE_HITS);
+    return k;
+  }
+  if (n < SC.min_n) return k;
+  std::lock_guard<std::mutex> up(SC.upload_mu);
+  bool grow2 = false;
+  if (cache_find(curve, mont, b, n, &k, &grow2)) {  // another thread uploaded it while this one waited
+    stat_add(NMX_STAT_CACHE_HITS);
+    return k;
+  }
+  SliceEntry e;
+  e.curve = curve;
+  e.mont = mont;
+  e.host = b;
+  e.n = n;
+  e.fingerprint();
+  e.bs = make_key(curve, n, [&](uint32_t* pc, uint32_t* pw) {
+    return o.upload(c, bases, n, (flags & NMX_BASES_MONT) | NMX_BASES_PRECOMPUTE, pc, pw, nullptr);
+  });
+  stat_add(NMX_STAT_CACHE_UPLOADS);
+  if (grow || grow2) stat_add(NMX_STAT_CACHE_REGROWS);
+  stat_add(NMX_STAT_BASE_BYTES_H2D, n * 64);
+  k.bs = e.bs;
+  k.offset = 0;
+  std::lock_guard<std::mutex> lk(SC.mu);
+  e.tick = ++SC.clock;
+  SC.bytes += e.bs->bytes();
+  SC.entries.push_back(std::move(e));
+  while (SC.entries.size() > 1 && (SC.bytes > SC.max_bytes || SC.entries.size() > SC.max_entries)) {
+    auto lru = SC.entries.begin();
+    for (auto it = SC.entries.begin(); it != SC.entries.end(); ++it)
+      if (it->tick < lru->tick) lru = it;
+    cache_erase(lru);
+    stat_add(NMX_STAT_CACHE_EVICTIONS);
+  }
+  cache_publish_gauges();
+  return k;
+}
+// One-shot upload for a slice-form call that bypasses the cache (short arrays, NMX_BASES_NOCACHE): plain path, no
+// tables; freed when the call returns.
+static std::shared_ptr<BaseSet> temp_key(Ctx& c, const CurveOps& o, int curve, const void* bases, size_t n,
+                                         uint32_t flags) {
+  stat_add(NMX_STAT_UNCACHED_CALLS);
+  if (!(flags & NMX_BASES_DEVICE)) stat_add(NMX_STAT_BASE_BYTES_H2D, n * 64);
+  return make_key(curve, n, [&](uint32_t* pc, uint32_t* pw) {
+    return o.upload(c, bases, n, flags & ~(uint32_t)NMX_BASES_PRECOMPUTE, pc, pw, nullptr);
+  });
+}
+// the resident (or one-shot) key behind a slice-form call
+static SliceKey resolve_slice(Ctx& c, const CurveOps& o, int curve, const void* bases, size_t n, uint32_t flags) {
+  SliceKey k = slice_key(c, o, curve, bases, n, flags);
+  if (!k.bs) {
+    k.bs = temp_key(c, o, curve, bases, n, flags);
+    k.offset = 0;
+  }
+  return k;
 }
 
 }  // namespace nmx
@@ -192,15 +401,14 @@ int nmx_shutdown(void) {
     std::lock_guard<std::mutex> lk(G.mu);
     if (!G.inited) return;
     (void)hipSetDevice(G.device);
-    for (auto& kv : G.bases)
-      if (kv.second.d) (void)hipFree(kv.second.d);
-    G.bases.clear();
-    for (auto& kv : G.sparse) {
-      (void)hipFree(kv.second.indptr);
-      (void)hipFree(kv.second.indices);
-      (void)hipFree(kv.second.data);
-    }
+    G.bases.clear();  // the shared_ptr destructors free the HBM
     G.sparse.clear();
+    {
+      std::lock_guard<std::mutex> ck(SC.mu);
+      SC.entries.clear();
+      SC.bytes = 0;
+      cache_publish_gauges();
+    }
     for (Ctx* c : G.all_ctx) {
       if (c->arena) (void)hipFree(c->arena);
       if (c->aux) (void)hipFree(c->aux);
@@ -230,9 +438,9 @@ int nmx_bases_register(int curve, const void* bases, size_t n, uint32_t flags, u
     require(handle && (bases || n == 0), NMX_E_ARG, "null argument");
     const CurveOps& o = ops(curve);
     CtxLease L;
-    BaseSet bs{curve, n, nullptr, 0, 0};
-    bs.d = o.upload(*L.c, bases, n, flags, &bs.pre_c, &bs.pre_W, nullptr);
-    *handle = publish(bs);
+    *handle = publish(make_key(curve, n, [&](uint32_t* pc, uint32_t* pw) {
+      return o.upload(*L.c, bases, n, flags, pc, pw, nullptr);
+    }));
   });
 }
 
@@ -249,11 +457,11 @@ int nmx_bases_register_ptau(int curve, const char* path, size_t num_g1, size_t n
     ptau_read_header(fc.f, o.base_modulus_words, num_g1, num_g2);
     seek_to(fc.f, meta.pos_tau_g1);
     CtxLease L;
-    BaseSet bs{curve, num_g1, nullptr, 0, 0};
     const BaseFill fill = file_fill(fc.f, num_g1);
     const uint32_t fl = (flags & NMX_BASES_PRECOMPUTE) | NMX_BASES_MONT | NMX_BASES_VALIDATE;
-    bs.d = o.upload(*L.c, nullptr, num_g1, fl, &bs.pre_c, &bs.pre_W, &fill);
-    *handle = publish(bs);
+    *handle = publish(make_key(curve, num_g1, [&](uint32_t* pc, uint32_t* pw) {
+      return o.upload(*L.c, nullptr, num_g1, fl, pc, pw, &fill);
+    }));
   });
 }
 
@@ -274,28 +482,25 @@ int nmx_bases_register_keyfile(int curve, const char* path, size_t n, uint32_t f
     require(o.check_point_host(h_raw, NMX_BASES_MONT, h_canon), NMX_E_POINT,
             "PointNotOnCurve: h is not canonical or not on the curve");
     CtxLease L;
-    BaseSet bs{curve, n, nullptr, 0, 0};
     const BaseFill fill = file_fill(fc.f, n);
     const uint32_t fl = (flags & NMX_BASES_PRECOMPUTE) | NMX_BASES_MONT | NMX_BASES_VALIDATE;
-    bs.d = o.upload(*L.c, nullptr, n, fl, &bs.pre_c, &bs.pre_W, &fill);
+    auto bs = make_key(curve, n, [&](uint32_t* pc, uint32_t* pw) { return o.upload(*L.c, nullptr, n, fl, pc, pw, &fill); });
     memcpy(h_xy64, h_canon, 64);
-    *handle = publish(bs);
+    *handle = publish(std::move(bs));
   });
 }
 
 int nmx_bases_unregister(uint64_t handle) {
   return guarded([&] {
     ensure_init();
-    BaseSet bs;
+    std::shared_ptr<BaseSet> bs;  // dropped outside the lock; the HBM is freed when the last in-flight call lets go
     {
       std::lock_guard<std::mutex> lk(G.mu);
       auto it = G.bases.find(handle);
       if (it == G.bases.end()) throw Fail{NMX_E_HANDLE, "unknown base handle"};
-      bs = it->second;
+      bs = std::move(it->second);
       G.bases.erase(it);
     }
-    HIPCHK(hipSetDevice(G.device));
-    if (bs.d) HIPCHK(hipFree(bs.d));
   });
 }
 
@@ -303,12 +508,12 @@ int nmx_bases_read(uint64_t handle, size_t offset, size_t n, void* out_xy64) {
   return guarded([&] {
     require(out_xy64 || n == 0, NMX_E_ARG, "null argument");
     auto bs = lookup(handle);
-    require(offset + n <= bs.n, NMX_E_HANDLE, "offset + n beyond the registered key");
+    require(slice_ok(*bs, offset, n), NMX_E_HANDLE, "offset + n beyond the registered key");
     CtxLease L;
-    HIPCHK(hipMemcpyAsync(out_xy64, (const char*)bs.d + offset * 64, n * 64, hipMemcpyDeviceToHost,
+    HIPCHK(hipMemcpyAsync(out_xy64, (const char*)bs->d + offset * 64, n * 64, hipMemcpyDeviceToHost,
                           L.c->stream));
     HIPCHK(hipStreamSynchronize(L.c->stream));
-    ops(bs.curve).internal_to_canonical((uint8_t*)out_xy64, 2 * n);
+    ops(bs->curve).internal_to_canonical((uint8_t*)out_xy64, 2 * n);
   });
 }
 
@@ -318,9 +523,7 @@ int nmx_bases_generate(int curve, uint64_t k0, size_t n, uint32_t flags, uint64_
     require(n < (1ull << 31) && k0 < (1ull << 62), NMX_E_ARG, "k0 / n out of range");
     const CurveOps& o = ops(curve);
     CtxLease L;
-    BaseSet bs{curve, n, nullptr, 0, 0};
-    bs.d = o.generate(*L.c, k0, n, flags, &bs.pre_c, &bs.pre_W);
-    *handle = publish(bs);
+    *handle = publish(make_key(curve, n, [&](uint32_t* pc, uint32_t* pw) { return o.generate(*L.c, k0, n, flags, pc, pw); }));
   });
 }
 
@@ -329,9 +532,10 @@ int nmx_msm_handle(uint64_t handle, size_t offset, const void* scalars, size_t n
   return guarded([&] {
     require(out && (scalars || n == 0), NMX_E_ARG, "null argument");
     auto bs = lookup(handle);
-    require(offset + n <= bs.n, NMX_E_HANDLE, "offset + n beyond the registered key");
+    require(slice_ok(*bs, offset, n), NMX_E_HANDLE, "offset + n beyond the registered key");
     CtxLease L;
-    ops(bs.curve).msm_key(*L.c, bs, offset, n, field_call(scalars, flags), flags, out, out_is_inf);
+    stat_add(NMX_STAT_MSM_CALLS);
+    ops(bs->curve).msm_key(*L.c, *bs, offset, n, field_call(scalars, flags), flags, out, out_is_inf);
   });
 }
 
@@ -341,10 +545,9 @@ int nmx_msm(int curve, const void* scalars, const void* bases, size_t n, uint32_
     require(out && ((scalars && bases) || n == 0), NMX_E_ARG, "null argument");
     const CurveOps& o = ops(curve);
     CtxLease L;
-    TempBases tb;
-    uint32_t pc, pw;
-    tb.d = o.upload(*L.c, bases, n, flags & ~(uint32_t)NMX_BASES_PRECOMPUTE, &pc, &pw, nullptr);
-    o.msm_plain(*L.c, tb.d, n, field_call(scalars, flags), flags, out, out_is_inf);
+    const SliceKey k = resolve_slice(*L.c, o, curve, bases, n, flags);
+    stat_add(NMX_STAT_MSM_CALLS);
+    o.msm_key(*L.c, *k.bs, k.offset, n, field_call(scalars, flags), flags, out, out_is_inf);
   });
 }
 
@@ -353,12 +556,13 @@ int nmx_msm_u64_handle(uint64_t handle, size_t offset, const uint64_t* scalars, 
   return guarded([&] {
     require(out && (scalars || n == 0), NMX_E_ARG, "null argument");
     auto bs = lookup(handle);
-    require(offset + n <= bs.n, NMX_E_HANDLE, "offset + n beyond the registered key");
+    require(slice_ok(*bs, offset, n), NMX_E_HANDLE, "offset + n beyond the registered key");
     CtxLease L;
     bool dev = (flags & NMX_SCALARS_DEVICE) != 0;
     uint32_t bits = resolve_u64_bits(*L.c, scalars, n, dev, max_num_bits);
     MsmCall mc{scalars, dev, false, bits, true};
-    ops(bs.curve).msm_key(*L.c, bs, offset, n, mc, flags, out, out_is_inf);
+    stat_add(NMX_STAT_MSM_CALLS);
+    ops(bs->curve).msm_key(*L.c, *bs, offset, n, mc, flags, out, out_is_inf);
   });
 }
 
@@ -368,13 +572,12 @@ int nmx_msm_u64(int curve, const uint64_t* scalars, const void* bases, size_t n,
     require(out && ((scalars && bases) || n == 0), NMX_E_ARG, "null argument");
     const CurveOps& o = ops(curve);
     CtxLease L;
-    TempBases tb;
     bool dev = (flags & NMX_SCALARS_DEVICE) != 0;
     uint32_t bits = resolve_u64_bits(*L.c, scalars, n, dev, max_num_bits);
     MsmCall mc{scalars, dev, false, bits, true};
-    uint32_t pc, pw;
-    tb.d = o.upload(*L.c, bases, n, flags & ~(uint32_t)NMX_BASES_PRECOMPUTE, &pc, &pw, nullptr);
-    o.msm_plain(*L.c, tb.d, n, mc, flags, out, out_is_inf);
+    const SliceKey k = resolve_slice(*L.c, o, curve, bases, n, flags);
+    stat_add(NMX_STAT_MSM_CALLS);
+    o.msm_key(*L.c, *k.bs, k.offset, n, mc, flags, out, out_is_inf);
   });
 }
 
@@ -386,14 +589,15 @@ int nmx_msm_sparse_handle(uint64_t handle, const uint64_t* indices, const void* 
     auto bs = lookup(handle);
     std::vector<uint32_t> idx(k ? k : 1);
     for (size_t i = 0; i < k; i++) {
-      require(indices[i] < bs.n, NMX_E_HANDLE, "index beyond the registered key");  // ck.ck[i] would panic
+      require(indices[i] < bs->n, NMX_E_HANDLE, "index beyond the registered key");  // ck.ck[i] would panic
       idx[i] = (uint32_t)indices[i];
     }
     CtxLease L;
     MsmCall mc = scalars ? field_call(scalars, flags) : MsmCall{nullptr, false, false, 1, true};
     mc.gather_host = idx.data();
     mc.all_ones = scalars == nullptr;
-    ops(bs.curve).msm_key(*L.c, bs, 0, k, mc, flags, out, out_is_inf);
+    stat_add(NMX_STAT_MSM_CALLS);
+    ops(bs->curve).msm_key(*L.c, *bs, 0, k, mc, flags, out, out_is_inf);
   });
 }
 
@@ -402,13 +606,20 @@ int nmx_msm_sparse_handle(uint64_t handle, const uint64_t* indices, const void* 
 // the GPU -- the latency-bound fold / reduction passes of one run under the accumulate kernel of another
 // (profiles/r01_msm_2p20/concurrent_callers.txt: 1.5-1.7x for the short vectors of a HyperKZG batch_commit).
 static constexpr size_t kBatchLanes = 4;
-static void batch_impl(const BaseSet& bs, const void* const* vecs, const size_t* lens, size_t k, uint32_t flags,
-                       uint8_t* out, uint8_t* out_is_inf, Ctx& c) {
+struct JoinAll {  // unwinding must never destroy a joinable std::thread (std::terminate)
+  std::vector<std::thread>& th;
+  ~JoinAll() {
+    for (auto& t : th)
+      if (t.joinable()) t.join();
+  }
+};
+static void batch_impl(const BaseSet& bs, size_t base_off, size_t n_bases, const void* const* vecs, const size_t* lens,
+                       size_t k, uint32_t flags, uint8_t* out, uint8_t* out_is_inf, Ctx& c) {
   require((vecs && lens && out) || k == 0, NMX_E_ARG, "null argument");
   require(!(flags & NMX_OUT_PARTIAL), NMX_E_ARG, "NMX_OUT_PARTIAL is not supported for batches");
   const CurveOps& o = ops(bs.curve);
   for (size_t j = 0; j < k; j++) {
-    require(lens[j] <= bs.n, NMX_E_ARG, "vector longer than the base array");  // traits.rs:88 slices bases[..len]
+    require(lens[j] <= n_bases, NMX_E_ARG, "vector longer than the base array");  // traits.rs:88 slices bases[..len]
     require(vecs[j] || lens[j] == 0, NMX_E_ARG, "null scalar vector");
   }
   std::vector<size_t> order(k);
@@ -420,39 +631,55 @@ static void batch_impl(const BaseSet& bs, const void* const* vecs, const size_t*
   std::mutex err_mu;
   bool failed = false;
   Fail first_fail{0, ""};
-  auto worker = [&](Ctx* ctx) {
-    for (;;) {
-      size_t i = next.fetch_add(1);
-      if (i >= k) return;
-      size_t j = order[i];
-      try {
-        o.msm_key(*ctx, bs, 0, lens[j], field_call(vecs[j], flags), flags, tmp.data() + 64 * j, tinf.data() + j);
-      } catch (const Fail& f) {
-        std::lock_guard<std::mutex> lk(err_mu);
-        if (!failed) first_fail = f;
-        failed = true;
-        return;
+  auto record = [&](const Fail& f) {
+    std::lock_guard<std::mutex> lk(err_mu);
+    if (!failed) first_fail = f;
+    failed = true;
+  };
+  // nothing may escape a worker: an exception leaving a std::thread body is std::terminate in the host process
+  auto guarded_worker = [&](Ctx* ctx) {
+    try {
+      for (;;) {
+        size_t i = next.fetch_add(1);
+        if (i >= k) return;
+        size_t j = order[i];
+        stat_add(NMX_STAT_MSM_CALLS);
+        o.msm_key(*ctx, bs, base_off, lens[j], field_call(vecs[j], flags), flags, tmp.data() + 64 * j, tinf.data() + j);
       }
+    } catch (const Fail& f) {
+      record(f);
+    } catch (const std::exception& e) {
+      record(Fail{NMX_E_HIP, e.what()});
+    } catch (...) {
+      record(Fail{NMX_E_HIP, "unknown exception in a batch worker"});
     }
   };
   const size_t lanes = k < kBatchLanes ? k : kBatchLanes;
   if (lanes <= 1) {
-    worker(&c);
+    guarded_worker(&c);
   } else {
     std::vector<std::thread> th;
-    for (size_t t = 1; t < lanes; t++)
-      th.emplace_back([&] {
-        try {
-          CtxLease L;
-          worker(L.c);
-        } catch (const Fail& f) {
-          std::lock_guard<std::mutex> lk(err_mu);
-          if (!failed) first_fail = f;
-          failed = true;
-        }
-      });
-    worker(&c);
-    for (auto& t : th) t.join();
+    {
+      JoinAll join{th};
+      try {
+        for (size_t t = 1; t < lanes; t++)
+          th.emplace_back([&] {
+            try {
+              CtxLease L;
+              guarded_worker(L.c);
+            } catch (const Fail& f) {
+              record(f);
+            } catch (const std::exception& e) {
+              record(Fail{NMX_E_HIP, e.what()});
+            } catch (...) {
+              record(Fail{NMX_E_HIP, "unknown exception in a batch worker"});
+            }
+          });
+      } catch (const std::exception& e) {  // std::system_error from thread creation: run with the lanes we have
+        record(Fail{NMX_E_HIP, std::string("cannot start a batch worker thread: ") + e.what()});
+      }
+      guarded_worker(&c);
+    }
   }
   if (failed) throw first_fail;
   memcpy(out, tmp.data(), 64 * k);
@@ -464,7 +691,7 @@ int nmx_msm_batch_handle(uint64_t handle, const void* const* scalar_vecs, const 
   return guarded([&] {
     auto bs = lookup(handle);
     CtxLease L;
-    batch_impl(bs, scalar_vecs, lens, k, flags, out, out_is_inf, *L.c);
+    batch_impl(*bs, 0, bs->n, scalar_vecs, lens, k, flags, out, out_is_inf, *L.c);
   });
 }
 
@@ -474,10 +701,13 @@ int nmx_msm_batch(int curve, const void* const* scalar_vecs, const size_t* lens,
     require(bases || n_bases == 0, NMX_E_ARG, "null argument");
     const CurveOps& o = ops(curve);
     CtxLease L;
-    TempBases tb;
-    uint32_t pc, pw;
-    tb.d = o.upload(*L.c, bases, n_bases, flags & ~(uint32_t)NMX_BASES_PRECOMPUTE, &pc, &pw, nullptr);
-    batch_impl(BaseSet{curve, n_bases, tb.d, 0, 0}, scalar_vecs, lens, k, flags, out, out_is_inf, *L.c);
+    if (n_bases == 0) {
+      BaseSet empty(curve, 0);
+      batch_impl(empty, 0, 0, scalar_vecs, lens, k, flags, out, out_is_inf, *L.c);
+      return;
+    }
+    const SliceKey key = resolve_slice(*L.c, o, curve, bases, n_bases, flags);
+    batch_impl(*key.bs, key.offset, n_bases, scalar_vecs, lens, k, flags, out, out_is_inf, *L.c);
   });
 }
 
@@ -486,9 +716,10 @@ int nmx_commit(uint64_t ck_handle, const void* v, size_t n, const void* h_xy64, 
   return guarded([&] {
     require(out && (v || n == 0) && h_xy64 && r, NMX_E_ARG, "null argument");
     auto bs = lookup(ck_handle);
-    require(n <= bs.n, NMX_E_HANDLE, "ck shorter than v");  // assert!(ck.ck.len() >= v.len()), pedersen.rs:264
+    require(n <= bs->n, NMX_E_HANDLE, "ck shorter than v");  // assert!(ck.ck.len() >= v.len()), pedersen.rs:264
     CtxLease L;
-    ops(bs.curve).commit(*L.c, bs, n, field_call(v, flags), h_xy64, r, flags, out, out_is_inf);
+    stat_add(NMX_STAT_MSM_CALLS);
+    ops(bs->curve).commit(*L.c, *bs, n, field_call(v, flags), h_xy64, r, flags, out, out_is_inf);
   });
 }
 
@@ -739,7 +970,9 @@ int nmx_spmv_register(int field, const uint64_t* indptr, const uint64_t* indices
       ix[k] = (uint32_t)indices[k];
     }
     CtxLease L;
-    Global::SparseSet ss{field, rows, cols, nnz, nullptr, nullptr, nullptr};
+    auto sp = std::make_shared<Global::SparseSet>();  // a failure below frees what was allocated (destructor)
+    Global::SparseSet& ss = *sp;
+    ss.field = field, ss.rows = rows, ss.cols = cols, ss.nnz = nnz;
     HIPCHK(hipMalloc((void**)&ss.indptr, (rows + 1) * 4));
     HIPCHK(hipMalloc((void**)&ss.indices, (nnz ? nnz : 1) * 4));
     HIPCHK(hipMalloc((void**)&ss.data, (nnz ? nnz : 1) * 32));
@@ -750,36 +983,33 @@ int nmx_spmv_register(int field, const uint64_t* indptr, const uint64_t* indices
     HIPCHK(hipStreamSynchronize(L.c->stream));
     std::lock_guard<std::mutex> lk(G.mu);
     uint64_t h = G.next_handle++;
-    G.sparse[h] = ss;
+    G.sparse[h] = std::move(sp);
     *handle = h;
   });
 }
 int nmx_spmv_unregister(uint64_t handle) {
   return guarded([&] {
-    Global::SparseSet ss;
+    std::shared_ptr<Global::SparseSet> sp;  // freed when the last in-flight apply lets go
     {
       std::lock_guard<std::mutex> lk(G.mu);
       auto it = G.sparse.find(handle);
       if (it == G.sparse.end()) throw Fail{NMX_E_HANDLE, "unknown matrix handle"};
-      ss = it->second;
+      sp = std::move(it->second);
       G.sparse.erase(it);
     }
-    HIPCHK(hipSetDevice(G.device));
-    (void)hipFree(ss.indptr);
-    (void)hipFree(ss.indices);
-    (void)hipFree(ss.data);
   });
 }
 int nmx_spmv_apply(uint64_t handle, const void* z, size_t z_len, uint32_t flags, void* out) {
   return guarded([&] {
     require(z && out, NMX_E_ARG, "null argument");
-    Global::SparseSet ss;
+    std::shared_ptr<Global::SparseSet> sp;
     {
       std::lock_guard<std::mutex> lk(G.mu);
       auto it = G.sparse.find(handle);
       if (it == G.sparse.end()) throw Fail{NMX_E_HANDLE, "unknown matrix handle"};
-      ss = it->second;
+      sp = it->second;
     }
+    const Global::SparseSet& ss = *sp;
     require(z_len == ss.cols, NMX_E_ARG, "invalid shape");  // assert_eq!(self.cols, vector.len(), "invalid shape")
     if (ss.rows == 0) return;
     CtxLease L;
@@ -791,13 +1021,14 @@ int nmx_spmv_apply_pair(uint64_t handle, const void* z1, const void* z2, size_t 
                         void* out2) {
   return guarded([&] {
     require(z1 && z2 && out1 && out2, NMX_E_ARG, "null argument");
-    Global::SparseSet ss;
+    std::shared_ptr<Global::SparseSet> sp;
     {
       std::lock_guard<std::mutex> lk(G.mu);
       auto it = G.sparse.find(handle);
       if (it == G.sparse.end()) throw Fail{NMX_E_HANDLE, "unknown matrix handle"};
-      ss = it->second;
+      sp = it->second;
     }
+    const Global::SparseSet& ss = *sp;
     require(z_len == ss.cols, NMX_E_ARG, "invalid shape for v1 / v2");  // sparse.rs:217-218
     if (ss.rows == 0) return;
     CtxLease L;
@@ -806,7 +1037,7 @@ int nmx_spmv_apply_pair(uint64_t handle, const void* z1, const void* z2, size_t 
 }
 
 int nmx_set_profiling(int on) {
-  G.profiling = on != 0;
+  G.profiling.store(on != 0);
   return NMX_OK;
 }
 int nmx_profile_last(float* ms, int cap) {
@@ -816,8 +1047,56 @@ int nmx_profile_last(float* ms, int cap) {
 }
 int nmx_set_window_bits(uint32_t c) {
   if (c > 24) return NMX_E_ARG;
-  G.force_c = c;
+  G.force_c.store(c);
   return NMX_OK;
+}
+
+int nmx_cache_clear(void) {
+  return guarded([&] {
+    std::lock_guard<std::mutex> up(SC.upload_mu);
+    std::list<SliceEntry> drop;
+    {
+      std::lock_guard<std::mutex> lk(SC.mu);
+      drop.swap(SC.entries);
+      SC.bytes = 0;
+      cache_publish_gauges();
+    }
+  });
+}
+int nmx_cache_invalidate(const void* bases) {
+  return guarded([&] {
+    std::lock_guard<std::mutex> lk(SC.mu);
+    const uint8_t* b = (const uint8_t*)bases;
+    for (auto it = SC.entries.begin(); it != SC.entries.end();) {
+      auto cur = it++;
+      if (b >= cur->host && b < cur->host + 64 * cur->n) cache_erase(cur);
+    }
+    cache_publish_gauges();
+  });
+}
+int nmx_cache_configure(size_t max_bytes, size_t min_n, size_t max_entries) {
+  return guarded([&] {
+    std::lock_guard<std::mutex> lk(SC.mu);
+    if (max_bytes) SC.max_bytes = max_bytes;
+    if (min_n) SC.min_n = min_n;
+    if (max_entries) SC.max_entries = max_entries;
+  });
+}
+size_t nmx_min_gpu_n(int curve) {
+  (void)curve;  // one threshold for the four curves: the floor is launch + dependent-addition latency, not field size
+  if (const char* t = getenv("NMX_MIN_N")) return (size_t)atoll(t);
+  return 128;
+}
+int nmx_check_layout(int curve, const void* generator_raw64, const void* scalar_raw32, uint64_t value) {
+  return guarded([&] {
+    require(generator_raw64 && scalar_raw32, NMX_E_ARG, "null argument");
+    require(ops(curve).check_layout((const uint8_t*)generator_raw64, (const uint8_t*)scalar_raw32, value), NMX_E_FORMAT,
+            "in-memory layout is not 4 x u64 little-endian Montgomery (R = 2^256) limbs: use the canonical byte forms");
+  });
+}
+int nmx_stats(uint64_t* out, int cap) {
+  for (int i = 0; i < NMX_STAT_COUNT && i < cap; i++) out[i] = g_stats[i].load(std::memory_order_relaxed);
+  return NMX_STAT_COUNT;
 }
 
 }  // extern "C"

@@ -80,6 +80,18 @@ template <int CID> struct GenFn {  // P_i = (k0 + i) * G
 // ---------------------------------------------------------------------------------------------------
 // one MSM on the device
 // ---------------------------------------------------------------------------------------------------
+static inline uint64_t shape_hash(const MsmArgs& a, const MsmCall& mc, size_t sbytes) {
+  const uint64_t v[8] = {a.n, a.u64_bits, a.force_c, a.force_lmax, a.force_fold_t, ((uint64_t)a.pre_stride << 8) | a.pre_c,
+                         (uint64_t)(mc.gather_host != nullptr) | (mc.all_ones ? 2u : 0u) | (mc.scalars_device ? 4u : 0u),
+                         sbytes};
+  uint64_t h = 0x9e3779b97f4a7c15ull;
+  for (uint64_t x : v) {
+    h = (h ^ x) * 0xff51afd7ed558ccdull;
+    h ^= h >> 31;
+  }
+  return h | 1u;  // never 0 (= "nothing remembered")
+}
+
 template <int CID>
 static XYZZ<CurveT<CID>::BF> run_msm(Ctx& c, const void* d_bases, size_t n, const MsmCall& mc) {
   using C = CurveT<CID>;
@@ -95,7 +107,7 @@ static XYZZ<CurveT<CID>::BF> run_msm(Ctx& c, const void* d_bases, size_t n, cons
   a.n = (uint32_t)n;
   a.scalars_mont = mc.scalars_mont ? 1u : 0u;
   a.u64_bits = mc.u64_mode ? mc.u64_bits : 0u;
-  a.force_c = G.force_c;
+  a.force_c = G.force_c.load(std::memory_order_relaxed);
   a.force_lmax = G.force_lmax;
   a.force_fold_t = G.force_fold_t;
   a.pre_stride = mc.pre_stride;
@@ -107,11 +119,14 @@ static XYZZ<CurveT<CID>::BF> run_msm(Ctx& c, const void* d_bases, size_t n, cons
     require((uint64_t)n * sh.W < 0xffffffffull && n < 0x7fffffffull, NMX_E_TOO_LARGE,
             "n * windows must be < 2^32");
   }
-  XYZZW wsum[260];
+  c.wsum.resize(260);
+  XYZZW* wsum = c.wsum.data();
   uint32_t err = 0;
   MsmShape sh{};
-  const bool prof = G.profiling;
-  for (int pass = 0; pass < 2; pass++) {
+  const bool prof = G.profiling.load(std::memory_order_relaxed);
+  // The dry pass only sizes the workspace; its answer is a function of the call's shape, remembered per context.
+  const uint64_t shape_key = shape_hash(a, mc, sbytes);
+  for (int pass = (c.shape_key == shape_key && c.shape_bytes <= c.cap) ? 1 : 0; pass < 2; pass++) {
     DeviceBackend be(c, pass == 0, prof);
     if (mc.gather_host) {
       uint32_t* d_g = be.alloc<uint32_t>(n);
@@ -132,6 +147,8 @@ static XYZZ<CurveT<CID>::BF> run_msm(Ctx& c, const void* d_bases, size_t n, cons
     sh = msm_pipeline<DeviceBackend, BF, SF>(be, a, sbits, wsum, &err);
     if (pass == 0) {
       arena_reserve(c, be.used);
+      c.shape_key = shape_key;
+      c.shape_bytes = be.used;
     } else if (prof) {
       float st[kMaxMarks];
       int ns = 0;
@@ -172,7 +189,8 @@ template <int CID> static void table_shape(size_t n, uint32_t flags, uint32_t* p
   *pre_c = 0;
   *pre_W = 0;
   if (!(flags & NMX_BASES_PRECOMPUTE) || n < G.precomp_min_n) return;
-  uint32_t c = G.force_c ? G.force_c : choose_c_precomp((uint32_t)n, FpParams<CurveT<CID>::SF>::BITS);
+  const uint32_t fc = G.force_c.load(std::memory_order_relaxed);
+  uint32_t c = fc ? fc : choose_c_precomp((uint32_t)n, FpParams<CurveT<CID>::SF>::BITS);
   uint32_t W = (FpParams<CurveT<CID>::SF>::BITS + 1 + c - 1) / c;
   if ((uint64_t)W * n >= (1ull << 31)) return;  // table index must fit 31 bits
   *pre_c = c;
@@ -190,6 +208,8 @@ static void* upload_bases(Ctx& c, const void* src, size_t n, uint32_t flags, uin
                           const BaseFill* fill) {
   constexpr int BF = CurveT<CID>::BF;
   void* d = nullptr;
+  // lane counts below are 32-bit: 2 * n conversions, n validations (the file-backed entry points check this too)
+  require(n < (1ull << 31), NMX_E_TOO_LARGE, "key too large (n must be < 2^31)");
   table_shape<CID>(n, flags, pre_c, pre_W);
   if (n == 0) return nullptr;
   HIPCHK(hipMalloc(&d, n * 64 * (*pre_W ? *pre_W : 1)));
@@ -225,16 +245,11 @@ static void* upload_bases(Ctx& c, const void* src, size_t n, uint32_t flags, uin
   return d;
 }
 
-template <int CID>
-static void msm_entry(const void* d_bases, size_t n, const MsmCall& mc, uint32_t flags, uint8_t* out,
-                      uint8_t* is_inf, Ctx& c) {
-  auto r = run_msm<CID>(c, d_bases, n, mc);
-  write_result<CID>(r, flags, out, is_inf);
-}
 // MSM over bs[offset, offset + n): through the key's window tables when it has them and n is large enough
 template <int CID>
 static XYZZ<CurveT<CID>::BF> run_msm_key(Ctx& c, const BaseSet& bs, size_t offset, size_t n, MsmCall mc) {
-  if (bs.pre_W && n >= G.precomp_min_n && (G.force_c == 0 || G.force_c == bs.pre_c)) {
+  const uint32_t fc = G.force_c.load(std::memory_order_relaxed);
+  if (bs.pre_W && n >= G.precomp_min_n && (fc == 0 || fc == bs.pre_c)) {
     mc.pre_stride = (uint32_t)bs.n;
     mc.pre_offset = (uint32_t)offset;
     mc.pre_c = bs.pre_c;
@@ -257,10 +272,6 @@ template <int CID> struct CurveImpl {
   using C = CurveT<CID>;
   static constexpr int BF = C::BF, SF = C::SF;
 
-  static void msm_plain(Ctx& c, const void* d_bases, size_t n, const MsmCall& mc, uint32_t flags, uint8_t* out,
-                        uint8_t* inf) {
-    msm_entry<CID>(d_bases, n, mc, flags, out, inf, c);
-  }
   static void msm_key(Ctx& c, const BaseSet& bs, size_t offset, size_t n, const MsmCall& mc, uint32_t flags,
                       uint8_t* out, uint8_t* inf) {
     msm_key_entry<CID>(bs, offset, n, mc, flags, out, inf, c);
@@ -340,9 +351,25 @@ template <int CID> struct CurveImpl {
     }
     xyzz_to_xy64<BF>(acc, out, inf);
   }
+  // nmx_check_layout: raw bytes of the standard generator and of Scalar::from(value) must be x * 2^256 mod p limbs
+  static bool check_layout(const uint8_t* gen64, const uint8_t* s32, uint64_t value) {
+    uint32_t w[8];
+    for (int k = 0; k < 2; k++) {
+      memcpy(w, gen64 + 32 * k, 32);
+      if (!Fp<BF>::words_lt_p(w)) return false;
+      uint32_t got[8];
+      Fp<BF>::from_words(w).mont256_to_canonical().to_words(got);
+      if (memcmp(got, k ? C::GY : C::GX, 32) != 0) return false;
+    }
+    memcpy(w, s32, 32);
+    if (!Fp<SF>::words_lt_p(w)) return false;
+    uint32_t got[8], want[8] = {(uint32_t)value, (uint32_t)(value >> 32), 0, 0, 0, 0, 0, 0};
+    Fp<SF>::from_words(w).mont256_to_canonical().to_words(got);
+    return memcmp(got, want, 32) == 0;
+  }
   static CurveOps ops() {
-    return CurveOps{&msm_plain, &msm_key, &commit, &upload, &check_point_host, FpParams<BF>::PW,
-                    &generate, &internal_to_canonical, &point_sum};
+    return CurveOps{&msm_key, &commit, &upload, &check_point_host, FpParams<BF>::PW,
+                    &generate, &internal_to_canonical, &point_sum, &check_layout};
   }
 };
 

@@ -154,7 +154,7 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
   }
   {
     PlanFn f{start, end, counters, heavy, big, sh};
-    be.launch(f, sh.nbuckets);
+    be.launch(f, (sh.nbuckets + PlanFn::kPerLane - 1) / PlanFn::kPerLane);  // each lane plans kPerLane buckets
     const uint32_t hb = heavy_cap < sh.nbuckets ? heavy_cap : sh.nbuckets;
     ExpandFn e{start, end, counters, heavy, extra, sh, 64, hb < 16384 ? hb : 16384};
     be.launch(e, e.groups * e.lanes);
@@ -173,7 +173,8 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
     // typical task count per bucket decides the last split: ~22 partials fold fastest as 4 lanes x 6 then 1 x 4
     const uint32_t typical = (uint32_t)(total / ((size_t)sh.nbuckets * sh.lmax));
     uint32_t mid = typical > 32 ? 8u : 4u;
-    if (a.force_fold_t) mid = a.force_fold_t == 1 ? 64 : a.force_fold_t;  // tuning: 1 = no middle pass
+    // tuning: 1 = no middle pass; otherwise 2..63 lanes (a wider middle pass would overlap the 64-lane pass before it)
+    if (a.force_fold_t) mid = a.force_fold_t == 1 ? 64 : (a.force_fold_t > 63 ? 63 : a.force_fold_t);
     const uint32_t Ts[6] = {32768, 4096, 512, 64, mid, 1};
     for (int p = 0; p < 6; p++) {
       const uint32_t T = Ts[p];

@@ -8,10 +8,12 @@
 #include <type_traits>
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -67,15 +69,29 @@ struct Ctx {
   size_t aux_cap = 0;
   hipEvent_t ev[kMaxMarks];
   bool have_ev = false;
+  std::vector<XYZZW> wsum;  // landing buffer of the per-window sums (off the caller's stack)
+  uint64_t shape_key = 0;   // shape of the last MSM sized on this context and the workspace it needs
+  size_t shape_bytes = 0;
 };
 
+// A key resident in HBM.  Owned through shared_ptr: the registry (or the slice cache) holds one reference and every
+// in-flight call holds another, so nmx_bases_unregister / a cache eviction on one host thread can never free the
+// device memory under an MSM running on another (the trait is called from rayon workers).
 struct BaseSet {
-  int curve;
-  size_t n;
-  void* d;             // AffineW[pre_W ? pre_W * n : n]: the key (internal form), then its window tables
+  int curve = 0;
+  size_t n = 0;
+  void* d = nullptr;   // AffineW[pre_W ? pre_W * n : n]: the key (internal form), then its window tables
   uint32_t pre_c = 0;  // window width of the tables (0: none)
   uint32_t pre_W = 0;
+  bool owns = true;    // false: `d` belongs to somebody else (one-shot uploads wrapped for batch_impl)
+  BaseSet() = default;
+  BaseSet(int curve_, size_t n_) : curve(curve_), n(n_) {}
+  BaseSet(const BaseSet&) = delete;
+  BaseSet& operator=(const BaseSet&) = delete;
+  size_t bytes() const { return n * 64 * (pre_W ? pre_W : 1); }
+  ~BaseSet();  // capi.hip: hipFree(d) on the library's device
 };
+using BaseRef = std::shared_ptr<const BaseSet>;
 
 // A registered key gets window tables from this many points on, and MSMs over it use them from this many pairs on:
 // everything but the trivial sizes.  (4096 until the small sizes were measured, scripts/gpu_smallmsm.py: with tables a
@@ -87,16 +103,21 @@ struct Global {
   int device = 0;
   std::vector<Ctx*> free_ctx;
   std::vector<Ctx*> all_ctx;
-  std::unordered_map<uint64_t, BaseSet> bases;
+  std::unordered_map<uint64_t, std::shared_ptr<BaseSet>> bases;
   struct SparseSet {  // a CSR matrix resident in HBM (R1CS matrices are fixed per circuit: upload once)
-    int field;
-    size_t rows, cols, nnz;
-    uint32_t *indptr, *indices, *data;
+    int field = 0;
+    size_t rows = 0, cols = 0, nnz = 0;
+    uint32_t *indptr = nullptr, *indices = nullptr, *data = nullptr;
+    SparseSet() = default;
+    SparseSet(const SparseSet&) = delete;
+    SparseSet& operator=(const SparseSet&) = delete;
+    ~SparseSet();  // capi.hip
   };
-  std::unordered_map<uint64_t, SparseSet> sparse;
+  std::unordered_map<uint64_t, std::shared_ptr<SparseSet>> sparse;
   uint64_t next_handle = 1;
-  bool profiling = false;
-  uint32_t force_c = 0;
+  // written by nmx_set_profiling / nmx_set_window_bits while calls on other threads read them
+  std::atomic<bool> profiling{false};
+  std::atomic<uint32_t> force_c{0};
   uint32_t force_lmax = 0;  // env NMX_TUNE_LMAX (tuning only)
   size_t precomp_min_n = kPrecompMinN;  // env NMX_TUNE_PRECOMP_MIN_N (tuning only)
   uint32_t force_fold_t = 0;  // env NMX_TUNE_FOLD_T (tuning only)
@@ -245,9 +266,7 @@ struct MsmCall {
 using BaseFill = std::function<void(void* d_dst, hipStream_t stream)>;
 
 struct CurveOps {
-  // out = sum scalars[i] * bases[i] over device-resident internal-form bases
-  void (*msm_plain)(Ctx&, const void* d_bases, size_t n, const MsmCall&, uint32_t flags, uint8_t* out, uint8_t* inf);
-  // same over key[offset, offset+n), through the key's window tables when it has them
+  // out = sum scalars[i] * key[offset + i], i < n, through the key's window tables when it has them
   void (*msm_key)(Ctx&, const BaseSet&, size_t offset, size_t n, const MsmCall&, uint32_t flags, uint8_t* out,
                   uint8_t* inf);
   // msm_key(v) + h * r
@@ -260,6 +279,7 @@ struct CurveOps {
   void* (*generate)(Ctx&, uint64_t k0, size_t n, uint32_t flags, uint32_t* pre_c, uint32_t* pre_W);
   void (*internal_to_canonical)(uint8_t* elems32, size_t count);  // host, in place
   void (*point_sum)(const uint8_t* partials128, size_t count, uint8_t* out, uint8_t* inf);  // host
+  bool (*check_layout)(const uint8_t* generator_raw64, const uint8_t* scalar_raw32, uint64_t value);  // host
 };
 // field-vector kernels (fieldvec.hip)
 void fv_axpy(Ctx&, int field, const void* a, const void* b, const void* r, size_t n, uint32_t flags, void* out);

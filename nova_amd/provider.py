@@ -163,11 +163,20 @@ class DlogGroup:
         assert curve in CURVE_NAMES
         self.curve = curve
 
+    def min_gpu_n(self):
+        """Smallest n the reference-side shim should send to the GPU (below it the CPU `msm()` wins: IPA's two-point
+        MSMs, src/provider/pedersen.rs:484-497; msm_simple for n <= 16, src/provider/msm.rs:233).  This mirror has no
+        CPU path, so it only reports the rule."""
+        return int(L.lib().nmx_min_gpu_n(self.curve))
+
     # -- vartime_multiscalar_mul (traits.rs:79; msm(), src/provider/msm.rs:225) -------------------------
-    def vartime_multiscalar_mul(self, scalars, bases, mont=False, partial=False, offset=0):
-        """offset: with a CommitmentKey, use bases[offset .. offset + n) of it (`&ck.ck[offset..][..n]`)."""
+    def vartime_multiscalar_mul(self, scalars, bases, mont=False, partial=False, offset=0, nocache=False):
+        """offset: with a CommitmentKey, use bases[offset .. offset + n) of it (`&ck.ck[offset..][..n]`).
+        With a host array (the trait's slice form) the library's slice cache makes the array resident on first
+        sight -- pass the SAME array object (or a prefix view of it) again and no bases move; nocache=True uploads
+        for this call only."""
         sp, n, dev, _k = _scalar_arg(scalars, 32)
-        flags = dev | (L.SCALARS_MONT if mont else 0) | (L.OUT_PARTIAL if partial else 0)
+        flags = dev | (L.SCALARS_MONT if mont else 0) | (L.OUT_PARTIAL if partial else 0) | (L.BASES_NOCACHE if nocache else 0)
         out = _Out(partial=partial)
         if isinstance(bases, CommitmentKey):
             assert bases.curve == self.curve

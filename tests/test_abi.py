@@ -36,7 +36,7 @@ def test_header_symbols_exported(L):
 def test_python_binding_covers_header(L):
     from nova_amd import _lib
     bound = {s for s in declared_symbols() if getattr(getattr(L, s), "argtypes", None) is not None or s in
-             ("nmx_last_error", "nmx_version", "nmx_shutdown", "nmx_device_count")}
+             ("nmx_last_error", "nmx_version", "nmx_shutdown", "nmx_device_count", "nmx_cache_clear")}
     assert bound == set(declared_symbols())
     assert L.nmx_version().decode().startswith("nova-mi355x")
     assert _lib.E_NO_DEVICE == -2
@@ -81,3 +81,25 @@ def test_point_sum_is_host_side_and_matches_oracle(L):
         inf = np.zeros(1, np.uint8)
         assert L.nmx_point_sum(c.cid, buf.ctypes.data, 3, out.ctypes.data, inf.ctypes.data) == 0
         assert (out.tobytes(), int(inf[0])) == cref.msm(c.cid, sc, bases, n)
+
+
+def test_layout_selfcheck_min_n_and_stats_are_host_side(L):
+    """nmx_check_layout (the shim's one-time zero-copy self-check), nmx_min_gpu_n and nmx_stats need no device."""
+    from nova_amd import _lib
+    from oracle import pyref as R
+    Rm = 1 << 256
+    for c in R.CURVES.values():
+        gen = b"".join(((v * Rm) % c.p).to_bytes(32, "little") for v in (c.gx, c.gy))
+        s = ((123456789 * Rm) % c.r).to_bytes(32, "little")
+        assert L.nmx_check_layout(c.cid, gen, s, 123456789) == 0
+        # canonical bytes, a wrong value, swapped coordinates, a non-reduced limb pattern: all rejected
+        canon = b"".join(v.to_bytes(32, "little") for v in (c.gx, c.gy))
+        assert L.nmx_check_layout(c.cid, canon, s, 123456789) == _lib.E_FORMAT
+        assert L.nmx_check_layout(c.cid, gen, s, 123456788) == _lib.E_FORMAT
+        assert L.nmx_check_layout(c.cid, gen[32:] + gen[:32], s, 123456789) == _lib.E_FORMAT
+        assert L.nmx_check_layout(c.cid, b"\xff" * 64, s, 123456789) == _lib.E_FORMAT
+        assert b"Montgomery" in L.nmx_last_error()
+        assert L.nmx_min_gpu_n(c.cid) == int(os.environ.get("NMX_MIN_N", 128))
+    st = _lib.stats()
+    assert len(st) == _lib.STAT_COUNT and all(v >= 0 for v in st)
+    assert L.nmx_check_layout(9, gen, s, 1) == _lib.E_ARG

@@ -1,0 +1,226 @@
+"""The drop-in boundary as the reference calls it (-m gpu): `vartime_multiscalar_mul(&scalars, &ck.ck[..n])` passes a
+SLICE and no handle (/root/reference/src/provider/pedersen.rs:263-270, hyperkzg.rs:584-591, traits.rs:79,
+blitzar.rs:7-20).  The library's slice cache must make that signature reach the resident-key path: one upload per
+array whatever the prefix length, window tables included, results bit-exact against the oracle; and it must never
+serve stale points (content fingerprints), leak under eviction, or upload twice under concurrent first use.
+"""
+import ctypes
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import cref
+from oracle import pyref as R
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def as_pair(com):
+    return (com.xy, int(com.is_inf))
+
+
+@pytest.fixture()
+def fresh(nmx):
+    from nova_amd import _lib
+    L = _lib.lib()
+    assert L.nmx_cache_clear() == 0
+    yield _lib
+    assert L.nmx_cache_clear() == 0
+
+
+def delta(_lib, before):
+    now = _lib.stats()
+    return [a - b for a, b in zip(now, before)]
+
+
+def test_two_prefixes_one_upload(nmx, fresh):
+    """Done-criterion of the boundary row: nmx_msm twice on the same host array with two prefix lengths -> ONE upload,
+    both results == oracle (the second call moves no base bytes)."""
+    S = fresh
+    c = R.BN254_G1
+    n = 1 << 16
+    bases = cref.sequential_bases(c, 77, n)
+    g = nmx.DlogGroup(c.cid)
+    before = S.stats()
+    for m in (n, 13058, n - 1, 4096, 129):          # longest first, then the shapes callers use (prove_step N, n-1 openings)
+        sc = util.random_scalars(c.cid, m, seed=m)
+        assert as_pair(g.vartime_multiscalar_mul(sc, bases[:m])) == cref.msm(c.cid, sc, bases[:m], m), m
+    d = delta(S, before)
+    assert d[S.STAT_CACHE_UPLOADS] == 1 and d[S.STAT_CACHE_REGROWS] == 0
+    assert d[S.STAT_CACHE_HITS] == 4 and d[S.STAT_UNCACHED_CALLS] == 0
+    assert d[S.STAT_BASE_BYTES_H2D] == 64 * n
+    now = S.stats()
+    assert now[S.STAT_CACHE_ENTRIES] == 1 and now[S.STAT_CACHE_BYTES] >= 64 * n * 2   # key + window tables
+
+
+def test_growing_prefix_regrows(nmx, fresh):
+    S = fresh
+    c = R.GRUMPKIN
+    n = 20000
+    bases = cref.sequential_bases(c, 5, n)
+    g = nmx.DlogGroup(c.cid)
+    before = S.stats()
+    for m in (5000, 5000, 10538, n):
+        sc = util.random_scalars(c.cid, m, seed=m)
+        assert as_pair(g.vartime_multiscalar_mul(sc, bases[:m])) == cref.msm(c.cid, sc, bases[:m], m)
+    d = delta(S, before)
+    assert d[S.STAT_CACHE_UPLOADS] == 3 and d[S.STAT_CACHE_REGROWS] == 2 and d[S.STAT_CACHE_HITS] == 1
+    assert S.stats()[S.STAT_CACHE_ENTRIES] == 1
+
+
+def test_interior_slice_small_and_batch_forms_hit(nmx, fresh):
+    """`&ck.ck[a..b]` (commit_small_range, pedersen.rs:285-305), msm_small and batch forms over one resident array."""
+    S = fresh
+    c = R.PALLAS
+    n = 9000
+    bases = cref.sequential_bases(c, 21, n)
+    g = nmx.DlogGroup(c.cid)
+    sc = util.random_scalars(c.cid, n, seed=3)
+    before = S.stats()
+    assert as_pair(g.vartime_multiscalar_mul(sc, bases)) == cref.msm(c.cid, sc, bases, n)
+    a, b = 1234, 8000
+    assert as_pair(g.vartime_multiscalar_mul(sc[: b - a], bases[a:b])) == cref.msm(c.cid, sc[: b - a], bases[a:b], b - a)
+    s64 = util.small_scalars(3000, 20)
+    assert as_pair(g.vartime_multiscalar_mul_small(s64, bases[:3000])) == cref.msm_u64(c.cid, s64, bases[:3000], 3000, 20)
+    lens = [n, n // 2, 17, 0, 4096]
+    vecs = [util.random_scalars(c.cid, m, seed=50 + j) for j, m in enumerate(lens)]
+    got = [as_pair(x) for x in g.batch_vartime_multiscalar_mul(vecs, bases)]
+    assert got == cref.msm_batch(c.cid, [v.tobytes() for v in vecs], bases, n)
+    d = delta(S, before)
+    assert d[S.STAT_CACHE_UPLOADS] == 1 and d[S.STAT_CACHE_HITS] == 3 and d[S.STAT_UNCACHED_CALLS] == 0
+
+
+@pytest.mark.parametrize("n", [1500, 50000])
+def test_reused_address_with_new_content_is_detected(nmx, fresh, n):
+    """A Vec freed and reallocated at the same address must not be served from the old resident copy: overwrite the
+    array in place with a different key (every point changes), same address, same length."""
+    S = fresh
+    c = R.BN254_G1
+    g = nmx.DlogGroup(c.cid)
+    bases = cref.sequential_bases(c, 1000, n).copy()
+    sc = util.random_scalars(c.cid, n, seed=9)
+    assert as_pair(g.vartime_multiscalar_mul(sc, bases)) == cref.msm(c.cid, sc, bases, n)
+    addr = bases.ctypes.data
+    bases[:] = cref.sequential_bases(c, 500000, n)
+    assert bases.ctypes.data == addr
+    before = S.stats()
+    assert as_pair(g.vartime_multiscalar_mul(sc, bases)) == cref.msm(c.cid, sc, bases, n)
+    d = delta(S, before)
+    assert d[S.STAT_CACHE_UPLOADS] == 1 and d[S.STAT_CACHE_HITS] == 0
+    if n <= 2048:   # short arrays are verified in full: a single changed point is caught too
+        bases[n // 3] = cref.sequential_bases(c, 42, 1)[0]
+        assert as_pair(g.vartime_multiscalar_mul(sc, bases)) == cref.msm(c.cid, sc, bases, n)
+    else:           # long arrays: the documented contract is nmx_cache_invalidate after an in-place edit
+        bases[n // 3] = cref.sequential_bases(c, 42, 1)[0]
+        assert S.lib().nmx_cache_invalidate(bases.ctypes.data) == 0
+        assert as_pair(g.vartime_multiscalar_mul(sc, bases)) == cref.msm(c.cid, sc, bases, n)
+
+
+def test_short_arrays_and_nocache_bypass(nmx, fresh):
+    S = fresh
+    c = R.VESTA
+    g = nmx.DlogGroup(c.cid)
+    assert g.min_gpu_n() == 128
+    before = S.stats()
+    for n in (1, 2, 16, 127):                       # below the cache's min_n: one-shot upload, plain path
+        bases = cref.sequential_bases(c, 3, n)
+        sc = util.random_scalars(c.cid, n, seed=n)
+        assert as_pair(g.vartime_multiscalar_mul(sc, bases)) == cref.msm(c.cid, sc, bases, n)
+    n = 5000
+    bases = cref.sequential_bases(c, 3, n)
+    sc = util.random_scalars(c.cid, n, seed=n)
+    assert as_pair(g.vartime_multiscalar_mul(sc, bases, nocache=True)) == cref.msm(c.cid, sc, bases, n)
+    d = delta(S, before)
+    assert d[S.STAT_UNCACHED_CALLS] == 5 and d[S.STAT_CACHE_UPLOADS] == 0
+    assert S.stats()[S.STAT_CACHE_ENTRIES] == 0
+
+
+def test_montgomery_zero_copy_layout_at_2p16(nmx, fresh):
+    """The documented default of the shim: NMX_BASES_MONT | NMX_SCALARS_MONT straight from halo2curves' in-memory
+    limbs (x * 2^256 mod p, little-endian 4 x u64), through the slice cache, at 2^16."""
+    S = fresh
+    c = R.BN254_G1
+    n = 1 << 16
+    bases = cref.sequential_bases(c, 31337, n)
+    sc = util.random_scalars(c.cid, n, seed=4)
+    Rm = 1 << 256
+
+    def mont(rows, mod):
+        out = np.zeros_like(rows)
+        for i, row in enumerate(rows):
+            out[i] = np.frombuffer(((int.from_bytes(bytes(row), "little") * Rm) % mod).to_bytes(32, "little"), np.uint8)
+        return out
+
+    bm = mont(bases.reshape(-1, 32), c.p).reshape(n, 64)
+    sm = mont(sc, c.r)
+    g = nmx.DlogGroup(c.cid)
+    exp = cref.msm(c.cid, sc, bases, n)
+    before = S.stats()
+    assert as_pair(g.vartime_multiscalar_mul(sm, bm, mont=True)) == exp
+    assert as_pair(g.vartime_multiscalar_mul(sm[:40000], bm[:40000], mont=True)) == cref.msm(c.cid, sc[:40000], bases[:40000], 40000)
+    d = delta(S, before)
+    assert d[S.STAT_CACHE_UPLOADS] == 1 and d[S.STAT_CACHE_HITS] == 1
+    # the same address in the OTHER layout is a different key (the flag is part of the identity)
+    assert as_pair(g.vartime_multiscalar_mul(sc, bases)) == exp
+    # layout self-check the shim runs once per curve: raw generator + Scalar::from(7)
+    for cc in R.CURVES.values():
+        gen = b"".join(((v * Rm) % cc.p).to_bytes(32, "little") for v in (cc.gx, cc.gy))
+        seven = ((7 * Rm) % cc.r).to_bytes(32, "little")
+        assert S.lib().nmx_check_layout(cc.cid, gen, seven, 7) == 0
+        assert S.lib().nmx_check_layout(cc.cid, gen, (7).to_bytes(32, "little"), 7) == S.E_FORMAT
+
+
+def test_eviction_under_budget_and_clear(nmx, fresh):
+    S = fresh
+    L = S.lib()
+    c = R.BN254_G1
+    g = nmx.DlogGroup(c.cid)
+    n = 4096
+    arrays = [cref.sequential_bases(c, 10000 * (j + 1), n) for j in range(4)]
+    sc = util.random_scalars(c.cid, n, seed=1)
+    exp = [cref.msm(c.cid, sc, a, n) for a in arrays]
+    assert L.nmx_cache_configure(0, 0, 2) == 0      # at most two resident arrays
+    try:
+        before = S.stats()
+        for rnd in range(2):
+            for a, e in zip(arrays, exp):
+                assert as_pair(g.vartime_multiscalar_mul(sc, a)) == e
+        d = delta(S, before)
+        assert d[S.STAT_CACHE_UPLOADS] == 8 and d[S.STAT_CACHE_EVICTIONS] == 6
+        assert S.stats()[S.STAT_CACHE_ENTRIES] == 2
+        assert as_pair(g.vartime_multiscalar_mul(sc, arrays[3])) == exp[3]      # most recent: still resident
+        assert delta(S, before)[S.STAT_CACHE_UPLOADS] == 8
+    finally:
+        assert L.nmx_cache_configure(0, 0, 32) == 0
+    assert L.nmx_cache_clear() == 0
+    assert S.stats()[S.STAT_CACHE_ENTRIES] == 0 and S.stats()[S.STAT_CACHE_BYTES] == 0
+
+
+def test_concurrent_first_use_uploads_once(nmx, fresh):
+    """rayon::join of two commits over the same ck (r1cs/mod.rs:509-512): eight threads hit a cold array at once."""
+    S = fresh
+    c = R.BN254_G1
+    n = 30000
+    bases = cref.sequential_bases(c, 123, n)
+    g = nmx.DlogGroup(c.cid)
+    lens = [n, 13058, 10538, n - 1, 20000, 4097, n, 999]
+    scs = [util.random_scalars(c.cid, m, seed=70 + j) for j, m in enumerate(lens)]
+    exp = [cref.msm(c.cid, s, bases[:m], m) for s, m in zip(scs, lens)]
+    got = [None] * len(lens)
+    start = threading.Barrier(len(lens))
+
+    def run(j):
+        start.wait()
+        got[j] = as_pair(g.vartime_multiscalar_mul(scs[j], bases[: lens[j]]))
+
+    before = S.stats()
+    ths = [threading.Thread(target=run, args=(j,)) for j in range(len(lens))]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert got == exp
+    d = delta(S, before)
+    # shorter prefixes may arrive first and be regrown: at most one upload per distinct length in growing order
+    assert 1 <= d[S.STAT_CACHE_UPLOADS] <= 7 and S.stats()[S.STAT_CACHE_ENTRIES] == 1
+    assert d[S.STAT_CACHE_UPLOADS] + d[S.STAT_CACHE_HITS] == len(lens)

@@ -1,0 +1,117 @@
+"""C-ABI robustness under rayon-style concurrency (-m gpu).  The trait methods are static and are called from many
+worker threads at once (/root/reference/src/r1cs/mod.rs:509-512, hyperkzg.rs:1062-1065, nova/mod.rs:862-881); a handle
+may be unregistered, or a cached array evicted, on one thread while MSMs over it run on others.  Every call must
+either return the right point or a clean NMX_E_HANDLE -- never a wrong point, a crash or a use-after-free."""
+import ctypes
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import cref
+from oracle import pyref as R
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def test_register_msm_unregister_from_eight_threads(nmx):
+    from nova_amd import _lib
+    L = _lib.lib()
+    c = R.BN254_G1
+    n = 6000
+    bases = cref.sequential_bases(c, 2024, n)
+    lens = [n, 4097, 300, 5999]
+    scs = [util.random_scalars(c.cid, m, seed=m) for m in lens]
+    exp = [cref.msm(c.cid, s, bases[:m], m) for s, m in zip(scs, lens)]
+    shared = {"h": 0}
+    lock = threading.Lock()
+    errors = []
+    stop = threading.Event()
+    counts = {"ok": 0, "stale": 0, "cycles": 0}
+
+    def registrar():
+        """register -> publish -> (others use it) -> unregister while they may still be running -> repeat"""
+        for _ in range(40):
+            h = ctypes.c_uint64(0)
+            rc = L.nmx_bases_register(c.cid, bases.ctypes.data, n, _lib.BASES_PRECOMPUTE, ctypes.byref(h))
+            if rc != 0:
+                errors.append(("register", rc, L.nmx_last_error().decode()))
+                break
+            with lock:
+                old, shared["h"] = shared["h"], h.value
+            if old:
+                rc = L.nmx_bases_unregister(old)     # callers may be in the middle of an MSM over `old`
+                if rc != 0:
+                    errors.append(("unregister", rc))
+            counts["cycles"] += 1
+        stop.set()
+
+    def caller(tid):
+        out = np.zeros(64, np.uint8)
+        inf = np.zeros(1, np.uint8)
+        k = 0
+        while not stop.is_set():
+            j = (tid + k) % len(lens)
+            k += 1
+            with lock:
+                h = shared["h"]
+            if not h:
+                continue
+            out[:] = 0xAB
+            rc = L.nmx_msm_handle(h, 0, scs[j].ctypes.data, lens[j], 0, out.ctypes.data, inf.ctypes.data)
+            if rc == 0:
+                if (out.tobytes(), int(inf[0])) != exp[j]:
+                    errors.append(("wrong point", tid, j))
+                counts["ok"] += 1
+            elif rc == _lib.E_HANDLE:                # unregistered between the read of `h` and the call: clean error,
+                if not (out == 0xAB).all():          # and a failed call never writes a point
+                    errors.append(("failed call wrote output", tid))
+                counts["stale"] += 1
+            else:
+                errors.append(("msm", rc, L.nmx_last_error().decode()))
+
+    def slice_caller(tid):
+        """the slice form over the same array, with the cache being cleared under it"""
+        g = nmx.DlogGroup(c.cid)
+        k = 0
+        while not stop.is_set():
+            j = (tid + k) % len(lens)
+            k += 1
+            got = g.vartime_multiscalar_mul(scs[j], bases[: lens[j]])
+            if (got.xy, int(got.is_inf)) != exp[j]:
+                errors.append(("wrong point (slice form)", tid, j))
+            if k % 5 == 0:
+                L.nmx_cache_clear()
+
+    ths = [threading.Thread(target=registrar)]
+    ths += [threading.Thread(target=caller, args=(t,)) for t in range(5)]
+    ths += [threading.Thread(target=slice_caller, args=(t,)) for t in range(2)]
+    [t.start() for t in ths]
+    [t.join(timeout=300) for t in ths]
+    assert not any(t.is_alive() for t in ths), "a thread hung"
+    assert not errors, errors[:5]
+    assert counts["cycles"] == 40 and counts["ok"] > 40
+    with lock:
+        if shared["h"]:
+            assert L.nmx_bases_unregister(shared["h"]) == 0
+    assert L.nmx_cache_clear() == 0
+
+
+def test_slice_bounds_cannot_wrap(nmx):
+    """offset + n is checked without overflow: offset = SIZE_MAX, n = 1 must be NMX_E_HANDLE, not an HBM read."""
+    from nova_amd import _lib
+    L = _lib.lib()
+    c = R.BN254_G1
+    ck = nmx.CommitmentKey.from_host(c.cid, cref.sequential_bases(c, 1, 64))
+    out = np.zeros(64, np.uint8)
+    inf = np.zeros(1, np.uint8)
+    sc = util.random_scalars(c.cid, 4)
+    big = ctypes.c_size_t(-1).value
+    for off, n in ((big, 1), (big - 2, 4), (64, 1), (1, big)):
+        assert L.nmx_msm_handle(ck.handle, off, sc.ctypes.data, n, 0, out.ctypes.data, inf.ctypes.data) == _lib.E_HANDLE
+        assert L.nmx_bases_read(ck.handle, off, n, out.ctypes.data) == _lib.E_HANDLE
+    s64 = np.ones(4, np.uint64)
+    assert L.nmx_msm_u64_handle(ck.handle, big, s64.ctypes.data, 1, 8, 0, out.ctypes.data, inf.ctypes.data) == _lib.E_HANDLE
+    assert not out.any()
+    ck.close()
