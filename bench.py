@@ -2,13 +2,24 @@
 """bench.py -- BN254 MSM throughput (BASELINE.json metric: scalar-point pairs/s) on N MI355X GPUs of one node.
 
 A "step" is one pass of the hot path over one batch of synthetic input: one `CommitmentEngine::commit(ck, v, 0)`
-(= DlogGroupExt::vartime_multiscalar_mul, /root/reference benches/commit.rs:120-124) over 2^LOG2N uniformly random
-BN254 scalars per GPU, commitment key resident in HBM, scalars resident in HBM when the timed region starts.
-N > 1: every rank runs the full single-GPU MSM on its own contiguous shard of the (scalar, base) array (weak
-scaling: 2^LOG2N pairs per GPU), then the 128-byte partial sums are all-gathered over RCCL and combined
-(SURVEY.md 8(e)); value = pairs of all ranks / max-over-ranks time.
+(= DlogGroupExt::vartime_multiscalar_mul, /root/reference benches/commit.rs:120-124) over uniformly random BN254
+scalars, commitment key resident in HBM, scalars resident in HBM when the timed region starts.
+
+  N = 1 (default)  BASELINE.json configs[1]: 2^20 pairs on one GPU.  The same JSON line also carries the other
+                   headline-adjacent numbers, each cross-checked against the CPU oracle: `incl_h2d` (scalars in pageable
+                   host memory), `trait_form` (the reference's slice-form signature over pageable
+                   Montgomery-layout host arrays: the slice cache path), `anchor_2p24_single_gpu` (the N = 1 point of the
+                   configs[2] curve), `prove_step_replay_ms` (configs[3] shapes incl. the six SpMVs) and
+                   `hyperkzg_replay_ms` (configs[4]).  --no-extras skips them.
+  N > 1 (default)  BASELINE.json configs[2]: a FIXED TOTAL of 2^24 pairs sharded contiguously over the N ranks
+                   (2^24 / N per GPU, "scaling": "strong"): every rank runs the full single-GPU MSM on its shard of
+                   the (scalar, base) array, then the 128-byte partial sums are all-gathered over RCCL and combined
+                   (SURVEY.md 8(e), the reference's par_chunks + reduce, src/provider/msm.rs:564-574);
+                   value = 2^24 x steps / max-over-ranks time; `combine_ms` is the exchange + point sum alone.
+                   (--log2n X with N > 1 gives the old weak-scaling run, 2^X pairs per GPU.)
 
   python bench.py                      # 1 GPU, 2^20 pairs, prints ONE JSON line
+  python bench.py --log2n 24 --no-extras   # the single-GPU anchor of the 2^24 curve on its own
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus 8 --steps K --warmup W
 """
@@ -38,7 +49,7 @@ MADS_PER_MADD_BY_CURVE = {0: 1305, 1: 1305, 2: 1089, 3: 1089}
 def madds_per_launch(n, args):
     """Mixed additions of one accumulate launch on uniformly random scalars: one per (pair, window)."""
     bits = {0: 254, 1: 254, 2: 255, 3: 255}[args.curve]
-    c = args.window_bits or (20 if args.log2n >= 22 else 16)
+    c = args.window_bits or (20 if n >= (1 << 22) else 16)
     return n * (-(-(bits + 1) // c))
 
 
@@ -47,11 +58,13 @@ def pmc_traffic(args, world):
     collected on (BN254, 2^20, random scalars, one GPU); everything else reports null."""
     if not (world == 1 and args.curve == 0 and args.log2n == 20 and args.dist == "random" and not args.window_bits):
         return None
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_msm_2p20", "pmc_traffic.json")))["accum"]
-        return d["hbm_read_bytes_corrected"] + d["hbm_write_bytes"]
-    except (OSError, KeyError, ValueError):
-        return None
+    for rnd in ("r02_msm_2p20", "r01_msm_2p20"):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")))["accum"]
+            return d["hbm_read_bytes_corrected"] + d["hbm_write_bytes"]
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def main():
@@ -59,7 +72,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--log2n", type=int, default=20, help="pairs per GPU = 2^log2n (BASELINE configs[1]: 20)")
+    ap.add_argument("--log2n", type=int, default=None,
+                    help="pairs per GPU = 2^log2n.  Default: 20 on one GPU (BASELINE configs[1]); with --gpus N > 1 the "
+                         "default is the strong-scaling run of configs[2] instead (see --total-log2n)")
+    ap.add_argument("--total-log2n", type=int, default=24,
+                    help="N > 1: total pairs = 2^total_log2n split contiguously over the ranks (BASELINE configs[2]: 24)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="N = 1 headline run: skip incl_h2d / trait_form / 2^24 anchor / prove_step / HyperKZG replays")
     ap.add_argument("--curve", type=int, default=0, help="0 bn254_g1 (headline), 1 grumpkin, 2 pallas, 3 vesta")
     ap.add_argument("--dist", default="random", help="scalar distribution: random | u1 | u10 | u16 | u32 | u64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -69,6 +88,9 @@ def main():
                     help="msm = the headline (default); the others time one HBM-bound field-vector kernel of "
                          "SURVEY.md 8(f) at 2^log2n elements per GPU")
     args = ap.parse_args()
+    strong = args.gpus > 1 and args.log2n is None      # configs[2] as written: fixed total, contiguous shards
+    if args.log2n is None:
+        args.log2n = 20
 
     # RCCL writes its version banner / warnings to stdout; stdout must end with ONE JSON line: send RCCL's log to
     # stderr and (see emit()) print the JSON only after the process group is gone and C stdio is flushed.
@@ -101,27 +123,37 @@ def main():
         L.nmx_set_window_bits(args.window_bits)
 
     if args.workload == "prove_step_replay":
-        return prove_step_replay(args, world, rank, L, torch, dist)
+        assert world == 1, "prove_step is sequential: replicas only"
+        return emit(prove_step_replay(args, torch), False, dist)
     if args.workload == "hyperkzg_replay":
-        return hyperkzg_replay(args, world, rank, L, torch, dist)
+        assert world == 1
+        return emit(hyperkzg_replay(args, torch), False, dist)
     if args.workload != "msm":
         return field_workload(args, world, rank, L, torch, dist)
 
-    n = 1 << args.log2n
+    from nova_amd.dist import shard_range, sharded_msm
     cid = args.curve
+    if strong:
+        total = 1 << args.total_log2n
+        lo, hi = shard_range(total, rank, world)
+        n, k0 = hi - lo, 1 + lo            # this rank's contiguous shard of ONE key: P_i = (1 + i) * G, i in [lo, hi)
+    else:
+        n = 1 << args.log2n
+        total = n * world
+        k0 = 1 + rank * n
     ce = nova_amd.CommitmentEngine(cid)
     group = ce.group
-    # shard `rank` of the key: bases P_i = (1 + rank*n + i) * G, generated in HBM
-    ck = nova_amd.CommitmentKey.generate(cid, n, k0=1 + rank * n)
+    ck = nova_amd.CommitmentKey.generate(cid, n, k0=k0)
     # two scalar vectors per rank, alternated between steps, resident in HBM before timing starts
     host_sc = [util.scalar_set(cid, n, args.dist, seed=util.SEED + 1000 * rank + j) for j in range(2)]
     dev_sc = [torch.from_numpy(s.copy()).cuda() for s in host_sc]
-    from nova_amd.dist import sharded_msm
+    multi = world > 1 or force_dist
+    combine_s = [0.0]
 
     def step(j):
-        if world == 1 and not force_dist:
+        if not multi:
             return group.vartime_multiscalar_mul(dev_sc[j & 1], ck)
-        return sharded_msm(group, ck, dev_sc[j & 1])
+        return sharded_msm(group, ck, dev_sc[j & 1], timing=combine_s)
 
     def fence():
         torch.cuda.synchronize()
@@ -131,6 +163,7 @@ def main():
 
     for j in range(args.warmup):
         step(j)
+    combine_s[0] = 0.0
     L.nmx_set_profiling(1)
     import ctypes
     prof = (ctypes.c_float * 16)()
@@ -158,10 +191,18 @@ def main():
     if rank == 0:
         stage_ms = stage_sum / max(args.steps, 1)
         accum_ms = float(stage_ms[STAGES.index("accum")])
-        pairs = n * world * args.steps
+        pairs = total * args.steps
         achieved = BYTES_PER_PAIR * n / (accum_ms * 1e-3) / 1e9 if accum_ms > 0 else 0.0
+        name = nova_amd.CURVE_NAMES[cid]
+        if strong:
+            workload = (f"{name} Pippenger MSM, 2^{args.total_log2n} pairs in total sharded contiguously over {world} GPUs "
+                        f"({n} pairs on rank 0), {args.dist} scalars, bases+scalars resident in HBM, 128-byte partials "
+                        "all-gathered over RCCL and summed (BASELINE.json configs[2])")
+        else:
+            workload = (f"{name} Pippenger MSM 2^{args.log2n} pairs per GPU, {args.dist} scalars, bases+scalars resident in "
+                        f"HBM (BASELINE.json configs[{1 if args.log2n == 20 and world == 1 else 2}])")
         out = {
-            "metric": "BN254 MSM scalar-point pairs/sec" if cid == 0 else f"{nova_amd.CURVE_NAMES[cid]} MSM scalar-point pairs/sec",
+            "metric": "BN254 MSM scalar-point pairs/sec" if cid == 0 else f"{name} MSM scalar-point pairs/sec",
             "value": pairs / dt,
             "unit": "pairs/s",
             "n_gpus": world,
@@ -169,16 +210,16 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "u32x8 (256-bit modular integer, Montgomery)",
             "data": "synthetic",
             "config": {
-                "workload": f"{nova_amd.CURVE_NAMES[cid]} Pippenger MSM 2^{args.log2n} pairs per GPU, {args.dist} scalars, "
-                            "bases+scalars resident in HBM (BASELINE.json configs[1])",
+                "workload": workload,
+                "pairs_total": total,
                 "pairs_per_gpu": n,
                 "parallelism": f"shard{world}" if world > 1 else "single",
-                "combine": "rccl all_gather of 128-byte partials + host point sum" if world > 1 else "none",
+                "combine": "rccl all_gather of 128-byte partials + host point sum" if multi else "none",
             },
             "stages_ms": {s: round(float(v), 4) for s, v in zip(STAGES, stage_ms)},
             # median and min of the timed calls (rank 0's own calls; `value` uses the whole region)
@@ -201,10 +242,111 @@ def main():
                              "mads_per_mixed_add": MADS_PER_MADD},
             },
         }
+        if multi:
+            out["combine_ms"] = round(combine_s[0] / max(args.steps, 1) * 1e3, 4)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cid, ck, host_sc[(args.steps - 1) & 1], n, result)
+        if world == 1 and not force_dist and not args.no_extras and args.log2n == 20 and args.dist == "random" and cid == 0:
+            extras(out, args, torch, L, ck, host_sc[0], dev_sc[0])
     ck.close()
-    emit(out if rank == 0 else None, world > 1 or force_dist, dist)
+    emit(out if rank == 0 else None, multi, dist)
+
+
+def extras(out, args, torch, L, ck, host_scalars, dev_scalars):
+    """The other headline-adjacent numbers of the N = 1 run, in the same JSON line (each with its own cross-check
+    against the CPU oracle).  BN254, 2^20 unless stated."""
+    import nova_amd
+    from nova_amd import _lib, fieldvec as fv
+    from oracle import cref
+    from tests import util
+    cid, n = 0, len(host_scalars)
+    g = nova_amd.DlogGroup(cid)
+    K = 5
+
+    def med_ms(fn, reps=K, warm=1):
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            r = fn()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)) * 1e3, r
+
+    ref = g.vartime_multiscalar_mul(dev_scalars, ck)       # HBM-resident result of the same inputs (checked by cpu_baseline)
+    # (1) SURVEY.md 8(d) "incl. H2D of scalars": canonical scalars in pageable host memory, key resident (handle form)
+    ms, r = med_ms(lambda: g.vartime_multiscalar_mul(host_scalars, ck))
+    out["incl_h2d"] = {"ms": round(ms, 4), "value": n / (ms * 1e-3), "unit": "pairs/s", "scalars": "pageable host memory, canonical",
+                       "matches_hbm_resident_result": r == ref}
+    # (2) the reference's own signature: vartime_multiscalar_mul(&[Scalar], &ck.ck[..n]) = nmx_msm(slice) over host arrays
+    # in halo2curves' in-memory layout (Montgomery limbs, NMX_SCALARS_MONT | NMX_BASES_MONT), bases through the slice cache
+    host_bases = ck.read(0, n)
+    one256 = {fid: ((1 << 256) % util_modulus(fid)).to_bytes(32, "little") for fid in (fv.BN254_FQ, fv.BN254_FR)}
+
+    def to_mont(fid, canon_rows):                           # x -> x * 2^256 mod p on the GPU: 0 + R * x
+        d = torch.from_numpy(np.ascontiguousarray(canon_rows).reshape(-1, 32)).cuda()
+        return fv.axpy(fid, torch.zeros_like(d), d, one256[fid]).cpu().numpy()
+
+    bm = to_mont(fv.BN254_FQ, host_bases).reshape(n, 64)
+    sm = to_mont(fv.BN254_FR, host_scalars)
+    L.nmx_cache_clear()
+    s0 = _lib.stats()
+    t0 = time.perf_counter()
+    cold = g.vartime_multiscalar_mul(sm, bm, mont=True)    # first sight: upload + convert + window tables
+    cold_ms = (time.perf_counter() - t0) * 1e3
+    ms, r = med_ms(lambda: g.vartime_multiscalar_mul(sm, bm, mont=True), warm=0)
+    short = n - 1 - 12345                                   # a shorter prefix of the same array: still no upload
+    r_short = g.vartime_multiscalar_mul(sm[:short], bm[:short], mont=True)
+    s1 = _lib.stats()
+    out["trait_form"] = {
+        "ms": round(ms, 4), "value": n / (ms * 1e-3), "unit": "pairs/s", "first_call_ms": round(cold_ms, 3),
+        "what": "nmx_msm(curve, scalars, bases, n, NMX_SCALARS_MONT|NMX_BASES_MONT): slice form, pageable host arrays, "
+                "bases resident via the slice cache (tables included), scalars cross PCIe inside the call",
+        "uploads": s1[_lib.STAT_CACHE_UPLOADS] - s0[_lib.STAT_CACHE_UPLOADS],
+        "hits": s1[_lib.STAT_CACHE_HITS] - s0[_lib.STAT_CACHE_HITS],
+        "vs_incl_h2d": round(ms / out["incl_h2d"]["ms"], 3),
+        "matches_hbm_resident_result": r == ref and cold == ref,
+        "prefix_matches_handle_form": r_short == g.vartime_multiscalar_mul(host_scalars[:short], ck),
+    }
+    L.nmx_cache_clear()
+    del bm, sm
+    # (3) N = 1 anchor of the configs[2] curve: 2^24 pairs on one GPU (c = 20 tables, 13 GiB)
+    try:
+        n24 = 1 << 24
+        ck24 = nova_amd.CommitmentKey.generate(cid, n24, k0=1)
+        # 2^22 random scalars tiled four times over 2^24 distinct bases: the same bucket statistics, a quarter of the
+        # host-side generation time
+        sc24 = torch.from_numpy(util.random_scalars(cid, n24 // 4, seed=util.SEED + 24)).cuda().repeat(4, 1).contiguous()
+        ms, r24 = med_ms(lambda: g.vartime_multiscalar_mul(sc24, ck24), reps=3)
+        # size-independent check: the two halves as partials sum to the whole (shard additivity)
+        h = n24 // 2
+        parts = [g.vartime_multiscalar_mul(sc24[:h], ck24, partial=True).xy,
+                 g.vartime_multiscalar_mul(sc24[h:], ck24, partial=True, offset=h).xy]
+        out["anchor_2p24_single_gpu"] = {"ms": round(ms, 3), "value": n24 / (ms * 1e-3), "unit": "pairs/s",
+                                         "halves_sum_to_whole": g.point_sum(parts) == r24}
+        ck24.close()
+        del sc24
+    except nova_amd.NmxError as e:                          # e.g. a box with less free HBM: report, do not fail the headline
+        out["anchor_2p24_single_gpu"] = {"error": str(e)}
+    # (4) configs[3]: prove_step provider-call replay, 65 536 MinRoot iterations per step, incl. the six SpMVs
+    a2 = argparse.Namespace(**vars(args))
+    a2.iters, a2.steps, a2.warmup = 65536, 5, 2
+    ps = prove_step_replay(a2, torch)
+    out["prove_step_replay_ms"] = {"ms": round(ps["value"], 4), "iters_per_step": 65536, "cpu_ms": round(ps["cpu_baseline"]["value"], 2),
+                                   "cpu_cores": ps["cpu_baseline"]["cores"], "gpu_matches_cpu": ps["cpu_baseline"]["gpu_matches_cpu"],
+                                   "what": ps["config"]["workload"]}
+    # (5) configs[4]: HyperKZG prove replay at n = 2^20
+    a3 = argparse.Namespace(**vars(args))
+    a3.log2n, a3.steps, a3.warmup = 20, 3, 1
+    hk = hyperkzg_replay(a3, torch, ck=ck)
+    out["hyperkzg_replay_ms"] = {"ms": round(hk["value"], 3), "log2n": 20, "cpu_ms": round(hk["cpu_baseline"]["value"], 1),
+                                 "cpu_cores": hk["cpu_baseline"]["cores"], "gpu_matches_cpu": hk["cpu_baseline"]["gpu_matches_cpu"],
+                                 "what": hk["config"]["workload"]}
+
+
+def util_modulus(fid):
+    from oracle import pyref as R
+    return [R.BN254_Q, R.BN254_R, R.PALLAS_P, R.PALLAS_Q][fid]
 
 
 def emit(result, world_or_dist, dist):
@@ -224,41 +366,54 @@ def emit(result, world_or_dist, dist):
 
 
 def witness_like(cid, n, seed):
-    """Scalars shaped like an R1CS witness: half zeros, a quarter small (< 2^16), a quarter full-width
-    (why msm() partitions by bit width, src/provider/msm.rs:237-279)."""
     from tests import util
-    v = util.random_scalars(cid, n, seed=seed).copy()
+    return util.witness_like(cid, n, seed)
+
+
+def minroot_like_matrices(fid, rows, cols, seed):
+    """Three CSR matrices shaped like the MinRoot step circuit's A, B, C (examples/minroot.rs:83-135: x_{i+1}^5 = x_i + y_i as
+    three multiplication gates per iteration): A rows carry two terms, B and C one; nine coefficients in ten are 1, the
+    rest full-width (the augmented circuit's constants)."""
+    from tests import util
     rng = np.random.Generator(np.random.PCG64(seed))
-    kind = rng.integers(0, 4, size=n)
-    v[kind < 2] = 0
-    small = util.u64_to_le32(util.small_scalars(n, 16, seed=seed))
-    v[kind == 2] = small[kind == 2]
-    return v
+    mats = []
+    for j, per_row in enumerate((2, 1, 1)):
+        nnz = per_row * rows
+        indptr = np.arange(0, nnz + 1, per_row, dtype=np.uint64)
+        indices = rng.integers(0, cols, size=nnz).astype(np.uint64)
+        data = np.zeros((nnz, 32), np.uint8)
+        data[:, 0] = 1
+        big = rng.random(nnz) < 0.1
+        cidx = {0: 1, 1: 0, 2: 3, 3: 2}[fid]          # a curve whose scalar field is `fid`
+        data[big] = util.random_scalars(cidx, int(big.sum()), seed=seed + j)
+        mats.append((indptr, indices, data))
+    return mats
 
 
-def prove_step_replay(args, world, rank, L, torch, dist):
+def prove_step_replay(args, torch):
     """REPLAY of the provider calls of one RecursiveSNARK::prove_step (src/nova/mod.rs:456-541, SURVEY.md 3(B)) on the
     MinRoot step circuit (examples/minroot.rs: 3 constraints per iteration + the 9 986-constraint augmented circuit
-    on BN254, 10 538 on Grumpkin): 4 MSMs + 2 cross terms + 4 AXPY folds, vectors resident in HBM, commitments
-    returned to the host after each MSM (they feed the Poseidon RO challenge on the reference side).  NOT replayed:
-    witness synthesis, Poseidon hashing and the sparse matrix-vector products (CPU side of the reference; SpMV is
-    SURVEY 8(f) row 3, not built yet).  This is a replay, not prove_step: the Rust reference cannot be built here."""
+    on BN254, 10 538 on Grumpkin).  Per step, as the reference orders them: for each of the two NIFS folds Z = Z1 + Z2,
+    the three sparse products A*Z, B*Z, C*Z (`multiply_vec`, src/r1cs/mod.rs:612 -> sparse.rs:201-229; matrices resident in
+    HBM), the cross term T, commit(T), the two AXPY folds; plus the two witness commitments: 4 MSMs + 6 SpMVs + 2 vector
+    adds + 2 cross terms + 4 AXPYs, every vector resident in HBM, every commitment returned to the host (they feed the
+    Poseidon RO challenge on the reference side).  NOT replayed: witness synthesis and Poseidon hashing (host side of
+    the reference).  This is a replay, not prove_step: the Rust reference cannot be built here."""
     import nova_amd
     from nova_amd import fieldvec as fv
     from tests import util
-    assert world == 1, "prove_step is sequential: replicas only"
     N = 3 * args.iters + 9986          # primary (BN254) witness / constraint count
     n2 = 10538                         # secondary (Grumpkin)
     cur = {"P": (0, fv.SCALAR_FIELD_OF_CURVE[0], N), "S": (1, fv.SCALAR_FIELD_OF_CURVE[1], n2)}
     ce = {k: nova_amd.CommitmentEngine(c[0]) for k, c in cur.items()}
     ck = {k: ce[k].setup_synthetic(c[2], k0=3) for k, c in cur.items()}
-    host, dev = {}, {}
+    host, dev, csr, mats = {}, {}, {}, {}
     for k, (cid, fid, n) in cur.items():
         host[k] = {"W": witness_like(cid, n, 11), "W1": util.random_scalars(cid, n, seed=12),
                    "E1": util.random_scalars(cid, n, seed=13)}
-        for j, nm in enumerate(("AZ", "BZ", "CZ")):
-            host[k][nm] = util.random_scalars(cid, n, seed=20 + j)
         dev[k] = {nm: torch.from_numpy(v).cuda() for nm, v in host[k].items()}
+        csr[k] = minroot_like_matrices(fid, n, n, seed=100 + cid)     # Z has one entry per variable here (io folded in)
+        mats[k] = [fv.SparseMatrix(fid, ip, ix, dt, n) for ip, ix, dt in csr[k]]
     u = util.random_scalars(0, 1, seed=31)
     r = {k: util.random_scalars(c[0], 1, seed=32) for k, c in cur.items()}
     rT = {k: util.random_scalars(c[0], 1, seed=33) for k, c in cur.items()}
@@ -267,7 +422,9 @@ def prove_step_replay(args, world, rank, L, torch, dist):
     def nifs(k, uu):
         cid, fid, n = cur[k]
         d = dev[k]
-        T = fv.cross_term(fid, d["AZ"], d["BZ"], d["CZ"], d["E1"], uu)     # r1cs/mod.rs:614-620
+        Z = fv.vec_add(fid, d["W1"], d["W"])                                  # r1cs/mod.rs:590-609
+        AZ, BZ, CZ = (m.multiply_vec(Z) for m in mats[k])                     # r1cs/mod.rs:612
+        T = fv.cross_term(fid, AZ, BZ, CZ, d["E1"], uu)                       # r1cs/mod.rs:614-620
         comT = ce[k].commit(ck[k], T, rT[k])                                  # r1cs/mod.rs:622
         W = fv.axpy(fid, d["W1"], d["W"], r[k])                               # r1cs/mod.rs:1058-1062
         E = fv.axpy(fid, d["E1"], T, r[k])                                    # r1cs/mod.rs:1063-1067
@@ -294,7 +451,8 @@ def prove_step_replay(args, world, rank, L, torch, dist):
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": False,
         "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (256-bit modular integer)", "data": "synthetic",
         "config": {"workload": f"prove_step replay: minroot {args.iters} iterations/step -> primary N={N} (BN254), secondary n={n2} "
-                               "(Grumpkin); 4 MSMs + 2 cross terms + 4 folds; no SpMV / synthesis / Poseidon (BASELINE.json configs[3])"},
+                               "(Grumpkin); 4 MSMs + 6 SpMVs + 2 vector adds + 2 cross terms + 4 folds; no synthesis / Poseidon "
+                               "(BASELINE.json configs[3])"},
         "roofline": None,
     }
     if not args.no_cpu_baseline:
@@ -308,7 +466,9 @@ def prove_step_replay(args, world, rank, L, torch, dist):
         for k, uu in (("S", uS), ("P", u)):
             cid, fid, n = cur[k]
             h = host[k]
-            T = cref.field_cross_term(fid, h["AZ"], h["BZ"], h["CZ"], h["E1"], uu, n)
+            Z = np.frombuffer(cref.field_axpy(fid, h["W1"], h["W"], util.int_to_le32(1), n), np.uint8).reshape(n, 32)  # W1 + 1*W
+            AZ, BZ, CZ = (cref.spmv(fid, ip, ix, dt, n, Z) for ip, ix, dt in csr[k])
+            T = cref.field_cross_term(fid, AZ, BZ, CZ, h["E1"], uu, n)
             comT = cref.commit(cid, T, keys[k], n, ck[k].h, rT[k])
             cref.field_axpy(fid, h["W1"], h["W"], r[k], n)
             cref.field_axpy(fid, h["E1"], T, r[k], n)
@@ -320,12 +480,14 @@ def prove_step_replay(args, world, rank, L, torch, dist):
         outj["cpu_baseline"] = {"value": t_cpu * 1e3, "unit": "ms", "cores": threads, "kind": "port",
                                 "sample": "the same call sequence once through oracle/nova_ref.c (commit re-loads the key "
                                           "each call, as a fresh Vec<Affine> would not)", "gpu_matches_cpu": all(ok)}
-    print(json.dumps(outj), flush=True)
     for k in ck:
         ck[k].close()
+        for m in mats[k]:
+            m.close()
+    return outj
 
 
-def hyperkzg_replay(args, world, rank, L, torch, dist):
+def hyperkzg_replay(args, torch, ck=None):
     """REPLAY of the provider-side work of one HyperKZG `prove` (src/provider/hyperkzg.rs:926-1110) for
     n = 2^log2n on BN254, everything resident in HBM, commitments / evaluations returned to the host:
       ell-1 pair folds Pi[j] = P[2j] + x*(P[2j+1]-P[2j])                      (hyperkzg.rs:1085-1095)
@@ -333,17 +495,20 @@ def hyperkzg_replay(args, world, rank, L, torch, dist):
       3*ell Horner evaluations f_i(u_j)                                       (hyperkzg.rs:1011-1020,1049-1056)
       B = sum q^i f_i                                                         (hyperkzg.rs:1028-1040)
       3 x kzg_open: h = div_by_monomial(B, u_j), commit(h)                    (hyperkzg.rs:961-1004,1062-1065)
-    NOT replayed: the Keccak transcript (challenges are fixed random scalars).  A replay, not `prove`."""
+    NOT replayed: the Keccak transcript (challenges are fixed random scalars).  A replay, not `prove`.
+    ck: an already resident key of >= n points to use (the headline run passes its own)."""
     import nova_amd
     from nova_amd import fieldvec as fv
     from tests import util
-    assert world == 1
     ell = args.log2n
     n = 1 << ell
     cid = 0
     fid = fv.SCALAR_FIELD_OF_CURVE[cid]
     ce = nova_amd.CommitmentEngine(cid)
-    ck = ce.setup_synthetic(n, k0=5)
+    own_ck = ck is None
+    if own_ck:
+        ck = ce.setup_synthetic(n, k0=5)
+    assert len(ck) >= n
     hP = util.random_scalars(cid, n, seed=41)
     xs = util.random_scalars(cid, ell, seed=42)
     us = util.random_scalars(cid, 3, seed=43)
@@ -415,8 +580,9 @@ def hyperkzg_replay(args, world, rank, L, torch, dist):
         outj["cpu_baseline"] = {"value": t_cpu * 1e3, "unit": "ms", "cores": threads, "kind": "port",
                                 "sample": "the same call sequence once through oracle/nova_ref.c (Horner / division passes are "
                                           "single-threaded there)", "gpu_matches_cpu": ok}
-    print(json.dumps(outj), flush=True)
-    ck.close()
+    if own_ck:
+        ck.close()
+    return outj
 
 
 def effective_cpus():

@@ -41,7 +41,50 @@ def combine_partials(group, partial128, pg=None, device=None):
     return group.point_sum(np.ascontiguousarray(recv.cpu().numpy().reshape(world, 128)))
 
 
-def sharded_msm(group, ck_shard, scalars_shard, pg=None, mont=False):
-    """Each rank: full single-GPU MSM over its shard (key shard resident in HBM) -> partial -> combine."""
-    part = group.vartime_multiscalar_mul(scalars_shard, ck_shard, mont=mont, partial=True)
-    return combine_partials(group, part.xy, pg)
+def sharded_msm(group, ck_shard, scalars_shard, pg=None, mont=False, timing=None, msm_fn=None):
+    """Each rank: full single-GPU MSM over its shard (key shard resident in HBM) -> 128-byte partial -> combine.
+    timing: a one-element list that accumulates the seconds spent in the exchange + point sum alone (bench.py's
+    `combine_ms`).  msm_fn(scalars_shard, ck_shard) -> 128-byte partial replaces the per-shard MSM (the CPU tests
+    inject the oracle there: there is no GPU in the build container)."""
+    import time
+    if msm_fn is None:
+        part = group.vartime_multiscalar_mul(scalars_shard, ck_shard, mont=mont, partial=True).xy
+    else:
+        part = msm_fn(scalars_shard, ck_shard)
+    t0 = time.perf_counter()
+    out = combine_partials(group, part, pg)
+    if timing is not None:
+        timing[0] += time.perf_counter() - t0
+    return out
+
+
+def round_robin_batch_msm(group, ck, scalar_vecs, pg=None, mont=False, batch_fn=None):
+    """`batch_vartime_multiscalar_mul` (src/provider/traits.rs:82-90) across the GPUs of a node: WHOLE vectors are dealt
+    round-robin to the ranks (short MSMs are not worth sharding), every rank holds the full key, runs
+    its share as one batch and the k affine results (65 bytes each) are all-gathered.  Returns the k Commitments in
+    input order on every rank.  batch_fn(vecs, ck) -> [(xy64, is_inf)] replaces the per-rank batch in the CPU tests."""
+    import torch
+    import torch.distributed as dist
+    from .provider import Commitment
+    world, rank = dist.get_world_size(pg), dist.get_rank(pg)
+    k = len(scalar_vecs)
+    mine = list(range(rank, k, world))
+    if batch_fn is None:
+        res = [(c.xy, int(c.is_inf)) for c in group.batch_vartime_multiscalar_mul([scalar_vecs[j] for j in mine], ck, mont)]
+    else:
+        res = batch_fn([scalar_vecs[j] for j in mine], ck)
+    per = (k + world - 1) // world
+    nccl = dist.get_backend(pg) == "nccl"
+    device = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
+    send = torch.zeros(65 * per, dtype=torch.uint8)
+    for slot, (xy, inf) in enumerate(res):
+        send[65 * slot: 65 * slot + 64] = torch.frombuffer(bytearray(xy), dtype=torch.uint8)
+        send[65 * slot + 64] = inf
+    send = send.to(device)
+    recv = torch.zeros(65 * per * world, dtype=torch.uint8, device=device)
+    if nccl:
+        dist.all_gather_into_tensor(recv, send, group=pg)
+    else:
+        dist.all_gather(list(recv.view(world, 65 * per).unbind(0)), send, group=pg)
+    flat = recv.cpu().numpy().reshape(world, per, 65)
+    return [Commitment(flat[j % world, j // world, :64].tobytes(), bool(flat[j % world, j // world, 64])) for j in range(k)]

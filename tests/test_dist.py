@@ -1,6 +1,7 @@
-"""N > 1 path on CPU: world_size-2 (and 3) gloo processes run shard_range + combine_partials (all_gather of
-128-byte partials + nmx_point_sum, which is host code and needs no GPU).  The per-shard MSM itself is stood in by
-the oracle here (no GPU in this container); on the GPU box the same exchange runs over RCCL in bench.py."""
+"""N > 1 path on CPU: world_size-2 (and 3) gloo processes drive nova_amd.dist.sharded_msm / round_robin_batch_msm
+themselves (shard_range, the all_gather of 128-byte partials, nmx_point_sum -- host code, needs no GPU) with the
+per-shard MSM injected (the oracle: there is no GPU in this container).  On the GPU box the same functions run with
+the HIP MSM inside an `nccl` process group: tests/test_gpu_dist.py and bench.py --gpus N."""
 import os
 import socket
 import sys
@@ -24,7 +25,7 @@ def _worker(rank, world, port, n, cid, q):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from nova_amd import DlogGroup
-    from nova_amd.dist import combine_partials, shard_range
+    from nova_amd.dist import round_robin_batch_msm, shard_range, sharded_msm
     from oracle import cref
     from oracle import pyref as R
     from tests import util
@@ -35,11 +36,22 @@ def _worker(rank, world, port, n, cid, q):
     bases = cref.sequential_bases(c, 17, n)
     sc = util.random_scalars(cid, n, seed=3)
     lo, hi = shard_range(n, rank, world)
-    xy, inf = cref.msm(cid, sc[lo:hi], bases[lo:hi], hi - lo)
-    part = util.affine_to_partial(c.p, xy, inf)
-    got = combine_partials(DlogGroup(cid), part)
+
+    def shard_msm(s, b):          # stands in for the HIP MSM of this rank's shard: same contract, 128-byte partial
+        xy, inf = cref.msm(cid, s, b, len(b))
+        return util.affine_to_partial(c.p, xy, inf)
+
+    timing = [0.0]
+    got = sharded_msm(DlogGroup(cid), bases[lo:hi], sc[lo:hi], timing=timing, msm_fn=shard_msm)
     exp = cref.msm(cid, sc, bases, n)
-    q.put((rank, (got.xy, int(got.is_inf)) == exp))
+    ok = (got.xy, int(got.is_inf)) == exp and timing[0] > 0
+    # batch_msm across ranks: whole vectors round-robin, ragged lengths incl. an empty vector
+    lens = [n, 0, n // 2, 1, n - 1][: max(2, world + 2)]
+    vecs = [util.random_scalars(cid, m, seed=40 + j) for j, m in enumerate(lens)]
+    res = round_robin_batch_msm(DlogGroup(cid), bases, vecs,
+                                batch_fn=lambda vs, b: cref.msm_batch(cid, [v.tobytes() for v in vs], b, n))
+    ok = ok and [(r.xy, int(r.is_inf)) for r in res] == cref.msm_batch(cid, [v.tobytes() for v in vecs], bases, n)
+    q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()
 

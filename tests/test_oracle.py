@@ -162,3 +162,21 @@ def test_cref_field_axpy():
         got = cref.field_axpy(fid, a, b, r, 50)
         exp = R.axpy(p, ints(a), ints(b), ints(r)[0])
         assert got == b"".join(R.fe_to_le32(x) for x in exp)
+
+
+def test_public_eip196_vectors_pin_both_oracle_tiers():
+    """tests/golden/public_kats.json (EIP-196 ecMul vectors, not produced by this repository): tier 1 (big-int) and
+    tier 2 (C restatement) must reproduce every published product, and an MSM over all of them must equal the sum of
+    the published outputs."""
+    from tests import kats
+    c = R.BN254_G1
+    cases = kats.load()
+    assert len(cases) >= 5
+    bases, sc = kats.as_arrays(cases)
+    total = R.INF
+    for i, (name, P, k, Q) in enumerate(cases):
+        assert R.on_curve(c, P) and R.on_curve(c, Q), name
+        assert R.mul(c, k, P) == Q, name
+        assert cref.msm(c.cid, sc[i:i + 1], bases[i:i + 1], 1) == (R.point_to_xy64(Q), 0), name
+        total = R.add(c, total, Q)
+    assert cref.msm(c.cid, sc, bases, len(cases)) == (R.point_to_xy64(total), 0)

@@ -103,6 +103,18 @@ def scalar_set(cid, n, kind, seed=SEED):
     raise ValueError(kind)
 
 
+def witness_like(cid, n, seed):
+    """Scalars shaped like an R1CS witness: half zeros, a quarter small (< 2^16), a quarter full-width -- why msm()
+    partitions by bit width (/root/reference/src/provider/msm.rs:237-279)."""
+    v = random_scalars(cid, n, seed=seed).copy()
+    rng = np.random.Generator(np.random.PCG64(seed))
+    kind = rng.integers(0, 4, size=n)
+    v[kind < 2] = 0
+    small = u64_to_le32(small_scalars(n, 16, seed=seed))
+    v[kind == 2] = small[kind == 2]
+    return v
+
+
 R_INTERNAL = 1 << 261  # Montgomery radix of the library's internal residue form (nova_amd/csrc/fp.hpp)
 
 
