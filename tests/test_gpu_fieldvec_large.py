@@ -92,7 +92,8 @@ def test_spmv_2p22_rows(nmx):
     indptr = np.arange(0, 3 * n + 1, 3, dtype=np.uint64)
     indices = rng.integers(0, n, size=3 * n).astype(np.uint64)
     data = big_vec(22, 4)
-    data = np.concatenate([data, data[: 2 * n]])[: 3 * n].copy()
+    data = np.concatenate([data, data, data]).copy()        # 3 n coefficients
+    assert len(data) == 3 * n
     data[::5] = util.int_to_le32(1)                        # +1, -1 and small coefficients as R1CS matrices have
     data[1::7] = util.int_to_le32(C.FIELDS[FID] - 1)
     data[2::11] = util.int_to_le32(3)
