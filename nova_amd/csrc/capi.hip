@@ -80,6 +80,7 @@ static void ensure_init() {
     G.force_fold_t = v < 1 ? 0u : v > 63 ? 63u : (uint32_t)v;
   }
   if (const char* t = getenv("NMX_TUNE_NO_QUAD_ACCUM")) G.no_quad_accum = (uint32_t)atoi(t);
+  if (const char* t = getenv("NMX_TUNE_NO_PARTITION")) G.no_partition = (uint32_t)atoi(t);
   HIPCHK(hipSetDevice(dev));
   cache_init_defaults();
   G.inited = true;
@@ -141,7 +142,7 @@ static inline bool slice_ok(const BaseSet& bs, size_t offset, size_t n) { return
 // upload / generate a key and wrap it
 template <class Make> static std::shared_ptr<BaseSet> make_key(int curve, size_t n, Make&& make) {
   auto bs = std::make_shared<BaseSet>(curve, n);
-  bs->d = make(&bs->pre_c, &bs->pre_W);
+  make(*bs);
   return bs;
 }
 
@@ -336,8 +337,8 @@ static SliceKey slice_key(Ctx& c, const CurveOps& o, int curve, const void* base
   e.host = b;
   e.n = n;
   e.fingerprint();
-  e.bs = make_key(curve, n, [&](uint32_t* pc, uint32_t* pw) {
-    return o.upload(c, bases, n, (flags & NMX_BASES_MONT) | NMX_BASES_PRECOMPUTE, pc, pw, nullptr);
+  e.bs = make_key(curve, n, [&](BaseSet& bs) {
+    o.upload(c, bs, bases, (flags & NMX_BASES_MONT) | NMX_BASES_PRECOMPUTE, nullptr);
   });
   stat_add(NMX_STAT_CACHE_UPLOADS);
   if (grow || grow2) stat_add(NMX_STAT_CACHE_REGROWS);
@@ -364,9 +365,7 @@ static std::shared_ptr<BaseSet> temp_key(Ctx& c, const CurveOps& o, int curve, c
                                          uint32_t flags) {
   stat_add(NMX_STAT_UNCACHED_CALLS);
   if (!(flags & NMX_BASES_DEVICE)) stat_add(NMX_STAT_BASE_BYTES_H2D, n * 64);
-  return make_key(curve, n, [&](uint32_t* pc, uint32_t* pw) {
-    return o.upload(c, bases, n, flags & ~(uint32_t)NMX_BASES_PRECOMPUTE, pc, pw, nullptr);
-  });
+  return make_key(curve, n, [&](BaseSet& bs) { o.upload(c, bs, bases, flags & ~(uint32_t)NMX_BASES_PRECOMPUTE, nullptr); });
 }
 // the resident (or one-shot) key behind a slice-form call
 static SliceKey resolve_slice(Ctx& c, const CurveOps& o, int curve, const void* bases, size_t n, uint32_t flags) {
@@ -438,9 +437,7 @@ int nmx_bases_register(int curve, const void* bases, size_t n, uint32_t flags, u
     require(handle && (bases || n == 0), NMX_E_ARG, "null argument");
     const CurveOps& o = ops(curve);
     CtxLease L;
-    *handle = publish(make_key(curve, n, [&](uint32_t* pc, uint32_t* pw) {
-      return o.upload(*L.c, bases, n, flags, pc, pw, nullptr);
-    }));
+    *handle = publish(make_key(curve, n, [&](BaseSet& bs) { o.upload(*L.c, bs, bases, flags, nullptr); }));
   });
 }
 
@@ -459,9 +456,7 @@ int nmx_bases_register_ptau(int curve, const char* path, size_t num_g1, size_t n
     CtxLease L;
     const BaseFill fill = file_fill(fc.f, num_g1);
     const uint32_t fl = (flags & NMX_BASES_PRECOMPUTE) | NMX_BASES_MONT | NMX_BASES_VALIDATE;
-    *handle = publish(make_key(curve, num_g1, [&](uint32_t* pc, uint32_t* pw) {
-      return o.upload(*L.c, nullptr, num_g1, fl, pc, pw, &fill);
-    }));
+    *handle = publish(make_key(curve, num_g1, [&](BaseSet& bs) { o.upload(*L.c, bs, nullptr, fl, &fill); }));
   });
 }
 
@@ -484,7 +479,7 @@ int nmx_bases_register_keyfile(int curve, const char* path, size_t n, uint32_t f
     CtxLease L;
     const BaseFill fill = file_fill(fc.f, n);
     const uint32_t fl = (flags & NMX_BASES_PRECOMPUTE) | NMX_BASES_MONT | NMX_BASES_VALIDATE;
-    auto bs = make_key(curve, n, [&](uint32_t* pc, uint32_t* pw) { return o.upload(*L.c, nullptr, n, fl, pc, pw, &fill); });
+    auto bs = make_key(curve, n, [&](BaseSet& b) { o.upload(*L.c, b, nullptr, fl, &fill); });
     memcpy(h_xy64, h_canon, 64);
     *handle = publish(std::move(bs));
   });
@@ -523,7 +518,7 @@ int nmx_bases_generate(int curve, uint64_t k0, size_t n, uint32_t flags, uint64_
     require(n < (1ull << 31) && k0 < (1ull << 62), NMX_E_ARG, "k0 / n out of range");
     const CurveOps& o = ops(curve);
     CtxLease L;
-    *handle = publish(make_key(curve, n, [&](uint32_t* pc, uint32_t* pw) { return o.generate(*L.c, k0, n, flags, pc, pw); }));
+    *handle = publish(make_key(curve, n, [&](BaseSet& bs) { o.generate(*L.c, bs, k0, flags); }));
   });
 }
 

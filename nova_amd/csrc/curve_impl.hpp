@@ -54,6 +54,30 @@ template <int CID> struct ValidateFn {
     if (!ok) nmx_atomic_or(err, 1u);
   }
 };
+struct AnyIdentityFn {  // does the key hold the identity encoding (all-zero x || y) anywhere?
+  const uint32_t* v;  // n x 16 words
+  uint32_t* flag;
+  NMX_HD void operator()(uint32_t i) const {
+    const uint32_t* w = v + 16 * (size_t)i;
+    uint32_t any = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) any |= w[j];
+    if (!any) nmx_atomic_or(flag, 1u);
+  }
+};
+static bool scan_identity(Ctx& c, const void* d, size_t n) {
+  if (n == 0) return false;
+  arena_reserve(c, 256);
+  uint32_t* dflag = (uint32_t*)c.arena;
+  HIPCHK(hipMemsetAsync(dflag, 0, 4, c.stream));
+  DeviceBackend be(c, false, false);
+  AnyIdentityFn f{(const uint32_t*)d, dflag};
+  be.launch(f, (uint32_t)n);
+  uint32_t h = 0;
+  HIPCHK(hipMemcpyAsync(&h, dflag, 4, hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipStreamSynchronize(c.stream));
+  return h != 0;
+}
 template <int CID> struct GenFn {  // P_i = (k0 + i) * G
   using C = CurveT<CID>;
   AffineW* out;
@@ -113,6 +137,8 @@ static XYZZ<CurveT<CID>::BF> run_msm(Ctx& c, const void* d_bases, size_t n, cons
   a.pre_stride = mc.pre_stride;
   a.pre_offset = mc.pre_offset;
   a.pre_c = mc.pre_c;
+  a.bases_clean = mc.bases_clean ? 1u : 0u;
+  a.no_partition = G.no_partition;
   {
     uint32_t bits = a.u64_bits ? a.u64_bits : sbits;
     MsmShape sh = make_shape(a.n, bits, a.force_c, a.pre_stride ? a.pre_c : 0);
@@ -204,14 +230,17 @@ template <int CID> static void build_tables(Ctx& c, void* d, size_t n, uint32_t 
 }
 
 template <int CID>
-static void* upload_bases(Ctx& c, const void* src, size_t n, uint32_t flags, uint32_t* pre_c, uint32_t* pre_W,
-                          const BaseFill* fill) {
+static void upload_bases(Ctx& c, BaseSet& bs, const void* src, uint32_t flags, const BaseFill* fill) {
   constexpr int BF = CurveT<CID>::BF;
+  const size_t n = bs.n;
+  uint32_t* pre_c = &bs.pre_c;
+  uint32_t* pre_W = &bs.pre_W;
   void* d = nullptr;
   // lane counts below are 32-bit: 2 * n conversions, n validations (the file-backed entry points check this too)
   require(n < (1ull << 31), NMX_E_TOO_LARGE, "key too large (n must be < 2^31)");
   table_shape<CID>(n, flags, pre_c, pre_W);
-  if (n == 0) return nullptr;
+  bs.any_identity = false;
+  if (n == 0) return;
   HIPCHK(hipMalloc(&d, n * 64 * (*pre_W ? *pre_W : 1)));
   try {
     if (fill) (*fill)(d, c.stream);
@@ -237,12 +266,12 @@ static void* upload_bases(Ctx& c, const void* src, size_t n, uint32_t flags, uin
       be.launch(f, (uint32_t)(2 * n));
     }
     build_tables<CID>(c, d, n, *pre_c, *pre_W);
-    HIPCHK(hipStreamSynchronize(c.stream));
+    bs.any_identity = scan_identity(c, d, n);  // also the stream sync that ends the upload
   } catch (...) {
     (void)hipFree(d);
     throw;
   }
-  return d;
+  bs.d = d;
 }
 
 // MSM over bs[offset, offset + n): through the key's window tables when it has them and n is large enough
@@ -253,8 +282,10 @@ static XYZZ<CurveT<CID>::BF> run_msm_key(Ctx& c, const BaseSet& bs, size_t offse
     mc.pre_stride = (uint32_t)bs.n;
     mc.pre_offset = (uint32_t)offset;
     mc.pre_c = bs.pre_c;
+    mc.bases_clean = !bs.any_identity;
     return run_msm<CID>(c, bs.d, n, mc);
   }
+  mc.bases_clean = !bs.any_identity;
   return run_msm<CID>(c, (const char*)bs.d + offset * 64, n, mc);
 }
 template <int CID>
@@ -304,9 +335,8 @@ template <int CID> struct CurveImpl {
     if (any) acc.add(hr.get());
     write_result<CID>(acc, flags, out, inf);
   }
-  static void* upload(Ctx& c, const void* src, size_t n, uint32_t flags, uint32_t* pc, uint32_t* pw,
-                      const BaseFill* fill) {
-    return upload_bases<CID>(c, src, n, flags, pc, pw, fill);
+  static void upload(Ctx& c, BaseSet& bs, const void* src, uint32_t flags, const BaseFill* fill) {
+    upload_bases<CID>(c, bs, src, flags, fill);
   }
   static bool check_point_host(const uint8_t* xy64, uint32_t flags, uint8_t* out) {
     uint32_t w[16], err = 0;
@@ -320,21 +350,22 @@ template <int CID> struct CurveImpl {
     }
     return true;
   }
-  static void* generate(Ctx& c, uint64_t k0, size_t n, uint32_t flags, uint32_t* pc, uint32_t* pw) {
+  static void generate(Ctx& c, BaseSet& bs, uint64_t k0, uint32_t flags) {
     void* d = nullptr;
-    table_shape<CID>(n, flags, pc, pw);
-    if (n) HIPCHK(hipMalloc(&d, n * 64 * (*pw ? *pw : 1)));
+    const size_t n = bs.n;
+    table_shape<CID>(n, flags, &bs.pre_c, &bs.pre_W);
+    if (n) HIPCHK(hipMalloc(&d, n * 64 * (bs.pre_W ? bs.pre_W : 1)));
     try {
       DeviceBackend be(c, false, false);
       GenFn<CID> f{(AffineW*)d, k0};
       be.launch(f, (uint32_t)n);
-      build_tables<CID>(c, d, n, *pc, *pw);
-      HIPCHK(hipStreamSynchronize(c.stream));
+      build_tables<CID>(c, d, n, bs.pre_c, bs.pre_W);
+      bs.any_identity = scan_identity(c, d, n);  // (k0 + i) * G is the identity only if k0 + i = 0 mod r; also syncs
     } catch (...) {
       if (d) (void)hipFree(d);
       throw;
     }
-    return d;
+    bs.d = d;
   }
   static void internal_to_canonical(uint8_t* e, size_t count) {
     for (size_t i = 0; i < count; i++) {

@@ -24,21 +24,31 @@
 
 namespace nmx {
 
+// atomics: the device instruction on the GPU; a plain read-modify-write in the host passes (hipcc's host pass parses
+// the kernels too, and the g++ emulation runs one thread at a time)
+NMX_HD uint32_t nmx_atomic_add(uint32_t* p, uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ uint32_t nmx_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
-__device__ __forceinline__ void nmx_atomic_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
-__device__ __forceinline__ void nmx_atomic_max(uint32_t* p, uint32_t v) { atomicMax(p, v); }
+  return atomicAdd(p, v);
 #else
-inline void nmx_atomic_max(uint32_t* p, uint32_t v) {
-  if (v > *p) *p = v;
-}
-inline uint32_t nmx_atomic_add(uint32_t* p, uint32_t v) {
   uint32_t o = *p;
   *p = o + v;
   return o;
-}
-inline void nmx_atomic_or(uint32_t* p, uint32_t v) { *p |= v; }
 #endif
+}
+NMX_HD void nmx_atomic_or(uint32_t* p, uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  atomicOr(p, v);
+#else
+  *p |= v;
+#endif
+}
+NMX_HD void nmx_atomic_max(uint32_t* p, uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  atomicMax(p, v);
+#else
+  if (v > *p) *p = v;
+#endif
+}
 
 // error bits accumulated on the device
 enum : uint32_t { ERR_SCALAR_RANGE = 1u, ERR_SMALL_RANGE = 2u };
@@ -60,34 +70,34 @@ struct MsmShape {
 // ----------------------------------------------------------------------------------------------------
 // Signed-digit recoding: d_w in [-(2^(c-1) - 1), 2^(c-1)], sum_w d_w 2^(cw) = s.  With W*c >= bits + 1 the final
 // carry is always zero.
-template <int SFID> struct DigitsFn {
+// ----------------------------------------------------------------------------------------------------
+// digit source: everything the digit stage knows about a call, shared by DigitsFn (generic sort path) and the
+// partition kernels (msm_partition.hpp)
+// ----------------------------------------------------------------------------------------------------
+template <int SFID> struct DigitSrc {
   const uint32_t* scalars;  // n x 8 u32 (canonical or Montgomery), or n x 2 (u64 mode)
-  const uint32_t* bases;    // n x 16 u32: only tested for the all-zero identity encoding; may be null
-  uint32_t* keys;           // W x n
-  uint32_t* vals;           // W x n
+  const uint32_t* bases;    // n x 16 u32, only to test for the identity encoding; null when the key holds none
   uint32_t* err;
   MsmShape sh;
-  uint32_t scalars_mont;  // 1: scalars are in Montgomery form
-  uint32_t u64_bits;      // 0: field scalars; >0: scalars are u64 and must be < 2^u64_bits
-  uint32_t pre_stride;    // 0: plain bases[i]; else window w uses table entry w*pre_stride + pre_offset + i
-  uint32_t pre_offset;
-  const uint32_t* gather;  // non-null: pair i uses base index gather[i] (commit_sparse / batch_add, pedersen.rs:395-427)
-  uint32_t all_ones;       // 1: every scalar is 1 (commit_sparse_binary); `scalars` is not read
+  uint32_t scalars_mont, u64_bits, pre_stride, pre_offset;
+  const uint32_t* gather;
+  uint32_t all_ones;
 
-  NMX_HD void operator()(uint32_t i) const {
-    uint32_t s[9];
-    bool skip = false;
-    const uint32_t bi = (gather ? gather[i] : i) + pre_offset;  // index of this pair's base in the key
+  // canonical scalar words of pair i and the row of its base in the key; false: the pair contributes nothing
+  // (out-of-range scalar -> error bit; identity base, msm.rs:247-249)
+  NMX_HD bool load(uint32_t i, uint32_t (&s)[9], uint32_t& bi, bool report) const {
+    bool ok = true;
+    bi = (gather ? gather[i] : i) + pre_offset;
     if (u64_bits) {
       s[0] = all_ones ? 1u : scalars[2 * (size_t)i];
       s[1] = all_ones ? 0u : scalars[2 * (size_t)i + 1];
 #pragma unroll
       for (int j = 2; j < 9; j++) s[j] = 0;
       if (u64_bits < 64) {
-        uint64_t v = ((uint64_t)s[1] << 32) | s[0];
+        const uint64_t v = ((uint64_t)s[1] << 32) | s[0];
         if (v >> u64_bits) {
-          nmx_atomic_or(err, ERR_SMALL_RANGE);
-          skip = true;
+          if (report) nmx_atomic_or(err, ERR_SMALL_RANGE);
+          ok = false;
         }
       }
     } else {
@@ -95,38 +105,54 @@ template <int SFID> struct DigitsFn {
       for (int j = 0; j < 8; j++) s[j] = scalars[8 * (size_t)i + j];
       s[8] = 0;
       if (!Fp<SFID>::words_lt_p(s)) {  // from_repr would have rejected it on the reference side
-        nmx_atomic_or(err, ERR_SCALAR_RANGE);
-        skip = true;
+        if (report) nmx_atomic_or(err, ERR_SCALAR_RANGE);
+        ok = false;
       }
       if (scalars_mont) Fp<SFID>::from_words(s).mont256_to_canonical().to_words(s);
     }
-    if (bases) {  // identity base contributes nothing (msm.rs:247-249)
+    if (bases) {
       uint32_t o = 0;
       const uint32_t* b = bases + 16 * (size_t)bi;
 #pragma unroll
       for (int j = 0; j < 16; j++) o |= b[j];
-      if (o == 0) skip = true;
+      if (o == 0) ok = false;
     }
+    return ok;
+  }
+  // signed digit of window w: |d| in [0, 2^(c-1)], neg = sign; carry threads through the windows low to high
+  NMX_HD void digit(const uint32_t (&s)[9], uint32_t w, uint32_t& carry, uint32_t& d, uint32_t& neg) const {
+    const uint32_t bit = w * sh.c, word = bit >> 5, off = bit & 31;
+    const uint64_t two = (word < 8) ? (((uint64_t)s[word + 1] << 32) | s[word]) : 0;
+    d = (uint32_t)((two >> off) & ((1u << sh.c) - 1u)) + carry;
+    neg = 0;
+    if (d > sh.M) {
+      d = (1u << sh.c) - d;
+      neg = 1;
+      carry = 1;
+    } else {
+      carry = 0;
+    }
+  }
+};
+
+
+// Generic path (plain keys, c = 20 tables): materialises (key, val) pairs for the radix sort.
+template <int SFID> struct DigitsFn {
+  DigitSrc<SFID> src;
+  uint32_t* keys;  // W x n
+  uint32_t* vals;  // W x n
+  NMX_HD void operator()(uint32_t i) const {
+    const MsmShape& sh = src.sh;
+    uint32_t s[9], bi;
+    const bool skip = !src.load(i, s, bi, true);
     uint32_t carry = 0;
-    const uint32_t mask = (1u << sh.c) - 1u;
-    const uint32_t half = sh.M;  // 2^(c-1)
     for (uint32_t w = 0; w < sh.W; w++) {
-      uint32_t bit = w * sh.c;
-      uint32_t word = bit >> 5, off = bit & 31;
-      uint64_t two = (word < 8) ? (((uint64_t)s[word + 1] << 32) | s[word]) : 0;
-      uint32_t d = (uint32_t)((two >> off) & mask) + carry;
-      uint32_t neg = 0;
-      if (d > half) {
-        d = (1u << sh.c) - d;
-        neg = 1;
-        carry = 1;
-      } else {
-        carry = 0;
-      }
-      uint32_t key = (d == 0 || skip) ? sh.nbuckets : ((pre_stride ? 0u : w * sh.M) + d - 1);
-      size_t o = (size_t)w * sh.n + i;
+      uint32_t d, neg;
+      src.digit(s, w, carry, d, neg);
+      const uint32_t key = (d == 0 || skip) ? sh.nbuckets : ((src.pre_stride ? 0u : w * sh.M) + d - 1);
+      const size_t o = (size_t)w * sh.n + i;
       keys[o] = key;
-      vals[o] = (w * pre_stride + bi) | (neg << 31);
+      vals[o] = (w * src.pre_stride + bi) | (neg << 31);
     }
   }
 };

@@ -48,70 +48,6 @@
 namespace nmx {
 
 // ----------------------------------------------------------------------------------------------------
-// digit source: everything DigitsFn knows about a call, shared by the rocPRIM path and the partition kernels
-// ----------------------------------------------------------------------------------------------------
-template <int SFID> struct DigitSrc {
-  const uint32_t* scalars;  // n x 8 u32 (canonical or Montgomery), or n x 2 (u64 mode)
-  const uint32_t* bases;    // n x 16 u32, only to test for the identity encoding; null when the key holds none
-  uint32_t* err;
-  MsmShape sh;
-  uint32_t scalars_mont, u64_bits, pre_stride, pre_offset;
-  const uint32_t* gather;
-  uint32_t all_ones;
-
-  // canonical scalar words of pair i and the row of its base in the key; false: the pair contributes nothing
-  // (out-of-range scalar -> error bit; identity base, msm.rs:247-249)
-  NMX_HD bool load(uint32_t i, uint32_t (&s)[9], uint32_t& bi, bool report) const {
-    bool ok = true;
-    bi = (gather ? gather[i] : i) + pre_offset;
-    if (u64_bits) {
-      s[0] = all_ones ? 1u : scalars[2 * (size_t)i];
-      s[1] = all_ones ? 0u : scalars[2 * (size_t)i + 1];
-#pragma unroll
-      for (int j = 2; j < 9; j++) s[j] = 0;
-      if (u64_bits < 64) {
-        const uint64_t v = ((uint64_t)s[1] << 32) | s[0];
-        if (v >> u64_bits) {
-          if (report) nmx_atomic_or(err, ERR_SMALL_RANGE);
-          ok = false;
-        }
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; j++) s[j] = scalars[8 * (size_t)i + j];
-      s[8] = 0;
-      if (!Fp<SFID>::words_lt_p(s)) {  // from_repr would have rejected it on the reference side
-        if (report) nmx_atomic_or(err, ERR_SCALAR_RANGE);
-        ok = false;
-      }
-      if (scalars_mont) Fp<SFID>::from_words(s).mont256_to_canonical().to_words(s);
-    }
-    if (bases) {
-      uint32_t o = 0;
-      const uint32_t* b = bases + 16 * (size_t)bi;
-#pragma unroll
-      for (int j = 0; j < 16; j++) o |= b[j];
-      if (o == 0) ok = false;
-    }
-    return ok;
-  }
-  // signed digit of window w: |d| in [0, 2^(c-1)], neg = sign; carry threads through the windows low to high
-  NMX_HD void digit(const uint32_t (&s)[9], uint32_t w, uint32_t& carry, uint32_t& d, uint32_t& neg) const {
-    const uint32_t bit = w * sh.c, word = bit >> 5, off = bit & 31;
-    const uint64_t two = (word < 8) ? (((uint64_t)s[word + 1] << 32) | s[word]) : 0;
-    d = (uint32_t)((two >> off) & ((1u << sh.c) - 1u)) + carry;
-    neg = 0;
-    if (d > sh.M) {
-      d = (1u << sh.c) - d;
-      neg = 1;
-      carry = 1;
-    } else {
-      carry = 0;
-    }
-  }
-};
-
-// ----------------------------------------------------------------------------------------------------
 // partition geometry
 // ----------------------------------------------------------------------------------------------------
 struct PartShape {
@@ -150,11 +86,10 @@ inline PartShape make_part_shape(const MsmShape& sh) {
 // every thread of the block must call it (barriers inside).  A plain loop per thread: n is at most a few hundred and
 // the reads are LDS broadcasts.
 NMX_DEV void block_excl_scan(const uint32_t* a, uint32_t* out, uint32_t n) {
-  const uint32_t t = NMX_TID;
-  if (t <= n) {
+  for (uint32_t i = NMX_TID; i <= n; i += NMX_BDIM) {
     uint32_t acc = 0;
-    for (uint32_t j = 0; j < t; j++) acc += a[j];
-    out[t] = acc;
+    for (uint32_t j = 0; j < i; j++) acc += a[j];
+    out[i] = acc;
   }
   NMX_SYNC();
 }
@@ -190,7 +125,7 @@ template <int SFID> struct PartArgs {
 template <int SFID> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_hist_hi(PartArgs<SFID> a) {
   NMX_LDS uint32_t cnt[256];
   const uint32_t t = NMX_TID, bs = NMX_BDIM;
-  if (t < 256) cnt[t] = 0;
+  for (uint32_t j = t; j < 256; j += bs) cnt[j] = 0;
   NMX_SYNC();
   const MsmShape& sh = a.src.sh;
   for (uint32_t base = NMX_BID * bs; base < sh.n; base += NMX_GDIM * bs) {
@@ -208,7 +143,8 @@ template <int SFID> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_hist_hi(PartArgs<S
     }
   }
   NMX_SYNC();
-  if (t < a.ps.nhi && cnt[t]) nmx_atomic_add(&a.hist_hi[t], cnt[t]);
+  for (uint32_t j = t; j < a.ps.nhi; j += bs)
+    if (cnt[j]) nmx_atomic_add(&a.hist_hi[j], cnt[j]);
 }
 
 template <int SFID> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_part_hi(PartArgs<SFID> a) {
@@ -218,11 +154,11 @@ template <int SFID> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_part_hi(PartArgs<S
   const uint32_t t = NMX_TID, bs = NMX_BDIM;
   const MsmShape& sh = a.src.sh;
   const uint32_t nhi = a.ps.nhi, LB = a.ps.LB, lomask = a.ps.nlo - 1u;
-  if (t < 256) cnt[t] = t < nhi ? a.hist_hi[t] : 0;
+  for (uint32_t j = t; j < 256; j += bs) cnt[j] = j < nhi ? a.hist_hi[j] : 0;
   NMX_SYNC();
   block_excl_scan(cnt, binstart, nhi);  // where each high bin's region starts in ent_val / ent_lo
   for (uint32_t base = NMX_BID * bs; base < sh.n; base += NMX_GDIM * bs) {
-    if (t < 256) cnt[t] = 0, cur[t] = 0;
+    for (uint32_t j = t; j < 256; j += bs) cnt[j] = 0, cur[j] = 0;
     NMX_SYNC();
     const uint32_t i = base + t;
     uint32_t s[9], bi = 0;
@@ -237,7 +173,8 @@ template <int SFID> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_part_hi(PartArgs<S
     }
     NMX_SYNC();
     block_excl_scan(cnt, lbase, nhi);
-    if (t < nhi && cnt[t]) gbase[t] = binstart[t] + nmx_atomic_add(&a.cur_hi[t], cnt[t]);  // reserve the bin's run
+    for (uint32_t j = t; j < nhi; j += bs)
+      if (cnt[j]) gbase[j] = binstart[j] + nmx_atomic_add(&a.cur_hi[j], cnt[j]);  // reserve the bin's run
     NMX_SYNC();
     if (live) {  // phase B: the same digits again, now placed: LDS slot = bin's local base + arrival rank
       uint32_t carry = 0;

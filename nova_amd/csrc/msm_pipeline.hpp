@@ -5,7 +5,7 @@
 //   HostEmulBackend (tests/host_emul) plain loops + std::sort, g++ only     -> indexing debug aid in tests
 #pragma once
 #include <stddef.h>
-#include "msm_kernels.hpp"
+#include "msm_partition.hpp"
 
 namespace nmx {
 
@@ -24,6 +24,8 @@ struct MsmArgs {
   // sparse forms (commit_sparse / commit_sparse_binary): pair i uses base gather[i]; all_ones: scalars are all 1
   const uint32_t* gather = nullptr;
   uint32_t all_ones = 0;
+  uint32_t bases_clean = 0;  // 1: the key is known to hold no identity point: the digit stage need not read the bases
+  uint32_t no_partition = 0; // 1: generic radix-sort path even where the hand-written partition applies (tests / A-B runs)
 };
 
 inline uint32_t ilog2_u32(uint32_t v) {
@@ -109,48 +111,78 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
   const uint32_t heavy_cap = (uint32_t)(total / sh.lmax) + 1;
   const uint32_t extra_cap = 2 * heavy_cap;
 
-  uint32_t* keys0 = be.template alloc<uint32_t>(total);
-  uint32_t* vals0 = be.template alloc<uint32_t>(total);
-  uint32_t* keys1 = be.template alloc<uint32_t>(total);
-  uint32_t* vals1 = be.template alloc<uint32_t>(total);
+  const bool part = partition_supported(sh, a.pre_stride != 0) && !a.no_partition;
   uint32_t* start = be.template alloc<uint32_t>(2 * ((size_t)sh.nbuckets + 1) + 8);
   uint32_t* end = start + sh.nbuckets + 1;
-  uint32_t* counters = end + sh.nbuckets + 1;  // [0] extra tasks, [1] split buckets, [2] error bits, [3] max tasks, [4] big
+  uint32_t* counters = end + sh.nbuckets + 1;  // [0] extra tasks, [1] split buckets, [2] error bits, [3] max tasks, [4] big, [5] non-zero digits
   HeavyRec* heavy = be.template alloc<HeavyRec>(heavy_cap);
   const uint32_t big_cap = (uint32_t)(total / ((size_t)64 * sh.lmax)) + 1;
   HeavyRec* big = be.template alloc<HeavyRec>(big_cap);
   TaskRec* extra = be.template alloc<TaskRec>(extra_cap);
   XYZZW* buckets = be.template alloc<XYZZW>(sh.nbuckets);
   XYZZW* partials = be.template alloc<XYZZW>(extra_cap);
-
   be.memset0(start, (2 * ((size_t)sh.nbuckets + 1) + 8) * sizeof(uint32_t));
 
-  be.mark("digits");
-  {
-    DigitsFn<SFID> f;
-    f.scalars = a.scalars;
-    f.bases = (const uint32_t*)a.bases;
-    f.keys = keys0;
-    f.vals = vals0;
-    f.err = counters + 2;
-    f.sh = sh;
-    f.scalars_mont = a.scalars_mont;
-    f.u64_bits = a.u64_bits;
-    f.pre_stride = a.pre_stride;
-    f.pre_offset = a.pre_offset;
-    f.gather = a.gather;
-    f.all_ones = a.all_ones;
-    be.launch(f, sh.n);
-  }
-  be.mark("sort");
-  {
-    uint32_t key_bits = ilog2_u32(sh.nbuckets) + 1;  // keys in [0, nbuckets]
-    be.sort_pairs(keys0, keys1, vals0, vals1, total, key_bits);
-  }
-  be.mark("bounds");
-  {
-    BoundsFn f{keys1, start, end, (uint32_t)total};
-    be.launch(f, (uint32_t)((total + BoundsFn::kPerLane - 1) / BoundsFn::kPerLane));
+  DigitSrc<SFID> src;
+  src.scalars = a.scalars;
+  src.bases = a.bases_clean ? nullptr : (const uint32_t*)a.bases;
+  src.err = counters + 2;
+  src.sh = sh;
+  src.scalars_mont = a.scalars_mont;
+  src.u64_bits = a.u64_bits;
+  src.pre_stride = a.pre_stride;
+  src.pre_offset = a.pre_offset;
+  src.gather = a.gather;
+  src.all_ones = a.all_ones;
+
+  uint32_t* vals1;
+  if (part) {
+    // hand-written two-level LDS partition fused with digit extraction (msm_partition.hpp)
+    PartArgs<SFID> pa;
+    pa.src = src;
+    pa.ps = make_part_shape(sh);
+    const size_t nctr = 512 + 2 * ((size_t)sh.nbuckets + 1);
+    uint32_t* ctr = be.template alloc<uint32_t>(nctr);
+    pa.hist_hi = ctr;
+    pa.cur_hi = ctr + 256;
+    pa.bucket_cnt = ctr + 512;
+    pa.bucket_cur = pa.bucket_cnt + sh.nbuckets + 1;
+    pa.ent_val = be.template alloc<uint32_t>(total);
+    pa.ent_lo = be.template alloc<uint8_t>(total);
+    vals1 = be.template alloc<uint32_t>(total);
+    pa.vals = vals1;
+    pa.start = start;
+    pa.end = end;
+    pa.total_out = counters + 5;
+    be.memset0(ctr, nctr * sizeof(uint32_t));
+    be.mark("digits");
+    be.launch_kernel(&k_hist_hi<SFID>, pa.ps.grid1, pa.ps.bs1, pa);
+    be.mark("sort");
+    be.launch_kernel(&k_part_hi<SFID>, pa.ps.grid1, pa.ps.bs1, pa);
+    be.launch_kernel(&k_hist_lo<SFID>, pa.ps.tiles_cap, kTileThreads, pa);
+    be.launch_kernel(&k_scan_buckets<SFID>, 1u, 1024u, pa);
+    be.launch_kernel(&k_part_lo<SFID>, pa.ps.tiles_cap, kTileThreads, pa);
+    be.mark("bounds");
+  } else {
+    uint32_t* keys0 = be.template alloc<uint32_t>(total);
+    uint32_t* vals0 = be.template alloc<uint32_t>(total);
+    uint32_t* keys1 = be.template alloc<uint32_t>(total);
+    vals1 = be.template alloc<uint32_t>(total);
+    be.mark("digits");
+    {
+      DigitsFn<SFID> f{src, keys0, vals0};
+      be.launch(f, sh.n);
+    }
+    be.mark("sort");
+    {
+      uint32_t key_bits = ilog2_u32(sh.nbuckets) + 1;  // keys in [0, nbuckets]
+      be.sort_pairs(keys0, keys1, vals0, vals1, total, key_bits);
+    }
+    be.mark("bounds");
+    {
+      BoundsFn f{keys1, start, end, (uint32_t)total};
+      be.launch(f, (uint32_t)((total + BoundsFn::kPerLane - 1) / BoundsFn::kPerLane));
+    }
   }
   {
     PlanFn f{start, end, counters, heavy, big, sh};

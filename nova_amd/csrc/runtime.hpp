@@ -83,6 +83,8 @@ struct BaseSet {
   void* d = nullptr;   // AffineW[pre_W ? pre_W * n : n]: the key (internal form), then its window tables
   uint32_t pre_c = 0;  // window width of the tables (0: none)
   uint32_t pre_W = 0;
+  bool any_identity = true;  // false: no point of the key is the identity (checked at registration): the digit stage of
+                             // an MSM then never reads the bases (64 B per pair saved); true is always safe
   bool owns = true;    // false: `d` belongs to somebody else (one-shot uploads wrapped for batch_impl)
   BaseSet() = default;
   BaseSet(int curve_, size_t n_) : curve(curve_), n(n_) {}
@@ -122,6 +124,7 @@ struct Global {
   size_t precomp_min_n = kPrecompMinN;  // env NMX_TUNE_PRECOMP_MIN_N (tuning only)
   uint32_t force_fold_t = 0;  // env NMX_TUNE_FOLD_T (tuning only)
   uint32_t no_quad_accum = 0;  // env NMX_TUNE_NO_QUAD_ACCUM (tuning only)
+  uint32_t no_partition = 0;   // env NMX_TUNE_NO_PARTITION: generic radix-sort path everywhere (A/B runs)
 };
 extern Global G;                 // capi.hip
 void prof_store(const float* ms, int n);   // last call's stage times of this thread (capi.hip)
@@ -154,6 +157,12 @@ struct DeviceBackend {
   template <class F> void launch(const F& f, uint32_t n) {
     if (dry || n == 0) return;
     hipLaunchKernelGGL((k_launch<F>), dim3((n + 255) / 256), dim3(256), 0, c.stream, f, n);
+    HIPCHK(hipGetLastError());
+  }
+  // block-level kernels (msm_partition.hpp): explicit grid / block, static LDS
+  template <class A> void launch_kernel(void (*k)(A), uint32_t grid, uint32_t block, const A& a) {
+    if (dry || grid == 0) return;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(block), 0, c.stream, a);
     HIPCHK(hipGetLastError());
   }
   // Fold / reduction passes with fewer work items than the chip has lanes are bound by the latency of a point
@@ -259,6 +268,7 @@ struct MsmCall {
   // sparse forms: host base indices (validated < key length by the caller), and "all scalars are 1"
   const uint32_t* gather_host = nullptr;
   bool all_ones = false;
+  bool bases_clean = false;  // the key holds no identity point
 };
 
 // Fills the freshly allocated device key (n x 64 raw bytes) -- nullptr: one hipMemcpy from `src`; key files stream
@@ -272,11 +282,12 @@ struct CurveOps {
   // msm_key(v) + h * r
   void (*commit)(Ctx&, const BaseSet&, size_t n, const MsmCall&, const void* h_xy64, const void* r, uint32_t flags,
                  uint8_t* out, uint8_t* inf);
-  void* (*upload)(Ctx&, const void* src, size_t n, uint32_t flags, uint32_t* pre_c, uint32_t* pre_W, const BaseFill* fill);
+  // fill bs.d / pre_c / pre_W / any_identity for bs.curve, bs.n: from a host / device array, or through `fill`
+  void (*upload)(Ctx&, BaseSet& bs, const void* src, uint32_t flags, const BaseFill* fill);
   // host: one point in the ABI form (flags & NMX_BASES_MONT) -> canonical x||y; false if not canonical / off the curve
   bool (*check_point_host)(const uint8_t* xy64, uint32_t flags, uint8_t* out_canonical_xy64);
   const uint32_t* base_modulus_words;  // 8 x u32
-  void* (*generate)(Ctx&, uint64_t k0, size_t n, uint32_t flags, uint32_t* pre_c, uint32_t* pre_W);
+  void (*generate)(Ctx&, BaseSet& bs, uint64_t k0, uint32_t flags);
   void (*internal_to_canonical)(uint8_t* elems32, size_t count);  // host, in place
   void (*point_sum)(const uint8_t* partials128, size_t count, uint8_t* out, uint8_t* inf);  // host
   bool (*check_layout)(const uint8_t* generator_raw64, const uint8_t* scalar_raw32, uint64_t value);  // host

@@ -13,6 +13,8 @@
 #include <numeric>
 #include <vector>
 
+#include "simt.hpp"
+
 #include "../../nova_amd/csrc/curves.hpp"
 #include "../../nova_amd/csrc/msm_pipeline.hpp"
 
@@ -31,6 +33,10 @@ struct HostEmulBackend {
   void memset0(void* p, size_t bytes) { memset(p, 0, bytes); }
   template <class F> void launch(const F& f, uint32_t n) {
     for (uint32_t t = 0; t < n; t++) f(t);
+  }
+  template <class A> void launch_kernel(void (*k)(A), uint32_t grid, uint32_t block, const A& a) {
+    if (grid == 0) return;
+    simt::launch(grid, block, [&] { k(a); });  // one fiber per thread, real barriers (tests/host_emul/simt.hpp)
   }
   template <int FID>
   void launch_accum(const AffineW* bases, const uint32_t* vals, const uint32_t* start, const uint32_t* end,
@@ -135,7 +141,74 @@ template <int FID> static void fp_op_t(int op, const uint8_t* a, const uint8_t* 
   fp_to_bytes(r, out);
 }
 
+// The partition kernels alone (no curve arithmetic) against DigitsFn + std::sort: same multiset of (row | sign) words
+// per bucket, consistent start / end, total = number of non-zero digits.  grid_override forces the grid-stride loops.
+static int partition_check(const uint8_t* scalars, size_t n, uint32_t c, uint32_t u64_bits, uint32_t grid_override,
+                           uint32_t stride, uint32_t offset) {
+  constexpr int SF = F_BN254_FR;
+  const uint32_t bits = u64_bits ? u64_bits : (uint32_t)FpParams<SF>::BITS;
+  MsmShape sh = make_shape((uint32_t)n, bits, 0, c);
+  if (!partition_supported(sh, true)) return -2;
+  const size_t total = sh.total;
+  std::vector<uint32_t> start(sh.nbuckets + 1), end(sh.nbuckets + 1), ctr(512 + 2 * ((size_t)sh.nbuckets + 1)), vals(total + 1),
+      ent_val(total + 1), keys(total + 1), kvals(total + 1);
+  std::vector<uint8_t> ent_lo(total + 1);
+  uint32_t err = 0, tot = 0;
+  DigitSrc<SF> src{(const uint32_t*)scalars, nullptr, &err, sh, 0, u64_bits, stride, offset, nullptr, 0};
+  PartArgs<SF> pa;
+  pa.src = src;
+  pa.ps = make_part_shape(sh);
+  if (grid_override) pa.ps.grid1 = grid_override;
+  pa.hist_hi = ctr.data();
+  pa.cur_hi = ctr.data() + 256;
+  pa.bucket_cnt = ctr.data() + 512;
+  pa.bucket_cur = pa.bucket_cnt + sh.nbuckets + 1;
+  pa.ent_val = ent_val.data();
+  pa.ent_lo = ent_lo.data();
+  pa.start = start.data();
+  pa.end = end.data();
+  pa.vals = vals.data();
+  pa.total_out = &tot;
+  HostEmulBackend be;
+  be.launch_kernel(&k_hist_hi<SF>, pa.ps.grid1, pa.ps.bs1, pa);
+  be.launch_kernel(&k_part_hi<SF>, pa.ps.grid1, pa.ps.bs1, pa);
+  be.launch_kernel(&k_hist_lo<SF>, pa.ps.tiles_cap, kTileThreads, pa);
+  be.launch_kernel(&k_scan_buckets<SF>, 1u, 1024u, pa);
+  be.launch_kernel(&k_part_lo<SF>, pa.ps.tiles_cap, kTileThreads, pa);
+  // reference: materialised (key, val) pairs grouped by key
+  uint32_t err2 = 0;
+  DigitSrc<SF> src2 = src;
+  src2.err = &err2;
+  DigitsFn<SF> df{src2, keys.data(), kvals.data()};
+  for (uint32_t i = 0; i < n; i++) df(i);
+  if (err != err2) return -3;
+  std::vector<std::vector<uint32_t>> ref(sh.nbuckets);
+  size_t nz = 0;
+  for (size_t e = 0; e < total; e++)
+    if (keys[e] < sh.nbuckets) {
+      ref[keys[e]].push_back(kvals[e]);
+      nz++;
+    }
+  if (tot != nz) return -4;
+  uint32_t run = 0;
+  for (uint32_t k = 0; k < sh.nbuckets; k++) {
+    if (start[k] != run || end[k] != run + ref[k].size()) return -5;
+    std::vector<uint32_t> got(vals.begin() + start[k], vals.begin() + end[k]);
+    std::sort(got.begin(), got.end());
+    std::sort(ref[k].begin(), ref[k].end());
+    if (got != ref[k]) return -6;
+    run = end[k];
+  }
+  if (start[sh.nbuckets] != run || end[sh.nbuckets] != run) return -7;
+  return 0;
+}
+
 extern "C" {
+
+int emul_partition_check(const uint8_t* scalars, size_t n, uint32_t c, uint32_t u64_bits, uint32_t grid_override,
+                         uint32_t stride, uint32_t offset) {
+  return partition_check(scalars, n, c, u64_bits, grid_override, stride, offset);
+}
 
 int emul_msm(int curve, const uint8_t* scalars, const uint8_t* bases_xy64, size_t n, uint32_t u64_bits,
              uint32_t u64_mode, uint32_t scalars_mont, uint32_t force_c, uint8_t* out, uint8_t* inf) {

@@ -23,7 +23,9 @@ CSRC = os.path.join(os.path.dirname(HERE), "nova_amd", "csrc")
 
 @pytest.fixture(scope="module")
 def emul():
-    deps = [SRC] + [os.path.join(CSRC, f) for f in ("fp.hpp", "curve.hpp", "curves.hpp", "msm_kernels.hpp", "msm_pipeline.hpp")]
+    deps = [SRC, os.path.join(HERE, "host_emul", "simt.hpp")] + [
+        os.path.join(CSRC, f) for f in ("fp.hpp", "curve.hpp", "curves.hpp", "msm_kernels.hpp", "msm_pipeline.hpp",
+                                        "msm_partition.hpp")]
     if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-DNMX_DEBUG_BOUNDS", "-shared", "-fPIC", "-o", SO, SRC])
     L = ctypes.CDLL(SO)
@@ -33,6 +35,8 @@ def emul():
                                    ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p,
                                    ctypes.c_void_p]
     L.emul_fp_op.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
+    L.emul_partition_check.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                       ctypes.c_uint32, ctypes.c_uint32]
     return L
 
 
@@ -245,3 +249,18 @@ def test_emul_precomputed_tables(emul, c):
         s = util.small_scalars(n_key, bits)
         rc, got, inf = run_pre(emul, c.cid, s, key, n_key, 0, n_key, 9, u64_bits=bits)
         assert rc == 0 and (got, inf) == cref.msm_u64(c.cid, s, key, n_key, bits)
+
+
+@pytest.mark.parametrize("c,n,grid", [(16, 40000, 0), (16, 40000, 3), (15, 20011, 2), (8, 30000, 5), (8, 700, 0), (12, 5000, 1),
+                                      (4, 300, 0), (16, 1, 0), (16, 1025, 0)])
+def test_emul_partition_kernels(emul, c, n, grid):
+    """The hand-written LDS partition (msm_partition.hpp) run thread by thread on the CPU (tests/host_emul/simt.hpp:
+    one fiber per GPU thread, real barriers) against DigitsFn + a sort: per-bucket multisets, start / end, totals.
+    Scalar sets include the adversarial ones for a counting sort: every entry in one bucket per window (equal), almost
+    everything dropped as a zero digit (u1), and 0 / r-1."""
+    for kind in ["random", "equal", "zero_rm1", "u1", "pm_small"]:
+        sc = np.ascontiguousarray(util.scalar_set(0, n, kind))
+        rc = emul.emul_partition_check(sc.ctypes.data, n, c, 0, grid, n + 7, 3)
+        assert rc == 0, (c, n, grid, kind, rc)
+    s64 = np.ascontiguousarray(util.small_scalars(n, 33))
+    assert emul.emul_partition_check(s64.ctypes.data, n, c, 33, grid, n, 0) == 0
