@@ -27,6 +27,13 @@ struct alignas(16) XYZZW {
   uint32_t w[32];
 };
 
+// 144 bytes in HBM: the four coordinates as their 9 in-register limbs, NOT reduced -- whatever weakly reduced value the
+// accumulator holds (bounds of the XYZZ invariants).  Storing it is 36 plain word stores and no arithmetic, which is
+// what a lane of the segment-balanced accumulate kernel can afford inside a divergent branch; identity <=> zz limbs 0.
+struct alignas(16) XYZZL {
+  uint32_t l[36];
+};
+
 template <int FID> struct Affine {
   Fp<FID> x, y;  // canonical
   static NMX_HD Affine load(const AffineW& m) {
@@ -71,6 +78,26 @@ template <int FID> struct XYZZ {
     y.canon().to_words(m.w + 8);
     zz.canon().to_words(m.w + 16);
     zzz.canon().to_words(m.w + 24);
+  }
+  static NMX_HD XYZZ load_raw(const XYZZL& m) {
+    XYZZ r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      r.x.l[i] = m.l[i];
+      r.y.l[i] = m.l[9 + i];
+      r.zz.l[i] = m.l[18 + i];
+      r.zzz.l[i] = m.l[27 + i];
+    }
+    return r;
+  }
+  NMX_HD void store_raw(XYZZL& m) const {  // limbs must be normalized (they are after every add / dbl)
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      m.l[i] = x.l[i];
+      m.l[9 + i] = y.l[i];
+      m.l[18 + i] = zz.l[i];
+      m.l[27 + i] = zzz.l[i];
+    }
   }
   NMX_HD void check() const {
     x.check_below(5.3, "x");

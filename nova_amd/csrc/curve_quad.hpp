@@ -151,7 +151,64 @@ template <int FID> __device__ __forceinline__ Fp<FID> quad_madd(const Fp<FID>& c
 
 #if defined(__HIPCC__) || defined(__HIP__)
 #include "msm_kernels.hpp"
+#include "msm_seg.hpp"
 namespace nmx {
+
+// coordinate `q` of a raw-limb record (msm_seg.hpp)
+template <int FID> __device__ __forceinline__ Fp<FID> quad_load_raw(const XYZZL& m, uint32_t q) {
+  Fp<FID> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = m.l[9 * q + i];
+  return r;
+}
+template <int FID> __device__ __forceinline__ void quad_store_raw(XYZZL& m, uint32_t q, const Fp<FID>& c) {
+#pragma unroll
+  for (int i = 0; i < 9; i++) m.l[9 * q + i] = c.l[i];
+}
+// FoldRawFn / FinalSegFn (msm_seg.hpp) with one quad per work item
+template <int FID> struct FoldRawQuadFn {
+  const uint32_t* counters;
+  const HeavyRec* list;
+  XYZZL* partial_raw;
+  uint32_t T, cap, groups, use_big;
+  __device__ __forceinline__ void operator()(uint32_t tid) const {
+    if (use_big && counters[3] <= T) return;
+    const uint32_t q = tid & 3u, item = tid >> 2;
+    const uint32_t j = item % T, nh = counters[use_big ? 4 : 1];
+    for (uint32_t h = item / T; h < nh; h += groups) {
+      const HeavyRec r = list[h];
+      const uint32_t cnt = r.cnt < cap ? r.cnt : cap;
+      if (j + T >= cnt) continue;
+      Fp<FID> acc = quad_load_raw<FID>(partial_raw[r.off + j], q);
+      for (uint32_t k = j + T; k < cnt; k += T) acc = quad_add<FID>(acc, quad_load_raw<FID>(partial_raw[r.off + k], q), q);
+      quad_store_raw<FID>(partial_raw[r.off + j], q, acc);
+    }
+  }
+};
+template <int FID> struct FinalSegQuadFn {
+  const uint32_t* start;
+  const uint32_t* end;
+  const uint32_t* total_p;
+  const XYZZL* bucket_raw;
+  const XYZZL* partial_raw;
+  XYZZW* buckets;
+  uint32_t nbuckets, lanes, min_seg;
+  __device__ __forceinline__ void operator()(uint32_t tid) const {
+    const uint32_t q = tid & 3u, k = tid >> 2;
+    if (k >= nbuckets) return;  // quad-uniform
+    const uint32_t s0 = start[k], e0 = end[k];
+    Fp<FID> acc = Fp<FID>::zero();  // zz = 0: the identity
+    if (e0 > s0) {
+      const uint32_t seg = seg_len(*total_p, lanes, min_seg);
+      const uint32_t l0 = s0 / seg, l1 = (e0 - 1) / seg;
+      uint32_t cnt = l1 - l0;
+      if (cnt > PlanSegFn::kHeavyAbove) cnt = PlanSegFn::kHeavyAbove;
+      acc = quad_load_raw<FID>(bucket_raw[k], q);
+      for (uint32_t j = 0; j < cnt; j++) acc = quad_add<FID>(acc, quad_load_raw<FID>(partial_raw[l0 + 1 + j], q), q);
+    }
+    quad_store<FID>(buckets[k], q, acc);
+  }
+};
 
 // FoldFn / ReducePairFn (msm_kernels.hpp) with one quad per work item.  tid = 4 * item + coordinate.
 template <int FID> struct FoldQuadFn {

@@ -6,21 +6,31 @@
 // (table row | sign) words of a bucket to be contiguous, in any order.  So the partition is a two-level counting
 // scatter fused with digit extraction, staged through LDS so that every global write is a contiguous run:
 //
-//   k_hist_hi      scalars -> signed digits (never materialised) -> LDS histogram of the HIGH key bits (<= 256 bins)
-//   k_part_hi      same digits again -> LDS counting sort of the block's entries by high bits -> coalesced runs of
-//                  (row | sign) words + one byte of LOW key bits into the bin's region (global cursor per bin)
-//   k_hist_lo      tiles of one bin: LDS histogram of the low 7 bits -> per-bucket counts
-//   k_scan_buckets exclusive scan: bucket -> [start, end)           (BoundsFn's job, without reading a sorted array)
-//   k_part_lo      tiles again: LDS counting sort by low bits -> contiguous run per bucket (global cursor per bucket)
+//   k_hist_hi   scalars -> signed digits (never materialised) -> LDS histogram of the HIGH key bits (<= 256 bins)
+//   k_tiles     one block: bin regions (16-entry aligned) of the intermediate arrays, bin regions of the final array,
+//               tile table of level 2, start / end of the buckets of empty bins
+//   k_part_hi   the same digits (kept in registers between the counting and the placing phase) -> LDS counting sort of
+//               the block's entries by high bits -> coalesced runs of (row | sign) words + one byte of LOW key bits
+//               into the bin's region (one global cursor per bin)
+//   k_hist_lo   tiles of one bin: LDS histogram of the low 7 bits -> per-bucket counts
+//   k_part_lo   tiles again: bucket offsets from a bin-local scan of those counts (no global scan kernel: a bin's buckets
+//               occupy the bin's region of the final array), LDS counting sort by low bits -> contiguous run per
+//               bucket (one global cursor per bucket); the first tile of a bin publishes its buckets' [start, end)
 //
-// Traffic at 2^20 pairs / 16 windows: 2 x 32 MB scalars + 84 MB written + 2 x 17 MB + 67 MB read + 67 MB written
+// Traffic at 2^20 pairs / 16 windows: 2 x 32 MB scalars + 84 MB written + 17 MB + 84 MB read + 67 MB written
 // = 0.32 GB against ~0.94 GB for digits + onesweep + bounds; zero digits are dropped instead of carried to a trash
 // bucket.  Order inside a bucket depends on atomics' arrival order; the bucket SUM does not (group law), and the
 // affine result is canonical, so outputs stay bit-exact.
 //
-// The kernels use only block-level primitives (LDS atomics, __syncthreads): tests/host_emul/simt.hpp runs the very
-// same bodies on the CPU, one fiber per thread, to debug them without a GPU.
+// The window width is a template parameter of the level-1 kernels (8 / 15 / 16: the widths the tables are built
+// with; 0 = any width at run time): with constant bit positions the scalar words stay in registers -- indexed
+// dynamically they are promoted to LDS (36 KB per block) -- and the digit loop unrolls to ~10 instructions a window.
+//
+// Apart from the wave scan (device only; a plain loop elsewhere) the kernels use block-level primitives only (LDS
+// atomics, __syncthreads): tests/host_emul/simt.hpp runs the same bodies on the CPU, one fiber per thread.
 #pragma once
+#include <string.h>
+
 #include "msm_kernels.hpp"
 
 #if defined(__HIPCC__) || defined(__HIP__)
@@ -48,22 +58,25 @@
 namespace nmx {
 
 // ----------------------------------------------------------------------------------------------------
-// partition geometry
+// geometry
 // ----------------------------------------------------------------------------------------------------
 struct PartShape {
-  uint32_t LB, HB;    // low / high key bits: key = bucket index in [0, 2^(c-1)), LB = min(c - 1, 7), HB <= 8
-  uint32_t nlo, nhi;  // 2^LB, 2^HB
-  uint32_t bs1;       // threads (= scalars) per block iteration of the first level: bs1 * W <= kStageCap
-  uint32_t grid1;     // blocks of the first level (grid-stride over chunks of bs1 scalars)
-  uint32_t tiles_cap; // upper bound on second-level tiles
+  uint32_t LB, HB;     // low / high key bits: key = bucket index in [0, 2^(c-1)), LB = min(c - 1, 7), HB <= 8
+  uint32_t nlo, nhi;   // 2^LB, 2^HB
+  uint32_t bs1;        // threads (= scalars) per block iteration of the first level: bs1 * W <= kStageCap
+  uint32_t grid1;      // blocks of the first level (grid-stride over chunks of bs1 scalars)
+  uint32_t tiles_cap;  // upper bound on second-level tiles
+  uint32_t ent_cap;    // entries of the intermediate arrays (bin regions are 16-entry aligned, one tile of slack)
 };
-static constexpr uint32_t kStageCap = 16384;  // entries staged in LDS per first-level chunk (64 KiB + 16 KiB)
-static constexpr uint32_t kTile = 8192;       // entries per second-level tile (32 KiB of LDS)
+static constexpr uint32_t kStageCap = 12288;  // entries staged in LDS per first-level chunk: 48 KiB + 24 KiB, 2 blocks / CU
+static constexpr uint32_t kTile = 8192;       // entries per second-level tile
 static constexpr uint32_t kTileThreads = 1024;
-static constexpr uint32_t kTilePer = kTile / kTileThreads;
+static constexpr uint32_t kTilePer = kTile / kTileThreads;  // 8: one aligned 8-byte load of low bits per thread
+static constexpr uint32_t kBinAlign = 16;
 
 inline bool partition_supported(const MsmShape& sh, bool table_mode) {
-  return table_mode && sh.WB == 1 && sh.c >= 2 && sh.c <= 16 && sh.W <= 64;
+  // 256 threads (one scalar each) is the smallest first-level block: its W digits per scalar must fit the LDS stage
+  return table_mode && sh.WB == 1 && sh.c >= 2 && sh.c <= 16 && sh.W * 256u <= kStageCap;
 }
 inline PartShape make_part_shape(const MsmShape& sh) {
   PartShape p;
@@ -74,24 +87,44 @@ inline PartShape make_part_shape(const MsmShape& sh) {
   p.nhi = 1u << p.HB;
   uint32_t bs = (kStageCap / sh.W) & ~63u;
   if (bs > 1024) bs = 1024;
-  if (bs < 64) bs = 64;
+  if (bs < 256) bs = 256;  // the block also scans up to 256 bins; partition_supported guarantees 256 * W <= kStageCap
   p.bs1 = bs;
   const uint32_t chunks = (sh.n + bs - 1) / bs;
-  p.grid1 = chunks < 512 ? chunks : 512;
-  p.tiles_cap = (uint32_t)(((uint64_t)sh.n * sh.W) / kTile) + p.nhi + 1;
+  p.grid1 = chunks < 1024 ? chunks : 1024;
+  p.ent_cap = (uint32_t)((uint64_t)sh.n * sh.W) + kBinAlign * p.nhi + kTile;
+  p.tiles_cap = p.ent_cap / kTile + p.nhi + 1;
   return p;
 }
 
-// exclusive prefix sums of a[0..n) into out[0..n] (out[n] = total), n <= 1024, by the first n threads of the block;
-// every thread of the block must call it (barriers inside).  A plain loop per thread: n is at most a few hundred and
-// the reads are LDS broadcasts.
-NMX_DEV void block_excl_scan(const uint32_t* a, uint32_t* out, uint32_t n) {
+// Exclusive prefix sums of a[0..n) into out[0..n] (out[n] = total), n <= 1024; every thread of the block must call it
+// (barriers inside).  Device: wave scan + one LDS hop (needs blockDim >= n); elsewhere: a loop per element.
+NMX_DEV void block_excl_scan(const uint32_t* a, uint32_t* out, uint32_t n, uint32_t* wtot /* LDS, 16 words */) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint32_t t = NMX_TID, lane = t & 63u, wv = t >> 6;
+  const uint32_t v = t < n ? a[t] : 0u;
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t u = __shfl_up(inc, d);
+    if (lane >= (uint32_t)d) inc += u;
+  }
+  if (lane == 63) wtot[wv] = inc;
+  NMX_SYNC();
+  uint32_t pre = 0;
+  for (uint32_t w = 0; w < wv; w++) pre += wtot[w];
+  if (t < n) out[t] = pre + inc - v;
+  if (t + 1 == n) out[n] = pre + inc;
+  if (n == 0 && t == 0) out[0] = 0;
+  NMX_SYNC();
+#else
+  (void)wtot;
   for (uint32_t i = NMX_TID; i <= n; i += NMX_BDIM) {
     uint32_t acc = 0;
     for (uint32_t j = 0; j < i; j++) acc += a[j];
     out[i] = acc;
   }
   NMX_SYNC();
+#endif
 }
 // largest b in [0, n) with base[b] <= s, for base[] nondecreasing, base[0] = 0 <= s < base[n]
 NMX_DEV uint32_t find_bin(const uint32_t* base, uint32_t n, uint32_t s) {
@@ -104,192 +137,265 @@ NMX_DEV uint32_t find_bin(const uint32_t* base, uint32_t n, uint32_t s) {
   return lo;
 }
 
-// ----------------------------------------------------------------------------------------------------
-// level 1
-// ----------------------------------------------------------------------------------------------------
+// buffers shared by all partition kernels
+struct PartBufs {
+  PartShape ps;
+  uint32_t nbuckets;
+  uint32_t* hist_hi;     // [256]  entries per high bin                                  (zeroed)
+  uint32_t* cur_hi;      // [256]  scatter cursors per high bin                          (zeroed)
+  uint32_t* tab;         // [3 x 257] ent_base | binstart | tilestart  (k_tiles)
+  uint32_t* ent_val;     // [ent_cap] level-1 output: (table row | sign << 31), grouped by high bin
+  uint8_t* ent_lo;       // [ent_cap] low key bits of the same entries
+  uint32_t* bucket_cnt;  // [nbuckets] entries per bucket                                (zeroed)
+  uint32_t* bucket_cur;  // [nbuckets] scatter cursors per bucket                        (zeroed)
+  uint32_t* start;       // [nbuckets + 1]
+  uint32_t* end;         // [nbuckets + 1]
+  uint32_t* vals;        // [n * W] final: words of bucket k at [start[k], end[k])
+  uint32_t* total_out;   // number of non-zero digits of the whole MSM
+};
 template <int SFID> struct PartArgs {
   DigitSrc<SFID> src;
-  PartShape ps;
-  uint32_t* hist_hi;    // [256]  entries per high bin                    (zeroed)
-  uint32_t* cur_hi;     // [256]  scatter cursors per high bin            (zeroed)
-  uint32_t* ent_val;    // [n * W] first-level output: (table row | sign << 31), grouped by high bin
-  uint8_t* ent_lo;      // [n * W] low key bits of the same entries
-  uint32_t* bucket_cnt; // [nbuckets + 1] entries per bucket               (zeroed)
-  uint32_t* bucket_cur; // [nbuckets]     scatter cursors per bucket       (zeroed)
-  uint32_t* start;      // [nbuckets + 1]
-  uint32_t* end;        // [nbuckets + 1]
-  uint32_t* vals;       // [n * W] final: words of bucket k at [start[k], end[k])
-  uint32_t* total_out;  // number of non-zero digits of the whole MSM
+  PartBufs b;
 };
 
-template <int SFID> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_hist_hi(PartArgs<SFID> a) {
-  NMX_LDS uint32_t cnt[256];
-  const uint32_t t = NMX_TID, bs = NMX_BDIM;
-  for (uint32_t j = t; j < 256; j += bs) cnt[j] = 0;
-  NMX_SYNC();
-  const MsmShape& sh = a.src.sh;
-  for (uint32_t base = NMX_BID * bs; base < sh.n; base += NMX_GDIM * bs) {
-    const uint32_t i = base + t;
-    if (i < sh.n) {
-      uint32_t s[9], bi;
-      if (a.src.load(i, s, bi, true)) {
-        uint32_t carry = 0;
-        for (uint32_t w = 0; w < sh.W; w++) {
-          uint32_t d, neg;
-          a.src.digit(s, w, carry, d, neg);
-          if (d) nmx_atomic_add(&cnt[(d - 1) >> a.ps.LB], 1u);
+// ----------------------------------------------------------------------------------------------------
+// digits of one scalar, window width C at compile time (C = 0: run-time width, src.sh.c)
+// ----------------------------------------------------------------------------------------------------
+template <int C> struct WinMax {
+  static constexpr uint32_t value = C ? (256 + C - 1) / C : 64;
+};
+// calls f(w, |d|, neg) for every window with a non-zero digit
+template <int SFID, int C, class Fn> NMX_HD void for_each_digit(const DigitSrc<SFID>& src, const uint32_t (&s)[9], Fn&& f) {
+  const MsmShape& sh = src.sh;
+  uint32_t carry = 0;
+  if constexpr (C == 0) {
+    for (uint32_t w = 0; w < sh.W; w++) {
+      uint32_t d, neg;
+      src.digit(s, w, carry, d, neg);
+      if (d) f(w, d, neg);
+    }
+  } else {
+    constexpr uint32_t mask = (1u << C) - 1u, half = 1u << (C - 1);
+#pragma unroll
+    for (uint32_t w = 0; w < WinMax<C>::value; w++) {
+      if (w < sh.W) {
+        const uint32_t bit = w * C, word = bit >> 5, off = bit & 31;  // constants after unrolling
+        const uint64_t two = ((uint64_t)s[word < 8 ? word + 1 : 8] << 32) | s[word < 8 ? word : 8];  // s[8] = 0
+        uint32_t d = (uint32_t)((two >> off) & mask) + carry;
+        uint32_t neg = 0;
+        if (d > half) {
+          d = (1u << C) - d;
+          neg = 1;
+          carry = 1;
+        } else {
+          carry = 0;
         }
+        if (d) f(w, d, neg);
       }
     }
   }
-  NMX_SYNC();
-  for (uint32_t j = t; j < a.ps.nhi; j += bs)
-    if (cnt[j]) nmx_atomic_add(&a.hist_hi[j], cnt[j]);
 }
 
-template <int SFID> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_part_hi(PartArgs<SFID> a) {
-  NMX_LDS uint32_t stage_val[kStageCap];
-  NMX_LDS uint8_t stage_lo[kStageCap];
-  NMX_LDS uint32_t binstart[257], cnt[256], lbase[257], gbase[256], cur[256];
-  const uint32_t t = NMX_TID, bs = NMX_BDIM;
-  const MsmShape& sh = a.src.sh;
-  const uint32_t nhi = a.ps.nhi, LB = a.ps.LB, lomask = a.ps.nlo - 1u;
-  for (uint32_t j = t; j < 256; j += bs) cnt[j] = j < nhi ? a.hist_hi[j] : 0;
+// ----------------------------------------------------------------------------------------------------
+// level 1
+// ----------------------------------------------------------------------------------------------------
+template <int SFID, int C> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_hist_hi(PartArgs<SFID> a) {
+  NMX_LDS uint32_t cnt[256];
+  const uint32_t t = NMX_TID, bs = NMX_BDIM, LB = a.b.ps.LB;
+  for (uint32_t j = t; j < 256; j += bs) cnt[j] = 0;
   NMX_SYNC();
-  block_excl_scan(cnt, binstart, nhi);  // where each high bin's region starts in ent_val / ent_lo
-  for (uint32_t base = NMX_BID * bs; base < sh.n; base += NMX_GDIM * bs) {
+  const uint32_t n = a.src.sh.n;
+  for (uint32_t base = NMX_BID * bs; base < n; base += NMX_GDIM * bs) {
+    const uint32_t i = base + t;
+    if (i < n) {
+      uint32_t s[9], bi;
+      if (a.src.load(i, s, bi, true))
+        for_each_digit<SFID, C>(a.src, s, [&](uint32_t, uint32_t d, uint32_t) { nmx_atomic_add(&cnt[(d - 1) >> LB], 1u); });
+    }
+  }
+  NMX_SYNC();
+  for (uint32_t j = t; j < a.b.ps.nhi; j += bs)
+    if (cnt[j]) nmx_atomic_add(&a.b.hist_hi[j], cnt[j]);
+}
+
+// (The SFID-independent kernels are templates on a dummy parameter only to get inline linkage across the curve TUs.)
+// One block of 256 threads.  tab[0..257) = ent_base (bin regions of ent_val / ent_lo, 16-entry aligned),
+// tab[257..514) = binstart (bin regions of the final array = exclusive scan of the bin sizes), tab[514..771) = tilestart.
+template <int U> NMX_KERNEL void NMX_LAUNCH_BOUNDS(256) k_tiles(PartBufs b) {
+  NMX_LDS uint32_t h[256], al[256], tl[256], o1[257], o2[257], o3[257], wtot[16];
+  const uint32_t t = NMX_TID, nhi = b.ps.nhi;
+  const uint32_t c = t < nhi ? b.hist_hi[t] : 0;
+  h[t] = c;
+  al[t] = (c + kBinAlign - 1) & ~(kBinAlign - 1);
+  tl[t] = (c + kTile - 1) / kTile;
+  NMX_SYNC();
+  block_excl_scan(al, o1, nhi, wtot);
+  block_excl_scan(h, o2, nhi, wtot);
+  block_excl_scan(tl, o3, nhi, wtot);
+  for (uint32_t j = t; j <= nhi; j += NMX_BDIM) {
+    b.tab[j] = o1[j];
+    b.tab[257 + j] = o2[j];
+    b.tab[514 + j] = o3[j];
+  }
+  if (t < nhi && c == 0) {  // no tile will ever visit this bin: its buckets are empty, placed at the bin's offset
+    for (uint32_t l = 0; l < b.ps.nlo; l++) {
+      b.start[(t << b.ps.LB) + l] = o2[t];
+      b.end[(t << b.ps.LB) + l] = o2[t];
+    }
+  }
+  if (t == 0) {
+    b.start[b.nbuckets] = o2[nhi];  // the (empty) trash slot of the generic layout stays defined
+    b.end[b.nbuckets] = o2[nhi];
+    *b.total_out = o2[nhi];
+  }
+}
+
+template <int SFID, int C> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_part_hi(PartArgs<SFID> a) {
+  NMX_LDS uint32_t stage_val[kStageCap];
+  NMX_LDS uint16_t stage_key[kStageCap];
+  NMX_LDS uint32_t ent_base[256], cnt[256], lbase[257], gbase[256], cur[256], wtot[16];
+  const uint32_t t = NMX_TID, bs = NMX_BDIM;
+  const uint32_t n = a.src.sh.n, nhi = a.b.ps.nhi, LB = a.b.ps.LB, lomask = a.b.ps.nlo - 1u;
+  for (uint32_t j = t; j < nhi; j += bs) ent_base[j] = a.b.tab[j];
+  for (uint32_t base = NMX_BID * bs; base < n; base += NMX_GDIM * bs) {
     for (uint32_t j = t; j < 256; j += bs) cnt[j] = 0, cur[j] = 0;
     NMX_SYNC();
     const uint32_t i = base + t;
     uint32_t s[9], bi = 0;
-    const bool live = i < sh.n && a.src.load(i, s, bi, false);
-    if (live) {  // phase A: count this chunk's entries per bin
-      uint32_t carry = 0;
-      for (uint32_t w = 0; w < sh.W; w++) {
-        uint32_t d, neg;
-        a.src.digit(s, w, carry, d, neg);
-        if (d) nmx_atomic_add(&cnt[(d - 1) >> LB], 1u);
-      }
+    const bool live = i < n && a.src.load(i, s, bi, false);
+    // phase A: this chunk's entries per bin.  With a compile-time width the digits stay in registers for phase B
+    // (key | neg << 15, 0xffff = none); at run-time width they are extracted again.
+    uint16_t dig[C ? WinMax<C>::value : 1];
+    if constexpr (C != 0) {
+#pragma unroll
+      for (uint32_t w = 0; w < WinMax<C>::value; w++) dig[w] = 0xffffu;
     }
+    if (live)
+      for_each_digit<SFID, C>(a.src, s, [&](uint32_t w, uint32_t d, uint32_t neg) {
+        nmx_atomic_add(&cnt[(d - 1) >> LB], 1u);
+        if constexpr (C != 0) dig[w] = (uint16_t)((d - 1) | (neg << 15));
+      });
     NMX_SYNC();
-    block_excl_scan(cnt, lbase, nhi);
+    block_excl_scan(cnt, lbase, nhi, wtot);
     for (uint32_t j = t; j < nhi; j += bs)
-      if (cnt[j]) gbase[j] = binstart[j] + nmx_atomic_add(&a.cur_hi[j], cnt[j]);  // reserve the bin's run
-    NMX_SYNC();
-    if (live) {  // phase B: the same digits again, now placed: LDS slot = bin's local base + arrival rank
-      uint32_t carry = 0;
-      for (uint32_t w = 0; w < sh.W; w++) {
-        uint32_t d, neg;
-        a.src.digit(s, w, carry, d, neg);
-        if (d) {
-          const uint32_t key = d - 1, bin = key >> LB;
-          const uint32_t slot = lbase[bin] + nmx_atomic_add(&cur[bin], 1u);
-          stage_val[slot] = (w * a.src.pre_stride + bi) | (neg << 31);
-          stage_lo[slot] = (uint8_t)(key & lomask);
-        }
+      if (cnt[j]) gbase[j] = ent_base[j] + nmx_atomic_add(&a.b.cur_hi[j], cnt[j]);  // reserve the bin's run
+    // phase B: placed -- LDS slot = bin's local base + arrival rank
+    if (live) {
+      auto place = [&](uint32_t w, uint32_t key, uint32_t neg) {
+        const uint32_t bin = key >> LB;
+        const uint32_t slot = lbase[bin] + nmx_atomic_add(&cur[bin], 1u);
+        stage_val[slot] = (w * a.src.pre_stride + bi) | (neg << 31);
+        stage_key[slot] = (uint16_t)key;
+      };
+      if constexpr (C != 0) {
+#pragma unroll
+        for (uint32_t w = 0; w < WinMax<C>::value; w++)
+          if (dig[w] != 0xffffu) place(w, dig[w] & 0x7fffu, dig[w] >> 15);
+      } else {
+        for_each_digit<SFID, C>(a.src, s, [&](uint32_t w, uint32_t d, uint32_t neg) { place(w, d - 1, neg); });
       }
     }
     NMX_SYNC();
     const uint32_t tot = lbase[nhi];
     for (uint32_t sl = t; sl < tot; sl += bs) {  // consecutive threads -> consecutive addresses inside a bin's run
-      const uint32_t bin = find_bin(lbase, nhi, sl);
+      const uint32_t key = stage_key[sl], bin = key >> LB;
       const uint32_t g = gbase[bin] + (sl - lbase[bin]);
-      a.ent_val[g] = stage_val[sl];
-      a.ent_lo[g] = stage_lo[sl];
+      a.b.ent_val[g] = stage_val[sl];
+      a.b.ent_lo[g] = (uint8_t)(key & lomask);
     }
     NMX_SYNC();
   }
 }
 
 // ----------------------------------------------------------------------------------------------------
-// level 2: tiles of <= kTile entries, each inside one high bin
+// level 2: tiles of <= kTile entries, each inside one high bin (tile starts are 16-entry aligned)
 // ----------------------------------------------------------------------------------------------------
-// tile -> (bin, first entry, length); false past the last tile.  Every thread of the block calls it.
-template <int SFID> NMX_DEV bool tile_of_block(const PartArgs<SFID>& a, uint32_t* binstart, uint32_t* tilestart,
-                                               uint32_t* scratch, uint32_t& bin, uint32_t& first, uint32_t& len) {
-  const uint32_t t = NMX_TID, nhi = a.ps.nhi;
-  if (t < 256) scratch[t] = t < nhi ? a.hist_hi[t] : 0;
+// tile -> (bin, tile index inside the bin, first entry in ent_*, length); false past the last tile (block-uniform).
+NMX_DEV bool tile_of_block(const PartBufs& b, uint32_t* tilestart /* LDS 257 */, uint32_t& bin, uint32_t& j,
+                           uint32_t& first, uint32_t& len) {
+  const uint32_t nhi = b.ps.nhi;
+  for (uint32_t k = NMX_TID; k <= nhi; k += NMX_BDIM) tilestart[k] = b.tab[514 + k];
   NMX_SYNC();
-  block_excl_scan(scratch, binstart, nhi);
-  if (t < 256) scratch[t] = t < nhi ? (scratch[t] + kTile - 1) / kTile : 0;
-  NMX_SYNC();
-  block_excl_scan(scratch, tilestart, nhi);
   const uint32_t tile = NMX_BID;
-  if (tile >= tilestart[nhi]) return false;  // block-uniform
+  if (tile >= tilestart[nhi]) return false;
   bin = find_bin(tilestart, nhi, tile);
-  const uint32_t j = tile - tilestart[bin], size = binstart[bin + 1] - binstart[bin];
-  first = binstart[bin] + j * kTile;
+  j = tile - tilestart[bin];
+  const uint32_t size = b.tab[257 + bin + 1] - b.tab[257 + bin];
+  first = b.tab[bin] + j * kTile;
   len = size - j * kTile < kTile ? size - j * kTile : kTile;
   return true;
 }
+// this thread's kTilePer consecutive low-bit bytes: one aligned 8-byte load (bytes past the tile's length may be read
+// -- the arrays carry a tile of slack -- and are masked by the callers)
+NMX_DEV void load_lo8(const uint8_t* p, uint32_t (&lo)[kTilePer]) {
+  uint64_t w;
+  memcpy(&w, __builtin_assume_aligned(p, 8), 8);
+#pragma unroll
+  for (uint32_t k = 0; k < kTilePer; k++) lo[k] = (uint32_t)(w >> (8 * k)) & 0x7fu;
+}
 
-template <int SFID> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_hist_lo(PartArgs<SFID> a) {
-  NMX_LDS uint32_t binstart[257], tilestart[257], scratch[256], cnt[128];
-  uint32_t bin, first, len;
-  if (!tile_of_block(a, binstart, tilestart, scratch, bin, first, len)) return;
+template <int U> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_hist_lo(PartBufs b) {
+  NMX_LDS uint32_t tilestart[257], cnt[128];
+  uint32_t bin, j, first, len;
+  if (!tile_of_block(b, tilestart, bin, j, first, len)) return;
   const uint32_t t = NMX_TID;
   if (t < 128) cnt[t] = 0;
   NMX_SYNC();
-  for (uint32_t j = t; j < len; j += NMX_BDIM) nmx_atomic_add(&cnt[a.ent_lo[first + j]], 1u);
+  const uint32_t e0 = t * kTilePer;
+  if (e0 < len) {
+    uint32_t lo[kTilePer];
+    load_lo8(b.ent_lo + first + e0, lo);
+#pragma unroll
+    for (uint32_t k = 0; k < kTilePer; k++)
+      if (e0 + k < len) nmx_atomic_add(&cnt[lo[k]], 1u);
+  }
   NMX_SYNC();
-  if (t < a.ps.nlo && cnt[t]) nmx_atomic_add(&a.bucket_cnt[(bin << a.ps.LB) + t], cnt[t]);
+  if (t < b.ps.nlo && cnt[t]) nmx_atomic_add(&b.bucket_cnt[(bin << b.ps.LB) + t], cnt[t]);
 }
 
-// bucket -> [start, end): exclusive scan of the bucket counts (one block; nbuckets <= 2^15)
-template <int SFID> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_scan_buckets(PartArgs<SFID> a) {
-  NMX_LDS uint32_t part[1024], pre[1025];
-  const uint32_t t = NMX_TID, bs = NMX_BDIM, nb = a.src.sh.nbuckets;
-  const uint32_t per = (nb + bs - 1) / bs, lo = t * per, hi = lo + per < nb ? lo + per : nb;
-  uint32_t sum = 0;
-  for (uint32_t k = lo; k < hi; k++) sum += a.bucket_cnt[k];
-  part[t] = sum;
-  NMX_SYNC();
-  block_excl_scan(part, pre, bs);
-  uint32_t run = pre[t];
-  for (uint32_t k = lo; k < hi; k++) {
-    const uint32_t c = a.bucket_cnt[k];
-    a.start[k] = run;
-    run += c;
-    a.end[k] = run;
-  }
-  if (t == 0) {
-    a.start[nb] = pre[bs];  // the (empty) trash slot of the rocPRIM layout: keeps start[nbuckets] / end[nbuckets] defined
-    a.end[nb] = pre[bs];
-    *a.total_out = pre[bs];
-  }
-}
-
-template <int SFID> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_part_lo(PartArgs<SFID> a) {
+template <int U> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_part_lo(PartBufs b) {
   NMX_LDS uint32_t stage[kTile];
-  NMX_LDS uint32_t binstart[257], tilestart[257], scratch[256], cnt[128], lbase[129], gbase[128];
-  uint32_t bin, first, len;
-  if (!tile_of_block(a, binstart, tilestart, scratch, bin, first, len)) return;
-  const uint32_t t = NMX_TID, bs = NMX_BDIM, nlo = a.ps.nlo;
-  if (t < 128) cnt[t] = 0;
+  NMX_LDS uint8_t stage_lo[kTile];
+  NMX_LDS uint32_t tilestart[257], bcnt[128], bstart[129], cnt[128], lbase[129], gbase[128], wtot[16];
+  uint32_t bin, j, first, len;
+  if (!tile_of_block(b, tilestart, bin, j, first, len)) return;
+  const uint32_t t = NMX_TID, bs = NMX_BDIM, nlo = b.ps.nlo, k0 = bin << b.ps.LB;
+  if (t < 128) {
+    cnt[t] = 0;
+    bcnt[t] = t < nlo ? b.bucket_cnt[k0 + t] : 0;
+  }
   NMX_SYNC();
+  block_excl_scan(bcnt, bstart, nlo, wtot);  // the bin's buckets inside the bin's region of the final array
+  const uint32_t region = b.tab[257 + bin];
+  if (j == 0 && t < nlo) {  // first tile of the bin: publish [start, end) of its buckets
+    b.start[k0 + t] = region + bstart[t];
+    b.end[k0 + t] = region + bstart[t + 1];
+  }
   uint32_t v[kTilePer], lo[kTilePer], pos[kTilePer];
+  const uint32_t e0 = t * kTilePer;
+  if (e0 < len) {
+    load_lo8(b.ent_lo + first + e0, lo);
+    memcpy(v, __builtin_assume_aligned(b.ent_val + first + e0, 16), 4 * kTilePer);  // two aligned 16-byte loads
 #pragma unroll
-  for (uint32_t j = 0; j < kTilePer; j++) {
-    const uint32_t e = j * bs + t;
-    if (e < len) {
-      v[j] = a.ent_val[first + e];
-      lo[j] = a.ent_lo[first + e];
-      pos[j] = nmx_atomic_add(&cnt[lo[j]], 1u);  // arrival rank inside the tile's sub-bin
-    }
+    for (uint32_t k = 0; k < kTilePer; k++)
+      if (e0 + k < len) pos[k] = nmx_atomic_add(&cnt[lo[k]], 1u);  // arrival rank inside the tile's sub-bin
   }
   NMX_SYNC();
-  block_excl_scan(cnt, lbase, nlo);
-  if (t < nlo && cnt[t]) {
-    const uint32_t k = (bin << a.ps.LB) + t;
-    gbase[t] = a.start[k] + nmx_atomic_add(&a.bucket_cur[k], cnt[t]);  // this tile's run inside bucket k
-  }
+  block_excl_scan(cnt, lbase, nlo, wtot);
+  if (t < nlo && cnt[t]) gbase[t] = region + bstart[t] + nmx_atomic_add(&b.bucket_cur[k0 + t], cnt[t]);  // the tile's run
+  if (e0 < len) {
 #pragma unroll
-  for (uint32_t j = 0; j < kTilePer; j++)
-    if (j * bs + t < len) stage[lbase[lo[j]] + pos[j]] = v[j];
+    for (uint32_t k = 0; k < kTilePer; k++)
+      if (e0 + k < len) {
+        const uint32_t slot = lbase[lo[k]] + pos[k];
+        stage[slot] = v[k];
+        stage_lo[slot] = (uint8_t)lo[k];
+      }
+  }
   NMX_SYNC();
   for (uint32_t sl = t; sl < len; sl += bs) {
-    const uint32_t b = find_bin(lbase, nlo, sl);
-    a.vals[gbase[b] + (sl - lbase[b])] = stage[sl];
+    const uint32_t l = stage_lo[sl];
+    b.vals[gbase[l] + (sl - lbase[l])] = stage[sl];
   }
 }
 

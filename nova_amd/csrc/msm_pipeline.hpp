@@ -6,6 +6,7 @@
 #pragma once
 #include <stddef.h>
 #include "msm_partition.hpp"
+#include "msm_seg.hpp"
 
 namespace nmx {
 
@@ -26,6 +27,8 @@ struct MsmArgs {
   uint32_t all_ones = 0;
   uint32_t bases_clean = 0;  // 1: the key is known to hold no identity point: the digit stage need not read the bases
   uint32_t no_partition = 0; // 1: generic radix-sort path even where the hand-written partition applies (tests / A-B runs)
+  uint32_t seg_min_total = 1u << 21;  // segment-balanced accumulate (msm_seg.hpp) from this many sorted entries on
+  uint32_t seg_min_len = 8;           // shortest segment a lane is given
 };
 
 inline uint32_t ilog2_u32(uint32_t v) {
@@ -140,28 +143,41 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
     // hand-written two-level LDS partition fused with digit extraction (msm_partition.hpp)
     PartArgs<SFID> pa;
     pa.src = src;
-    pa.ps = make_part_shape(sh);
-    const size_t nctr = 512 + 2 * ((size_t)sh.nbuckets + 1);
+    PartBufs& pb = pa.b;
+    pb.ps = make_part_shape(sh);
+    pb.nbuckets = sh.nbuckets;
+    const size_t nctr = 512 + 3 * 257 + 1 + 2 * (size_t)sh.nbuckets;
     uint32_t* ctr = be.template alloc<uint32_t>(nctr);
-    pa.hist_hi = ctr;
-    pa.cur_hi = ctr + 256;
-    pa.bucket_cnt = ctr + 512;
-    pa.bucket_cur = pa.bucket_cnt + sh.nbuckets + 1;
-    pa.ent_val = be.template alloc<uint32_t>(total);
-    pa.ent_lo = be.template alloc<uint8_t>(total);
+    pb.hist_hi = ctr;
+    pb.cur_hi = ctr + 256;
+    pb.tab = ctr + 512;
+    pb.bucket_cnt = ctr + 512 + 3 * 257 + 1;
+    pb.bucket_cur = pb.bucket_cnt + sh.nbuckets;
+    pb.ent_val = be.template alloc<uint32_t>(pb.ps.ent_cap);
+    pb.ent_lo = be.template alloc<uint8_t>(pb.ps.ent_cap);
     vals1 = be.template alloc<uint32_t>(total);
-    pa.vals = vals1;
-    pa.start = start;
-    pa.end = end;
-    pa.total_out = counters + 5;
+    pb.vals = vals1;
+    pb.start = start;
+    pb.end = end;
+    pb.total_out = counters + 5;
     be.memset0(ctr, nctr * sizeof(uint32_t));
     be.mark("digits");
-    be.launch_kernel(&k_hist_hi<SFID>, pa.ps.grid1, pa.ps.bs1, pa);
+    switch (sh.c) {  // the widths the tables are built with get their own instantiation (constant bit positions)
+      case 16: be.launch_kernel(&k_hist_hi<SFID, 16>, pb.ps.grid1, pb.ps.bs1, pa); break;
+      case 15: be.launch_kernel(&k_hist_hi<SFID, 15>, pb.ps.grid1, pb.ps.bs1, pa); break;
+      case 8: be.launch_kernel(&k_hist_hi<SFID, 8>, pb.ps.grid1, pb.ps.bs1, pa); break;
+      default: be.launch_kernel(&k_hist_hi<SFID, 0>, pb.ps.grid1, pb.ps.bs1, pa);
+    }
+    be.launch_kernel(&k_tiles<0>, 1u, 256u, pb);
     be.mark("sort");
-    be.launch_kernel(&k_part_hi<SFID>, pa.ps.grid1, pa.ps.bs1, pa);
-    be.launch_kernel(&k_hist_lo<SFID>, pa.ps.tiles_cap, kTileThreads, pa);
-    be.launch_kernel(&k_scan_buckets<SFID>, 1u, 1024u, pa);
-    be.launch_kernel(&k_part_lo<SFID>, pa.ps.tiles_cap, kTileThreads, pa);
+    switch (sh.c) {
+      case 16: be.launch_kernel(&k_part_hi<SFID, 16>, pb.ps.grid1, pb.ps.bs1, pa); break;
+      case 15: be.launch_kernel(&k_part_hi<SFID, 15>, pb.ps.grid1, pb.ps.bs1, pa); break;
+      case 8: be.launch_kernel(&k_part_hi<SFID, 8>, pb.ps.grid1, pb.ps.bs1, pa); break;
+      default: be.launch_kernel(&k_part_hi<SFID, 0>, pb.ps.grid1, pb.ps.bs1, pa);
+    }
+    be.launch_kernel(&k_hist_lo<0>, pb.ps.tiles_cap, kTileThreads, pb);
+    be.launch_kernel(&k_part_lo<0>, pb.ps.tiles_cap, kTileThreads, pb);
     be.mark("bounds");
   } else {
     uint32_t* keys0 = be.template alloc<uint32_t>(total);
@@ -184,6 +200,42 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
       be.launch(f, (uint32_t)((total + BoundsFn::kPerLane - 1) / BoundsFn::kPerLane));
     }
   }
+  const uint32_t seg_lanes = part ? be.template seg_lanes<FID>() : 0;
+  if (part && seg_lanes && total >= a.seg_min_total) {
+    // large MSM: equal segments of the entry array per resident lane, raw-limb pieces, short folds (msm_seg.hpp)
+    XYZZL* bucket_raw = be.template alloc<XYZZL>(sh.nbuckets);
+    XYZZL* partial_raw = be.template alloc<XYZZL>(seg_lanes);
+    be.memset0(bucket_raw, sizeof(XYZZL) * sh.nbuckets);
+    const uint32_t* total_p = counters + 5;
+    be.mark("accum");
+    {
+      AccumSegFn<FID> f{(const AffineW*)a.bases, vals1, start, end, total_p, bucket_raw, partial_raw, sh.nbuckets, seg_lanes,
+                        a.seg_min_len};
+      be.launch(f, seg_lanes);
+    }
+    be.mark("fold");
+    {
+      PlanSegFn f{start, end, total_p, counters, heavy, big, sh.nbuckets, seg_lanes, a.seg_min_len};
+      be.launch(f, sh.nbuckets);
+    }
+    {
+      // a bucket spans at most seg_lanes segments; buckets above T partials number at most seg_lanes / T
+      const uint32_t Ts[5] = {32768, 4096, 512, 64, PlanSegFn::kHeavyAbove};
+      for (int p = 0; p < 5; p++) {
+        const uint32_t T = Ts[p], cap = p == 0 ? 0xffffffffu : Ts[p - 1];
+        if (T >= seg_lanes) continue;  // no bucket can have more than T partials
+        const bool use_big = T >= 64;
+        uint32_t bound = seg_lanes / T + 1;
+        if (bound > sh.nbuckets) bound = sh.nbuckets;
+        uint32_t groups = use_big ? (1u << 18) / T : bound;
+        if (groups > bound) groups = bound;
+        if (groups < 1) groups = 1;
+        be.template launch_fold_raw<FID>(counters, use_big ? big : heavy, partial_raw, T, cap, groups, use_big ? 1u : 0u);
+      }
+      be.template launch_final_seg<FID>(start, end, total_p, bucket_raw, partial_raw, buckets, sh.nbuckets, seg_lanes,
+                                        a.seg_min_len);
+    }
+  } else {
   {
     PlanFn f{start, end, counters, heavy, big, sh};
     be.launch(f, (sh.nbuckets + PlanFn::kPerLane - 1) / PlanFn::kPerLane);  // each lane plans kPerLane buckets
@@ -222,6 +274,7 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
       if (groups < 1) groups = 1;
       be.template launch_fold<FID>(counters, T >= 64 ? big : heavy, partials, buckets, T, cap, groups);
     }
+  }
   }
   be.mark("reduce");
   const XYZZW* D = buckets;

@@ -1,0 +1,181 @@
+// msm_seg.hpp -- segment-balanced bucket accumulation (large MSMs on the table path).
+//
+// Round 1's accumulate kernel gave every lane one TASK (<= lmax = 24 consecutive entries of one bucket): ~730 k tasks
+// at 2^20 = 3.7 rounds of the chip's resident lanes, so the last round ran partly empty (7 % of the kernel), and
+// every bucket was left as ~22 partial sums for the fold passes (0.13 ms).  Here the sorted entry array [0, total) is
+// cut into exactly as many equal SEGMENTS as lanes are resident (CUs x waves x 64), whatever the bucket boundaries:
+//
+//   AccumSegFn   lane L adds entries [L * seg, (L + 1) * seg) in order, crossing bucket boundaries as they come.  The
+//                piece of a bucket that STARTS inside the lane is written to bucket_raw[k]; the piece that continues a
+//                bucket begun in an earlier lane (at most one per lane, its first) to partial_raw[L].  Hence
+//                     bucket k = bucket_raw[k] + sum of partial_raw[L] for L in (L0, L1],  L0 = start[k] / seg,
+//                                                                                             L1 = (end[k] - 1) / seg
+//                -- a contiguous range.  All lanes do the same number of mixed additions (+-1): no tail round.
+//   PlanSegFn    buckets spanning more than 8 / 64 lanes -> `heavy` / `big` lists (same records as round 1's plan)
+//   FoldRawFn    strided pre-folds of those ranges (T = 32768 ... 64 over `big`, then 8 over `heavy`)
+//   FinalSegFn   every bucket: bucket_raw[k] + its (<= 8 remaining) partials -> canonical XYZZW for the reduction tree
+//
+// A bucket of 512 entries spans ~6 segments of 86: the fold work per bucket drops from ~22 partials to ~6.
+// Pieces are stored as raw 9-limb coordinates (XYZZL, 144 B): a flush sits inside a divergent branch (lanes of a wave
+// cross bucket boundaries at different entries), so it must be a handful of stores, not four canonicalisations.
+#pragma once
+#include "msm_kernels.hpp"
+
+namespace nmx {
+
+// entries per lane for `total` entries over `lanes` lanes (computed on the device: `total` is only known there)
+NMX_HD uint32_t seg_len(uint32_t total, uint32_t lanes, uint32_t min_seg) {
+  const uint32_t s = (uint32_t)(((uint64_t)total + lanes - 1) / lanes);
+  return s < min_seg ? min_seg : s;
+}
+
+template <int FID> struct AccumSegFn {
+  const AffineW* bases;
+  const uint32_t* vals;
+  const uint32_t* start;
+  const uint32_t* end;
+  const uint32_t* total_p;  // number of entries (device memory: written by the partition's scan kernel)
+  XYZZL* bucket_raw;        // [nbuckets], zero-initialised (= identity)
+  XYZZL* partial_raw;       // [lanes]
+  uint32_t nbuckets, lanes, min_seg;
+
+  NMX_HD void operator()(uint32_t L) const {
+    const uint32_t total = *total_p;
+    const uint32_t seg = seg_len(total, lanes, min_seg);
+    const uint64_t a64 = (uint64_t)L * seg;
+    if (a64 >= total) return;
+    const uint32_t a = (uint32_t)a64, b = (a64 + seg < total) ? a + seg : total;
+    // bucket of entry a: the smallest k with end[k] > a (end[] is nondecreasing, end[nbuckets - 1] = total > a)
+    uint32_t lo = 0, hi = nbuckets - 1;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (end[mid] > a) hi = mid;
+      else lo = mid + 1;
+    }
+    uint32_t k = lo, e = end[k];
+    bool head = start[k] < a;  // this lane's first piece continues a bucket begun earlier
+    XYZZ<FID> acc = XYZZ<FID>::identity();
+    // same two-stage software pipeline as AccumFn: index two entries ahead, gather one ahead
+    uint32_t v = vals[a];
+    uint32_t vn = a + 1 < b ? vals[a + 1] : v;
+    AffineW cur = bases[v & 0x7fffffffu];
+    for (uint32_t j = a; j < b; j++) {
+      uint32_t vnn = vn;
+      AffineW nxt = cur;
+      if (j + 1 < b) nxt = bases[vn & 0x7fffffffu];
+      if (j + 2 < b) vnn = vals[j + 2];
+      if (j == e) {  // bucket k is complete inside this lane (or its continued piece is)
+        if (head) acc.store_raw(partial_raw[L]);
+        else acc.store_raw(bucket_raw[k]);
+        head = false;
+        acc = XYZZ<FID>::identity();
+        do {  // the next non-empty bucket
+          k++;
+          e = end[k];
+        } while (e <= j);
+      }
+      acc.add_affine(Affine<FID>::load(cur), (v >> 31) != 0);
+      cur = nxt;
+      v = vn;
+      vn = vnn;
+    }
+    if (head) acc.store_raw(partial_raw[L]);
+    else acc.store_raw(bucket_raw[k]);
+  }
+};
+
+// Buckets whose entries span many lanes: lists for the pre-fold passes.  counters as in PlanFn: [1] heavy count,
+// [3] largest partial count among the big buckets, [4] big count.
+struct PlanSegFn {
+  static constexpr bool kFullWaves = true;
+  static constexpr uint32_t kHeavyAbove = 8, kBigAbove = 64;
+  const uint32_t* start;
+  const uint32_t* end;
+  const uint32_t* total_p;
+  uint32_t* counters;
+  HeavyRec* heavy;
+  HeavyRec* big;
+  uint32_t nbuckets, lanes, min_seg;
+  NMX_HD void operator()(uint32_t k) const { (*this)(k, true); }
+  NMX_HD void operator()(uint32_t k, bool valid) const {
+    const uint32_t seg = seg_len(*total_p, lanes, min_seg);
+    uint32_t cnt = 0, off = 0;
+    if (valid && k < nbuckets) {
+      const uint32_t s0 = start[k], e0 = end[k];
+      if (e0 > s0) {
+        const uint32_t l0 = s0 / seg, l1 = (e0 - 1) / seg;
+        cnt = l1 - l0;
+        off = l0 + 1;
+      }
+    }
+    const bool is_heavy = cnt > kHeavyAbove;
+    uint32_t slot = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long m = __ballot(is_heavy);
+    if (m == 0) return;  // wave-uniform
+    const uint32_t lane = __lane_id();
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&counters[1], (uint32_t)__popcll(m));  // one atomic per wave
+    base = __shfl(base, 0);
+    slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+#else
+    if (is_heavy) slot = counters[1]++;
+#endif
+    if (!is_heavy) return;
+    const HeavyRec r{k, off, cnt, 0};
+    heavy[slot] = r;
+    if (cnt > kBigAbove) {
+      nmx_atomic_max(&counters[3], cnt);
+      big[nmx_atomic_add(&counters[4], 1)] = r;
+    }
+  }
+};
+
+// FoldFn on raw partials: lane j of group g folds positions j, j + T, j + 2T, ... < min(cnt, cap) of a listed bucket
+// into position j (in place).  T = 32768, 4096, 512, 64 over `big`; T = 8 over `heavy`.
+template <int FID> struct FoldRawFn {
+  const uint32_t* counters;
+  const HeavyRec* list;
+  XYZZL* partial_raw;
+  uint32_t T, cap, groups;
+  uint32_t use_big;  // 1: walk the big list (counters[4], skip the pass when counters[3] <= T)
+  NMX_HD void operator()(uint32_t tid) const {
+    if (use_big && counters[3] <= T) return;
+    const uint32_t j = tid % T, nh = counters[use_big ? 4 : 1];
+    for (uint32_t h = tid / T; h < nh; h += groups) {
+      const HeavyRec r = list[h];
+      const uint32_t cnt = r.cnt < cap ? r.cnt : cap;
+      if (j + T >= cnt) continue;  // nothing to add into position j
+      XYZZ<FID> acc = XYZZ<FID>::load_raw(partial_raw[r.off + j]);
+      for (uint32_t q = j + T; q < cnt; q += T) acc.add(XYZZ<FID>::load_raw(partial_raw[r.off + q]));
+      acc.store_raw(partial_raw[r.off + j]);
+    }
+  }
+};
+
+// Every bucket: the piece that started it + the partials that continue it (after the pre-folds at most kHeavyAbove of
+// them hold everything) -> canonical XYZZW.
+template <int FID> struct FinalSegFn {
+  const uint32_t* start;
+  const uint32_t* end;
+  const uint32_t* total_p;
+  const XYZZL* bucket_raw;
+  const XYZZL* partial_raw;
+  XYZZW* buckets;
+  uint32_t nbuckets, lanes, min_seg;
+  NMX_HD void operator()(uint32_t k) const {
+    const uint32_t s0 = start[k], e0 = end[k];
+    XYZZ<FID> acc = XYZZ<FID>::identity();
+    if (e0 > s0) {
+      const uint32_t seg = seg_len(*total_p, lanes, min_seg);
+      const uint32_t l0 = s0 / seg, l1 = (e0 - 1) / seg;
+      uint32_t cnt = l1 - l0;
+      if (cnt > PlanSegFn::kHeavyAbove) cnt = PlanSegFn::kHeavyAbove;
+      acc = XYZZ<FID>::load_raw(bucket_raw[k]);
+      for (uint32_t j = 0; j < cnt; j++) acc.add(XYZZ<FID>::load_raw(partial_raw[l0 + 1 + j]));
+    }
+    acc.store(buckets[k]);
+  }
+};
+
+}  // namespace nmx

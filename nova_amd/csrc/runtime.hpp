@@ -125,6 +125,10 @@ struct Global {
   uint32_t force_fold_t = 0;  // env NMX_TUNE_FOLD_T (tuning only)
   uint32_t no_quad_accum = 0;  // env NMX_TUNE_NO_QUAD_ACCUM (tuning only)
   uint32_t no_partition = 0;   // env NMX_TUNE_NO_PARTITION: generic radix-sort path everywhere (A/B runs)
+  uint32_t seg_min_total = 1u << 21;  // env NMX_TUNE_SEG_MIN_TOTAL: msm_seg.hpp from this many sorted entries (0xffffffff: never)
+  uint32_t seg_min_len = 8;           // env NMX_TUNE_SEG_MIN_LEN
+  uint32_t seg_lanes_override = 0;    // env NMX_TUNE_SEG_LANES (0: the kernel's resident lane count)
+  uint32_t no_quad_final = 0;         // env NMX_TUNE_NO_QUAD_FINAL
 };
 extern Global G;                 // capi.hip
 void prof_store(const float* ms, int n);   // last call's stage times of this thread (capi.hip)
@@ -194,6 +198,39 @@ struct DeviceBackend {
     } else {
       AccumFn<FID> f{bases, vals, start, end, counters, extra, buckets, partials, sh};
       launch(f, slots);
+    }
+  }
+  // segment-balanced accumulate (msm_seg.hpp): exactly as many lanes as the chip holds resident for that kernel
+  template <int FID> uint32_t seg_lanes() {
+    static const uint32_t lanes = [] {
+      int blocks = 0, dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0u;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_launch<AccumSegFn<FID>>, 256, 0) != hipSuccess) return 0u;
+      return (uint32_t)blocks * 256u * (uint32_t)prop.multiProcessorCount;
+    }();
+    return G.seg_lanes_override ? G.seg_lanes_override : lanes;
+  }
+  template <int FID>
+  void launch_fold_raw(const uint32_t* counters, const HeavyRec* list, XYZZL* partial_raw, uint32_t T, uint32_t cap,
+                       uint32_t groups, uint32_t use_big) {
+    if (groups * T < kQuadBelowItems) {
+      FoldRawQuadFn<FID> f{counters, list, partial_raw, T, cap, groups, use_big};
+      launch(f, groups * T * 4);
+    } else {
+      FoldRawFn<FID> f{counters, list, partial_raw, T, cap, groups, use_big};
+      launch(f, groups * T);
+    }
+  }
+  template <int FID>
+  void launch_final_seg(const uint32_t* start, const uint32_t* end, const uint32_t* total_p, const XYZZL* bucket_raw,
+                        const XYZZL* partial_raw, XYZZW* buckets, uint32_t nbuckets, uint32_t lanes, uint32_t min_seg) {
+    if (nbuckets < kQuadBelowItems && !G.no_quad_final) {
+      FinalSegQuadFn<FID> f{start, end, total_p, bucket_raw, partial_raw, buckets, nbuckets, lanes, min_seg};
+      launch(f, nbuckets * 4);
+    } else {
+      FinalSegFn<FID> f{start, end, total_p, bucket_raw, partial_raw, buckets, nbuckets, lanes, min_seg};
+      launch(f, nbuckets);
     }
   }
   template <int FID>

@@ -20,6 +20,9 @@
 
 using namespace nmx;
 
+static uint32_t g_seg_lanes = 37;             // emul_set_seg_lanes
+static uint32_t g_seg_min_total = 1u << 21;  // emul_set_seg_min_total: lower it to route small MSMs through msm_seg.hpp
+
 struct HostEmulBackend {
   std::vector<void*> blocks;
   ~HostEmulBackend() {
@@ -58,6 +61,20 @@ struct HostEmulBackend {
     ReducePairFn<FID> f{D, Y, Do, Yo, n_in, pairs, padded, first};
     launch(f, 2 * padded);
   }
+  // segment-balanced accumulate (msm_seg.hpp): an odd lane count so segments straddle bucket boundaries everywhere
+  template <int FID> uint32_t seg_lanes() { return g_seg_lanes; }
+  template <int FID>
+  void launch_fold_raw(const uint32_t* counters, const HeavyRec* list, XYZZL* partial_raw, uint32_t T, uint32_t cap,
+                       uint32_t groups, uint32_t use_big) {
+    FoldRawFn<FID> f{counters, list, partial_raw, T, cap, groups, use_big};
+    launch(f, groups * T);
+  }
+  template <int FID>
+  void launch_final_seg(const uint32_t* start, const uint32_t* end, const uint32_t* total_p, const XYZZL* bucket_raw,
+                        const XYZZL* partial_raw, XYZZW* buckets, uint32_t nbuckets, uint32_t lanes, uint32_t min_seg) {
+    FinalSegFn<FID> f{start, end, total_p, bucket_raw, partial_raw, buckets, nbuckets, lanes, min_seg};
+    launch(f, nbuckets);
+  }
   void sort_pairs(uint32_t* k_in, uint32_t* k_out, uint32_t* v_in, uint32_t* v_out, size_t total, uint32_t bits) {
     std::vector<uint32_t> idx(total);
     std::iota(idx.begin(), idx.end(), 0u);
@@ -73,6 +90,7 @@ struct HostEmulBackend {
   void sync() {}
   void mark(const char*) {}
 };
+
 
 template <int CID>
 static int emul_msm_t(const uint8_t* scalars, const uint8_t* bases_xy64, size_t n, uint32_t u64_bits,
@@ -107,6 +125,8 @@ static int emul_msm_t(const uint8_t* scalars, const uint8_t* bases_xy64, size_t 
     a.scalars_mont = scalars_mont;
     a.u64_bits = u64_mode ? u64_bits : 0;
     a.force_c = force_c;
+    a.seg_min_total = g_seg_min_total;
+    a.seg_min_len = 3;
     HostEmulBackend be;
     XYZZW wsum[260];
     uint32_t err = 0;
@@ -144,37 +164,47 @@ template <int FID> static void fp_op_t(int op, const uint8_t* a, const uint8_t* 
 // The partition kernels alone (no curve arithmetic) against DigitsFn + std::sort: same multiset of (row | sign) words
 // per bucket, consistent start / end, total = number of non-zero digits.  grid_override forces the grid-stride loops.
 static int partition_check(const uint8_t* scalars, size_t n, uint32_t c, uint32_t u64_bits, uint32_t grid_override,
-                           uint32_t stride, uint32_t offset) {
+                           uint32_t stride, uint32_t offset, uint32_t ct_width) {
   constexpr int SF = F_BN254_FR;
   const uint32_t bits = u64_bits ? u64_bits : (uint32_t)FpParams<SF>::BITS;
   MsmShape sh = make_shape((uint32_t)n, bits, 0, c);
   if (!partition_supported(sh, true)) return -2;
   const size_t total = sh.total;
-  std::vector<uint32_t> start(sh.nbuckets + 1), end(sh.nbuckets + 1), ctr(512 + 2 * ((size_t)sh.nbuckets + 1)), vals(total + 1),
-      ent_val(total + 1), keys(total + 1), kvals(total + 1);
-  std::vector<uint8_t> ent_lo(total + 1);
+  PartArgs<SF> pa;
+  PartBufs& pb = pa.b;
+  pb.ps = make_part_shape(sh);
+  if (grid_override) pb.ps.grid1 = grid_override;
+  pb.nbuckets = sh.nbuckets;
+  std::vector<uint32_t> start(sh.nbuckets + 1), end(sh.nbuckets + 1), ctr(512 + 3 * 257 + 1 + 2 * (size_t)sh.nbuckets),
+      vals(total + 1), ent_val(pb.ps.ent_cap), keys(total + 1), kvals(total + 1);
+  std::vector<uint8_t> ent_lo(pb.ps.ent_cap);
   uint32_t err = 0, tot = 0;
   DigitSrc<SF> src{(const uint32_t*)scalars, nullptr, &err, sh, 0, u64_bits, stride, offset, nullptr, 0};
-  PartArgs<SF> pa;
   pa.src = src;
-  pa.ps = make_part_shape(sh);
-  if (grid_override) pa.ps.grid1 = grid_override;
-  pa.hist_hi = ctr.data();
-  pa.cur_hi = ctr.data() + 256;
-  pa.bucket_cnt = ctr.data() + 512;
-  pa.bucket_cur = pa.bucket_cnt + sh.nbuckets + 1;
-  pa.ent_val = ent_val.data();
-  pa.ent_lo = ent_lo.data();
-  pa.start = start.data();
-  pa.end = end.data();
-  pa.vals = vals.data();
-  pa.total_out = &tot;
+  pb.hist_hi = ctr.data();
+  pb.cur_hi = ctr.data() + 256;
+  pb.tab = ctr.data() + 512;
+  pb.bucket_cnt = ctr.data() + 512 + 3 * 257 + 1;
+  pb.bucket_cur = pb.bucket_cnt + sh.nbuckets;
+  pb.ent_val = ent_val.data();
+  pb.ent_lo = ent_lo.data();
+  pb.start = start.data();
+  pb.end = end.data();
+  pb.vals = vals.data();
+  pb.total_out = &tot;
   HostEmulBackend be;
-  be.launch_kernel(&k_hist_hi<SF>, pa.ps.grid1, pa.ps.bs1, pa);
-  be.launch_kernel(&k_part_hi<SF>, pa.ps.grid1, pa.ps.bs1, pa);
-  be.launch_kernel(&k_hist_lo<SF>, pa.ps.tiles_cap, kTileThreads, pa);
-  be.launch_kernel(&k_scan_buckets<SF>, 1u, 1024u, pa);
-  be.launch_kernel(&k_part_lo<SF>, pa.ps.tiles_cap, kTileThreads, pa);
+  auto l1 = [&](auto hist, auto part) {
+    be.launch_kernel(hist, pb.ps.grid1, pb.ps.bs1, pa);
+    be.launch_kernel(&k_tiles<0>, 1u, 256u, pb);
+    be.launch_kernel(part, pb.ps.grid1, pb.ps.bs1, pa);
+  };
+  const uint32_t cc = ct_width ? c : 0;  // compile-time-width instantiation (when there is one) or the run-time one
+  if (cc == 16) l1(&k_hist_hi<SF, 16>, &k_part_hi<SF, 16>);
+  else if (cc == 15) l1(&k_hist_hi<SF, 15>, &k_part_hi<SF, 15>);
+  else if (cc == 8) l1(&k_hist_hi<SF, 8>, &k_part_hi<SF, 8>);
+  else l1(&k_hist_hi<SF, 0>, &k_part_hi<SF, 0>);
+  be.launch_kernel(&k_hist_lo<0>, pb.ps.tiles_cap, kTileThreads, pb);
+  be.launch_kernel(&k_part_lo<0>, pb.ps.tiles_cap, kTileThreads, pb);
   // reference: materialised (key, val) pairs grouped by key
   uint32_t err2 = 0;
   DigitSrc<SF> src2 = src;
@@ -205,9 +235,12 @@ static int partition_check(const uint8_t* scalars, size_t n, uint32_t c, uint32_
 
 extern "C" {
 
+void emul_set_seg_min_total(uint32_t v) { g_seg_min_total = v; }
+void emul_set_seg_lanes(uint32_t v) { g_seg_lanes = v; }
+
 int emul_partition_check(const uint8_t* scalars, size_t n, uint32_t c, uint32_t u64_bits, uint32_t grid_override,
-                         uint32_t stride, uint32_t offset) {
-  return partition_check(scalars, n, c, u64_bits, grid_override, stride, offset);
+                         uint32_t stride, uint32_t offset, uint32_t ct_width) {
+  return partition_check(scalars, n, c, u64_bits, grid_override, stride, offset, ct_width);
 }
 
 int emul_msm(int curve, const uint8_t* scalars, const uint8_t* bases_xy64, size_t n, uint32_t u64_bits,

@@ -36,7 +36,7 @@ def emul():
                                    ctypes.c_void_p]
     L.emul_fp_op.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
     L.emul_partition_check.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
-                                       ctypes.c_uint32, ctypes.c_uint32]
+                                       ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
     return L
 
 
@@ -252,7 +252,7 @@ def test_emul_precomputed_tables(emul, c):
 
 
 @pytest.mark.parametrize("c,n,grid", [(16, 40000, 0), (16, 40000, 3), (15, 20011, 2), (8, 30000, 5), (8, 700, 0), (12, 5000, 1),
-                                      (4, 300, 0), (16, 1, 0), (16, 1025, 0)])
+                                      (6, 300, 0), (16, 1, 0), (16, 1025, 0)])
 def test_emul_partition_kernels(emul, c, n, grid):
     """The hand-written LDS partition (msm_partition.hpp) run thread by thread on the CPU (tests/host_emul/simt.hpp:
     one fiber per GPU thread, real barriers) against DigitsFn + a sort: per-bucket multisets, start / end, totals.
@@ -260,7 +260,38 @@ def test_emul_partition_kernels(emul, c, n, grid):
     everything dropped as a zero digit (u1), and 0 / r-1."""
     for kind in ["random", "equal", "zero_rm1", "u1", "pm_small"]:
         sc = np.ascontiguousarray(util.scalar_set(0, n, kind))
-        rc = emul.emul_partition_check(sc.ctypes.data, n, c, 0, grid, n + 7, 3)
-        assert rc == 0, (c, n, grid, kind, rc)
+        for ct in (1, 0):     # the compile-time-width instantiation (c = 8 / 15 / 16) and the run-time-width one
+            rc = emul.emul_partition_check(sc.ctypes.data, n, c, 0, grid, n + 7, 3, ct)
+            assert rc == 0, (c, n, grid, kind, ct, rc)
     s64 = np.ascontiguousarray(util.small_scalars(n, 33))
-    assert emul.emul_partition_check(s64.ctypes.data, n, c, 33, grid, n, 0) == 0
+    assert emul.emul_partition_check(s64.ctypes.data, n, c, 33, grid, n, 0, 1) == 0
+
+
+@pytest.mark.parametrize("lanes", [37, 700, 5000])
+def test_emul_segment_balanced_accumulate(emul, lanes):
+    """msm_seg.hpp (AccumSegFn / PlanSegFn / FoldRawFn / FinalSegFn) on the table path: segments that straddle bucket
+    boundaries, buckets spanning 0, a few, > 8 (heavy list) and > 64 (big list, strided pre-folds) lanes, empty buckets,
+    identity points inside the key, prefixes / interior slices, small-scalar mode -- all against the oracle."""
+    emul.emul_set_seg_min_total(0)
+    emul.emul_set_seg_lanes(lanes)
+    try:
+        c = R.BN254_G1
+        n_key = 1000
+        key = cref.sequential_bases(c, 21, n_key).copy()
+        key[13] = 0
+        for pre_c, off, n, kind in [(8, 0, n_key, "random"), (8, 0, n_key, "equal"), (8, 100, 777, "zero_rm1"), (11, 0, 999, "pm_small"),
+                                    (16, 5, 150, "random"), (8, 0, 1, "random"), (8, 0, n_key, "u1"), (12, 3, 900, "equal")]:
+            sc = util.scalar_set(c.cid, n, kind)
+            rc, got, inf = run_pre(emul, c.cid, sc, key, n_key, off, n, pre_c)
+            assert rc == 0 and (got, inf) == cref.msm(c.cid, sc, key[off:off + n], n), (lanes, pre_c, off, n, kind)
+        s = util.small_scalars(n_key, 33)
+        rc, got, inf = run_pre(emul, c.cid, s, key, n_key, 0, n_key, 9, u64_bits=33)
+        assert rc == 0 and (got, inf) == cref.msm_u64(c.cid, s, key, n_key, 33)
+        cc = R.VESTA
+        key = cref.sequential_bases(cc, 5, 300)
+        sc = util.scalar_set(cc.cid, 300, "zero_rm1")
+        rc, got, inf = run_pre(emul, cc.cid, sc, key, 300, 0, 300, 8)
+        assert rc == 0 and (got, inf) == cref.msm(cc.cid, sc, key, 300)
+    finally:
+        emul.emul_set_seg_min_total(1 << 21)
+        emul.emul_set_seg_lanes(37)
