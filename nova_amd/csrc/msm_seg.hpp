@@ -39,21 +39,28 @@ template <int FID> struct AccumSegFn {
   XYZZL* partial_raw;       // [lanes]
   uint32_t nbuckets, lanes, min_seg;
 
+  // the smallest k >= k0 with end[k] > j (end[] is nondecreasing and end[nbuckets - 1] = total > j)
+  NMX_HD uint32_t first_bucket_after(uint32_t k0, uint32_t j) const {
+    uint32_t lo = k0, hi = nbuckets - 1;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (end[mid] > j) hi = mid;
+      else lo = mid + 1;
+    }
+    return lo;
+  }
   NMX_HD void operator()(uint32_t L) const {
     const uint32_t total = *total_p;
     const uint32_t seg = seg_len(total, lanes, min_seg);
     const uint64_t a64 = (uint64_t)L * seg;
     if (a64 >= total) return;
     const uint32_t a = (uint32_t)a64, b = (a64 + seg < total) ? a + seg : total;
-    // bucket of entry a: the smallest k with end[k] > a (end[] is nondecreasing, end[nbuckets - 1] = total > a)
-    uint32_t lo = 0, hi = nbuckets - 1;
-    while (lo < hi) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (end[mid] > a) hi = mid;
-      else lo = mid + 1;
-    }
-    uint32_t k = lo, e = end[k];
-    bool head = start[k] < a;  // this lane's first piece continues a bucket begun earlier
+    uint32_t k = first_bucket_after(0, a), e = end[k];
+    // The boundary after next is loaded one bucket ahead: a load issued inside the crossing branch would make the wave
+    // wait for everything in flight (vmcnt retires in order: the prefetched gathers, the flush's stores) on EVERY
+    // crossing of ANY of its lanes -- ~75 times per 86 additions.
+    uint32_t e_next = end[k + 1];  // end[] has nbuckets + 1 entries
+    bool head = start[k] < a;      // this lane's first piece continues a bucket begun earlier
     XYZZ<FID> acc = XYZZ<FID>::identity();
     // same two-stage software pipeline as AccumFn: index two entries ahead, gather one ahead
     uint32_t v = vals[a];
@@ -69,10 +76,13 @@ template <int FID> struct AccumSegFn {
         else acc.store_raw(bucket_raw[k]);
         head = false;
         acc = XYZZ<FID>::identity();
-        do {  // the next non-empty bucket
-          k++;
+        k++;
+        e = e_next;
+        if (e <= j) {  // empty buckets follow (skewed scalars): search instead of walking them one dependent load at a time
+          k = first_bucket_after(k, j);
           e = end[k];
-        } while (e <= j);
+        }
+        e_next = end[k + 1];
       }
       acc.add_affine(Affine<FID>::load(cur), (v >> 31) != 0);
       cur = nxt;
