@@ -226,7 +226,8 @@ def main():
             "per_call_ms": {"median": round(float(np.median(per_call)) * 1e3, 4), "min": round(min(per_call) * 1e3, 4)},
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_launch<AccumFn> (bucket accumulation)",
+                "kernel": "k_launch<AccumSegFn> (bucket accumulation, segment-balanced)" if n * madds_per_launch(1, args) >= (1 << 22) and not args.window_bits
+                          else "k_launch<AccumFn> (bucket accumulation)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

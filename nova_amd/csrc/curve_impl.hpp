@@ -141,6 +141,7 @@ static XYZZ<CurveT<CID>::BF> run_msm(Ctx& c, const void* d_bases, size_t n, cons
   a.no_partition = G.no_partition;
   a.seg_min_total = G.seg_min_total;
   a.seg_min_len = G.seg_min_len;
+  a.accum_prefetch = G.accum_prefetch;
   {
     uint32_t bits = a.u64_bits ? a.u64_bits : sbits;
     MsmShape sh = make_shape(a.n, bits, a.force_c, a.pre_stride ? a.pre_c : 0);

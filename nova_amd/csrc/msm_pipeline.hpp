@@ -27,8 +27,9 @@ struct MsmArgs {
   uint32_t all_ones = 0;
   uint32_t bases_clean = 0;  // 1: the key is known to hold no identity point: the digit stage need not read the bases
   uint32_t no_partition = 0; // 1: generic radix-sort path even where the hand-written partition applies (tests / A-B runs)
-  uint32_t seg_min_total = 1u << 21;  // segment-balanced accumulate (msm_seg.hpp) from this many sorted entries on
+  uint32_t seg_min_total = 1u << 22;  // segment-balanced accumulate (msm_seg.hpp) from this many sorted entries on
   uint32_t seg_min_len = 8;           // shortest segment a lane is given
+  uint32_t accum_prefetch = 1;        // gathers in flight ahead of the addition (AccumSegFn PF)
 };
 
 inline uint32_t ilog2_u32(uint32_t v) {
@@ -65,16 +66,18 @@ inline uint32_t choose_c(uint32_t n, uint32_t bits) {
   return (uint32_t)c;
 }
 
-// Window width of the precomputed tables of a key of n_key points, from two measured sweeps
-// (profiles/r01_msm_2p20/window_width_sweep.txt, window_width_sweep_small.txt):
+// Window width of the precomputed tables of a key of n_key points, from measured sweeps
+// (profiles/r01_msm_2p20/window_width_sweep.txt for >= 2^20; profiles/r02_msm_2p20/window_width_sweep_partition.txt for
+// the smaller keys, re-swept with the hand-written partition, whose cost no longer steps with the key width):
 //   >= 2^22 points  c = 20   13 windows instead of 16: -19 % mixed additions; 2^19 buckets need that many points
-//   >= 2^18         c = 16   16-bit sort keys (two radix passes), 2^15 buckets
-//   >= 2^16         c = 15   one level less in the (latency-bound) bucket reduction tree
-//   below           c = 8    8-bit keys sort in ONE radix pass and the tree has 7 levels; these MSMs are pure latency
+//   >= 2^17         c = 16   2^15 buckets (2^17: 0.503 ms against 0.515 at c = 15, 0.683 at c = 8)
+//   >= 2^14         c = 15   one level less in the (latency-bound) reduction tree (2^15: 0.373 against 0.410 at c = 8;
+//                            2^16: 0.415 against 0.438 at c = 16)
+//   below           c = 8    2^7 buckets: seven tree levels; these MSMs are pure latency (2^13: 0.310, flat in c)
 inline uint32_t choose_c_precomp(uint32_t n_key, uint32_t bits) {
   uint32_t lg = ilog2_u32(n_key < 2 ? 2 : n_key);
   if (lg >= 22) return 20;
-  const int c = lg >= 18 ? 16 : lg >= 16 ? 15 : 8;
+  const int c = lg >= 17 ? 16 : lg >= 14 ? 15 : 8;
   return settle_c(c, 8, 16, bits);
 }
 
@@ -208,9 +211,13 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
     be.memset0(bucket_raw, sizeof(XYZZL) * sh.nbuckets);
     const uint32_t* total_p = counters + 5;
     be.mark("accum");
-    {
-      AccumSegFn<FID> f{(const AffineW*)a.bases, vals1, start, end, total_p, bucket_raw, partial_raw, sh.nbuckets, seg_lanes,
-                        a.seg_min_len};
+    if (a.accum_prefetch > 1) {
+      AccumSegFn<FID, 2> f{(const AffineW*)a.bases, vals1, start, end, total_p, bucket_raw, partial_raw, sh.nbuckets,
+                           seg_lanes, a.seg_min_len};
+      be.launch(f, seg_lanes);
+    } else {
+      AccumSegFn<FID, 1> f{(const AffineW*)a.bases, vals1, start, end, total_p, bucket_raw, partial_raw, sh.nbuckets,
+                           seg_lanes, a.seg_min_len};
       be.launch(f, seg_lanes);
     }
     be.mark("fold");

@@ -29,7 +29,9 @@ NMX_HD uint32_t seg_len(uint32_t total, uint32_t lanes, uint32_t min_seg) {
   return s < min_seg ? min_seg : s;
 }
 
-template <int FID> struct AccumSegFn {
+// PF = how many gathers are in flight ahead of the addition being computed (1: as AccumFn; 2: one more 64-byte row
+// in registers, for the case where the gather latency under full load exceeds one addition of the wave's neighbours)
+template <int FID, int PF = 1> struct AccumSegFn {
   const AffineW* bases;
   const uint32_t* vals;
   const uint32_t* start;
@@ -62,15 +64,25 @@ template <int FID> struct AccumSegFn {
     uint32_t e_next = end[k + 1];  // end[] has nbuckets + 1 entries
     bool head = start[k] < a;      // this lane's first piece continues a bucket begun earlier
     XYZZ<FID> acc = XYZZ<FID>::identity();
-    // same two-stage software pipeline as AccumFn: index two entries ahead, gather one ahead
+    // same software pipeline as AccumFn: indices PF + 1 entries ahead, gathers PF ahead
     uint32_t v = vals[a];
     uint32_t vn = a + 1 < b ? vals[a + 1] : v;
+    uint32_t vn2 = (PF > 1 && a + 2 < b) ? vals[a + 2] : vn;
     AffineW cur = bases[v & 0x7fffffffu];
+    AffineW nx1 = cur;
+    if (PF > 1 && a + 1 < b) nx1 = bases[vn & 0x7fffffffu];
     for (uint32_t j = a; j < b; j++) {
-      uint32_t vnn = vn;
-      AffineW nxt = cur;
-      if (j + 1 < b) nxt = bases[vn & 0x7fffffffu];
-      if (j + 2 < b) vnn = vals[j + 2];
+      uint32_t vnn = vn, vnn2 = vn2;
+      AffineW nxt = cur, nxt2 = nx1;
+      if constexpr (PF == 1) {
+        if (j + 1 < b) nxt = bases[vn & 0x7fffffffu];
+        if (j + 2 < b) vnn = vals[j + 2];
+      } else {
+        nxt = nx1;                                          // gathered during the previous addition
+        if (j + 2 < b) nxt2 = bases[vn2 & 0x7fffffffu];     // the row for entry j + 2
+        vnn = vn2;
+        if (j + 3 < b) vnn2 = vals[j + 3];
+      }
       if (j == e) {  // bucket k is complete inside this lane (or its continued piece is)
         if (head) acc.store_raw(partial_raw[L]);
         else acc.store_raw(bucket_raw[k]);
@@ -88,6 +100,10 @@ template <int FID> struct AccumSegFn {
       cur = nxt;
       v = vn;
       vn = vnn;
+      if constexpr (PF > 1) {
+        nx1 = nxt2;
+        vn2 = vnn2;
+      }
     }
     if (head) acc.store_raw(partial_raw[L]);
     else acc.store_raw(bucket_raw[k]);

@@ -125,10 +125,11 @@ struct Global {
   uint32_t force_fold_t = 0;  // env NMX_TUNE_FOLD_T (tuning only)
   uint32_t no_quad_accum = 0;  // env NMX_TUNE_NO_QUAD_ACCUM (tuning only)
   uint32_t no_partition = 0;   // env NMX_TUNE_NO_PARTITION: generic radix-sort path everywhere (A/B runs)
-  uint32_t seg_min_total = 1u << 21;  // env NMX_TUNE_SEG_MIN_TOTAL: msm_seg.hpp from this many sorted entries (0xffffffff: never)
+  uint32_t seg_min_total = 1u << 22;  // env NMX_TUNE_SEG_MIN_TOTAL (profiles/r02_msm_2p20/seg_threshold.txt): msm_seg.hpp from this many sorted entries (0xffffffff: never)
   uint32_t seg_min_len = 8;           // env NMX_TUNE_SEG_MIN_LEN
   uint32_t seg_lanes_override = 0;    // env NMX_TUNE_SEG_LANES (0: the kernel's resident lane count)
   uint32_t no_quad_final = 0;         // env NMX_TUNE_NO_QUAD_FINAL
+  uint32_t accum_prefetch = 1;        // env NMX_TUNE_ACCUM_PF
 };
 extern Global G;                 // capi.hip
 void prof_store(const float* ms, int n);   // last call's stage times of this thread (capi.hip)
@@ -200,14 +201,17 @@ struct DeviceBackend {
       launch(f, slots);
     }
   }
-  // segment-balanced accumulate (msm_seg.hpp): exactly as many lanes as the chip holds resident for that kernel
+  // segment-balanced accumulate (msm_seg.hpp): a small multiple of the lanes the chip holds resident for that kernel.
+  // Measured (profiles/r02_msm_2p20/seg_lanes_sweep.txt; 196 608 lanes are resident): whole multiples only -- 1.5x
+  // leaves half the chip idle in the second round (+7 %); 1x (every wave in lock step from start to end) accumulate
+  // 1.25 ms + fold 0.06 at 2^20, 3x 1.17 + 0.13; at 2^21 3x wins by 2.5 % (3.05 against 3.13 ms).
   template <int FID> uint32_t seg_lanes() {
     static const uint32_t lanes = [] {
       int blocks = 0, dev = 0;
       hipDeviceProp_t prop;
       if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0u;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_launch<AccumSegFn<FID>>, 256, 0) != hipSuccess) return 0u;
-      return (uint32_t)blocks * 256u * (uint32_t)prop.multiProcessorCount;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_launch<AccumSegFn<FID, 1>>, 256, 0) != hipSuccess) return 0u;
+      return 3u * (uint32_t)blocks * 256u * (uint32_t)prop.multiProcessorCount;
     }();
     return G.seg_lanes_override ? G.seg_lanes_override : lanes;
   }
