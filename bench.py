@@ -53,6 +53,17 @@ def madds_per_launch(n, args):
     return n * (-(-(bits + 1) // c))
 
 
+def pmc_valu(args, world):
+    """VALU wave-instructions per accumulate launch from the committed PMC summary (same configuration rule as
+    pmc_traffic): the basis of roofline.valu_issue."""
+    if not (world == 1 and args.curve == 0 and args.log2n == 20 and args.dist == "random" and not args.window_bits):
+        return None
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "r02_msm_2p20", "pmc_traffic.json")))["accum"]["SQ_INSTS_VALU"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def pmc_traffic(args, world):
     """HBM bytes per accumulate launch from the committed PMC summary -- only for the exact configuration it was
     collected on (BN254, 2^20, random scalars, one GPU); everything else reports null."""
@@ -243,6 +254,19 @@ def main():
                              "mads_per_mixed_add": MADS_PER_MADD},
             },
         }
+        insts = pmc_valu(args, world)
+        if insts and accum_ms > 0:
+            # What binds the kernel: every VOP3 instruction of gfx950 -- v_mad_u64_u32, the 64-bit carry
+            # shifts, v_mul_lo_u32, v_add3 -- issues at 29-35 T lane-ops/s (profiles/r01_ubench_instruction_rates.jsonl), and a
+            # mixed addition is 2 187 VALU instructions of which 1 305 are multiply-adds (SQ_INSTS_VALU / wave-additions).
+            lane_ops = insts * 64
+            out["roofline"]["valu_issue"] = {
+                "valu_insts_per_mixed_add": round(insts / (madds_per_launch(n, args) / 64), 1),
+                "achieved_T_lane_ops_per_s": lane_ops / (accum_ms * 1e-3) / 1e12,
+                "vop3_issue_rate_T_per_s": [29.4, 35.2],
+                "frac_of_v_mad_rate": lane_ops / (accum_ms * 1e-3) / 1e12 / 29.4,
+                "source": "profiles/r02_msm_2p20/pmc_traffic.json (rocprofv3 --pmc SQ_INSTS_VALU, separate pass) / accum-kernel time of this run",
+            }
         if multi:
             out["combine_ms"] = round(combine_s[0] / max(args.steps, 1) * 1e3, 4)
         if world == 1 and not args.no_cpu_baseline:
