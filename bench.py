@@ -676,11 +676,17 @@ def field_workload(args, world, rank, L, torch, dist):
         work = [torch.empty_like(t) for t in dev]
     if wl == "mle_eval":
         point = util.random_scalars(cid, args.log2n, seed=8)
-    if wl == "spmv":  # n rows x n columns, 3 random non-zeros per row (the minroot shape: 3 constraints per iteration)
+    if wl == "spmv":  # n rows x n columns, 3 random non-zeros per row (the minroot shape: 3 constraints per iteration);
+        # coefficients as R1CS matrices have them: +1 / -1 in nine entries of ten, full-width otherwise (--dist random:
+        # every coefficient full-width, the worst case for the class encoding of nova_amd/csrc/fieldvec.hip)
         rng = np.random.Generator(np.random.PCG64(5))
         indptr = np.arange(0, 3 * n + 1, 3, dtype=np.uint64)
         indices = rng.integers(0, n, size=3 * n).astype(np.uint64)
-        data = util.random_scalars(cid, 3 * n, seed=4)
+        data = util.random_scalars(cid, 3 * n, seed=4).copy()
+        if args.dist != "random_coeffs":
+            kind = rng.random(3 * n)
+            data[kind < 0.6] = util.int_to_le32(1)
+            data[(kind >= 0.6) & (kind < 0.9)] = util.int_to_le32(util.MODULI[cid] - 1)
         csr = (indptr, indices, data)
         mat = fv.SparseMatrix(fid, indptr, indices, data, n)
 

@@ -980,6 +980,7 @@ int nmx_spmv_register(int field, const uint64_t* indptr, const uint64_t* indices
     HIPCHK(hipMemcpyAsync(ss.indices, ix.data(), nnz * 4, hipMemcpyHostToDevice, L.c->stream));
     HIPCHK(hipMemcpyAsync(ss.data, data, nnz * 32, hipMemcpyHostToDevice, L.c->stream));
     fv_spmv_convert(*L.c, field, ss.data, nnz, flags);
+    fv_spmv_classify(*L.c, field, ss.data, ss.indices, nnz, cols);  // +-1 / small coefficients: class bits in the index
     HIPCHK(hipStreamSynchronize(L.c->stream));
     std::lock_guard<std::mutex> lk(G.mu);
     uint64_t h = G.next_handle++;

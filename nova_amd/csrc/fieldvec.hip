@@ -97,21 +97,66 @@ template <int FID> struct EqDirectFn {
   }
 };
 
-// CSR sparse matrix x vector, one row per lane (/root/reference/src/r1cs/sparse.rs:201-229, SparseMatrix::multiply_vec;
-// the reference's +-1 / small-coefficient fast paths are a CPU optimisation of the same product).  Matrix values are
-// stored in internal form at registration, so data * z comes out in z's own form with no correction.
+// Coefficient classes, the GPU form of the reference's PrecomputedSparseMatrix (src/r1cs/sparse.rs:19-199: +-1 entries
+// are added / subtracted, |k| <= 7 by repeated doubling, the rest multiplied).  R1CS matrices are almost all +-1: here
+// the class rides in the top four bits of the 32-bit column index (columns < 2^28), so a unit or small entry costs
+// 4 B of matrix traffic instead of 36 B and its 32-byte coefficient is never read -- SpMV is gather-bound, the saving
+// is bytes, not multiplications.  Classes: 0 general, 1 +1, 2 -1, 3..8 +2..+7, 9..14 -2..-7.
+static constexpr uint32_t kSpmvColBits = 28;
+template <int FID> struct SpmvClassifyFn {  // after the coefficients are in internal form; writes the class into indices
+  const uint32_t* data;
+  uint32_t* indices;
+  NMX_HD void operator()(uint32_t k) const {
+    using F = Fp<FID>;
+    uint32_t w[8], m[8];
+    ld<FID>(data, k).to_canonical().to_words(w);
+    uint32_t hi = 0;
+    for (int j = 1; j < 8; j++) hi |= w[j];
+    uint32_t cls = 0;
+    if (hi == 0 && w[0] >= 1 && w[0] <= 7) cls = w[0] == 1 ? 1u : w[0] + 1u;  // +1 -> 1, +2..+7 -> 3..8
+    if (!cls) {  // p - value small?
+      uint64_t bw = 0;
+      uint32_t mh = 0;
+      for (int j = 0; j < 8; j++) {
+        const uint64_t d = (uint64_t)FpParams<FID>::PW[j] - w[j] - bw;
+        m[j] = (uint32_t)d;
+        bw = (d >> 32) & 1u;
+        if (j) mh |= m[j];
+      }
+      if (mh == 0 && m[0] >= 1 && m[0] <= 7) cls = m[0] == 1 ? 2u : m[0] + 7u;  // -1 -> 2, -2..-7 -> 9..14
+    }
+    indices[k] |= cls << kSpmvColBits;
+  }
+};
+// coefficient class `cls` (>= 1) applied to z: a value < p, canonical
+template <int FID> NMX_HD Fp<FID> spmv_small_term(uint32_t cls, const Fp<FID>& zf) {
+  using F = Fp<FID>;
+  const uint32_t k = cls <= 2 ? 1u : (cls <= 8 ? cls - 1u : cls - 7u);  // |coefficient|
+  F t;
+#pragma unroll
+  for (int i = 0; i < 9; i++) t.l[i] = zf.l[i] * k;  // z canonical: limbs < 2^29, k <= 7
+  t = t.norm();                                       // value < 7 p
+  if (cls == 2 || cls >= 9) t = F::sub8(F::zero(), t).norm();  // 8p - k z
+  return t.canon();
+}
+
+// CSR sparse matrix x vector, one row per lane (src/r1cs/sparse.rs:201-229 multiply_vec).  Matrix values are stored in
+// internal form at registration, so data * z comes out in z's own form with no correction.
 template <int FID> struct SpmvFn {
   const uint32_t* indptr;   // rows + 1
-  const uint32_t* indices;  // nnz
+  const uint32_t* indices;  // nnz: column | class << 28 (class 0 everywhere when the matrix is not tagged)
   const uint32_t* data;     // nnz x 8, internal form
   const uint32_t* z;        // cols x 8
   uint32_t* out;            // rows x 8
+  uint32_t colmask;         // 2^28 - 1 (tagged) or all ones
   NMX_HD void operator()(uint32_t row) const {
     using F = Fp<FID>;
     F acc = F::zero();
     uint32_t pending = 0;
     for (uint32_t k = indptr[row]; k < indptr[row + 1]; k++) {
-      acc = acc + ld<FID>(data, k) * ld<FID>(z, indices[k]);
+      const uint32_t w = indices[k], cls = (w & ~colmask) >> kSpmvColBits;
+      const F zf = ld<FID>(z, w & colmask);
+      acc = acc + (cls ? spmv_small_term<FID>(cls, zf) : ld<FID>(data, k) * zf);
       if (++pending == 6) {
         acc = acc.norm().canon();
         pending = 0;
@@ -128,15 +173,22 @@ template <int FID> struct SpmvPairFn {
   const uint32_t* data;
   const uint32_t *z1, *z2;
   uint32_t *out1, *out2;
+  uint32_t colmask;
   NMX_HD void operator()(uint32_t row) const {
     using F = Fp<FID>;
     F a1 = F::zero(), a2 = F::zero();
     uint32_t pending = 0;
     for (uint32_t k = indptr[row]; k < indptr[row + 1]; k++) {
-      const F m = ld<FID>(data, k);
-      const uint32_t col = indices[k];
-      a1 = a1 + m * ld<FID>(z1, col);
-      a2 = a2 + m * ld<FID>(z2, col);
+      const uint32_t w = indices[k], cls = (w & ~colmask) >> kSpmvColBits, col = w & colmask;
+      const F y1 = ld<FID>(z1, col), y2 = ld<FID>(z2, col);
+      if (cls) {
+        a1 = a1 + spmv_small_term<FID>(cls, y1);
+        a2 = a2 + spmv_small_term<FID>(cls, y2);
+      } else {
+        const F m = ld<FID>(data, k);
+        a1 = a1 + m * y1;
+        a2 = a2 + m * y2;
+      }
       if (++pending == 6) {
         a1 = a1.norm().canon();
         a2 = a2.norm().canon();
@@ -368,13 +420,18 @@ template <int FID> static void spmv_convert_t(Ctx& c, uint32_t* d_data, size_t n
   Conv f{d_data, (flags & NMX_SCALARS_MONT) ? 1u : 0u};
   be.launch(f, (uint32_t)nnz);
 }
+template <int FID> static void spmv_classify_t(Ctx& c, const uint32_t* d_data, uint32_t* d_indices, size_t nnz) {
+  DeviceBackend be(c, false, false);
+  SpmvClassifyFn<FID> f{d_data, d_indices};
+  be.launch(f, (uint32_t)nnz);
+}
 template <int FID>
 static void spmv_apply_t(Ctx& c, const uint32_t* indptr, const uint32_t* indices, const uint32_t* data, size_t rows,
                          size_t cols, const void* z, uint32_t flags, void* out) {
   VecIO io(c, flags & NMX_SCALARS_DEVICE, rows + cols, 2);
   const uint32_t* dz = io.in(z, cols);
   uint32_t* dout = io.out(out, rows);
-  SpmvFn<FID> f{indptr, indices, data, dz, dout};
+  SpmvFn<FID> f{indptr, indices, data, dz, dout, cols <= ((size_t)1 << kSpmvColBits) ? (1u << kSpmvColBits) - 1u : 0xffffffffu};
   timed_launch(c, f, rows, &io);
 }
 
@@ -386,7 +443,7 @@ static void spmv_apply_pair_t(Ctx& c, const uint32_t* indptr, const uint32_t* in
   const uint32_t* d2 = io.in(z2, cols);
   uint32_t* o1 = io.out(out1, rows);
   uint32_t* o2 = io.out(out2, rows);
-  SpmvPairFn<FID> f{indptr, indices, data, d1, d2, o1, o2};
+  SpmvPairFn<FID> f{indptr, indices, data, d1, d2, o1, o2, cols <= ((size_t)1 << kSpmvColBits) ? (1u << kSpmvColBits) - 1u : 0xffffffffu};
   timed_launch(c, f, rows, &io);
 }
 
@@ -557,6 +614,16 @@ void fv_spmv_convert(Ctx& c, int field, uint32_t* d_data, size_t nnz, uint32_t f
     case 1: spmv_convert_t<1>(c, d_data, nnz, flags); break;
     case 2: spmv_convert_t<2>(c, d_data, nnz, flags); break;
     case 3: spmv_convert_t<3>(c, d_data, nnz, flags); break;
+    default: throw Fail{NMX_E_ARG, "bad field id"};
+  }
+}
+void fv_spmv_classify(Ctx& c, int field, const uint32_t* d_data, uint32_t* d_indices, size_t nnz, size_t cols) {
+  if (cols > ((size_t)1 << kSpmvColBits)) return;  // no room for the class bits: every entry stays general
+  switch (field) {
+    case 0: spmv_classify_t<0>(c, d_data, d_indices, nnz); break;
+    case 1: spmv_classify_t<1>(c, d_data, d_indices, nnz); break;
+    case 2: spmv_classify_t<2>(c, d_data, d_indices, nnz); break;
+    case 3: spmv_classify_t<3>(c, d_data, d_indices, nnz); break;
     default: throw Fail{NMX_E_ARG, "bad field id"};
   }
 }

@@ -346,6 +346,7 @@ void fv_bind(Ctx&, int field, const void* z, size_t z_len, size_t lo_off, size_t
 void fv_suffix_horner(Ctx&, int field, const void* f, size_t n, const void* u, uint32_t flags, void* out);
 void fv_eq_evals(Ctx&, int field, const void* r_host, uint32_t ell, uint32_t flags, uint32_t* d_out);
 void fv_spmv_convert(Ctx&, int field, uint32_t* d_data, size_t nnz, uint32_t flags);
+void fv_spmv_classify(Ctx&, int field, const uint32_t* d_data, uint32_t* d_indices, size_t nnz, size_t cols);
 void fv_spmv_apply(Ctx&, int field, const uint32_t* indptr, const uint32_t* indices, const uint32_t* data, size_t rows,
                    size_t cols, const void* z, uint32_t flags, void* out);
 void fv_spmv_apply_pair(Ctx&, int field, const uint32_t* indptr, const uint32_t* indices, const uint32_t* data,

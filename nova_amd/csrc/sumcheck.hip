@@ -106,6 +106,56 @@ __global__ __launch_bounds__(256) void k_eq_sums(const uint32_t* A, const uint32
   }
 }
 
+// MODE 1 with both eq tables -- MultilinearPolynomial::evaluate_with (multilinear.rs:98-129) and the first-half rounds of
+// quadratic_with_one_input -- factored by rows:  sum_hi eqL[hi] * (sum_lo a[hi, lo] * eqR[lo]).  The generic kernel pays
+// eqL * eqR and a * factor per element (1.75 reductions per element: multiplier-bound, 0.28 ms for 2^24 elements = 24 %
+// of the HBM roofline); here an element costs one product with two of them sharing a reduction, and eqL enters once
+// per lane and row: 1.25 + 1/K reductions per element.  A block walks whole rows (2^shift consecutive elements,
+// coalesced); rows shorter than the block share it.
+template <int FID>
+__global__ __launch_bounds__(256) void k_eq_rows(const uint32_t* A, const uint32_t* eqL, const uint32_t* eqR, uint32_t shift,
+                                                 uint32_t h, uint32_t* partial) {
+  using F = Fp<FID>;
+  __shared__ uint32_t lds[9 * 256];
+  const uint32_t row = 1u << shift, P = row < 256u ? row : 256u, rows_per_block = 256u / P, K = row / P;
+  const uint32_t t = threadIdx.x, lo0 = t % P, sub = t / P;
+  const uint32_t nrows = (uint32_t)(((uint64_t)h + row - 1) >> shift);
+  F g = F::zero();
+  uint32_t pend_g = 0;
+  for (uint32_t hi = blockIdx.x * rows_per_block + sub; hi < nrows; hi += gridDim.x * rows_per_block) {
+    const size_t base = (size_t)hi << shift;
+    F rp = F::zero();
+    uint32_t pend = 0;
+    uint32_t k = 0;
+    for (; k + 1 < K; k += 2) {  // two elements per reduction
+      const uint32_t l0 = lo0 + k * P, l1 = l0 + P;
+      if (base + l1 < h) {
+        rp = rp + F::mul_add(ldw<FID>(A, base + l0), ldw<FID>(eqR, l0), ldw<FID>(A, base + l1), ldw<FID>(eqR, l1));
+      } else if (base + l0 < h) {
+        rp = rp + ldw<FID>(A, base + l0) * ldw<FID>(eqR, l0);
+      }
+      if (++pend == 6) {
+        rp = rp.norm().canon();
+        pend = 0;
+      }
+    }
+    if (k < K) {
+      const uint32_t l0 = lo0 + k * P;
+      if (base + l0 < h) rp = rp + ldw<FID>(A, base + l0) * ldw<FID>(eqR, l0);
+    }
+    g = g + rp.norm().canon() * ldw<FID>(eqL, hi);
+    if (++pend_g == 6) {
+      g = g.norm().canon();
+      pend_g = 0;
+    }
+  }
+  g = block_sum<FID>(g.norm().canon(), lds);
+  if (threadIdx.x == 0) {
+    g.to_words(partial + 16 * blockIdx.x);
+    F::zero().to_words(partial + 16 * blockIdx.x + 8);
+  }
+}
+
 template <int FID> __global__ __launch_bounds__(256) void k_sum_partials(const uint32_t* partial, uint32_t nparts, uint32_t* out) {
   using F = Fp<FID>;
   __shared__ uint32_t lds[9 * 256];
@@ -193,8 +243,12 @@ static void eq_sums_t(Ctx& c, const void* A, const void* B, const void* C, size_
   DeviceBackend be(c, false, prof);
   be.mark("k");
   const uint32_t mask = shift >= 32 ? 0xffffffffu : ((1u << shift) - 1u);
-  hipLaunchKernelGGL((k_eq_sums<FID, MODE>), dim3(blocks), dim3(256), 0, c.stream, dA, dB, dC, dL, dR, shift, mask, h,
-                     nk, partial);
+  if (MODE == 1 && dL && shift < 31) {
+    hipLaunchKernelGGL((k_eq_rows<FID>), dim3(blocks), dim3(256), 0, c.stream, dA, dL, dR, shift, h, partial);
+  } else {
+    hipLaunchKernelGGL((k_eq_sums<FID, MODE>), dim3(blocks), dim3(256), 0, c.stream, dA, dB, dC, dL, dR, shift, mask, h,
+                       nk, partial);
+  }
   HIPCHK(hipGetLastError());
   hipLaunchKernelGGL((k_sum_partials<FID>), dim3(1), dim3(256), 0, c.stream, partial, blocks, dout);
   HIPCHK(hipGetLastError());
