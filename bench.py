@@ -88,6 +88,9 @@ def main():
                          "default is the strong-scaling run of configs[2] instead (see --total-log2n)")
     ap.add_argument("--total-log2n", type=int, default=24,
                     help="N > 1: total pairs = 2^total_log2n split contiguously over the ranks (BASELINE configs[2]: 24)")
+    ap.add_argument("--strong", action="store_true",
+                    help="force the fixed-total (strong-scaling) sharding even at N = 1 (exercises the N > 1 code path on one GPU "
+                         "together with NMX_BENCH_FORCE_DIST=1)")
     ap.add_argument("--no-extras", action="store_true",
                     help="N = 1 headline run: skip incl_h2d / trait_form / 2^24 anchor / prove_step / HyperKZG replays")
     ap.add_argument("--curve", type=int, default=0, help="0 bn254_g1 (headline), 1 grumpkin, 2 pallas, 3 vesta")
@@ -99,7 +102,7 @@ def main():
                     help="msm = the headline (default); the others time one HBM-bound field-vector kernel of "
                          "SURVEY.md 8(f) at 2^log2n elements per GPU")
     args = ap.parse_args()
-    strong = args.gpus > 1 and args.log2n is None      # configs[2] as written: fixed total, contiguous shards
+    strong = (args.gpus > 1 and args.log2n is None) or args.strong      # configs[2] as written: fixed total, contiguous shards
     if args.log2n is None:
         args.log2n = 20
 

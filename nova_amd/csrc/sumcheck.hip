@@ -48,10 +48,12 @@ template <int FID, int MODE> struct EqTerm {
 template <int FID, int MODE>
 __device__ __forceinline__ EqTerm<FID, MODE> eq_term(const uint32_t* A, const uint32_t* B, const uint32_t* C,
                                                      const uint32_t* eqL, const uint32_t* eqR, uint32_t shift,
-                                                     uint32_t mask, uint32_t h, const Fp<FID>& nk, uint32_t id) {
+                                                     uint32_t mask, uint32_t h, const Fp<FID>& nk, uint32_t id,
+                                                     uint32_t eq_index = 0xffffffffu) {
   using F = Fp<FID>;
   EqTerm<FID, MODE> t;
-  t.fac = ldw<FID>(eqR, eqL ? (id & mask) : id);
+  // eq_index given (k_eq_rows): the factor is eqR[eq_index] alone, eqL is applied once per row by the caller
+  t.fac = ldw<FID>(eqR, eq_index != 0xffffffffu ? eq_index : (eqL ? (id & mask) : id));
   if (eqL) t.fac = ldw<FID>(eqL, id >> shift) * t.fac;
   const F a0 = ldw<FID>(A, id);
   if (MODE == 1) {
@@ -106,53 +108,70 @@ __global__ __launch_bounds__(256) void k_eq_sums(const uint32_t* A, const uint32
   }
 }
 
-// MODE 1 with both eq tables -- MultilinearPolynomial::evaluate_with (multilinear.rs:98-129) and the first-half rounds of
-// quadratic_with_one_input -- factored by rows:  sum_hi eqL[hi] * (sum_lo a[hi, lo] * eqR[lo]).  The generic kernel pays
-// eqL * eqR and a * factor per element (1.75 reductions per element: multiplier-bound, 0.28 ms for 2^24 elements = 24 %
-// of the HBM roofline); here an element costs one product with two of them sharing a reduction, and eqL enters once
-// per lane and row: 1.25 + 1/K reductions per element.  A block walks whole rows (2^shift consecutive elements,
-// coalesced); rows shorter than the block share it.
-template <int FID>
-__global__ __launch_bounds__(256) void k_eq_rows(const uint32_t* A, const uint32_t* eqL, const uint32_t* eqR, uint32_t shift,
-                                                 uint32_t h, uint32_t* partial) {
+// First-half rounds (both eq tables), factored by rows:  sum_hi eqL[hi] * (sum_lo term[hi, lo] * eqR[lo]).  The generic
+// kernel pays eqL * eqR and term * factor per element -- 1.75 reductions per element in mode 1
+// (MultilinearPolynomial::evaluate_with, multilinear.rs:98-129: multiplier-bound, 0.28 ms for 2^24 elements = 24 % of the HBM
+// roofline), 5 per index in mode 3.  Here eqL enters once per lane and row and two terms share a reduction:
+// 1.25 + 1/K per element in mode 1 (0.17 ms, 39 %), 4 + 2/K per index in mode 3.  A block walks whole rows (2^shift
+// consecutive indices, coalesced); rows shorter than the block share it.
+template <int FID, int MODE>
+__global__ __launch_bounds__(256) void k_eq_rows(const uint32_t* A, const uint32_t* B, const uint32_t* C, const uint32_t* eqL,
+                                                 const uint32_t* eqR, uint32_t shift, uint32_t h, Fp<FID> nk,
+                                                 uint32_t* partial) {
   using F = Fp<FID>;
   __shared__ uint32_t lds[9 * 256];
   const uint32_t row = 1u << shift, P = row < 256u ? row : 256u, rows_per_block = 256u / P, K = row / P;
   const uint32_t t = threadIdx.x, lo0 = t % P, sub = t / P;
   const uint32_t nrows = (uint32_t)(((uint64_t)h + row - 1) >> shift);
-  F g = F::zero();
+  F g0 = F::zero(), g1 = F::zero();
   uint32_t pend_g = 0;
   for (uint32_t hi = blockIdx.x * rows_per_block + sub; hi < nrows; hi += gridDim.x * rows_per_block) {
-    const size_t base = (size_t)hi << shift;
-    F rp = F::zero();
-    uint32_t pend = 0;
-    uint32_t k = 0;
-    for (; k + 1 < K; k += 2) {  // two elements per reduction
+    const uint32_t base = hi << shift;
+    F r0 = F::zero(), r1 = F::zero();
+    uint32_t pend = 0, k = 0;
+    for (; k + 1 < K; k += 2) {  // two indices per reduction
       const uint32_t l0 = lo0 + k * P, l1 = l0 + P;
       if (base + l1 < h) {
-        rp = rp + F::mul_add(ldw<FID>(A, base + l0), ldw<FID>(eqR, l0), ldw<FID>(A, base + l1), ldw<FID>(eqR, l1));
+        const EqTerm<FID, MODE> x = eq_term<FID, MODE>(A, B, C, nullptr, eqR, 0, 0, h, nk, base + l0, l0);
+        const EqTerm<FID, MODE> y = eq_term<FID, MODE>(A, B, C, nullptr, eqR, 0, 0, h, nk, base + l1, l1);
+        r0 = r0 + F::mul_add(x.e0, x.fac, y.e0, y.fac);
+        if (MODE != 1) r1 = r1 + F::mul_add(x.q, x.fac, y.q, y.fac);
       } else if (base + l0 < h) {
-        rp = rp + ldw<FID>(A, base + l0) * ldw<FID>(eqR, l0);
+        const EqTerm<FID, MODE> x = eq_term<FID, MODE>(A, B, C, nullptr, eqR, 0, 0, h, nk, base + l0, l0);
+        r0 = r0 + x.e0 * x.fac;
+        if (MODE != 1) r1 = r1 + x.q * x.fac;
       }
       if (++pend == 6) {
-        rp = rp.norm().canon();
+        r0 = r0.norm().canon();
+        r1 = r1.norm().canon();
         pend = 0;
       }
     }
     if (k < K) {
       const uint32_t l0 = lo0 + k * P;
-      if (base + l0 < h) rp = rp + ldw<FID>(A, base + l0) * ldw<FID>(eqR, l0);
+      if (base + l0 < h) {
+        const EqTerm<FID, MODE> x = eq_term<FID, MODE>(A, B, C, nullptr, eqR, 0, 0, h, nk, base + l0, l0);
+        r0 = r0 + x.e0 * x.fac;
+        if (MODE != 1) r1 = r1 + x.q * x.fac;
+      }
     }
-    g = g + rp.norm().canon() * ldw<FID>(eqL, hi);
+    const F el = ldw<FID>(eqL, hi);
+    g0 = g0 + r0.norm().canon() * el;
+    if (MODE != 1) g1 = g1 + r1.norm().canon() * el;
     if (++pend_g == 6) {
-      g = g.norm().canon();
+      g0 = g0.norm().canon();
+      g1 = g1.norm().canon();
       pend_g = 0;
     }
   }
-  g = block_sum<FID>(g.norm().canon(), lds);
+  g0 = block_sum<FID>(g0.norm().canon(), lds);
+  if (MODE != 1) {
+    __syncthreads();
+    g1 = block_sum<FID>(g1.norm().canon(), lds);
+  }
   if (threadIdx.x == 0) {
-    g.to_words(partial + 16 * blockIdx.x);
-    F::zero().to_words(partial + 16 * blockIdx.x + 8);
+    g0.to_words(partial + 16 * blockIdx.x);
+    g1.to_words(partial + 16 * blockIdx.x + 8);
   }
 }
 
@@ -243,8 +262,8 @@ static void eq_sums_t(Ctx& c, const void* A, const void* B, const void* C, size_
   DeviceBackend be(c, false, prof);
   be.mark("k");
   const uint32_t mask = shift >= 32 ? 0xffffffffu : ((1u << shift) - 1u);
-  if (MODE == 1 && dL && shift < 31) {
-    hipLaunchKernelGGL((k_eq_rows<FID>), dim3(blocks), dim3(256), 0, c.stream, dA, dL, dR, shift, h, partial);
+  if (dL && shift < 31) {
+    hipLaunchKernelGGL((k_eq_rows<FID, MODE>), dim3(blocks), dim3(256), 0, c.stream, dA, dB, dC, dL, dR, shift, h, nk, partial);
   } else {
     hipLaunchKernelGGL((k_eq_sums<FID, MODE>), dim3(blocks), dim3(256), 0, c.stream, dA, dB, dC, dL, dR, shift, mask, h,
                        nk, partial);
