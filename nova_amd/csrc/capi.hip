@@ -86,7 +86,6 @@ static void ensure_init() {
   if (const char* t = getenv("NMX_TUNE_SEG_LANES")) G.seg_lanes_override = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_NO_QUAD_FINAL")) G.no_quad_final = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_ACCUM_PF")) G.accum_prefetch = (uint32_t)atoi(t);
-  if (const char* t = getenv("NMX_TUNE_NO_HORNER_TILE")) G.no_horner_tile = (uint32_t)atoi(t);
   HIPCHK(hipSetDevice(dev));
   cache_init_defaults();
   G.inited = true;

@@ -15,7 +15,6 @@
 // R = 2^256 Montgomery limbs) with the challenge pre-scaled once on the host; only the product az*bz needs a
 // form-dependent constant.  Results stay in HBM so the next MSM (`NMX_SCALARS_DEVICE`) reads them in place.
 #include "runtime.hpp"
-#include "horner_tile.hpp"
 
 namespace nmx {
 
@@ -226,6 +225,8 @@ template <int FID> struct LinCombFn {
   }
 };
 
+// (A tiled variant -- 2048-coefficient tiles transposed through LDS, block scan of lane heads -- was built and measured in
+// round 2: bit-exact but 17 % slower at 2^24, see profiles/r02_fieldvec/horner_tiled_rejected.txt.)
 // Suffix Horner  out[i] = sum_{k >= i} f[k] * u^(k-i):  out[0] is `poly_eval(f, u)` (hyperkzg.rs:1011-1020) and out[1..]
 // is the quotient of `div_by_monomial` (hyperkzg.rs:961-999: h[i-1] = f[i] + h[i]*u).  Same three phases as the
 // reference's chunked version -- chunk-local recurrences, carries between chunks with u^chunk, fix-up -- with
@@ -543,80 +544,11 @@ template <int FID> static void horner_dev(Ctx& c, const uint32_t* f, uint32_t n,
   HornerFixFn<FID> ff{out, carries, pw_all + (size_t)lvl * (kHornerChunk + 1) * 8, n};
   be.launch(ff, n);
 }
-// tiled version (horner_tile.hpp): f, out 16-byte aligned device arrays; power tables of all levels go by value
-template <int FID>
-static void horner_tiled_dev(Ctx& c, const uint32_t* f, uint32_t n, const std::vector<HtPowers>& pw, uint32_t lvl, uint32_t* out,
-                             HornerArena& ws) {
-  const uint32_t nt = (n + kHtTile - 1) / kHtTile;
-  uint32_t* lane_heads = (uint32_t*)ws.take((size_t)nt * kHtThreads * 32);
-  uint32_t* tile_heads = (uint32_t*)ws.take((size_t)nt * 32);
-  hipLaunchKernelGGL((k_horner_heads<FID>), dim3(nt), dim3(kHtThreads), 0, c.stream, f, n, pw[lvl], lane_heads, tile_heads);
-  HIPCHK(hipGetLastError());
-  uint32_t* carries = nullptr;
-  if (nt > 1) {
-    carries = (uint32_t*)ws.take((size_t)nt * 32);
-    horner_tiled_dev<FID>(c, tile_heads, nt, pw, lvl + 1, carries, ws);
-  }
-  hipLaunchKernelGGL((k_horner_apply<FID>), dim3(nt), dim3(kHtThreads), 0, c.stream, f, n, pw[lvl], (const uint32_t*)lane_heads,
-                     (const uint32_t*)carries, nt, out);
-  HIPCHK(hipGetLastError());
-}
-template <int FID>
-static void horner_tiled_t(Ctx& c, const void* f, size_t n, const void* u, uint32_t flags, void* out) {
-  using F = Fp<FID>;
-  const bool dev = flags & NMX_SCALARS_DEVICE;
-  // per level: u_l = u^(2048^l); the table holds u_l and u_l^(8 * 2^k), k = 0..7 (u_l^1024 squared is the next level's u)
-  std::vector<HtPowers> pw;
-  {
-    F ul = challenge<FID>(u, flags & NMX_SCALARS_MONT);
-    for (size_t m = n;;) {
-      HtPowers t;
-      ul.canon().to_words(t.w[0]);
-      F p = ul;
-      for (int k = 0; k < 3; k++) p = p.sqr().canon();  // u^8
-      for (int k = 0; k < 8; k++) {
-        p.to_words(t.w[1 + k]);
-        p = p.sqr().canon();
-      }
-      pw.push_back(t);
-      ul = p;  // u_l^2048
-      const size_t nt = (m + kHtTile - 1) / kHtTile;
-      if (nt == 1) break;
-      m = nt;
-    }
-  }
-  arena_reserve(c, horner_tiled_need(n) + (dev ? 0 : 2 * HornerArena::pad(n * 32)));
-  HornerArena ws{c.arena};
-  const uint32_t* df = (const uint32_t*)f;
-  uint32_t* dout = (uint32_t*)out;
-  if (!dev) {
-    void* a = ws.take(n * 32);
-    dout = (uint32_t*)ws.take(n * 32);
-    HIPCHK(hipMemcpyAsync(a, f, n * 32, hipMemcpyHostToDevice, c.stream));
-    df = (const uint32_t*)a;
-  }
-  const bool prof = G.profiling;
-  DeviceBackend be(c, false, prof);
-  be.mark("kernel");
-  horner_tiled_dev<FID>(c, df, (uint32_t)n, pw, 0, dout, ws);
-  be.mark("end");
-  if (!dev) HIPCHK(hipMemcpyAsync(out, dout, n * 32, hipMemcpyDeviceToHost, c.stream));
-  HIPCHK(hipStreamSynchronize(c.stream));
-  if (prof && be.nmarks == 2) {
-    float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
-    prof_store(&ms, 1);
-  }
-}
 template <int FID>
 static void horner_t(Ctx& c, const void* f, size_t n, const void* u, uint32_t flags, void* out) {
   using F = Fp<FID>;
   const bool dev = flags & NMX_SCALARS_DEVICE;
-  // the tiled kernels move 16-byte pieces: device operands must be 16-byte aligned (staged host operands always are)
-  if (!G.no_horner_tile && (!dev || ((((uintptr_t)f) | ((uintptr_t)out)) & 15u) == 0)) {
-    horner_tiled_t<FID>(c, f, n, u, flags, out);
-    return;
-  }
+
   // per level: u_l = u^(16^l) and its powers 0..16 -- 16 host multiplications per level, at most 8 levels
   std::vector<F> u_lvl;
   std::vector<uint32_t> pwh;

@@ -130,7 +130,6 @@ struct Global {
   uint32_t seg_lanes_override = 0;    // env NMX_TUNE_SEG_LANES (0: the kernel's resident lane count)
   uint32_t no_quad_final = 0;         // env NMX_TUNE_NO_QUAD_FINAL
   uint32_t accum_prefetch = 1;        // env NMX_TUNE_ACCUM_PF
-  uint32_t no_horner_tile = 0;        // env NMX_TUNE_NO_HORNER_TILE: round-1 chunk-per-lane suffix Horner (A/B runs)
 };
 extern Global G;                 // capi.hip
 void prof_store(const float* ms, int n);   // last call's stage times of this thread (capi.hip)
