@@ -240,7 +240,9 @@ def main():
             "per_call_ms": {"median": round(float(np.median(per_call)) * 1e3, 4), "min": round(min(per_call) * 1e3, 4)},
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_launch<AccumSegFn> (bucket accumulation, segment-balanced)" if n * madds_per_launch(1, args) >= (1 << 22) and not args.window_bits
+                # msm_seg.hpp from 2^22 sorted entries on, on the c <= 16 table path (keys below 2^22 points)
+                "kernel": "k_launch<AccumSegFn> (bucket accumulation, segment-balanced)"
+                          if madds_per_launch(n, args) >= (1 << 22) and n < (1 << 22) and (args.window_bits or 16) <= 16
                           else "k_launch<AccumFn> (bucket accumulation)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,

@@ -78,6 +78,7 @@ def lib():
     L.nmx_set_profiling.argtypes = [i]
     L.nmx_profile_last.argtypes = [ctypes.POINTER(ctypes.c_float), i]
     L.nmx_set_window_bits.argtypes = [u32]
+    L.nmx_set_option.argtypes = [ctypes.c_char_p, u32]
     L.nmx_cache_clear.argtypes = []
     L.nmx_cache_invalidate.argtypes = [vp]
     L.nmx_cache_configure.argtypes = [sz, sz, sz]

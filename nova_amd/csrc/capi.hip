@@ -1052,6 +1052,23 @@ int nmx_set_window_bits(uint32_t c) {
   return NMX_OK;
 }
 
+int nmx_set_option(const char* name, uint32_t value) {
+  return guarded([&] {
+    require(name != nullptr, NMX_E_ARG, "null argument");
+    ensure_init();  // the environment defaults are applied first, then overridden
+    const std::string n(name);
+    std::lock_guard<std::mutex> lk(G.mu);
+    if (n == "no_partition") G.no_partition = value;
+    else if (n == "seg_min_total") G.seg_min_total = value;
+    else if (n == "seg_min_len") G.seg_min_len = value ? value : 1u;
+    else if (n == "seg_lanes") G.seg_lanes_override = value;
+    else if (n == "no_quad_accum") G.no_quad_accum = value;
+    else if (n == "no_quad_final") G.no_quad_final = value;
+    else if (n == "accum_prefetch") G.accum_prefetch = value;
+    else throw Fail{NMX_E_ARG, "unknown option name"};
+  });
+}
+
 int nmx_cache_clear(void) {
   return guarded([&] {
     std::lock_guard<std::mutex> up(SC.upload_mu);

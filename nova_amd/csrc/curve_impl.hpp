@@ -105,9 +105,10 @@ template <int CID> struct GenFn {  // P_i = (k0 + i) * G
 // one MSM on the device
 // ---------------------------------------------------------------------------------------------------
 static inline uint64_t shape_hash(const MsmArgs& a, const MsmCall& mc, size_t sbytes) {
-  const uint64_t v[8] = {a.n, a.u64_bits, a.force_c, a.force_lmax, a.force_fold_t, ((uint64_t)a.pre_stride << 8) | a.pre_c,
-                         (uint64_t)(mc.gather_host != nullptr) | (mc.all_ones ? 2u : 0u) | (mc.scalars_device ? 4u : 0u),
-                         sbytes};
+  const uint64_t v[10] = {a.n, a.u64_bits, a.force_c, a.force_lmax, a.force_fold_t, ((uint64_t)a.pre_stride << 8) | a.pre_c,
+                          (uint64_t)(mc.gather_host != nullptr) | (mc.all_ones ? 2u : 0u) | (mc.scalars_device ? 4u : 0u) |
+                              (a.no_partition ? 8u : 0u),
+                          sbytes, a.seg_min_total, G.seg_lanes_override};
   uint64_t h = 0x9e3779b97f4a7c15ull;
   for (uint64_t x : v) {
     h = (h ^ x) * 0xff51afd7ed558ccdull;

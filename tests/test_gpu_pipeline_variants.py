@@ -1,0 +1,58 @@
+"""-m gpu: every pipeline variant computes the same, oracle-exact result.  The hand-written LDS partition
+(msm_partition.hpp), the generic radix-sort path, the task accumulate and the segment-balanced accumulate (msm_seg.hpp,
+forced on at small sizes, with lane counts that make buckets span 0 .. thousands of segments) are selected with
+nmx_set_option and run on all nine scalar sets of the reference's test matrix
+(/root/reference/src/provider/curve_property_tests.rs:196-212, benches/commit.rs:33-110)."""
+import numpy as np
+import pytest
+
+from oracle import cref
+from oracle import pyref as R
+from tests import util
+
+pytestmark = pytest.mark.gpu
+KINDS = ["random", "equal", "zero_rm1", "pm_small", "u1", "u10", "u16", "u32", "u64"]
+VARIANTS = [
+    {},                                                            # defaults
+    {"no_partition": 1},                                           # round-1 pipeline
+    {"seg_min_total": 0xFFFFFFFF},                                 # partition + task accumulate
+    {"seg_min_total": 0, "seg_lanes": 4096, "seg_min_len": 3},     # segments everywhere, few long ones
+    {"seg_min_total": 0, "seg_lanes": 1 << 19, "seg_min_len": 1},  # more lanes than entries per bucket: one-entry pieces
+    {"seg_min_total": 0, "seg_lanes": 70001, "no_quad_final": 1},  # odd lane count, single-lane final pass
+    {"seg_min_total": 0, "accum_prefetch": 2},
+]
+DEFAULTS = {"no_partition": 0, "seg_min_total": 1 << 22, "seg_lanes": 0, "seg_min_len": 8, "no_quad_final": 0, "accum_prefetch": 1}
+
+
+@pytest.mark.parametrize("c,n", [(R.BN254_G1, 20000), (R.BN254_G1, 1 << 16), (R.PALLAS, 1 << 17)], ids=lambda v: getattr(v, "name", v))
+def test_variants_agree_with_oracle(nmx, c, n):
+    from nova_amd import _lib
+    L = _lib.lib()
+    bases = cref.sequential_bases(c, 606 + n, n).copy()
+    bases[n // 7] = 0                                             # an identity point: the digit stage must then read bases
+    prep = cref.Prepared(c.cid, bases, n)
+    ck = nmx.CommitmentKey.from_host(c.cid, bases)
+    clean = nmx.CommitmentKey.from_host(c.cid, cref.sequential_bases(c, 5, n))   # and a key without one (bases never read)
+    prep_clean = cref.Prepared(c.cid, clean.read(0, n), n)
+    g = nmx.DlogGroup(c.cid)
+    scs = {k: util.scalar_set(c.cid, n, k) for k in KINDS}
+    exp = {k: prep.msm(s, n) for k, s in scs.items()}
+    exp_clean = prep_clean.msm(scs["random"], n)
+    try:
+        for var in VARIANTS:
+            for k, v in {**DEFAULTS, **var}.items():
+                assert L.nmx_set_option(k.encode(), v) == 0
+            for kind in KINDS:
+                got = g.vartime_multiscalar_mul(scs[kind], ck)
+                assert (got.xy, int(got.is_inf)) == exp[kind], (var, kind)
+            got = g.vartime_multiscalar_mul(scs["random"], clean)
+            assert (got.xy, int(got.is_inf)) == exp_clean, var
+            s64 = util.small_scalars(n, 33)
+            got = g.vartime_multiscalar_mul_small(s64, clean)
+            assert (got.xy, int(got.is_inf)) == cref.msm_u64(c.cid, s64, clean.read(0, n), n, 33), var
+    finally:
+        for k, v in DEFAULTS.items():
+            L.nmx_set_option(k.encode(), v)
+        assert L.nmx_set_option(b"no_such_knob", 1) == _lib.E_ARG
+    ck.close()
+    clean.close()
