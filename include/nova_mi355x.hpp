@@ -45,7 +45,9 @@ class CommitmentKey {
   // `CommitmentEngineTrait::load_setup` (src/traits/commitment.rs:64-76).  HyperKZG (hyperkzg.rs:658-674): the first
   // n.next_power_of_two() tauG1 points of a .ptau file; `h` is derived from the label on the reference side and tau_H
   // (G2) stays with the host, so the caller supplies h.  Pedersen (pedersen.rs:318-340): "PEDERSEN_KEY" | h | ck.
-  // Points are validated as `read_points` does (ptau.rs:372-391); errors throw Error with NMX_E_IO / _FORMAT / _POINT.
+  // The G1 points are validated as `read_points` does (ptau.rs:372-391: canonical coordinates, on the curve); errors throw
+  // Error with NMX_E_IO / _FORMAT / _POINT.  The two G2 points of section 3 (tau_H) are NOT read or validated here: pairings
+  // are outside this library, the caller that needs tau_H reads and checks it as the reference does.
   static CommitmentKey load_ptau(int curve, const std::string& path, size_t n, const Affine& h, bool precompute = true) {
     CommitmentKey k(curve, next_power_of_two(n), h);
     check(nmx_bases_register_ptau(curve, path.c_str(), k.n_, 2, precompute ? NMX_BASES_PRECOMPUTE : 0u, &k.handle_));

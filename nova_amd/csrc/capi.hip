@@ -9,7 +9,11 @@
 
 namespace nmx {
 
-Global G;
+// Process-lifetime singletons, deliberately never destroyed: keys are reference-counted and free their HBM in their
+// destructor, and running those destructors during static destruction at process exit would call into a HIP runtime
+// that may already be gone.  nmx_shutdown releases everything explicitly; a process that simply exits lets the driver
+// reclaim the device memory.
+Global& G = *new Global;
 static std::atomic<uint64_t> g_stats[NMX_STAT_COUNT];
 static inline void stat_add(int k, uint64_t v = 1) { g_stats[k].fetch_add(v, std::memory_order_relaxed); }
 
@@ -259,13 +263,14 @@ struct SliceEntry {
     return true;
   }
 };
-static struct SliceCache {
+struct SliceCache {
   std::mutex mu;         // entries, budget
   std::mutex upload_mu;  // one miss at a time: two rayon workers committing to the same key upload it once
   std::list<SliceEntry> entries;
   size_t bytes = 0, max_bytes = 0, min_n = 128, max_entries = 32;
   uint64_t clock = 0;
-} SC;
+};
+static SliceCache& SC = *new SliceCache;  // never destroyed (see G)
 
 static void cache_init_defaults() {
   std::lock_guard<std::mutex> ck(SC.mu);

@@ -26,10 +26,17 @@
 // with; 0 = any width at run time): with constant bit positions the scalar words stay in registers -- indexed
 // dynamically they are promoted to LDS (36 KB per block) -- and the digit loop unrolls to ~10 instructions a window.
 //
+// Two geometries (template parameter BIG): keys of up to 15 bits (c <= 16: every key below 2^22 points) use 256 x 128 bins,
+// 12288-entry chunks, 8192-entry tiles, one byte of low bits per entry and two first-level blocks per CU; keys of up to
+// 19 bits (the c = 20 tables of keys >= 2^22 points) use 1024 x 512 bins, 16384-entry chunks and tiles, two bytes of low
+// bits, one block per CU -- shorter runs per bin (64 B), still one pass per level.
+//
 // Apart from the wave scan (device only; a plain loop elsewhere) the kernels use block-level primitives only (LDS
 // atomics, __syncthreads): tests/host_emul/simt.hpp runs the same bodies on the CPU, one fiber per thread.
 #pragma once
 #include <string.h>
+
+#include <type_traits>
 
 #include "msm_kernels.hpp"
 
@@ -61,38 +68,51 @@ namespace nmx {
 // geometry
 // ----------------------------------------------------------------------------------------------------
 struct PartShape {
-  uint32_t LB, HB;     // low / high key bits: key = bucket index in [0, 2^(c-1)), LB = min(c - 1, 7), HB <= 8
+  uint32_t LB, HB;     // low / high key bits: key = bucket index in [0, 2^(c-1))
   uint32_t nlo, nhi;   // 2^LB, 2^HB
-  uint32_t bs1;        // threads (= scalars) per block iteration of the first level: bs1 * W <= kStageCap
+  uint32_t big;        // 1: the wide-key geometry (PartCfg<true>)
+  uint32_t bs1;        // threads (= scalars) per block iteration of the first level: bs1 * W <= stage capacity
   uint32_t grid1;      // blocks of the first level (grid-stride over chunks of bs1 scalars)
   uint32_t tiles_cap;  // upper bound on second-level tiles
   uint32_t ent_cap;    // entries of the intermediate arrays (bin regions are 16-entry aligned, one tile of slack)
 };
-static constexpr uint32_t kStageCap = 12288;  // entries staged in LDS per first-level chunk: 48 KiB + 24 KiB, 2 blocks / CU
-static constexpr uint32_t kTile = 8192;       // entries per second-level tile
+template <bool BIG> struct PartCfg {
+  static constexpr uint32_t kMaxHi = BIG ? 1024 : 256;    // first-level bins
+  static constexpr uint32_t kMaxLo = BIG ? 512 : 128;     // buckets per bin
+  static constexpr uint32_t kStage = BIG ? 16384 : 12288; // entries staged in LDS per first-level chunk
+  static constexpr uint32_t kTile = BIG ? 16384 : 8192;   // entries per second-level tile
+  static constexpr uint32_t kTilePer = kTile / 1024;      // consecutive entries per thread of a tile
+  using KeyT = typename std::conditional<BIG, uint32_t, uint16_t>::type;  // staged key
+  using LoT = typename std::conditional<BIG, uint16_t, uint8_t>::type;    // low key bits between the levels
+};
 static constexpr uint32_t kTileThreads = 1024;
-static constexpr uint32_t kTilePer = kTile / kTileThreads;  // 8: one aligned 8-byte load of low bits per thread
 static constexpr uint32_t kBinAlign = 16;
+static constexpr uint32_t kTabStride = 1025;  // tab = 3 arrays of nhi + 1 <= 1025 words
 
 inline bool partition_supported(const MsmShape& sh, bool table_mode) {
   // 256 threads (one scalar each) is the smallest first-level block: its W digits per scalar must fit the LDS stage
-  return table_mode && sh.WB == 1 && sh.c >= 2 && sh.c <= 16 && sh.W * 256u <= kStageCap;
+  if (!(table_mode && sh.WB == 1 && sh.c >= 2 && sh.c <= 20)) return false;
+  return sh.W * 256u <= (sh.c <= 16 ? PartCfg<false>::kStage : PartCfg<true>::kStage);
 }
 inline PartShape make_part_shape(const MsmShape& sh) {
   PartShape p;
   const uint32_t kb = sh.c - 1;
-  p.LB = kb < 7 ? kb : 7;
+  p.big = kb > 15 ? 1u : 0u;
+  p.LB = p.big ? 9u : (kb < 7 ? kb : 7);
   p.HB = kb - p.LB;
   p.nlo = 1u << p.LB;
   p.nhi = 1u << p.HB;
-  uint32_t bs = (kStageCap / sh.W) & ~63u;
+  const uint32_t stage = p.big ? PartCfg<true>::kStage : PartCfg<false>::kStage;
+  const uint32_t tile = p.big ? PartCfg<true>::kTile : PartCfg<false>::kTile;
+  uint32_t bs = (stage / sh.W) & ~63u;
   if (bs > 1024) bs = 1024;
-  if (bs < 256) bs = 256;  // the block also scans up to 256 bins; partition_supported guarantees 256 * W <= kStageCap
+  if (bs < 256) bs = 256;  // partition_supported guarantees 256 * W <= stage
+  if (p.big) bs = 1024;    // the block also scans up to 1024 bins (W <= 16 at these widths: 1024 * W <= 16384)
   p.bs1 = bs;
   const uint32_t chunks = (sh.n + bs - 1) / bs;
   p.grid1 = chunks < 1024 ? chunks : 1024;
-  p.ent_cap = (uint32_t)((uint64_t)sh.n * sh.W) + kBinAlign * p.nhi + kTile;
-  p.tiles_cap = p.ent_cap / kTile + p.nhi + 1;
+  p.ent_cap = (uint32_t)((uint64_t)sh.n * sh.W) + kBinAlign * p.nhi + tile;
+  p.tiles_cap = p.ent_cap / tile + p.nhi + 1;
   return p;
 }
 
@@ -172,11 +192,11 @@ NMX_DEV uint32_t lds_rank(uint32_t* cur, uint32_t bin) {
 struct PartBufs {
   PartShape ps;
   uint32_t nbuckets;
-  uint32_t* hist_hi;     // [256]  entries per high bin                                  (zeroed)
-  uint32_t* cur_hi;      // [256]  scatter cursors per high bin                          (zeroed)
-  uint32_t* tab;         // [3 x 257] ent_base | binstart | tilestart  (k_tiles)
+  uint32_t* hist_hi;     // [nhi]  entries per high bin                                  (zeroed)
+  uint32_t* cur_hi;      // [nhi]  scatter cursors per high bin                          (zeroed)
+  uint32_t* tab;         // [3 x kTabStride] ent_base | binstart | tilestart  (k_tiles)
   uint32_t* ent_val;     // [ent_cap] level-1 output: (table row | sign << 31), grouped by high bin
-  uint8_t* ent_lo;       // [ent_cap] low key bits of the same entries
+  void* ent_lo;          // [ent_cap] low key bits of the same entries (PartCfg::LoT: one or two bytes)
   uint32_t* bucket_cnt;  // [nbuckets] entries per bucket                                (zeroed)
   uint32_t* bucket_cur;  // [nbuckets] scatter cursors per bucket                        (zeroed)
   uint32_t* start;       // [nbuckets + 1]
@@ -230,10 +250,11 @@ template <int SFID, int C, class Fn> NMX_HD void for_each_digit(const DigitSrc<S
 // ----------------------------------------------------------------------------------------------------
 // level 1
 // ----------------------------------------------------------------------------------------------------
-template <int SFID, int C> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_hist_hi(PartArgs<SFID> a) {
-  NMX_LDS uint32_t cnt[256];
+template <int SFID, int C, bool BIG> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_hist_hi(PartArgs<SFID> a) {
+  using Cfg = PartCfg<BIG>;
+  NMX_LDS uint32_t cnt[Cfg::kMaxHi];
   const uint32_t t = NMX_TID, bs = NMX_BDIM, LB = a.b.ps.LB;
-  for (uint32_t j = t; j < 256; j += bs) cnt[j] = 0;
+  for (uint32_t j = t; j < Cfg::kMaxHi; j += bs) cnt[j] = 0;
   NMX_SYNC();
   const uint32_t n = a.src.sh.n;
   for (uint32_t base = NMX_BID * bs; base < n; base += NMX_GDIM * bs) {
@@ -249,24 +270,26 @@ template <int SFID, int C> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_hist_hi(Par
     if (cnt[j]) nmx_atomic_add(&a.b.hist_hi[j], cnt[j]);
 }
 
-// (The SFID-independent kernels are templates on a dummy parameter only to get inline linkage across the curve TUs.)
-// One block of 256 threads.  tab[0..257) = ent_base (bin regions of ent_val / ent_lo, 16-entry aligned),
-// tab[257..514) = binstart (bin regions of the final array = exclusive scan of the bin sizes), tab[514..771) = tilestart.
-template <int U> NMX_KERNEL void NMX_LAUNCH_BOUNDS(256) k_tiles(PartBufs b) {
-  NMX_LDS uint32_t h[256], al[256], tl[256], o1[257], o2[257], o3[257], wtot[16];
+// One block of 1024 threads.  tab[0 .. nhi] = ent_base (bin regions of ent_val / ent_lo, 16-entry aligned),
+// tab[kTabStride ..] = binstart (bin regions of the final array = exclusive scan of the bin sizes),
+// tab[2 * kTabStride ..] = tilestart.  (The SFID-independent kernels are templates only to get inline linkage
+// across the curve TUs.)
+template <bool BIG> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_tiles(PartBufs b) {
+  using Cfg = PartCfg<BIG>;
+  NMX_LDS uint32_t h[1024], al[1024], tl[1024], o1[1025], o2[1025], o3[1025], wtot[16];
   const uint32_t t = NMX_TID, nhi = b.ps.nhi;
   const uint32_t c = t < nhi ? b.hist_hi[t] : 0;
   h[t] = c;
   al[t] = (c + kBinAlign - 1) & ~(kBinAlign - 1);
-  tl[t] = (c + kTile - 1) / kTile;
+  tl[t] = (c + Cfg::kTile - 1) / Cfg::kTile;
   NMX_SYNC();
   block_excl_scan(al, o1, nhi, wtot);
   block_excl_scan(h, o2, nhi, wtot);
   block_excl_scan(tl, o3, nhi, wtot);
   for (uint32_t j = t; j <= nhi; j += NMX_BDIM) {
     b.tab[j] = o1[j];
-    b.tab[257 + j] = o2[j];
-    b.tab[514 + j] = o3[j];
+    b.tab[kTabStride + j] = o2[j];
+    b.tab[2 * kTabStride + j] = o3[j];
   }
   if (t < nhi && c == 0) {  // no tile will ever visit this bin: its buckets are empty, placed at the bin's offset
     for (uint32_t l = 0; l < b.ps.nlo; l++) {
@@ -281,30 +304,34 @@ template <int U> NMX_KERNEL void NMX_LAUNCH_BOUNDS(256) k_tiles(PartBufs b) {
   }
 }
 
-template <int SFID, int C> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_part_hi(PartArgs<SFID> a) {
-  NMX_LDS uint32_t stage_val[kStageCap];
-  NMX_LDS uint16_t stage_key[kStageCap];
-  NMX_LDS uint32_t ent_base[256], cnt[256], lbase[257], gbase[256], cur[256], wtot[16];
+template <int SFID, int C, bool BIG> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_part_hi(PartArgs<SFID> a) {
+  using Cfg = PartCfg<BIG>;
+  using KeyT = typename Cfg::KeyT;
+  using LoT = typename Cfg::LoT;
+  NMX_LDS uint32_t stage_val[Cfg::kStage];
+  NMX_LDS KeyT stage_key[Cfg::kStage];
+  NMX_LDS uint32_t ent_base[Cfg::kMaxHi], cnt[Cfg::kMaxHi], lbase[Cfg::kMaxHi + 1], gbase[Cfg::kMaxHi], cur[Cfg::kMaxHi], wtot[16];
   const uint32_t t = NMX_TID, bs = NMX_BDIM;
   const uint32_t n = a.src.sh.n, nhi = a.b.ps.nhi, LB = a.b.ps.LB, lomask = a.b.ps.nlo - 1u;
+  LoT* ent_lo = static_cast<LoT*>(a.b.ent_lo);
   for (uint32_t j = t; j < nhi; j += bs) ent_base[j] = a.b.tab[j];
   for (uint32_t base = NMX_BID * bs; base < n; base += NMX_GDIM * bs) {
-    for (uint32_t j = t; j < 256; j += bs) cnt[j] = 0, cur[j] = 0;
+    for (uint32_t j = t; j < Cfg::kMaxHi; j += bs) cnt[j] = 0, cur[j] = 0;
     NMX_SYNC();
     const uint32_t i = base + t;
     uint32_t s[9], bi = 0;
     const bool live = i < n && a.src.load(i, s, bi, false);
     // phase A: this chunk's entries per bin.  With a compile-time width the digits stay in registers for phase B
-    // (key | neg << 15, 0xffff = none); at run-time width they are extracted again.
-    uint16_t dig[C ? WinMax<C>::value : 1];
+    // (key | neg << 31, all ones = none); at run-time width they are extracted again.
+    uint32_t dig[C ? WinMax<C>::value : 1];
     if constexpr (C != 0) {
 #pragma unroll
-      for (uint32_t w = 0; w < WinMax<C>::value; w++) dig[w] = 0xffffu;
+      for (uint32_t w = 0; w < WinMax<C>::value; w++) dig[w] = 0xffffffffu;
     }
     if (live)
       for_each_digit<SFID, C>(a.src, s, [&](uint32_t w, uint32_t d, uint32_t neg) {
         lds_count(cnt, (d - 1) >> LB);
-        if constexpr (C != 0) dig[w] = (uint16_t)((d - 1) | (neg << 15));
+        if constexpr (C != 0) dig[w] = (d - 1) | (neg << 31);
       });
     NMX_SYNC();
     block_excl_scan(cnt, lbase, nhi, wtot);
@@ -316,12 +343,12 @@ template <int SFID, int C> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_part_hi(Par
         const uint32_t bin = key >> LB;
         const uint32_t slot = lbase[bin] + lds_rank(cur, bin);
         stage_val[slot] = (w * a.src.pre_stride + bi) | (neg << 31);
-        stage_key[slot] = (uint16_t)key;
+        stage_key[slot] = (KeyT)key;
       };
       if constexpr (C != 0) {
 #pragma unroll
         for (uint32_t w = 0; w < WinMax<C>::value; w++)
-          if (dig[w] != 0xffffu) place(w, dig[w] & 0x7fffu, dig[w] >> 15);
+          if (dig[w] != 0xffffffffu) place(w, dig[w] & 0x7fffffffu, dig[w] >> 31);
       } else {
         for_each_digit<SFID, C>(a.src, s, [&](uint32_t w, uint32_t d, uint32_t neg) { place(w, d - 1, neg); });
       }
@@ -332,7 +359,7 @@ template <int SFID, int C> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_part_hi(Par
       const uint32_t key = stage_key[sl], bin = key >> LB;
       const uint32_t g = gbase[bin] + (sl - lbase[bin]);
       a.b.ent_val[g] = stage_val[sl];
-      a.b.ent_lo[g] = (uint8_t)(key & lomask);
+      ent_lo[g] = (LoT)(key & lomask);
     }
     NMX_SYNC();
   }
@@ -342,73 +369,86 @@ template <int SFID, int C> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_part_hi(Par
 // level 2: tiles of <= kTile entries, each inside one high bin (tile starts are 16-entry aligned)
 // ----------------------------------------------------------------------------------------------------
 // tile -> (bin, tile index inside the bin, first entry in ent_*, length); false past the last tile (block-uniform).
-NMX_DEV bool tile_of_block(const PartBufs& b, uint32_t* tilestart /* LDS 257 */, uint32_t& bin, uint32_t& j,
+template <bool BIG>
+NMX_DEV bool tile_of_block(const PartBufs& b, uint32_t* tilestart /* LDS kMaxHi + 1 */, uint32_t& bin, uint32_t& j,
                            uint32_t& first, uint32_t& len) {
+  constexpr uint32_t T = PartCfg<BIG>::kTile;
   const uint32_t nhi = b.ps.nhi;
-  for (uint32_t k = NMX_TID; k <= nhi; k += NMX_BDIM) tilestart[k] = b.tab[514 + k];
+  for (uint32_t k = NMX_TID; k <= nhi; k += NMX_BDIM) tilestart[k] = b.tab[2 * kTabStride + k];
   NMX_SYNC();
   const uint32_t tile = NMX_BID;
   if (tile >= tilestart[nhi]) return false;
   bin = find_bin(tilestart, nhi, tile);
   j = tile - tilestart[bin];
-  const uint32_t size = b.tab[257 + bin + 1] - b.tab[257 + bin];
-  first = b.tab[bin] + j * kTile;
-  len = size - j * kTile < kTile ? size - j * kTile : kTile;
+  const uint32_t size = b.tab[kTabStride + bin + 1] - b.tab[kTabStride + bin];
+  first = b.tab[bin] + j * T;
+  len = size - j * T < T ? size - j * T : T;
   return true;
 }
-// this thread's kTilePer consecutive low-bit bytes: one aligned 8-byte load (bytes past the tile's length may be read
+// this thread's kTilePer consecutive low-bit values: aligned 8- / 32-byte loads (values past the tile's length may be read
 // -- the arrays carry a tile of slack -- and are masked by the callers)
-NMX_DEV void load_lo8(const uint8_t* p, uint32_t (&lo)[kTilePer]) {
-  uint64_t w;
-  memcpy(&w, __builtin_assume_aligned(p, 8), 8);
+template <bool BIG> NMX_DEV void load_lo(const void* base, size_t e, uint32_t (&lo)[PartCfg<BIG>::kTilePer]) {
+  if constexpr (!BIG) {
+    uint64_t w;
+    memcpy(&w, __builtin_assume_aligned(static_cast<const uint8_t*>(base) + e, 8), 8);
 #pragma unroll
-  for (uint32_t k = 0; k < kTilePer; k++) lo[k] = (uint32_t)(w >> (8 * k)) & 0x7fu;
+    for (uint32_t k = 0; k < 8; k++) lo[k] = (uint32_t)(w >> (8 * k)) & 0x7fu;
+  } else {
+    uint16_t w[16];
+    memcpy(w, __builtin_assume_aligned(static_cast<const uint16_t*>(base) + e, 16), 32);
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) lo[k] = w[k] & 0x1ffu;
+  }
 }
 
-template <int U> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_hist_lo(PartBufs b) {
-  NMX_LDS uint32_t tilestart[257], cnt[128];
+template <bool BIG> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_hist_lo(PartBufs b) {
+  using Cfg = PartCfg<BIG>;
+  NMX_LDS uint32_t tilestart[Cfg::kMaxHi + 1], cnt[Cfg::kMaxLo];
   uint32_t bin, j, first, len;
-  if (!tile_of_block(b, tilestart, bin, j, first, len)) return;
+  if (!tile_of_block<BIG>(b, tilestart, bin, j, first, len)) return;
   const uint32_t t = NMX_TID;
-  if (t < 128) cnt[t] = 0;
+  if (t < Cfg::kMaxLo) cnt[t] = 0;
   NMX_SYNC();
-  const uint32_t e0 = t * kTilePer;
+  const uint32_t e0 = t * Cfg::kTilePer;
   if (e0 < len) {
-    uint32_t lo[kTilePer];
-    load_lo8(b.ent_lo + first + e0, lo);
+    uint32_t lo[Cfg::kTilePer];
+    load_lo<BIG>(b.ent_lo, (size_t)first + e0, lo);
 #pragma unroll
-    for (uint32_t k = 0; k < kTilePer; k++)
+    for (uint32_t k = 0; k < Cfg::kTilePer; k++)
       if (e0 + k < len) lds_count(cnt, lo[k]);
   }
   NMX_SYNC();
   if (t < b.ps.nlo && cnt[t]) nmx_atomic_add(&b.bucket_cnt[(bin << b.ps.LB) + t], cnt[t]);
 }
 
-template <int U> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_part_lo(PartBufs b) {
-  NMX_LDS uint32_t stage[kTile];
-  NMX_LDS uint8_t stage_lo[kTile];
-  NMX_LDS uint32_t tilestart[257], bcnt[128], bstart[129], cnt[128], lbase[129], gbase[128], wtot[16];
+template <bool BIG> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_part_lo(PartBufs b) {
+  using Cfg = PartCfg<BIG>;
+  using LoT = typename Cfg::LoT;
+  NMX_LDS uint32_t stage[Cfg::kTile];
+  NMX_LDS LoT stage_lo[Cfg::kTile];
+  NMX_LDS uint32_t tilestart[Cfg::kMaxHi + 1], bcnt[Cfg::kMaxLo], bstart[Cfg::kMaxLo + 1], cnt[Cfg::kMaxLo], lbase[Cfg::kMaxLo + 1],
+      gbase[Cfg::kMaxLo], wtot[16];
   uint32_t bin, j, first, len;
-  if (!tile_of_block(b, tilestart, bin, j, first, len)) return;
+  if (!tile_of_block<BIG>(b, tilestart, bin, j, first, len)) return;
   const uint32_t t = NMX_TID, bs = NMX_BDIM, nlo = b.ps.nlo, k0 = bin << b.ps.LB;
-  if (t < 128) {
+  if (t < Cfg::kMaxLo) {
     cnt[t] = 0;
     bcnt[t] = t < nlo ? b.bucket_cnt[k0 + t] : 0;
   }
   NMX_SYNC();
   block_excl_scan(bcnt, bstart, nlo, wtot);  // the bin's buckets inside the bin's region of the final array
-  const uint32_t region = b.tab[257 + bin];
+  const uint32_t region = b.tab[kTabStride + bin];
   if (j == 0 && t < nlo) {  // first tile of the bin: publish [start, end) of its buckets
     b.start[k0 + t] = region + bstart[t];
     b.end[k0 + t] = region + bstart[t + 1];
   }
-  uint32_t v[kTilePer], lo[kTilePer], pos[kTilePer];
-  const uint32_t e0 = t * kTilePer;
+  uint32_t v[Cfg::kTilePer], lo[Cfg::kTilePer], pos[Cfg::kTilePer];
+  const uint32_t e0 = t * Cfg::kTilePer;
   if (e0 < len) {
-    load_lo8(b.ent_lo + first + e0, lo);
-    memcpy(v, __builtin_assume_aligned(b.ent_val + first + e0, 16), 4 * kTilePer);  // two aligned 16-byte loads
+    load_lo<BIG>(b.ent_lo, (size_t)first + e0, lo);
+    memcpy(v, __builtin_assume_aligned(b.ent_val + first + e0, 16), 4 * Cfg::kTilePer);  // aligned 16-byte loads
 #pragma unroll
-    for (uint32_t k = 0; k < kTilePer; k++)
+    for (uint32_t k = 0; k < Cfg::kTilePer; k++)
       if (e0 + k < len) pos[k] = lds_rank(cnt, lo[k]);  // arrival rank inside the tile's sub-bin
   }
   NMX_SYNC();
@@ -416,11 +456,11 @@ template <int U> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_part_lo(PartBufs b) {
   if (t < nlo && cnt[t]) gbase[t] = region + bstart[t] + nmx_atomic_add(&b.bucket_cur[k0 + t], cnt[t]);  // the tile's run
   if (e0 < len) {
 #pragma unroll
-    for (uint32_t k = 0; k < kTilePer; k++)
+    for (uint32_t k = 0; k < Cfg::kTilePer; k++)
       if (e0 + k < len) {
         const uint32_t slot = lbase[lo[k]] + pos[k];
         stage[slot] = v[k];
-        stage_lo[slot] = (uint8_t)lo[k];
+        stage_lo[slot] = (LoT)lo[k];
       }
   }
   NMX_SYNC();

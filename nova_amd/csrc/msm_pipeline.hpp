@@ -149,38 +149,45 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
     PartBufs& pb = pa.b;
     pb.ps = make_part_shape(sh);
     pb.nbuckets = sh.nbuckets;
-    const size_t nctr = 512 + 3 * 257 + 1 + 2 * (size_t)sh.nbuckets;
+    const size_t nctr = 2048 + 3 * kTabStride + 1 + 2 * (size_t)sh.nbuckets;
     uint32_t* ctr = be.template alloc<uint32_t>(nctr);
     pb.hist_hi = ctr;
-    pb.cur_hi = ctr + 256;
-    pb.tab = ctr + 512;
-    pb.bucket_cnt = ctr + 512 + 3 * 257 + 1;
+    pb.cur_hi = ctr + 1024;
+    pb.tab = ctr + 2048;
+    pb.bucket_cnt = ctr + 2048 + 3 * kTabStride + 1;
     pb.bucket_cur = pb.bucket_cnt + sh.nbuckets;
     pb.ent_val = be.template alloc<uint32_t>(pb.ps.ent_cap);
-    pb.ent_lo = be.template alloc<uint8_t>(pb.ps.ent_cap);
+    pb.ent_lo = be.template alloc<uint8_t>((size_t)pb.ps.ent_cap * (pb.ps.big ? 2 : 1));
     vals1 = be.template alloc<uint32_t>(total);
     pb.vals = vals1;
     pb.start = start;
     pb.end = end;
     pb.total_out = counters + 5;
     be.memset0(ctr, nctr * sizeof(uint32_t));
-    be.mark("digits");
-    switch (sh.c) {  // the widths the tables are built with get their own instantiation (constant bit positions)
-      case 16: be.launch_kernel(&k_hist_hi<SFID, 16>, pb.ps.grid1, pb.ps.bs1, pa); break;
-      case 15: be.launch_kernel(&k_hist_hi<SFID, 15>, pb.ps.grid1, pb.ps.bs1, pa); break;
-      case 8: be.launch_kernel(&k_hist_hi<SFID, 8>, pb.ps.grid1, pb.ps.bs1, pa); break;
-      default: be.launch_kernel(&k_hist_hi<SFID, 0>, pb.ps.grid1, pb.ps.bs1, pa);
+    // the widths the tables are built with get their own instantiation (constant bit positions); BIG = keys wider than 15 bits
+    auto level1 = [&](auto hist, auto part) {
+      be.mark("digits");
+      be.launch_kernel(hist, pb.ps.grid1, pb.ps.bs1, pa);
+      if (pb.ps.big) be.launch_kernel(&k_tiles<true>, 1u, 1024u, pb);
+      else be.launch_kernel(&k_tiles<false>, 1u, 1024u, pb);
+      be.mark("sort");
+      be.launch_kernel(part, pb.ps.grid1, pb.ps.bs1, pa);
+    };
+    if (pb.ps.big) {
+      if (sh.c == 20) level1(&k_hist_hi<SFID, 20, true>, &k_part_hi<SFID, 20, true>);
+      else level1(&k_hist_hi<SFID, 0, true>, &k_part_hi<SFID, 0, true>);
+      be.launch_kernel(&k_hist_lo<true>, pb.ps.tiles_cap, kTileThreads, pb);
+      be.launch_kernel(&k_part_lo<true>, pb.ps.tiles_cap, kTileThreads, pb);
+    } else {
+      switch (sh.c) {
+        case 16: level1(&k_hist_hi<SFID, 16, false>, &k_part_hi<SFID, 16, false>); break;
+        case 15: level1(&k_hist_hi<SFID, 15, false>, &k_part_hi<SFID, 15, false>); break;
+        case 8: level1(&k_hist_hi<SFID, 8, false>, &k_part_hi<SFID, 8, false>); break;
+        default: level1(&k_hist_hi<SFID, 0, false>, &k_part_hi<SFID, 0, false>);
+      }
+      be.launch_kernel(&k_hist_lo<false>, pb.ps.tiles_cap, kTileThreads, pb);
+      be.launch_kernel(&k_part_lo<false>, pb.ps.tiles_cap, kTileThreads, pb);
     }
-    be.launch_kernel(&k_tiles<0>, 1u, 256u, pb);
-    be.mark("sort");
-    switch (sh.c) {
-      case 16: be.launch_kernel(&k_part_hi<SFID, 16>, pb.ps.grid1, pb.ps.bs1, pa); break;
-      case 15: be.launch_kernel(&k_part_hi<SFID, 15>, pb.ps.grid1, pb.ps.bs1, pa); break;
-      case 8: be.launch_kernel(&k_part_hi<SFID, 8>, pb.ps.grid1, pb.ps.bs1, pa); break;
-      default: be.launch_kernel(&k_part_hi<SFID, 0>, pb.ps.grid1, pb.ps.bs1, pa);
-    }
-    be.launch_kernel(&k_hist_lo<0>, pb.ps.tiles_cap, kTileThreads, pb);
-    be.launch_kernel(&k_part_lo<0>, pb.ps.tiles_cap, kTileThreads, pb);
     be.mark("bounds");
   } else {
     uint32_t* keys0 = be.template alloc<uint32_t>(total);

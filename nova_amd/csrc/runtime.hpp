@@ -131,7 +131,7 @@ struct Global {
   uint32_t no_quad_final = 0;         // env NMX_TUNE_NO_QUAD_FINAL
   uint32_t accum_prefetch = 1;        // env NMX_TUNE_ACCUM_PF
 };
-extern Global G;                 // capi.hip
+extern Global& G;                // capi.hip (heap singleton, never destroyed)
 void prof_store(const float* ms, int n);   // last call's stage times of this thread (capi.hip)
 void prof_add_tail(float ms);
 void arena_reserve(Ctx& c, size_t bytes);  // capi.hip

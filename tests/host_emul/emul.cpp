@@ -175,16 +175,16 @@ static int partition_check(const uint8_t* scalars, size_t n, uint32_t c, uint32_
   pb.ps = make_part_shape(sh);
   if (grid_override) pb.ps.grid1 = grid_override;
   pb.nbuckets = sh.nbuckets;
-  std::vector<uint32_t> start(sh.nbuckets + 1), end(sh.nbuckets + 1), ctr(512 + 3 * 257 + 1 + 2 * (size_t)sh.nbuckets),
+  std::vector<uint32_t> start(sh.nbuckets + 1), end(sh.nbuckets + 1), ctr(2048 + 3 * kTabStride + 1 + 2 * (size_t)sh.nbuckets),
       vals(total + 1), ent_val(pb.ps.ent_cap), keys(total + 1), kvals(total + 1);
-  std::vector<uint8_t> ent_lo(pb.ps.ent_cap);
+  std::vector<uint16_t> ent_lo(pb.ps.ent_cap);
   uint32_t err = 0, tot = 0;
   DigitSrc<SF> src{(const uint32_t*)scalars, nullptr, &err, sh, 0, u64_bits, stride, offset, nullptr, 0};
   pa.src = src;
   pb.hist_hi = ctr.data();
-  pb.cur_hi = ctr.data() + 256;
-  pb.tab = ctr.data() + 512;
-  pb.bucket_cnt = ctr.data() + 512 + 3 * 257 + 1;
+  pb.cur_hi = ctr.data() + 1024;
+  pb.tab = ctr.data() + 2048;
+  pb.bucket_cnt = ctr.data() + 2048 + 3 * kTabStride + 1;
   pb.bucket_cur = pb.bucket_cnt + sh.nbuckets;
   pb.ent_val = ent_val.data();
   pb.ent_lo = ent_lo.data();
@@ -195,16 +195,24 @@ static int partition_check(const uint8_t* scalars, size_t n, uint32_t c, uint32_
   HostEmulBackend be;
   auto l1 = [&](auto hist, auto part) {
     be.launch_kernel(hist, pb.ps.grid1, pb.ps.bs1, pa);
-    be.launch_kernel(&k_tiles<0>, 1u, 256u, pb);
+    if (pb.ps.big) be.launch_kernel(&k_tiles<true>, 1u, 1024u, pb);
+    else be.launch_kernel(&k_tiles<false>, 1u, 1024u, pb);
     be.launch_kernel(part, pb.ps.grid1, pb.ps.bs1, pa);
   };
   const uint32_t cc = ct_width ? c : 0;  // compile-time-width instantiation (when there is one) or the run-time one
-  if (cc == 16) l1(&k_hist_hi<SF, 16>, &k_part_hi<SF, 16>);
-  else if (cc == 15) l1(&k_hist_hi<SF, 15>, &k_part_hi<SF, 15>);
-  else if (cc == 8) l1(&k_hist_hi<SF, 8>, &k_part_hi<SF, 8>);
-  else l1(&k_hist_hi<SF, 0>, &k_part_hi<SF, 0>);
-  be.launch_kernel(&k_hist_lo<0>, pb.ps.tiles_cap, kTileThreads, pb);
-  be.launch_kernel(&k_part_lo<0>, pb.ps.tiles_cap, kTileThreads, pb);
+  if (pb.ps.big) {
+    if (cc == 20) l1(&k_hist_hi<SF, 20, true>, &k_part_hi<SF, 20, true>);
+    else l1(&k_hist_hi<SF, 0, true>, &k_part_hi<SF, 0, true>);
+    be.launch_kernel(&k_hist_lo<true>, pb.ps.tiles_cap, kTileThreads, pb);
+    be.launch_kernel(&k_part_lo<true>, pb.ps.tiles_cap, kTileThreads, pb);
+  } else {
+    if (cc == 16) l1(&k_hist_hi<SF, 16, false>, &k_part_hi<SF, 16, false>);
+    else if (cc == 15) l1(&k_hist_hi<SF, 15, false>, &k_part_hi<SF, 15, false>);
+    else if (cc == 8) l1(&k_hist_hi<SF, 8, false>, &k_part_hi<SF, 8, false>);
+    else l1(&k_hist_hi<SF, 0, false>, &k_part_hi<SF, 0, false>);
+    be.launch_kernel(&k_hist_lo<false>, pb.ps.tiles_cap, kTileThreads, pb);
+    be.launch_kernel(&k_part_lo<false>, pb.ps.tiles_cap, kTileThreads, pb);
+  }
   // reference: materialised (key, val) pairs grouped by key
   uint32_t err2 = 0;
   DigitSrc<SF> src2 = src;
