@@ -240,9 +240,9 @@ def main():
             "per_call_ms": {"median": round(float(np.median(per_call)) * 1e3, 4), "min": round(min(per_call) * 1e3, 4)},
             "roofline": {
                 "bound": "hbm",
-                # msm_seg.hpp from 2^22 sorted entries on, on the c <= 16 table path (keys below 2^22 points)
+                # msm_seg.hpp from 2^22 sorted entries on (table path, c <= 20)
                 "kernel": "k_launch<AccumSegFn> (bucket accumulation, segment-balanced)"
-                          if madds_per_launch(n, args) >= (1 << 22) and n < (1 << 22) and (args.window_bits or 16) <= 16
+                          if madds_per_launch(n, args) >= (1 << 22) and (args.window_bits or 16) <= 20
                           else "k_launch<AccumFn> (bucket accumulation)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,

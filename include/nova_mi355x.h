@@ -290,7 +290,7 @@ int nmx_set_window_bits(uint32_t c);
  * start-up); every combination computes the same result.  Names: "no_partition" (1: generic radix-sort path instead of
  * the hand-written LDS partition), "seg_min_total" (segment-balanced accumulate from this many sorted entries on;
  * 0xffffffff: never), "seg_min_len", "seg_lanes" (0: a multiple of the kernel's resident lanes), "no_quad_accum",
- * "no_quad_final", "accum_prefetch" (1 or 2).  Unknown name: NMX_E_ARG. */
+ * "no_quad_final", "accum_prefetch" (0: by table size; 1 or 2).  Unknown name: NMX_E_ARG. */
 int nmx_set_option(const char* name, uint32_t value);
 
 #ifdef __cplusplus

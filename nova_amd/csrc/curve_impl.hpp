@@ -142,7 +142,12 @@ static XYZZ<CurveT<CID>::BF> run_msm(Ctx& c, const void* d_bases, size_t n, cons
   a.no_partition = G.no_partition;
   a.seg_min_total = G.seg_min_total;
   a.seg_min_len = G.seg_min_len;
-  a.accum_prefetch = G.accum_prefetch;
+  // gathers in flight per lane: one is enough while the key's tables (W x 64 B per point) mostly hit the 256 MB Infinity Cache
+  // and L2; from ~6 GiB of tables on the gather latency shows and a second row in flight pays (2^24: accumulate 17.6 ->
+  // 16.0 ms; neutral at 2^22, slightly worse at 2^20 / 2^21: profiles/r02_msm_2p20/prefetch_depth.txt)
+  a.accum_prefetch = G.accum_prefetch ? G.accum_prefetch
+                                      : ((uint64_t)mc.pre_stride * 64u * ((FpParams<SF>::BITS + 1 + (mc.pre_c ? mc.pre_c : 16) - 1) /
+                                                                         (mc.pre_c ? mc.pre_c : 16)) >= (6ull << 30) ? 2u : 1u);
   {
     uint32_t bits = a.u64_bits ? a.u64_bits : sbits;
     MsmShape sh = make_shape(a.n, bits, a.force_c, a.pre_stride ? a.pre_c : 0);

@@ -129,7 +129,7 @@ struct Global {
   uint32_t seg_min_len = 8;           // env NMX_TUNE_SEG_MIN_LEN
   uint32_t seg_lanes_override = 0;    // env NMX_TUNE_SEG_LANES (0: the kernel's resident lane count)
   uint32_t no_quad_final = 0;         // env NMX_TUNE_NO_QUAD_FINAL
-  uint32_t accum_prefetch = 1;        // env NMX_TUNE_ACCUM_PF
+  uint32_t accum_prefetch = 0;        // env NMX_TUNE_ACCUM_PF / option accum_prefetch: 0 = by table size, 1, 2
 };
 extern Global& G;                // capi.hip (heap singleton, never destroyed)
 void prof_store(const float* ms, int n);   // last call's stage times of this thread (capi.hip)

@@ -21,7 +21,7 @@ VARIANTS = [
     {"seg_min_total": 0, "seg_lanes": 70001, "no_quad_final": 1},  # odd lane count, single-lane final pass
     {"seg_min_total": 0, "accum_prefetch": 2},
 ]
-DEFAULTS = {"no_partition": 0, "seg_min_total": 1 << 22, "seg_lanes": 0, "seg_min_len": 8, "no_quad_final": 0, "accum_prefetch": 1}
+DEFAULTS = {"no_partition": 0, "seg_min_total": 1 << 22, "seg_lanes": 0, "seg_min_len": 8, "no_quad_final": 0, "accum_prefetch": 0}
 
 
 @pytest.mark.parametrize("c,n", [(R.BN254_G1, 20000), (R.BN254_G1, 1 << 16), (R.PALLAS, 1 << 17)], ids=lambda v: getattr(v, "name", v))
