@@ -151,7 +151,8 @@ static XYZZ<CurveT<CID>::BF> run_msm(Ctx& c, const void* d_bases, size_t n, cons
   {
     uint32_t bits = a.u64_bits ? a.u64_bits : sbits;
     MsmShape sh = make_shape(a.n, bits, a.force_c, a.pre_stride ? a.pre_c : 0);
-    require((uint64_t)n * sh.W < 0xffffffffull && n < 0x7fffffffull, NMX_E_TOO_LARGE,
+    // (the partition's intermediate arrays carry up to 2^20 entries of alignment slack on top of n * windows)
+    require((uint64_t)n * sh.W < 0xfff00000ull && n < 0x7fffffffull, NMX_E_TOO_LARGE,
             "n * windows must be < 2^32");
   }
   c.wsum.resize(260);

@@ -10,7 +10,7 @@ timeout 1200 python -m pytest tests -q -m gpu --maxfail=5 > "$OUT/pytest_gpu.txt
 fi
 echo "== default bench (with extras)"
 t0=$(date +%s); timeout 900 python bench.py --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "rc=$? wall=$(( $(date +%s) - t0 ))s"; cat "$OUT/bench.json"
-for v in "NMX_TUNE_ACCUM_PF=2" "NMX_TUNE_ACCUM_PF=1"; do
+for v in "NMX_TUNE_ACCUM_PF=2"; do
   echo "== $v"
   for lg in 20 21; do
   env $v timeout 300 python bench.py --steps 20 --warmup 5 --log2n $lg --no-extras --no-cpu-baseline > "$OUT/b.json" 2> "$OUT/b.err"
