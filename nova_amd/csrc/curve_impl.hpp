@@ -232,11 +232,34 @@ template <int CID> static void table_shape(size_t n, uint32_t flags, uint32_t* p
   *pre_c = c;
   *pre_W = W;
 }
+struct ScratchFree {  // registration-time scratch (not the per-call arena: it can be gigabytes, and it is needed once)
+  void* p = nullptr;
+  ~ScratchFree() {
+    if (p) (void)hipFree(p);
+  }
+};
 template <int CID> static void build_tables(Ctx& c, void* d, size_t n, uint32_t pre_c, uint32_t pre_W) {
   if (!pre_W) return;
+  constexpr int BF = CurveT<CID>::BF;
   DeviceBackend be(c, false, false);
-  PrecompFn<CurveT<CID>::BF> f{(AffineW*)d, (uint32_t)n, pre_c, pre_W};
-  be.launch(f, (uint32_t)n);
+  if (pre_W < 3 || n < 1024) {  // small keys: one pass, one inversion per table point
+    PrecompFn<BF> f{(AffineW*)d, (uint32_t)n, pre_c, pre_W};
+    be.launch(f, (uint32_t)n);
+    return;
+  }
+  // two passes with a shared inversion per key point, 2^20 key points at a time (scratch: 176 B per table point)
+  const size_t chunk = n < ((size_t)1 << 20) ? n : ((size_t)1 << 20);
+  const size_t raw_bytes = (size_t)(pre_W - 1) * chunk * sizeof(XYZZL), pref_bytes = (size_t)(pre_W - 1) * chunk * 32;
+  ScratchFree sc;
+  HIPCHK(hipMalloc(&sc.p, raw_bytes + pref_bytes));
+  for (size_t i0 = 0; i0 < n; i0 += chunk) {
+    const uint32_t m = (uint32_t)(n - i0 < chunk ? n - i0 : chunk);
+    PrecompDblFn<BF> f1{(const AffineW*)d, (XYZZL*)sc.p, (uint32_t)i0, m, pre_c, pre_W};
+    be.launch(f1, m);
+    PrecompNormFn<BF> f2{(const XYZZL*)sc.p, (uint32_t*)((char*)sc.p + raw_bytes), (AffineW*)d, (uint32_t)n, (uint32_t)i0, m, pre_W};
+    be.launch(f2, m);
+  }
+  HIPCHK(hipStreamSynchronize(c.stream));  // the scratch is freed on return
 }
 
 template <int CID>

@@ -387,6 +387,54 @@ template <int FID> struct PrecompFn {
   }
 };
 
+// The same tables in two passes, for keys large enough to matter (round 2): PrecompFn pays one Fermat inversion (380
+// multiplications) per table point, 77 % of its time.  Pass 1 keeps doubling in extended-Jacobian form and parks every
+// window's point as raw limbs; pass 2 inverts the W - 1 denominators zz * zzz of a key point with ONE inversion (Montgomery's
+// trick: running products out, back-substitution in) and writes the affine table points.  9 multiplications + 1/(W-1)
+// of an inversion per table point instead of 384: 2^20 BN254 points 45 -> 13 ms.  Identical table bytes (canonical affine).
+template <int FID> struct PrecompDblFn {
+  const AffineW* key;  // the key (table 0)
+  XYZZL* raw;          // (W - 1) x m
+  uint32_t i0, m, c, W;
+  NMX_HD void operator()(uint32_t j) const {
+    XYZZ<FID> p = XYZZ<FID>::from_affine(Affine<FID>::load(key[i0 + j]));
+    for (uint32_t w = 1; w < W; w++) {
+      for (uint32_t q = 0; q < c; q++) p.dbl_in_place();
+      p.store_raw(raw[(size_t)(w - 1) * m + j]);
+    }
+  }
+};
+template <int FID> struct PrecompNormFn {
+  const XYZZL* raw;  // (W - 1) x m
+  uint32_t* pref;    // (W - 1) x m x 8 words: running products of the denominators
+  AffineW* tables;   // W x n
+  uint32_t n, i0, m, W;
+  NMX_HD void operator()(uint32_t j) const {
+    using F = Fp<FID>;
+    F acc = F::one();
+    for (uint32_t w = 1; w < W; w++) {
+      const XYZZ<FID> p = XYZZ<FID>::load_raw(raw[(size_t)(w - 1) * m + j]);
+      acc.canon().to_words(pref + 8 * ((size_t)(w - 1) * m + j));
+      if (!p.is_identity()) acc = acc * (p.zz * p.zzz);
+    }
+    F inv = acc.inv();
+    for (uint32_t w = W - 1; w >= 1; w--) {
+      const XYZZ<FID> p = XYZZ<FID>::load_raw(raw[(size_t)(w - 1) * m + j]);
+      Affine<FID> a;
+      if (p.is_identity()) {
+        a.x = F::zero();
+        a.y = F::zero();
+      } else {
+        const F iw = inv * F::from_words(pref + 8 * ((size_t)(w - 1) * m + j));  // 1 / (zz * zzz) of this window
+        inv = inv * (p.zz * p.zzz);
+        a.x = (p.x * (iw * p.zzz)).canon();
+        a.y = (p.y * (iw * p.zz)).canon();
+      }
+      a.store(tables[(size_t)w * n + i0 + j]);
+    }
+  }
+};
+
 // ----------------------------------------------------------------------------------------------------
 // 7. bucket reduction:  F = sum_{b=0..n-1} (b+1) * B_b  per window, as a binary tree that is shallow in
 //    *dependent point additions* (the lower levels have fewer lanes than the chip has SIMDs, so their cost is

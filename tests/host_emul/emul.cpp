@@ -241,7 +241,51 @@ static int partition_check(const uint8_t* scalars, size_t n, uint32_t c, uint32_
   return 0;
 }
 
+// window tables built in one pass (PrecompFn) and in two passes with a shared inversion (PrecompDblFn + PrecompNormFn):
+// byte-identical?
+template <int CID> static int precomp_check_t(const uint8_t* key_xy64, size_t n, uint32_t c) {
+  using C = CurveT<CID>;
+  constexpr int BF = C::BF;
+  const uint32_t W = (FpParams<C::SF>::BITS + 1 + c - 1) / c;
+  std::vector<AffineW> a(n * W), b(n * W);
+  for (size_t i = 0; i < n; i++) {
+    Affine<BF> p;
+    p.x = fp_from_bytes<BF>(key_xy64 + 64 * i);
+    p.y = fp_from_bytes<BF>(key_xy64 + 64 * i + 32);
+    if (!p.is_identity()) {
+      p.x = p.x.to_internal().canon();
+      p.y = p.y.to_internal().canon();
+    }
+    p.store(a[i]);
+    b[i] = a[i];
+  }
+  HostEmulBackend be;
+  PrecompFn<BF> f0{a.data(), (uint32_t)n, c, W};
+  be.launch(f0, (uint32_t)n);
+  const size_t chunk = n / 2 + 1;  // two chunks: exercises i0 != 0
+  std::vector<XYZZL> raw((W - 1) * chunk);
+  std::vector<uint32_t> pref((W - 1) * chunk * 8);
+  for (size_t i0 = 0; i0 < n; i0 += chunk) {
+    const uint32_t m = (uint32_t)(n - i0 < chunk ? n - i0 : chunk);
+    PrecompDblFn<BF> f1{b.data(), raw.data(), (uint32_t)i0, m, c, W};
+    be.launch(f1, m);
+    PrecompNormFn<BF> f2{raw.data(), pref.data(), b.data(), (uint32_t)n, (uint32_t)i0, m, W};
+    be.launch(f2, m);
+  }
+  return memcmp(a.data(), b.data(), sizeof(AffineW) * n * W) == 0 ? 0 : -1;
+}
+
 extern "C" {
+
+int emul_precomp_check(int curve, const uint8_t* key_xy64, size_t n, uint32_t c) {
+  switch (curve) {
+    case 0: return precomp_check_t<0>(key_xy64, n, c);
+    case 1: return precomp_check_t<1>(key_xy64, n, c);
+    case 2: return precomp_check_t<2>(key_xy64, n, c);
+    case 3: return precomp_check_t<3>(key_xy64, n, c);
+  }
+  return -2;
+}
 
 void emul_set_seg_min_total(uint32_t v) { g_seg_min_total = v; }
 void emul_set_seg_lanes(uint32_t v) { g_seg_lanes = v; }

@@ -296,3 +296,15 @@ def test_emul_segment_balanced_accumulate(emul, lanes):
     finally:
         emul.emul_set_seg_min_total(1 << 21)
         emul.emul_set_seg_lanes(37)
+
+
+@pytest.mark.parametrize("c", list(R.CURVES.values()), ids=lambda c: c.name)
+def test_emul_two_pass_tables_match_one_pass(emul, c):
+    """PrecompDblFn + PrecompNormFn (one shared inversion per key point) build byte-identical window tables to PrecompFn,
+    identity points inside the key included."""
+    n = 37
+    key = cref.sequential_bases(c, 1234, n).copy()
+    key[0] = 0
+    key[20] = 0
+    for width in (8, 16, 20):
+        assert emul.emul_precomp_check(c.cid, key.ctypes.data_as(ctypes.c_void_p), n, width) == 0, (c.name, width)
