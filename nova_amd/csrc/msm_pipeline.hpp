@@ -215,6 +215,13 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
     // large MSM: equal segments of the entry array per resident lane, raw-limb pieces, short folds (msm_seg.hpp)
     XYZZL* bucket_raw = be.template alloc<XYZZL>(sh.nbuckets);
     XYZZL* partial_raw = be.template alloc<XYZZL>(seg_lanes);
+    // a listed bucket spans more than 8 (64) segments: at most seg_lanes / 9 (/ 65) of them, whatever the distribution
+    auto list_cap = [&](uint32_t above) {
+      const uint32_t by_lanes = seg_lanes / (above + 1) + 1;
+      return by_lanes < sh.nbuckets ? by_lanes : sh.nbuckets;
+    };
+    HeavyRec* heavy_s = be.template alloc<HeavyRec>(list_cap(PlanSegFn::kHeavyAbove));
+    HeavyRec* big_s = be.template alloc<HeavyRec>(list_cap(PlanSegFn::kBigAbove));
     be.memset0(bucket_raw, sizeof(XYZZL) * sh.nbuckets);
     const uint32_t* total_p = counters + 5;
     be.mark("accum");
@@ -229,7 +236,7 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
     }
     be.mark("fold");
     {
-      PlanSegFn f{start, end, total_p, counters, heavy, big, sh.nbuckets, seg_lanes, a.seg_min_len};
+      PlanSegFn f{start, end, total_p, counters, heavy_s, big_s, sh.nbuckets, seg_lanes, a.seg_min_len};
       be.launch(f, sh.nbuckets);
     }
     {
@@ -244,7 +251,7 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
         uint32_t groups = use_big ? (1u << 18) / T : bound;
         if (groups > bound) groups = bound;
         if (groups < 1) groups = 1;
-        be.template launch_fold_raw<FID>(counters, use_big ? big : heavy, partial_raw, T, cap, groups, use_big ? 1u : 0u);
+        be.template launch_fold_raw<FID>(counters, use_big ? big_s : heavy_s, partial_raw, T, cap, groups, use_big ? 1u : 0u);
       }
       be.template launch_final_seg<FID>(start, end, total_p, bucket_raw, partial_raw, buckets, sh.nbuckets, seg_lanes,
                                         a.seg_min_len);
