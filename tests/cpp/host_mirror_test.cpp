@@ -37,6 +37,24 @@ template <int CURVE> static int run(const uint8_t gen[64], int topmask) {
   ref_msm(CURVE, sc[0].data(), bases[0].data(), n, exp.xy.data(), &inf);
   exp.is_inf = inf;
   if (!(got == exp)) return 1;
+  // the slice form keeps the caller's bases resident: the second call over the same vector is a cache hit, uploads
+  // nothing and returns the same point (the reference passes &ck.ck[..n] on every call: pedersen.rs:263-270)
+  if (DlogGroupExt<CURVE>::min_gpu_n() == 0) return 1;
+  {
+    const std::vector<Affine> held(bases.begin(), bases.begin() + n);
+    uint64_t st0[NMX_STAT_COUNT], st1[NMX_STAT_COUNT], st2[NMX_STAT_COUNT];
+    nmx_cache_clear();
+    nmx_cache_configure(0, 64, 0);  // n = 100 is below the default caching threshold (128)
+    nmx_stats(st0, NMX_STAT_COUNT);
+    if (!(DlogGroupExt<CURVE>::vartime_multiscalar_mul(sc, held) == exp)) return 1;
+    nmx_stats(st1, NMX_STAT_COUNT);
+    if (!(DlogGroupExt<CURVE>::vartime_multiscalar_mul(sc, held) == exp)) return 1;
+    nmx_stats(st2, NMX_STAT_COUNT);
+    if (st1[NMX_STAT_CACHE_UPLOADS] != st0[NMX_STAT_CACHE_UPLOADS] + 1) return 1;
+    if (st2[NMX_STAT_CACHE_UPLOADS] != st1[NMX_STAT_CACHE_UPLOADS] || st2[NMX_STAT_CACHE_HITS] != st1[NMX_STAT_CACHE_HITS] + 1) return 1;
+    if (st2[NMX_STAT_BASE_BYTES_H2D] != st1[NMX_STAT_BASE_BYTES_H2D]) return 1;
+    nmx_cache_configure(0, 128, 0);
+  }
   // empty -> identity (blitzar.rs:48-66)
   if (!DlogGroupExt<CURVE>::vartime_multiscalar_mul({}, std::vector<Affine>{}).is_inf) return 1;
   // commit with blinding over a registered key (pedersen.rs:263-270)

@@ -25,7 +25,7 @@ CSRC = os.path.join(os.path.dirname(HERE), "nova_amd", "csrc")
 def emul():
     deps = [SRC, os.path.join(HERE, "host_emul", "simt.hpp")] + [
         os.path.join(CSRC, f) for f in ("fp.hpp", "curve.hpp", "curves.hpp", "msm_kernels.hpp", "msm_pipeline.hpp",
-                                        "msm_partition.hpp")]
+                                        "msm_partition.hpp", "msm_seg.hpp", "curve_quad.hpp")]
     if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-DNMX_DEBUG_BOUNDS", "-shared", "-fPIC", "-o", SO, SRC])
     L = ctypes.CDLL(SO)
