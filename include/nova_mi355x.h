@@ -150,7 +150,8 @@ enum {
   NMX_STAT_UNCACHED_CALLS = 6,/* slice-form calls that uploaded their bases for the call only                 */
   NMX_STAT_BASE_BYTES_H2D = 7,/* bytes of base points copied host -> device by slice-form calls               */
   NMX_STAT_MSM_CALLS = 8,     /* MSMs run (every entry point; a batch counts each vector)                     */
-  NMX_STAT_COUNT = 9
+  NMX_STAT_FUSED_RUNS = 9,    /* batch calls whose short vectors ran as one fused pipeline run                */
+  NMX_STAT_COUNT = 10
 };
 int nmx_stats(uint64_t* out, int cap);
 /* same, bases taken from a registered key */
@@ -177,7 +178,9 @@ int nmx_msm_sparse_handle(uint64_t handle, const uint64_t* indices, const void* 
 
 /* DlogGroupExt::batch_vartime_multiscalar_mul (src/provider/traits.rs:82-90; blitzar override
  * src/provider/blitzar.rs:22-40): k MSMs over one base array, the j-th using bases[..lens[j]]
- * (HyperKZG batch_commit, src/provider/hyperkzg.rs:593-612).  out = k x 64 bytes, out_is_inf = k bytes. */
+ * (HyperKZG batch_commit, src/provider/hyperkzg.rs:593-612).  out = k x 64 bytes, out_is_inf = k bytes.
+ * The shortest vectors of a batch (up to 16 on a 2^14 .. 2^21-point key, 256 below) run as ONE fused pass over the
+ * key's window tables with a bucket set per vector; the others run as independent MSMs on concurrent streams. */
 int nmx_msm_batch(int curve, const void* const* scalar_vecs, const size_t* lens, size_t k,
                   const void* bases_xy64, size_t n_bases, uint32_t flags, uint8_t* out, uint8_t* out_is_inf);
 int nmx_msm_batch_handle(uint64_t handle, const void* const* scalar_vecs, const size_t* lens, size_t k,
@@ -290,7 +293,8 @@ int nmx_set_window_bits(uint32_t c);
  * start-up); every combination computes the same result.  Names: "no_partition" (1: generic radix-sort path instead of
  * the hand-written LDS partition), "seg_min_total" (segment-balanced accumulate from this many sorted entries on;
  * 0xffffffff: never), "seg_min_len", "seg_lanes" (0: a multiple of the kernel's resident lanes), "no_quad_accum",
- * "no_quad_final", "accum_prefetch" (0: by table size; 1 or 2).  Unknown name: NMX_E_ARG. */
+ * "no_quad_final", "accum_prefetch" (0: by table size; 1 or 2), "no_batch_fuse" (1: every vector of a batch call runs
+ * as its own MSM).  Unknown name: NMX_E_ARG. */
 int nmx_set_option(const char* name, uint32_t value);
 
 #ifdef __cplusplus

@@ -89,6 +89,7 @@ static void ensure_init() {
   if (const char* t = getenv("NMX_TUNE_SEG_MIN_LEN")) G.seg_min_len = (uint32_t)atoi(t) ? (uint32_t)atoi(t) : 1u;
   if (const char* t = getenv("NMX_TUNE_SEG_LANES")) G.seg_lanes_override = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_NO_QUAD_FINAL")) G.no_quad_final = (uint32_t)atoi(t);
+  if (const char* t = getenv("NMX_TUNE_NO_BATCH_FUSE")) G.no_batch_fuse = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_ACCUM_PF")) G.accum_prefetch = (uint32_t)atoi(t);
   HIPCHK(hipSetDevice(dev));
   cache_init_defaults();
@@ -606,10 +607,13 @@ int nmx_msm_sparse_handle(uint64_t handle, const uint64_t* indices, const void* 
   });
 }
 
-// The reference's default is `scalars.par_iter().map(msm)` (traits.rs:82-90).  Here up to kBatchLanes host threads
-// each lease their own context (stream + workspace) and take vectors longest-first: independent MSMs overlap on
-// the GPU -- the latency-bound fold / reduction passes of one run under the accumulate kernel of another
-// (profiles/r01_msm_2p20/concurrent_callers.txt: 1.5-1.7x for the short vectors of a HyperKZG batch_commit).
+// The reference's default is `scalars.par_iter().map(msm)` (traits.rs:82-90).  Here the shortest vectors (as many as the
+// key's window width leaves key bits for: 16 on a 2^17..2^21-point key) are FUSED into one pipeline run over the key's
+// tables, one bucket set per vector -- an MSM of a few thousand pairs costs ~0.3 ms of dependent point additions
+// whatever its length, and the fused run pays that once (profiles/r02_msm_2p20/batch_fused.txt).  The remaining
+// (longest) vectors and the fused run are jobs taken longest-first by up to kBatchLanes host threads, each leasing its
+// own context (stream + workspace): independent runs overlap on the GPU -- the latency-bound fold / reduction passes
+// of one under the accumulate kernel of another.
 static constexpr size_t kBatchLanes = 4;
 struct JoinAll {  // unwinding must never destroy a joinable std::thread (std::terminate)
   std::vector<std::thread>& th;
@@ -630,6 +634,27 @@ static void batch_impl(const BaseSet& bs, size_t base_off, size_t n_bases, const
   std::vector<size_t> order(k);
   for (size_t j = 0; j < k; j++) order[j] = j;
   std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return lens[a] > lens[b]; });
+  // jobs: runs of consecutive vectors in `order` -- one vector = an MSM of its own, several = one fused run.  Groups are
+  // cut from the short end, as many vectors each as the key takes; jobs are taken longest-first.
+  struct Job {
+    size_t first, count;
+    uint64_t weight;
+  };
+  std::vector<Job> jobs;
+  {
+    const size_t limit = k >= 2 ? o.batch_limit(bs) : 0;
+    size_t hi = k;
+    while (hi > 0) {
+      size_t lo = hi - 1;
+      uint64_t sum = lens[order[lo]];
+      while (limit >= 2 && lo > 0 && hi - lo < limit && (sum + lens[order[lo - 1]]) * bs.pre_W < 0xfff00000ull)
+        sum += lens[order[--lo]];  // (entry indices of a run are 32 bits)
+      jobs.push_back(Job{lo, hi - lo, sum});
+      hi = lo;
+    }
+    std::stable_sort(jobs.begin(), jobs.end(), [](const Job& x, const Job& y) { return x.weight > y.weight; });
+  }
+  const size_t njobs = jobs.size();
   // results are staged so that a failure in any vector leaves `out` untouched
   std::vector<uint8_t> tmp(64 * (k ? k : 1)), tinf(k ? k : 1);
   std::atomic<size_t> next{0};
@@ -646,8 +671,23 @@ static void batch_impl(const BaseSet& bs, size_t base_off, size_t n_bases, const
     try {
       for (;;) {
         size_t i = next.fetch_add(1);
-        if (i >= k) return;
-        size_t j = order[i];
+        if (i >= njobs) return;
+        const Job& job = jobs[i];
+        if (job.count > 1) {
+          const size_t m = job.count;
+          std::vector<BatchItem> items(m);
+          for (size_t q = 0; q < m; q++) items[q] = BatchItem{vecs[order[job.first + q]], lens[order[job.first + q]]};
+          std::vector<uint8_t> r(64 * m), rinf(m);
+          stat_add(NMX_STAT_MSM_CALLS, m);
+          stat_add(NMX_STAT_FUSED_RUNS);
+          o.msm_key_batch(*ctx, bs, base_off, items.data(), m, field_call(nullptr, flags), flags, r.data(), rinf.data());
+          for (size_t q = 0; q < m; q++) {
+            memcpy(tmp.data() + 64 * order[job.first + q], r.data() + 64 * q, 64);
+            tinf[order[job.first + q]] = rinf[q];
+          }
+          continue;
+        }
+        const size_t j = order[job.first];
         stat_add(NMX_STAT_MSM_CALLS);
         o.msm_key(*ctx, bs, base_off, lens[j], field_call(vecs[j], flags), flags, tmp.data() + 64 * j, tinf.data() + j);
       }
@@ -659,7 +699,7 @@ static void batch_impl(const BaseSet& bs, size_t base_off, size_t n_bases, const
       record(Fail{NMX_E_HIP, "unknown exception in a batch worker"});
     }
   };
-  const size_t lanes = k < kBatchLanes ? k : kBatchLanes;
+  const size_t lanes = njobs < kBatchLanes ? njobs : kBatchLanes;
   if (lanes <= 1) {
     guarded_worker(&c);
   } else {
@@ -1070,6 +1110,7 @@ int nmx_set_option(const char* name, uint32_t value) {
     else if (n == "no_quad_accum") G.no_quad_accum = value;
     else if (n == "no_quad_final") G.no_quad_final = value;
     else if (n == "accum_prefetch") G.accum_prefetch = value;
+    else if (n == "no_batch_fuse") G.no_batch_fuse = value;
     else throw Fail{NMX_E_ARG, "unknown option name"};
   });
 }

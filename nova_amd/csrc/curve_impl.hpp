@@ -321,6 +321,104 @@ static XYZZ<CurveT<CID>::BF> run_msm_key(Ctx& c, const BaseSet& bs, size_t offse
   mc.bases_clean = !bs.any_identity;
   return run_msm<CID>(c, (const char*)bs.d + offset * 64, n, mc);
 }
+// Fused batch over the key's tables: every vector's digits go through one partition / accumulate / reduction run, vector j
+// owning bucket set j.  The fixed latency of a run (~0.2-0.3 ms of dependent point additions) is paid once, not k times.
+template <int CID> static uint32_t batch_limit_for(const BaseSet& bs) {
+  if (!bs.pre_W || G.no_batch_fuse) return 0;
+  const uint32_t fc = G.force_c.load(std::memory_order_relaxed);
+  if (fc && fc != bs.pre_c) return 0;
+  uint32_t best = 0;
+  for (uint32_t k = 2; k <= 256; k <<= 1) {
+    MsmShape sh = make_shape(1024, FpParams<CurveT<CID>::SF>::BITS, 0, bs.pre_c, k);
+    if (!partition_supported(sh, true)) break;
+    best = k;
+  }
+  return best;
+}
+template <int CID>
+static void run_msm_batch(Ctx& c, const BaseSet& bs, size_t offset, const BatchItem* items, size_t k, const MsmCall& shared,
+                          XYZZ<CurveT<CID>::BF>* results) {
+  using C = CurveT<CID>;
+  constexpr int BF = C::BF, SF = C::SF;
+  require(bs.pre_W && k >= 1 && k <= 256 && !shared.u64_mode && !shared.gather_host && !shared.all_ones, NMX_E_ARG,
+          "fused batch: unsupported call");
+  const uint32_t sbits = FpParams<SF>::BITS;
+  std::vector<uint32_t> off(k + 1);
+  std::vector<const uint32_t*> ptrs(k);
+  uint64_t total_n = 0, lens_hash = 0x243f6a8885a308d3ull;
+  for (size_t j = 0; j < k; j++) {
+    off[j] = (uint32_t)total_n;
+    total_n += items[j].n;
+    lens_hash = (lens_hash ^ items[j].n) * 0x9e3779b97f4a7c15ull;
+    lens_hash ^= lens_hash >> 29;
+  }
+  for (size_t j = 0; j < k; j++) results[j] = XYZZ<BF>::identity();
+  if (total_n == 0) return;  // msm.rs:228, every vector
+  require(total_n * bs.pre_W < 0xfff00000ull, NMX_E_TOO_LARGE, "n * windows must be < 2^32");
+  off[k] = (uint32_t)total_n;
+
+  MsmArgs a;
+  a.scalars = nullptr;
+  a.bases = bs.d;
+  a.n = (uint32_t)total_n;
+  a.scalars_mont = shared.scalars_mont ? 1u : 0u;
+  a.u64_bits = 0;
+  a.force_c = 0;
+  a.force_lmax = G.force_lmax;
+  a.force_fold_t = G.force_fold_t;
+  a.pre_stride = (uint32_t)bs.n;
+  a.pre_offset = (uint32_t)offset;
+  a.pre_c = bs.pre_c;
+  a.bases_clean = bs.any_identity ? 0u : 1u;
+  a.no_partition = G.no_partition;
+  a.seg_min_total = G.seg_min_total;
+  a.seg_min_len = G.seg_min_len;
+  a.accum_prefetch = G.accum_prefetch ? G.accum_prefetch : 1u;
+  a.batch_k = (uint32_t)k;
+  c.wsum.resize(260);
+  XYZZW* wsum = c.wsum.data();
+  uint32_t err = 0;
+  const bool prof = G.profiling.load(std::memory_order_relaxed);
+  const uint64_t shape_key = (shape_hash(a, shared, 32) ^ lens_hash ^ (k << 48)) | 1u;
+  for (int pass = (c.shape_key == shape_key && c.shape_bytes <= c.cap) ? 1 : 0; pass < 2; pass++) {
+    DeviceBackend be(c, pass == 0, prof);
+    uint32_t* d_off = be.alloc<uint32_t>(k + 1);
+    const uint32_t** d_ptr = be.alloc<const uint32_t*>(k);
+    for (size_t j = 0; j < k; j++) {
+      if (shared.scalars_device) {
+        ptrs[j] = (const uint32_t*)items[j].scalars;
+      } else {
+        uint32_t* d_s = be.alloc<uint32_t>(items[j].n * 8);
+        ptrs[j] = d_s;
+        if (pass == 1 && items[j].n)
+          HIPCHK(hipMemcpyAsync(d_s, items[j].scalars, items[j].n * 32, hipMemcpyHostToDevice, c.stream));
+      }
+    }
+    if (pass == 1) {  // (pageable sources: the copies are staged before the call returns; both vectors outlive the sync)
+      HIPCHK(hipMemcpyAsync(d_off, off.data(), (k + 1) * 4, hipMemcpyHostToDevice, c.stream));
+      HIPCHK(hipMemcpyAsync(d_ptr, ptrs.data(), k * sizeof(void*), hipMemcpyHostToDevice, c.stream));
+    }
+    a.batch_off = d_off;
+    a.batch_vec = d_ptr;
+    msm_pipeline<DeviceBackend, BF, SF>(be, a, sbits, wsum, &err);
+    if (pass == 0) {
+      arena_reserve(c, be.used);
+      c.shape_key = shape_key;
+      c.shape_bytes = be.used;
+    } else if (prof) {
+      float st[kMaxMarks];
+      int ns = 0;
+      for (int i = 0; i + 1 < be.nmarks; i++) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, c.ev[i], c.ev[i + 1]));
+        st[ns++] = ms;
+      }
+      prof_store(st, ns);
+    }
+  }
+  require(!(err & ERR_SCALAR_RANGE), NMX_E_SCALAR_RANGE, "scalar >= field modulus");
+  for (size_t j = 0; j < k; j++) results[j] = XYZZ<BF>::load(wsum[j]);
+}
 template <int CID>
 static void msm_key_entry(const BaseSet& bs, size_t offset, size_t n, const MsmCall& mc, uint32_t flags,
                           uint8_t* out, uint8_t* is_inf, Ctx& c) {
@@ -340,6 +438,13 @@ template <int CID> struct CurveImpl {
                       uint8_t* out, uint8_t* inf) {
     msm_key_entry<CID>(bs, offset, n, mc, flags, out, inf, c);
   }
+  static void msm_key_batch(Ctx& c, const BaseSet& bs, size_t offset, const BatchItem* items, size_t k,
+                            const MsmCall& shared, uint32_t flags, uint8_t* out, uint8_t* inf) {
+    std::vector<XYZZ<BF>> r(k, XYZZ<BF>::identity());
+    run_msm_batch<CID>(c, bs, offset, items, k, shared, r.data());
+    for (size_t j = 0; j < k; j++) write_result<CID>(r[j], flags, out + 64 * j, inf ? inf + j : nullptr);
+  }
+  static uint32_t batch_limit(const BaseSet& bs) { return batch_limit_for<CID>(bs); }
   static void commit(Ctx& c, const BaseSet& bs, size_t n, const MsmCall& mc, const void* h_xy64, const void* r,
                      uint32_t flags, uint8_t* out, uint8_t* inf) {
     // the blinding term h * r is ~380 host point operations (0.1-0.2 ms): computed on a second host thread while the
@@ -432,7 +537,7 @@ template <int CID> struct CurveImpl {
     return memcmp(got, want, 32) == 0;
   }
   static CurveOps ops() {
-    return CurveOps{&msm_key, &commit, &upload, &check_point_host, FpParams<BF>::PW,
+    return CurveOps{&msm_key, &msm_key_batch, &batch_limit, &commit, &upload, &check_point_host, FpParams<BF>::PW,
                     &generate, &internal_to_canonical, &point_sum, &check_layout};
   }
 };

@@ -58,7 +58,8 @@ struct MsmShape {
   uint32_t c;         // window width (bits)
   uint32_t W;         // digit windows
   uint32_t WB;        // bucket sets: W, or 1 when window w reads the precomputed table 2^(cw) * P (all windows share
-                      // one bucket set and no window combination is needed)
+                      // one bucket set and no window combination is needed); a fused batch over tables has one set per
+                      // vector (rounded up to a power of two)
   uint32_t M;         // buckets per set = 2^(c-1)
   uint32_t nbuckets;  // WB*M ; key nbuckets is the trash bucket
   uint32_t lmax;      // longest run one lane accumulates
@@ -82,15 +83,33 @@ template <int SFID> struct DigitSrc {
   uint32_t scalars_mont, u64_bits, pre_stride, pre_offset;
   const uint32_t* gather;
   uint32_t all_ones;
+  // fused batch (a7: k vectors over prefixes of one key, run as ONE pipeline): pair i of the concatenation is pair
+  // i - batch_off[j] of vector j, read from batch_vec[j]; its buckets are set j (kbase = j * M).  batch_k = 0: one vector.
+  uint32_t batch_k = 0;
+  const uint32_t* batch_off = nullptr;          // [batch_k + 1] prefix sums of the vector lengths
+  const uint32_t* const* batch_vec = nullptr;   // [batch_k] scalar arrays (n_j x 8 u32)
 
-  // canonical scalar words of pair i and the row of its base in the key; false: the pair contributes nothing
-  // (out-of-range scalar -> error bit; identity base, msm.rs:247-249)
-  NMX_HD bool load(uint32_t i, uint32_t (&s)[9], uint32_t& bi, bool report) const {
+  // canonical scalar words of pair i, the row of its base in the key and the first bucket of its bucket set; false: the
+  // pair contributes nothing (out-of-range scalar -> error bit; identity base, msm.rs:247-249)
+  NMX_HD bool load(uint32_t i, uint32_t (&s)[9], uint32_t& bi, uint32_t& kbase, bool report) const {
     bool ok = true;
+    const uint32_t* sc = scalars;
+    kbase = 0;
+    if (batch_k) {
+      uint32_t lo = 0, hi = batch_k;  // batch_off[lo] <= i < batch_off[hi]
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (batch_off[mid] <= i) lo = mid;
+        else hi = mid;
+      }
+      i -= batch_off[lo];
+      sc = batch_vec[lo];
+      kbase = lo * sh.M;
+    }
     bi = (gather ? gather[i] : i) + pre_offset;
     if (u64_bits) {
-      s[0] = all_ones ? 1u : scalars[2 * (size_t)i];
-      s[1] = all_ones ? 0u : scalars[2 * (size_t)i + 1];
+      s[0] = all_ones ? 1u : sc[2 * (size_t)i];
+      s[1] = all_ones ? 0u : sc[2 * (size_t)i + 1];
 #pragma unroll
       for (int j = 2; j < 9; j++) s[j] = 0;
       if (u64_bits < 64) {
@@ -102,7 +121,7 @@ template <int SFID> struct DigitSrc {
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < 8; j++) s[j] = scalars[8 * (size_t)i + j];
+      for (int j = 0; j < 8; j++) s[j] = sc[8 * (size_t)i + j];
       s[8] = 0;
       if (!Fp<SFID>::words_lt_p(s)) {  // from_repr would have rejected it on the reference side
         if (report) nmx_atomic_or(err, ERR_SCALAR_RANGE);
@@ -143,13 +162,13 @@ template <int SFID> struct DigitsFn {
   uint32_t* vals;  // W x n
   NMX_HD void operator()(uint32_t i) const {
     const MsmShape& sh = src.sh;
-    uint32_t s[9], bi;
-    const bool skip = !src.load(i, s, bi, true);
+    uint32_t s[9], bi, kbase;
+    const bool skip = !src.load(i, s, bi, kbase, true);
     uint32_t carry = 0;
     for (uint32_t w = 0; w < sh.W; w++) {
       uint32_t d, neg;
       src.digit(s, w, carry, d, neg);
-      const uint32_t key = (d == 0 || skip) ? sh.nbuckets : ((src.pre_stride ? 0u : w * sh.M) + d - 1);
+      const uint32_t key = (d == 0 || skip) ? sh.nbuckets : ((src.pre_stride ? kbase : w * sh.M) + d - 1);
       const size_t o = (size_t)w * sh.n + i;
       keys[o] = key;
       vals[o] = (w * src.pre_stride + bi) | (neg << 31);

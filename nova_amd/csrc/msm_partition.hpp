@@ -89,14 +89,14 @@ static constexpr uint32_t kTileThreads = 1024;
 static constexpr uint32_t kBinAlign = 16;
 static constexpr uint32_t kTabStride = 1025;  // tab = 3 arrays of nhi + 1 <= 1025 words
 
-inline bool partition_supported(const MsmShape& sh, bool table_mode) {
-  // 256 threads (one scalar each) is the smallest first-level block: its W digits per scalar must fit the LDS stage
-  if (!(table_mode && sh.WB == 1 && sh.c >= 2 && sh.c <= 20)) return false;
-  return sh.W * 256u <= (sh.c <= 16 ? PartCfg<false>::kStage : PartCfg<true>::kStage);
-}
-inline PartShape make_part_shape(const MsmShape& sh) {
+// Geometry for a table-mode shape; false when the hand-written partition does not cover it (the generic sort path runs).
+// Keys are bucket indices in [0, WB * M): c - 1 bits for one vector, up to 19 with the bucket sets of a fused batch.
+inline bool make_part_shape(const MsmShape& sh, bool table_mode, PartShape* out) {
+  if (!(table_mode && sh.c >= 2 && sh.c <= 20 && sh.WB >= 1 && (sh.WB & (sh.WB - 1)) == 0)) return false;
+  uint32_t kb = sh.c - 1;
+  for (uint32_t v = sh.WB; v > 1; v >>= 1) kb++;
+  if (kb > 19) return false;
   PartShape p;
-  const uint32_t kb = sh.c - 1;
   p.big = kb > 15 ? 1u : 0u;
   p.LB = p.big ? 9u : (kb < 7 ? kb : 7);
   p.HB = kb - p.LB;
@@ -104,15 +104,26 @@ inline PartShape make_part_shape(const MsmShape& sh) {
   p.nhi = 1u << p.HB;
   const uint32_t stage = p.big ? PartCfg<true>::kStage : PartCfg<false>::kStage;
   const uint32_t tile = p.big ? PartCfg<true>::kTile : PartCfg<false>::kTile;
+  // one scalar per thread and chunk: its W digits must fit the LDS stage; 256 threads is the smallest first-level block,
+  // and the block also scans the nhi bins (block_excl_scan needs a thread per bin)
   uint32_t bs = (stage / sh.W) & ~63u;
   if (bs > 1024) bs = 1024;
-  if (bs < 256) bs = 256;  // partition_supported guarantees 256 * W <= stage
-  if (p.big) bs = 1024;    // the block also scans up to 1024 bins (W <= 16 at these widths: 1024 * W <= 16384)
+  if (bs < 256 || bs < p.nhi) return false;
   p.bs1 = bs;
   const uint32_t chunks = (sh.n + bs - 1) / bs;
   p.grid1 = chunks < 1024 ? chunks : 1024;
   p.ent_cap = (uint32_t)((uint64_t)sh.n * sh.W) + kBinAlign * p.nhi + tile;
   p.tiles_cap = p.ent_cap / tile + p.nhi + 1;
+  *out = p;
+  return true;
+}
+inline bool partition_supported(const MsmShape& sh, bool table_mode) {
+  PartShape p;
+  return make_part_shape(sh, table_mode, &p);
+}
+inline PartShape make_part_shape(const MsmShape& sh) {
+  PartShape p{};
+  (void)make_part_shape(sh, true, &p);
   return p;
 }
 
@@ -260,9 +271,9 @@ template <int SFID, int C, bool BIG> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_h
   for (uint32_t base = NMX_BID * bs; base < n; base += NMX_GDIM * bs) {
     const uint32_t i = base + t;
     if (i < n) {
-      uint32_t s[9], bi;
-      if (a.src.load(i, s, bi, true))
-        for_each_digit<SFID, C>(a.src, s, [&](uint32_t, uint32_t d, uint32_t) { lds_count(cnt, (d - 1) >> LB); });
+      uint32_t s[9], bi, kbase;
+      if (a.src.load(i, s, bi, kbase, true))
+        for_each_digit<SFID, C>(a.src, s, [&](uint32_t, uint32_t d, uint32_t) { lds_count(cnt, (kbase + d - 1) >> LB); });
     }
   }
   NMX_SYNC();
@@ -291,10 +302,14 @@ template <bool BIG> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_tiles(PartBufs b) 
     b.tab[kTabStride + j] = o2[j];
     b.tab[2 * kTabStride + j] = o3[j];
   }
-  if (t < nhi && c == 0) {  // no tile will ever visit this bin: its buckets are empty, placed at the bin's offset
-    for (uint32_t l = 0; l < b.ps.nlo; l++) {
-      b.start[(t << b.ps.LB) + l] = o2[t];
-      b.end[(t << b.ps.LB) + l] = o2[t];
+  // No tile will ever visit an empty bin: its buckets are empty, placed at the bin's offset.  The block walks the bucket
+  // array with consecutive threads on consecutive buckets (a thread per bin, writing its nlo buckets one by one, was
+  // 0.15 ms of uncoalesced stores for the sparse bucket sets of a fused batch of short vectors).
+  for (uint32_t bin = 0; bin < nhi; bin++) {
+    if (h[bin] != 0) continue;  // block-uniform
+    for (uint32_t l = t; l < b.ps.nlo; l += NMX_BDIM) {
+      b.start[(bin << b.ps.LB) + l] = o2[bin];
+      b.end[(bin << b.ps.LB) + l] = o2[bin];
     }
   }
   if (t == 0) {
@@ -319,8 +334,8 @@ template <int SFID, int C, bool BIG> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_p
     for (uint32_t j = t; j < Cfg::kMaxHi; j += bs) cnt[j] = 0, cur[j] = 0;
     NMX_SYNC();
     const uint32_t i = base + t;
-    uint32_t s[9], bi = 0;
-    const bool live = i < n && a.src.load(i, s, bi, false);
+    uint32_t s[9], bi = 0, kbase = 0;
+    const bool live = i < n && a.src.load(i, s, bi, kbase, false);
     // phase A: this chunk's entries per bin.  With a compile-time width the digits stay in registers for phase B
     // (key | neg << 31, all ones = none); at run-time width they are extracted again.
     uint32_t dig[C ? WinMax<C>::value : 1];
@@ -330,8 +345,8 @@ template <int SFID, int C, bool BIG> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_p
     }
     if (live)
       for_each_digit<SFID, C>(a.src, s, [&](uint32_t w, uint32_t d, uint32_t neg) {
-        lds_count(cnt, (d - 1) >> LB);
-        if constexpr (C != 0) dig[w] = (d - 1) | (neg << 31);
+        lds_count(cnt, (kbase + d - 1) >> LB);
+        if constexpr (C != 0) dig[w] = (kbase + d - 1) | (neg << 31);
       });
     NMX_SYNC();
     block_excl_scan(cnt, lbase, nhi, wtot);
@@ -350,7 +365,7 @@ template <int SFID, int C, bool BIG> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_p
         for (uint32_t w = 0; w < WinMax<C>::value; w++)
           if (dig[w] != 0xffffffffu) place(w, dig[w] & 0x7fffffffu, dig[w] >> 31);
       } else {
-        for_each_digit<SFID, C>(a.src, s, [&](uint32_t w, uint32_t d, uint32_t neg) { place(w, d - 1, neg); });
+        for_each_digit<SFID, C>(a.src, s, [&](uint32_t w, uint32_t d, uint32_t neg) { place(w, kbase + d - 1, neg); });
       }
     }
     NMX_SYNC();

@@ -30,6 +30,11 @@ struct MsmArgs {
   uint32_t seg_min_total = 1u << 22;  // segment-balanced accumulate (msm_seg.hpp) from this many sorted entries on
   uint32_t seg_min_len = 8;           // shortest segment a lane is given
   uint32_t accum_prefetch = 1;        // gathers in flight ahead of the addition (AccumSegFn PF)
+  // fused batch over the key's tables (DigitSrc::batch_*): n = sum of the vector lengths, `scalars` unused;
+  // wsum_host[j] receives vector j's sum
+  uint32_t batch_k = 0;
+  const uint32_t* batch_off = nullptr;
+  const uint32_t* const* batch_vec = nullptr;
 };
 
 inline uint32_t ilog2_u32(uint32_t v) {
@@ -81,12 +86,17 @@ inline uint32_t choose_c_precomp(uint32_t n_key, uint32_t bits) {
   return settle_c(c, 8, 16, bits);
 }
 
-inline MsmShape make_shape(uint32_t n, uint32_t bits, uint32_t force_c, uint32_t pre_c = 0) {
+inline uint32_t batch_sets(uint32_t k) {  // bucket sets of a fused batch of k vectors: the next power of two
+  uint32_t p = 1;
+  while (p < k) p <<= 1;
+  return p;
+}
+inline MsmShape make_shape(uint32_t n, uint32_t bits, uint32_t force_c, uint32_t pre_c = 0, uint32_t batch_k = 0) {
   MsmShape sh;
   sh.n = n;
   sh.c = pre_c ? pre_c : (force_c ? force_c : choose_c(n, bits));
   sh.W = (bits + 1 + sh.c - 1) / sh.c;
-  sh.WB = pre_c ? 1 : sh.W;
+  sh.WB = pre_c ? (batch_k ? batch_sets(batch_k) : 1) : sh.W;
   sh.M = 1u << (sh.c - 1);
   sh.nbuckets = sh.WB * sh.M;
   sh.total = n * sh.W;
@@ -111,7 +121,7 @@ template <class BE, int FID, int SFID>
 MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsum_host,
                       uint32_t* err_host) {
   const uint32_t bits = a.u64_bits ? a.u64_bits : scalar_bits;
-  MsmShape sh = make_shape(a.n, bits, a.force_c, a.pre_stride ? a.pre_c : 0);
+  MsmShape sh = make_shape(a.n, bits, a.force_c, a.pre_stride ? a.pre_c : 0, a.pre_stride ? a.batch_k : 0);
   if (a.force_lmax) sh.lmax = a.force_lmax;
   const size_t total = sh.total;
   const uint32_t heavy_cap = (uint32_t)(total / sh.lmax) + 1;
@@ -140,6 +150,9 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
   src.pre_offset = a.pre_offset;
   src.gather = a.gather;
   src.all_ones = a.all_ones;
+  src.batch_k = a.pre_stride ? a.batch_k : 0;
+  src.batch_off = a.batch_off;
+  src.batch_vec = a.batch_vec;
 
   uint32_t* vals1;
   if (part) {
@@ -173,8 +186,10 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
       be.mark("sort");
       be.launch_kernel(part, pb.ps.grid1, pb.ps.bs1, pa);
     };
-    if (pb.ps.big) {
+    if (pb.ps.big) {  // c = 20 tables, or the bucket sets of a fused batch over c = 15 / 16 tables
       if (sh.c == 20) level1(&k_hist_hi<SFID, 20, true>, &k_part_hi<SFID, 20, true>);
+      else if (sh.c == 16) level1(&k_hist_hi<SFID, 16, true>, &k_part_hi<SFID, 16, true>);
+      else if (sh.c == 15) level1(&k_hist_hi<SFID, 15, true>, &k_part_hi<SFID, 15, true>);
       else level1(&k_hist_hi<SFID, 0, true>, &k_part_hi<SFID, 0, true>);
       be.launch_kernel(&k_hist_lo<true>, pb.ps.tiles_cap, kTileThreads, pb);
       be.launch_kernel(&k_part_lo<true>, pb.ps.tiles_cap, kTileThreads, pb);

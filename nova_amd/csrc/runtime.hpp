@@ -130,6 +130,7 @@ struct Global {
   uint32_t seg_lanes_override = 0;    // env NMX_TUNE_SEG_LANES (0: the kernel's resident lane count)
   uint32_t no_quad_final = 0;         // env NMX_TUNE_NO_QUAD_FINAL
   uint32_t accum_prefetch = 0;        // env NMX_TUNE_ACCUM_PF / option accum_prefetch: 0 = by table size, 1, 2
+  uint32_t no_batch_fuse = 0;         // env NMX_TUNE_NO_BATCH_FUSE / option no_batch_fuse: every vector of a batch runs alone
 };
 extern Global& G;                // capi.hip (heap singleton, never destroyed)
 void prof_store(const float* ms, int n);   // last call's stage times of this thread (capi.hip)
@@ -312,6 +313,12 @@ struct MsmCall {
   bool bases_clean = false;  // the key holds no identity point
 };
 
+// one vector of a fused batch (msm_key_batch): n field scalars, host or device as the shared MsmCall says
+struct BatchItem {
+  const void* scalars;
+  size_t n;
+};
+
 // Fills the freshly allocated device key (n x 64 raw bytes) -- nullptr: one hipMemcpy from `src`; key files stream
 // through pinned staging buffers (keyfile.hip)
 using BaseFill = std::function<void(void* d_dst, hipStream_t stream)>;
@@ -320,6 +327,12 @@ struct CurveOps {
   // out = sum scalars[i] * key[offset + i], i < n, through the key's window tables when it has them
   void (*msm_key)(Ctx&, const BaseSet&, size_t offset, size_t n, const MsmCall&, uint32_t flags, uint8_t* out,
                   uint8_t* inf);
+  // Fused batch (a7, traits.rs:82-90 / hyperkzg.rs:593-612): out[j] = sum items[j].scalars[i] * key[offset + i], all k
+  // vectors in ONE pipeline run over the key's tables (one bucket set per vector).  batch_limit: how many vectors one
+  // run can take for this key (0: the key has no tables or its window width leaves no key bits for vector ids).
+  void (*msm_key_batch)(Ctx&, const BaseSet&, size_t offset, const BatchItem* items, size_t k, const MsmCall& shared,
+                        uint32_t flags, uint8_t* out64, uint8_t* inf);
+  uint32_t (*batch_limit)(const BaseSet&);
   // msm_key(v) + h * r
   void (*commit)(Ctx&, const BaseSet&, size_t n, const MsmCall&, const void* h_xy64, const void* r, uint32_t flags,
                  uint8_t* out, uint8_t* inf);

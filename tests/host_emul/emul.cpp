@@ -138,6 +138,63 @@ static int emul_msm_t(const uint8_t* scalars, const uint8_t* bases_xy64, size_t 
   return 0;
 }
 
+// fused batch over the tables of one key (MsmArgs::batch_*): k vectors, vector j over key[offset .. offset + lens[j])
+template <int CID>
+static int emul_msm_batch_t(const uint8_t* const* vecs, const size_t* lens, size_t k, const uint8_t* key_xy64, size_t n_key,
+                            size_t offset, uint32_t pre_c, uint32_t scalars_mont, uint8_t* out, uint8_t* inf) {
+  using C = CurveT<CID>;
+  constexpr int BF = C::BF, SF = C::SF;
+  const uint32_t Wt = (FpParams<SF>::BITS + 1 + pre_c - 1) / pre_c;
+  std::vector<AffineW> b(n_key * Wt);
+  for (size_t i = 0; i < n_key; i++) {
+    Affine<BF> a;
+    a.x = fp_from_bytes<BF>(key_xy64 + 64 * i);
+    a.y = fp_from_bytes<BF>(key_xy64 + 64 * i + 32);
+    if (!a.is_identity()) {
+      a.x = a.x.to_internal().canon();
+      a.y = a.y.to_internal().canon();
+    }
+    a.store(b[i]);
+  }
+  {
+    HostEmulBackend pb;
+    PrecompFn<BF> pf{b.data(), (uint32_t)n_key, pre_c, Wt};
+    pb.launch(pf, (uint32_t)n_key);
+  }
+  std::vector<uint32_t> off(k + 1, 0);
+  std::vector<const uint32_t*> ptrs(k);
+  for (size_t j = 0; j < k; j++) {
+    off[j + 1] = off[j] + (uint32_t)lens[j];
+    ptrs[j] = (const uint32_t*)vecs[j];
+  }
+  XYZZW wsum[260];
+  for (size_t j = 0; j < 260; j++) XYZZ<BF>::identity().store(wsum[j]);
+  if (off[k]) {
+    MsmArgs a;
+    a.scalars = nullptr;
+    a.bases = b.data();
+    a.n = off[k];
+    a.scalars_mont = scalars_mont;
+    a.u64_bits = 0;
+    a.force_c = 0;
+    a.pre_stride = (uint32_t)n_key;
+    a.pre_offset = (uint32_t)offset;
+    a.pre_c = pre_c;
+    a.seg_min_total = g_seg_min_total;
+    a.seg_min_len = 3;
+    a.batch_k = (uint32_t)k;
+    a.batch_off = off.data();
+    a.batch_vec = ptrs.data();
+    HostEmulBackend be;
+    uint32_t err = 0;
+    MsmShape sh = msm_pipeline<HostEmulBackend, BF, SF>(be, a, FpParams<SF>::BITS, wsum, &err);
+    if (err) return -(int)err - 100;
+    if (!partition_supported(sh, true)) return -3;  // the test means to exercise the partition's batch keys
+  }
+  for (size_t j = 0; j < k; j++) xyzz_to_xy64<BF>(XYZZ<BF>::load(wsum[j]), out + 64 * j, inf + j);
+  return 0;
+}
+
 // inputs: 256-bit integers (any value the test wants, e.g. up to 8p); outputs canonicalised
 template <int FID> static void fp_op_t(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
   using F = Fp<FID>;
@@ -314,6 +371,17 @@ int emul_msm_precomp(int curve, const uint8_t* scalars, const uint8_t* key_xy64,
     case 1: return emul_msm_t<1>(scalars, key_xy64, n, u64_bits, u64_mode, 0, 0, out, inf, pre_c, n_key, offset);
     case 2: return emul_msm_t<2>(scalars, key_xy64, n, u64_bits, u64_mode, 0, 0, out, inf, pre_c, n_key, offset);
     case 3: return emul_msm_t<3>(scalars, key_xy64, n, u64_bits, u64_mode, 0, 0, out, inf, pre_c, n_key, offset);
+  }
+  return -1;
+}
+
+int emul_msm_batch(int curve, const uint8_t* const* vecs, const size_t* lens, size_t k, const uint8_t* key_xy64,
+                   size_t n_key, size_t offset, uint32_t pre_c, uint32_t scalars_mont, uint8_t* out, uint8_t* inf) {
+  switch (curve) {
+    case 0: return emul_msm_batch_t<0>(vecs, lens, k, key_xy64, n_key, offset, pre_c, scalars_mont, out, inf);
+    case 1: return emul_msm_batch_t<1>(vecs, lens, k, key_xy64, n_key, offset, pre_c, scalars_mont, out, inf);
+    case 2: return emul_msm_batch_t<2>(vecs, lens, k, key_xy64, n_key, offset, pre_c, scalars_mont, out, inf);
+    case 3: return emul_msm_batch_t<3>(vecs, lens, k, key_xy64, n_key, offset, pre_c, scalars_mont, out, inf);
   }
   return -1;
 }

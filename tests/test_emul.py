@@ -37,6 +37,9 @@ def emul():
     L.emul_fp_op.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
     L.emul_partition_check.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                        ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+    L.emul_msm_batch.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
+                                 ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p,
+                                 ctypes.c_void_p]
     return L
 
 
@@ -308,3 +311,58 @@ def test_emul_two_pass_tables_match_one_pass(emul, c):
     key[20] = 0
     for width in (8, 16, 20):
         assert emul.emul_precomp_check(c.cid, key.ctypes.data_as(ctypes.c_void_p), n, width) == 0, (c.name, width)
+
+
+def run_batch(L, cid, vecs, key, n_key, offset, pre_c, mont=0):
+    k = len(vecs)
+    arrs = [np.ascontiguousarray(v).reshape(-1, 32) for v in vecs]
+    ptrs = (ctypes.c_void_p * k)(*[a.ctypes.data if len(a) else None for a in arrs])
+    lens = (ctypes.c_size_t * k)(*[len(a) for a in arrs])
+    kk = np.ascontiguousarray(key)
+    out = np.zeros((k, 64), np.uint8)
+    inf = np.zeros(k, np.uint8)
+    rc = L.emul_msm_batch(cid, ptrs, lens, k, kk.ctypes.data, n_key, offset, pre_c, mont, out.ctypes.data, inf.ctypes.data)
+    return rc, [(out[j].tobytes(), int(inf[j])) for j in range(k)]
+
+
+@pytest.mark.parametrize("seg", [False, True], ids=["tasks", "segments"])
+def test_emul_fused_batch(emul, seg):
+    """a7 as ONE pipeline run (MsmArgs::batch_*): k ragged vectors over prefixes / interior slices of one key's tables, a
+    bucket set per vector -- the partition's keys carry the vector id above the bucket bits (narrow geometry up to 15 key
+    bits, wide above; compile-time widths 8 / 15 / 16 and a run-time one), empty vectors, single pairs, an identity point
+    in the key, every scalar set, Montgomery-form scalars.  Each vector against the oracle's MSM over its own prefix."""
+    if seg:
+        emul.emul_set_seg_min_total(0)
+        emul.emul_set_seg_lanes(701)
+    try:
+        c = R.BN254_G1
+        n_key = 330
+        key = cref.sequential_bases(c, 77, n_key).copy()
+        key[5] = 0
+        kinds = ["random", "equal", "zero_rm1", "u1", "pm_small"]
+        cases = [(8, 0, [330, 37, 0, 1, 300]),            # 5 vectors -> 8 bucket sets, 10 key bits
+                 (8, 7, [2, 1, 0, 0, 3] * 40),            # 200 tiny vectors -> 256 sets, 15 key bits
+                 (16, 0, [150, 20, 1]),                   # c = 16 tables: 17 key bits, the wide geometry
+                 (15, 3, [100, 64, 32, 16, 8]),           # c = 15: 17 windows, 960-thread first-level blocks
+                 (11, 0, [90, 45]),                       # run-time window width
+                 (16, 1, [40] * 16)]                      # 16 sets over c = 16: all 19 key bits
+        for pre_c, off, lens in (cases[:1] + cases[2:4] if seg else cases):
+            vecs = [util.scalar_set(c.cid, n, kinds[j % len(kinds)], seed=100 + j) if n else np.zeros((0, 32), np.uint8)
+                    for j, n in enumerate(lens)]
+            rc, got = run_batch(emul, c.cid, vecs, key, n_key, off, pre_c)
+            assert rc == 0, (pre_c, off, lens, rc)
+            for j, n in enumerate(lens):
+                exp = cref.msm(c.cid, vecs[j], key[off:off + n], n) if n else (bytes(64), 1)
+                assert got[j] == exp, (seg, pre_c, off, lens, j)
+        # Montgomery-form scalars on another curve
+        cc = R.PALLAS
+        key = cref.sequential_bases(cc, 9, 120)
+        vecs = [util.scalar_set(cc.cid, n, "random", seed=7 + n) for n in (120, 60, 30)]
+        mont = [util.to_mont_scalars(cc.cid, v) for v in vecs]
+        rc, got = run_batch(emul, cc.cid, mont, key, 120, 0, 8, mont=1)
+        assert rc == 0
+        for j, v in enumerate(vecs):
+            assert got[j] == cref.msm(cc.cid, v, key[:len(v)], len(v))
+    finally:
+        emul.emul_set_seg_min_total(1 << 21)
+        emul.emul_set_seg_lanes(37)

@@ -127,3 +127,21 @@ def affine_to_partial(p_mod, xy64, is_inf):
     x = int.from_bytes(xy64[:32], "little")
     y = int.from_bytes(xy64[32:64], "little")
     return b"".join((v * R_INTERNAL % p_mod).to_bytes(32, "little") for v in (x, y, 1, 1))
+
+
+def to_mont_scalars(cid, sc):
+    """Scalars (n x 32 canonical LE) in the in-memory layout of halo2curves: x * 2^256 mod r as LE limbs."""
+    from oracle import pyref as R
+    r = [c for c in R.CURVES.values() if c.cid == cid][0].r
+    rows = np.ascontiguousarray(sc).reshape(-1, 32)
+    out = b"".join(R.fe_to_le32((int.from_bytes(bytes(row), "little") << 256) % r) for row in rows)
+    return np.frombuffer(out, np.uint8).reshape(-1, 32).copy()
+
+
+def to_mont_bases(cid, xy64):
+    """Affine points (n x 64 canonical x || y) with both coordinates as x * 2^256 mod p; the identity (0, 0) stays (0, 0)."""
+    from oracle import pyref as R
+    p = [c for c in R.CURVES.values() if c.cid == cid][0].p
+    rows = np.ascontiguousarray(xy64).reshape(-1, 64)
+    out = b"".join(R.fe_to_le32((int.from_bytes(bytes(row[j:j + 32]), "little") << 256) % p) for row in rows for j in (0, 32))
+    return np.frombuffer(out, np.uint8).reshape(-1, 64).copy()
