@@ -113,6 +113,25 @@ def test_more_vectors_than_one_run_takes(nmx):
     ck.close()
 
 
+def test_fused_run_on_the_segment_path(nmx):
+    """Long vectors fused: 7.8 M sorted entries take the segment-balanced accumulate (msm_seg.hpp) over 8 bucket sets
+    (2^18 buckets: FinalSegFn one lane per bucket), witness-like and skewed scalars included."""
+    c = R.BN254_G1
+    n = 1 << 18
+    host = cref.sequential_bases(c, 3, n)
+    ck = nmx.CommitmentKey.from_host(c.cid, host)
+    g = nmx.DlogGroup(c.cid)
+    lens = [n, n >> 1, n >> 2, n >> 3, 5, 0]
+    vecs = [util.random_scalars(c.cid, lens[0], seed=1), util.witness_like(c.cid, lens[1], seed=2),
+            util.scalar_set(c.cid, lens[2], "equal", seed=3), util.scalar_set(c.cid, lens[3], "zero_rm1", seed=4),
+            util.random_scalars(c.cid, 5, seed=5), np.zeros((0, 32), np.uint8)]
+    prep = cref.Prepared(c.cid, host, n)
+    exp = [prep.msm(np.ascontiguousarray(v), len(v)) if len(v) else (bytes(64), 1) for v in vecs]
+    got, fused, calls = fused_delta(lambda: [as_pair(x) for x in g.batch_vartime_multiscalar_mul(vecs, ck)])
+    assert got == exp and fused == 1 and calls == 6
+    ck.close()
+
+
 def test_out_of_range_scalar_fails_the_batch_and_leaves_out_untouched(nmx):
     c = R.BN254_G1
     n = 2048
