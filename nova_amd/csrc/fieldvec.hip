@@ -265,6 +265,70 @@ template <int FID> struct HornerFixFn {
   }
 };
 
+// Top level for long inputs: the chunk-per-lane kernels above write every local value 512 B away from its neighbour lane's
+// (32 of the 128 bytes of a line per store) and read it back in the fix-up -- 2 GB of traffic and mostly partial lines at
+// 2^24.  Here a lane holds its 8 coefficients in registers (all 16 loads issued before the dependent chain: both of its
+// 128-byte lines are consumed while they are in flight), the first pass keeps only the chunk head, the carries come from
+// the recursion above run over the heads at u^8, and the second pass re-walks the chunk from the carry and stores its
+// 256 bytes back to back: 96 B and 2 multiplications per coefficient, no power table.  Applied level after level while a
+// level has >= 2^15 elements (K = chunk: 8, or 4 = one 128-byte line per lane); the short levels use the kernels above.
+template <int FID, uint32_t K> struct HornerHeadFn {
+  const uint32_t* f;
+  uint32_t* heads;  // heads[c] = sum_{k < K} f[K c + k] u^k
+  Fp<FID> u;
+  uint32_t n;
+  NMX_HD void operator()(uint32_t c) const {
+    using F = Fp<FID>;
+    const uint32_t lo = c * K, cnt = n - lo < K ? n - lo : K;
+    F t = F::zero();
+    if (cnt == K) {
+      uint32_t w[K][8];
+#pragma unroll
+      for (uint32_t k = 0; k < K; k++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) w[k][j] = f[8 * (size_t)(lo + k) + j];
+#pragma unroll
+      for (uint32_t k = K; k-- > 0;) t = (F::from_words(w[k]) + u * t).norm();
+    } else {
+      for (uint32_t k = cnt; k-- > 0;) t = (ld<FID>(f, lo + k) + u * t).norm();
+    }
+    st<FID>(heads, c, t);
+  }
+};
+template <int FID, uint32_t K> struct HornerWalkFn {
+  const uint32_t* f;
+  const uint32_t* carries;  // carries[c] = global suffix value at the start of chunk c
+  uint32_t* out;
+  Fp<FID> u;
+  uint32_t n, nc;
+  NMX_HD void operator()(uint32_t c) const {
+    using F = Fp<FID>;
+    const uint32_t lo = c * K, cnt = n - lo < K ? n - lo : K;
+    F t = c + 1 < nc ? ld<FID>(carries, c + 1) : F::zero();
+    if (cnt == K) {
+      uint32_t w[K][8];
+#pragma unroll
+      for (uint32_t k = 0; k < K; k++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) w[k][j] = f[8 * (size_t)(lo + k) + j];
+#pragma unroll
+      for (uint32_t k = K; k-- > 0;) {
+        t = (F::from_words(w[k]) + u * t).norm().canon();
+        t.to_words(w[k]);
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < K; k++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) out[8 * (size_t)(lo + k) + j] = w[k][j];
+    } else {
+      for (uint32_t k = cnt; k-- > 0;) {
+        t = (ld<FID>(f, lo + k) + u * t).norm().canon();
+        t.to_words(out + 8 * (size_t)(lo + k));
+      }
+    }
+  }
+};
+
 // ---- host side ---------------------------------------------------------------------------------------
 // launch one functor over n lanes; with profiling on, bracket it with hipEvents on the context's stream
 struct VecIO;
@@ -508,12 +572,18 @@ static void lincomb_t(Ctx& c, const void* const* vecs, const size_t* lens, size_
 
 // Workspace of one suffix-Horner call, carved from the context arena (no allocation on the call path once the arena
 // has grown): per recursion level the chunk heads and carries, plus one 65-entry power table.
+static constexpr size_t kHornerTopMin = 1u << 15;  // shorter inputs are launch-latency-bound either way
 struct HornerArena {
   char* base;
   size_t used = 0;
   static size_t pad(size_t b) { return (b + 255) & ~(size_t)255; }
-  static size_t need(size_t n) {
+  static size_t need(size_t n, bool top) {
     size_t total = 0;
+    while (top && n >= kHornerTopMin) {  // heads + carries of every register-resident level (sized for the smaller chunk)
+      const size_t nc = (n + 3) / 4;
+      total += 2 * pad(nc * 32);
+      n = nc;
+    }
     for (size_t m = n; m > 1;) {
       const size_t nc = (m + kHornerChunk - 1) / kHornerChunk;
       total += 2 * pad(nc * 32) + pad((kHornerChunk + 1) * 32);
@@ -552,9 +622,22 @@ static void horner_t(Ctx& c, const void* f, size_t n, const void* u, uint32_t fl
   // per level: u_l = u^(16^l) and its powers 0..16 -- 16 host multiplications per level, at most 8 levels
   std::vector<F> u_lvl;
   std::vector<uint32_t> pwh;
+  const F u0 = challenge<FID>(u, flags & NMX_SCALARS_MONT);
+  const uint32_t K = G.horner_top == 4 ? 4u : 8u;
+  // register-resident levels: level l works on n_top[l] elements at u_top[l] = u^(K^l); the chunk-per-lane recursion takes
+  // over at the first level shorter than 2^15
+  std::vector<F> u_top;
+  std::vector<size_t> n_top;
+  size_t n_rec = n;
   {
-    F ul = challenge<FID>(u, flags & NMX_SCALARS_MONT);
-    for (size_t m = n;; m = (m + kHornerChunk - 1) / kHornerChunk) {
+    F ul = u0;
+    while (n_rec >= kHornerTopMin && G.horner_top != 1) {
+      u_top.push_back(ul);
+      n_top.push_back(n_rec);
+      for (uint32_t q = K; q > 1; q >>= 1) ul = ul.sqr().canon();
+      n_rec = (n_rec + K - 1) / K;
+    }
+    for (size_t m = n_rec;; m = (m + kHornerChunk - 1) / kHornerChunk) {
       u_lvl.push_back(ul);
       F p = F::one();
       for (uint32_t k = 0; k <= kHornerChunk; k++) {
@@ -567,7 +650,7 @@ static void horner_t(Ctx& c, const void* f, size_t n, const void* u, uint32_t fl
       if (m <= kHornerChunk) break;
     }
   }
-  arena_reserve(c, HornerArena::need(n) + HornerArena::pad(pwh.size() * 4) + (dev ? 0 : 2 * HornerArena::pad(n * 32)));
+  arena_reserve(c, HornerArena::need(n, G.horner_top != 1) + HornerArena::pad(pwh.size() * 4) + (dev ? 0 : 2 * HornerArena::pad(n * 32)));
   HornerArena ws{c.arena};
   uint32_t* d_pw = (uint32_t*)ws.take(pwh.size() * 4);
   HIPCHK(hipMemcpyAsync(d_pw, pwh.data(), pwh.size() * 4, hipMemcpyHostToDevice, c.stream));  // pwh lives to the sync below
@@ -582,7 +665,38 @@ static void horner_t(Ctx& c, const void* f, size_t n, const void* u, uint32_t fl
   const bool prof = G.profiling;
   DeviceBackend be(c, false, prof);
   be.mark("kernel");
-  horner_dev<FID>(c, df, (uint32_t)n, u_lvl, d_pw, 0, dout, ws);
+  {
+    // down: heads of every register-resident level; bottom: the chunk-per-lane recursion; up: re-walk from the carries
+    const size_t L = n_top.size();
+    std::vector<const uint32_t*> src(L + 1);
+    std::vector<uint32_t*> carr(L + 1);
+    src[0] = df;
+    carr[0] = dout;
+    for (size_t l = 0; l < L; l++) {
+      const uint32_t nl = (uint32_t)n_top[l], nc = (nl + K - 1) / K;
+      uint32_t* heads = (uint32_t*)ws.take((size_t)nc * 32);
+      carr[l + 1] = (uint32_t*)ws.take((size_t)nc * 32);
+      src[l + 1] = heads;
+      if (K == 4) {
+        HornerHeadFn<FID, 4> hf{src[l], heads, u_top[l], nl};
+        be.launch(hf, nc);
+      } else {
+        HornerHeadFn<FID, 8> hf{src[l], heads, u_top[l], nl};
+        be.launch(hf, nc);
+      }
+    }
+    horner_dev<FID>(c, src[L], (uint32_t)n_rec, u_lvl, d_pw, 0, carr[L], ws);
+    for (size_t l = L; l-- > 0;) {
+      const uint32_t nl = (uint32_t)n_top[l], nc = (nl + K - 1) / K;
+      if (K == 4) {
+        HornerWalkFn<FID, 4> wf{src[l], carr[l + 1], carr[l], u_top[l], nl, nc};
+        be.launch(wf, nc);
+      } else {
+        HornerWalkFn<FID, 8> wf{src[l], carr[l + 1], carr[l], u_top[l], nl, nc};
+        be.launch(wf, nc);
+      }
+    }
+  }
   be.mark("end");
   if (!dev) HIPCHK(hipMemcpyAsync(out, dout, n * 32, hipMemcpyDeviceToHost, c.stream));
   HIPCHK(hipStreamSynchronize(c.stream));

@@ -130,6 +130,7 @@ struct Global {
   uint32_t seg_lanes_override = 0;    // env NMX_TUNE_SEG_LANES (0: the kernel's resident lane count)
   uint32_t no_quad_final = 0;         // env NMX_TUNE_NO_QUAD_FINAL
   uint32_t accum_prefetch = 0;        // env NMX_TUNE_ACCUM_PF / option accum_prefetch: 0 = by table size, 1, 2
+  uint32_t horner_top = 0;            // env NMX_TUNE_HORNER_TOP / option horner_top: suffix Horner's register-resident levels: 0 / 8 = 8-element chunks, 4, 1 = off
   uint32_t no_batch_fuse = 0;         // env NMX_TUNE_NO_BATCH_FUSE / option no_batch_fuse: every vector of a batch runs alone
 };
 extern Global& G;                // capi.hip (heap singleton, never destroyed)

@@ -150,9 +150,10 @@ def test_eq_mle_spmv_vs_oracle(nmx, fid):
 
 
 @pytest.mark.parametrize("fid", range(4))
-@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 4096, 4097, 300000])
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 4096, 4097, 32767, 32768, 32775, 300000, 300003])
 def test_horner_and_div_by_monomial(nmx, fid, n):
-    """poly_eval + div_by_monomial (hyperkzg.rs:946-1020) as one suffix-Horner pass; chunk boundaries and recursion."""
+    """poly_eval + div_by_monomial (hyperkzg.rs:946-1020) as one suffix-Horner pass; chunk boundaries and recursion, both
+    sides of the 2^15 threshold of the register-resident top level, lengths that are not multiples of its 8-element chunks."""
     import torch
     from nova_amd import fieldvec as fv
     f = C.edge_vectors(fid, n, 3) if n > 5 else C.rand_vec(fid, n, 3)
@@ -160,7 +161,7 @@ def test_horner_and_div_by_monomial(nmx, fid, n):
     exp = cref.suffix_horner(fid, f, n, u)
     assert fv.suffix_horner(fid, f, u).tobytes() == exp
     assert fv.poly_eval(fid, f, u) == exp[:32]
-    if n in (65, 300000):
+    if n in (65, 32775, 300000):
         d = torch.from_numpy(f.copy()).cuda()
         assert fv.div_by_monomial(fid, d, u).cpu().numpy().tobytes() == exp[32:]
     for special in (0, 1):
