@@ -46,11 +46,19 @@ MAD_PEAK_T = 28.8              # measured v_mad_u64_u32 rate, T/s (bench/ubench.
 MADS_PER_MADD_BY_CURVE = {0: 1305, 1: 1305, 2: 1089, 3: 1089}
 
 
+def table_window_bits(n, args):
+    """Window width of the tables of an n-point key: choose_c_precomp (nova_amd/csrc/msm_pipeline.hpp), restated for the
+    operation counts below (the library owns the rule)."""
+    if args.window_bits:
+        return args.window_bits
+    lg = max(n, 2).bit_length() - 1
+    return 20 if lg >= 22 else 17 if lg >= 20 else 16 if lg >= 17 else 15 if lg >= 14 else 8
+
+
 def madds_per_launch(n, args):
     """Mixed additions of one accumulate launch on uniformly random scalars: one per (pair, window)."""
     bits = {0: 254, 1: 254, 2: 255, 3: 255}[args.curve]
-    c = args.window_bits or (20 if n >= (1 << 22) else 16)
-    return n * (-(-(bits + 1) // c))
+    return n * (-(-(bits + 1) // table_window_bits(n, args)))
 
 
 def pmc_valu(args, world):
@@ -242,7 +250,7 @@ def main():
                 "bound": "hbm",
                 # msm_seg.hpp from 2^22 sorted entries on (table path, c <= 20)
                 "kernel": "k_launch<AccumSegFn> (bucket accumulation, segment-balanced)"
-                          if madds_per_launch(n, args) >= (1 << 22) and (args.window_bits or 16) <= 20
+                          if madds_per_launch(n, args) >= (1 << 22) and table_window_bits(n, args) <= 20
                           else "k_launch<AccumFn> (bucket accumulation)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,

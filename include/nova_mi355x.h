@@ -40,7 +40,7 @@ enum {
   NMX_BASES_VALIDATE = 1u << 6,   /* nmx_bases_register*: reject coordinates >= p and points off the curve with
                                      NMX_E_POINT (identity (0,0) passes) -- what read_points enforces on loaded
                                      keys, /root/reference/src/provider/ptau.rs:372-391                            */
-                                /* 2^(c*w) * P_i in HBM (W x the key size; c = 16, W = 16 for keys >= 2^20).    */
+                                /* 2^(c*w) * P_i in HBM (W x the key size; c = 17, W = 15 for keys of 2^20 points).    */
                                 /* MSMs over >= 4096 points of such a key run all windows into one bucket set. */
   NMX_BASES_NOCACHE = 1u << 7,  /* slice-form calls (nmx_msm, nmx_msm_u64, nmx_msm_batch): do not look the base  */
                                 /* array up in / insert it into the slice cache (one-shot arrays)               */
@@ -179,7 +179,7 @@ int nmx_msm_sparse_handle(uint64_t handle, const uint64_t* indices, const void* 
 /* DlogGroupExt::batch_vartime_multiscalar_mul (src/provider/traits.rs:82-90; blitzar override
  * src/provider/blitzar.rs:22-40): k MSMs over one base array, the j-th using bases[..lens[j]]
  * (HyperKZG batch_commit, src/provider/hyperkzg.rs:593-612).  out = k x 64 bytes, out_is_inf = k bytes.
- * The shortest vectors of a batch (up to 16 on a 2^14 .. 2^21-point key, 256 below) run as ONE fused pass over the
+ * The shortest vectors of a batch (up to 32 on a 2^14 .. 2^19-point key, 16 at 2^20 .. 2^21, 256 below 2^14) run as ONE fused pass over the
  * key's window tables with a bucket set per vector; the others run as independent MSMs on concurrent streams. */
 int nmx_msm_batch(int curve, const void* const* scalar_vecs, const size_t* lens, size_t k,
                   const void* bases_xy64, size_t n_bases, uint32_t flags, uint8_t* out, uint8_t* out_is_inf);

@@ -609,7 +609,7 @@ int nmx_msm_sparse_handle(uint64_t handle, const uint64_t* indices, const void* 
 }
 
 // The reference's default is `scalars.par_iter().map(msm)` (traits.rs:82-90).  Here the shortest vectors (as many as the
-// key's window width leaves key bits for: 16 on a 2^17..2^21-point key) are FUSED into one pipeline run over the key's
+// key's window width leaves key bits for: 32 on a 2^14..2^19-point key, 16 at 2^20..2^21) are FUSED into one pipeline run over the key's
 // tables, one bucket set per vector -- an MSM of a few thousand pairs costs ~0.3 ms of dependent point additions
 // whatever its length, and the fused run pays that once (profiles/r02_msm_2p20/batch_fused.txt).  The remaining
 // (longest) vectors and the fused run are jobs taken longest-first by up to kBatchLanes host threads, each leasing its

@@ -17,7 +17,7 @@
 //               occupy the bin's region of the final array), LDS counting sort by low bits -> contiguous run per
 //               bucket (one global cursor per bucket); the first tile of a bin publishes its buckets' [start, end)
 //
-// Traffic at 2^20 pairs / 16 windows: 2 x 32 MB scalars + 84 MB written + 17 MB + 84 MB read + 67 MB written
+// Traffic at 2^20 pairs / 16 windows (c = 16; the c = 17 tables of 2^20-point keys have 15): 2 x 32 MB scalars + 84 MB written + 17 MB + 84 MB read + 67 MB written
 // = 0.32 GB against ~0.94 GB for digits + onesweep + bounds; zero digits are dropped instead of carried to a trash
 // bucket.  Order inside a bucket depends on atomics' arrival order; the bucket SUM does not (group law), and the
 // affine result is canonical, so outputs stay bit-exact.
@@ -26,10 +26,11 @@
 // with; 0 = any width at run time): with constant bit positions the scalar words stay in registers -- indexed
 // dynamically they are promoted to LDS (36 KB per block) -- and the digit loop unrolls to ~10 instructions a window.
 //
-// Two geometries (template parameter BIG): keys of up to 15 bits (c <= 16: every key below 2^22 points) use 256 x 128 bins,
-// 12288-entry chunks, 8192-entry tiles, one byte of low bits per entry and two first-level blocks per CU; keys of up to
-// 19 bits (the c = 20 tables of keys >= 2^22 points) use 1024 x 512 bins, 16384-entry chunks and tiles, two bytes of low
-// bits, one block per CU -- shorter runs per bin (64 B), still one pass per level.
+// Two geometries (template parameter BIG): keys of up to 16 bits (c <= 17: every key below 2^22 points) use 256 x 128 bins
+// (256 x 256 for 16 bits), 12288-entry chunks, 8192-entry tiles, one byte of low bits per entry and two first-level blocks
+// per CU; keys of up to 20 bits (the c = 20 tables of keys >= 2^22 points, the bucket sets of fused batches) use 1024 x 512
+// bins (1024 x 1024 for 20 bits), 16384-entry chunks and tiles, two bytes of low bits, one block per CU -- shorter runs per bin (64 B), still one
+// pass per level.
 //
 // Apart from the wave scan (device only; a plain loop elsewhere) the kernels use block-level primitives only (LDS
 // atomics, __syncthreads): tests/host_emul/simt.hpp runs the same bodies on the CPU, one fiber per thread.
@@ -78,7 +79,7 @@ struct PartShape {
 };
 template <bool BIG> struct PartCfg {
   static constexpr uint32_t kMaxHi = BIG ? 1024 : 256;    // first-level bins
-  static constexpr uint32_t kMaxLo = BIG ? 512 : 128;     // buckets per bin
+  static constexpr uint32_t kMaxLo = BIG ? 1024 : 256;    // buckets per bin (narrow: 128 up to 15 key bits, 256 for 16; wide: 512, 1024 for 20)
   static constexpr uint32_t kStage = BIG ? 16384 : 12288; // entries staged in LDS per first-level chunk
   static constexpr uint32_t kTile = BIG ? 16384 : 8192;   // entries per second-level tile
   static constexpr uint32_t kTilePer = kTile / 1024;      // consecutive entries per thread of a tile
@@ -90,15 +91,15 @@ static constexpr uint32_t kBinAlign = 16;
 static constexpr uint32_t kTabStride = 1025;  // tab = 3 arrays of nhi + 1 <= 1025 words
 
 // Geometry for a table-mode shape; false when the hand-written partition does not cover it (the generic sort path runs).
-// Keys are bucket indices in [0, WB * M): c - 1 bits for one vector, up to 19 with the bucket sets of a fused batch.
+// Keys are bucket indices in [0, WB * M): c - 1 bits for one vector, up to 20 with the bucket sets of a fused batch.
 inline bool make_part_shape(const MsmShape& sh, bool table_mode, PartShape* out) {
   if (!(table_mode && sh.c >= 2 && sh.c <= 20 && sh.WB >= 1 && (sh.WB & (sh.WB - 1)) == 0)) return false;
   uint32_t kb = sh.c - 1;
   for (uint32_t v = sh.WB; v > 1; v >>= 1) kb++;
-  if (kb > 19) return false;
+  if (kb > 20) return false;
   PartShape p;
-  p.big = kb > 15 ? 1u : 0u;
-  p.LB = p.big ? 9u : (kb < 7 ? kb : 7);
+  p.big = kb > 16 ? 1u : 0u;
+  p.LB = p.big ? (kb == 20 ? 10u : 9u) : (kb < 7 ? kb : (kb == 16 ? 8u : 7u));
   p.HB = kb - p.LB;
   p.nlo = 1u << p.LB;
   p.nhi = 1u << p.HB;
@@ -303,13 +304,14 @@ template <bool BIG> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_tiles(PartBufs b) 
     b.tab[2 * kTabStride + j] = o3[j];
   }
   // No tile will ever visit an empty bin: its buckets are empty, placed at the bin's offset.  The block walks the bucket
-  // array with consecutive threads on consecutive buckets (a thread per bin, writing its nlo buckets one by one, was
-  // 0.15 ms of uncoalesced stores for the sparse bucket sets of a fused batch of short vectors).
-  for (uint32_t bin = 0; bin < nhi; bin++) {
-    if (h[bin] != 0) continue;  // block-uniform
-    for (uint32_t l = t; l < b.ps.nlo; l += NMX_BDIM) {
-      b.start[(bin << b.ps.LB) + l] = o2[bin];
-      b.end[(bin << b.ps.LB) + l] = o2[bin];
+  // array with consecutive threads on consecutive buckets (a thread per bin writing its nlo buckets one by one was 0.15 ms
+  // of uncoalesced stores for the sparse bucket sets of a fused batch of short vectors; a serial walk over the bins cost
+  // 18 us of dependent LDS reads on every call).
+  for (uint32_t k = t; k < (nhi << b.ps.LB); k += NMX_BDIM) {
+    const uint32_t bin = k >> b.ps.LB;
+    if (h[bin] == 0) {
+      b.start[k] = o2[bin];
+      b.end[k] = o2[bin];
     }
   }
   if (t == 0) {
@@ -407,12 +409,12 @@ template <bool BIG> NMX_DEV void load_lo(const void* base, size_t e, uint32_t (&
     uint64_t w;
     memcpy(&w, __builtin_assume_aligned(static_cast<const uint8_t*>(base) + e, 8), 8);
 #pragma unroll
-    for (uint32_t k = 0; k < 8; k++) lo[k] = (uint32_t)(w >> (8 * k)) & 0x7fu;
+    for (uint32_t k = 0; k < 8; k++) lo[k] = (uint32_t)(w >> (8 * k)) & 0xffu;
   } else {
     uint16_t w[16];
     memcpy(w, __builtin_assume_aligned(static_cast<const uint16_t*>(base) + e, 16), 32);
 #pragma unroll
-    for (uint32_t k = 0; k < 16; k++) lo[k] = w[k] & 0x1ffu;
+    for (uint32_t k = 0; k < 16; k++) lo[k] = w[k] & 0x3ffu;
   }
 }
 

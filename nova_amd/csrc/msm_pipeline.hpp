@@ -75,6 +75,9 @@ inline uint32_t choose_c(uint32_t n, uint32_t bits) {
 // (profiles/r01_msm_2p20/window_width_sweep.txt for >= 2^20; profiles/r02_msm_2p20/window_width_sweep_partition.txt for
 // the smaller keys, re-swept with the hand-written partition, whose cost no longer steps with the key width):
 //   >= 2^22 points  c = 20   13 windows instead of 16: -19 % mixed additions; 2^19 buckets need that many points
+//   >= 2^20         c = 17   15 windows instead of 16: -6 % mixed additions for one more reduction level; the 16-bit keys
+//                            still take the narrow partition geometry (2^20: 1.71-1.74 ms against 1.77-1.78 at c = 16,
+//                            2^21: 2.98 against 3.11; 2^19: a tie -- profiles/r02_msm_2p20/window_width_sweep_final.txt)
 //   >= 2^17         c = 16   2^15 buckets (2^17: 0.503 ms against 0.515 at c = 15, 0.683 at c = 8)
 //   >= 2^14         c = 15   one level less in the (latency-bound) reduction tree (2^15: 0.373 against 0.410 at c = 8;
 //                            2^16: 0.415 against 0.438 at c = 16)
@@ -82,6 +85,7 @@ inline uint32_t choose_c(uint32_t n, uint32_t bits) {
 inline uint32_t choose_c_precomp(uint32_t n_key, uint32_t bits) {
   uint32_t lg = ilog2_u32(n_key < 2 ? 2 : n_key);
   if (lg >= 22) return 20;
+  if (lg >= 20 && bits > 64) return 17;
   const int c = lg >= 17 ? 16 : lg >= 14 ? 15 : 8;
   return settle_c(c, 8, 16, bits);
 }
@@ -186,8 +190,9 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
       be.mark("sort");
       be.launch_kernel(part, pb.ps.grid1, pb.ps.bs1, pa);
     };
-    if (pb.ps.big) {  // c = 20 tables, or the bucket sets of a fused batch over c = 15 / 16 tables
+    if (pb.ps.big) {  // c = 20 tables, or the bucket sets of a fused batch over c = 15 / 16 / 17 tables
       if (sh.c == 20) level1(&k_hist_hi<SFID, 20, true>, &k_part_hi<SFID, 20, true>);
+      else if (sh.c == 17) level1(&k_hist_hi<SFID, 17, true>, &k_part_hi<SFID, 17, true>);
       else if (sh.c == 16) level1(&k_hist_hi<SFID, 16, true>, &k_part_hi<SFID, 16, true>);
       else if (sh.c == 15) level1(&k_hist_hi<SFID, 15, true>, &k_part_hi<SFID, 15, true>);
       else level1(&k_hist_hi<SFID, 0, true>, &k_part_hi<SFID, 0, true>);
@@ -195,6 +200,7 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
       be.launch_kernel(&k_part_lo<true>, pb.ps.tiles_cap, kTileThreads, pb);
     } else {
       switch (sh.c) {
+        case 17: level1(&k_hist_hi<SFID, 17, false>, &k_part_hi<SFID, 17, false>); break;
         case 16: level1(&k_hist_hi<SFID, 16, false>, &k_part_hi<SFID, 16, false>); break;
         case 15: level1(&k_hist_hi<SFID, 15, false>, &k_part_hi<SFID, 15, false>); break;
         case 8: level1(&k_hist_hi<SFID, 8, false>, &k_part_hi<SFID, 8, false>); break;

@@ -1,0 +1,8 @@
+cd $GRAFT_REPO_ROOT
+timeout 600 python -m pytest tests/test_gpu_pipeline_variants.py tests/test_gpu_batch_fused.py tests/test_gpu_large.py -x -q 2>&1 | tail -3
+for rep in 1 2; do
+for lg in 19 20 21; do for c in 16 17; do
+  timeout 600 python bench.py --log2n $lg --window-bits $c --steps 10 --warmup 3 --no-extras --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('2^$lg c=$c', round(d['ms_per_step'],3), 'ms', d['stages_ms'])"
+done; done; done

@@ -259,11 +259,14 @@ static int partition_check(const uint8_t* scalars, size_t n, uint32_t c, uint32_
   const uint32_t cc = ct_width ? c : 0;  // compile-time-width instantiation (when there is one) or the run-time one
   if (pb.ps.big) {
     if (cc == 20) l1(&k_hist_hi<SF, 20, true>, &k_part_hi<SF, 20, true>);
+    else if (cc == 16) l1(&k_hist_hi<SF, 16, true>, &k_part_hi<SF, 16, true>);
+    else if (cc == 15) l1(&k_hist_hi<SF, 15, true>, &k_part_hi<SF, 15, true>);
     else l1(&k_hist_hi<SF, 0, true>, &k_part_hi<SF, 0, true>);
     be.launch_kernel(&k_hist_lo<true>, pb.ps.tiles_cap, kTileThreads, pb);
     be.launch_kernel(&k_part_lo<true>, pb.ps.tiles_cap, kTileThreads, pb);
   } else {
-    if (cc == 16) l1(&k_hist_hi<SF, 16, false>, &k_part_hi<SF, 16, false>);
+    if (cc == 17) l1(&k_hist_hi<SF, 17, false>, &k_part_hi<SF, 17, false>);
+    else if (cc == 16) l1(&k_hist_hi<SF, 16, false>, &k_part_hi<SF, 16, false>);
     else if (cc == 15) l1(&k_hist_hi<SF, 15, false>, &k_part_hi<SF, 15, false>);
     else if (cc == 8) l1(&k_hist_hi<SF, 8, false>, &k_part_hi<SF, 8, false>);
     else l1(&k_hist_hi<SF, 0, false>, &k_part_hi<SF, 0, false>);

@@ -345,7 +345,8 @@ def test_emul_fused_batch(emul, seg):
                  (16, 0, [150, 20, 1]),                   # c = 16 tables: 17 key bits, the wide geometry
                  (15, 3, [100, 64, 32, 16, 8]),           # c = 15: 17 windows, 960-thread first-level blocks
                  (11, 0, [90, 45]),                       # run-time window width
-                 (16, 1, [40] * 16)]                      # 16 sets over c = 16: all 19 key bits
+                 (16, 1, [40] * 16),                      # 16 sets over c = 16: 19 key bits
+                 (17, 2, [25] * 9 + [0, 3])]              # 11 -> 16 sets over c = 17: all 20 key bits (1024 x 1024 bins)
         for pre_c, off, lens in (cases[:1] + cases[2:4] if seg else cases):
             vecs = [util.scalar_set(c.cid, n, kinds[j % len(kinds)], seed=100 + j) if n else np.zeros((0, 32), np.uint8)
                     for j, n in enumerate(lens)]

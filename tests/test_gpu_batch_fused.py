@@ -46,7 +46,7 @@ def test_hyperkzg_batch_shape(nmx, lg):
     exp = expected(c, vecs, host)
     got, fused, calls = fused_delta(lambda: [as_pair(x) for x in g.batch_vartime_multiscalar_mul(vecs, ck)])
     assert got == exp
-    assert fused == {10: 1, 15: 1, 17: 2}[lg]   # 11 vectors in one run; 17 -> 16 + 1 alone; 18 -> 16 + 2
+    assert fused == 1   # 11, 17 and 18 vectors: one run each (a c = 15 / 16 key takes 32 vectors per run)
     assert calls == len(vecs)
     assert _lib.lib().nmx_set_option(b"no_batch_fuse", 1) == 0
     try:
@@ -91,7 +91,7 @@ def test_ragged_sets_identity_points_and_layouts(nmx, c):
 
 
 def test_more_vectors_than_one_run_takes(nmx):
-    """A c = 16 key leaves 4 key bits for vector ids: 40 vectors -> fused runs of 16, 16 and 8; a c = 8 key takes 256:
+    """A c = 16 key leaves 5 key bits for vector ids: 40 vectors -> fused runs of 32 and 8; a c = 8 key takes 256:
     300 tiny vectors -> 256 + 44."""
     c = R.BN254_G1
     g = nmx.DlogGroup(c.cid)
@@ -101,7 +101,7 @@ def test_more_vectors_than_one_run_takes(nmx):
     lens = [(j * 7919) % 5000 + 1 for j in range(40)]
     vecs = [util.random_scalars(c.cid, m, seed=900 + j) for j, m in enumerate(lens)]
     got, fused, calls = fused_delta(lambda: [as_pair(x) for x in g.batch_vartime_multiscalar_mul(vecs, ck)])
-    assert got == expected(c, vecs, host) and fused == 3 and calls == 40
+    assert got == expected(c, vecs, host) and fused == 2 and calls == 40
     ck.close()
     n = 512
     host = cref.sequential_bases(c, 6, n)
