@@ -288,9 +288,12 @@ template <int SFID, int C, bool BIG> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_h
 // across the curve TUs.)
 template <bool BIG> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_tiles(PartBufs b) {
   using Cfg = PartCfg<BIG>;
-  NMX_LDS uint32_t h[1024], al[1024], tl[1024], o1[1025], o2[1025], o3[1025], wtot[16];
+  NMX_LDS uint32_t h[1024], al[1024], tl[1024], o1[1025], o2[1025], o3[1025], wtot[16], any_empty;
   const uint32_t t = NMX_TID, nhi = b.ps.nhi;
   const uint32_t c = t < nhi ? b.hist_hi[t] : 0;
+  if (t == 0) any_empty = 0;
+  NMX_SYNC();
+  if (t < nhi && c == 0) any_empty = 1;  // (same value from every writer)
   h[t] = c;
   al[t] = (c + kBinAlign - 1) & ~(kBinAlign - 1);
   tl[t] = (c + Cfg::kTile - 1) / Cfg::kTile;
@@ -307,7 +310,7 @@ template <bool BIG> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_tiles(PartBufs b) 
   // array with consecutive threads on consecutive buckets (a thread per bin writing its nlo buckets one by one was 0.15 ms
   // of uncoalesced stores for the sparse bucket sets of a fused batch of short vectors; a serial walk over the bins cost
   // 18 us of dependent LDS reads on every call).
-  for (uint32_t k = t; k < (nhi << b.ps.LB); k += NMX_BDIM) {
+  for (uint32_t k = t; any_empty && k < (nhi << b.ps.LB); k += NMX_BDIM) {  // uniform random scalars: no empty bin, no walk
     const uint32_t bin = k >> b.ps.LB;
     if (h[bin] == 0) {
       b.start[k] = o2[bin];
