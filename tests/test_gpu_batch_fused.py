@@ -113,6 +113,30 @@ def test_more_vectors_than_one_run_takes(nmx):
     ck.close()
 
 
+@pytest.mark.parametrize("width", [17, 20])
+def test_fused_runs_on_wide_tables(nmx, width):
+    """Keys of 2^20+ points carry c = 17 (16 vectors per run, 20 key bits: 1024 x 1024 bins) or c = 20 tables (2 per run);
+    forced here on a 2^13-point key so the oracle stays cheap.  7 vectors -> one run at c = 17; 2 + 2 + 2 + 1 at c = 20."""
+    L = _lib.lib()
+    c = R.BN254_G1
+    n = 1 << 13
+    host = cref.sequential_bases(c, 99, n).copy()
+    host[4000] = 0
+    assert L.nmx_set_window_bits(width) == 0
+    try:
+        ck = nmx.CommitmentKey.from_host(c.cid, host)
+        g = nmx.DlogGroup(c.cid)
+        lens = [n, n - 1, 5000, 4097, 300, 1, 0]
+        kinds = ["random", "zero_rm1", "equal", "pm_small", "random", "random", "random"]
+        vecs = [util.scalar_set(c.cid, m, kinds[j], seed=70 + j) if m else np.zeros((0, 32), np.uint8) for j, m in enumerate(lens)]
+        got, fused, calls = fused_delta(lambda: [as_pair(x) for x in g.batch_vartime_multiscalar_mul(vecs, ck)])
+        assert got == expected(c, vecs, host)
+        assert fused == (1 if width == 17 else 3) and calls == 7
+        ck.close()
+    finally:
+        assert L.nmx_set_window_bits(0) == 0
+
+
 def test_fused_run_on_the_segment_path(nmx):
     """Long vectors fused: 7.8 M sorted entries take the segment-balanced accumulate (msm_seg.hpp) over 8 bucket sets
     (2^18 buckets: FinalSegFn one lane per bucket), witness-like and skewed scalars included."""
