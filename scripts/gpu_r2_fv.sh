@@ -19,12 +19,12 @@ except Exception as e:
 PY
 done
 echo "== done"
-echo "== horner A/B (NMX_TUNE_NO_HORNER_TILE=1 = round-1 chunk-per-lane)"
-for lg in 16 20 24; do for v in 1 0; do
-  NMX_TUNE_NO_HORNER_TILE=$v timeout 300 python bench.py --workload horner --log2n $lg --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/h.json" 2>/dev/null
+echo "== horner A/B (NMX_TUNE_HORNER_TOP: 8 = register-resident 8-coefficient levels (shipped), 4, 1 = round-1 chunk-per-lane only)"
+for lg in 16 20 22 24; do for v in 8 4 1; do
+  NMX_TUNE_HORNER_TOP=$v timeout 300 python bench.py --workload horner --log2n $lg --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/h.json" 2>/dev/null
   python - "$OUT/h.json" $lg $v <<'PY'
 import json,sys
-d=json.load(open(sys.argv[1])); print(f"horner 2^{sys.argv[2]} no_tile={sys.argv[3]}: kernel {d['kernel_ms']:.4f} ms  frac {d['roofline']['frac']:.3f}")
+d=json.load(open(sys.argv[1])); print(f"horner 2^{sys.argv[2]} top={sys.argv[3]}: kernel {d['kernel_ms']:.4f} ms  frac {d['roofline']['frac']:.3f}")
 PY
 done; done
 echo "== N>1 code path on one GPU: RCCL world 1, strong sharding of 2^22"
