@@ -294,7 +294,8 @@ int nmx_set_window_bits(uint32_t c);
  * the hand-written LDS partition), "seg_min_total" (segment-balanced accumulate from this many sorted entries on;
  * 0xffffffff: never), "seg_min_len", "seg_lanes" (0: a multiple of the kernel's resident lanes), "no_quad_accum",
  * "no_quad_final", "accum_prefetch" (0: by table size; 1 or 2), "no_batch_fuse" (1: every vector of a batch call runs
- * as its own MSM), "horner_top" (suffix Horner's long levels: 0 / 8 = 8-coefficient chunks in registers, 4, 1 = off).
+ * as its own MSM), "horner_top" (suffix Horner's long levels: 0 / 8 = 8-coefficient chunks in registers, 4, 1 = off),
+ * "seg_heavy_above" (pieces per bucket summed without a pre-fold pass: 0 = by table width, else 1..63).
  * Unknown name: NMX_E_ARG. */
 int nmx_set_option(const char* name, uint32_t value);
 

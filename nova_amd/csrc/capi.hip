@@ -91,6 +91,7 @@ static void ensure_init() {
   if (const char* t = getenv("NMX_TUNE_NO_QUAD_FINAL")) G.no_quad_final = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_NO_BATCH_FUSE")) G.no_batch_fuse = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_HORNER_TOP")) G.horner_top = (uint32_t)atoi(t);
+  if (const char* t = getenv("NMX_TUNE_SEG_HEAVY_ABOVE")) G.seg_heavy_above = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_ACCUM_PF")) G.accum_prefetch = (uint32_t)atoi(t);
   HIPCHK(hipSetDevice(dev));
   cache_init_defaults();
@@ -1113,6 +1114,7 @@ int nmx_set_option(const char* name, uint32_t value) {
     else if (n == "accum_prefetch") G.accum_prefetch = value;
     else if (n == "no_batch_fuse") G.no_batch_fuse = value;
     else if (n == "horner_top") G.horner_top = value;
+    else if (n == "seg_heavy_above") G.seg_heavy_above = value > 63u ? 63u : value;
     else throw Fail{NMX_E_ARG, "unknown option name"};
   });
 }

@@ -108,7 +108,7 @@ static inline uint64_t shape_hash(const MsmArgs& a, const MsmCall& mc, size_t sb
   const uint64_t v[10] = {a.n, a.u64_bits, a.force_c, a.force_lmax, a.force_fold_t, ((uint64_t)a.pre_stride << 8) | a.pre_c,
                           (uint64_t)(mc.gather_host != nullptr) | (mc.all_ones ? 2u : 0u) | (mc.scalars_device ? 4u : 0u) |
                               (a.no_partition ? 8u : 0u),
-                          sbytes, a.seg_min_total, G.seg_lanes_override};
+                          sbytes, a.seg_min_total, G.seg_lanes_override ^ ((uint64_t)a.seg_heavy_above << 32)};
   uint64_t h = 0x9e3779b97f4a7c15ull;
   for (uint64_t x : v) {
     h = (h ^ x) * 0xff51afd7ed558ccdull;
@@ -142,6 +142,7 @@ static XYZZ<CurveT<CID>::BF> run_msm(Ctx& c, const void* d_bases, size_t n, cons
   a.no_partition = G.no_partition;
   a.seg_min_total = G.seg_min_total;
   a.seg_min_len = G.seg_min_len;
+  a.seg_heavy_above = G.seg_heavy_above;
   // gathers in flight per lane: one is enough while the key's tables (W x 64 B per point) mostly hit the 256 MB Infinity Cache
   // and L2; from ~6 GiB of tables on the gather latency shows and a second row in flight pays (2^24: accumulate 17.6 ->
   // 16.0 ms; neutral at 2^22, slightly worse at 2^20 / 2^21: profiles/r02_msm_2p20/prefetch_depth.txt)
@@ -373,6 +374,7 @@ static void run_msm_batch(Ctx& c, const BaseSet& bs, size_t offset, const BatchI
   a.no_partition = G.no_partition;
   a.seg_min_total = G.seg_min_total;
   a.seg_min_len = G.seg_min_len;
+  a.seg_heavy_above = G.seg_heavy_above;
   a.accum_prefetch = G.accum_prefetch ? G.accum_prefetch : 1u;
   a.batch_k = (uint32_t)k;
   c.wsum.resize(260);

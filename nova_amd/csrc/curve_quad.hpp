@@ -192,7 +192,7 @@ template <int FID> struct FinalSegQuadFn {
   const XYZZL* bucket_raw;
   const XYZZL* partial_raw;
   XYZZW* buckets;
-  uint32_t nbuckets, lanes, min_seg;
+  uint32_t nbuckets, lanes, min_seg, heavy_above;
   __device__ __forceinline__ void operator()(uint32_t tid) const {
     const uint32_t q = tid & 3u, k = tid >> 2;
     if (k >= nbuckets) return;  // quad-uniform
@@ -202,7 +202,7 @@ template <int FID> struct FinalSegQuadFn {
       const uint32_t seg = seg_len(*total_p, lanes, min_seg);
       const uint32_t l0 = s0 / seg, l1 = (e0 - 1) / seg;
       uint32_t cnt = l1 - l0;
-      if (cnt > PlanSegFn::kHeavyAbove) cnt = PlanSegFn::kHeavyAbove;
+      if (cnt > heavy_above) cnt = heavy_above;
       acc = quad_load_raw<FID>(bucket_raw[k], q);
       for (uint32_t j = 0; j < cnt; j++) acc = quad_add<FID>(acc, quad_load_raw<FID>(partial_raw[l0 + 1 + j], q), q);
     }

@@ -30,6 +30,7 @@ struct MsmArgs {
   uint32_t seg_min_total = 1u << 22;  // segment-balanced accumulate (msm_seg.hpp) from this many sorted entries on
   uint32_t seg_min_len = 8;           // shortest segment a lane is given
   uint32_t accum_prefetch = 1;        // gathers in flight ahead of the addition (AccumSegFn PF)
+  uint32_t seg_heavy_above = 0;       // pieces FinalSegFn sums per bucket without a pre-fold (0: PlanSegFn::heavy_above_for)
   // fused batch over the key's tables (DigitSrc::batch_*): n = sum of the vector lengths, `scalars` unused;
   // wsum_host[j] receives vector j's sum
   uint32_t batch_k = 0;
@@ -241,7 +242,8 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
       const uint32_t by_lanes = seg_lanes / (above + 1) + 1;
       return by_lanes < sh.nbuckets ? by_lanes : sh.nbuckets;
     };
-    HeavyRec* heavy_s = be.template alloc<HeavyRec>(list_cap(PlanSegFn::kHeavyAbove));
+    const uint32_t heavy_above = a.seg_heavy_above ? a.seg_heavy_above : PlanSegFn::heavy_above_for(seg_lanes, sh.nbuckets);
+    HeavyRec* heavy_s = be.template alloc<HeavyRec>(list_cap(heavy_above));
     HeavyRec* big_s = be.template alloc<HeavyRec>(list_cap(PlanSegFn::kBigAbove));
     be.memset0(bucket_raw, sizeof(XYZZL) * sh.nbuckets);
     const uint32_t* total_p = counters + 5;
@@ -257,12 +259,12 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
     }
     be.mark("fold");
     {
-      PlanSegFn f{start, end, total_p, counters, heavy_s, big_s, sh.nbuckets, seg_lanes, a.seg_min_len};
+      PlanSegFn f{start, end, total_p, counters, heavy_s, big_s, sh.nbuckets, seg_lanes, a.seg_min_len, heavy_above};
       be.launch(f, sh.nbuckets);
     }
     {
       // a bucket spans at most seg_lanes segments; buckets above T partials number at most seg_lanes / T
-      const uint32_t Ts[5] = {32768, 4096, 512, 64, PlanSegFn::kHeavyAbove};
+      const uint32_t Ts[5] = {32768, 4096, 512, 64, heavy_above};
       for (int p = 0; p < 5; p++) {
         const uint32_t T = Ts[p], cap = p == 0 ? 0xffffffffu : Ts[p - 1];
         if (T >= seg_lanes) continue;  // no bucket can have more than T partials
@@ -275,7 +277,7 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
         be.template launch_fold_raw<FID>(counters, use_big ? big_s : heavy_s, partial_raw, T, cap, groups, use_big ? 1u : 0u);
       }
       be.template launch_final_seg<FID>(start, end, total_p, bucket_raw, partial_raw, buckets, sh.nbuckets, seg_lanes,
-                                        a.seg_min_len);
+                                        a.seg_min_len, heavy_above);
     }
   } else {
   {

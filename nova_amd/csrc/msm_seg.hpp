@@ -114,14 +114,18 @@ template <int FID, int PF = 1> struct AccumSegFn {
 // [3] largest partial count among the big buckets, [4] big count.
 struct PlanSegFn {
   static constexpr bool kFullWaves = true;
-  static constexpr uint32_t kHeavyAbove = 8, kBigAbove = 64;
+  static constexpr uint32_t kBigAbove = 64;
+  // A bucket with more than `heavy_above` continuation pieces is listed for the T = heavy_above pre-fold; FinalSegFn sums up
+  // to that many serially.  lanes / nbuckets pieces per bucket on uniformly random scalars: 18 at c = 16 (8: one pre-fold
+  // pass halves them), 9 at c = 17 (12: no bucket is listed, no pre-fold work, FinalSegFn adds one more piece).
+  static uint32_t heavy_above_for(uint32_t lanes, uint32_t nbuckets) { return lanes / nbuckets <= 12u ? 12u : 8u; }
   const uint32_t* start;
   const uint32_t* end;
   const uint32_t* total_p;
   uint32_t* counters;
   HeavyRec* heavy;
   HeavyRec* big;
-  uint32_t nbuckets, lanes, min_seg;
+  uint32_t nbuckets, lanes, min_seg, heavy_above;
   NMX_HD void operator()(uint32_t k) const { (*this)(k, true); }
   NMX_HD void operator()(uint32_t k, bool valid) const {
     const uint32_t seg = seg_len(*total_p, lanes, min_seg);
@@ -134,7 +138,7 @@ struct PlanSegFn {
         off = l0 + 1;
       }
     }
-    const bool is_heavy = cnt > kHeavyAbove;
+    const bool is_heavy = cnt > heavy_above;
     uint32_t slot = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
     const unsigned long long m = __ballot(is_heavy);
@@ -179,7 +183,7 @@ template <int FID> struct FoldRawFn {
   }
 };
 
-// Every bucket: the piece that started it + the partials that continue it (after the pre-folds at most kHeavyAbove of
+// Every bucket: the piece that started it + the partials that continue it (after the pre-folds at most heavy_above of
 // them hold everything) -> canonical XYZZW.
 template <int FID> struct FinalSegFn {
   const uint32_t* start;
@@ -188,7 +192,7 @@ template <int FID> struct FinalSegFn {
   const XYZZL* bucket_raw;
   const XYZZL* partial_raw;
   XYZZW* buckets;
-  uint32_t nbuckets, lanes, min_seg;
+  uint32_t nbuckets, lanes, min_seg, heavy_above;
   NMX_HD void operator()(uint32_t k) const {
     const uint32_t s0 = start[k], e0 = end[k];
     XYZZ<FID> acc = XYZZ<FID>::identity();
@@ -196,7 +200,7 @@ template <int FID> struct FinalSegFn {
       const uint32_t seg = seg_len(*total_p, lanes, min_seg);
       const uint32_t l0 = s0 / seg, l1 = (e0 - 1) / seg;
       uint32_t cnt = l1 - l0;
-      if (cnt > PlanSegFn::kHeavyAbove) cnt = PlanSegFn::kHeavyAbove;
+      if (cnt > heavy_above) cnt = heavy_above;
       acc = XYZZ<FID>::load_raw(bucket_raw[k]);
       for (uint32_t j = 0; j < cnt; j++) acc.add(XYZZ<FID>::load_raw(partial_raw[l0 + 1 + j]));
     }

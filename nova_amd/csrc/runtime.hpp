@@ -131,6 +131,7 @@ struct Global {
   uint32_t no_quad_final = 0;         // env NMX_TUNE_NO_QUAD_FINAL
   uint32_t accum_prefetch = 0;        // env NMX_TUNE_ACCUM_PF / option accum_prefetch: 0 = by table size, 1, 2
   uint32_t horner_top = 0;            // env NMX_TUNE_HORNER_TOP / option horner_top: suffix Horner's register-resident levels: 0 / 8 = 8-element chunks, 4, 1 = off
+  uint32_t seg_heavy_above = 0;       // env NMX_TUNE_SEG_HEAVY_ABOVE / option seg_heavy_above: 0 = by pieces per bucket (8 or 12)
   uint32_t no_batch_fuse = 0;         // env NMX_TUNE_NO_BATCH_FUSE / option no_batch_fuse: every vector of a batch runs alone
 };
 extern Global& G;                // capi.hip (heap singleton, never destroyed)
@@ -230,12 +231,13 @@ struct DeviceBackend {
   }
   template <int FID>
   void launch_final_seg(const uint32_t* start, const uint32_t* end, const uint32_t* total_p, const XYZZL* bucket_raw,
-                        const XYZZL* partial_raw, XYZZW* buckets, uint32_t nbuckets, uint32_t lanes, uint32_t min_seg) {
+                        const XYZZL* partial_raw, XYZZW* buckets, uint32_t nbuckets, uint32_t lanes, uint32_t min_seg,
+                        uint32_t heavy_above) {
     if (nbuckets < kQuadBelowItems && !G.no_quad_final) {
-      FinalSegQuadFn<FID> f{start, end, total_p, bucket_raw, partial_raw, buckets, nbuckets, lanes, min_seg};
+      FinalSegQuadFn<FID> f{start, end, total_p, bucket_raw, partial_raw, buckets, nbuckets, lanes, min_seg, heavy_above};
       launch(f, nbuckets * 4);
     } else {
-      FinalSegFn<FID> f{start, end, total_p, bucket_raw, partial_raw, buckets, nbuckets, lanes, min_seg};
+      FinalSegFn<FID> f{start, end, total_p, bucket_raw, partial_raw, buckets, nbuckets, lanes, min_seg, heavy_above};
       launch(f, nbuckets);
     }
   }

@@ -71,8 +71,9 @@ struct HostEmulBackend {
   }
   template <int FID>
   void launch_final_seg(const uint32_t* start, const uint32_t* end, const uint32_t* total_p, const XYZZL* bucket_raw,
-                        const XYZZL* partial_raw, XYZZW* buckets, uint32_t nbuckets, uint32_t lanes, uint32_t min_seg) {
-    FinalSegFn<FID> f{start, end, total_p, bucket_raw, partial_raw, buckets, nbuckets, lanes, min_seg};
+                        const XYZZL* partial_raw, XYZZW* buckets, uint32_t nbuckets, uint32_t lanes, uint32_t min_seg,
+                        uint32_t heavy_above) {
+    FinalSegFn<FID> f{start, end, total_p, bucket_raw, partial_raw, buckets, nbuckets, lanes, min_seg, heavy_above};
     launch(f, nbuckets);
   }
   void sort_pairs(uint32_t* k_in, uint32_t* k_out, uint32_t* v_in, uint32_t* v_out, size_t total, uint32_t bits) {
