@@ -20,8 +20,11 @@ VARIANTS = [
     {"seg_min_total": 0, "seg_lanes": 1 << 19, "seg_min_len": 1},  # more lanes than entries per bucket: one-entry pieces
     {"seg_min_total": 0, "seg_lanes": 70001, "no_quad_final": 1},  # odd lane count, single-lane final pass
     {"seg_min_total": 0, "accum_prefetch": 2},
+    {"seg_min_total": 0, "seg_lanes": 1 << 18, "seg_heavy_above": 3},   # nearly every bucket through the pre-fold passes
+    {"seg_min_total": 0, "seg_lanes": 1 << 18, "seg_heavy_above": 40},  # long serial sums in the final pass instead
 ]
-DEFAULTS = {"no_partition": 0, "seg_min_total": 1 << 22, "seg_lanes": 0, "seg_min_len": 8, "no_quad_final": 0, "accum_prefetch": 0}
+DEFAULTS = {"no_partition": 0, "seg_min_total": 1 << 22, "seg_lanes": 0, "seg_min_len": 8, "no_quad_final": 0, "accum_prefetch": 0,
+            "seg_heavy_above": 0}
 
 
 @pytest.mark.parametrize("c,n", [(R.BN254_G1, 20000), (R.BN254_G1, 1 << 16), (R.PALLAS, 1 << 17)], ids=lambda v: getattr(v, "name", v))
