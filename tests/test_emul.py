@@ -255,7 +255,7 @@ def test_emul_precomputed_tables(emul, c):
 
 
 @pytest.mark.parametrize("c,n,grid", [(16, 40000, 0), (16, 40000, 3), (15, 20011, 2), (8, 30000, 5), (8, 700, 0), (12, 5000, 1),
-                                      (6, 300, 0), (16, 1, 0), (16, 1025, 0), (20, 9000, 2), (18, 5000, 0),
+                                      (6, 300, 0), (16, 1, 0), (16, 1025, 0), (20, 4000, 2), (18, 5000, 0),
                                       (17, 2500, 1)])
 def test_emul_partition_kernels(emul, c, n, grid):
     """The hand-written LDS partition (msm_partition.hpp) run thread by thread on the CPU (tests/host_emul/simt.hpp:
