@@ -262,7 +262,8 @@ def test_emul_partition_kernels(emul, c, n, grid):
     one fiber per GPU thread, real barriers) against DigitsFn + a sort: per-bucket multisets, start / end, totals.
     Scalar sets include the adversarial ones for a counting sort: every entry in one bucket per window (equal), almost
     everything dropped as a zero digit (u1), and 0 / r-1."""
-    for kind in ["random", "equal", "zero_rm1", "u1", "pm_small"]:
+    # (the wide geometry launches ~1000 mostly idle 1024-thread blocks per level: two scalar sets keep its emulation short)
+    for kind in (["random", "equal", "zero_rm1", "u1", "pm_small"] if c <= 17 else ["random", "zero_rm1"]):
         sc = np.ascontiguousarray(util.scalar_set(0, n, kind))
         for ct in (1, 0):     # the compile-time-width instantiation (c = 8 / 15 / 16) and the run-time-width one
             rc = emul.emul_partition_check(sc.ctypes.data, n, c, 0, grid, n + 7, 3, ct)
