@@ -25,6 +25,23 @@ for it in range(iters):
             host[j] = 0 if rng.integers(0, 2) else host[0]
         keys[(c.cid, nk)] = (host, nova_amd.CommitmentKey.from_host(c.cid, host, precompute=bool(rng.integers(0, 2))))
     host, ck = keys[(c.cid, nk)]
+    if it % 5 == 4:   # a ragged batch (fused runs on keys with tables, one MSM per vector otherwise)
+        kv = int(rng.choice([1, 2, 3, 7, 16, 17, 40]))
+        lens = [int(rng.integers(0, nk + 1)) if rng.integers(0, 3) else int(rng.integers(0, min(nk, 9) + 1)) for _ in range(kv)]
+        fk = [kk for kk in kinds if not kk.startswith("u")]
+        vecs = [util.scalar_set(c.cid, max(m, 1), fk[rng.integers(0, len(fk))], seed=int(rng.integers(0, 1 << 30)))[:m] for m in lens]
+        exp = [cref.msm(c.cid, v, host[:len(v)], len(v)) if len(v) else (bytes(64), 1) for v in vecs]
+        mode = int(rng.integers(0, 3))
+        if mode == 0:
+            got = g.batch_vartime_multiscalar_mul(vecs, ck)
+        elif mode == 1:
+            got = g.batch_vartime_multiscalar_mul([torch.from_numpy(np.ascontiguousarray(v)).cuda() for v in vecs], ck)
+        else:
+            got = g.batch_vartime_multiscalar_mul(vecs, host)
+        if [(x.xy, int(x.is_inf)) for x in got] != exp:
+            print(f"MISMATCH (batch) it={it} curve={c.name} nk={nk} lens={lens} mode={mode}", flush=True)
+            sys.exit(1)
+        continue
     n = int(rng.integers(0, nk + 1))
     off = int(rng.integers(0, nk - n + 1))
     kind = kinds[rng.integers(0, len(kinds))]
