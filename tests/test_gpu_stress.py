@@ -15,7 +15,7 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
-def test_register_msm_unregister_from_eight_threads(nmx):
+def test_register_msm_unregister_from_ten_threads(nmx):
     from nova_amd import _lib
     L = _lib.lib()
     c = R.BN254_G1
@@ -84,8 +84,34 @@ def test_register_msm_unregister_from_eight_threads(nmx):
             if k % 5 == 0:
                 L.nmx_cache_clear()
 
+    def batch_caller(tid):
+        """whole batches (fused runs + worker threads inside the library) over a handle that may vanish under them"""
+        k = len(lens)
+        ptrs = (ctypes.c_void_p * k)(*[v.ctypes.data for v in scs])
+        ls = (ctypes.c_size_t * k)(*lens)
+        out = np.zeros((k, 64), np.uint8)
+        inf = np.zeros(k, np.uint8)
+        while not stop.is_set():
+            with lock:
+                h = shared["h"]
+            if not h:
+                continue
+            out[:] = 0xAB
+            rc = L.nmx_msm_batch_handle(h, ptrs, ls, k, 0, out.ctypes.data, inf.ctypes.data)
+            if rc == 0:
+                if [(out[j].tobytes(), int(inf[j])) for j in range(k)] != exp:
+                    errors.append(("wrong point (batch)", tid))
+                counts["ok"] += 1
+            elif rc == _lib.E_HANDLE:
+                if not (out == 0xAB).all():
+                    errors.append(("failed batch wrote output", tid))
+                counts["stale"] += 1
+            else:
+                errors.append(("batch", rc, L.nmx_last_error().decode()))
+
     ths = [threading.Thread(target=registrar)]
     ths += [threading.Thread(target=caller, args=(t,)) for t in range(5)]
+    ths += [threading.Thread(target=batch_caller, args=(t,)) for t in range(2)]
     ths += [threading.Thread(target=slice_caller, args=(t,)) for t in range(2)]
     [t.start() for t in ths]
     [t.join(timeout=300) for t in ths]
