@@ -74,6 +74,25 @@ def test_natural_c20_key_2p22(nmx):
     ck.close()
 
 
+def test_shard_size_2p21_c17_tables(nmx):
+    """The per-GPU shard of BASELINE configs[2] at 8 GPUs: a 2^21-point key (c = 17 tables, 15 windows, 16-bit bucket keys in
+    the narrow partition geometry).  Full compare for random and witness-like scalars, prefix / interior slices of the key."""
+    c = R.BN254_G1
+    n = 1 << 21
+    g = nmx.DlogGroup(c.cid)
+    ck = nmx.CommitmentKey.generate(c.cid, n, k0=1 + 3 * n)       # rank 3's shard of P_i = (1 + i) G
+    bases = ck.read(0, n)
+    prep = cref.Prepared(c.cid, bases, n)
+    sc = util.random_scalars(c.cid, n, seed=21)
+    assert as_pair(g.vartime_multiscalar_mul(sc, ck)) == prep.msm(sc, n)
+    w = util.witness_like(c.cid, n, 5)
+    assert as_pair(g.vartime_multiscalar_mul(w, ck)) == prep.msm(w, n)
+    m = 1234567
+    assert as_pair(g.vartime_multiscalar_mul(sc[:m], ck)) == prep.msm(sc[:m], m)
+    assert as_pair(g.vartime_multiscalar_mul(sc[:100000], ck, offset=777777)) == cref.msm(c.cid, sc[:100000], bases[777777:877777], 100000)
+    ck.close()
+
+
 @pytest.mark.parametrize("c", [R.GRUMPKIN, R.PALLAS, R.VESTA], ids=lambda c: c.name)
 @pytest.mark.parametrize("log2n", [16, 18])
 def test_other_curves_with_tables(nmx, c, log2n):
