@@ -39,6 +39,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 BYTES_PER_PAIR = 96            # 32 B scalar + 64 B affine base, each read once
 STAGES = ["digits", "sort", "bounds_plan", "accum", "fold", "reduce", "tail"]
+DTYPE = "9x29-bit limbs (256-bit modular integer, Montgomery R = 2^261)"
 MAD_PEAK_T = 28.8              # measured v_mad_u64_u32 rate, T/s (bench/ubench.hip)
 # multiply-adds per XYZZ mixed addition (curve.hpp add_affine: 5 products, 2 squarings, 1 two-product sum) by base
 # field: BN254 Fq / Fr 5 x 162 + 2 x 126 + 243; the Pasta moduli have three zero limbs of nine, whose reduction
@@ -111,6 +112,7 @@ def main():
                          "SURVEY.md 8(f) at 2^log2n elements per GPU")
     args = ap.parse_args()
     strong = (args.gpus > 1 and args.log2n is None) or args.strong      # configs[2] as written: fixed total, contiguous shards
+    args.inproc_log2n = args.total_log2n if strong else args.log2n     # in-process mode (below): pairs in total
     if args.log2n is None:
         args.log2n = 20
 
@@ -123,7 +125,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: ONE process drives the N GPUs through the C ABI's multi-device
+        # keys (nmx_init_devices) -- the way a Rust host process would (one address space)
+        return emit(inprocess_multi(args, torch), False, dist)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run, or " \
+                               f"without a launcher for the in-process mode)"
     torch.cuda.set_device(local_rank)
     # NMX_BENCH_FORCE_DIST=1 exercises the RCCL exchange path with a single rank (1-GPU boxes)
     force_dist = os.environ.get("NMX_BENCH_FORCE_DIST") == "1"
@@ -234,7 +241,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
-            "dtype": "u32x8 (256-bit modular integer, Montgomery)",
+            "dtype": DTYPE,
             "data": "synthetic",
             "config": {
                 "workload": workload,
@@ -288,6 +295,88 @@ def main():
             extras(out, args, torch, L, ck, host_sc[0], dev_sc[0])
     ck.close()
     emit(out if rank == 0 else None, multi, dist)
+
+
+def inprocess_multi(args, torch):
+    """BASELINE.json configs[2] from ONE process: a key of 2^total_log2n points sharded over the GPUs by the library
+    itself (nmx_init_devices: shard i and its window tables resident on GPU i), every step one synchronous
+    nmx_msm_handle call that fans out a host thread + stream per GPU and sums the 128-byte partials on the host.
+    Fewer GPUs visible than asked for: says so on stderr and in the JSON, and runs on what there is."""
+    import nova_amd
+    from nova_amd import _lib
+    from tests import util
+    L = _lib.lib()
+    assert L.nmx_init(0) == 0, L.nmx_last_error().decode()
+    visible = L.nmx_device_count()
+    k = min(args.gpus, visible)
+    if k < args.gpus:
+        print(f"bench.py: WARNING --gpus {args.gpus} requested but only {visible} HIP device(s) visible: running the "
+              f"in-process sharded MSM on {k} device(s)", file=sys.stderr, flush=True)
+    assert nova_amd.init_devices(k) == k, L.nmx_last_error().decode()
+    cid = args.curve
+    total = 1 << args.inproc_log2n
+    torch.cuda.set_device(0)
+    t0 = time.perf_counter()
+    ck = nova_amd.CommitmentKey.generate(cid, total, k0=1)   # P_i = (1 + i) G, cut into k contiguous shards
+    t_key = time.perf_counter() - t0
+    group = nova_amd.DlogGroup(cid)
+    # 2^22 random scalars tiled: drawing 2^24 by rejection sampling on the host takes longer than the whole run
+    base = util.scalar_set(cid, min(total, 1 << 22), args.dist, seed=util.SEED + 7)
+    host = np.tile(base, (total // len(base), 1)) if total > len(base) else base
+    dev_sc = [torch.from_numpy(host.copy()).cuda(), torch.from_numpy(np.ascontiguousarray(host[::-1])).cuda()]
+    for j in range(args.warmup):
+        group.vartime_multiscalar_mul(dev_sc[j & 1], ck)
+    before = _lib.stats()[_lib.STAT_SHARDED_CALLS]
+    for d in range(k):
+        torch.cuda.synchronize(d)
+    t0 = time.perf_counter()
+    res = None
+    for j in range(args.steps):
+        res = group.vartime_multiscalar_mul(dev_sc[j & 1], ck)   # synchronous: returns the affine point
+    for d in range(k):
+        torch.cuda.synchronize(d)
+    dt = time.perf_counter() - t0
+    sharded_calls = _lib.stats()[_lib.STAT_SHARDED_CALLS] - before
+    # size-independent check at full size: the two halves of the key (which straddle the shards differently) add up
+    half = total // 2
+    a = group.vartime_multiscalar_mul(dev_sc[0][:half], ck, partial=True)
+    b = group.vartime_multiscalar_mul(dev_sc[0][half:], ck, partial=True, offset=half)
+    whole = group.vartime_multiscalar_mul(dev_sc[0], ck)
+    halves_ok = group.point_sum([a.xy, b.xy]) == whole
+    name = nova_amd.CURVE_NAMES[cid]
+    out = {
+        "metric": "BN254 MSM scalar-point pairs/sec" if cid == 0 else f"{name} MSM scalar-point pairs/sec",
+        "value": total * args.steps / dt,
+        "unit": "pairs/s",
+        "n_gpus": k,
+        "requested_gpus": args.gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": DTYPE,
+        "data": "synthetic",
+        "config": {
+            "workload": f"{name} Pippenger MSM, 2^{total.bit_length() - 1} pairs of one key sharded contiguously over {k} "
+                        f"GPU(s) by ONE host process (nmx_init_devices; BASELINE.json configs[2]), {args.dist} scalars "
+                        "(2^22 drawn, tiled) resident in the HBM of GPU 0 -- the other shards pull their slice over xGMI "
+                        "inside the call --, one 128-byte partial per shard summed on the host",
+            "pairs_total": total,
+            "pairs_per_gpu": total // k,
+            "parallelism": f"in-process shard{k}" if k > 1 else "single (in-process mode, one device visible)",
+            "combine": "host sum of 128-byte partials (nmx_point_sum)" if k > 1 else "none",
+        },
+        "sharded_calls": sharded_calls,
+        "key_generation_s": round(t_key, 3),
+        "halves_sum_to_whole": bool(halves_ok),
+        "last_result_is_inf": bool(res.is_inf),
+    }
+    if k < args.gpus:
+        out["fallback"] = f"{args.gpus} GPUs requested, {visible} visible"
+    ck.close()
+    return out
 
 
 def extras(out, args, torch, L, ck, host_scalars, dev_scalars):
@@ -487,7 +576,7 @@ def prove_step_replay(args, torch):
     outj = {
         "metric": "RecursiveSNARK prove_step provider-call REPLAY ms (minroot, BN254/Grumpkin)", "value": dt * 1e3, "unit": "ms",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": False,
-        "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (256-bit modular integer)", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
         "config": {"workload": f"prove_step replay: minroot {args.iters} iterations/step -> primary N={N} (BN254), secondary n={n2} "
                                "(Grumpkin); 4 MSMs + 6 SpMVs + 2 vector adds + 2 cross terms + 4 folds; no synthesis / Poseidon "
                                "(BASELINE.json configs[3])"},
@@ -588,7 +677,7 @@ def hyperkzg_replay(args, torch, ck=None):
     outj = {
         "metric": "HyperKZG prove provider-call REPLAY ms (BN254)", "value": dt * 1e3, "unit": "ms", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": False, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u32x8 (256-bit modular integer)", "data": "synthetic",
+        "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
         "config": {"workload": f"HyperKZG prove replay, n = 2^{ell}: {ell - 1} pair folds, batch_commit of lengths n/2..2, {3 * ell} Horner "
                                "evaluations (one launch), batch polynomial (one launch), 3 x (div_by_monomial + MSM of n-1) (BASELINE.json configs[4]); no transcript"},
         "roofline": None,
@@ -783,7 +872,7 @@ def field_workload(args, world, rank, L, torch, dist):
             "metric": f"field elements/sec ({wl})", "value": n * world * args.steps / dt, "unit": "elements/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32x8 (256-bit modular integer)", "data": "synthetic",
+            "dtype": DTYPE, "data": "synthetic",
             "config": {"workload": f"{wl} over 2^{args.log2n} {['bn254_fq','bn254_fr','pasta_fp','pasta_fq'][fid]} "
                                    "elements per GPU, HBM-resident (SURVEY.md 8(f))", "parallelism": f"replicas{world}"},
             "kernel_ms": kms,

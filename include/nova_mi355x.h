@@ -74,6 +74,27 @@ enum {
 int nmx_init(int device);
 int nmx_shutdown(void);
 int nmx_device_count(void);
+/* Several GPUs behind ONE host process (the reference is one address space: its own MSM decomposition is in-process,
+ * `par_chunks` + `reduce(identity, +)`, src/provider/msm.rs:564-574,664-676).  After
+ * nmx_init_devices(k, flags) the process owns logical devices 0 .. k-1 (HIP devices 0 .. k-1; k == 0: every visible
+ * device; k > nmx_device_count(): NMX_E_NO_DEVICE unless NMX_DEVICES_OVERSUBSCRIBE, which maps logical device i to HIP
+ * device i mod count -- several shards per GPU, for tests on a 1-GPU box).  Every key of at least `shard_min_n` points
+ * (default 2^20, env NMX_SHARD_MIN_N, nmx_set_option("shard_min_n")) registered AFTERWARDS -- nmx_bases_register*,
+ * nmx_bases_generate, and the slice cache behind nmx_msm / nmx_msm_u64 / nmx_msm_batch -- is cut into k contiguous shards
+ * (shard i = points [i*n/k ...), exactly nova_amd/dist.py shard_range), shard i resident on device i with its own window
+ * tables.  An MSM / commit over such a key runs one host thread + stream per shard touched, each producing a 128-byte
+ * partial, summed on the host (the G-term combine of nmx_point_sum): no bucket array crosses devices, and the call is
+ * still one synchronous C call.  HBM-resident scalars (NMX_SCALARS_DEVICE) live on logical device 0; a shard on another
+ * GPU pulls its slice peer-to-peer over xGMI.  Field-vector kernels, keys below the threshold and keys registered from a
+ * device pointer stay on logical device 0.  Without this call (or env NMX_DEVICES=k) the library uses one device, as
+ * before.  May be called again to change k (keys keep the layout they were registered with). */
+#define NMX_DEVICES_OVERSUBSCRIBE 1u
+int nmx_init_devices(int count, uint32_t flags);
+int nmx_devices_in_use(void); /* logical devices new keys are sharded over (1 = unsharded) */
+/* How a key of n_key points is laid out over k devices and which shards a call over key[offset, offset + n) touches:
+ * writes up to cap triples (device, offset inside the shard, count) and returns how many the call needs.  Pure host
+ * arithmetic (no device needed): the rule the library itself uses. */
+int nmx_shard_plan(size_t n_key, int k, size_t offset, size_t n, size_t* out_triples, int cap);
 const char* nmx_last_error(void);
 const char* nmx_version(void);
 
@@ -151,7 +172,8 @@ enum {
   NMX_STAT_BASE_BYTES_H2D = 7,/* bytes of base points copied host -> device by slice-form calls               */
   NMX_STAT_MSM_CALLS = 8,     /* MSMs run (every entry point; a batch counts each vector)                     */
   NMX_STAT_FUSED_RUNS = 9,    /* batch calls whose short vectors ran as one fused pipeline run                */
-  NMX_STAT_COUNT = 10
+  NMX_STAT_SHARDED_CALLS = 10,/* MSMs that fanned out over the shards of a multi-device key                   */
+  NMX_STAT_COUNT = 11
 };
 int nmx_stats(uint64_t* out, int cap);
 /* same, bases taken from a registered key */

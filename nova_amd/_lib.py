@@ -3,14 +3,15 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libnova_mi355x.so")
+SO_PATH = os.environ.get("NMX_SO") or os.path.join(_HERE, "libnova_mi355x.so")  # NMX_SO: an A/B build of the same library
 
 # flags / error codes (include/nova_mi355x.h)
 SCALARS_MONT, BASES_MONT, SCALARS_DEVICE, BASES_DEVICE, OUT_PARTIAL, BASES_PRECOMPUTE, BASES_VALIDATE = 1, 2, 4, 8, 16, 32, 64
 BASES_NOCACHE = 128
 # nmx_stats indices
 (STAT_CACHE_HITS, STAT_CACHE_UPLOADS, STAT_CACHE_REGROWS, STAT_CACHE_EVICTIONS, STAT_CACHE_ENTRIES, STAT_CACHE_BYTES,
- STAT_UNCACHED_CALLS, STAT_BASE_BYTES_H2D, STAT_MSM_CALLS, STAT_FUSED_RUNS, STAT_COUNT) = range(11)
+ STAT_UNCACHED_CALLS, STAT_BASE_BYTES_H2D, STAT_MSM_CALLS, STAT_FUSED_RUNS, STAT_SHARDED_CALLS, STAT_COUNT) = range(12)
+DEVICES_OVERSUBSCRIBE = 1
 E_ARG, E_NO_DEVICE, E_HIP, E_SCALAR_RANGE, E_SMALL_RANGE, E_HANDLE, E_TOO_LARGE = -1, -2, -3, -4, -5, -6, -7
 E_IO, E_FORMAT, E_POINT = -8, -9, -10
 BITS_AUTO = 0xFFFFFFFF
@@ -39,6 +40,9 @@ def lib():
     L.nmx_init.argtypes = [i]
     L.nmx_shutdown.argtypes = []
     L.nmx_device_count.argtypes = []
+    L.nmx_init_devices.argtypes = [i, u32]
+    L.nmx_devices_in_use.argtypes = []
+    L.nmx_shard_plan.argtypes = [sz, i, sz, sz, vp, i]
     L.nmx_last_error.restype = ctypes.c_char_p
     L.nmx_version.restype = ctypes.c_char_p
     L.nmx_bases_register.argtypes = [i, vp, sz, u32, ctypes.POINTER(u64)]

@@ -1,7 +1,9 @@
 // capi.hip -- the C ABI of include/nova_mi355x.h: global state, context pool, key registry, dispatch to the
 // per-curve operation tables (curve_*.hip).  No group arithmetic and no CPU fallback in this file.
 #include <algorithm>
+#include <array>
 #include <atomic>
+#include <future>
 #include <list>
 #include <thread>
 
@@ -17,9 +19,12 @@ Global& G = *new Global;
 static std::atomic<uint64_t> g_stats[NMX_STAT_COUNT];
 static inline void stat_add(int k, uint64_t v = 1) { g_stats[k].fetch_add(v, std::memory_order_relaxed); }
 
+static inline int hip_device_of(int logical) {  // hip_dev only grows, within reserved capacity: safe to read unlocked
+  return (size_t)logical < G.hip_dev.size() ? G.hip_dev[(size_t)logical] : G.device;
+}
 BaseSet::~BaseSet() {
   if (d && owns) {
-    (void)hipSetDevice(G.device);
+    (void)hipSetDevice(hip_device_of(dev));
     (void)hipFree(d);
   }
 }
@@ -75,6 +80,11 @@ static void ensure_init() {
   }
   if (dev >= cnt) throw Fail{NMX_E_ARG, "device index out of range"};
   G.device = dev;
+  G.hip_dev.reserve(Global::kMaxDevices);
+  G.hip_dev.assign(1, dev);
+  G.free_ctx.assign(Global::kMaxDevices, {});
+  G.ndev_active.store(1);
+  if (const char* t = getenv("NMX_SHARD_MIN_N")) G.shard_min_n.store((size_t)atoll(t));
   if (const char* t = getenv("NMX_TUNE_LMAX")) G.force_lmax = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_PRECOMP_MIN_N")) G.precomp_min_n = (size_t)atoll(t);
   if (const char* t = getenv("NMX_TUNE_FOLD_T")) {
@@ -90,37 +100,50 @@ static void ensure_init() {
   if (const char* t = getenv("NMX_TUNE_SEG_LANES")) G.seg_lanes_override = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_NO_QUAD_FINAL")) G.no_quad_final = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_NO_BATCH_FUSE")) G.no_batch_fuse = (uint32_t)atoi(t);
+  if (const char* t = getenv("NMX_TUNE_NO_TREE_FUSE")) G.no_tree_fuse = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_HORNER_TOP")) G.horner_top = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_SEG_HEAVY_ABOVE")) G.seg_heavy_above = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_ACCUM_PF")) G.accum_prefetch = (uint32_t)atoi(t);
   HIPCHK(hipSetDevice(dev));
   cache_init_defaults();
+  if (const char* t = getenv("NMX_DEVICES")) {  // same as nmx_init_devices(k, 0), for hosts that cannot call it
+    const int k = atoi(t);
+    if (k > cnt || k < 0) throw Fail{NMX_E_NO_DEVICE, "NMX_DEVICES asks for more devices than are visible"};
+    for (int i = 1; i < (k ? k : cnt); i++) G.hip_dev.push_back((dev + i) % cnt);
+    G.ndev_active.store((uint32_t)(k ? k : cnt));
+  }
   G.inited = true;
 }
 
 // One context per in-flight call: concurrent callers (rayon workers on the reference side) never share a stream
 // or a workspace, so a small MSM does not queue behind a 2^20 one.
+// The lease also makes the context's device current on the calling thread (hipSetDevice is per thread).
 struct CtxLease {
   Ctx* c;
-  CtxLease() {
+  explicit CtxLease(int dev = 0) {
     ensure_init();
-    HIPCHK(hipSetDevice(G.device));
+    require(dev >= 0 && (size_t)dev < G.hip_dev.size(), NMX_E_ARG, "logical device out of range");
+    HIPCHK(hipSetDevice(hip_device_of(dev)));
     {
       std::lock_guard<std::mutex> lk(G.mu);
-      if (!G.free_ctx.empty()) {
-        c = G.free_ctx.back();
-        G.free_ctx.pop_back();
+      auto& pool = G.free_ctx[(size_t)dev];
+      if (!pool.empty()) {
+        c = pool.back();
+        pool.pop_back();
         return;
       }
     }
     c = new Ctx();
+    c->dev = dev;
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     std::lock_guard<std::mutex> lk(G.mu);
     G.all_ctx.push_back(c);
   }
+  CtxLease(const CtxLease&) = delete;
+  CtxLease& operator=(const CtxLease&) = delete;
   ~CtxLease() {
     std::lock_guard<std::mutex> lk(G.mu);
-    G.free_ctx.push_back(c);
+    G.free_ctx[(size_t)c->dev].push_back(c);
   }
 };
 
@@ -151,11 +174,184 @@ static uint64_t publish(std::shared_ptr<BaseSet> bs) {
 // key[offset, offset + n) inside the registered key?  Written so that offset + n cannot wrap (the Rust slice would
 // have panicked; a C caller must get an error, not an out-of-bounds HBM read).
 static inline bool slice_ok(const BaseSet& bs, size_t offset, size_t n) { return offset <= bs.n && n <= bs.n - offset; }
-// upload / generate a key and wrap it
-template <class Make> static std::shared_ptr<BaseSet> make_key(int curve, size_t n, Make&& make) {
+struct JoinAll {  // unwinding must never destroy a joinable std::thread (std::terminate)
+  std::vector<std::thread>& th;
+  ~JoinAll() {
+    for (auto& t : th)
+      if (t.joinable()) t.join();
+  }
+};
+static MsmCall field_call(const void* scalars, uint32_t flags) {
+  return MsmCall{scalars, (flags & NMX_SCALARS_DEVICE) != 0, (flags & NMX_SCALARS_MONT) != 0, 0, false};
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Keys over several devices of ONE process.  The reference decomposes an MSM inside
+// one address space -- `par_chunks` + `reduce(identity, +)`, /root/reference/src/provider/msm.rs:564-574,664-676 -- so
+// the Rust host that binds this library is one process too: a key registered after nmx_init_devices(k) is cut into k
+// contiguous shards (same rule as nova_amd/dist.py shard_range), shard i resident on logical device i with its own window
+// tables, and every MSM over it fans out one host thread + stream per device touched, collects one 128-byte partial per
+// shard and sums them on the host.  No bucket array ever crosses devices.
+// ---------------------------------------------------------------------------------------------------
+struct PartRange {
+  size_t begin, n;
+};
+static inline PartRange shard_range(size_t n, uint32_t i, uint32_t k) {
+  const size_t base = n / k, rem = n % k;
+  return PartRange{(size_t)i * base + (i < rem ? i : rem), base + (i < rem ? 1u : 0u)};
+}
+// fn(i) for i in [0, count): i = 0 on the calling thread, the others on their own threads when `parallel`.  Nothing
+// escapes a worker thread; the first failure is rethrown here.  The calling thread ends on the primary device.
+template <class Fn> static void run_on_parts(size_t count, bool parallel, Fn&& fn) {
+  std::mutex err_mu;
+  bool failed = false;
+  Fail first{0, ""};
+  auto guarded_fn = [&](size_t i) {
+    try {
+      fn(i);
+    } catch (const Fail& f) {
+      std::lock_guard<std::mutex> lk(err_mu);
+      if (!failed) first = f;
+      failed = true;
+    } catch (const std::exception& e) {
+      std::lock_guard<std::mutex> lk(err_mu);
+      if (!failed) first = Fail{NMX_E_HIP, e.what()};
+      failed = true;
+    } catch (...) {
+      std::lock_guard<std::mutex> lk(err_mu);
+      if (!failed) first = Fail{NMX_E_HIP, "unknown exception in a device worker"};
+      failed = true;
+    }
+  };
+  if (!parallel || count <= 1) {
+    for (size_t i = 0; i < count; i++) guarded_fn(i);
+  } else {
+    std::vector<std::thread> th;
+    size_t started = 1;
+    {
+      JoinAll join{th};
+      try {
+        for (size_t i = 1; i < count; i++) {
+          th.emplace_back([&guarded_fn, i] { guarded_fn(i); });
+          started = i + 1;
+        }
+      } catch (const std::exception&) {  // std::system_error from thread creation: the rest runs on this thread
+      }
+      guarded_fn(0);
+      for (size_t i = started; i < count; i++) guarded_fn(i);
+    }
+  }
+  (void)hipSetDevice(G.device);
+  if (failed) throw first;
+}
+// A key of n points: whole on the primary device (mk runs on `c0`), or -- allow_shard, more than one active device, at
+// least shard_min_n points -- sharded.  mk(ctx, part, begin) fills `part` (part.n points starting at point `begin` of the
+// key) on ctx's device: an upload, a file read, a generator.
+template <class MakePart>
+static std::shared_ptr<BaseSet> build_key(Ctx& c0, int curve, size_t n, bool allow_shard, bool parallel, MakePart&& mk) {
+  const uint32_t k = allow_shard ? G.ndev_active.load(std::memory_order_relaxed) : 1u;
   auto bs = std::make_shared<BaseSet>(curve, n);
-  make(*bs);
+  if (k <= 1 || n < G.shard_min_n.load(std::memory_order_relaxed) || n < k) {
+    mk(c0, *bs, (size_t)0);
+    return bs;
+  }
+  bs->parts.resize(k);
+  bs->part_begin.resize(k + 1);
+  for (uint32_t i = 0; i < k; i++) {
+    const PartRange r = shard_range(n, i, k);
+    bs->parts[i] = std::make_shared<BaseSet>(curve, r.n);
+    bs->parts[i]->dev = (int)i;
+    bs->part_begin[i] = r.begin;
+  }
+  bs->part_begin[k] = n;
+  run_on_parts(k, parallel, [&](size_t i) {
+    CtxLease L((int)i);
+    mk(*L.c, *bs->parts[i], bs->part_begin[i]);
+  });
   return bs;
+}
+// the pieces of key[offset, offset + n) by shard: (part, offset inside the part, count, offset inside the call)
+struct PartJob {
+  const BaseSet* part;
+  size_t poff, cnt, goff;
+};
+static std::vector<PartJob> parts_of(const BaseSet& bs, size_t offset, size_t n) {
+  std::vector<PartJob> jobs;
+  for (size_t i = 0; i < bs.parts.size() && n; i++) {
+    const size_t b = bs.part_begin[i], e = bs.part_begin[i + 1];
+    const size_t lo = offset > b ? offset : b, hi = offset + n < e ? offset + n : e;
+    if (lo < hi) jobs.push_back(PartJob{bs.parts[i].get(), lo - b, hi - lo, lo - offset});
+  }
+  return jobs;
+}
+// out = sum scalars[i] * key[offset + i] for any key: one device, or one partial per shard touched + a host sum
+static void key_msm(Ctx& c0, const BaseSet& bs, size_t offset, size_t n, const MsmCall& mc, uint32_t flags, uint8_t* out,
+                    uint8_t* inf) {
+  const CurveOps& o = ops(bs.curve);
+  if (bs.parts.empty()) {
+    o.msm_key(c0, bs, offset, n, mc, flags, out, inf);
+    return;
+  }
+  require(!mc.gather_host, NMX_E_ARG, "internal: sparse calls over a sharded key go through key_msm_sparse");
+  const std::vector<PartJob> jobs = parts_of(bs, offset, n);
+  std::vector<uint8_t> partials(128 * (jobs.size() ? jobs.size() : 1));
+  const size_t sbytes = mc.u64_mode ? 8 : 32;
+  run_on_parts(jobs.size(), true, [&](size_t i) {
+    const PartJob& j = jobs[i];
+    CtxLease L(j.part->dev);
+    MsmCall m = mc;
+    if (mc.scalars) {
+      const char* src = (const char*)mc.scalars + j.goff * sbytes;
+      if (mc.scalars_device && hip_device_of(j.part->dev) != G.device) {
+        // HBM-resident scalars live on the primary device: this shard's slice crosses xGMI once, peer to peer
+        aux_reserve(*L.c, j.cnt * sbytes);
+        HIPCHK(hipMemcpyPeerAsync(L.c->aux, hip_device_of(j.part->dev), src, G.device, j.cnt * sbytes, L.c->stream));
+        m.scalars = L.c->aux;
+      } else {
+        m.scalars = src;
+      }
+    }
+    o.msm_key(*L.c, *j.part, j.poff, j.cnt, m, (flags & ~(uint32_t)NMX_OUT_PARTIAL) | NMX_OUT_PARTIAL,
+              partials.data() + 128 * i, nullptr);
+  });
+  stat_add(NMX_STAT_SHARDED_CALLS, 1);
+  o.point_sum(partials.data(), jobs.size(), flags, out, inf);
+}
+// sparse forms over any key: indices are positions in the whole key; scalars == nullptr: all ones
+static void key_msm_sparse(Ctx& c0, const BaseSet& bs, const uint32_t* idx, const void* scalars, size_t k, uint32_t flags,
+                           uint8_t* out, uint8_t* inf) {
+  const CurveOps& o = ops(bs.curve);
+  MsmCall mc = scalars ? field_call(scalars, flags) : MsmCall{nullptr, false, false, 1, true};
+  mc.all_ones = scalars == nullptr;
+  if (bs.parts.empty()) {
+    mc.gather_host = idx;
+    o.msm_key(c0, bs, 0, k, mc, flags, out, inf);
+    return;
+  }
+  require(!(flags & NMX_SCALARS_DEVICE), NMX_E_ARG, "sparse MSM over a multi-device key takes host scalars");
+  const size_t np = bs.parts.size();
+  std::vector<std::vector<uint32_t>> pidx(np);
+  std::vector<std::vector<uint8_t>> psc(np);
+  for (size_t t = 0; t < k; t++) {
+    size_t p = std::upper_bound(bs.part_begin.begin(), bs.part_begin.end(), (size_t)idx[t]) - bs.part_begin.begin() - 1;
+    pidx[p].push_back((uint32_t)(idx[t] - bs.part_begin[p]));
+    if (scalars) psc[p].insert(psc[p].end(), (const uint8_t*)scalars + 32 * t, (const uint8_t*)scalars + 32 * t + 32);
+  }
+  std::vector<size_t> used;
+  for (size_t p = 0; p < np; p++)
+    if (!pidx[p].empty()) used.push_back(p);
+  std::vector<uint8_t> partials(128 * (used.size() ? used.size() : 1));
+  run_on_parts(used.size(), true, [&](size_t i) {
+    const size_t p = used[i];
+    CtxLease L(bs.parts[p]->dev);
+    MsmCall m = mc;
+    m.scalars = scalars ? psc[p].data() : nullptr;
+    m.gather_host = pidx[p].data();
+    o.msm_key(*L.c, *bs.parts[p], 0, pidx[p].size(), m, (flags & ~(uint32_t)NMX_OUT_PARTIAL) | NMX_OUT_PARTIAL,
+              partials.data() + 128 * i, nullptr);
+  });
+  stat_add(NMX_STAT_SHARDED_CALLS, 1);
+  o.point_sum(partials.data(), used.size(), flags, out, inf);
 }
 
 struct OrFn {  // OR of all u64 scalars -> bit length of the maximum
@@ -205,9 +401,6 @@ template <class Fn> static int guarded(Fn&& fn) {
   }
 }
 
-static MsmCall field_call(const void* scalars, uint32_t flags) {
-  return MsmCall{scalars, (flags & NMX_SCALARS_DEVICE) != 0, (flags & NMX_SCALARS_MONT) != 0, 0, false};
-}
 
 // ---------------------------------------------------------------------------------------------------
 // Slice cache: device residency for the trait's slice-form calls (include/nova_mi355x.h, "Slice form").
@@ -350,8 +543,8 @@ static SliceKey slice_key(Ctx& c, const CurveOps& o, int curve, const void* base
   e.host = b;
   e.n = n;
   e.fingerprint();
-  e.bs = make_key(curve, n, [&](BaseSet& bs) {
-    o.upload(c, bs, bases, (flags & NMX_BASES_MONT) | NMX_BASES_PRECOMPUTE, nullptr);
+  e.bs = build_key(c, curve, n, true, true, [&](Ctx& cx, BaseSet& part, size_t begin) {
+    o.upload(cx, part, (const char*)bases + 64 * begin, (flags & NMX_BASES_MONT) | NMX_BASES_PRECOMPUTE, nullptr);
   });
   stat_add(NMX_STAT_CACHE_UPLOADS);
   if (grow || grow2) stat_add(NMX_STAT_CACHE_REGROWS);
@@ -378,7 +571,9 @@ static std::shared_ptr<BaseSet> temp_key(Ctx& c, const CurveOps& o, int curve, c
                                          uint32_t flags) {
   stat_add(NMX_STAT_UNCACHED_CALLS);
   if (!(flags & NMX_BASES_DEVICE)) stat_add(NMX_STAT_BASE_BYTES_H2D, n * 64);
-  return make_key(curve, n, [&](BaseSet& bs) { o.upload(c, bs, bases, flags & ~(uint32_t)NMX_BASES_PRECOMPUTE, nullptr); });
+  return build_key(c, curve, n, false, false, [&](Ctx& cx, BaseSet& part, size_t) {
+    o.upload(cx, part, bases, flags & ~(uint32_t)NMX_BASES_PRECOMPUTE, nullptr);
+  });
 }
 // the resident (or one-shot) key behind a slice-form call
 static SliceKey resolve_slice(Ctx& c, const CurveOps& o, int curve, const void* bases, size_t n, uint32_t flags) {
@@ -422,6 +617,7 @@ int nmx_shutdown(void) {
       cache_publish_gauges();
     }
     for (Ctx* c : G.all_ctx) {
+      (void)hipSetDevice(hip_device_of(c->dev));
       if (c->arena) (void)hipFree(c->arena);
       if (c->aux) (void)hipFree(c->aux);
       if (c->pinned) (void)hipHostFree(c->pinned);
@@ -432,6 +628,8 @@ int nmx_shutdown(void) {
     }
     G.all_ctx.clear();
     G.free_ctx.clear();
+    G.hip_dev.clear();
+    G.ndev_active.store(1);
     G.inited = false;
   });
 }
@@ -439,6 +637,48 @@ int nmx_shutdown(void) {
 int nmx_device_count(void) {
   int cnt = 0;
   if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
+  return cnt;
+}
+
+int nmx_init_devices(int count, uint32_t flags) {
+  return guarded([&] {
+    ensure_init();
+    int phys = 0;
+    HIPCHK(hipGetDeviceCount(&phys));
+    require(count >= 0 && (size_t)count <= Global::kMaxDevices, NMX_E_ARG, "device count out of range");
+    if (count == 0) count = phys;
+    const bool over = (flags & NMX_DEVICES_OVERSUBSCRIBE) != 0;
+    if (count > phys && !over)
+      throw Fail{NMX_E_NO_DEVICE, "nmx_init_devices: " + std::to_string(count) + " devices requested, " +
+                                      std::to_string(phys) + " visible"};
+    std::lock_guard<std::mutex> lk(G.mu);
+    // logical device i -> HIP device: 0 is the primary chosen by nmx_init, the others count up from it (mod the visible
+    // devices when oversubscribed); existing entries never change, so keys registered earlier stay valid
+    for (size_t i = G.hip_dev.size(); i < (size_t)count; i++) G.hip_dev.push_back((G.device + (int)i) % phys);
+    for (int i = 0; i < count; i++)
+      require(over || G.hip_dev[(size_t)i] == (G.device + i) % phys, NMX_E_ARG, "device map changed between calls");
+    if (!over) {  // distinct GPUs only: the map must not wrap
+      for (int i = 1; i < count; i++) require(G.hip_dev[(size_t)i] != G.device, NMX_E_NO_DEVICE, "not enough devices after the primary");
+    }
+    G.ndev_active.store((uint32_t)count);
+  });
+}
+int nmx_devices_in_use(void) { return (int)G.ndev_active.load(); }
+int nmx_shard_plan(size_t n_key, int k, size_t offset, size_t n, size_t* out_triples, int cap) {
+  if (k < 1 || offset > n_key || n > n_key - offset) return NMX_E_ARG;
+  int cnt = 0;
+  for (int i = 0; i < k && n; i++) {
+    const PartRange r = shard_range(n_key, (uint32_t)i, (uint32_t)k);
+    const size_t b = r.begin, e = r.begin + r.n;
+    const size_t lo = offset > b ? offset : b, hi = offset + n < e ? offset + n : e;
+    if (lo >= hi) continue;
+    if (out_triples && cnt < cap) {
+      out_triples[3 * cnt] = (size_t)i;
+      out_triples[3 * cnt + 1] = lo - b;
+      out_triples[3 * cnt + 2] = hi - lo;
+    }
+    cnt++;
+  }
   return cnt;
 }
 
@@ -450,7 +690,10 @@ int nmx_bases_register(int curve, const void* bases, size_t n, uint32_t flags, u
     require(handle && (bases || n == 0), NMX_E_ARG, "null argument");
     const CurveOps& o = ops(curve);
     CtxLease L;
-    *handle = publish(make_key(curve, n, [&](BaseSet& bs) { o.upload(*L.c, bs, bases, flags, nullptr); }));
+    // (a device-resident source array lives on one device: such keys stay whole)
+    *handle = publish(build_key(*L.c, curve, n, !(flags & NMX_BASES_DEVICE), true, [&](Ctx& cx, BaseSet& part, size_t begin) {
+      o.upload(cx, part, (const char*)bases + 64 * begin, flags, nullptr);
+    }));
   });
 }
 
@@ -467,9 +710,12 @@ int nmx_bases_register_ptau(int curve, const char* path, size_t num_g1, size_t n
     ptau_read_header(fc.f, o.base_modulus_words, num_g1, num_g2);
     seek_to(fc.f, meta.pos_tau_g1);
     CtxLease L;
-    const BaseFill fill = file_fill(fc.f, num_g1);
     const uint32_t fl = (flags & NMX_BASES_PRECOMPUTE) | NMX_BASES_MONT | NMX_BASES_VALIDATE;
-    *handle = publish(make_key(curve, num_g1, [&](BaseSet& bs) { o.upload(*L.c, bs, nullptr, fl, &fill); }));
+    // shards are read in file order, one after the other (the file position advances through them)
+    *handle = publish(build_key(*L.c, curve, num_g1, true, false, [&](Ctx& cx, BaseSet& part, size_t) {
+      const BaseFill fill = file_fill(fc.f, part.n);
+      o.upload(cx, part, nullptr, fl, &fill);
+    }));
   });
 }
 
@@ -490,9 +736,11 @@ int nmx_bases_register_keyfile(int curve, const char* path, size_t n, uint32_t f
     require(o.check_point_host(h_raw, NMX_BASES_MONT, h_canon), NMX_E_POINT,
             "PointNotOnCurve: h is not canonical or not on the curve");
     CtxLease L;
-    const BaseFill fill = file_fill(fc.f, n);
     const uint32_t fl = (flags & NMX_BASES_PRECOMPUTE) | NMX_BASES_MONT | NMX_BASES_VALIDATE;
-    auto bs = make_key(curve, n, [&](BaseSet& b) { o.upload(*L.c, b, nullptr, fl, &fill); });
+    auto bs = build_key(*L.c, curve, n, true, false, [&](Ctx& cx, BaseSet& part, size_t) {
+      const BaseFill fill = file_fill(fc.f, part.n);
+      o.upload(cx, part, nullptr, fl, &fill);
+    });
     memcpy(h_xy64, h_canon, 64);
     *handle = publish(std::move(bs));
   });
@@ -517,10 +765,18 @@ int nmx_bases_read(uint64_t handle, size_t offset, size_t n, void* out_xy64) {
     require(out_xy64 || n == 0, NMX_E_ARG, "null argument");
     auto bs = lookup(handle);
     require(slice_ok(*bs, offset, n), NMX_E_HANDLE, "offset + n beyond the registered key");
-    CtxLease L;
-    HIPCHK(hipMemcpyAsync(out_xy64, (const char*)bs->d + offset * 64, n * 64, hipMemcpyDeviceToHost,
-                          L.c->stream));
-    HIPCHK(hipStreamSynchronize(L.c->stream));
+    auto copy_back = [&](const BaseSet& part, size_t poff, size_t cnt, size_t goff) {
+      CtxLease L(part.dev);
+      HIPCHK(hipMemcpyAsync((char*)out_xy64 + goff * 64, (const char*)part.d + poff * 64, cnt * 64, hipMemcpyDeviceToHost,
+                            L.c->stream));
+      HIPCHK(hipStreamSynchronize(L.c->stream));
+    };
+    if (bs->parts.empty()) {
+      if (n) copy_back(*bs, offset, n, 0);
+    } else {
+      for (const PartJob& j : parts_of(*bs, offset, n)) copy_back(*j.part, j.poff, j.cnt, j.goff);
+      (void)hipSetDevice(G.device);
+    }
     ops(bs->curve).internal_to_canonical((uint8_t*)out_xy64, 2 * n);
   });
 }
@@ -531,7 +787,9 @@ int nmx_bases_generate(int curve, uint64_t k0, size_t n, uint32_t flags, uint64_
     require(n < (1ull << 31) && k0 < (1ull << 62), NMX_E_ARG, "k0 / n out of range");
     const CurveOps& o = ops(curve);
     CtxLease L;
-    *handle = publish(make_key(curve, n, [&](BaseSet& bs) { o.generate(*L.c, bs, k0, flags); }));
+    *handle = publish(build_key(*L.c, curve, n, true, true, [&](Ctx& cx, BaseSet& part, size_t begin) {
+      o.generate(cx, part, k0 + begin, flags);
+    }));
   });
 }
 
@@ -543,7 +801,7 @@ int nmx_msm_handle(uint64_t handle, size_t offset, const void* scalars, size_t n
     require(slice_ok(*bs, offset, n), NMX_E_HANDLE, "offset + n beyond the registered key");
     CtxLease L;
     stat_add(NMX_STAT_MSM_CALLS);
-    ops(bs->curve).msm_key(*L.c, *bs, offset, n, field_call(scalars, flags), flags, out, out_is_inf);
+    key_msm(*L.c, *bs, offset, n, field_call(scalars, flags), flags, out, out_is_inf);
   });
 }
 
@@ -555,7 +813,7 @@ int nmx_msm(int curve, const void* scalars, const void* bases, size_t n, uint32_
     CtxLease L;
     const SliceKey k = resolve_slice(*L.c, o, curve, bases, n, flags);
     stat_add(NMX_STAT_MSM_CALLS);
-    o.msm_key(*L.c, *k.bs, k.offset, n, field_call(scalars, flags), flags, out, out_is_inf);
+    key_msm(*L.c, *k.bs, k.offset, n, field_call(scalars, flags), flags, out, out_is_inf);
   });
 }
 
@@ -570,7 +828,7 @@ int nmx_msm_u64_handle(uint64_t handle, size_t offset, const uint64_t* scalars, 
     uint32_t bits = resolve_u64_bits(*L.c, scalars, n, dev, max_num_bits);
     MsmCall mc{scalars, dev, false, bits, true};
     stat_add(NMX_STAT_MSM_CALLS);
-    ops(bs->curve).msm_key(*L.c, *bs, offset, n, mc, flags, out, out_is_inf);
+    key_msm(*L.c, *bs, offset, n, mc, flags, out, out_is_inf);
   });
 }
 
@@ -585,7 +843,7 @@ int nmx_msm_u64(int curve, const uint64_t* scalars, const void* bases, size_t n,
     MsmCall mc{scalars, dev, false, bits, true};
     const SliceKey k = resolve_slice(*L.c, o, curve, bases, n, flags);
     stat_add(NMX_STAT_MSM_CALLS);
-    o.msm_key(*L.c, *k.bs, k.offset, n, mc, flags, out, out_is_inf);
+    key_msm(*L.c, *k.bs, k.offset, n, mc, flags, out, out_is_inf);
   });
 }
 
@@ -601,11 +859,8 @@ int nmx_msm_sparse_handle(uint64_t handle, const uint64_t* indices, const void* 
       idx[i] = (uint32_t)indices[i];
     }
     CtxLease L;
-    MsmCall mc = scalars ? field_call(scalars, flags) : MsmCall{nullptr, false, false, 1, true};
-    mc.gather_host = idx.data();
-    mc.all_ones = scalars == nullptr;
     stat_add(NMX_STAT_MSM_CALLS);
-    ops(bs->curve).msm_key(*L.c, *bs, 0, k, mc, flags, out, out_is_inf);
+    key_msm_sparse(*L.c, *bs, idx.data(), scalars, k, flags, out, out_is_inf);
   });
 }
 
@@ -617,13 +872,6 @@ int nmx_msm_sparse_handle(uint64_t handle, const uint64_t* indices, const void* 
 // own context (stream + workspace): independent runs overlap on the GPU -- the latency-bound fold / reduction passes
 // of one under the accumulate kernel of another.
 static constexpr size_t kBatchLanes = 4;
-struct JoinAll {  // unwinding must never destroy a joinable std::thread (std::terminate)
-  std::vector<std::thread>& th;
-  ~JoinAll() {
-    for (auto& t : th)
-      if (t.joinable()) t.join();
-  }
-};
 static void batch_impl(const BaseSet& bs, size_t base_off, size_t n_bases, const void* const* vecs, const size_t* lens,
                        size_t k, uint32_t flags, uint8_t* out, uint8_t* out_is_inf, Ctx& c) {
   require((vecs && lens && out) || k == 0, NMX_E_ARG, "null argument");
@@ -632,6 +880,16 @@ static void batch_impl(const BaseSet& bs, size_t base_off, size_t n_bases, const
   for (size_t j = 0; j < k; j++) {
     require(lens[j] <= n_bases, NMX_E_ARG, "vector longer than the base array");  // traits.rs:88 slices bases[..len]
     require(vecs[j] || lens[j] == 0, NMX_E_ARG, "null scalar vector");
+  }
+  if (!bs.parts.empty()) {  // multi-device key: every vector is a sharded MSM of its own, all devices busy with each
+    std::vector<uint8_t> tmp(64 * (k ? k : 1)), tinf(k ? k : 1);
+    for (size_t j = 0; j < k; j++) {
+      stat_add(NMX_STAT_MSM_CALLS);
+      key_msm(c, bs, base_off, lens[j], field_call(vecs[j], flags), flags, tmp.data() + 64 * j, tinf.data() + j);
+    }
+    memcpy(out, tmp.data(), 64 * k);
+    if (out_is_inf) memcpy(out_is_inf, tinf.data(), k);
+    return;
   }
   std::vector<size_t> order(k);
   for (size_t j = 0; j < k; j++) order[j] = j;
@@ -722,8 +980,7 @@ static void batch_impl(const BaseSet& bs, size_t base_off, size_t n_bases, const
               record(Fail{NMX_E_HIP, "unknown exception in a batch worker"});
             }
           });
-      } catch (const std::exception& e) {  // std::system_error from thread creation: run with the lanes we have
-        record(Fail{NMX_E_HIP, std::string("cannot start a batch worker thread: ") + e.what()});
+      } catch (const std::exception&) {  // std::system_error from thread creation: run with the lanes we have
       }
       guarded_worker(&c);
     }
@@ -766,14 +1023,32 @@ int nmx_commit(uint64_t ck_handle, const void* v, size_t n, const void* h_xy64, 
     require(n <= bs->n, NMX_E_HANDLE, "ck shorter than v");  // assert!(ck.ck.len() >= v.len()), pedersen.rs:264
     CtxLease L;
     stat_add(NMX_STAT_MSM_CALLS);
-    ops(bs->curve).commit(*L.c, *bs, n, field_call(v, flags), h_xy64, r, flags, out, out_is_inf);
+    const CurveOps& o = ops(bs->curve);
+    if (bs->parts.empty()) {
+      o.commit(*L.c, *bs, n, field_call(v, flags), h_xy64, r, flags, out, out_is_inf);
+    } else {  // sharded key: the blinding term is one more partial, computed on the host under the device MSMs
+      uint8_t two[256];
+      std::array<uint8_t, 64> hb;
+      std::array<uint8_t, 32> rb;
+      memcpy(hb.data(), h_xy64, 64);
+      memcpy(rb.data(), r, 32);
+      auto hr = std::async(std::launch::async, [&o, hb, rb, flags] {
+        std::array<uint8_t, 128> t;
+        o.blind_term(hb.data(), rb.data(), flags, t.data());
+        return t;
+      });
+      key_msm(*L.c, *bs, 0, n, field_call(v, flags), flags | NMX_OUT_PARTIAL, two, nullptr);
+      const auto t = hr.get();  // (an out-of-range r surfaces here, NMX_E_SCALAR_RANGE, before anything is written)
+      memcpy(two + 128, t.data(), 128);
+      o.point_sum(two, 2, flags, out, out_is_inf);
+    }
   });
 }
 
 int nmx_point_sum(int curve, const uint8_t* partials128, size_t count, uint8_t* out, uint8_t* out_is_inf) {
   return guarded([&] {
     require(out && (partials128 || count == 0), NMX_E_ARG, "null argument");
-    ops(curve).point_sum(partials128, count, out, out_is_inf);
+    ops(curve).point_sum(partials128, count, 0, out, out_is_inf);
   });
 }
 
@@ -1113,6 +1388,8 @@ int nmx_set_option(const char* name, uint32_t value) {
     else if (n == "no_quad_final") G.no_quad_final = value;
     else if (n == "accum_prefetch") G.accum_prefetch = value;
     else if (n == "no_batch_fuse") G.no_batch_fuse = value;
+    else if (n == "no_tree_fuse") G.no_tree_fuse = value;
+    else if (n == "shard_min_n") G.shard_min_n.store(value ? value : 1u);
     else if (n == "horner_top") G.horner_top = value;
     else if (n == "seg_heavy_above") G.seg_heavy_above = value > 63u ? 63u : value;
     else throw Fail{NMX_E_ARG, "unknown option name"};

@@ -123,24 +123,25 @@ template <int FID> struct XYZZ {
   }
 
   // dbl-2008-s-1 with a = 0 (msm.rs:65-88).                                     bound (x p)
-  NMX_HD void dbl_in_place() {
+  // LAT (here and below): the latency-oriented products of fp.hpp (kernels that run one or two waves per SIMD)
+  template <bool LAT = false> NMX_HD void dbl_in_place() {
     if (is_identity()) return;
     // a point of order 2 (y == 0) cannot occur on these prime-order curves
     F u = y.dbl().norm();                          //  7.0
-    F v = u.sqr();                                 //  1 + 49/127      < 1.39
-    F w = u * v;                                   //  1 + 9.8/127     < 1.08
-    F s = x * v;                                   //  1 + 7.4/127     < 1.06
-    F xx = x.sqr();                                //  1 + 28.1/127    < 1.23
+    F v = F::template sqrx<LAT>(u);                                 //  1 + 49/127      < 1.39
+    F w = F::template mulx<LAT>(u, v);                                   //  1 + 9.8/127     < 1.08
+    F s = F::template mulx<LAT>(x, v);                                   //  1 + 7.4/127     < 1.06
+    F xx = F::template sqrx<LAT>(x);                                //  1 + 28.1/127    < 1.23
     F m = (xx.dbl() + xx).norm();                  //  3.69
     F s2 = s.dbl().norm();                         //  2.12
-    F x3 = F::sub4(m.sqr(), s2).norm();            //  1.11 + 4        < 5.11
+    F x3 = F::sub4(F::template sqrx<LAT>(m), s2).norm();            //  1.11 + 4        < 5.11
     F e = F::sub8(s, x3).norm();                   //  1.06 + 8        < 9.06
     F ny = F::sub4(F::zero(), y);                  //  4p - y in (0.5, 4], limbs < 2^31 (left un-normalized)
-    F y3 = F::mul_add(m, e, w, ny);                //  m*e - w*y:  1 + (33.5 + 4.4)/127 < 1.3   [one reduction]
+    F y3 = F::template mul_addx<LAT>(m, e, w, ny);                //  m*e - w*y:  1 + (33.5 + 4.4)/127 < 1.3   [one reduction]
     x = x3;
     y = y3;
-    zz = zz * v;                                   //  1 + 1.67/127    < 1.02
-    zzz = zzz * w;                                 //  < 1.02
+    zz = F::template mulx<LAT>(zz, v);                                   //  1 + 1.67/127    < 1.02
+    zzz = F::template mulx<LAT>(zzz, w);                                 //  < 1.02
 #ifdef NMX_BOUND_CHECKS
     check();
 #endif
@@ -148,7 +149,7 @@ template <int FID> struct XYZZ {
 
   // madd-2008-s (msm.rs:129-165): this += (px, py), the affine operand non-identity.
   // px canonical (< p); py < 2p normalized (a canonical y, or 2p - y for a negated point).
-  NMX_HD void add_affine(const F& px, const F& py) {
+  template <bool LAT = false> NMX_HD void add_affine(const F& px, const F& py) {
     if (is_identity()) {
       x = px;
       y = py;
@@ -156,31 +157,31 @@ template <int FID> struct XYZZ {
       zzz = F::one();
       return;
     }
-    F u2 = px * zz;                                //  1 + 1.2/127     < 1.01
-    F s2 = py * zzz;                               //  1 + 2.4/127     < 1.02
+    F u2 = F::template mulx<LAT>(px, zz);                                //  1 + 1.2/127     < 1.01
+    F s2 = F::template mulx<LAT>(py, zzz);                               //  1 + 2.4/127     < 1.02
     F d = F::sub8(u2, x).norm();                   //  in (2.7, 9.01)             [x < 5.3 < 8]
     if (d.maybe_zero_mod_p()) {                    //  taken with probability 2^-29 unless u2 == x
       if (F::eq_mod_p(u2, x)) {
         if (F::eq_mod_p(s2, y))
-          dbl_in_place();                          //  P == Q   (msm.rs:148-150)
+          dbl_in_place<LAT>();                          //  P == Q   (msm.rs:148-150)
         else
           *this = identity();                      //  P == -Q  (msm.rs:151-153)
         return;
       }
     }
     F r = F::sub4(s2, y).norm();                   //  1.02 + 4        < 5.02     [y < 3.5 < 4]
-    F pp = d.sqr();                                //  1 + 81.2/127    < 1.64
-    F ppp = d * pp;                                //  1 + 14.8/127    < 1.12
-    F q = x * pp;                                  //  1 + 8.7/127     < 1.07
+    F pp = F::template sqrx<LAT>(d);                                //  1 + 81.2/127    < 1.64
+    F ppp = F::template mulx<LAT>(d, pp);                                //  1 + 14.8/127    < 1.12
+    F q = F::template mulx<LAT>(x, pp);                                  //  1 + 8.7/127     < 1.07
     F t = (ppp + q.dbl()).norm();                  //  3.26
-    F x3 = F::sub4(r.sqr(), t).norm();             //  (1 + 25.2/127) + 4 < 5.2
+    F x3 = F::sub4(F::template sqrx<LAT>(r), t).norm();             //  (1 + 25.2/127) + 4 < 5.2
     F e = F::sub8(q, x3).norm();                   //  1.07 + 8        < 9.07
     F ny = F::sub4(F::zero(), y);                  //  4p - y in (0.5, 4], limbs < 2^31 (left un-normalized)
-    F y3 = F::mul_add(r, e, ppp, ny);              //  r*e - y*ppp:  1 + (45.6 + 4.5)/127 < 1.4  [one reduction]
+    F y3 = F::template mul_addx<LAT>(r, e, ppp, ny);              //  r*e - y*ppp:  1 + (45.6 + 4.5)/127 < 1.4  [one reduction]
     x = x3;
     y = y3;
-    zz = zz * pp;                                  //  1 + 1.97/127    < 1.02
-    zzz = zzz * ppp;                               //  < 1.02
+    zz = F::template mulx<LAT>(zz, pp);                                  //  1 + 1.97/127    < 1.02
+    zzz = F::template mulx<LAT>(zzz, ppp);                               //  < 1.02
 #ifdef NMX_BOUND_CHECKS
     check();
 #endif
@@ -188,49 +189,49 @@ template <int FID> struct XYZZ {
   // affine operand as loaded from HBM; negate = the sign of a signed window digit
   // The sign is applied with a per-limb select, NOT a branch: lanes of one wave carry digits of both signs, and
   // two call sites of the (fully inlined) addition would make every wave execute it twice.
-  NMX_HD void add_affine(const Affine<FID>& p, bool negate = false) {
+  template <bool LAT = false> NMX_HD void add_affine(const Affine<FID>& p, bool negate = false) {
     if (p.is_identity()) return;  // msm.rs:130-132
     F ny = F::sub2(F::zero(), p.y).norm();  // 2p - y in (p, 2p]
     F y;
 #pragma unroll
     for (int i = 0; i < 9; i++) y.l[i] = negate ? ny.l[i] : p.y.l[i];
-    add_affine(p.x, y);
+    add_affine<LAT>(p.x, y);
   }
 
   // add-2008-s (msm.rs:91-123): this += o, both operands within the in-register invariants.
-  NMX_HD void add(const XYZZ& o) {
+  template <bool LAT = false> NMX_HD void add(const XYZZ& o) {
     if (o.is_identity()) return;
     if (is_identity()) {
       *this = o;
       return;
     }
-    F u1 = x * o.zz;                               //  1 + 6.4/127     < 1.06
-    F u2 = o.x * zz;                               //  < 1.06
-    F s1 = y * o.zzz;                              //  1 + 4.2/127     < 1.04
-    F s2 = o.y * zzz;                              //  < 1.04
+    F u1 = F::template mulx<LAT>(x, o.zz);                               //  1 + 6.4/127     < 1.06
+    F u2 = F::template mulx<LAT>(o.x, zz);                               //  < 1.06
+    F s1 = F::template mulx<LAT>(y, o.zzz);                              //  1 + 4.2/127     < 1.04
+    F s2 = F::template mulx<LAT>(o.y, zzz);                              //  < 1.04
     F d = F::sub2(u2, u1).norm();                  //  in (0.94, 3.06)
     if (d.maybe_zero_mod_p()) {
       if (F::eq_mod_p(u1, u2)) {
         if (F::eq_mod_p(s1, s2))
-          dbl_in_place();                          //  msm.rs:106-108
+          dbl_in_place<LAT>();                          //  msm.rs:106-108
         else
           *this = identity();                      //  msm.rs:109-111
         return;
       }
     }
     F r = F::sub2(s2, s1).norm();                  //  3.04
-    F pp = d.sqr();                                //  1 + 9.4/127     < 1.08
-    F ppp = d * pp;                                //  < 1.03
-    F q = u1 * pp;                                 //  < 1.01
+    F pp = F::template sqrx<LAT>(d);                                //  1 + 9.4/127     < 1.08
+    F ppp = F::template mulx<LAT>(d, pp);                                //  < 1.03
+    F q = F::template mulx<LAT>(u1, pp);                                 //  < 1.01
     F t = (ppp + q.dbl()).norm();                  //  3.05
-    F x3 = F::sub4(r.sqr(), t).norm();             //  (1 + 9.3/127) + 4 < 5.08
+    F x3 = F::sub4(F::template sqrx<LAT>(r), t).norm();             //  (1 + 9.3/127) + 4 < 5.08
     F e = F::sub8(q, x3).norm();                   //  < 9.01
     F ns1 = F::sub2(F::zero(), s1);                //  2p - s1 in (0.9, 2], limbs < 2^31 (left un-normalized)
-    F y3 = F::mul_add(r, e, ppp, ns1);             //  r*e - s1*ppp:  1 + (27.4 + 2.1)/127 < 1.24 [one reduction]
+    F y3 = F::template mul_addx<LAT>(r, e, ppp, ns1);             //  r*e - s1*ppp:  1 + (27.4 + 2.1)/127 < 1.24 [one reduction]
     x = x3;
     y = y3;
-    zz = (zz * o.zz) * pp;                         //  < 1.02
-    zzz = (zzz * o.zzz) * ppp;                     //  < 1.02
+    zz = F::template mulx<LAT>(F::template mulx<LAT>(zz, o.zz), pp);                         //  < 1.02
+    zzz = F::template mulx<LAT>(F::template mulx<LAT>(zzz, o.zzz), ppp);                     //  < 1.02
 #ifdef NMX_BOUND_CHECKS
     check();
 #endif

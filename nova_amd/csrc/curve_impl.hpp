@@ -104,8 +104,9 @@ template <int CID> struct GenFn {  // P_i = (k0 + i) * G
 // ---------------------------------------------------------------------------------------------------
 // one MSM on the device
 // ---------------------------------------------------------------------------------------------------
-static inline uint64_t shape_hash(const MsmArgs& a, const MsmCall& mc, size_t sbytes) {
-  const uint64_t v[10] = {a.n, a.u64_bits, a.force_c, a.force_lmax, a.force_fold_t, ((uint64_t)a.pre_stride << 8) | a.pre_c,
+static inline uint64_t shape_hash(const MsmArgs& a, const MsmCall& mc, size_t sbytes, uint32_t cid, uint32_t sbits,
+                                  uint32_t seg_lanes) {
+  const uint64_t v[11] = {((uint64_t)cid << 56) | ((uint64_t)sbits << 40) | seg_lanes, a.n, a.u64_bits, a.force_c, a.force_lmax, a.force_fold_t, ((uint64_t)a.pre_stride << 8) | a.pre_c,
                           (uint64_t)(mc.gather_host != nullptr) | (mc.all_ones ? 2u : 0u) | (mc.scalars_device ? 4u : 0u) |
                               (a.no_partition ? 8u : 0u),
                           sbytes, a.seg_min_total, G.seg_lanes_override ^ ((uint64_t)a.seg_heavy_above << 32)};
@@ -146,7 +147,8 @@ static XYZZ<CurveT<CID>::BF> run_msm(Ctx& c, const void* d_bases, size_t n, cons
   // gathers in flight per lane: one is enough while the key's tables (W x 64 B per point) mostly hit the 256 MB Infinity Cache
   // and L2; from ~6 GiB of tables on the gather latency shows and a second row in flight pays (2^24: accumulate 17.6 ->
   // 16.0 ms; neutral at 2^22, slightly worse at 2^20 / 2^21: profiles/r02_msm_2p20/prefetch_depth.txt)
-  a.accum_prefetch = G.accum_prefetch ? G.accum_prefetch
+  const uint32_t pf_opt = G.accum_prefetch.load(std::memory_order_relaxed);
+  a.accum_prefetch = pf_opt ? pf_opt
                                       : ((uint64_t)mc.pre_stride * 64u * ((FpParams<SF>::BITS + 1 + (mc.pre_c ? mc.pre_c : 16) - 1) /
                                                                          (mc.pre_c ? mc.pre_c : 16)) >= (6ull << 30) ? 2u : 1u);
   {
@@ -162,7 +164,9 @@ static XYZZ<CurveT<CID>::BF> run_msm(Ctx& c, const void* d_bases, size_t n, cons
   MsmShape sh{};
   const bool prof = G.profiling.load(std::memory_order_relaxed);
   // The dry pass only sizes the workspace; its answer is a function of the call's shape, remembered per context.
-  const uint64_t shape_key = shape_hash(a, mc, sbytes);
+  const uint64_t shape_key = shape_hash(a, mc, sbytes, (uint32_t)CID, sbits, DeviceBackend(c, true, false).template seg_lanes<BF>());
+  // A remembered workspace size that turns out too small (a stale entry) is not fatal: forget it and size again.
+  for (int attempt = 0; attempt < 2; attempt++) try {
   for (int pass = (c.shape_key == shape_key && c.shape_bytes <= c.cap) ? 1 : 0; pass < 2; pass++) {
     DeviceBackend be(c, pass == 0, prof);
     if (mc.gather_host) {
@@ -196,6 +200,12 @@ static XYZZ<CurveT<CID>::BF> run_msm(Ctx& c, const void* d_bases, size_t n, cons
       }
       prof_store(st, ns);
     }
+  }
+  break;
+  } catch (const Fail& f) {
+    if (attempt == 1 || f.msg != "workspace arena overflow") throw;
+    (void)hipStreamSynchronize(c.stream);
+    c.shape_key = 0;
   }
   require(!(err & ERR_SCALAR_RANGE), NMX_E_SCALAR_RANGE, "scalar >= field modulus");
   require(!(err & ERR_SMALL_RANGE), NMX_E_SMALL_RANGE, "small scalar >= 2^max_num_bits");
@@ -375,13 +385,18 @@ static void run_msm_batch(Ctx& c, const BaseSet& bs, size_t offset, const BatchI
   a.seg_min_total = G.seg_min_total;
   a.seg_min_len = G.seg_min_len;
   a.seg_heavy_above = G.seg_heavy_above;
-  a.accum_prefetch = G.accum_prefetch ? G.accum_prefetch : 1u;
+  {
+    const uint32_t pf = G.accum_prefetch.load(std::memory_order_relaxed);
+    a.accum_prefetch = pf ? pf : 1u;
+  }
   a.batch_k = (uint32_t)k;
   c.wsum.resize(260);
   XYZZW* wsum = c.wsum.data();
   uint32_t err = 0;
   const bool prof = G.profiling.load(std::memory_order_relaxed);
-  const uint64_t shape_key = (shape_hash(a, shared, 32) ^ lens_hash ^ (k << 48)) | 1u;
+  const uint64_t shape_key =
+      (shape_hash(a, shared, 32, (uint32_t)CID, sbits, DeviceBackend(c, true, false).template seg_lanes<BF>()) ^ lens_hash ^ (k << 48)) | 1u;
+  for (int attempt = 0; attempt < 2; attempt++) try {
   for (int pass = (c.shape_key == shape_key && c.shape_bytes <= c.cap) ? 1 : 0; pass < 2; pass++) {
     DeviceBackend be(c, pass == 0, prof);
     uint32_t* d_off = be.alloc<uint32_t>(k + 1);
@@ -418,6 +433,12 @@ static void run_msm_batch(Ctx& c, const BaseSet& bs, size_t offset, const BatchI
       prof_store(st, ns);
     }
   }
+  break;
+  } catch (const Fail& f) {
+    if (attempt == 1 || f.msg != "workspace arena overflow") throw;
+    (void)hipStreamSynchronize(c.stream);
+    c.shape_key = 0;
+  }
   require(!(err & ERR_SCALAR_RANGE), NMX_E_SCALAR_RANGE, "scalar >= field modulus");
   for (size_t j = 0; j < k; j++) results[j] = XYZZ<BF>::load(wsum[j]);
 }
@@ -447,29 +468,46 @@ template <int CID> struct CurveImpl {
     for (size_t j = 0; j < k; j++) write_result<CID>(r[j], flags, out + 64 * j, inf ? inf + j : nullptr);
   }
   static uint32_t batch_limit(const BaseSet& bs) { return batch_limit_for<CID>(bs); }
-  static void commit(Ctx& c, const BaseSet& bs, size_t n, const MsmCall& mc, const void* h_xy64, const void* r,
-                     uint32_t flags, uint8_t* out, uint8_t* inf) {
-    // the blinding term h * r is ~380 host point operations (0.1-0.2 ms): computed on a second host thread while the
-    // GPU runs the MSM, so a blinded commit costs what an unblinded one does
+  // h * r on the host (~380 point operations, 0.1-0.2 ms); identity when r == 0
+  static XYZZ<BF> blind_point(const void* h_xy64, const void* r, uint32_t flags) {
     uint32_t rw[8];
     memcpy(rw, r, 32);
     require(Fp<SF>::words_lt_p(rw), NMX_E_SCALAR_RANGE, "blinding scalar >= field modulus");
     if (flags & NMX_SCALARS_MONT) Fp<SF>::from_words(rw).mont256_to_canonical().to_words(rw);
     uint32_t any = 0;
     for (int i = 0; i < 8; i++) any |= rw[i];
+    if (!any) return XYZZ<BF>::identity();
+    Affine<BF> h;
+    h.x = fp_from_bytes<BF>((const uint8_t*)h_xy64);
+    h.y = fp_from_bytes<BF>((const uint8_t*)h_xy64 + 32);
+    if (!h.is_identity()) {
+      const bool m = (flags & NMX_BASES_MONT) != 0;
+      h.x = (m ? h.x.mont256_to_internal() : h.x.to_internal()).canon();
+      h.y = (m ? h.y.mont256_to_internal() : h.y.to_internal()).canon();
+    }
+    return scalar_mul<BF>(XYZZ<BF>::from_affine(h), rw);
+  }
+  static void blind_term(const void* h_xy64, const void* r, uint32_t flags, uint8_t* out128) {
+    XYZZW w;
+    blind_point(h_xy64, r, flags).store(w);
+    memcpy(out128, w.w, 128);
+  }
+  static void commit(Ctx& c, const BaseSet& bs, size_t n, const MsmCall& mc, const void* h_xy64, const void* r,
+                     uint32_t flags, uint8_t* out, uint8_t* inf) {
+    // the blinding term is computed on a second host thread while the GPU runs the MSM, so a blinded commit costs what
+    // an unblinded one does; the range check of r happens before anything is launched
+    uint32_t rw[8];
+    memcpy(rw, r, 32);
+    require(Fp<SF>::words_lt_p(rw), NMX_E_SCALAR_RANGE, "blinding scalar >= field modulus");
+    uint32_t any = 0;
+    for (int i = 0; i < 8; i++) any |= rw[i];
     std::future<XYZZ<BF>> hr;
     if (any) {
-      Affine<BF> h;
-      h.x = fp_from_bytes<BF>((const uint8_t*)h_xy64);
-      h.y = fp_from_bytes<BF>((const uint8_t*)h_xy64 + 32);
-      if (!h.is_identity()) {
-        const bool m = (flags & NMX_BASES_MONT) != 0;
-        h.x = (m ? h.x.mont256_to_internal() : h.x.to_internal()).canon();
-        h.y = (m ? h.y.mont256_to_internal() : h.y.to_internal()).canon();
-      }
-      std::array<uint32_t, 8> k;
-      memcpy(k.data(), rw, 32);
-      hr = std::async(std::launch::async, [h, k] { return scalar_mul<BF>(XYZZ<BF>::from_affine(h), k.data()); });
+      std::array<uint8_t, 64> hb;
+      std::array<uint8_t, 32> rb;
+      memcpy(hb.data(), h_xy64, 64);
+      memcpy(rb.data(), r, 32);
+      hr = std::async(std::launch::async, [hb, rb, flags] { return blind_point(hb.data(), rb.data(), flags); });
     }
     auto acc = run_msm_key<CID>(c, bs, 0, n, mc);  // a failure here unwinds through hr's destructor, which joins
     if (any) acc.add(hr.get());
@@ -513,14 +551,14 @@ template <int CID> struct CurveImpl {
       fp_to_bytes(f.to_canonical(), e + 32 * i);
     }
   }
-  static void point_sum(const uint8_t* partials128, size_t count, uint8_t* out, uint8_t* inf) {
+  static void point_sum(const uint8_t* partials128, size_t count, uint32_t flags, uint8_t* out, uint8_t* inf) {
     XYZZ<BF> acc = XYZZ<BF>::identity();
     for (size_t i = 0; i < count; i++) {
       XYZZW w;
       memcpy(w.w, partials128 + 128 * i, 128);
       acc.add(XYZZ<BF>::load(w));
     }
-    xyzz_to_xy64<BF>(acc, out, inf);
+    write_result<CID>(acc, flags, out, inf);
   }
   // nmx_check_layout: raw bytes of the standard generator and of Scalar::from(value) must be x * 2^256 mod p limbs
   static bool check_layout(const uint8_t* gen64, const uint8_t* s32, uint64_t value) {
@@ -540,7 +578,7 @@ template <int CID> struct CurveImpl {
   }
   static CurveOps ops() {
     return CurveOps{&msm_key, &msm_key_batch, &batch_limit, &commit, &upload, &check_point_host, FpParams<BF>::PW,
-                    &generate, &internal_to_canonical, &point_sum, &check_layout};
+                    &generate, &internal_to_canonical, &point_sum, &blind_term, &check_layout};
   }
 };
 

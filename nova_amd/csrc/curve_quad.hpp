@@ -58,35 +58,35 @@ template <int FID> __device__ __forceinline__ Fp<FID> quad_pick(const XYZZ<FID>&
 }
 
 // dbl-2008-s-1 (curve.hpp dbl_in_place), three steps.  c = this lane's coordinate; returns the new one.
-template <int FID> __device__ __forceinline__ Fp<FID> quad_dbl(const Fp<FID>& c, uint32_t q) {
+template <int FID, bool LAT = kLatTail> __device__ __forceinline__ Fp<FID> quad_dbl(const Fp<FID>& c, uint32_t q) {
   using F = Fp<FID>;
   if (qperm_u32<QP_L2>(c.is_zero_limbs() ? 1u : 0u)) return c;  // identity (quad-uniform)
   const F x = qperm<QP_L0>(c), y = qperm<QP_L1>(c);
   const F u = y.dbl().norm();                                   //  7.0
   const F m1 = fsel(q == 0, x, u);
-  const F t1 = m1 * m1;                                         //  l0: xx < 1.23 ; others: v = u^2 < 1.39
+  const F t1 = F::template mulx<LAT>(m1, m1);                                         //  l0: xx < 1.23 ; others: v = u^2 < 1.39
   const F xx = qperm<QP_L0>(t1), v = qperm<QP_L1>(t1);
   const F m = (xx.dbl() + xx).norm();                           //  3.69
   const F a2 = q == 0 ? x : q == 1 ? u : q == 2 ? c : m;
   const F b2 = fsel(q == 3, m, v);
-  const F t2 = a2 * b2;                                         //  l0: s = x*v ; l1: w = u*v ; l2: zz*v ; l3: m^2
+  const F t2 = F::template mulx<LAT>(a2, b2);                                         //  l0: s = x*v ; l1: w = u*v ; l2: zz*v ; l3: m^2
   const F s = qperm<QP_L0>(t2), w = qperm<QP_L1>(t2), mm = qperm<QP_L3>(t2);
   const F x3 = F::sub4(mm, s.dbl().norm()).norm();              //  < 5.11
   const F e = F::sub8(s, x3).norm();                            //  < 9.06
   const F ny = F::sub4(F::zero(), y);                           //  4p - y, limbs < 2^30
-  const F t3 = F::mul_add(fsel(q == 3, c, m), fsel(q == 3, w, e), w, fsel(q == 3, F::zero(), ny));
+  const F t3 = F::template mul_addx<LAT>(fsel(q == 3, c, m), fsel(q == 3, w, e), w, fsel(q == 3, F::zero(), ny));
   //                                                                l1: y3 = m*e - w*y ; l3: zzz*w
   return q == 0 ? x3 : q == 2 ? t2 : t3;
 }
 
 // add-2008-s (curve.hpp add): (c1 coordinates) += (c2 coordinates); returns this lane's coordinate of the sum.
-template <int FID> __device__ __forceinline__ Fp<FID> quad_add(const Fp<FID>& c1, const Fp<FID>& c2, uint32_t q) {
+template <int FID, bool LAT = kLatTail> __device__ __forceinline__ Fp<FID> quad_add(const Fp<FID>& c1, const Fp<FID>& c2, uint32_t q) {
   using F = Fp<FID>;
   if (qperm_u32<QP_L2>(c2.is_zero_limbs() ? 1u : 0u)) return c1;  // += identity
   if (qperm_u32<QP_L2>(c1.is_zero_limbs() ? 1u : 0u)) return c2;  // identity += o
   const bool lo = q < 2;
   const F o2 = qperm<QP_SWAP2>(c2);
-  const F t1 = c1 * o2;                      //  l0: u1 = x1*zz2 ; l1: s1 = y1*zzz2 ; l2: u2 = zz1*x2 ; l3: s2 = zzz1*y2
+  const F t1 = F::template mulx<LAT>(c1, o2);                      //  l0: u1 = x1*zz2 ; l1: s1 = y1*zzz2 ; l2: u2 = zz1*x2 ; l3: s2 = zzz1*y2
   const F tp = qperm<QP_SWAP2>(t1);
   const F a = fsel(lo, tp, t1);              //  the "2" product of this lane's pair (u2 | s2)
   const F b = fsel(lo, t1, tp);              //  the "1" product (u1 | s1)
@@ -94,21 +94,21 @@ template <int FID> __device__ __forceinline__ Fp<FID> quad_add(const Fp<FID>& c1
   if (qperm_u32<QP_L0>(d.maybe_zero_mod_p() ? 1u : 0u)) {
     // p may be 0 mod p (P == +-Q, or a 2^-29 false alarm): single-lane formulas on gathered operands
     XYZZ<FID> A = quad_gather<FID>(c1);
-    A.add(quad_gather<FID>(c2));
+    A.template add<LAT>(quad_gather<FID>(c2));
     return quad_pick<FID>(A, q);
   }
-  const F t2 = fsel(lo, d, c1) * fsel(lo, d, c2);   //  l0: pp ; l1: rr ; l2: zz1*zz2 ; l3: zzz1*zzz2
+  const F t2 = F::template mulx<LAT>(fsel(lo, d, c1), fsel(lo, d, c2));   //  l0: pp ; l1: rr ; l2: zz1*zz2 ; l3: zzz1*zzz2
   const F pp = qperm<QP_L0>(t2);
   const F u1 = qperm<QP_L0>(b);
   const F m3 = q == 0 ? d : q == 1 ? u1 : t2;
-  const F t3 = m3 * pp;                      //  l0: ppp = p*pp ; l1: q = u1*pp ; l2: zz3 ; l3: unused
+  const F t3 = F::template mulx<LAT>(m3, pp);                      //  l0: ppp = p*pp ; l1: q = u1*pp ; l2: zz3 ; l3: unused
   const F ppp = qperm<QP_L0>(t3), qq = qperm<QP_L1>(t3), rr = qperm<QP_L1>(t2);
   const F r = qperm<QP_L1>(d), s1 = qperm<QP_L1>(b);
   const F tt = (ppp + qq.dbl()).norm();      //  3.05
   const F x3 = F::sub4(rr, tt).norm();       //  < 5.08
   const F e = F::sub8(qq, x3).norm();        //  < 9.01
   const F ns1 = F::sub2(F::zero(), s1);      //  2p - s1, limbs < 2^30
-  const F t4 = F::mul_add(fsel(q == 3, t2, r), fsel(q == 3, ppp, e), ppp, fsel(q == 3, F::zero(), ns1));
+  const F t4 = F::template mul_addx<LAT>(fsel(q == 3, t2, r), fsel(q == 3, ppp, e), ppp, fsel(q == 3, F::zero(), ns1));
   //                                             l1: y3 = r*e - s1*ppp ; l3: zzz3 = zzz1*zzz2*ppp
   return q == 0 ? x3 : q == 2 ? t3 : t4;
 }
@@ -121,27 +121,27 @@ template <int FID> __device__ __forceinline__ Fp<FID> quad_add(const Fp<FID>& c1
 //     step 4   [      -      | y3 = r*e - y1*ppp (one reduction) | - | zzz3 = zzz1*ppp ]   x3 = rr-ppp-2q, e = q-x3
 // against 9 dependent multiplications on one lane.  r carries +8p instead of curve.hpp's +4p (one subtraction
 // constant for both lanes): y3 < p * (1 + (9.02*9.07 + 4.5)/127) < 1.7p, inside the y < 3.5p invariant.
-template <int FID> __device__ __forceinline__ Fp<FID> quad_madd(const Fp<FID>& c, const Fp<FID>& o, uint32_t q) {
+template <int FID, bool LAT = kLatTail> __device__ __forceinline__ Fp<FID> quad_madd(const Fp<FID>& c, const Fp<FID>& o, uint32_t q) {
   using F = Fp<FID>;
   if (qperm_u32<QP_L2>(c.is_zero_limbs() ? 1u : 0u)) return q < 2 ? o : F::one();  // identity += P  (msm.rs:133-139)
-  const F t1 = o * c;                              //  l2: u2 < 1.01 ; l3: s2 < 1.02
+  const F t1 = F::template mulx<LAT>(o, c);                              //  l2: u2 < 1.01 ; l3: s2 < 1.02
   const F a = qperm<QP_SWAP2>(t1);                 //  l0: u2 ; l1: s2
   const F d = F::sub8(a, c).norm();                //  l0: p in (2.7, 9.01) ; l1: r < 9.02
   if (qperm_u32<QP_L0>(d.maybe_zero_mod_p() ? 1u : 0u)) {
     // P == +-Q, or a 2^-29 false alarm: single-lane formulas on gathered operands
     XYZZ<FID> A = quad_gather<FID>(c);
-    A.add_affine(qperm<QP_L0>(o), qperm<QP_L1>(o));
+    A.template add_affine<LAT>(qperm<QP_L0>(o), qperm<QP_L1>(o));
     return quad_pick<FID>(A, q);
   }
   const F p = qperm<QP_L0>(d);
-  const F t2 = fsel(q == 1, d, p).sqr();           //  l1: rr < 1.65 ; others: pp < 1.64
-  const F t3 = fsel(q == 3, p, c) * t2;            //  l0: q < 1.07 ; l2: zz3 < 1.02 ; l3: ppp < 1.12
+  const F t2 = F::template sqrx<LAT>(fsel(q == 1, d, p));           //  l1: rr < 1.65 ; others: pp < 1.64
+  const F t3 = F::template mulx<LAT>(fsel(q == 3, p, c), t2);            //  l0: q < 1.07 ; l2: zz3 < 1.02 ; l3: ppp < 1.12
   const F rr = qperm<QP_L1>(t2), ppp = qperm<QP_L3>(t3), qq = qperm<QP_L0>(t3);
   const F tt = (ppp + qq.dbl()).norm();            //  3.26
   const F x3 = F::sub4(rr, tt).norm();             //  < 5.65 ... rr < 1.65: (1.65 + 4) within the x < 8 bound of sub8
   const F e = F::sub8(qq, x3).norm();              //  < 9.07
   const F ny = F::sub4(F::zero(), c);              //  l1: 4p - y1, limbs < 2^31
-  const F t4 = F::mul_add(fsel(q == 3, c, d), fsel(q == 3, t3, e), ppp, fsel(q == 3, F::zero(), ny));
+  const F t4 = F::template mul_addx<LAT>(fsel(q == 3, c, d), fsel(q == 3, t3, e), ppp, fsel(q == 3, F::zero(), ny));
   //                                                   l1: y3 = r*e - y1*ppp ; l3: zzz3 = zzz1*ppp
   return q == 0 ? x3 : q == 2 ? t3 : t4;
 }
@@ -202,6 +202,7 @@ template <int FID> struct FinalSegQuadFn {
       const uint32_t seg = seg_len(*total_p, lanes, min_seg);
       const uint32_t l0 = s0 / seg, l1 = (e0 - 1) / seg;
       uint32_t cnt = l1 - l0;
+      if (cnt > SegPlan::kBigAbove) return;  // written by k_big_all (quad-uniform)
       if (cnt > heavy_above) cnt = heavy_above;
       acc = quad_load_raw<FID>(bucket_raw[k], q);
       for (uint32_t j = 0; j < cnt; j++) acc = quad_add<FID>(acc, quad_load_raw<FID>(partial_raw[l0 + 1 + j], q), q);
@@ -311,6 +312,144 @@ template <int FID> struct ReducePairQuadFn {
     }
   }
 };
+
+// ----------------------------------------------------------------------------------------------------
+// Block-level kernels of the MSM tail (round 3).  Round 2's tail was ~30 dependent launches of a few waves each (one per
+// reduction level, five strided fold passes that exit at once on ordinary inputs): on some boxes of the pool every such
+// launch cost twice what it did on others, and the driver-timed MSM lost 0.2 ms to it.  Here the dependency between
+// steps is a __syncthreads() with the points in LDS (raw limbs, 144 B per point, stride-9 words per lane: conflict-free).
+// ----------------------------------------------------------------------------------------------------
+template <int FID> __device__ __forceinline__ Fp<FID> lds_load_pt(const uint32_t* buf, uint32_t idx, uint32_t q) {
+  Fp<FID> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = buf[idx * 36u + q * 9u + i];
+  return r;
+}
+template <int FID> __device__ __forceinline__ void lds_store_pt(uint32_t* buf, uint32_t idx, uint32_t q, const Fp<FID>& c) {
+#pragma unroll
+  for (int i = 0; i < 9; i++) buf[idx * 36u + q * 9u + i] = c.l[i];
+}
+
+// Sum of the block's per-quad points (NQ quads, a power of two), result in quad 0.  Every thread of the block calls it.
+template <int FID, uint32_t NQ>
+__device__ __forceinline__ Fp<FID> block_sum_quads(Fp<FID> acc, uint32_t* lds /* NQ * 36 words */, uint32_t qd, uint32_t q) {
+  lds_store_pt<FID>(lds, qd, q, acc);
+  __syncthreads();
+  for (uint32_t st = NQ / 2; st >= 1; st >>= 1) {
+    if (qd < st) acc = quad_add<FID>(acc, lds_load_pt<FID>(lds, qd + st, q), q);
+    __syncthreads();
+    if (qd < st) lds_store_pt<FID>(lds, qd, q, acc);
+    __syncthreads();
+  }
+  return acc;
+}
+
+// Every big bucket (more than 64 continuation pieces; SegPlan) completely, in ONE launch whatever its size.
+// grid = (groups, slices): block (g, s) walks big buckets g, g + groups, ... and sums slice s (4096 pieces) of each:
+// 128 quads x <= 32 strided additions, then a 7-level LDS tree.  A bucket of one slice is finished on the spot
+// (+ bucket_raw[k], canonical store).  Otherwise the slice sum is parked in the slice's own first position, and the
+// block that draws the last ticket of the bucket sums the parked slices the same way -- no block ever waits for another.
+struct BigAllArgs {
+  const uint32_t* counters;
+  const HeavyRec* big;
+  const XYZZL* bucket_raw;
+  XYZZL* partial_raw;
+  XYZZW* buckets;
+  uint32_t* done;  // [big capacity], zero-initialised: tickets
+};
+static constexpr uint32_t kBigSlice = 4096, kBigThreads = 512;
+template <int FID> __global__ __launch_bounds__(512) void k_big_all(BigAllArgs a) {
+  const uint32_t nbig = a.counters[4];
+  if (nbig == 0) return;
+  constexpr uint32_t NQ = kBigThreads / 4;
+  __shared__ uint32_t lds[NQ * 36];
+  __shared__ uint32_t s_ticket;
+  const uint32_t qd = threadIdx.x >> 2, q = threadIdx.x & 3u, s = blockIdx.y;
+  for (uint32_t h = blockIdx.x; h < nbig; h += gridDim.x) {
+    const HeavyRec r = a.big[h];
+    const uint32_t nsl = (r.cnt + kBigSlice - 1) / kBigSlice;
+    if (s >= nsl) continue;  // block-uniform
+    const uint32_t lo = s * kBigSlice, hi = r.cnt < lo + kBigSlice ? r.cnt : lo + kBigSlice;
+    Fp<FID> acc = Fp<FID>::zero();  // zz = 0: the identity
+    for (uint32_t p = lo + qd; p < hi; p += NQ) acc = quad_add<FID>(acc, quad_load_raw<FID>(a.partial_raw[r.off + p], q), q);
+    acc = block_sum_quads<FID, NQ>(acc, lds, qd, q);
+    if (nsl > 1) {
+      if (qd == 0) {
+        quad_store_raw<FID>(a.partial_raw[r.off + lo], q, acc);
+        __threadfence();
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        __threadfence();
+        s_ticket = atomicAdd(&a.done[h], 1u);
+      }
+      __syncthreads();
+      const bool last = s_ticket == nsl - 1;
+      __syncthreads();  // s_ticket is rewritten by the next bucket of this block
+      if (!last) continue;
+      __threadfence();
+      acc = Fp<FID>::zero();
+      for (uint32_t t = qd; t < nsl; t += NQ) acc = quad_add<FID>(acc, quad_load_raw<FID>(a.partial_raw[r.off + t * kBigSlice], q), q);
+      acc = block_sum_quads<FID, NQ>(acc, lds, qd, q);
+    }
+    if (qd == 0) {
+      acc = quad_add<FID>(quad_load_raw<FID>(a.bucket_raw[r.bucket], q), acc, q);
+      quad_store<FID>(a.buckets[r.bucket], q, acc);
+    }
+    __syncthreads();  // lds is reused by the next bucket
+  }
+}
+
+// LV levels of the bucket-reduction pair tree (ReducePairFn, msm_kernels.hpp: D' = 2 (D_2j + D_2j+1),
+// Y' = Y_2j + Y_2j+1 + D_2j+1) inside one block: a block owns S = THREADS / 4 consecutive inputs (the tree is oblivious to
+// where a bucket set ends as long as 2^LV divides the set size), the first half of its quads computes D', the second half Y'
+// (whole waves per role: the two formulas never share a wave), levels are separated by __syncthreads() with the points
+// in LDS.  16 levels = 3 launches (6 + 5 + 5) instead of 16.
+struct ReduceTreeArgs {
+  const XYZZW* D;
+  const XYZZW* Y;  // == D when first
+  XYZZW* D_out;
+  XYZZW* Y_out;
+  uint32_t n_total;  // inputs of this launch (a multiple of 2^levels)
+  uint32_t levels;   // 1 .. log2(S)
+  uint32_t first;    // Y = D = B on entry
+  uint32_t last;     // the tree ends with this launch: the final D is not needed
+  const uint32_t* err_src;  // last launch: the pipeline's error word, copied behind the sums (one device->host copy)
+};
+template <int FID, int THREADS> __global__ __launch_bounds__(THREADS) void k_reduce_tree(ReduceTreeArgs a) {
+  constexpr uint32_t S = THREADS / 4, H = S / 2;
+  __shared__ uint32_t lds[(S + S / 2) * 36];
+  // two buffers (levels alternate): [0] holds H points per role, [1] S / 4
+  auto bufD = [&](uint32_t b) { return lds + b * (S * 36); };
+  auto bufY = [&](uint32_t b) { return lds + b * (S * 36) + (b ? (S / 4) * 36 : H * 36); };
+  const uint32_t qd = threadIdx.x >> 2, q = threadIdx.x & 3u;
+  const uint32_t role = qd >= H ? 1u : 0u, j = qd - role * H;
+  const uint32_t base = blockIdx.x * S;
+  const uint32_t n_in = a.n_total - base < S ? a.n_total - base : S;
+  if (a.err_src && blockIdx.x == 0 && threadIdx.x == 0) *(uint32_t*)(a.Y_out + (a.n_total >> a.levels)) = *a.err_src;
+  for (uint32_t lv = 1; lv <= a.levels; lv++) {
+    const bool from_g = lv == 1, to_g = lv == a.levels;
+    const uint32_t rb = lv & 1u, wb = (lv - 1u) & 1u;
+    if (j < (n_in >> lv) && !(role == 0 && to_g && a.last)) {
+      auto ldD = [&](uint32_t i) { return from_g ? quad_load<FID>(a.D[base + i], q) : lds_load_pt<FID>(bufD(rb), i, q); };
+      auto ldY = [&](uint32_t i) { return from_g ? quad_load<FID>(a.Y[base + i], q) : lds_load_pt<FID>(bufY(rb), i, q); };
+      const bool fst = from_g && a.first;
+      const Fp<FID> d1 = ldD(2 * j + 1);
+      Fp<FID> c;
+      if (role == 0) {
+        c = quad_dbl<FID>(quad_add<FID>(ldD(2 * j), d1, q), q);
+      } else {
+        // first level of the whole tree (Y = D = B):  B_2j + 2 B_2j+1 ; afterwards  (Y_2j+1 + D_2j+1) + Y_2j
+        const Fp<FID> o1 = fst ? d1 : ldY(2 * j + 1), o0 = fst ? ldD(2 * j) : ldY(2 * j);
+        c = fst ? quad_dbl<FID>(d1, q) : quad_add<FID>(o1, d1, q);
+        c = quad_add<FID>(c, o0, q);
+      }
+      if (to_g) quad_store<FID>((role ? a.Y_out : a.D_out)[(base >> a.levels) + j], q, c);
+      else lds_store_pt<FID>(role ? bufY(wb) : bufD(wb), j, q, c);
+    }
+    __syncthreads();
+  }
+}
 
 }  // namespace nmx
 #endif

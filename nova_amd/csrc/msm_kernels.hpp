@@ -375,7 +375,7 @@ template <int FID> struct FoldFn {
       if (j >= cnt) continue;
       if (T != 1 && j + T >= cnt) continue;  // nothing to add: position j already holds its sum
       XYZZ<FID> acc = XYZZ<FID>::load(partials[r.off + j]);
-      for (uint32_t q = j + T; q < cnt; q += T) acc.add(XYZZ<FID>::load(partials[r.off + q]));
+      for (uint32_t q = j + T; q < cnt; q += T) acc.template add<kLatTail>(XYZZ<FID>::load(partials[r.off + q]));
       if (T == 1)
         acc.store(buckets[r.bucket]);
       else
@@ -485,19 +485,19 @@ template <int FID> struct ReducePairFn {
     if (role == 0) {
       if (n_in == 2) return;  // last level: only Y_0 is needed
       XYZZ<FID> d = XYZZ<FID>::load(D[base]);
-      d.add(XYZZ<FID>::load(D[base + 1]));
-      d.dbl_in_place();
+      d.template add<kLatTail>(XYZZ<FID>::load(D[base + 1]));
+      d.template dbl_in_place<kLatTail>();
       d.store(D_out[o]);
     } else {
       XYZZ<FID> y;
       if (first) {  // Y = D = B:  B_2j + 2 * B_2j+1
         y = XYZZ<FID>::load(D[base + 1]);
-        y.dbl_in_place();
-        y.add(XYZZ<FID>::load(D[base]));
+        y.template dbl_in_place<kLatTail>();
+        y.template add<kLatTail>(XYZZ<FID>::load(D[base]));
       } else {
         y = XYZZ<FID>::load(Y[base + 1]);
-        y.add(XYZZ<FID>::load(D[base + 1]));
-        y.add(XYZZ<FID>::load(Y[base]));
+        y.template add<kLatTail>(XYZZ<FID>::load(D[base + 1]));
+        y.template add<kLatTail>(XYZZ<FID>::load(Y[base]));
       }
       y.store(Y_out[o]);
     }

@@ -30,7 +30,7 @@ struct MsmArgs {
   uint32_t seg_min_total = 1u << 22;  // segment-balanced accumulate (msm_seg.hpp) from this many sorted entries on
   uint32_t seg_min_len = 8;           // shortest segment a lane is given
   uint32_t accum_prefetch = 1;        // gathers in flight ahead of the addition (AccumSegFn PF)
-  uint32_t seg_heavy_above = 0;       // pieces FinalSegFn sums per bucket without a pre-fold (0: PlanSegFn::heavy_above_for)
+  uint32_t seg_heavy_above = 0;       // pieces FinalSegFn sums per bucket without a pre-fold (0: SegPlan::heavy_above_for)
   // fused batch over the key's tables (DigitSrc::batch_*): n = sum of the vector lengths, `scalars` unused;
   // wsum_host[j] receives vector j's sum
   uint32_t batch_k = 0;
@@ -133,16 +133,27 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
   const uint32_t extra_cap = 2 * heavy_cap;
 
   const bool part = partition_supported(sh, a.pre_stride != 0) && !a.no_partition;
-  uint32_t* start = be.template alloc<uint32_t>(2 * ((size_t)sh.nbuckets + 1) + 8);
+  const uint32_t seg_lanes = part ? be.template seg_lanes<FID>() : 0;
+  const bool seg = part && seg_lanes && total >= a.seg_min_total;  // segment-balanced accumulate (msm_seg.hpp)
+  // Everything that must start as zero lives in ONE block, cleared by ONE fill: bucket bounds, counters, the tickets of the
+  // big-bucket pass and the partition's histograms / cursors.  (Round 2 issued five fills per MSM, 3-5 us each plus the
+  // gap before the next launch, and cleared the 9 MB bucket_raw array that every reader only touches where it was written.)
+  const uint32_t big_cap_s = seg ? (seg_lanes / (SegPlan::kBigAbove + 1) + 1 < sh.nbuckets ? seg_lanes / (SegPlan::kBigAbove + 1) + 1 : sh.nbuckets) : 0;
+  const size_t nbounds = 2 * ((size_t)sh.nbuckets + 1) + 8;
+  const size_t nctr = part ? 2048 + 3 * kTabStride + 1 + 2 * (size_t)sh.nbuckets : 0;
+  const size_t nzero = nbounds + big_cap_s + nctr;
+  uint32_t* start = be.template alloc<uint32_t>(nzero);
   uint32_t* end = start + sh.nbuckets + 1;
   uint32_t* counters = end + sh.nbuckets + 1;  // [0] extra tasks, [1] split buckets, [2] error bits, [3] max tasks, [4] big, [5] non-zero digits
-  HeavyRec* heavy = be.template alloc<HeavyRec>(heavy_cap);
+  uint32_t* big_done = start + nbounds;
+  uint32_t* ctr = big_done + big_cap_s;
+  HeavyRec* heavy = be.template alloc<HeavyRec>(seg ? 1 : heavy_cap);
   const uint32_t big_cap = (uint32_t)(total / ((size_t)64 * sh.lmax)) + 1;
-  HeavyRec* big = be.template alloc<HeavyRec>(big_cap);
-  TaskRec* extra = be.template alloc<TaskRec>(extra_cap);
+  HeavyRec* big = be.template alloc<HeavyRec>(seg ? 1 : big_cap);
+  TaskRec* extra = be.template alloc<TaskRec>(seg ? 1 : extra_cap);
   XYZZW* buckets = be.template alloc<XYZZW>(sh.nbuckets);
-  XYZZW* partials = be.template alloc<XYZZW>(extra_cap);
-  be.memset0(start, (2 * ((size_t)sh.nbuckets + 1) + 8) * sizeof(uint32_t));
+  XYZZW* partials = be.template alloc<XYZZW>(seg ? 1 : extra_cap);
+  be.memset0(start, nzero * sizeof(uint32_t));
 
   DigitSrc<SFID> src;
   src.scalars = a.scalars;
@@ -167,8 +178,6 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
     PartBufs& pb = pa.b;
     pb.ps = make_part_shape(sh);
     pb.nbuckets = sh.nbuckets;
-    const size_t nctr = 2048 + 3 * kTabStride + 1 + 2 * (size_t)sh.nbuckets;
-    uint32_t* ctr = be.template alloc<uint32_t>(nctr);
     pb.hist_hi = ctr;
     pb.cur_hi = ctr + 1024;
     pb.tab = ctr + 2048;
@@ -181,7 +190,6 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
     pb.start = start;
     pb.end = end;
     pb.total_out = counters + 5;
-    be.memset0(ctr, nctr * sizeof(uint32_t));
     // the widths the tables are built with get their own instantiation (constant bit positions); BIG = keys wider than 15 bits
     auto level1 = [&](auto hist, auto part) {
       be.mark("digits");
@@ -232,53 +240,46 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
       be.launch(f, (uint32_t)((total + BoundsFn::kPerLane - 1) / BoundsFn::kPerLane));
     }
   }
-  const uint32_t seg_lanes = part ? be.template seg_lanes<FID>() : 0;
-  if (part && seg_lanes && total >= a.seg_min_total) {
+  if (seg) {
     // large MSM: equal segments of the entry array per resident lane, raw-limb pieces, short folds (msm_seg.hpp)
-    XYZZL* bucket_raw = be.template alloc<XYZZL>(sh.nbuckets);
     XYZZL* partial_raw = be.template alloc<XYZZL>(seg_lanes);
     // a listed bucket spans more than 8 (64) segments: at most seg_lanes / 9 (/ 65) of them, whatever the distribution
     auto list_cap = [&](uint32_t above) {
       const uint32_t by_lanes = seg_lanes / (above + 1) + 1;
       return by_lanes < sh.nbuckets ? by_lanes : sh.nbuckets;
     };
-    const uint32_t heavy_above = a.seg_heavy_above ? a.seg_heavy_above : PlanSegFn::heavy_above_for(seg_lanes, sh.nbuckets);
+    const uint32_t heavy_above = a.seg_heavy_above ? a.seg_heavy_above : SegPlan::heavy_above_for(seg_lanes, sh.nbuckets);
     HeavyRec* heavy_s = be.template alloc<HeavyRec>(list_cap(heavy_above));
-    HeavyRec* big_s = be.template alloc<HeavyRec>(list_cap(PlanSegFn::kBigAbove));
-    be.memset0(bucket_raw, sizeof(XYZZL) * sh.nbuckets);
+    HeavyRec* big_s = be.template alloc<HeavyRec>(big_cap_s);
+    // not cleared: every non-empty bucket's first piece is written by the lane its first entry falls into, and the passes
+    // below read bucket_raw[k] for non-empty buckets only
+    XYZZL* bucket_raw = be.template alloc<XYZZL>(sh.nbuckets);
     const uint32_t* total_p = counters + 5;
+    const SegPlan plan{start, end, total_p, counters, heavy_s, big_s, sh.nbuckets, seg_lanes, a.seg_min_len, heavy_above};
     be.mark("accum");
     if (a.accum_prefetch > 1) {
       AccumSegFn<FID, 2> f{(const AffineW*)a.bases, vals1, start, end, total_p, bucket_raw, partial_raw, sh.nbuckets,
-                           seg_lanes, a.seg_min_len};
+                           seg_lanes, a.seg_min_len, plan};
       be.launch(f, seg_lanes);
     } else {
       AccumSegFn<FID, 1> f{(const AffineW*)a.bases, vals1, start, end, total_p, bucket_raw, partial_raw, sh.nbuckets,
-                           seg_lanes, a.seg_min_len};
+                           seg_lanes, a.seg_min_len, plan};
       be.launch(f, seg_lanes);
     }
     be.mark("fold");
-    {
-      PlanSegFn f{start, end, total_p, counters, heavy_s, big_s, sh.nbuckets, seg_lanes, a.seg_min_len, heavy_above};
-      be.launch(f, sh.nbuckets);
+    // big buckets (> 64 pieces) completely; then the heavy ones (> heavy_above) down to heavy_above positions; then
+    // every other bucket.  On uniformly random scalars the first two launches find empty lists and exit.
+    be.template launch_big_all<FID>(counters, big_s, bucket_raw, partial_raw, buckets, big_done, seg_lanes);
+    if (heavy_above < SegPlan::kBigAbove) {
+      // listed buckets number at most seg_lanes / (heavy_above + 1); when the typical bucket is not heavy (c = 17 tables:
+      // 9 pieces against 12) a small grid walks whatever the input made heavy
+      const bool expected = seg_lanes / sh.nbuckets > heavy_above;
+      uint32_t groups = list_cap(heavy_above);
+      if (!expected && groups > 2048) groups = 2048;
+      be.template launch_fold_raw<FID>(counters, heavy_s, partial_raw, heavy_above, 0xffffffffu, groups, 0u);
     }
-    {
-      // a bucket spans at most seg_lanes segments; buckets above T partials number at most seg_lanes / T
-      const uint32_t Ts[5] = {32768, 4096, 512, 64, heavy_above};
-      for (int p = 0; p < 5; p++) {
-        const uint32_t T = Ts[p], cap = p == 0 ? 0xffffffffu : Ts[p - 1];
-        if (T >= seg_lanes) continue;  // no bucket can have more than T partials
-        const bool use_big = T >= 64;
-        uint32_t bound = seg_lanes / T + 1;
-        if (bound > sh.nbuckets) bound = sh.nbuckets;
-        uint32_t groups = use_big ? (1u << 18) / T : bound;
-        if (groups > bound) groups = bound;
-        if (groups < 1) groups = 1;
-        be.template launch_fold_raw<FID>(counters, use_big ? big_s : heavy_s, partial_raw, T, cap, groups, use_big ? 1u : 0u);
-      }
-      be.template launch_final_seg<FID>(start, end, total_p, bucket_raw, partial_raw, buckets, sh.nbuckets, seg_lanes,
-                                        a.seg_min_len, heavy_above);
-    }
+    be.template launch_final_seg<FID>(start, end, total_p, bucket_raw, partial_raw, buckets, sh.nbuckets, seg_lanes,
+                                      a.seg_min_len, heavy_above);
   } else {
   {
     PlanFn f{start, end, counters, heavy, big, sh};
@@ -321,23 +322,15 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
   }
   }
   be.mark("reduce");
-  const XYZZW* D = buckets;
-  const XYZZW* Y = buckets;
-  uint32_t n_in = sh.M, first = 1;  // M == 1 (c == 1): the bucket is the window sum
-  while (n_in > 1) {
-    const uint32_t half = n_in / 2;
-    XYZZW* Do = be.template alloc<XYZZW>((size_t)sh.WB * half);
-    XYZZW* Yo = be.template alloc<XYZZW>((size_t)sh.WB * half);
-    const uint32_t pairs = sh.WB * half;
-    be.template launch_reduce_pair<FID>(D, Y, Do, Yo, n_in, pairs, first);
-    D = Do;
-    Y = Yo;
-    n_in = half;
-    first = 0;
-  }
+  bool err_appended = false;  // the last tree launch parks the error word behind the sums: one copy instead of two
+  const XYZZW* Y = be.template reduce_tree<FID>(buckets, sh, counters + 2, &err_appended);
   be.mark("tail");
-  be.d2h(wsum_host, Y, sizeof(XYZZW) * sh.WB);
-  be.d2h(err_host, counters + 2, sizeof(uint32_t));
+  if (err_appended) {
+    be.d2h_split(wsum_host, sizeof(XYZZW) * sh.WB, err_host, sizeof(uint32_t), Y);
+  } else {
+    be.d2h(wsum_host, Y, sizeof(XYZZW) * sh.WB);
+    be.d2h(err_host, counters + 2, sizeof(uint32_t));
+  }
   be.mark("end");
   be.sync();
   return sh;

@@ -11,9 +11,15 @@
 //                     bucket k = bucket_raw[k] + sum of partial_raw[L] for L in (L0, L1],  L0 = start[k] / seg,
 //                                                                                             L1 = (end[k] - 1) / seg
 //                -- a contiguous range.  All lanes do the same number of mixed additions (+-1): no tail round.
-//   PlanSegFn    buckets spanning more than 8 / 64 lanes -> `heavy` / `big` lists (same records as round 1's plan)
-//   FoldRawFn    strided pre-folds of those ranges (T = 32768 ... 64 over `big`, then 8 over `heavy`)
-//   FinalSegFn   every bucket: bucket_raw[k] + its (<= 8 remaining) partials -> canonical XYZZW for the reduction tree
+//   SegPlan      (run by the first lanes of AccumSegFn itself: start / end are final before it starts) buckets spanning
+//                more than heavy_above lanes -> `heavy` list, more than 64 -> `big` list
+//   BigBucketFn  every big bucket completely: one block per 4096-piece slice, strided sums + an LDS tree; a bucket of
+//                several slices is finished by the block that arrives last (ticket counter, no spinning) -- ONE launch
+//                for every bucket size up to a whole window in one bucket (all-equal scalars); curve_quad.hpp k_big_all
+//   FoldRawFn    one strided pre-fold (T = heavy_above) of the heavy ranges
+//   FinalSegFn   every other bucket: bucket_raw[k] + its (<= heavy_above remaining) partials -> canonical XYZZW
+// Round 2 ran Plan + five FoldRaw passes (four of them over `big`, empty on ordinary inputs) + Final: seven dependent
+// launches, ~55 us of them doing nothing; now three, of which two exit at once on uniformly random scalars.
 //
 // A bucket of 512 entries spans ~6 segments of 86: the fold work per bucket drops from ~22 partials to ~6.
 // Pieces are stored as raw 9-limb coordinates (XYZZL, 144 B): a flush sits inside a divergent branch (lanes of a wave
@@ -31,6 +37,56 @@ NMX_HD uint32_t seg_len(uint32_t total, uint32_t lanes, uint32_t min_seg) {
 
 // PF = how many gathers are in flight ahead of the addition being computed (1: as AccumFn; 2: one more 64-byte row
 // in registers, for the case where the gather latency under full load exceeds one addition of the wave's neighbours)
+// Buckets whose entries span many lanes: lists for the pre-fold / big-bucket passes.  counters: [1] heavy count,
+// [3] largest partial count among the big buckets, [4] big count.  Wave-safe on the device (one atomic per wave).
+struct SegPlan {
+  static constexpr uint32_t kBigAbove = 64;
+  // A bucket with more than `heavy_above` continuation pieces is listed for the T = heavy_above pre-fold; FinalSegFn sums up
+  // to that many serially.  lanes / nbuckets pieces per bucket on uniformly random scalars: 18 at c = 16 (8: one pre-fold
+  // pass halves them), 9 at c = 17 (12: no bucket is listed, no pre-fold work, FinalSegFn adds one more piece).
+  static uint32_t heavy_above_for(uint32_t lanes, uint32_t nbuckets) { return lanes / nbuckets <= 12u ? 12u : 8u; }
+  const uint32_t* start;
+  const uint32_t* end;
+  const uint32_t* total_p;
+  uint32_t* counters;
+  HeavyRec* heavy;  // heavy_above < pieces <= kBigAbove
+  HeavyRec* big;    // pieces > kBigAbove
+  uint32_t nbuckets, lanes, min_seg, heavy_above;
+  // every lane of the wave calls this together (lanes without a bucket: valid = false)
+  NMX_HD void operator()(uint32_t k, bool valid) const {
+    const uint32_t seg = seg_len(*total_p, lanes, min_seg);
+    uint32_t cnt = 0, off = 0;
+    if (valid && k < nbuckets) {
+      const uint32_t s0 = start[k], e0 = end[k];
+      if (e0 > s0) {
+        const uint32_t l0 = s0 / seg, l1 = (e0 - 1) / seg;
+        cnt = l1 - l0;
+        off = l0 + 1;
+      }
+    }
+    const bool is_heavy = cnt > heavy_above && cnt <= kBigAbove, is_big = cnt > kBigAbove;
+    uint32_t slot = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long m = __ballot(is_heavy);
+    if (m != 0) {  // wave-uniform
+      const uint32_t lane = __lane_id(), leader = (uint32_t)__ffsll((long long)m) - 1u;
+      uint32_t base = 0;
+      if (lane == leader) base = atomicAdd(&counters[1], (uint32_t)__popcll(m));  // one atomic per wave
+      base = __shfl(base, (int)leader);
+      slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    }
+#else
+    if (is_heavy) slot = counters[1]++;
+#endif
+    const HeavyRec r{k, off, cnt, 0};
+    if (is_heavy) heavy[slot] = r;
+    if (is_big) {  // rare: a bucket holding more than 64 lanes' worth of entries
+      nmx_atomic_max(&counters[3], cnt);
+      big[nmx_atomic_add(&counters[4], 1)] = r;
+    }
+  }
+};
+
 template <int FID, int PF = 1> struct AccumSegFn {
   const AffineW* bases;
   const uint32_t* vals;
@@ -40,6 +96,7 @@ template <int FID, int PF = 1> struct AccumSegFn {
   XYZZL* bucket_raw;        // [nbuckets], zero-initialised (= identity)
   XYZZL* partial_raw;       // [lanes]
   uint32_t nbuckets, lanes, min_seg;
+  SegPlan plan;  // the bucket lists of the passes after this kernel, written by its first lanes
 
   // the smallest k >= k0 with end[k] > j (end[] is nondecreasing and end[nbuckets - 1] = total > j)
   NMX_HD uint32_t first_bucket_after(uint32_t k0, uint32_t j) const {
@@ -52,6 +109,8 @@ template <int FID, int PF = 1> struct AccumSegFn {
     return lo;
   }
   NMX_HD void operator()(uint32_t L) const {
+    // plan first: lane L classifies buckets L, L + lanes, ... (the launch has whole waves: `lanes` is a multiple of 256)
+    for (uint32_t kb = L & ~63u; kb < nbuckets; kb += lanes) plan(kb + (L & 63u), true);
     const uint32_t total = *total_p;
     const uint32_t seg = seg_len(total, lanes, min_seg);
     const uint64_t a64 = (uint64_t)L * seg;
@@ -110,59 +169,8 @@ template <int FID, int PF = 1> struct AccumSegFn {
   }
 };
 
-// Buckets whose entries span many lanes: lists for the pre-fold passes.  counters as in PlanFn: [1] heavy count,
-// [3] largest partial count among the big buckets, [4] big count.
-struct PlanSegFn {
-  static constexpr bool kFullWaves = true;
-  static constexpr uint32_t kBigAbove = 64;
-  // A bucket with more than `heavy_above` continuation pieces is listed for the T = heavy_above pre-fold; FinalSegFn sums up
-  // to that many serially.  lanes / nbuckets pieces per bucket on uniformly random scalars: 18 at c = 16 (8: one pre-fold
-  // pass halves them), 9 at c = 17 (12: no bucket is listed, no pre-fold work, FinalSegFn adds one more piece).
-  static uint32_t heavy_above_for(uint32_t lanes, uint32_t nbuckets) { return lanes / nbuckets <= 12u ? 12u : 8u; }
-  const uint32_t* start;
-  const uint32_t* end;
-  const uint32_t* total_p;
-  uint32_t* counters;
-  HeavyRec* heavy;
-  HeavyRec* big;
-  uint32_t nbuckets, lanes, min_seg, heavy_above;
-  NMX_HD void operator()(uint32_t k) const { (*this)(k, true); }
-  NMX_HD void operator()(uint32_t k, bool valid) const {
-    const uint32_t seg = seg_len(*total_p, lanes, min_seg);
-    uint32_t cnt = 0, off = 0;
-    if (valid && k < nbuckets) {
-      const uint32_t s0 = start[k], e0 = end[k];
-      if (e0 > s0) {
-        const uint32_t l0 = s0 / seg, l1 = (e0 - 1) / seg;
-        cnt = l1 - l0;
-        off = l0 + 1;
-      }
-    }
-    const bool is_heavy = cnt > heavy_above;
-    uint32_t slot = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-    const unsigned long long m = __ballot(is_heavy);
-    if (m == 0) return;  // wave-uniform
-    const uint32_t lane = __lane_id();
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&counters[1], (uint32_t)__popcll(m));  // one atomic per wave
-    base = __shfl(base, 0);
-    slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-#else
-    if (is_heavy) slot = counters[1]++;
-#endif
-    if (!is_heavy) return;
-    const HeavyRec r{k, off, cnt, 0};
-    heavy[slot] = r;
-    if (cnt > kBigAbove) {
-      nmx_atomic_max(&counters[3], cnt);
-      big[nmx_atomic_add(&counters[4], 1)] = r;
-    }
-  }
-};
-
 // FoldFn on raw partials: lane j of group g folds positions j, j + T, j + 2T, ... < min(cnt, cap) of a listed bucket
-// into position j (in place).  T = 32768, 4096, 512, 64 over `big`; T = 8 over `heavy`.
+// into position j (in place).  One pass with T = heavy_above over `heavy` (use_big = 0; use_big = 1 walks the big list).
 template <int FID> struct FoldRawFn {
   const uint32_t* counters;
   const HeavyRec* list;
@@ -177,7 +185,7 @@ template <int FID> struct FoldRawFn {
       const uint32_t cnt = r.cnt < cap ? r.cnt : cap;
       if (j + T >= cnt) continue;  // nothing to add into position j
       XYZZ<FID> acc = XYZZ<FID>::load_raw(partial_raw[r.off + j]);
-      for (uint32_t q = j + T; q < cnt; q += T) acc.add(XYZZ<FID>::load_raw(partial_raw[r.off + q]));
+      for (uint32_t q = j + T; q < cnt; q += T) acc.template add<kLatTail>(XYZZ<FID>::load_raw(partial_raw[r.off + q]));
       acc.store_raw(partial_raw[r.off + j]);
     }
   }
@@ -200,11 +208,29 @@ template <int FID> struct FinalSegFn {
       const uint32_t seg = seg_len(*total_p, lanes, min_seg);
       const uint32_t l0 = s0 / seg, l1 = (e0 - 1) / seg;
       uint32_t cnt = l1 - l0;
+      if (cnt > SegPlan::kBigAbove) return;  // written by the big-bucket pass
       if (cnt > heavy_above) cnt = heavy_above;
       acc = XYZZ<FID>::load_raw(bucket_raw[k]);
-      for (uint32_t j = 0; j < cnt; j++) acc.add(XYZZ<FID>::load_raw(partial_raw[l0 + 1 + j]));
+      for (uint32_t j = 0; j < cnt; j++) acc.template add<kLatTail>(XYZZ<FID>::load_raw(partial_raw[l0 + 1 + j]));
     }
     acc.store(buckets[k]);
+  }
+};
+
+// A big bucket completely, one lane: the reference semantics of curve_quad.hpp's k_big_all (which the device runs); used as
+// is by the host emulation.
+template <int FID> struct BigBucketFn {
+  const uint32_t* counters;
+  const HeavyRec* big;
+  const XYZZL* bucket_raw;
+  const XYZZL* partial_raw;
+  XYZZW* buckets;
+  NMX_HD void operator()(uint32_t h) const {
+    if (h >= counters[4]) return;
+    const HeavyRec r = big[h];
+    XYZZ<FID> acc = XYZZ<FID>::load_raw(bucket_raw[r.bucket]);
+    for (uint32_t j = 0; j < r.cnt; j++) acc.add(XYZZ<FID>::load_raw(partial_raw[r.off + j]));
+    acc.store(buckets[r.bucket]);
   }
 };
 

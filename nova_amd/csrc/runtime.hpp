@@ -61,6 +61,7 @@ template <class F> __global__ __launch_bounds__(256) void k_launch(F f, uint32_t
 // ---------------------------------------------------------------------------------------------------
 static constexpr int kMaxMarks = 12;
 struct Ctx {
+  int dev = 0;  // logical device (index into Global::hip_dev) the stream, the arenas and the events belong to
   hipStream_t stream = nullptr;
   char* arena = nullptr;
   size_t cap = 0;
@@ -80,7 +81,12 @@ struct Ctx {
 struct BaseSet {
   int curve = 0;
   size_t n = 0;
+  int dev = 0;         // logical device `d` lives on (Global::hip_dev)
   void* d = nullptr;   // AffineW[pre_W ? pre_W * n : n]: the key (internal form), then its window tables
+  // A key sharded over the devices of the process (nmx_init_devices): d == nullptr and parts[i] is an
+  // ordinary single-device key holding points [part_begin[i], part_begin[i + 1]) with its own window tables.
+  std::vector<std::shared_ptr<BaseSet>> parts;
+  std::vector<size_t> part_begin;  // parts.size() + 1 entries
   uint32_t pre_c = 0;  // window width of the tables (0: none)
   uint32_t pre_W = 0;
   bool any_identity = true;  // false: no point of the key is the identity (checked at registration): the digit stage of
@@ -90,8 +96,12 @@ struct BaseSet {
   BaseSet(int curve_, size_t n_) : curve(curve_), n(n_) {}
   BaseSet(const BaseSet&) = delete;
   BaseSet& operator=(const BaseSet&) = delete;
-  size_t bytes() const { return n * 64 * (pre_W ? pre_W : 1); }
-  ~BaseSet();  // capi.hip: hipFree(d) on the library's device
+  size_t bytes() const {
+    size_t b = d ? n * 64 * (pre_W ? pre_W : 1) : 0;
+    for (const auto& p : parts) b += p->bytes();
+    return b;
+  }
+  ~BaseSet();  // capi.hip: hipFree(d) on its device
 };
 using BaseRef = std::shared_ptr<const BaseSet>;
 
@@ -102,8 +112,15 @@ static constexpr size_t kPrecompMinN = 2;  // default of Global::precomp_min_n
 struct Global {
   std::mutex mu;
   bool inited = false;
-  int device = 0;
-  std::vector<Ctx*> free_ctx;
+  int device = 0;  // HIP device of logical device 0 (the primary: field-vector kernels, unsharded keys, device scalars)
+  // Logical devices of this process (nmx_init_devices): hip_dev[i] = HIP device ordinal.  Entries are only ever appended
+  // (capacity reserved at start-up, so readers never see a reallocation); ndev_active of them receive the shards of
+  // newly registered keys.  Logical devices may share a physical GPU (NMX_DEVICES_OVERSUBSCRIBE: tests on a 1-GPU box).
+  static constexpr size_t kMaxDevices = 64;
+  std::vector<int> hip_dev;
+  std::atomic<uint32_t> ndev_active{1};
+  std::atomic<size_t> shard_min_n{(size_t)1 << 20};  // keys shorter than this stay whole on the primary device
+  std::vector<std::vector<Ctx*>> free_ctx;  // per logical device
   std::vector<Ctx*> all_ctx;
   std::unordered_map<uint64_t, std::shared_ptr<BaseSet>> bases;
   struct SparseSet {  // a CSR matrix resident in HBM (R1CS matrices are fixed per circuit: upload once)
@@ -120,19 +137,20 @@ struct Global {
   // written by nmx_set_profiling / nmx_set_window_bits while calls on other threads read them
   std::atomic<bool> profiling{false};
   std::atomic<uint32_t> force_c{0};
-  uint32_t force_lmax = 0;  // env NMX_TUNE_LMAX (tuning only)
-  size_t precomp_min_n = kPrecompMinN;  // env NMX_TUNE_PRECOMP_MIN_N (tuning only)
-  uint32_t force_fold_t = 0;  // env NMX_TUNE_FOLD_T (tuning only)
-  uint32_t no_quad_accum = 0;  // env NMX_TUNE_NO_QUAD_ACCUM (tuning only)
-  uint32_t no_partition = 0;   // env NMX_TUNE_NO_PARTITION: generic radix-sort path everywhere (A/B runs)
-  uint32_t seg_min_total = 1u << 22;  // env NMX_TUNE_SEG_MIN_TOTAL (profiles/r02_msm_2p20/seg_threshold.txt): msm_seg.hpp from this many sorted entries (0xffffffff: never)
-  uint32_t seg_min_len = 8;           // env NMX_TUNE_SEG_MIN_LEN
-  uint32_t seg_lanes_override = 0;    // env NMX_TUNE_SEG_LANES (0: the kernel's resident lane count)
-  uint32_t no_quad_final = 0;         // env NMX_TUNE_NO_QUAD_FINAL
-  uint32_t accum_prefetch = 0;        // env NMX_TUNE_ACCUM_PF / option accum_prefetch: 0 = by table size, 1, 2
-  uint32_t horner_top = 0;            // env NMX_TUNE_HORNER_TOP / option horner_top: suffix Horner's register-resident levels: 0 / 8 = 8-element chunks, 4, 1 = off
-  uint32_t seg_heavy_above = 0;       // env NMX_TUNE_SEG_HEAVY_ABOVE / option seg_heavy_above: 0 = by pieces per bucket (8 or 12)
-  uint32_t no_batch_fuse = 0;         // env NMX_TUNE_NO_BATCH_FUSE / option no_batch_fuse: every vector of a batch runs alone
+  std::atomic<uint32_t> force_lmax{0};  // env NMX_TUNE_LMAX (tuning only)
+  std::atomic<size_t> precomp_min_n{kPrecompMinN};  // env NMX_TUNE_PRECOMP_MIN_N (tuning only)
+  std::atomic<uint32_t> force_fold_t{0};  // env NMX_TUNE_FOLD_T (tuning only)
+  std::atomic<uint32_t> no_quad_accum{0};  // env NMX_TUNE_NO_QUAD_ACCUM (tuning only)
+  std::atomic<uint32_t> no_partition{0};   // env NMX_TUNE_NO_PARTITION: generic radix-sort path everywhere (A/B runs)
+  std::atomic<uint32_t> seg_min_total{1u << 22};  // env NMX_TUNE_SEG_MIN_TOTAL (profiles/r02_msm_2p20/seg_threshold.txt): msm_seg.hpp from this many sorted entries (0xffffffff: never)
+  std::atomic<uint32_t> seg_min_len{8};           // env NMX_TUNE_SEG_MIN_LEN
+  std::atomic<uint32_t> seg_lanes_override{0};    // env NMX_TUNE_SEG_LANES (0: the kernel's resident lane count)
+  std::atomic<uint32_t> no_quad_final{0};         // env NMX_TUNE_NO_QUAD_FINAL
+  std::atomic<uint32_t> accum_prefetch{0};        // env NMX_TUNE_ACCUM_PF / option accum_prefetch: 0 = by table size, 1, 2
+  std::atomic<uint32_t> horner_top{0};            // env NMX_TUNE_HORNER_TOP / option horner_top: suffix Horner's register-resident levels: 0 / 8 = 8-element chunks, 4, 1 = off
+  std::atomic<uint32_t> seg_heavy_above{0};       // env NMX_TUNE_SEG_HEAVY_ABOVE / option seg_heavy_above: 0 = by pieces per bucket (8 or 12)
+  std::atomic<uint32_t> no_batch_fuse{0};         // env NMX_TUNE_NO_BATCH_FUSE / option no_batch_fuse: every vector of a batch runs alone
+  std::atomic<uint32_t> no_tree_fuse{0};          // env NMX_TUNE_NO_TREE_FUSE / option no_tree_fuse: one launch per reduction level (round 2; A/B runs)
 };
 extern Global& G;                // capi.hip (heap singleton, never destroyed)
 void prof_store(const float* ms, int n);   // last call's stage times of this thread (capi.hip)
@@ -216,7 +234,8 @@ struct DeviceBackend {
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_launch<AccumSegFn<FID, 1>>, 256, 0) != hipSuccess) return 0u;
       return 3u * (uint32_t)blocks * 256u * (uint32_t)prop.multiProcessorCount;
     }();
-    return G.seg_lanes_override ? G.seg_lanes_override : lanes;
+    const uint32_t ov = G.seg_lanes_override.load(std::memory_order_relaxed);
+    return ov ? ov : lanes;
   }
   template <int FID>
   void launch_fold_raw(const uint32_t* counters, const HeavyRec* list, XYZZL* partial_raw, uint32_t T, uint32_t cap,
@@ -241,18 +260,64 @@ struct DeviceBackend {
       launch(f, nbuckets);
     }
   }
+  // every big bucket in one launch (curve_quad.hpp k_big_all); a bucket spans at most `lanes` pieces
   template <int FID>
-  void launch_reduce_pair(const XYZZW* D, const XYZZW* Y, XYZZW* Do, XYZZW* Yo, uint32_t n_in, uint32_t pairs,
-                          uint32_t first) {
-    if (2 * pairs < kQuadBelowItems) {
-      const uint32_t padded = (pairs + 15u) & ~15u;  // 16 quads = one wave: roles never share a wave
-      ReducePairQuadFn<FID> f{D, Y, Do, Yo, n_in, pairs, padded, first};
-      launch(f, 2 * padded * 4);
-    } else {
-      const uint32_t padded = (pairs + 63u) & ~63u;
-      ReducePairFn<FID> f{D, Y, Do, Yo, n_in, pairs, padded, first};
-      launch(f, 2 * padded);
+  void launch_big_all(const uint32_t* counters, const HeavyRec* big, const XYZZL* bucket_raw, XYZZL* partial_raw,
+                      XYZZW* buckets, uint32_t* done, uint32_t lanes) {
+    if (dry) return;
+    const BigAllArgs a{counters, big, bucket_raw, partial_raw, buckets, done};
+    const uint32_t slices = (lanes + kBigSlice - 1) / kBigSlice;
+    hipLaunchKernelGGL((k_big_all<FID>), dim3(16, slices), dim3(kBigThreads), 0, c.stream, a);
+    HIPCHK(hipGetLastError());
+  }
+  // Bucket reduction sum_k (k + 1) B_k per bucket set: the pair tree of ReducePairFn.  A level costs two dependent quad
+  // additions (~10 us) wherever it runs, so fusing levels into one launch gains nothing on a box whose launches chain
+  // back to back (measured: 16 launches 0.167 ms, fused 0.175) -- but on the boxes of the pool where every dependent
+  // launch of a few waves costs 5-10 us extra, round 2's tree took 0.34 ms.  Levels with more inputs than one round of
+  // blocks holds (256 CUs x 128 inputs: the kernel runs one 512-thread block per CU at 181 registers) are throughput-bound
+  // and keep one launch each; the others run fused, at most seven levels per launch (k_reduce_tree): 16 levels = 1 + 3
+  // launches at c = 17, 15 = 3 at c = 16, 7 = 1 at c = 8.  Returns the WB sums.
+  static constexpr uint32_t kTreeThreads = 512, kTreeLevels = 7, kTreeMaxInputs = 256 * 128;
+  template <int FID> const XYZZW* reduce_tree(const XYZZW* buckets, const MsmShape& sh, const uint32_t* err_src, bool* err_appended) {
+    const XYZZW* D = buckets;
+    const XYZZW* Y = buckets;
+    uint32_t n_in = sh.M, first = 1;  // M == 1 (c == 1): the bucket is the window sum
+    while (n_in > 1 && (G.no_tree_fuse || (uint64_t)sh.WB * n_in > kTreeMaxInputs)) {
+      const uint32_t half = n_in / 2, pairs = sh.WB * half;
+      XYZZW* Do = alloc<XYZZW>(pairs);
+      XYZZW* Yo = alloc<XYZZW>(pairs);
+      if (!dry) {
+        if (2 * pairs < kQuadBelowItems) {
+          const uint32_t padded = (pairs + 15u) & ~15u;  // 16 quads = one wave: roles never share a wave
+          ReducePairQuadFn<FID> f{D, Y, Do, Yo, n_in, pairs, padded, first};
+          launch(f, 2 * padded * 4);
+        } else {
+          const uint32_t padded = (pairs + 63u) & ~63u;
+          ReducePairFn<FID> f{D, Y, Do, Yo, n_in, pairs, padded, first};
+          launch(f, 2 * padded);
+        }
+      }
+      D = Do, Y = Yo, n_in = half, first = 0;
     }
+    uint32_t levels = 0;
+    while ((1u << levels) < n_in) levels++;
+    const uint32_t launches = (levels + kTreeLevels - 1) / kTreeLevels;
+    for (uint32_t i = 0; i < launches; i++) {
+      const uint32_t lv = levels / launches + (i < levels % launches ? 1u : 0u);
+      const uint32_t n_total = sh.WB * n_in, n_out = n_total >> lv;
+      const bool last = i + 1 == launches;
+      XYZZW* Do = alloc<XYZZW>(n_out);
+      XYZZW* Yo = alloc<XYZZW>(n_out + (last ? 1 : 0));  // + the error word
+      if (last) *err_appended = true;
+      if (!dry) {
+        const ReduceTreeArgs a{D, Y, Do, Yo, n_total, lv, first, last ? 1u : 0u, last ? err_src : nullptr};
+        const uint32_t S = kTreeThreads / 4;
+        hipLaunchKernelGGL((k_reduce_tree<FID, kTreeThreads>), dim3((n_total + S - 1) / S), dim3(kTreeThreads), 0, c.stream, a);
+        HIPCHK(hipGetLastError());
+      }
+      D = Do, Y = Yo, n_in >>= lv, first = 0;
+    }
+    return Y;
   }
   void sort_pairs(uint32_t* k_in, uint32_t* k_out, uint32_t* v_in, uint32_t* v_out, size_t total,
                   uint32_t bits) {
@@ -280,6 +345,20 @@ struct DeviceBackend {
       pinned_used += (bytes + 63) & ~(size_t)63;
     } else {
       HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c.stream));
+    }
+  }
+  // one copy of bytes1 + bytes2 contiguous device bytes, landing in two host destinations
+  void d2h_split(void* dst1, size_t bytes1, void* dst2, size_t bytes2, const void* src) {
+    if (dry) return;
+    if (!c.pinned) HIPCHK(hipHostMalloc((void**)&c.pinned, kPinnedBytes, hipHostMallocDefault));
+    if (pinned_used + bytes1 + bytes2 <= kPinnedBytes) {
+      HIPCHK(hipMemcpyAsync(c.pinned + pinned_used, src, bytes1 + bytes2, hipMemcpyDeviceToHost, c.stream));
+      landings.push_back({dst1, pinned_used, bytes1});
+      landings.push_back({dst2, pinned_used + bytes1, bytes2});
+      pinned_used += (bytes1 + bytes2 + 63) & ~(size_t)63;
+    } else {
+      d2h(dst1, src, bytes1);
+      d2h(dst2, (const char*)src + bytes1, bytes2);
     }
   }
   void sync() {
@@ -346,7 +425,10 @@ struct CurveOps {
   const uint32_t* base_modulus_words;  // 8 x u32
   void (*generate)(Ctx&, BaseSet& bs, uint64_t k0, uint32_t flags);
   void (*internal_to_canonical)(uint8_t* elems32, size_t count);  // host, in place
-  void (*point_sum)(const uint8_t* partials128, size_t count, uint8_t* out, uint8_t* inf);  // host
+  // host: sum of 128-byte partials -> affine point, or (flags & NMX_OUT_PARTIAL) one more partial
+  void (*point_sum)(const uint8_t* partials128, size_t count, uint32_t flags, uint8_t* out, uint8_t* inf);
+  // host: the blinding term h * r of `commit` as a 128-byte partial (h, r in the ABI forms `flags` names)
+  void (*blind_term)(const void* h_xy64, const void* r, uint32_t flags, uint8_t* out128);
   bool (*check_layout)(const uint8_t* generator_raw64, const uint8_t* scalar_raw32, uint64_t value);  // host
 };
 // field-vector kernels (fieldvec.hip)

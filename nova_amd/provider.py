@@ -32,6 +32,22 @@ def _check(rc):
         raise NmxError(rc, L.lib().nmx_last_error().decode())
 
 
+def init_devices(count=0, oversubscribe=False):
+    """nmx_init_devices: keys registered afterwards are sharded over `count` devices of THIS process (0 = all visible);
+    oversubscribe maps logical devices onto fewer GPUs (tests).  Returns the number of devices in use."""
+    _check(L.lib().nmx_init_devices(count, L.DEVICES_OVERSUBSCRIBE if oversubscribe else 0))
+    return L.lib().nmx_devices_in_use()
+
+
+def shard_plan(n_key, k, offset, n):
+    """[(device, offset inside the shard, count)] for a call over key[offset, offset + n) of a k-way sharded key."""
+    buf = (ctypes.c_size_t * (3 * max(k, 1)))()
+    cnt = L.lib().nmx_shard_plan(n_key, k, offset, n, buf, max(k, 1))
+    if cnt < 0:
+        raise NmxError(cnt, "bad shard_plan arguments")
+    return [(buf[3 * i], buf[3 * i + 1], buf[3 * i + 2]) for i in range(cnt)]
+
+
 def _is_device_tensor(x):
     return hasattr(x, "data_ptr") and getattr(x, "is_cuda", False)
 

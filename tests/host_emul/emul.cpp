@@ -54,12 +54,25 @@ struct HostEmulBackend {
     FoldFn<FID> f{counters, heavy, partials, buckets, T, cap, groups};
     launch(f, groups * T);
   }
+  template <int FID> const XYZZW* reduce_tree(const XYZZW* buckets, const MsmShape& sh, const uint32_t*, bool*) {  // one launch per level
+    const XYZZW* D = buckets;
+    const XYZZW* Y = buckets;
+    uint32_t n_in = sh.M, first = 1;
+    while (n_in > 1) {
+      const uint32_t half = n_in / 2, pairs = sh.WB * half, padded = (pairs + 63u) & ~63u;
+      XYZZW* Do = alloc<XYZZW>(pairs);
+      XYZZW* Yo = alloc<XYZZW>(pairs);
+      ReducePairFn<FID> f{D, Y, Do, Yo, n_in, pairs, padded, first};
+      launch(f, 2 * padded);
+      D = Do, Y = Yo, n_in = half, first = 0;
+    }
+    return Y;
+  }
   template <int FID>
-  void launch_reduce_pair(const XYZZW* D, const XYZZW* Y, XYZZW* Do, XYZZW* Yo, uint32_t n_in, uint32_t pairs,
-                          uint32_t first) {
-    const uint32_t padded = (pairs + 63u) & ~63u;
-    ReducePairFn<FID> f{D, Y, Do, Yo, n_in, pairs, padded, first};
-    launch(f, 2 * padded);
+  void launch_big_all(const uint32_t* counters, const HeavyRec* big, const XYZZL* bucket_raw, XYZZL* partial_raw,
+                      XYZZW* buckets, uint32_t*, uint32_t lanes) {
+    BigBucketFn<FID> f{counters, big, bucket_raw, partial_raw, buckets};
+    launch(f, lanes / (SegPlan::kBigAbove + 1) + 1);
   }
   // segment-balanced accumulate (msm_seg.hpp): an odd lane count so segments straddle bucket boundaries everywhere
   template <int FID> uint32_t seg_lanes() { return g_seg_lanes; }
@@ -88,6 +101,10 @@ struct HostEmulBackend {
     }
   }
   void d2h(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); }
+  void d2h_split(void* d1, size_t b1, void* d2, size_t b2, const void* src) {
+    memcpy(d1, src, b1);
+    memcpy(d2, (const char*)src + b1, b2);
+  }
   void sync() {}
   void mark(const char*) {}
 };
@@ -214,6 +231,10 @@ template <int FID> static void fp_op_t(int op, const uint8_t* a, const uint8_t* 
     case 10: r = F::sub4(x, y).norm().canon(); break;
     case 11: r = x.canon(); break;
     case 12: { r = F::zero(); r.l[0] = x.norm().maybe_zero_mod_p() ? 1u : 0u; } break;
+    // latency-oriented products (separated operand scanning): must equal the chained ones limb for limb
+    case 13: { F u = F::template mulx<true>(x, y), v = x * y; for (int i = 0; i < 9; i++) if (u.l[i] != v.l[i]) u = F::zero(); r = u.canon(); } break;
+    case 14: { F u = F::template sqrx<true>(x), v = x.sqr(); for (int i = 0; i < 9; i++) if (u.l[i] != v.l[i]) u = F::zero(); r = u.canon(); } break;
+    case 15: { F u = F::template mul_addx<true>(x, y, y, x), v = F::mul_add(x, y, y, x); for (int i = 0; i < 9; i++) if (u.l[i] != v.l[i]) u = F::zero(); r = u.canon(); } break;
     default: r = F::zero();
   }
   fp_to_bytes(r, out);

@@ -111,6 +111,9 @@ def test_field_ops(emul, fid):
         for b in edge + rnd[:6] + wide:
             if (a // p + 1) * (b // p + 1) < 127:
                 assert op(0, a, b) == a * b * Ri % p
+                assert op(13, a, b) == a * b * Ri % p                     # sos_mul: limb-identical to the chained product
+            if 2 * (a // p + 1) * (b // p + 1) < 127:
+                assert op(15, a, b) == 2 * a * b * Ri % p                 # a*b + b*a with one reduction
             assert op(1, a, b % (1 << 255)) == (a + b % (1 << 255)) % p
             if b < 2 * p - (1 << 233):
                 assert op(2, a, b) == (a - b) % p
@@ -120,6 +123,7 @@ def test_field_ops(emul, fid):
         assert op(3, a % p) == a * Rm % p
         assert op(4, a) == a * Ri % p
         assert op(7, a) == a * a * Ri % p
+        assert op(14, a) == a * a * Ri % p
         assert op(8, a % p) == (a % p) * 32 % p
         assert op(9, a % p) == (a % p) * pow(1 << 256, -1, p) % p
         assert op(11, a) == a % p
