@@ -379,6 +379,145 @@ def inprocess_multi(args, torch):
     return out
 
 
+def fieldvec_block(args, torch, L):
+    """The HBM-bound field-vector kernels either side of the MSM, one roofline entry each for the default
+    N = 1 line: BN254 scalar field, vectors resident in HBM, kernel time from hipEvents on the library's stream
+    (nmx_set_profiling), achieved = algorithmic bytes / kernel time, frac of the 8 TB/s HBM peak, and a cross-check of the GPU
+    output against the CPU oracle (element-wise kernels: the first 2^20 elements; reductions: the whole input).  Inputs are
+    drawn on the device (uniform 253-bit integers, all below the modulus)."""
+    import ctypes
+    from nova_amd import fieldvec as fv
+    from oracle import cref
+    cid, fid = 0, fv.BN254_FR
+    cref.set_threads(effective_cpus())
+    g = torch.Generator(device="cuda")
+    g.manual_seed(20260924)
+
+    def rand_vec(n):
+        w = torch.randint(0, 1 << 31, (n, 8), dtype=torch.int64, device="cuda", generator=g)
+        w = (w * 2 + torch.randint(0, 2, (n, 8), dtype=torch.int64, device="cuda", generator=g)).to(torch.int32)
+        w[:, 7] &= 0x1FFFFFFF                                  # < 2^253 < r
+        return w.view(torch.uint8).reshape(n, 32).contiguous()
+
+    N24, N22, N20 = 1 << 24, 1 << 22, 1 << 20
+    pool = [rand_vec(N24) for _ in range(5)]
+    torch.cuda.synchronize()                                   # the library runs on its own (non-blocking) streams
+    r = np.frombuffer((0x1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF12345678 % util_modulus(fid)).to_bytes(32, "little"),
+                      dtype=np.uint8).reshape(1, 32).copy()
+    host_cache = {}
+
+    def host(j, n):                                            # host copy of the first n elements of pool[j]
+        if (j, n) not in host_cache:
+            host_cache[(j, n)] = pool[j][:n].cpu().numpy()
+        return host_cache[(j, n)]
+
+    prof = (ctypes.c_float * 4)()
+
+    def kernel_ms(fn, steps=5, warm=2, pre=None):
+        for _ in range(warm):
+            if pre:
+                pre()
+            fn()
+        L.nmx_set_profiling(1)
+        tot, out = 0.0, None
+        for _ in range(steps):
+            if pre:
+                pre()
+            out = fn()
+            L.nmx_profile_last(prof, 4)
+            tot += prof[0]
+        L.nmx_set_profiling(0)
+        return tot / steps, out
+
+    def as_bytes(o, m=None):
+        if isinstance(o, tuple):
+            return b"".join(o)
+        if isinstance(o, bytes):
+            return o
+        return (o if m is None else o[:m]).cpu().numpy().reshape(-1).tobytes()
+
+    res = {}
+
+    def entry(name, n, bytes_per_elem, ms, ok, note=None):
+        ach = bytes_per_elem * n / (ms * 1e-3) / 1e9
+        res[name] = {"log2n": n.bit_length() - 1, "kernel_ms": round(ms, 4), "bytes_per_elem": bytes_per_elem,
+                     "achieved_GBs": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4), "gpu_matches_cpu": bool(ok)}
+        if note:
+            res[name]["note"] = note
+
+    m = N20                                                    # element-wise kernels: oracle on the first 2^20 elements
+    A, B, C, D, E = pool
+    ms, o = kernel_ms(lambda: fv.axpy(fid, A, B, r))
+    entry("axpy", N24, 96, ms, as_bytes(o, m) == cref.field_axpy(fid, host(0, m), host(1, m), r, m))
+    ms, o = kernel_ms(lambda: fv.axpy2(fid, A, B, C, r))
+    entry("axpy2", N24, 128, ms, as_bytes(o, m) == cref.field_axpy2(fid, host(0, m), host(1, m), host(2, m), r, m))
+    ms, o = kernel_ms(lambda: fv.cross_term(fid, A, B, C, D, r))
+    entry("cross_term", N24, 160, ms, as_bytes(o, m) == cref.field_cross_term(fid, host(0, m), host(1, m), host(2, m), host(3, m), r, m))
+    ms, o = kernel_ms(lambda: fv.cross_term2(fid, A, B, C, D, E, r))
+    entry("cross_term2", N24, 192, ms,
+          as_bytes(o, m) == cref.field_cross_term2(fid, host(0, m), host(1, m), host(2, m), host(3, m), host(4, m), r, m))
+    ms, o = kernel_ms(lambda: fv.bind_poly_var_top(fid, A, r))
+    hA = A.cpu().numpy()
+    entry("bind", N24, 48, ms, as_bytes(o, m) == cref.field_bind(fid, hA, 0, N24 // 2, 1, r, m))
+    # reductions: whole input through the oracle
+    hB, hC = B.cpu().numpy(), C.cpu().numpy()
+    shift = (24 - 1) // 2
+    eqR, eqL = rand_vec(1 << shift), rand_vec((N24 // 2) >> shift)
+    torch.cuda.synchronize()
+    ms, o = kernel_ms(lambda: fv.sumcheck_eq_sums(fid, 3, A, B, C, eqR, eqL, shift))
+    entry("sumcheck3", N24, 80, ms,
+          as_bytes(o) == b"".join(cref.sumcheck_eq_sums(fid, 3, hA, hB, hC, N24, eqR.cpu().numpy(), eqL.cpu().numpy(), shift)),
+          "multiplier-bound: 4 + 2/K field reductions per index")
+    ms, o = kernel_ms(lambda: fv.sumcheck_plain_sums(fid, 1, A, B))
+    entry("quad_prod", N24, 64, ms, as_bytes(o)[:64] == b"".join(cref.sumcheck_plain_sums(fid, 1, hA, hB, None, N24)[:2]))
+    shift3 = (24 - 2) // 2
+    eqR3, eqL3 = rand_vec(1 << shift3), rand_vec((N24 // 4) >> shift3)
+    torch.cuda.synchronize()
+    work = [torch.empty_like(t) for t in (A, B, C)]
+
+    def refresh():
+        for w, t in zip(work, (A, B, C)):
+            w.copy_(t)
+        torch.cuda.synchronize()
+    ms, o = kernel_ms(lambda: fv.sumcheck_bind_eq_sums(fid, 3, work[0], work[1], work[2], r, eqR3, eqL3, shift3)[3], pre=refresh)
+    bound = [cref.field_bind(fid, h, 0, N24 // 2, 1, r, N24 // 2) for h in (hA, hB, hC)]
+    entry("round3", N24, 144, ms,
+          as_bytes(o) == b"".join(cref.sumcheck_eq_sums(fid, 3, bound[0], bound[1], bound[2], N24 // 2, eqR3.cpu().numpy(),
+                                                        eqL3.cpu().numpy(), shift3)),
+          "one whole cubic round: bind A, B, C + the next round's sums")
+    del work, bound
+    point = rand_vec(24).cpu().numpy()
+    ms, o = kernel_ms(lambda: fv.mle_evaluate(fid, A, point))
+    entry("mle_eval", N24, 32, ms, as_bytes(o) == cref.mle_evaluate(fid, hA, 24, point))
+    ms, o = kernel_ms(lambda: fv.mle_evaluate(fid, A[:N20], point[:20]))
+    entry("mle_eval_2p20", N20, 32, ms, as_bytes(o) == cref.mle_evaluate(fid, hA[:N20], 20, point[:20]), "launch floor: three launches")
+    # 2^22: lincomb of 8, suffix Horner, SpMV
+    vecs = [p[j * N22:(j + 1) * N22] for p in (A, B) for j in range(4)]
+    ms, o = kernel_ms(lambda: fv.lincomb_powers(fid, vecs, r))
+    entry("lincomb8", N22, 288, ms, as_bytes(o, m) == cref.lincomb_powers(fid, [v[:m].cpu().numpy().tobytes() for v in vecs], r, m))
+    ms, o = kernel_ms(lambda: fv.suffix_horner(fid, A[:N22], r))
+    entry("horner", N22, 64, ms, as_bytes(o) == cref.suffix_horner(fid, hA[:N22], N22, r),
+          "a scan whose operator is a field multiplication: VALU-bound (DESIGN.md 3b)")
+    rng = np.random.Generator(np.random.PCG64(5))
+    indptr = np.arange(0, 3 * N22 + 1, 3, dtype=np.uint64)
+    indices = rng.integers(0, N22, size=3 * N22).astype(np.uint64)
+    data = hB[:3 * N22].copy()
+    kind = rng.random(3 * N22)
+    one = np.zeros(32, np.uint8)
+    one[0] = 1
+    data[kind < 0.6] = one
+    data[(kind >= 0.6) & (kind < 0.9)] = np.frombuffer((util_modulus(fid) - 1).to_bytes(32, "little"), dtype=np.uint8)
+    mat = fv.SparseMatrix(fid, indptr, indices, data, N22)
+    ms, o = kernel_ms(lambda: mat.multiply_vec(A[:N22]))
+    entry("spmv", N22, 3 * 68 + 40, ms, as_bytes(o, m) == cref.spmv(fid, indptr[: m + 1], indices, data, m, hA[:N22]),
+          "CSR, 3 non-zeros per row, 9 of 10 coefficients +-1 (R1CS-like)")
+    mat.close()
+    res["_what"] = ("bn254_fr vectors resident in HBM; kernel_ms = hipEvents on the library stream, mean of 5 launches; frac = "
+                    "algorithmic bytes / kernel time / 8000 GB/s; gpu_matches_cpu = oracle/nova_ref.c on the same inputs")
+    res["_min_frac"] = min(v["frac"] for k, v in res.items() if isinstance(v, dict) and k != "mle_eval_2p20")
+    return res
+
+
 def extras(out, args, torch, L, ck, host_scalars, dev_scalars):
     """The other headline-adjacent numbers of the N = 1 run, in the same JSON line (each with its own cross-check
     against the CPU oracle).  BN254, 2^20 unless stated."""
@@ -466,6 +605,11 @@ def extras(out, args, torch, L, ck, host_scalars, dev_scalars):
     a3 = argparse.Namespace(**vars(args))
     a3.log2n, a3.steps, a3.warmup = 20, 3, 1
     hk = hyperkzg_replay(a3, torch, ck=ck)
+    # (6) the field-vector kernels' rooflines (north_star: >= 40 % of HBM is about THESE kernels)
+    try:
+        out["fieldvec"] = fieldvec_block(args, torch, L)
+    except Exception as e:                                 # never lose the headline to an auxiliary block
+        out["fieldvec"] = {"error": repr(e)}
     out["hyperkzg_replay_ms"] = {"ms": round(hk["value"], 3), "log2n": 20, "cpu_ms": round(hk["cpu_baseline"]["value"], 1),
                                  "cpu_cores": hk["cpu_baseline"]["cores"], "gpu_matches_cpu": hk["cpu_baseline"]["gpu_matches_cpu"],
                                  "what": hk["config"]["workload"]}

@@ -173,7 +173,10 @@ enum {
   NMX_STAT_MSM_CALLS = 8,     /* MSMs run (every entry point; a batch counts each vector)                     */
   NMX_STAT_FUSED_RUNS = 9,    /* batch calls whose short vectors ran as one fused pipeline run                */
   NMX_STAT_SHARDED_CALLS = 10,/* MSMs that fanned out over the shards of a multi-device key                   */
-  NMX_STAT_COUNT = 11
+  NMX_STAT_CACHE_STALE = 11,  /* slice-form calls whose rolling content check caught an in-place edit of a cached
+                                 array: the entry was dropped and the call repeated on a fresh upload          */
+  NMX_STAT_TABLE_FALLBACKS = 12, /* keys left without window tables because the tables did not fit (budget / HBM) */
+  NMX_STAT_COUNT = 13
 };
 int nmx_stats(uint64_t* out, int cap);
 /* same, bases taken from a registered key */
@@ -233,6 +236,10 @@ int nmx_field_axpy2(int field, const void* a, const void* b, const void* c, cons
 /* out = az*bz - u*cz - e : the cross term T of commit_T (src/r1cs/mod.rs:614-620) */
 int nmx_field_cross_term(int field, const void* az, const void* bz, const void* cz, const void* e, const void* u,
                          size_t n, uint32_t flags, void* out);
+/* out = az*bz - u*cz - e1 - e2 : the cross term of commit_T_relaxed, two relaxed instances (src/r1cs/mod.rs:652-659;
+ * NIFSRelaxed::prove, src/nova/mod.rs:817,833), u = U1.u + U2.u formed by the caller */
+int nmx_field_cross_term2(int field, const void* az, const void* bz, const void* cz, const void* e1, const void* e2,
+                          const void* u, size_t n, uint32_t flags, void* out);
 /* out = a + b : Z = Z1 + Z2 (src/r1cs/mod.rs:590-609) */
 int nmx_field_vec_add(int field, const void* a, const void* b, size_t n, uint32_t flags, void* out);
 /* MultilinearPolynomial::bind_poly_var_top (src/spartan/polys/multilinear.rs:65-84):

@@ -10,7 +10,8 @@ SCALARS_MONT, BASES_MONT, SCALARS_DEVICE, BASES_DEVICE, OUT_PARTIAL, BASES_PRECO
 BASES_NOCACHE = 128
 # nmx_stats indices
 (STAT_CACHE_HITS, STAT_CACHE_UPLOADS, STAT_CACHE_REGROWS, STAT_CACHE_EVICTIONS, STAT_CACHE_ENTRIES, STAT_CACHE_BYTES,
- STAT_UNCACHED_CALLS, STAT_BASE_BYTES_H2D, STAT_MSM_CALLS, STAT_FUSED_RUNS, STAT_SHARDED_CALLS, STAT_COUNT) = range(12)
+ STAT_UNCACHED_CALLS, STAT_BASE_BYTES_H2D, STAT_MSM_CALLS, STAT_FUSED_RUNS, STAT_SHARDED_CALLS, STAT_CACHE_STALE,
+ STAT_TABLE_FALLBACKS, STAT_COUNT) = range(14)
 DEVICES_OVERSUBSCRIBE = 1
 E_ARG, E_NO_DEVICE, E_HIP, E_SCALAR_RANGE, E_SMALL_RANGE, E_HANDLE, E_TOO_LARGE = -1, -2, -3, -4, -5, -6, -7
 E_IO, E_FORMAT, E_POINT = -8, -9, -10
@@ -63,6 +64,7 @@ def lib():
     L.nmx_field_axpy.argtypes = [i, vp, vp, vp, sz, u32, vp]
     L.nmx_field_axpy2.argtypes = [i, vp, vp, vp, vp, sz, u32, vp]
     L.nmx_field_cross_term.argtypes = [i, vp, vp, vp, vp, vp, sz, u32, vp]
+    L.nmx_field_cross_term2.argtypes = [i, vp, vp, vp, vp, vp, vp, sz, u32, vp]
     L.nmx_field_vec_add.argtypes = [i, vp, vp, sz, u32, vp]
     L.nmx_mle_bind_top.argtypes = [i, vp, sz, vp, u32, vp]
     L.nmx_poly_fold_pairs.argtypes = [i, vp, sz, vp, u32, vp]

@@ -34,6 +34,7 @@ Global::SparseSet::~SparseSet() {
   if (indices) (void)hipFree(indices);
   if (data) (void)hipFree(data);
 }
+void note_table_fallback() { stat_add(NMX_STAT_TABLE_FALLBACKS); }
 static thread_local std::string t_err;
 static thread_local float t_prof[kMaxMarks];
 static thread_local int t_prof_n = 0;
@@ -85,6 +86,7 @@ static void ensure_init() {
   G.free_ctx.assign(Global::kMaxDevices, {});
   G.ndev_active.store(1);
   if (const char* t = getenv("NMX_SHARD_MIN_N")) G.shard_min_n.store((size_t)atoll(t));
+  if (const char* t = getenv("NMX_MAX_TABLE_MIB")) G.max_table_bytes.store((size_t)atoll(t) << 20);
   if (const char* t = getenv("NMX_TUNE_LMAX")) G.force_lmax = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_PRECOMP_MIN_N")) G.precomp_min_n = (size_t)atoll(t);
   if (const char* t = getenv("NMX_TUNE_FOLD_T")) {
@@ -407,55 +409,95 @@ template <class Fn> static int guarded(Fn&& fn) {
 // The reference passes `&ck.ck[..n]` (pedersen.rs:267, hyperkzg.rs:588) -- the address of element 0 of one long-lived
 // Vec for every n -- so (curve, layout, address) names the key and sampled content fingerprints confirm it.
 // ---------------------------------------------------------------------------------------------------
-static inline uint64_t point_hash(const void* p64) {
+static inline uint32_t point_hash(const void* p64) {  // 32 bits of a 64-bit multiply-xor hash of the 64 point bytes
   uint64_t w[8], h = 0x9e3779b97f4a7c15ull;
   memcpy(w, p64, 64);
   for (int i = 0; i < 8; i++) {
     h = (h ^ w[i]) * 0xff51afd7ed558ccdull;
     h ^= h >> 29;
   }
-  return h;
+  return (uint32_t)(h >> 32);
 }
-// Arrays up to this many points are verified in full on every call (stride-1 grid); longer ones by sampling.
-static constexpr size_t kFullVerifyBelow = 2048;
+// hashes of points [lo, hi) of a host array into out[lo, hi), on up to 8 threads for long ranges (2^20 points: ~1 ms)
+static void hash_points(const uint8_t* host, size_t lo, size_t hi, uint32_t* out) {
+  const size_t n = hi - lo;
+  const size_t nth = n < ((size_t)1 << 16) ? 1 : std::min<size_t>(8, n >> 15);
+  auto work = [&](size_t a, size_t b) {
+    for (size_t i = a; i < b; i++) out[i] = point_hash(host + 64 * i);
+  };
+  if (nth <= 1) {
+    work(lo, hi);
+    return;
+  }
+  std::vector<std::thread> th;
+  JoinAll join{th};
+  size_t started = 1;
+  try {
+    for (size_t t = 1; t < nth; t++) {
+      th.emplace_back(work, lo + n * t / nth, lo + n * (t + 1) / nth);
+      started = t + 1;
+    }
+  } catch (const std::system_error&) {  // no more threads: the remaining chunks on this one
+  }
+  work(lo, lo + n / nth);
+  for (size_t t = started; t < nth; t++) work(lo + n * t / nth, lo + n * (t + 1) / nth);
+}
+// Arrays (and slices) up to this many points are verified in full on every call; longer ones by the first and the last
+// point used, eight probes that move from call to call, and a ROLLING WINDOW of consecutive points that walks through
+// the whole array in at most 16 calls -- so a caller that rewrites even one point of a cached array in place (against the
+// documented contract) is caught within a bounded number of calls, and a freed-and-reused address at once.
+static constexpr size_t kFullVerifyBelow = 2048, kSyncWindow = 4096, kWindowFraction = 16;
+struct DeepCheck {  // the rolling-window part of a hit's verification; run() needs the caller's slice to stay valid
+  std::shared_ptr<const std::vector<uint32_t>> ph;
+  const uint8_t* slice = nullptr;
+  size_t off = 0, start = 0, count = 0;  // points [start, start + count) of the slice against ph[off + ...]
+  bool needed() const { return count != 0; }
+  bool run() const {
+    const uint32_t* h = ph->data() + off;
+    for (size_t i = start; i < start + count; i++)
+      if (point_hash(slice + 64 * i) != h[i]) return false;
+    return true;
+  }
+};
 struct SliceEntry {
   int curve;
   uint32_t mont;
   const uint8_t* host;  // address of element 0 (identity only; dereferenced solely through a live caller slice)
   size_t n;
-  size_t stride;             // fingerprint grid: hashes of points 0, stride, 2*stride, ... and of point n - 1
-  std::vector<uint64_t> fp;  // fp[k] = hash(point k * stride); fp.back() = hash(point n - 1)
+  std::shared_ptr<std::vector<uint32_t>> ph;  // ph[i] = hash(point i), all n points
   std::shared_ptr<BaseSet> bs;
+  bool tables = false;   // bs carries window tables (built once the array has proved long-lived: third use)
+  uint32_t uses = 0;
   uint64_t tick = 0, probes = 0;
-  size_t grid() const { return fp.size() - 1; }
-  void fingerprint() {
-    stride = n <= 4096 ? 1 : (n + 4095) / 4096;
-    const size_t g = (n + stride - 1) / stride;
-    fp.resize(g + 1);
-    for (size_t k = 0; k < g; k++) fp[k] = point_hash(host + 64 * k * stride);
-    fp[g] = point_hash(host + 64 * (n - 1));
-  }
-  // Do the caller's bytes for points [off, off + m) still match?  First and last grid point inside the range, the
-  // very last point when the whole array is used, and six grid points that move from call to call.
-  bool matches(const uint8_t* slice, size_t off, size_t m) {
+  size_t cursor = 0;     // rolling window position (array coordinates)
+  // Cheap part, under the cache lock: do the caller's bytes for points [off, off + m) still match?
+  bool matches(const uint8_t* slice, size_t off, size_t m, DeepCheck* deep) {
+    deep->count = 0;
     if (m == 0) return true;
-    const size_t g = grid();
-    if (n <= kFullVerifyBelow) {  // short arrays (<= 128 KiB): every point, ~10 us
+    const uint32_t* h = ph->data() + off;
+    auto ok = [&](size_t i) { return point_hash(slice + 64 * i) == h[i]; };
+    if (m <= kFullVerifyBelow) {  // <= 128 KiB: every point, ~10 us
       for (size_t i = 0; i < m; i++)
-        if (point_hash(slice + 64 * i) != fp[off + i]) return false;
+        if (!ok(i)) return false;
       return true;
     }
-    const size_t k_lo = (off + stride - 1) / stride, k_hi = (off + m - 1) / stride;  // grid points in range: [k_lo, k_hi]
-    if (off + m == n && point_hash(slice + 64 * (m - 1)) != fp[g]) return false;
-    if (k_lo > k_hi) return true;  // no grid point inside a very short interior slice
-    auto ok = [&](size_t k) { return point_hash(slice + 64 * (k * stride - off)) == fp[k]; };
-    if (!ok(k_lo) || !ok(k_hi)) return false;  // k_hi * stride <= off + m - 1 <= n - 1: always a grid point
-    const size_t span = k_hi - k_lo + 1;
+    if (!ok(0) || !ok(m - 1)) return false;
     uint64_t x = 0x2545f4914f6cdd1dull * (++probes);
-    for (int j = 0; j < 6; j++) {
+    for (int j = 0; j < 8; j++) {
       x ^= x >> 12, x ^= x << 25, x ^= x >> 27;
-      if (!ok(k_lo + (size_t)((x * 0x2545f4914f6cdd1dull) >> 33) % span)) return false;
+      if (!ok((size_t)((x * 0x2545f4914f6cdd1dull) >> 33) % m)) return false;
     }
+    // the rolling window: continues where the last call stopped, clipped to this call's range
+    size_t w = std::max(kSyncWindow, m / kWindowFraction);
+    if (w > m) w = m;
+    size_t st = cursor >= off && cursor < off + m ? cursor - off : 0;
+    if (st + w > m) w = m - st;
+    cursor = off + st + w >= off + m ? off : off + st + w;
+    deep->ph = ph;
+    deep->slice = slice;
+    deep->off = off;
+    deep->start = st;
+    deep->count = w;
     return true;
   }
 };
@@ -464,6 +506,7 @@ struct SliceCache {
   std::mutex upload_mu;  // one miss at a time: two rayon workers committing to the same key upload it once
   std::list<SliceEntry> entries;
   size_t bytes = 0, max_bytes = 0, min_n = 128, max_entries = 32;
+  uint32_t table_after_uses = 2;  // window tables are built when an array is used for the (this + 1)-th time (0: at upload)
   uint64_t clock = 0;
 };
 static SliceCache& SC = *new SliceCache;  // never destroyed (see G)
@@ -477,6 +520,7 @@ static void cache_init_defaults() {
   }
   if (const char* t = getenv("NMX_CACHE_BYTES")) SC.max_bytes = (size_t)atoll(t);
   if (const char* t = getenv("NMX_CACHE_MIN_N")) SC.min_n = (size_t)atoll(t);
+  if (const char* t = getenv("NMX_CACHE_TABLE_AFTER")) SC.table_after_uses = (uint32_t)atoi(t);
 }
 static void cache_publish_gauges() {  // SC.mu held
   g_stats[NMX_STAT_CACHE_ENTRIES].store(SC.entries.size(), std::memory_order_relaxed);
@@ -486,9 +530,18 @@ static void cache_erase(std::list<SliceEntry>::iterator it) {  // SC.mu held; in
   SC.bytes -= it->bs->bytes();
   SC.entries.erase(it);
 }
+static void cache_evict_lru_locked() {  // SC.mu held
+  auto lru = SC.entries.begin();
+  for (auto it = SC.entries.begin(); it != SC.entries.end(); ++it)
+    if (it->tick < lru->tick) lru = it;
+  cache_erase(lru);
+  stat_add(NMX_STAT_CACHE_EVICTIONS);
+}
 struct SliceKey {
   BaseRef bs;  // null: not cacheable, upload for this call only
   size_t offset = 0;
+  DeepCheck deep;       // hit on a long array: the rolling-window check still to run (with_slice)
+  bool want_tables = false;  // hit on an entry without tables that has now proved long-lived
 };
 // hit: the resident key and the offset of `bases` inside it
 static bool cache_find(int curve, uint32_t mont, const uint8_t* bases, size_t n, SliceKey* out, bool* grow) {
@@ -499,26 +552,95 @@ static bool cache_find(int curve, uint32_t mont, const uint8_t* bases, size_t n,
     if (e.curve != curve || e.mont != mont) continue;
     if (bases < e.host || bases >= e.host + 64 * e.n || ((size_t)(bases - e.host) & 63)) continue;
     const size_t off = (size_t)(bases - e.host) / 64;
+    DeepCheck dc;
     if (n > e.n - off) {  // reaches past the resident part
       if (off == 0) {     // a longer prefix of a known array: re-register at the new length
-        *grow = e.matches(bases, 0, e.n);
+        *grow = e.matches(bases, 0, e.n, &dc);
         cache_erase(it);
         cache_publish_gauges();
         return false;
       }
       continue;
     }
-    if (!e.matches(bases, off, n)) {  // same address, different content: the array was freed and reused
+    if (!e.matches(bases, off, n, &dc)) {  // same address, different content: the array was freed and reused
       cache_erase(it);
       cache_publish_gauges();
       return false;
     }
     e.tick = ++SC.clock;
+    e.uses++;
     out->bs = e.bs;
     out->offset = off;
+    out->deep = dc;
+    out->want_tables = !e.tables && e.uses > SC.table_after_uses;
     return true;
   }
   return false;
+}
+static bool is_oom(const Fail& f) { return f.code == NMX_E_HIP && f.msg.find("out of memory") != std::string::npos; }
+// key[0, n) with window tables from a resident copy without them (device to device; shard by shard)
+static std::shared_ptr<BaseSet> key_with_tables(const CurveOps& o, const BaseSet& src) {
+  auto dst = std::make_shared<BaseSet>(src.curve, src.n);
+  if (src.parts.empty()) {
+    CtxLease L(src.dev);
+    dst->dev = src.dev;
+    o.upload(*L.c, *dst, src.d, NMX_BASES_DEVICE | NMX_BASES_INTERNAL | NMX_BASES_PRECOMPUTE, nullptr);
+    (void)hipSetDevice(G.device);
+    return dst;
+  }
+  dst->parts.resize(src.parts.size());
+  dst->part_begin = src.part_begin;
+  for (size_t i = 0; i < src.parts.size(); i++) {
+    dst->parts[i] = std::make_shared<BaseSet>(src.curve, src.parts[i]->n);
+    dst->parts[i]->dev = src.parts[i]->dev;
+  }
+  run_on_parts(src.parts.size(), true, [&](size_t i) {
+    CtxLease L(src.parts[i]->dev);
+    o.upload(*L.c, *dst->parts[i], src.parts[i]->d, NMX_BASES_DEVICE | NMX_BASES_INTERNAL | NMX_BASES_PRECOMPUTE, nullptr);
+  });
+  return dst;
+}
+// An entry that has proved long-lived gets its window tables (built from the resident copy: no host traffic).  A failure --
+// tables that do not fit the budget or the HBM left -- leaves the plain entry in place: the MSM runs without tables.
+static void cache_add_tables(const CurveOps& o, int curve, uint32_t mont, const uint8_t* host0, SliceKey* k) {
+  std::lock_guard<std::mutex> up(SC.upload_mu);
+  BaseRef plain;
+  {
+    std::lock_guard<std::mutex> lk(SC.mu);
+    for (auto& e : SC.entries)
+      if (e.curve == curve && e.mont == mont && e.host == host0 && e.bs == k->bs) {
+        if (e.tables) return;  // another thread built them meanwhile; this call runs on the copy it already holds
+        plain = e.bs;
+      }
+  }
+  if (!plain) return;
+  size_t budget;
+  {
+    std::lock_guard<std::mutex> lk(SC.mu);
+    budget = SC.max_bytes;
+  }
+  std::shared_ptr<BaseSet> full;
+  try {
+    if (o.table_bytes(plain->n) > budget) throw Fail{NMX_E_HIP, "window tables beyond the cache budget: out of memory"};
+    full = key_with_tables(o, *plain);
+  } catch (const Fail& f) {
+    if (!is_oom(f)) throw;
+    stat_add(NMX_STAT_TABLE_FALLBACKS);
+    std::lock_guard<std::mutex> lk(SC.mu);
+    for (auto& e : SC.entries)
+      if (e.bs == plain) e.tables = true;  // do not try again on every call
+    return;
+  }
+  std::lock_guard<std::mutex> lk(SC.mu);
+  for (auto& e : SC.entries)
+    if (e.bs == plain) {
+      SC.bytes += full->bytes() - plain->bytes();
+      e.bs = full;
+      e.tables = true;
+      k->bs = full;
+    }
+  while (SC.entries.size() > 1 && SC.bytes > SC.max_bytes) cache_evict_lru_locked();
+  cache_publish_gauges();
 }
 static SliceKey slice_key(Ctx& c, const CurveOps& o, int curve, const void* bases, size_t n, uint32_t flags) {
   SliceKey k;
@@ -528,6 +650,7 @@ static SliceKey slice_key(Ctx& c, const CurveOps& o, int curve, const void* base
   bool grow = false;
   if (cache_find(curve, mont, b, n, &k, &grow)) {
     stat_add(NMX_STAT_CACHE_HITS);
+    if (k.want_tables) cache_add_tables(o, curve, mont, b - 64 * k.offset, &k);
     return k;
   }
   if (n < SC.min_n) return k;
@@ -537,17 +660,48 @@ static SliceKey slice_key(Ctx& c, const CurveOps& o, int curve, const void* base
     stat_add(NMX_STAT_CACHE_HITS);
     return k;
   }
+  size_t budget;
+  {
+    std::lock_guard<std::mutex> lk(SC.mu);
+    budget = SC.max_bytes;
+  }
+  if (n * 64 > budget) return k;  // does not fit the cache at all: one-shot upload
   SliceEntry e;
   e.curve = curve;
   e.mont = mont;
   e.host = b;
   e.n = n;
-  e.fingerprint();
-  e.bs = build_key(c, curve, n, true, true, [&](Ctx& cx, BaseSet& part, size_t begin) {
-    o.upload(cx, part, (const char*)bases + 64 * begin, (flags & NMX_BASES_MONT) | NMX_BASES_PRECOMPUTE, nullptr);
-  });
+  e.ph = std::make_shared<std::vector<uint32_t>>(n);
+  hash_points(b, 0, n, e.ph->data());
+  // First sight: the key only (upload + conversion).  Tables cost W - 1 more copies of it and ~13 ms per 2^20 points;
+  // arrays seen once or twice (IPA's folded keys, src/provider/pedersen.rs:484-497: a fresh n/2-point key per round,
+  // two MSMs each) never pay for them.  A re-registration because a longer prefix arrived keeps its standing.
+  const bool regrow = grow || grow2;
+  const uint32_t up_flags = (flags & NMX_BASES_MONT) | (regrow && SC.table_after_uses <= 2 ? NMX_BASES_PRECOMPUTE : 0u) |
+                            (SC.table_after_uses == 0 ? NMX_BASES_PRECOMPUTE : 0u);
+  auto upload = [&] {
+    return build_key(c, curve, n, true, true, [&](Ctx& cx, BaseSet& part, size_t begin) {
+      o.upload(cx, part, (const char*)bases + 64 * begin, up_flags, nullptr);
+    });
+  };
+  for (int attempt = 0;; attempt++) {
+    try {
+      e.bs = upload();
+      break;
+    } catch (const Fail& f) {
+      // out of HBM: give back what the cache holds, oldest first, and try again; with nothing left to evict the call
+      // still runs, on a one-shot upload without tables (temp_key)
+      if (!is_oom(f)) throw;
+      std::lock_guard<std::mutex> lk(SC.mu);
+      if (SC.entries.empty() || attempt >= 64) return k;
+      cache_evict_lru_locked();
+      cache_publish_gauges();
+    }
+  }
+  e.tables = (up_flags & NMX_BASES_PRECOMPUTE) != 0;
+  e.uses = 1;
   stat_add(NMX_STAT_CACHE_UPLOADS);
-  if (grow || grow2) stat_add(NMX_STAT_CACHE_REGROWS);
+  if (regrow) stat_add(NMX_STAT_CACHE_REGROWS);
   stat_add(NMX_STAT_BASE_BYTES_H2D, n * 64);
   k.bs = e.bs;
   k.offset = 0;
@@ -555,13 +709,7 @@ static SliceKey slice_key(Ctx& c, const CurveOps& o, int curve, const void* base
   e.tick = ++SC.clock;
   SC.bytes += e.bs->bytes();
   SC.entries.push_back(std::move(e));
-  while (SC.entries.size() > 1 && (SC.bytes > SC.max_bytes || SC.entries.size() > SC.max_entries)) {
-    auto lru = SC.entries.begin();
-    for (auto it = SC.entries.begin(); it != SC.entries.end(); ++it)
-      if (it->tick < lru->tick) lru = it;
-    cache_erase(lru);
-    stat_add(NMX_STAT_CACHE_EVICTIONS);
-  }
+  while (SC.entries.size() > 1 && (SC.bytes > SC.max_bytes || SC.entries.size() > SC.max_entries)) cache_evict_lru_locked();
   cache_publish_gauges();
   return k;
 }
@@ -583,6 +731,47 @@ static SliceKey resolve_slice(Ctx& c, const CurveOps& o, int curve, const void* 
     k.offset = 0;
   }
   return k;
+}
+// A slice-form call: run(key) computes into the caller's TEMPORARIES; on a long cached array the rolling-window check
+// of the caller's bytes runs on a second host thread meanwhile.  A mismatch (the array was edited in place) drops the
+// entry and repeats the call on a fresh upload -- the stale result is never handed out.  commit() publishes.
+template <class Run, class Commit>
+static void with_slice(Ctx& c, const CurveOps& o, int curve, const void* bases, size_t n, uint32_t flags, Run&& run,
+                       Commit&& commit) {
+  for (int attempt = 0;; attempt++) {
+    const SliceKey k = resolve_slice(c, o, curve, bases, n, flags);
+    bool ok = true;
+    std::future<bool> fut;
+    if (k.deep.needed()) {
+      if (k.deep.count > kSyncWindow) {
+        try {
+          const DeepCheck dc = k.deep;
+          fut = std::async(std::launch::async, [dc] { return dc.run(); });
+        } catch (const std::system_error&) {
+          ok = k.deep.run();
+        }
+      } else {
+        ok = k.deep.run();
+      }
+    }
+    if (ok) run(k);  // (an exception unwinds through fut's destructor, which waits for the check)
+    if (fut.valid()) ok = fut.get();
+    if (ok) {
+      commit();
+      return;
+    }
+    stat_add(NMX_STAT_CACHE_STALE);
+    {
+      std::lock_guard<std::mutex> lk(SC.mu);
+      const uint8_t* b = (const uint8_t*)bases;
+      for (auto it = SC.entries.begin(); it != SC.entries.end();) {
+        auto cur = it++;
+        if (b >= cur->host && b < cur->host + 64 * cur->n) cache_erase(cur);
+      }
+      cache_publish_gauges();
+    }
+    require(attempt < 2, NMX_E_ARG, "the base array keeps changing while the call runs");
+  }
 }
 
 }  // namespace nmx
@@ -811,9 +1000,14 @@ int nmx_msm(int curve, const void* scalars, const void* bases, size_t n, uint32_
     require(out && ((scalars && bases) || n == 0), NMX_E_ARG, "null argument");
     const CurveOps& o = ops(curve);
     CtxLease L;
-    const SliceKey k = resolve_slice(*L.c, o, curve, bases, n, flags);
     stat_add(NMX_STAT_MSM_CALLS);
-    key_msm(*L.c, *k.bs, k.offset, n, field_call(scalars, flags), flags, out, out_is_inf);
+    uint8_t res[128], rinf = 0;
+    with_slice(*L.c, o, curve, bases, n, flags,
+               [&](const SliceKey& k) { key_msm(*L.c, *k.bs, k.offset, n, field_call(scalars, flags), flags, res, &rinf); },
+               [&] {
+                 memcpy(out, res, (flags & NMX_OUT_PARTIAL) ? 128 : 64);
+                 if (out_is_inf) *out_is_inf = rinf;
+               });
   });
 }
 
@@ -841,9 +1035,14 @@ int nmx_msm_u64(int curve, const uint64_t* scalars, const void* bases, size_t n,
     bool dev = (flags & NMX_SCALARS_DEVICE) != 0;
     uint32_t bits = resolve_u64_bits(*L.c, scalars, n, dev, max_num_bits);
     MsmCall mc{scalars, dev, false, bits, true};
-    const SliceKey k = resolve_slice(*L.c, o, curve, bases, n, flags);
     stat_add(NMX_STAT_MSM_CALLS);
-    key_msm(*L.c, *k.bs, k.offset, n, mc, flags, out, out_is_inf);
+    uint8_t res[128], rinf = 0;
+    with_slice(*L.c, o, curve, bases, n, flags,
+               [&](const SliceKey& k) { key_msm(*L.c, *k.bs, k.offset, n, mc, flags, res, &rinf); },
+               [&] {
+                 memcpy(out, res, (flags & NMX_OUT_PARTIAL) ? 128 : 64);
+                 if (out_is_inf) *out_is_inf = rinf;
+               });
   });
 }
 
@@ -1010,8 +1209,16 @@ int nmx_msm_batch(int curve, const void* const* scalar_vecs, const size_t* lens,
       batch_impl(empty, 0, 0, scalar_vecs, lens, k, flags, out, out_is_inf, *L.c);
       return;
     }
-    const SliceKey key = resolve_slice(*L.c, o, curve, bases, n_bases, flags);
-    batch_impl(*key.bs, key.offset, n_bases, scalar_vecs, lens, k, flags, out, out_is_inf, *L.c);
+    require((out && lens) || k == 0, NMX_E_ARG, "null argument");
+    std::vector<uint8_t> res(64 * (k ? k : 1)), rinf(k ? k : 1);
+    with_slice(*L.c, o, curve, bases, n_bases, flags,
+               [&](const SliceKey& key) {
+                 batch_impl(*key.bs, key.offset, n_bases, scalar_vecs, lens, k, flags, res.data(), rinf.data(), *L.c);
+               },
+               [&] {
+                 memcpy(out, res.data(), 64 * k);
+                 if (out_is_inf) memcpy(out_is_inf, rinf.data(), k);
+               });
   });
 }
 
@@ -1080,6 +1287,16 @@ int nmx_field_cross_term(int field, const void* az, const void* bz, const void* 
     if (n == 0) return;
     CtxLease L;
     fv_cross_term(*L.c, field, az, bz, cz, e, u, n, flags, out);
+  });
+}
+int nmx_field_cross_term2(int field, const void* az, const void* bz, const void* cz, const void* e1, const void* e2,
+                          const void* u, size_t n, uint32_t flags, void* out) {
+  return guarded([&] {
+    require((az && bz && cz && e1 && e2 && out) || n == 0, NMX_E_ARG, "null argument");
+    require(u != nullptr, NMX_E_ARG, "null argument");
+    if (n == 0) return;
+    CtxLease L;
+    fv_cross_term2(*L.c, field, az, bz, cz, e1, e2, u, n, flags, out);
   });
 }
 int nmx_field_vec_add(int field, const void* a, const void* b, size_t n, uint32_t flags, void* out) {
@@ -1390,6 +1607,10 @@ int nmx_set_option(const char* name, uint32_t value) {
     else if (n == "no_batch_fuse") G.no_batch_fuse = value;
     else if (n == "no_tree_fuse") G.no_tree_fuse = value;
     else if (n == "shard_min_n") G.shard_min_n.store(value ? value : 1u);
+    else if (n == "cache_table_after") {  // slice cache: window tables from the (value + 1)-th use of an array on (0: at upload)
+      std::lock_guard<std::mutex> ck(SC.mu);
+      SC.table_after_uses = value;
+    } else if (n == "max_table_mib") G.max_table_bytes.store((size_t)value << 20);  // 0: no limit but the HBM itself
     else if (n == "horner_top") G.horner_top = value;
     else if (n == "seg_heavy_above") G.seg_heavy_above = value > 63u ? 63u : value;
     else throw Fail{NMX_E_ARG, "unknown option name"};

@@ -164,7 +164,7 @@ static XYZZ<CurveT<CID>::BF> run_msm(Ctx& c, const void* d_bases, size_t n, cons
   MsmShape sh{};
   const bool prof = G.profiling.load(std::memory_order_relaxed);
   // The dry pass only sizes the workspace; its answer is a function of the call's shape, remembered per context.
-  const uint64_t shape_key = shape_hash(a, mc, sbytes, (uint32_t)CID, sbits, DeviceBackend(c, true, false).template seg_lanes<BF>());
+  const uint64_t shape_key = shape_hash(a, mc, sbytes, (uint32_t)CID, sbits, DeviceBackend(c, true, false).template seg_lanes<BF>((size_t)a.n * 16));
   // A remembered workspace size that turns out too small (a stale entry) is not fatal: forget it and size again.
   for (int attempt = 0; attempt < 2; attempt++) try {
   for (int pass = (c.shape_key == shape_key && c.shape_bytes <= c.cap) ? 1 : 0; pass < 2; pass++) {
@@ -243,6 +243,13 @@ template <int CID> static void table_shape(size_t n, uint32_t flags, uint32_t* p
   *pre_c = c;
   *pre_W = W;
 }
+static inline void apply_table_limit(size_t n, uint32_t* pre_c, uint32_t* pre_W) {  // option max_table_mib
+  const size_t limit = G.max_table_bytes.load(std::memory_order_relaxed);
+  if (*pre_W && limit && n * 64 * (size_t)*pre_W > limit) {
+    *pre_c = *pre_W = 0;
+    note_table_fallback();
+  }
+}
 struct ScratchFree {  // registration-time scratch (not the per-call arena: it can be gigabytes, and it is needed once)
   void* p = nullptr;
   ~ScratchFree() {
@@ -285,14 +292,28 @@ static void upload_bases(Ctx& c, BaseSet& bs, const void* src, uint32_t flags, c
   table_shape<CID>(n, flags, pre_c, pre_W);
   bs.any_identity = false;
   if (n == 0) return;
-  HIPCHK(hipMalloc(&d, n * 64 * (*pre_W ? *pre_W : 1)));
+  // Degrade instead of failing when the window tables do not fit (the reference supports pruned .ptau
+  // keys up to 2^28 points, README.md:130-138 -- 13 table copies of those are ~208 GiB): over the configured limit, or
+  // hipMalloc out of memory -> the key alone, and MSMs over it take the plain path (W bucket sets, no tables).
+  apply_table_limit(n, pre_c, pre_W);
+  hipError_t me = hipMalloc(&d, n * 64 * (*pre_W ? *pre_W : 1));
+  if (me == hipErrorOutOfMemory && *pre_W) {
+    (void)hipGetLastError();
+    *pre_c = *pre_W = 0;
+    note_table_fallback();
+    me = hipMalloc(&d, n * 64);
+  }
+  if (me != hipSuccess) {
+    (void)hipGetLastError();
+    throw Fail{NMX_E_HIP, std::string("hipMalloc of the key: ") + hipGetErrorString(me)};
+  }
   try {
     if (fill) (*fill)(d, c.stream);
     else
       HIPCHK(hipMemcpyAsync(d, src, n * 64,
                             (flags & NMX_BASES_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                             c.stream));
-    if (flags & NMX_BASES_VALIDATE) {
+    if ((flags & NMX_BASES_VALIDATE) && !(flags & NMX_BASES_INTERNAL)) {
       arena_reserve(c, 256);
       uint32_t* derr = (uint32_t*)c.arena;
       HIPCHK(hipMemsetAsync(derr, 0, 4, c.stream));
@@ -304,12 +325,19 @@ static void upload_bases(Ctx& c, BaseSet& bs, const void* src, uint32_t flags, c
       HIPCHK(hipStreamSynchronize(c.stream));
       require(herr == 0, NMX_E_POINT, "PointNotOnCurve: a loaded point is not canonical or not on the curve");
     }
-    {
+    if (!(flags & NMX_BASES_INTERNAL)) {
       DeviceBackend be(c, false, false);
       ToInternalFn<BF> f{(uint32_t*)d, (flags & NMX_BASES_MONT) ? 1u : 0u};
       be.launch(f, (uint32_t)(2 * n));
     }
-    build_tables<CID>(c, d, n, *pre_c, *pre_W);
+    try {
+      build_tables<CID>(c, d, n, *pre_c, *pre_W);
+    } catch (const Fail& f) {  // the registration-time scratch (176 B per table point of a 2^20-point chunk) did not fit
+      if (f.msg.find("out of memory") == std::string::npos) throw;
+      (void)hipStreamSynchronize(c.stream);
+      *pre_c = *pre_W = 0;  // the table area stays allocated but unused: MSMs take the plain path
+      note_table_fallback();
+    }
     bs.any_identity = scan_identity(c, d, n);  // also the stream sync that ends the upload
   } catch (...) {
     (void)hipFree(d);
@@ -395,7 +423,7 @@ static void run_msm_batch(Ctx& c, const BaseSet& bs, size_t offset, const BatchI
   uint32_t err = 0;
   const bool prof = G.profiling.load(std::memory_order_relaxed);
   const uint64_t shape_key =
-      (shape_hash(a, shared, 32, (uint32_t)CID, sbits, DeviceBackend(c, true, false).template seg_lanes<BF>()) ^ lens_hash ^ (k << 48)) | 1u;
+      (shape_hash(a, shared, 32, (uint32_t)CID, sbits, DeviceBackend(c, true, false).template seg_lanes<BF>((size_t)a.n * 16)) ^ lens_hash ^ (k << 48)) | 1u;
   for (int attempt = 0; attempt < 2; attempt++) try {
   for (int pass = (c.shape_key == shape_key && c.shape_bytes <= c.cap) ? 1 : 0; pass < 2; pass++) {
     DeviceBackend be(c, pass == 0, prof);
@@ -468,6 +496,11 @@ template <int CID> struct CurveImpl {
     for (size_t j = 0; j < k; j++) write_result<CID>(r[j], flags, out + 64 * j, inf ? inf + j : nullptr);
   }
   static uint32_t batch_limit(const BaseSet& bs) { return batch_limit_for<CID>(bs); }
+  static size_t table_bytes(size_t n) {  // HBM a key of n points takes with its window tables
+    uint32_t c = 0, W = 0;
+    table_shape<CID>(n, NMX_BASES_PRECOMPUTE, &c, &W);
+    return n * 64 * (size_t)(W ? W : 1);
+  }
   // h * r on the host (~380 point operations, 0.1-0.2 ms); identity when r == 0
   static XYZZ<BF> blind_point(const void* h_xy64, const void* r, uint32_t flags) {
     uint32_t rw[8];
@@ -532,6 +565,7 @@ template <int CID> struct CurveImpl {
     void* d = nullptr;
     const size_t n = bs.n;
     table_shape<CID>(n, flags, &bs.pre_c, &bs.pre_W);
+    apply_table_limit(n, &bs.pre_c, &bs.pre_W);
     if (n) HIPCHK(hipMalloc(&d, n * 64 * (bs.pre_W ? bs.pre_W : 1)));
     try {
       DeviceBackend be(c, false, false);
@@ -578,7 +612,7 @@ template <int CID> struct CurveImpl {
   }
   static CurveOps ops() {
     return CurveOps{&msm_key, &msm_key_batch, &batch_limit, &commit, &upload, &check_point_host, FpParams<BF>::PW,
-                    &generate, &internal_to_canonical, &point_sum, &blind_term, &check_layout};
+                    &generate, &internal_to_canonical, &point_sum, &blind_term, &check_layout, &table_bytes};
   }
 };
 

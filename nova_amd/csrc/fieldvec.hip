@@ -49,6 +49,21 @@ template <int FID> struct CrossTermFn {
     st<FID>(out, i, t);
   }
 };
+// commit_T_relaxed's term (src/r1cs/mod.rs:652-659): az*bz - u*cz - e1 - e2, both error vectors in the one pass
+template <int FID> struct CrossTerm2Fn {
+  const uint32_t *az, *bz, *cz, *e1, *e2;
+  uint32_t* out;
+  Fp<FID> u, k;  // as CrossTermFn
+  NMX_HD void operator()(uint32_t i) const {
+    using F = Fp<FID>;
+    F ab = (ld<FID>(az, i) * ld<FID>(bz, i)) * k;       // < 1.02 p
+    F uc = u * ld<FID>(cz, i);                          // < 1.01 p
+    F t = F::sub2(ab, uc).norm();                       // ab - uc + 2p            < 3.1 p
+    F es = (ld<FID>(e1, i) + ld<FID>(e2, i)).norm();    // e1 + e2 (canonical)     < 2 p
+    t = F::sub4(t, es).norm();                          // - (e1 + e2) + 4p        < 7.1 p  (canon() takes < 16 p)
+    st<FID>(out, i, t);
+  }
+};
 template <int FID> struct VecAddFn {
   const uint32_t *a, *b;
   uint32_t* out;
@@ -128,10 +143,12 @@ template <int FID> struct SpmvClassifyFn {  // after the coefficients are in int
     indices[k] |= cls << kSpmvColBits;
   }
 };
-// coefficient class `cls` (>= 1) applied to z: a value < p, canonical
-template <int FID> NMX_HD Fp<FID> spmv_small_term(uint32_t cls, const Fp<FID>& zf) {
+// coefficient class `cls` (>= 1) applied to z: a value < p, canonical.  z is any 256-bit value: it is reduced first (a
+// z >= p -- the general Montgomery path reduces those correctly too -- would otherwise leave k z beyond canon()'s 16 p)
+template <int FID> NMX_HD Fp<FID> spmv_small_term(uint32_t cls, const Fp<FID>& z_any) {
   using F = Fp<FID>;
   const uint32_t k = cls <= 2 ? 1u : (cls <= 8 ? cls - 1u : cls - 7u);  // |coefficient|
+  const F zf = z_any.canon();                         // 2^256 < 6 p for all four fields
   F t;
 #pragma unroll
   for (int i = 0; i < 9; i++) t.l[i] = zf.l[i] * k;  // z canonical: limbs < 2^29, k <= 7
@@ -242,12 +259,14 @@ template <int FID> struct HornerLocalFn {
   NMX_HD void operator()(uint32_t c) const {
     using F = Fp<FID>;
     const uint32_t lo = c * kHornerChunk, hi = lo + kHornerChunk < n ? lo + kHornerChunk : n;
+    // t < 2.02 p throughout (f < p, u t < p (1 + 2.02 / 127)): the chain runs on the weakly reduced value and only the
+    // stored copy is canonicalised, with the two subtractions a value below 4p needs
     F t = F::zero();
     for (uint32_t i = hi; i-- > lo;) {
-      t = (ld<FID>(f, i) + u * t).norm().canon();
-      t.to_words(out + 8 * (size_t)i);
+      t = (ld<FID>(f, i) + u * t).norm();
+      t.canon4().to_words(out + 8 * (size_t)i);
     }
-    t.to_words(heads + 8 * (size_t)c);
+    t.canon4().to_words(heads + 8 * (size_t)c);
   }
 };
 template <int FID> struct HornerFixFn {
@@ -292,7 +311,7 @@ template <int FID, uint32_t K> struct HornerHeadFn {
     } else {
       for (uint32_t k = cnt; k-- > 0;) t = (ld<FID>(f, lo + k) + u * t).norm();
     }
-    st<FID>(heads, c, t);
+    t.canon4().to_words(heads + 8 * (size_t)c);  // t < 2.02 p
   }
 };
 template <int FID, uint32_t K> struct HornerWalkFn {
@@ -312,9 +331,9 @@ template <int FID, uint32_t K> struct HornerWalkFn {
 #pragma unroll
         for (int j = 0; j < 8; j++) w[k][j] = f[8 * (size_t)(lo + k) + j];
 #pragma unroll
-      for (uint32_t k = K; k-- > 0;) {
-        t = (F::from_words(w[k]) + u * t).norm().canon();
-        t.to_words(w[k]);
+      for (uint32_t k = K; k-- > 0;) {  // t < 2.02 p (carry canonical): the chain stays weakly reduced
+        t = (F::from_words(w[k]) + u * t).norm();
+        t.canon4().to_words(w[k]);
       }
 #pragma unroll
       for (uint32_t k = 0; k < K; k++)
@@ -322,8 +341,8 @@ template <int FID, uint32_t K> struct HornerWalkFn {
         for (int j = 0; j < 8; j++) out[8 * (size_t)(lo + k) + j] = w[k][j];
     } else {
       for (uint32_t k = cnt; k-- > 0;) {
-        t = (ld<FID>(f, lo + k) + u * t).norm().canon();
-        t.to_words(out + 8 * (size_t)(lo + k));
+        t = (ld<FID>(f, lo + k) + u * t).norm();
+        t.canon4().to_words(out + 8 * (size_t)(lo + k));
       }
     }
   }
@@ -411,6 +430,15 @@ template <int FID> struct FieldImpl {
     // canonical data: k = 2^522 (R2); Montgomery data (F = 2^256): k = 2^522 / 2^256 = 2^266 (C266)
     F k = mont ? F::from_limbs(FpParams<FID>::C266) : F::from_limbs(FpParams<FID>::R2);
     CrossTermFn<FID> f{io.in(az, n), io.in(bz, n), io.in(cz, n), io.in(e, n), io.out(out, n), challenge<FID>(u, mont), k};
+    timed_launch(c, f, n, &io);
+  }
+  static void cross_term2(Ctx& c, const void* az, const void* bz, const void* cz, const void* e1, const void* e2,
+                          const void* u, size_t n, uint32_t flags, void* out) {
+    const bool mont = flags & NMX_SCALARS_MONT;
+    VecIO io(c, flags & NMX_SCALARS_DEVICE, n, 6);
+    F k = mont ? F::from_limbs(FpParams<FID>::C266) : F::from_limbs(FpParams<FID>::R2);
+    CrossTerm2Fn<FID> f{io.in(az, n), io.in(bz, n), io.in(cz, n), io.in(e1, n), io.in(e2, n), io.out(out, n),
+                        challenge<FID>(u, mont), k};
     timed_launch(c, f, n, &io);
   }
   static void vec_add(Ctx& c, const void* a, const void* b, size_t n, uint32_t flags, void* out) {
@@ -795,6 +823,10 @@ void fv_axpy2(Ctx& c, int field, const void* a, const void* b, const void* cc, c
 void fv_cross_term(Ctx& c, int field, const void* az, const void* bz, const void* cz, const void* e, const void* u,
                    size_t n, uint32_t flags, void* out) {
   FIELD_SWITCH(field, cross_term(c, az, bz, cz, e, u, n, flags, out));
+}
+void fv_cross_term2(Ctx& c, int field, const void* az, const void* bz, const void* cz, const void* e1, const void* e2,
+                    const void* u, size_t n, uint32_t flags, void* out) {
+  FIELD_SWITCH(field, cross_term2(c, az, bz, cz, e1, e2, u, n, flags, out));
 }
 void fv_vec_add(Ctx& c, int field, const void* a, const void* b, size_t n, uint32_t flags, void* out) {
   FIELD_SWITCH(field, vec_add(c, a, b, n, flags, out));

@@ -133,7 +133,7 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
   const uint32_t extra_cap = 2 * heavy_cap;
 
   const bool part = partition_supported(sh, a.pre_stride != 0) && !a.no_partition;
-  const uint32_t seg_lanes = part ? be.template seg_lanes<FID>() : 0;
+  const uint32_t seg_lanes = part ? be.template seg_lanes<FID>(total) : 0;
   const bool seg = part && seg_lanes && total >= a.seg_min_total;  // segment-balanced accumulate (msm_seg.hpp)
   // Everything that must start as zero lives in ONE block, cleared by ONE fill: bucket bounds, counters, the tickets of the
   // big-bucket pass and the partition's histograms / cursors.  (Round 2 issued five fills per MSM, 3-5 us each plus the

@@ -109,6 +109,9 @@ using BaseRef = std::shared_ptr<const BaseSet>;
 // everything but the trivial sizes.  (4096 until the small sizes were measured, scripts/gpu_smallmsm.py: with tables a
 // 2^11-pair MSM takes 0.29 ms instead of 0.98 -- one bucket set instead of 37, no 250-doubling Horner on the host.)
 static constexpr size_t kPrecompMinN = 2;  // default of Global::precomp_min_n
+// internal upload flag (never part of the ABI): the source array is a resident key already in the internal form -- no
+// conversion, no validation (the slice cache adding window tables to a key it holds)
+static constexpr uint32_t NMX_BASES_INTERNAL = 1u << 30;
 struct Global {
   std::mutex mu;
   bool inited = false;
@@ -120,6 +123,7 @@ struct Global {
   std::vector<int> hip_dev;
   std::atomic<uint32_t> ndev_active{1};
   std::atomic<size_t> shard_min_n{(size_t)1 << 20};  // keys shorter than this stay whole on the primary device
+  std::atomic<size_t> max_table_bytes{0};  // option max_table_mib / env NMX_MAX_TABLE_MIB: window tables larger than this are not built (0: no limit)
   std::vector<std::vector<Ctx*>> free_ctx;  // per logical device
   std::vector<Ctx*> all_ctx;
   std::unordered_map<uint64_t, std::shared_ptr<BaseSet>> bases;
@@ -153,6 +157,7 @@ struct Global {
   std::atomic<uint32_t> no_tree_fuse{0};          // env NMX_TUNE_NO_TREE_FUSE / option no_tree_fuse: one launch per reduction level (round 2; A/B runs)
 };
 extern Global& G;                // capi.hip (heap singleton, never destroyed)
+void note_table_fallback();                // NMX_STAT_TABLE_FALLBACKS (capi.hip)
 void prof_store(const float* ms, int n);   // last call's stage times of this thread (capi.hip)
 void prof_add_tail(float ms);
 void arena_reserve(Ctx& c, size_t bytes);  // capi.hip
@@ -226,16 +231,23 @@ struct DeviceBackend {
   // Measured (profiles/r02_msm_2p20/seg_lanes_sweep.txt; 196 608 lanes are resident): whole multiples only -- 1.5x
   // leaves half the chip idle in the second round (+7 %); 1x (every wave in lock step from start to end) accumulate
   // 1.25 ms + fold 0.06 at 2^20, 3x 1.17 + 0.13; at 2^21 3x wins by 2.5 % (3.05 against 3.13 ms).
-  template <int FID> uint32_t seg_lanes() {
-    static const uint32_t lanes = [] {
+  // Round 3 (profiles/r03_msm_2p20/seg_lanes_sweep.txt), after the plan step moved into the accumulate kernel and the fold
+  // stage shrank: the accumulate kernel itself gains 1-2 % per extra round of lanes (2^20: 1.141 / 1.145 / 1.121 ms at 1x / 2x /
+  // 3x; 2^21: 2.41 / 2.32 / 2.29), the final pass loses 30 us per round (pieces per bucket: 3 / 6 / 9 at c = 17; fold
+  // 0.051 / 0.086 / 0.114 ms).  Up to 2^24 sorted entries (keys up to 2^20 points) one round wins (2^20: 1.627 ms against
+  // 1.666 / 1.672; 2^18: 0.687 against 0.719), above it two (2^21: 2.986 against 3.036 at 1x and 2.987 at 3x).
+  // Half rounds (1.5x) always lose: the second round runs half empty.
+  static uint32_t seg_rounds(size_t total_entries) { return total_entries <= ((size_t)1 << 24) ? 1u : 2u; }
+  template <int FID> uint32_t seg_lanes(size_t total_entries) {
+    static const uint32_t resident = [] {
       int blocks = 0, dev = 0;
       hipDeviceProp_t prop;
       if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0u;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_launch<AccumSegFn<FID, 1>>, 256, 0) != hipSuccess) return 0u;
-      return 3u * (uint32_t)blocks * 256u * (uint32_t)prop.multiProcessorCount;
+      return (uint32_t)blocks * 256u * (uint32_t)prop.multiProcessorCount;
     }();
     const uint32_t ov = G.seg_lanes_override.load(std::memory_order_relaxed);
-    return ov ? ov : lanes;
+    return ov ? ov : seg_rounds(total_entries) * resident;
   }
   template <int FID>
   void launch_fold_raw(const uint32_t* counters, const HeavyRec* list, XYZZL* partial_raw, uint32_t T, uint32_t cap,
@@ -430,6 +442,7 @@ struct CurveOps {
   // host: the blinding term h * r of `commit` as a 128-byte partial (h, r in the ABI forms `flags` names)
   void (*blind_term)(const void* h_xy64, const void* r, uint32_t flags, uint8_t* out128);
   bool (*check_layout)(const uint8_t* generator_raw64, const uint8_t* scalar_raw32, uint64_t value);  // host
+  size_t (*table_bytes)(size_t n);  // host: HBM bytes of an n-point key with its window tables
 };
 // field-vector kernels (fieldvec.hip)
 void fv_axpy(Ctx&, int field, const void* a, const void* b, const void* r, size_t n, uint32_t flags, void* out);
@@ -437,6 +450,8 @@ void fv_axpy2(Ctx&, int field, const void* a, const void* b, const void* c, cons
               void* out);
 void fv_cross_term(Ctx&, int field, const void* az, const void* bz, const void* cz, const void* e, const void* u,
                    size_t n, uint32_t flags, void* out);
+void fv_cross_term2(Ctx&, int field, const void* az, const void* bz, const void* cz, const void* e1, const void* e2,
+                    const void* u, size_t n, uint32_t flags, void* out);
 void fv_vec_add(Ctx&, int field, const void* a, const void* b, size_t n, uint32_t flags, void* out);
 void fv_bind(Ctx&, int field, const void* z, size_t z_len, size_t lo_off, size_t hi_off, size_t stride, const void* r,
              size_t n_out, uint32_t flags, void* out);

@@ -4,6 +4,7 @@ Reference sites (relative to /root/reference):
   axpy        W = W1 + r*W2, E = E1 + r*T           src/r1cs/mod.rs:1058-1067   (RelaxedR1CSWitness::fold)
   axpy2       E = E1 + r*T + r^2*E2                 src/r1cs/mod.rs:1096-1101   (fold_relaxed)
   cross_term  T = AZ o BZ - u*CZ - E                src/r1cs/mod.rs:614-620     (commit_T)
+  cross_term2 T = AZ o BZ - u*CZ - E1 - E2          src/r1cs/mod.rs:652-659     (commit_T_relaxed)
   vec_add     Z = Z1 + Z2                           src/r1cs/mod.rs:590-609
   bind_poly_var_top                                 src/spartan/polys/multilinear.rs:65-84
   fold_pairs  Pi[j] = P[2j] + x*(P[2j+1] - P[2j])   src/provider/hyperkzg.rs:1085-1095
@@ -76,6 +77,17 @@ def cross_term(field, az, bz, cz, e, u, mont=False):
     po, out = _out_like(dev, n, az)
     uu = _chal(u)
     _check(L.lib().nmx_field_cross_term(field, p1, p2, p3, p4, uu.ctypes.data, n, _flags(dev, mont), po))
+    return out
+
+
+def cross_term2(field, az, bz, cz, e1, e2, u, mont=False):
+    """T = AZ o BZ - u*CZ - E1 - E2, u = U1.u + U2.u (commit_T_relaxed, src/r1cs/mod.rs:652-659)."""
+    ps = [_vec(x) for x in (az, bz, cz, e1, e2)]
+    n, dev = ps[0][1], ps[0][2]
+    assert all(q[1] == n for q in ps)
+    po, out = _out_like(dev, n, az)
+    uu = _chal(u)
+    _check(L.lib().nmx_field_cross_term2(field, *[q[0] for q in ps], uu.ctypes.data, n, _flags(dev, mont), po))
     return out
 
 

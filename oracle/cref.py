@@ -42,6 +42,7 @@ def lib():
         L.ref_field_axpy.argtypes = [ctypes.c_int, vp, vp, vp, sz, vp]
         L.ref_field_axpy2.argtypes = [ctypes.c_int, vp, vp, vp, vp, sz, vp]
         L.ref_field_cross_term.argtypes = [ctypes.c_int, vp, vp, vp, vp, vp, sz, vp]
+        L.ref_field_cross_term2.argtypes = [ctypes.c_int, vp, vp, vp, vp, vp, vp, sz, vp]
         L.ref_field_bind.argtypes = [ctypes.c_int, vp, sz, sz, sz, vp, sz, vp]
         L.ref_poly_suffix_horner.argtypes = [ctypes.c_int, vp, sz, vp, vp]
         L.ref_eq_evals.argtypes = [ctypes.c_int, vp, sz, vp]
@@ -192,6 +193,13 @@ def field_cross_term(fid, az, bz, cz, e, u, n):
     ps = [_buf(x) for x in (az, bz, cz, e, u)]
     out = np.zeros(32 * n, dtype=np.uint8)
     lib().ref_field_cross_term(fid, ps[0][0], ps[1][0], ps[2][0], ps[3][0], ps[4][0], n, out.ctypes.data)
+    return out.tobytes()
+
+
+def field_cross_term2(fid, az, bz, cz, e1, e2, u, n):
+    ps = [_buf(x) for x in (az, bz, cz, e1, e2, u)]
+    out = np.zeros(32 * n, dtype=np.uint8)
+    lib().ref_field_cross_term2(fid, *[q[0] for q in ps], n, out.ctypes.data)
     return out.tobytes()
 
 

@@ -733,6 +733,20 @@ int ref_field_cross_term(int field, const uint8_t* az, const uint8_t* bz, const 
   }
   return 0;
 }
+/* T = az*bz - u*cz - e1 - e2 (commit_T_relaxed, r1cs/mod.rs:652-659) */
+int ref_field_cross_term2(int field, const uint8_t* az, const uint8_t* bz, const uint8_t* cz, const uint8_t* e1, const uint8_t* e2,
+                          const uint8_t* u, size_t n, uint8_t* out) {
+  const field_t* F = field_by_id(field); if (!F) return -1;
+  fe uu; ld_mont(F, &uu, u);
+#pragma omp parallel for num_threads(nthreads())
+  for (long i = 0; i < (long)n; i++) {
+    fe a, b, c, x, y, t; ld_mont(F, &a, az + 32 * i); ld_mont(F, &b, bz + 32 * i); ld_mont(F, &c, cz + 32 * i);
+    ld_mont(F, &x, e1 + 32 * i); ld_mont(F, &y, e2 + 32 * i);
+    fe_mul(F, &a, &a, &b); fe_mul(F, &t, &uu, &c); fe_sub(F, &a, &a, &t); fe_sub(F, &a, &a, &x); fe_sub(F, &a, &a, &y);
+    st_canon(F, out + 32 * i, &a);
+  }
+  return 0;
+}
 /* out[i] = z[lo + i*stride] + r*(z[hi + i*stride] - z[lo + i*stride]):
  * bind_poly_var_top (multilinear.rs:65-84: lo = 0, hi = len/2, stride 1) and the HyperKZG halving
  * (hyperkzg.rs:1085-1095: lo = 0, hi = 1, stride 2) */

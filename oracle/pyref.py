@@ -219,6 +219,11 @@ def cross_term(p, az, bz, cz, e, u):
     return [(a * b - u * c - ee) % p for a, b, c, ee in zip(az, bz, cz, e)]
 
 
+def cross_term2(p, az, bz, cz, e1, e2, u):
+    """T = AZ o BZ - u*CZ - E1 - E2 (commit_T_relaxed, src/r1cs/mod.rs:652-659)."""
+    return [(a * b - u * c - x - y) % p for a, b, c, x, y in zip(az, bz, cz, e1, e2)]
+
+
 def fold_pairs(p, P, x):
     """Pi[j] = P[2j] + x*(P[2j+1] - P[2j]) (src/provider/hyperkzg.rs:1085-1095)."""
     return [(P[2 * j] + x * (P[2 * j + 1] - P[2 * j])) % p for j in range(len(P) // 2)]

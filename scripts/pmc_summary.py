@@ -3,7 +3,7 @@ import collections, csv, glob, json, sys
 src, dst = sys.argv[1], sys.argv[2]
 names = {"AccumFn": "accum", "AccumSegFn": "accum", "ReducePair": "reduce", "FoldFn": "fold", "FoldRaw": "fold_raw", "FinalSeg": "final_seg",
          "radix_sort": "sort", "DigitsFn": "digits", "k_hist_hi": "hist_hi", "k_part_hi": "part_hi", "k_hist_lo": "hist_lo",
-         "k_part_lo": "part_lo"}
+         "k_part_lo": "part_lo", "k_reduce_tree": "reduce_tree", "k_big_all": "big_all"}
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(src + "/p*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):

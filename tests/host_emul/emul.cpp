@@ -75,7 +75,7 @@ struct HostEmulBackend {
     launch(f, lanes / (SegPlan::kBigAbove + 1) + 1);
   }
   // segment-balanced accumulate (msm_seg.hpp): an odd lane count so segments straddle bucket boundaries everywhere
-  template <int FID> uint32_t seg_lanes() { return g_seg_lanes; }
+  template <int FID> uint32_t seg_lanes(size_t) { return g_seg_lanes; }
   template <int FID>
   void launch_fold_raw(const uint32_t* counters, const HeavyRec* list, XYZZL* partial_raw, uint32_t T, uint32_t cap,
                        uint32_t groups, uint32_t use_big) {

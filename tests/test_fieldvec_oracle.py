@@ -34,6 +34,8 @@ def test_oracle_field_vectors(fid):
     assert cref.field_axpy(fid, a, b, r, n) == enc(R.axpy(p, C.ints(a), C.ints(b), ri))
     assert cref.field_axpy2(fid, a, b, c, r, n) == enc(R.axpy2(p, C.ints(a), C.ints(b), C.ints(c), ri))
     assert cref.field_cross_term(fid, a, b, c, e, r, n) == enc(R.cross_term(p, C.ints(a), C.ints(b), C.ints(c), C.ints(e), ri))
+    assert cref.field_cross_term2(fid, a, b, c, e, b, r, n) == enc(
+        R.cross_term2(p, C.ints(a), C.ints(b), C.ints(c), C.ints(e), C.ints(b), ri))
     assert cref.field_bind(fid, a, 0, n // 2, 1, r, n // 2) == enc(R.bind_poly_var_top(p, C.ints(a), ri))
     assert cref.field_bind(fid, a, 0, 1, 2, r, n // 2) == enc(R.fold_pairs(p, C.ints(a), ri))
 

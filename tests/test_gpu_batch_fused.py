@@ -78,10 +78,11 @@ def test_ragged_sets_identity_points_and_layouts(nmx, c):
     got, fused, _ = fused_delta(lambda: [as_pair(x) for x in g.batch_vartime_multiscalar_mul(dv, ck)])
     assert got == exp and fused == 1
     ck.close()
-    # slice form: pageable host bases (twice: upload, then cache hit)
-    for _ in range(2):
+    # slice form: pageable host bases.  First and second sight: the array is resident without window tables (no fused
+    # run: one MSM per vector); from the third use on it has them and the batch is fused
+    for use in range(4):
         got, fused, _ = fused_delta(lambda: [as_pair(x) for x in g.batch_vartime_multiscalar_mul(vecs, host)])
-        assert got == exp and fused == 1
+        assert got == exp and fused == (1 if use >= 2 else 0), use
     # Montgomery layouts (what the Rust shim passes: INTEGRATION.md)
     hm = util.to_mont_bases(c.cid, host)
     vm = [util.to_mont_scalars(c.cid, v) for v in vecs]

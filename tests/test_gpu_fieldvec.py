@@ -26,6 +26,8 @@ def test_field_vectors_vs_oracle(nmx, fid, n):
     assert fv.axpy(fid, a, b, r).tobytes() == cref.field_axpy(fid, a, b, r, n)
     assert fv.axpy2(fid, a, b, c, r).tobytes() == cref.field_axpy2(fid, a, b, c, r, n)
     assert fv.cross_term(fid, a, b, c, e, r).tobytes() == cref.field_cross_term(fid, a, b, c, e, r, n)
+    e2 = C.edge_vectors(fid, n, 5)
+    assert fv.cross_term2(fid, a, b, c, e, e2, r).tobytes() == cref.field_cross_term2(fid, a, b, c, e, e2, r, n)
     assert fv.vec_add(fid, a, b).tobytes() == cref.field_axpy(fid, a, b, util.int_to_le32(1), n)
     assert fv.bind_poly_var_top(fid, a, r).tobytes() == cref.field_bind(fid, a, 0, n // 2, 1, r, n // 2)
     assert fv.fold_pairs(fid, a, r).tobytes() == cref.field_bind(fid, a, 0, 1, 2, r, n // 2)
@@ -48,6 +50,8 @@ def test_montgomery_layout_and_device_residency(nmx, fid):
     r = C.rand_vec(fid, 1, 9)
     got = fv.cross_term(fid, to_m(a), to_m(b), to_m(c), to_m(e), to_m(r), mont=True)
     assert from_m(got).tobytes() == cref.field_cross_term(fid, a, b, c, e, r, n)
+    got = fv.cross_term2(fid, to_m(a), to_m(b), to_m(c), to_m(e), to_m(a), to_m(r), mont=True)
+    assert from_m(got).tobytes() == cref.field_cross_term2(fid, a, b, c, e, a, r, n)
     got = fv.axpy2(fid, to_m(a), to_m(b), to_m(c), to_m(r), mont=True)
     assert from_m(got).tobytes() == cref.field_axpy2(fid, a, b, c, r, n)
     # HBM-resident operands and results; in-place bind like the reference's `*a += r * (*b - *a)`

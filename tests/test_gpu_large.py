@@ -74,6 +74,54 @@ def test_natural_c20_key_2p22(nmx):
     ck.close()
 
 
+def test_2p22_key_without_room_for_tables_still_runs_on_the_gpu(nmx):
+    """when the window tables do not fit -- here a 1 GiB limit against 3.3 GiB of c = 20 tables for a
+    2^22-point key (the reference supports keys up to 2^28 points, README.md:130-138) -- the key is registered WITHOUT them
+    and the MSM takes the plain GPU path (13 bucket sets) instead of failing or falling back to the CPU."""
+    from nova_amd import _lib
+    L = _lib.lib()
+    c = R.BN254_G1
+    n = 1 << 22
+    g = nmx.DlogGroup(c.cid)
+    assert L.nmx_set_option(b"max_table_mib", 1024) == 0
+    try:
+        fb = _lib.stats()[_lib.STAT_TABLE_FALLBACKS]
+        ck = nmx.CommitmentKey.generate(c.cid, n, k0=99)
+        assert _lib.stats()[_lib.STAT_TABLE_FALLBACKS] == fb + 1
+    finally:
+        assert L.nmx_set_option(b"max_table_mib", 0) == 0
+    bases = ck.read(0, n)
+    sc = util.random_scalars(c.cid, n, seed=44)
+    assert as_pair(g.vartime_multiscalar_mul(sc, ck)) == cref.msm(c.cid, sc, bases, n)
+    m = 3000001
+    assert as_pair(g.vartime_multiscalar_mul(sc[:m], ck, offset=1000)) == cref.msm(c.cid, sc[:m], bases[1000:1000 + m], m)
+    ck.close()
+
+
+def test_2p24_against_the_oracle(nmx):
+    """BASELINE configs[2]'s total size on one GPU (c = 20 tables, 13 GiB), full compare with the oracle: 2^24 uniformly random
+    scalars -- 2^22 drawn, then made distinct per quarter by adding j to each (mod r) on the device -- over the generated key."""
+    import torch
+    from nova_amd import fieldvec as fv
+    c = R.BN254_G1
+    n = 1 << 24
+    g = nmx.DlogGroup(c.cid)
+    ck = nmx.CommitmentKey.generate(c.cid, n, k0=1)
+    bases = ck.read(0, n)
+    q = n // 4
+    base = util.random_scalars(c.cid, q, seed=240)
+    sc = np.empty((n, 32), np.uint8)
+    for j in range(4):
+        off = np.zeros((q, 32), np.uint8)
+        off[:, 0] = j
+        off[:, 8] = 7 * j                                   # + j + 7j * 2^64
+        d = fv.vec_add(fv.BN254_FR, torch.from_numpy(base).cuda(), torch.from_numpy(off).cuda())
+        sc[j * q:(j + 1) * q] = d.cpu().numpy().reshape(q, 32)
+    got = g.vartime_multiscalar_mul(torch.from_numpy(sc).cuda(), ck)
+    assert as_pair(got) == cref.msm(c.cid, sc, bases, n)
+    ck.close()
+
+
 def test_shard_size_2p21_c17_tables(nmx):
     """The per-GPU shard of BASELINE configs[2] at 8 GPUs: a 2^21-point key (c = 17 tables, 15 windows, 16-bit bucket keys in
     the narrow partition geometry).  Full compare for random and witness-like scalars, prefix / interior slices of the key."""

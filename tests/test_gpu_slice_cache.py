@@ -109,13 +109,119 @@ def test_reused_address_with_new_content_is_detected(nmx, fresh, n):
     assert as_pair(g.vartime_multiscalar_mul(sc, bases)) == cref.msm(c.cid, sc, bases, n)
     d = delta(S, before)
     assert d[S.STAT_CACHE_UPLOADS] == 1 and d[S.STAT_CACHE_HITS] == 0
-    if n <= 2048:   # short arrays are verified in full: a single changed point is caught too
+    if n <= 2048:   # short arrays are verified in full: a single changed point is caught at once
         bases[n // 3] = cref.sequential_bases(c, 42, 1)[0]
         assert as_pair(g.vartime_multiscalar_mul(sc, bases)) == cref.msm(c.cid, sc, bases, n)
-    else:           # long arrays: the documented contract is nmx_cache_invalidate after an in-place edit
+    else:           # long arrays: nmx_cache_invalidate is the contract for in-place edits (immediate) ...
         bases[n // 3] = cref.sequential_bases(c, 42, 1)[0]
         assert S.lib().nmx_cache_invalidate(bases.ctypes.data) == 0
         assert as_pair(g.vartime_multiscalar_mul(sc, bases)) == cref.msm(c.cid, sc, bases, n)
+
+
+@pytest.mark.parametrize("n,where", [(50000, 0.37), (1 << 17, 0.999), (50000, 0.0001)])
+def test_single_point_edit_without_invalidate_is_caught_within_bounded_calls(nmx, fresh, n, where):
+    """... and WITHOUT the invalidate (a caller breaking the contract): every call fully verifies a rolling
+    window of max(4096, n/16) consecutive points of the caller's bytes -- concurrently with the MSM -- so one edited point
+    anywhere in a long array is noticed within 16 calls; the call that notices drops the entry, re-uploads and returns the
+    RIGHT point.  Until then the answers are those of the resident (old) key, never anything else."""
+    S = fresh
+    c = R.BN254_G1
+    g = nmx.DlogGroup(c.cid)
+    bases = cref.sequential_bases(c, 4242, n).copy()
+    sc = util.random_scalars(c.cid, n, seed=19)
+    old = cref.msm(c.cid, sc, bases, n)
+    assert as_pair(g.vartime_multiscalar_mul(sc, bases)) == old
+    j = min(n - 2, max(1, int(n * where)))          # not the first / last point (those are checked on every call)
+    bases[j] = cref.sequential_bases(c, 987654, 1)[0]
+    new = cref.msm(c.cid, sc, bases, n)
+    assert new != old
+    before = S.stats()
+    seen_new = None
+    for call in range(1, 18):
+        got = as_pair(g.vartime_multiscalar_mul(sc, bases))
+        assert got in (old, new), call
+        if got == new:
+            seen_new = call
+            break
+    assert seen_new is not None and seen_new <= 17, "the rolling check never reached the edited point"
+    d = delta(S, before)
+    assert d[S.STAT_CACHE_STALE] == 1 and d[S.STAT_CACHE_UPLOADS] == 1
+    for _ in range(3):                              # and it stays right
+        assert as_pair(g.vartime_multiscalar_mul(sc, bases)) == new
+
+
+def test_interior_slice_after_address_reuse(nmx, fresh):
+    """a short interior slice (no sampled grid point inside it in round 2) of an array whose memory was
+    reused for another key: its first and last points are hashed on every call, so the stale copy is never used."""
+    S = fresh
+    c = R.GRUMPKIN
+    g = nmx.DlogGroup(c.cid)
+    n = 40000
+    bases = cref.sequential_bases(c, 31, n).copy()
+    sc = util.random_scalars(c.cid, n, seed=2)
+    assert as_pair(g.vartime_multiscalar_mul(sc, bases)) == cref.msm(c.cid, sc, bases, n)
+    bases[:] = cref.sequential_bases(c, 999999, n)    # same address, another key
+    for a, m in ((1234, 5), (20001, 130), (39990, 10)):
+        got = g.vartime_multiscalar_mul(sc[:m], bases[a:a + m])
+        assert as_pair(got) == cref.msm(c.cid, sc[:m], bases[a:a + m], m), (a, m)
+
+
+def test_ipa_shaped_churn_builds_no_tables(nmx, fresh):
+    """IPA's `ck.fold` (/root/reference/src/provider/pedersen.rs:484-497): every round makes a FRESH key of half the length
+    and uses it for two MSMs (c_L over its left half's partner, c_R likewise).  First and second sight of an array upload /
+    reuse the key WITHOUT window tables (a table build per round would cost more than both MSMs); results == oracle."""
+    import time
+    S = fresh
+    c = R.PALLAS
+    g = nmx.DlogGroup(c.cid)
+    n = 1 << 14
+    before = S.stats()
+    t0 = time.perf_counter()
+    rounds = 0
+    key = cref.sequential_bases(c, 777, n).copy()
+    while n >= 256:
+        h = n // 2
+        a = util.random_scalars(c.cid, h, seed=n)
+        assert as_pair(g.vartime_multiscalar_mul(a, key[h:n])) == cref.msm(c.cid, a, key[h:n], h)    # c_L = <a_L, ck_R>
+        assert as_pair(g.vartime_multiscalar_mul(a, key[:h])) == cref.msm(c.cid, a, key[:h], h)      # c_R = <a_R, ck_L>
+        key = cref.sequential_bases(c, 1000 + n, h).copy()     # the folded key: new points, new allocation
+        n = h
+        rounds += 1
+    dt = time.perf_counter() - t0
+    d = delta(S, before)
+    assert d[S.STAT_CACHE_UPLOADS] == rounds and d[S.STAT_CACHE_HITS] == rounds
+    now = S.stats()
+    # nothing resident carries tables: bytes = sum of the plain keys still cached (64 B per point)
+    assert now[S.STAT_CACHE_BYTES] <= 64 * (1 << 15)
+    print(f"IPA-shaped churn: {rounds} rounds, 2 MSMs each, {dt * 1e3:.1f} ms incl. the oracle compares")
+
+
+def test_tables_arrive_on_third_use_and_respect_the_budget(nmx, fresh):
+    S = fresh
+    L = S.lib()
+    c = R.BN254_G1
+    g = nmx.DlogGroup(c.cid)
+    n = 1 << 15
+    bases = cref.sequential_bases(c, 5150, n).copy()
+    sc = util.random_scalars(c.cid, n, seed=1)
+    exp = cref.msm(c.cid, sc, bases, n)
+    sizes = []
+    for _ in range(4):
+        assert as_pair(g.vartime_multiscalar_mul(sc, bases)) == exp
+        sizes.append(S.stats()[S.STAT_CACHE_BYTES])
+    assert sizes[0] == sizes[1] == 64 * n and sizes[2] == sizes[3] and sizes[2] >= 64 * n * 8   # plain, plain, tables, tables
+    # a budget the tables do not fit: the array stays resident WITHOUT them and every call still runs on the GPU
+    assert L.nmx_cache_clear() == 0
+    assert L.nmx_cache_configure(4 * 64 * n, 0, 0) == 0
+    try:
+        fb = S.stats()[S.STAT_TABLE_FALLBACKS]
+        for _ in range(4):
+            assert as_pair(g.vartime_multiscalar_mul(sc, bases)) == exp
+        now = S.stats()
+        assert now[S.STAT_CACHE_BYTES] == 64 * n and now[S.STAT_TABLE_FALLBACKS] == fb + 1 and now[S.STAT_CACHE_ENTRIES] == 1
+    finally:
+        import torch
+        assert L.nmx_cache_configure(torch.cuda.get_device_properties(0).total_memory // 4, 0, 0) == 0
 
 
 def test_short_arrays_and_nocache_bypass(nmx, fresh):
