@@ -232,12 +232,13 @@ struct DeviceBackend {
   // leaves half the chip idle in the second round (+7 %); 1x (every wave in lock step from start to end) accumulate
   // 1.25 ms + fold 0.06 at 2^20, 3x 1.17 + 0.13; at 2^21 3x wins by 2.5 % (3.05 against 3.13 ms).
   // Round 3 (profiles/r03_msm_2p20/seg_lanes_sweep.txt), after the plan step moved into the accumulate kernel and the fold
-  // stage shrank: the accumulate kernel itself gains 1-2 % per extra round of lanes (2^20: 1.141 / 1.145 / 1.121 ms at 1x / 2x /
-  // 3x; 2^21: 2.41 / 2.32 / 2.29), the final pass loses 30 us per round (pieces per bucket: 3 / 6 / 9 at c = 17; fold
-  // 0.051 / 0.086 / 0.114 ms).  Up to 2^24 sorted entries (keys up to 2^20 points) one round wins (2^20: 1.627 ms against
-  // 1.666 / 1.672; 2^18: 0.687 against 0.719), above it two (2^21: 2.986 against 3.036 at 1x and 2.987 at 3x).
-  // Half rounds (1.5x) always lose: the second round runs half empty.
-  static uint32_t seg_rounds(size_t total_entries) { return total_entries <= ((size_t)1 << 24) ? 1u : 2u; }
+  // stage shrank: the accumulate kernel gains 1-3 % per extra round of lanes (2^20: 1.091 / 1.050 / 1.028 ms at 1x / 2x / 3x
+  // resident), the final pass loses 30 us per round (pieces per bucket 3 / 6 / 9 at c = 17: fold 0.051 / 0.083 / 0.110 ms).
+  // 2^20: a wash (1.565-1.576 / 1.559-1.561 / 1.555-1.575 ms, two alternating repetitions on one box); 2^18: one round
+  // wins by 4 % (0.687 against 0.719 ms); 2^21: two rounds by 1.6 % (2.986 against 3.036 at 1x, 2.987 at 3x).  Hence one
+  // round up to 2^23 sorted entries (keys up to 2^19 points), two above.  Half rounds (1.5x) always lose: the second
+  // round runs half empty (2^20: 1.704 ms).
+  static uint32_t seg_rounds(size_t total_entries) { return total_entries <= ((size_t)1 << 23) ? 1u : 2u; }
   template <int FID> uint32_t seg_lanes(size_t total_entries) {
     static const uint32_t resident = [] {
       int blocks = 0, dev = 0;

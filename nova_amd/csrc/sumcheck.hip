@@ -175,21 +175,59 @@ __global__ __launch_bounds__(256) void k_eq_rows(const uint32_t* A, const uint32
   }
 }
 
-template <int FID> __global__ __launch_bounds__(256) void k_sum_partials(const uint32_t* partial, uint32_t nparts, uint32_t* out) {
-  using F = Fp<FID>;
-  __shared__ uint32_t lds[9 * 256];
-  F s0 = F::zero(), s1 = F::zero();
-  for (uint32_t i = threadIdx.x; i < nparts; i += 256) {
-    s0 = (s0 + ldw<FID>(partial, 2 * (size_t)i)).norm().canon();
-    s1 = (s1 + ldw<FID>(partial, 2 * (size_t)i + 1)).norm().canon();
-  }
-  s0 = block_sum<FID>(s0, lds);
+// Final sums of the per-block partials, one block.  This launch is pure latency behind a multiplier-bound pass (24 us of a
+// 0.41 ms sum-check pass in round 2: profiles/r03_fieldvec/): the adds run lazily (one canonicalisation per 8 terms: values stay
+// < 9p < canon()'s 16p), and the J sums go through ONE tree -- 8 levels, the canonicalisation of a level's sum (< 2p) is the
+// two-subtraction form.
+template <int FID, int J> __device__ __forceinline__ void block_sum_multi(Fp<FID> (&v)[J], uint32_t* lds /* J x 256 x 9 */) {
+  const uint32_t t = threadIdx.x;
+#pragma unroll
+  for (int j = 0; j < J; j++)
+#pragma unroll
+    for (int i = 0; i < 9; i++) lds[(j * 9 + i) * 256 + t] = v[j].l[i];
   __syncthreads();
-  s1 = block_sum<FID>(s1, lds);
-  if (threadIdx.x == 0) {
-    s0.to_words(out);
-    s1.to_words(out + 8);
+  for (uint32_t s = 128; s >= 1; s >>= 1) {
+    if (t < s) {
+#pragma unroll
+      for (int j = 0; j < J; j++) {
+        Fp<FID> o;
+#pragma unroll
+        for (int i = 0; i < 9; i++) o.l[i] = lds[(j * 9 + i) * 256 + t + s];
+        v[j] = (v[j] + o).norm().canon4();  // < 2p -> < p
+#pragma unroll
+        for (int i = 0; i < 9; i++) lds[(j * 9 + i) * 256 + t] = v[j].l[i];
+      }
+    }
+    __syncthreads();
   }
+}
+template <int FID, int J, int STRIDE>
+__device__ __forceinline__ void sum_partials_body(const uint32_t* partial, uint32_t nparts, uint32_t* out, uint32_t* lds) {
+  using F = Fp<FID>;
+  F s[J];
+#pragma unroll
+  for (int j = 0; j < J; j++) s[j] = F::zero();
+  uint32_t pending = 0;
+  for (uint32_t i = threadIdx.x; i < nparts; i += 256) {
+#pragma unroll
+    for (int j = 0; j < J; j++) s[j] = (s[j] + ldw<FID>(partial, STRIDE * (size_t)i + j)).norm();
+    if (++pending == 8) {
+#pragma unroll
+      for (int j = 0; j < J; j++) s[j] = s[j].canon();
+      pending = 0;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < J; j++) s[j] = s[j].canon();
+  block_sum_multi<FID, J>(s, lds);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int j = 0; j < J; j++) s[j].to_words(out + 8 * j);
+  }
+}
+template <int FID> __global__ __launch_bounds__(256) void k_sum_partials(const uint32_t* partial, uint32_t nparts, uint32_t* out) {
+  __shared__ uint32_t lds[2 * 9 * 256];
+  sum_partials_body<FID, 2, 2>(partial, nparts, out, lds);
 }
 
 template <int FID> static Fp<FID> challenge_internal(const void* r, bool mont) {
@@ -651,15 +689,8 @@ __global__ __launch_bounds__(256) void k_plain_sums(const uint32_t* A, const uin
 }
 
 template <int FID> __global__ __launch_bounds__(256) void k_sum_partials3(const uint32_t* partial, uint32_t nparts, uint32_t* out) {
-  using F = Fp<FID>;
-  __shared__ uint32_t lds[9 * 256];
-  for (int j = 0; j < 3; j++) {
-    F s = F::zero();
-    for (uint32_t i = threadIdx.x; i < nparts; i += 256) s = (s + ldw<FID>(partial, 4 * (size_t)i + j)).norm().canon();
-    s = block_sum<FID>(s, lds);
-    if (threadIdx.x == 0) s.to_words(out + 8 * j);
-    __syncthreads();
-  }
+  __shared__ uint32_t lds[3 * 9 * 256];
+  sum_partials_body<FID, 3, 4>(partial, nparts, out, lds);
 }
 
 template <int FID, int KIND>

@@ -167,9 +167,11 @@ def test_interior_slice_after_address_reuse(nmx, fresh):
 
 
 def test_ipa_shaped_churn_builds_no_tables(nmx, fresh):
-    """IPA's `ck.fold` (/root/reference/src/provider/pedersen.rs:484-497): every round makes a FRESH key of half the length
-    and uses it for two MSMs (c_L over its left half's partner, c_R likewise).  First and second sight of an array upload /
-    reuse the key WITHOUT window tables (a table build per round would cost more than both MSMs); results == oracle."""
+    """IPA's prover loop (/root/reference/src/provider/ipa_pc.rs:212-230 with pedersen.rs:461-497): every round clones the key
+    into two FRESH Vecs -- `ck_R.combine(&ck_c)` and `ck_L.combine(&ck_c)`, n/2 + 1 points each -- commits once to each, then
+    folds the key into yet another fresh Vec of half the length.  Every MSM therefore sees an array for the first time: the
+    slice cache uploads it WITHOUT window tables (a table build per array would cost more than the one MSM that uses it),
+    never hits, and evicts by LRU; results == oracle."""
     import time
     S = fresh
     c = R.PALLAS
@@ -178,22 +180,24 @@ def test_ipa_shaped_churn_builds_no_tables(nmx, fresh):
     before = S.stats()
     t0 = time.perf_counter()
     rounds = 0
-    key = cref.sequential_bases(c, 777, n).copy()
+    key = cref.sequential_bases(c, 777, n)
+    ck_c = cref.sequential_bases(c, 5, 1)
     while n >= 256:
         h = n // 2
-        a = util.random_scalars(c.cid, h, seed=n)
-        assert as_pair(g.vartime_multiscalar_mul(a, key[h:n])) == cref.msm(c.cid, a, key[h:n], h)    # c_L = <a_L, ck_R>
-        assert as_pair(g.vartime_multiscalar_mul(a, key[:h])) == cref.msm(c.cid, a, key[:h], h)      # c_R = <a_R, ck_L>
-        key = cref.sequential_bases(c, 1000 + n, h).copy()     # the folded key: new points, new allocation
+        a = util.random_scalars(c.cid, h + 1, seed=n)
+        for half in (key[h:n], key[:h]):                       # c_L = <a_L, ck_R> + <a_L, b_R> c ; c_R likewise
+            fresh_vec = np.concatenate([half, ck_c])           # combine(): a new allocation every time
+            assert as_pair(g.vartime_multiscalar_mul(a, fresh_vec)) == cref.msm(c.cid, a, fresh_vec, h + 1)
+        key = cref.sequential_bases(c, 1000 + n, h)            # ck.fold(): new points, new allocation
         n = h
         rounds += 1
     dt = time.perf_counter() - t0
     d = delta(S, before)
-    assert d[S.STAT_CACHE_UPLOADS] == rounds and d[S.STAT_CACHE_HITS] == rounds
+    assert d[S.STAT_CACHE_UPLOADS] == 2 * rounds and d[S.STAT_CACHE_HITS] == 0 and d[S.STAT_TABLE_FALLBACKS] == 0
     now = S.stats()
-    # nothing resident carries tables: bytes = sum of the plain keys still cached (64 B per point)
-    assert now[S.STAT_CACHE_BYTES] <= 64 * (1 << 15)
-    print(f"IPA-shaped churn: {rounds} rounds, 2 MSMs each, {dt * 1e3:.1f} ms incl. the oracle compares")
+    # nothing resident carries tables: the cache holds plain keys only (64 B per point; at most 32 entries)
+    assert now[S.STAT_CACHE_BYTES] <= 64 * 2 * ((1 << 14) + 64)
+    print(f"IPA-shaped churn: {rounds} rounds, 2 first-sight MSMs each ({(1 << 13) + 1} .. 129 points), {dt * 1e3:.1f} ms incl. the oracle compares")
 
 
 def test_tables_arrive_on_third_use_and_respect_the_budget(nmx, fresh):
