@@ -41,10 +41,12 @@ BYTES_PER_PAIR = 96            # 32 B scalar + 64 B affine base, each read once 
 STAGES = ["digits", "sort", "bounds_plan", "accum", "fold", "reduce", "tail"]
 DTYPE = "9x29-bit limbs (256-bit modular integer, Montgomery R = 2^261)"
 MAD_PEAK_T = 28.8              # measured v_mad_u64_u32 rate, T/s (bench/ubench.hip)
-# multiply-adds per XYZZ mixed addition (curve.hpp add_affine: 5 products, 2 squarings, 1 two-product sum) by base
-# field: BN254 Fq / Fr 5 x 162 + 2 x 126 + 243; the Pasta moduli have three zero limbs of nine, whose reduction
-# terms are dropped at compile time: 5 x 135 + 2 x 99 + 216
-MADS_PER_MADD_BY_CURVE = {0: 1305, 1: 1305, 2: 1089, 3: 1089}
+# multiply-adds per XYZZ mixed addition (curve.hpp add_affine: 6 products, 2 squarings, 1 two-product sum with one
+# reduction) by base field: BN254 Fq / Fr 6 x 162 + 2 x 126 + 243 = 1467 (the static count of the kernel agrees:
+# profiles/r03_msm_2p20/accum_isa_hist.txt); the Pasta moduli have three zero limbs of nine, whose reduction terms are
+# dropped at compile time: 6 x 135 + 2 x 99 + 216 = 1224
+MADS_PER_MADD_BY_CURVE = {0: 1467, 1: 1467, 2: 1224, 3: 1224}
+VALU_PEAK_T = 256 * 64 * 2.4e9 / 1e12   # 39.3 T lane-ops/s: 256 CUs x 64 lanes per clock x 2.4 GHz max clock (MI355X_MICROARCH.md)
 
 
 def table_window_bits(n, args):
@@ -68,7 +70,8 @@ def pmc_valu(args, world):
     if not (world == 1 and args.curve == 0 and args.log2n == 20 and args.dist == "random" and not args.window_bits):
         return None
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "r02_msm_2p20", "pmc_traffic.json")))["accum"]["SQ_INSTS_VALU"]
+        d = json.load(open(os.path.join(ROOT, "profiles", "r03_msm_2p20", "pmc_traffic.json")))["accum"]
+        return d["SQ_INSTS_VALU"], d.get("effective_clock_GHz")
     except (OSError, KeyError, ValueError):
         return None
 
@@ -78,7 +81,7 @@ def pmc_traffic(args, world):
     collected on (BN254, 2^20, random scalars, one GPU); everything else reports null."""
     if not (world == 1 and args.curve == 0 and args.log2n == 20 and args.dist == "random" and not args.window_bits):
         return None
-    for rnd in ("r02_msm_2p20", "r01_msm_2p20"):
+    for rnd in ("r03_msm_2p20", "r02_msm_2p20", "r01_msm_2p20"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")))["accum"]
             return d["hbm_read_bytes_corrected"] + d["hbm_write_bytes"]
@@ -270,23 +273,32 @@ def main():
                 # the roofline that actually binds this kernel: 32x32+64 multiply-adds against the measured
                 # v_mad_u64_u32 rate (profiles/r01_ubench_instruction_rates.jsonl)
                 "valu_mad": {"achieved_T_per_s": MADS_PER_MADD * madds_per_launch(n, args) / (accum_ms * 1e-3) / 1e12 if accum_ms > 0 else 0.0,
-                             "peak_T_per_s": MAD_PEAK_T, "frac": (MADS_PER_MADD * madds_per_launch(n, args) / (accum_ms * 1e-3) / 1e12) / MAD_PEAK_T if accum_ms > 0 else 0.0,
+                             "peak_T_per_s": VALU_PEAK_T, "frac": (MADS_PER_MADD * madds_per_launch(n, args) / (accum_ms * 1e-3) / 1e12) / VALU_PEAK_T if accum_ms > 0 else 0.0,
                              "mads_per_mixed_add": MADS_PER_MADD},
             },
         }
-        insts = pmc_valu(args, world)
-        if insts and accum_ms > 0:
-            # What binds the kernel: every VOP3 instruction of gfx950 -- v_mad_u64_u32, the 64-bit carry
-            # shifts, v_mul_lo_u32, v_add3 -- issues at 29-35 T lane-ops/s (profiles/r01_ubench_instruction_rates.jsonl), and a
-            # mixed addition is 2 187 VALU instructions of which 1 305 are multiply-adds (SQ_INSTS_VALU / wave-additions).
+        pv = pmc_valu(args, world)
+        if pv and accum_ms > 0:
+            # What binds the kernel: VALU instruction issue.  A mixed addition is ~2 230 VALU instructions
+            # (SQ_INSTS_VALU / wave-additions), 1 467 of them multiply-adds.  Ceiling = lanes x clock from the hardware guide
+            # (every VOP3 instruction at full rate, 2.4 GHz): no instruction mix can exceed it, so frac <= 1 by construction.
+            # Under this kernel the chip clocks to its power budget (effective clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel time of
+            # the profiled pass, ~2.06 GHz): at THAT clock the issue ports are ~99 % busy.
+            insts, gui = pv
             lane_ops = insts * 64
+            ach = lane_ops / (accum_ms * 1e-3) / 1e12
             out["roofline"]["valu_issue"] = {
                 "valu_insts_per_mixed_add": round(insts / (madds_per_launch(n, args) / 64), 1),
-                "achieved_T_lane_ops_per_s": lane_ops / (accum_ms * 1e-3) / 1e12,
-                "vop3_issue_rate_T_per_s": [29.4, 35.2],
-                "frac_of_v_mad_rate": lane_ops / (accum_ms * 1e-3) / 1e12 / 29.4,
-                "source": "profiles/r02_msm_2p20/pmc_traffic.json (rocprofv3 --pmc SQ_INSTS_VALU, separate pass) / accum-kernel time of this run",
+                "achieved_T_lane_ops_per_s": ach,
+                "peak_T_lane_ops_per_s": VALU_PEAK_T,
+                "frac": ach / VALU_PEAK_T,
+                "source": "profiles/r03_msm_2p20/pmc_traffic.json (rocprofv3 --pmc SQ_INSTS_VALU, separate pass) / accum-kernel time of this run",
             }
+            if gui:   # GRBM_GUI_ACTIVE / 8 XCDs / the kernel's duration in the same counter pass
+                out["roofline"]["valu_issue"]["effective_clock_GHz_profiled_pass"] = round(gui, 2)
+        tr = out["roofline"]["traffic"]
+        if tr:
+            out["roofline"]["traffic_ratio"] = round(tr / (BYTES_PER_PAIR * n), 1)   # HBM bytes moved / algorithmic bytes
         if multi:
             out["combine_ms"] = round(combine_s[0] / max(args.steps, 1) * 1e3, 4)
         if world == 1 and not args.no_cpu_baseline:

@@ -10,6 +10,7 @@
 
 namespace nmx {
 
+static constexpr uint32_t kSegMinTotalAuto = 0xfffffffeu;  // MsmArgs::seg_min_total: the default rule of msm_pipeline()
 struct MsmArgs {
   const uint32_t* scalars;  // backend-addressable: n x 8 u32 (field) or n x 2 u32 (u64 mode)
   const void* bases;        // backend-addressable AffineW[n]: internal form, canonical
@@ -27,7 +28,7 @@ struct MsmArgs {
   uint32_t all_ones = 0;
   uint32_t bases_clean = 0;  // 1: the key is known to hold no identity point: the digit stage need not read the bases
   uint32_t no_partition = 0; // 1: generic radix-sort path even where the hand-written partition applies (tests / A-B runs)
-  uint32_t seg_min_total = 1u << 22;  // segment-balanced accumulate (msm_seg.hpp) from this many sorted entries on
+  uint32_t seg_min_total = kSegMinTotalAuto;  // segment-balanced accumulate (msm_seg.hpp): automatic, or from this many sorted entries on
   uint32_t seg_min_len = 8;           // shortest segment a lane is given
   uint32_t accum_prefetch = 1;        // gathers in flight ahead of the addition (AccumSegFn PF)
   uint32_t seg_heavy_above = 0;       // pieces FinalSegFn sums per bucket without a pre-fold (0: SegPlan::heavy_above_for)
@@ -134,7 +135,13 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
 
   const bool part = partition_supported(sh, a.pre_stride != 0) && !a.no_partition;
   const uint32_t seg_lanes = part ? be.template seg_lanes<FID>(total) : 0;
-  const bool seg = part && seg_lanes && total >= a.seg_min_total;  // segment-balanced accumulate (msm_seg.hpp)
+  // Segment-balanced accumulate (msm_seg.hpp) or tasks (AccumFn)?  Default rule (profiles/r03_msm_2p20/seg_threshold.txt): segments
+  // when the key has enough buckets for them -- c >= 15 tables (>= 16 384 buckets): 2^14 0.324 ms against 0.341, 2^15 0.362 / 0.373,
+  // 2^17 0.490 / 0.510, 2^18 0.659 / 0.678 -- but never on the c = 8 tables of small keys, whose 128 buckets would each span
+  // hundreds of lanes (2^13: 0.492 ms against 0.309).  An explicit seg_min_total (option / NMX_TUNE_SEG_MIN_TOTAL) is a plain
+  // threshold on the sorted entries.
+  const bool seg_auto = a.seg_min_total == kSegMinTotalAuto;
+  const bool seg = part && seg_lanes && (seg_auto ? (sh.c >= 15 ? total >= (1u << 17) : total >= (1u << 22)) : total >= a.seg_min_total);
   // Everything that must start as zero lives in ONE block, cleared by ONE fill: bucket bounds, counters, the tickets of the
   // big-bucket pass and the partition's histograms / cursors.  (Round 2 issued five fills per MSM, 3-5 us each plus the
   // gap before the next launch, and cleared the 9 MB bucket_raw array that every reader only touches where it was written.)

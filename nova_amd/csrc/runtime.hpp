@@ -146,7 +146,7 @@ struct Global {
   std::atomic<uint32_t> force_fold_t{0};  // env NMX_TUNE_FOLD_T (tuning only)
   std::atomic<uint32_t> no_quad_accum{0};  // env NMX_TUNE_NO_QUAD_ACCUM (tuning only)
   std::atomic<uint32_t> no_partition{0};   // env NMX_TUNE_NO_PARTITION: generic radix-sort path everywhere (A/B runs)
-  std::atomic<uint32_t> seg_min_total{1u << 22};  // env NMX_TUNE_SEG_MIN_TOTAL (profiles/r02_msm_2p20/seg_threshold.txt): msm_seg.hpp from this many sorted entries (0xffffffff: never)
+  std::atomic<uint32_t> seg_min_total{kSegMinTotalAuto};  // env NMX_TUNE_SEG_MIN_TOTAL (profiles/r02_msm_2p20/seg_threshold.txt): msm_seg.hpp from this many sorted entries (0xffffffff: never)
   std::atomic<uint32_t> seg_min_len{8};           // env NMX_TUNE_SEG_MIN_LEN
   std::atomic<uint32_t> seg_lanes_override{0};    // env NMX_TUNE_SEG_LANES (0: the kernel's resident lane count)
   std::atomic<uint32_t> no_quad_final{0};         // env NMX_TUNE_NO_QUAD_FINAL

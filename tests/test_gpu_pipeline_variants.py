@@ -16,6 +16,7 @@ VARIANTS = [
     {},                                                            # defaults
     {"no_partition": 1},                                           # round-1 pipeline
     {"seg_min_total": 0xFFFFFFFF},                                 # partition + task accumulate
+    {"seg_min_total": 1 << 22},                                    # round 2's threshold
     {"seg_min_total": 0, "seg_lanes": 4096, "seg_min_len": 3},     # segments everywhere, few long ones
     {"seg_min_total": 0, "seg_lanes": 1 << 19, "seg_min_len": 1},  # more lanes than entries per bucket: one-entry pieces
     {"seg_min_total": 0, "seg_lanes": 70001, "no_quad_final": 1},  # odd lane count, single-lane final pass
@@ -23,7 +24,8 @@ VARIANTS = [
     {"seg_min_total": 0, "seg_lanes": 1 << 18, "seg_heavy_above": 3},   # nearly every bucket through the pre-fold passes
     {"seg_min_total": 0, "seg_lanes": 1 << 18, "seg_heavy_above": 40},  # long serial sums in the final pass instead
 ]
-DEFAULTS = {"no_partition": 0, "seg_min_total": 1 << 22, "seg_lanes": 0, "seg_min_len": 8, "no_quad_final": 0, "accum_prefetch": 0,
+DEFAULTS = {"no_partition": 0, "seg_min_total": 0xFFFFFFFE,   # 0xfffffffe = the automatic rule
+             "seg_lanes": 0, "seg_min_len": 8, "no_quad_final": 0, "accum_prefetch": 0,
             "seg_heavy_above": 0}
 
 
