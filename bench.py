@@ -601,7 +601,10 @@ def extras(out, args, torch, L, ck, host_scalars, dev_scalars):
         parts = [g.vartime_multiscalar_mul(sc24[:h], ck24, partial=True).xy,
                  g.vartime_multiscalar_mul(sc24[h:], ck24, partial=True, offset=h).xy]
         out["anchor_2p24_single_gpu"] = {"ms": round(ms, 3), "value": n24 / (ms * 1e-3), "unit": "pairs/s",
-                                         "halves_sum_to_whole": g.point_sum(parts) == r24}
+                                         "halves_sum_to_whole": g.point_sum(parts) == r24,
+                                         "what": "2^24 distinct bases (c = 20 tables, 13 GiB), 2^22 random scalars tiled x4 (host-side "
+                                                 "generation time); the full 2^24 oracle compare is tests/test_gpu_large.py::"
+                                                 "test_2p24_against_the_oracle"}
         ck24.close()
         del sc24
     except nova_amd.NmxError as e:                          # e.g. a box with less free HBM: report, do not fail the headline
