@@ -36,11 +36,14 @@ def main():
     total = len(body)
     valu = sum(v for k, v in hist.items() if k.startswith("v_"))
     print(f"kernel  {name}")
-    for key in ("vgpr_count", "sgpr_count", "vgpr_spill_count", "private_segment_fixed_size", "group_segment_fixed_size"):
-        m = re.search(r"\.name:\s+" + re.escape(name) + r"\b.*?\." + key + r":\s+(\d+)", notes, re.S) or \
-            re.search(r"\." + key + r":\s+(\d+)(?=(?:(?!\.name:).)*\.name:\s+" + re.escape(name) + r"\b)", notes, re.S)
-        if m:
-            print(f"  {key} {m.group(1)}")
+    # the kernel's metadata block: the YAML list item of the notes that carries its .name
+    for blk in re.split(r"\n\s+- \.", notes):
+        if re.search(r"\.?name:\s+" + re.escape(name) + r"\s*$", blk, re.M):
+            for key in ("vgpr_count", "sgpr_count", "vgpr_spill_count", "private_segment_fixed_size", "group_segment_fixed_size"):
+                m = re.search(r"\.?" + key + r":\s+(\d+)", blk)
+                if m:
+                    print(f"  {key} {m.group(1)}")
+            break
     print(f"static instructions {total}, of which VALU {valu} ({100.0 * valu / total:.1f} %)")
     print("(static: every path of the kernel -- the mixed addition, the doubling of the P == Q case, the boundary flush, the "
           "plan step -- counted once; the per-addition dynamic count is SQ_INSTS_VALU / wave-additions, profiles/*/pmc_traffic.json)")
