@@ -299,6 +299,9 @@ def main():
         tr = out["roofline"]["traffic"]
         if tr:
             out["roofline"]["traffic_ratio"] = round(tr / (BYTES_PER_PAIR * n), 1)   # HBM bytes moved / algorithmic bytes
+        st = _lib.stats()
+        out["launch_gap_us"] = round(st[_lib.STAT_LAUNCH_GAP_NS] / 1e3, 2)   # one dependent one-wave launch on this box
+        out["reduction_tree"] = "one launch per level" if st[_lib.STAT_LAUNCH_GAP_NS] < 6000 else "fused levels (slow dependent launches on this box)"
         if multi:
             out["combine_ms"] = round(combine_s[0] / max(args.steps, 1) * 1e3, 4)
         if world == 1 and not args.no_cpu_baseline:

@@ -176,7 +176,9 @@ enum {
   NMX_STAT_CACHE_STALE = 11,  /* slice-form calls whose rolling content check caught an in-place edit of a cached
                                  array: the entry was dropped and the call repeated on a fresh upload          */
   NMX_STAT_TABLE_FALLBACKS = 12, /* keys left without window tables because the tables did not fit (budget / HBM) */
-  NMX_STAT_COUNT = 13
+  NMX_STAT_LAUNCH_GAP_NS = 13, /* gauge: cost of one dependent one-wave launch on this box, measured once (decides fused vs
+                                  per-level bucket-reduction tree; 0 until the first MSM)                        */
+  NMX_STAT_COUNT = 14
 };
 int nmx_stats(uint64_t* out, int cap);
 /* same, bases taken from a registered key */
@@ -324,7 +326,9 @@ int nmx_set_window_bits(uint32_t c);
  * 0xffffffff: never), "seg_min_len", "seg_lanes" (0: a multiple of the kernel's resident lanes), "no_quad_accum",
  * "no_quad_final", "accum_prefetch" (0: by table size; 1 or 2), "no_batch_fuse" (1: every vector of a batch call runs
  * as its own MSM), "horner_top" (suffix Horner's long levels: 0 / 8 = 8-coefficient chunks in registers, 4, 1 = off),
- * "seg_heavy_above" (pieces per bucket summed without a pre-fold pass: 0 = by table width, else 1..63).
+ * "seg_heavy_above" (pieces per bucket summed without a pre-fold pass: 0 = by table width, else 1..63), "no_tree_fuse" (bucket
+ * reduction: 0 = fused levels or one launch per level by the box's measured launch gap, 1 = one launch per level, 2 = fused),
+ * "shard_min_n", "cache_table_after", "max_table_mib" (see the sections above).
  * Unknown name: NMX_E_ARG. */
 int nmx_set_option(const char* name, uint32_t value);
 

@@ -28,6 +28,14 @@ inline void check(int rc) {
   if (rc != NMX_OK) throw Error(rc, nmx_last_error());
 }
 
+// One host process, k GPUs (nmx_init_devices): keys of >= 2^20 points registered afterwards are sharded over the devices by
+// the library; every MSM / commit below stays one synchronous call (the reference decomposes in-process too:
+// /root/reference/src/provider/msm.rs:564-574).  Returns the number of devices in use.  count = 0: all visible GPUs.
+inline int init_devices(int count = 0, bool oversubscribe = false) {
+  check(nmx_init_devices(count, oversubscribe ? NMX_DEVICES_OVERSUBSCRIBE : 0u));
+  return nmx_devices_in_use();
+}
+
 struct Point {  // result of an MSM / commit, as `to_coordinates()` returns it
   Affine xy{};
   bool is_inf = true;

@@ -35,6 +35,36 @@ Global::SparseSet::~SparseSet() {
   if (data) (void)hipFree(data);
 }
 void note_table_fallback() { stat_add(NMX_STAT_TABLE_FALLBACKS); }
+// What one dependent few-wave launch costs on this box: 16 one-wave kernels chained on a stream between two events, best of
+// three, once per process.  The fast boxes of the pool chain such launches back to back; BENCH_r02's box paid ~10 us each.
+__global__ void k_gap_probe(uint32_t* p) {
+  if (p) *p = 1;
+}
+int32_t launch_gap_ns(hipStream_t stream) {
+  static std::once_flag once;
+  std::call_once(once, [&] {
+    int32_t best = 0x7fffffff;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+      for (int rep = 0; rep < 4; rep++) {  // rep 0 warms the code object up
+        (void)hipEventRecord(e0, stream);
+        for (int i = 0; i < 16; i++) hipLaunchKernelGGL(k_gap_probe, dim3(1), dim3(64), 0, stream, (uint32_t*)nullptr);
+        (void)hipEventRecord(e1, stream);
+        float ms = 0;
+        if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && rep > 0) {
+          const int32_t ns = (int32_t)(ms * 1e6f / 16.0f);
+          if (ns < best) best = ns;
+        }
+      }
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipGetLastError();
+    G.launch_gap_ns.store(best == 0x7fffffff ? 0 : best);
+    g_stats[NMX_STAT_LAUNCH_GAP_NS].store((uint64_t)G.launch_gap_ns.load());
+  });
+  return G.launch_gap_ns.load(std::memory_order_relaxed);
+}
 static thread_local std::string t_err;
 static thread_local float t_prof[kMaxMarks];
 static thread_local int t_prof_n = 0;
@@ -849,6 +879,13 @@ int nmx_init_devices(int count, uint32_t flags) {
     if (!over) {  // distinct GPUs only: the map must not wrap
       for (int i = 1; i < count; i++) require(G.hip_dev[(size_t)i] != G.device, NMX_E_NO_DEVICE, "not enough devices after the primary");
     }
+    // peer access for the xGMI pulls of HBM-resident scalars (key_msm); best effort: hipMemcpyPeerAsync works without it
+    for (int i = 1; i < count; i++) {
+      if (G.hip_dev[(size_t)i] == G.device) continue;
+      if (hipSetDevice(G.hip_dev[(size_t)i]) == hipSuccess) (void)hipDeviceEnablePeerAccess(G.device, 0);
+      (void)hipGetLastError();
+    }
+    (void)hipSetDevice(G.device);
     G.ndev_active.store((uint32_t)count);
   });
 }

@@ -154,10 +154,12 @@ struct Global {
   std::atomic<uint32_t> horner_top{0};            // env NMX_TUNE_HORNER_TOP / option horner_top: suffix Horner's register-resident levels: 0 / 8 = 8-element chunks, 4, 1 = off
   std::atomic<uint32_t> seg_heavy_above{0};       // env NMX_TUNE_SEG_HEAVY_ABOVE / option seg_heavy_above: 0 = by pieces per bucket (8 or 12)
   std::atomic<uint32_t> no_batch_fuse{0};         // env NMX_TUNE_NO_BATCH_FUSE / option no_batch_fuse: every vector of a batch runs alone
-  std::atomic<uint32_t> no_tree_fuse{0};          // env NMX_TUNE_NO_TREE_FUSE / option no_tree_fuse: one launch per reduction level (round 2; A/B runs)
+  std::atomic<uint32_t> no_tree_fuse{0};          // env NMX_TUNE_NO_TREE_FUSE / option no_tree_fuse: 0 = by the box's measured launch gap, 1 = one launch per reduction level, 2 = always fused
+  std::atomic<int32_t> launch_gap_ns{-1};         // cost of one dependent tiny launch on this box, measured once (capi.hip launch_gap_ns)
 };
 extern Global& G;                // capi.hip (heap singleton, never destroyed)
 void note_table_fallback();                // NMX_STAT_TABLE_FALLBACKS (capi.hip)
+int32_t launch_gap_ns(hipStream_t stream);  // measured once per process (capi.hip)
 void prof_store(const float* ms, int n);   // last call's stage times of this thread (capi.hip)
 void prof_add_tail(float ms);
 void arena_reserve(Ctx& c, size_t bytes);  // capi.hip
@@ -291,11 +293,19 @@ struct DeviceBackend {
   // and keep one launch each; the others run fused, at most seven levels per launch (k_reduce_tree): 16 levels = 1 + 3
   // launches at c = 17, 15 = 3 at c = 16, 7 = 1 at c = 8.  Returns the WB sums.
   static constexpr uint32_t kTreeThreads = 512, kTreeLevels = 7, kTreeMaxInputs = 256 * 128;
+  static constexpr int32_t kFuseAboveGapNs = 6000;
   template <int FID> const XYZZW* reduce_tree(const XYZZW* buckets, const MsmShape& sh, const uint32_t* err_src, bool* err_appended) {
     const XYZZW* D = buckets;
     const XYZZW* Y = buckets;
     uint32_t n_in = sh.M, first = 1;  // M == 1 (c == 1): the bucket is the window sum
-    while (n_in > 1 && (G.no_tree_fuse || (uint64_t)sh.WB * n_in > kTreeMaxInputs)) {
+    // Fused or one launch per level?  A level costs its two dependent quad additions either way (~10 us); what differs is the
+    // cost of the dependent launches between levels.  On boxes where those chain back to back one launch per level is 0.02 ms
+    // faster at 2^20 (0.167 against 0.185 ms: each level gets the whole chip's dispatch); on the boxes of the pool where a
+    // dependent few-wave launch costs 5-10 us extra (BENCH_r02: 0.341 ms for the same 16 launches) fusing bounds the damage.
+    // The box decides: the gap is measured once per process (16 chained one-wave launches between two events).
+    const uint32_t mode = G.no_tree_fuse.load(std::memory_order_relaxed);
+    const bool per_level = mode == 1 || (mode == 0 && launch_gap_ns(c.stream) < kFuseAboveGapNs);  // (same answer in the sizing pass)
+    while (n_in > 1 && (per_level || (uint64_t)sh.WB * n_in > kTreeMaxInputs)) {
       const uint32_t half = n_in / 2, pairs = sh.WB * half;
       XYZZW* Do = alloc<XYZZW>(pairs);
       XYZZW* Yo = alloc<XYZZW>(pairs);
