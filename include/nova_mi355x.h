@@ -328,6 +328,7 @@ int nmx_set_window_bits(uint32_t c);
  * as its own MSM), "horner_top" (suffix Horner's long levels: 0 / 8 = 8-coefficient chunks in registers, 4, 1 = off),
  * "seg_heavy_above" (pieces per bucket summed without a pre-fold pass: 0 = by table width, else 1..63), "no_tree_fuse" (bucket
  * reduction: 0 = fused levels or one launch per level by the box's measured launch gap, 1 = one launch per level, 2 = fused),
+ * "hist_grid" (blocks of the partition's counting pass; 0 = as the placing pass: measured flat, profiles/r03_msm_2p20/tail_ab.txt),
  * "shard_min_n", "cache_table_after", "max_table_mib" (see the sections above).
  * Unknown name: NMX_E_ARG. */
 int nmx_set_option(const char* name, uint32_t value);

@@ -31,6 +31,7 @@ struct MsmArgs {
   uint32_t seg_min_total = kSegMinTotalAuto;  // segment-balanced accumulate (msm_seg.hpp): automatic, or from this many sorted entries on
   uint32_t seg_min_len = 8;           // shortest segment a lane is given
   uint32_t accum_prefetch = 1;        // gathers in flight ahead of the addition (AccumSegFn PF)
+  uint32_t hist_grid = 0;             // blocks of the first-level counting pass (0: as many as the placing pass; tuning)
   uint32_t seg_heavy_above = 0;       // pieces FinalSegFn sums per bucket without a pre-fold (0: SegPlan::heavy_above_for)
   // fused batch over the key's tables (DigitSrc::batch_*): n = sum of the vector lengths, `scalars` unused;
   // wsum_host[j] receives vector j's sum
@@ -200,7 +201,8 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
     // the widths the tables are built with get their own instantiation (constant bit positions); BIG = keys wider than 15 bits
     auto level1 = [&](auto hist, auto part) {
       be.mark("digits");
-      be.launch_kernel(hist, pb.ps.grid1, pb.ps.bs1, pa);
+      // the counting pass ends with one global atomic per block and bin: fewer, longer-lived blocks (a.hist_grid) contend less
+      be.launch_kernel(hist, a.hist_grid && a.hist_grid < pb.ps.grid1 ? a.hist_grid : pb.ps.grid1, pb.ps.bs1, pa);
       if (pb.ps.big) be.launch_kernel(&k_tiles<true>, 1u, 1024u, pb);
       else be.launch_kernel(&k_tiles<false>, 1u, 1024u, pb);
       be.mark("sort");

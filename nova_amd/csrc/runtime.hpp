@@ -155,6 +155,7 @@ struct Global {
   std::atomic<uint32_t> seg_heavy_above{0};       // env NMX_TUNE_SEG_HEAVY_ABOVE / option seg_heavy_above: 0 = by pieces per bucket (8 or 12)
   std::atomic<uint32_t> no_batch_fuse{0};         // env NMX_TUNE_NO_BATCH_FUSE / option no_batch_fuse: every vector of a batch runs alone
   std::atomic<uint32_t> no_tree_fuse{0};          // env NMX_TUNE_NO_TREE_FUSE / option no_tree_fuse: 0 = by the box's measured launch gap, 1 = one launch per reduction level, 2 = always fused
+  std::atomic<uint32_t> hist_grid{0};             // env NMX_TUNE_HIST_GRID / option hist_grid
   std::atomic<int32_t> launch_gap_ns{-1};         // cost of one dependent tiny launch on this box, measured once (capi.hip launch_gap_ns)
 };
 extern Global& G;                // capi.hip (heap singleton, never destroyed)

@@ -141,3 +141,52 @@ def test_slice_bounds_cannot_wrap(nmx):
     assert L.nmx_msm_u64_handle(ck.handle, big, s64.ctypes.data, 1, 8, 0, out.ctypes.data, inf.ctypes.data) == _lib.E_HANDLE
     assert not out.any()
     ck.close()
+
+
+def test_sharded_keys_and_long_cached_arrays_from_many_threads(nmx):
+    """Round 3's concurrent paths: MSMs over a key sharded 3-way (a host thread per shard inside every call), slice-form
+    calls over a LONG array (the rolling content check runs on a second host thread, the window tables arrive on the third
+    use while other threads are mid-call, the cache is cleared under them) -- from six threads at once."""
+    from nova_amd import _lib
+    L = _lib.lib()
+    c = R.BN254_G1
+    n = 1 << 17
+    bases = cref.sequential_bases(c, 90210, n)
+    prep = cref.Prepared(c.cid, bases, n)
+    lens = [n, 70001, 66000, 4500]
+    scs = [util.random_scalars(c.cid, m, seed=7 * m) for m in lens]
+    exp = [prep.msm(s, m) for s, m in zip(scs, lens)]
+    assert nmx.init_devices(3, oversubscribe=True) == 3
+    assert L.nmx_set_option(b"shard_min_n", 4096) == 0
+    errors = []
+    try:
+        ck = nmx.CommitmentKey.from_host(c.cid, bases)       # three shards
+        g = nmx.DlogGroup(c.cid)
+
+        def handle_caller(tid):
+            for k in range(12):
+                j = (tid + k) % len(lens)
+                got = g.vartime_multiscalar_mul(scs[j], ck)
+                if (got.xy, int(got.is_inf)) != exp[j]:
+                    errors.append(("sharded handle", tid, j))
+
+        def slice_caller(tid):
+            for k in range(12):
+                j = (tid + k) % len(lens)
+                got = g.vartime_multiscalar_mul(scs[j], bases[: lens[j]])
+                if (got.xy, int(got.is_inf)) != exp[j]:
+                    errors.append(("slice form", tid, j))
+                if tid == 0 and k % 5 == 4:
+                    L.nmx_cache_clear()
+
+        ths = [threading.Thread(target=handle_caller, args=(t,)) for t in range(3)]
+        ths += [threading.Thread(target=slice_caller, args=(t,)) for t in range(3)]
+        [t.start() for t in ths]
+        [t.join(timeout=300) for t in ths]
+        assert not any(t.is_alive() for t in ths), "a thread hung"
+        assert not errors, errors[:5]
+        ck.close()
+    finally:
+        assert nmx.init_devices(1) == 1
+        assert L.nmx_set_option(b"shard_min_n", 1 << 20) == 0
+        assert L.nmx_cache_clear() == 0
