@@ -147,6 +147,68 @@ template <int FID> struct XYZZ {
 #endif
   }
 
+  // madd-2008-s (msm.rs:129-165): this += (px, +-py), the affine operand non-identity, px and py canonical (< p).
+  // The sign of a signed window digit is applied to the PRODUCT: s2 = +-(py * zzz), i.e. r = s2 - y is formed either as
+  // s2p + (4p - y) or as (2p - s2p) + (4p - y) -- 9 subtractions and 9 selects instead of negating, normalising and
+  // selecting the operand (round 3: -24 instructions per addition); t = ppp + 2q enters x3 un-normalised against a spread
+  // 4p whose limbs dominate 3 * 2^29 (-24 more).
+  template <bool LAT = false> NMX_HD void add_affine_signed(const F& px, const F& py, bool negate) {
+    if (is_identity()) {
+      x = px;
+      y = negate ? F::sub2(F::zero(), py).norm() : py;  // 2p - y in (p, 2p]
+      zz = F::one();
+      zzz = F::one();
+      return;
+    }
+    F u2 = F::template mulx<LAT>(px, zz);          //  1 + 1.2/127     < 1.01
+    F s2p = F::template mulx<LAT>(py, zzz);        //  1 + 1.2/127     < 1.01
+    F d = F::sub8(u2, x).norm();                   //  in (2.7, 9.01)             [x < 5.3 < 8]
+    if (d.maybe_zero_mod_p()) {                    //  taken with probability 2^-29 unless u2 == x
+      if (F::eq_mod_p(u2, x)) {
+        const F s2 = negate ? F::sub2(F::zero(), s2p).norm() : s2p;
+        if (F::eq_mod_p(s2, y))
+          dbl_in_place<LAT>();                     //  P == Q   (msm.rs:148-150)
+        else
+          *this = identity();                      //  P == -Q  (msm.rs:151-153)
+        return;
+      }
+    }
+    F r;                                           //  s2 - y + 4p < 5.02   |   -s2 - y + 6p in (1.4, 6)
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      const uint32_t t4 = F::PP::K4P[i] - y.l[i];                          //  [y < 3.5 < 4: K4P dominates its limbs]
+      r.l[i] = (negate ? F::PP::K2P[i] - s2p.l[i] : s2p.l[i]) + t4;        //  [s2p < 2p - 2^233: K2P dominates]
+    }
+    r = r.norm();
+    F pp = F::template sqrx<LAT>(d);               //  1 + 81.2/127    < 1.64
+    F ppp = F::template mulx<LAT>(d, pp);          //  1 + 14.8/127    < 1.12
+    F q = F::template mulx<LAT>(x, pp);            //  1 + 8.7/127     < 1.07
+    F rr = F::template sqrx<LAT>(r);               //  1 + 36/127      < 1.29
+    F x3;                                          //  rr - (ppp + 2q) + 4p  < 5.3: limbs of ppp + 2q are <= 3 (2^29 - 1), which the
+#pragma unroll                                     //  spread 4p below dominates limb by limb (top limb: 3.26 p < 4p - 3)
+    for (int i = 0; i < 9; i++) {
+      const uint32_t k4w = F::PP::P4[i] + (i < 8 ? 3u << 29 : 0u) - (i > 0 ? 3u : 0u);
+      x3.l[i] = rr.l[i] + (k4w - (ppp.l[i] + 2u * q.l[i]));
+    }
+    x3 = x3.norm();
+    F e = F::sub8(q, x3).norm();                   //  1.07 + 8        < 9.07
+    F ny = F::sub4(F::zero(), y);                  //  4p - y in (0.5, 4], limbs < 2^31 (left un-normalized)
+    F y3 = F::template mul_addx<LAT>(r, e, ppp, ny);  //  r*e - y*ppp:  1 + (54.4 + 4.5)/127 < 1.47  [one reduction]
+    x = x3;
+    y = y3;
+    zz = F::template mulx<LAT>(zz, pp);            //  1 + 1.97/127    < 1.02
+    zzz = F::template mulx<LAT>(zzz, ppp);         //  < 1.02
+#ifdef NMX_BOUND_CHECKS
+    for (int i = 0; i < 9; i++) {
+      const uint32_t k4w = F::PP::P4[i] + (i < 8 ? 3u << 29 : 0u) - (i > 0 ? 3u : 0u);
+      if (ppp.l[i] + 2u * q.l[i] > k4w || s2p.l[i] > F::PP::K2P[i]) {
+        fprintf(stderr, "add_affine_signed: limb %d not dominated\n", i);
+        abort();
+      }
+    }
+    check();
+#endif
+  }
   // madd-2008-s (msm.rs:129-165): this += (px, py), the affine operand non-identity.
   // px canonical (< p); py < 2p normalized (a canonical y, or 2p - y for a negated point).
   template <bool LAT = false> NMX_HD void add_affine(const F& px, const F& py) {
@@ -191,6 +253,10 @@ template <int FID> struct XYZZ {
   // two call sites of the (fully inlined) addition would make every wave execute it twice.
   template <bool LAT = false> NMX_HD void add_affine(const Affine<FID>& p, bool negate = false) {
     if (p.is_identity()) return;  // msm.rs:130-132
+#ifndef NMX_MADD_R2
+    add_affine_signed<LAT>(p.x, p.y, negate);
+    return;
+#endif
     F ny = F::sub2(F::zero(), p.y).norm();  // 2p - y in (p, 2p]
     F y;
 #pragma unroll
