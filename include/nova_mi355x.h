@@ -134,15 +134,21 @@ int nmx_bases_generate(int curve, uint64_t k0, size_t n, uint32_t flags, uint64_
  * Slice form = the trait's own signature: the reference passes `&ck.ck[..n]` and no handle (pedersen.rs:263-270,
  * hyperkzg.rs:584-591, blitzar.rs:7-20).  The library therefore keeps a SLICE CACHE of resident keys: a call whose
  * `bases_xy64` pointer is the first element of (or lies inside) an array it has seen before runs over the resident
- * copy, window tables included, exactly like nmx_msm_handle -- no upload, no conversion.  Identity of an array =
- * (curve, layout flag, host address) confirmed on every call by 64-bit content fingerprints read from the caller's
- * slice (valid for the duration of the call): every point for arrays up to 2048 points, otherwise the first and last
- * point used plus eight probes of a <= 4096-point grid that move from call to call; a longer prefix of the
- * same array re-registers it at the new length, so one resident copy serves `&ck[..n]` for every n.  Arrays are
- * assumed immutable while cached (Nova's commitment keys are: created once by `setup`, pedersen.rs:249-259); a caller
- * that rewrites one in place must call nmx_cache_invalidate.  Arrays shorter than the cache's min_n (default 128
- * points) and calls with NMX_BASES_NOCACHE are uploaded for the call only.  LRU eviction under a byte budget
- * (default: a quarter of the device's HBM); evicted or invalidated keys stay alive until the calls using them return. */
+ * copy exactly like nmx_msm_handle -- no upload, no conversion; a longer prefix of the same array re-registers it at the
+ * new length, so one resident copy serves `&ck[..n]` for every n.  First and second sight of an array: the key alone;
+ * from its third use on it also has its window tables, built from the resident copy (arrays seen once or twice -- IPA's
+ * per-round Vecs, ipa_pc.rs:212-230 -- never pay for them; nmx_set_option("cache_table_after")).  Tables that do not
+ * fit the cache budget or the HBM left: the key stays resident without them (plain GPU path).
+ * The trait is a pure function of the slice, and the cache keeps it one: identity of an array = (curve, layout flag, host
+ * address), confirmed on EVERY call by 32-bit hashes of the caller's bytes against the hashes of all points recorded at
+ * upload -- every point for slices up to 2048 points; otherwise the first and the last point used, eight probes that move from
+ * call to call, and a rolling window of max(4096, n/16) consecutive points that continues where the previous call stopped,
+ * hashed on a second host thread while the GPU runs.  A freed-and-reused address is caught at once; a caller that rewrites
+ * even ONE point of a long cached array in place is caught within 16 calls (the entry is dropped, the call repeated on a fresh
+ * upload, the stale result discarded: NMX_STAT_CACHE_STALE) -- nmx_cache_invalidate makes that immediate, and is the
+ * documented contract for in-place edits.  Arrays shorter than the cache's min_n (default 128 points) and calls with
+ * NMX_BASES_NOCACHE are uploaded for the call only.  LRU eviction under a byte budget (default: a quarter of the device's HBM),
+ * also when an upload runs out of HBM; evicted or invalidated keys stay alive until the calls using them return. */
 int nmx_msm(int curve, const void* scalars, const void* bases_xy64, size_t n, uint32_t flags,
             uint8_t* out, uint8_t* out_is_inf);
 /* Slice-cache control.  nmx_cache_configure: max_bytes / min_n / max_entries, 0 = leave unchanged. */
@@ -163,7 +169,7 @@ int nmx_check_layout(int curve, const void* generator_raw64, const void* scalar_
 /* Monotonic counters of this process (cap >= NMX_STAT_COUNT entries are written; returns NMX_STAT_COUNT). */
 enum {
   NMX_STAT_CACHE_HITS = 0,    /* slice-form calls served by a resident key                                   */
-  NMX_STAT_CACHE_UPLOADS = 1, /* keys uploaded into the slice cache (first sight, or fingerprint mismatch)    */
+  NMX_STAT_CACHE_UPLOADS = 1, /* keys uploaded into the slice cache (first sight, or content mismatch)        */
   NMX_STAT_CACHE_REGROWS = 2, /* of those: re-registrations because a longer prefix of a known array arrived  */
   NMX_STAT_CACHE_EVICTIONS = 3,
   NMX_STAT_CACHE_ENTRIES = 4, /* current                                                                      */
