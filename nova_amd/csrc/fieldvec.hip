@@ -389,7 +389,7 @@ struct VecIO {  // stages host vectors through the context arena; device vectors
   void finish() {
     for (auto& o : outs)
       HIPCHK(hipMemcpyAsync((void*)o.second, o.first, out_elems * 32, hipMemcpyDeviceToHost, c.stream));
-    HIPCHK(hipStreamSynchronize(c.stream));
+    stream_wait(c.stream);
   }
 };
 
@@ -492,7 +492,7 @@ template <int FID> static void eq_evals_t(Ctx& c, const void* r_host, uint32_t e
     return;
   }
   HIPCHK(hipMemcpyAsync(d_out, w, 32, hipMemcpyHostToDevice, c.stream));
-  HIPCHK(hipStreamSynchronize(c.stream));  // w is a stack buffer
+  stream_wait(c.stream);  // w is a stack buffer
   uint32_t size = 1;
   for (int j = (int)ell - 1; j >= 0; j--) {  // for r in r.iter().rev()
     EqStepFn<FID> f{d_out, challenge<FID>((const uint8_t*)r_host + 32 * j, mont), size};
@@ -590,7 +590,7 @@ static void lincomb_t(Ctx& c, const void* const* vecs, const size_t* lens, size_
   be.launch(f, (uint32_t)n_out);
   be.mark("end");
   if (!dev) HIPCHK(hipMemcpyAsync(out, d_out, n_out * 32, hipMemcpyDeviceToHost, c.stream));
-  HIPCHK(hipStreamSynchronize(c.stream));  // also: addr / ln / w are stack-owned
+  stream_wait(c.stream);  // also: addr / ln / w are stack-owned
   if (prof && be.nmarks == 2) {
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
@@ -727,7 +727,7 @@ static void horner_t(Ctx& c, const void* f, size_t n, const void* u, uint32_t fl
   }
   be.mark("end");
   if (!dev) HIPCHK(hipMemcpyAsync(out, dout, n * 32, hipMemcpyDeviceToHost, c.stream));
-  HIPCHK(hipStreamSynchronize(c.stream));
+  stream_wait(c.stream);
   if (prof && be.nmarks == 2) {
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));

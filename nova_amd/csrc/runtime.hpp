@@ -156,6 +156,7 @@ struct Global {
   std::atomic<uint32_t> no_batch_fuse{0};         // env NMX_TUNE_NO_BATCH_FUSE / option no_batch_fuse: every vector of a batch runs alone
   std::atomic<uint32_t> no_tree_fuse{0};          // env NMX_TUNE_NO_TREE_FUSE / option no_tree_fuse: 0 = by the box's measured launch gap, 1 = one launch per reduction level, 2 = always fused
   std::atomic<uint32_t> hist_grid{0};             // env NMX_TUNE_HIST_GRID / option hist_grid
+  std::atomic<uint32_t> sync_spin_us{0};          // env NMX_SYNC_SPIN_US / option sync_spin_us: poll the stream this long before blocking
   std::atomic<int32_t> launch_gap_ns{-1};         // cost of one dependent tiny launch on this box, measured once (capi.hip launch_gap_ns)
 };
 extern Global& G;                // capi.hip (heap singleton, never destroyed)
@@ -168,6 +169,23 @@ void aux_reserve(Ctx& c, size_t bytes);    // capi.hip
 // rocPRIM radix sort of (key, value) pairs, its own TU (sort.hip).  tmp == nullptr: size query.
 void device_sort_pairs(void* tmp, size_t& tmp_bytes, uint32_t* k_in, uint32_t* k_out, uint32_t* v_in,
                        uint32_t* v_out, size_t total, uint32_t bits, hipStream_t stream);
+
+// End-of-call wait.  hipStreamSynchronize may block on an interrupt (tens of microseconds to wake up: a visible share of a
+// 0.3 ms MSM, and of every field-vector call); option sync_spin_us = N polls hipStreamQuery for up to N microseconds first.
+static inline void stream_wait(hipStream_t s) {
+  const uint32_t spin_us = G.sync_spin_us.load(std::memory_order_relaxed);
+  if (spin_us) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      const hipError_t e = hipStreamQuery(s);
+      if (e == hipSuccess) return;
+      if (e != hipErrorNotReady) break;  // a real error: let hipStreamSynchronize report it
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) break;
+    }
+    (void)hipGetLastError();
+  }
+  HIPCHK(hipStreamSynchronize(s));
+}
 
 struct DeviceBackend {
   Ctx& c;
@@ -387,7 +405,7 @@ struct DeviceBackend {
   }
   void sync() {
     if (dry) return;
-    HIPCHK(hipStreamSynchronize(c.stream));
+    stream_wait(c.stream);
     for (const Landing& l : landings) memcpy(l.dst, c.pinned + l.off, l.bytes);
     landings.clear();
     pinned_used = 0;
