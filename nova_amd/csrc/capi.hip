@@ -24,8 +24,13 @@ static inline int hip_device_of(int logical) {  // hip_dev only grows, within re
 }
 BaseSet::~BaseSet() {
   if (d && owns) {
+    // the last reference can be dropped on any thread in the middle of its own call (an eviction, an unregister): free on the
+    // key's device, then give the thread its device back
+    int prev = -1;
+    (void)hipGetDevice(&prev);
     (void)hipSetDevice(hip_device_of(dev));
     (void)hipFree(d);
+    if (prev >= 0) (void)hipSetDevice(prev);
   }
 }
 Global::SparseSet::~SparseSet() {
