@@ -344,11 +344,15 @@ __device__ __forceinline__ Fp<FID> block_sum_quads(Fp<FID> acc, uint32_t* lds /*
   return acc;
 }
 
-// Every big bucket (more than 64 continuation pieces; SegPlan) completely, in ONE launch whatever its size.
-// grid = (groups, slices): block (g, s) walks big buckets g, g + groups, ... and sums slice s (4096 pieces) of each:
-// 128 quads x <= 32 strided additions, then a 7-level LDS tree.  A bucket of one slice is finished on the spot
-// (+ bucket_raw[k], canonical store).  Otherwise the slice sum is parked in the slice's own first position, and the
-// block that draws the last ticket of the bucket sums the parked slices the same way -- no block ever waits for another.
+// Every big bucket (more than 64 continuation pieces; SegPlan) completely, in ONE launch whatever its size.  1-D grid of two roles:
+//   blocks [0, 16 x slices)         block (g, s) walks the list with stride 16 and sums slice s of the buckets of SEVERAL slices
+//                                   (all-equal or 0/1 scalars: a whole window in one bucket); the slice sum is parked in the slice's
+//                                   own first position and the block that draws the bucket's last ticket sums the parked slices the
+//                                   same way -- no block ever waits for another;
+//   blocks [16 x slices, + n_single) walk the big list with stride n_single and finish the buckets of ONE slice (<= 4096 pieces: 128
+//                                   quads x <= 32 strided additions, a 7-level LDS tree, + bucket_raw[k], canonical store) -- e.g. the
+//                                   1023 buckets of 10-bit scalars, 127 pieces each: one block per bucket (a first version walked the
+//                                   list with 16 blocks: 1.8 ms for that input).
 struct BigAllArgs {
   const uint32_t* counters;
   const HeavyRec* big;
@@ -356,19 +360,27 @@ struct BigAllArgs {
   XYZZL* partial_raw;
   XYZZW* buckets;
   uint32_t* done;  // [big capacity], zero-initialised: tickets
+  uint32_t n_single, slices;
 };
-static constexpr uint32_t kBigSlice = 4096, kBigThreads = 512;
+static constexpr uint32_t kBigSlice = 4096, kBigThreads = 512, kBigMultiGroups = 16;
 template <int FID> __global__ __launch_bounds__(512) void k_big_all(BigAllArgs a) {
   const uint32_t nbig = a.counters[4];
   if (nbig == 0) return;
   constexpr uint32_t NQ = kBigThreads / 4;
   __shared__ uint32_t lds[NQ * 36];
   __shared__ uint32_t s_ticket;
-  const uint32_t qd = threadIdx.x >> 2, q = threadIdx.x & 3u, s = blockIdx.y;
-  for (uint32_t h = blockIdx.x; h < nbig; h += gridDim.x) {
+  const uint32_t qd = threadIdx.x >> 2, q = threadIdx.x & 3u;
+  // block ids: the multi-slice role first, slice index slowest -- the blocks with work (slices 0 .. nsl-1 of the first buckets of
+  // the list) are then the first ids of the launch and start together (with them scattered over 2560 ids the last ones started
+  // ~200 us late: 0.41 ms instead of 0.21 for all-equal scalars); then one block per single-slice bucket
+  const uint32_t n_multi = kBigMultiGroups * a.slices;
+  const bool multi = blockIdx.x < n_multi;
+  const uint32_t s = multi ? blockIdx.x / kBigMultiGroups : 0u;
+  const uint32_t h0 = multi ? blockIdx.x % kBigMultiGroups : blockIdx.x - n_multi, stride = multi ? kBigMultiGroups : a.n_single;
+  for (uint32_t h = h0; h < nbig; h += stride) {
     const HeavyRec r = a.big[h];
     const uint32_t nsl = (r.cnt + kBigSlice - 1) / kBigSlice;
-    if (s >= nsl) continue;  // block-uniform
+    if ((nsl > 1) != multi || s >= nsl) continue;  // block-uniform
     const uint32_t lo = s * kBigSlice, hi = r.cnt < lo + kBigSlice ? r.cnt : lo + kBigSlice;
     Fp<FID> acc = Fp<FID>::zero();  // zz = 0: the identity
     for (uint32_t p = lo + qd; p < hi; p += NQ) acc = quad_add<FID>(acc, quad_load_raw<FID>(a.partial_raw[r.off + p], q), q);

@@ -278,7 +278,7 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
     be.mark("fold");
     // big buckets (> 64 pieces) completely; then the heavy ones (> heavy_above) down to heavy_above positions; then
     // every other bucket.  On uniformly random scalars the first two launches find empty lists and exit.
-    be.template launch_big_all<FID>(counters, big_s, bucket_raw, partial_raw, buckets, big_done, seg_lanes);
+    be.template launch_big_all<FID>(counters, big_s, bucket_raw, partial_raw, buckets, big_done, seg_lanes, big_cap_s);
     if (heavy_above < SegPlan::kBigAbove) {
       // listed buckets number at most seg_lanes / (heavy_above + 1); when the typical bucket is not heavy (c = 17 tables:
       // 9 pieces against 12) a small grid walks whatever the input made heavy

@@ -294,14 +294,15 @@ struct DeviceBackend {
       launch(f, nbuckets);
     }
   }
-  // every big bucket in one launch (curve_quad.hpp k_big_all); a bucket spans at most `lanes` pieces
+  // every big bucket in one launch (curve_quad.hpp k_big_all); a bucket spans at most `lanes` pieces, `big_cap` buckets can be big
   template <int FID>
   void launch_big_all(const uint32_t* counters, const HeavyRec* big, const XYZZL* bucket_raw, XYZZL* partial_raw,
-                      XYZZW* buckets, uint32_t* done, uint32_t lanes) {
+                      XYZZW* buckets, uint32_t* done, uint32_t lanes, uint32_t big_cap) {
     if (dry) return;
-    const BigAllArgs a{counters, big, bucket_raw, partial_raw, buckets, done};
     const uint32_t slices = (lanes + kBigSlice - 1) / kBigSlice;
-    hipLaunchKernelGGL((k_big_all<FID>), dim3(16, slices), dim3(kBigThreads), 0, c.stream, a);
+    const uint32_t n_single = big_cap < 1024u ? (big_cap ? big_cap : 1u) : 1024u;
+    const BigAllArgs a{counters, big, bucket_raw, partial_raw, buckets, done, n_single, slices};
+    hipLaunchKernelGGL((k_big_all<FID>), dim3(n_single + kBigMultiGroups * slices), dim3(kBigThreads), 0, c.stream, a);
     HIPCHK(hipGetLastError());
   }
   // Bucket reduction sum_k (k + 1) B_k per bucket set: the pair tree of ReducePairFn.  A level costs two dependent quad

@@ -70,7 +70,7 @@ struct HostEmulBackend {
   }
   template <int FID>
   void launch_big_all(const uint32_t* counters, const HeavyRec* big, const XYZZL* bucket_raw, XYZZL* partial_raw,
-                      XYZZW* buckets, uint32_t*, uint32_t lanes) {
+                      XYZZW* buckets, uint32_t*, uint32_t lanes, uint32_t) {
     BigBucketFn<FID> f{counters, big, bucket_raw, partial_raw, buckets};
     launch(f, lanes / (SegPlan::kBigAbove + 1) + 1);
   }
