@@ -301,7 +301,7 @@ def main():
             out["roofline"]["traffic_ratio"] = round(tr / (BYTES_PER_PAIR * n), 1)   # HBM bytes moved / algorithmic bytes
         st = _lib.stats()
         out["launch_gap_us"] = round(st[_lib.STAT_LAUNCH_GAP_NS] / 1e3, 2)   # one dependent one-wave launch on this box
-        out["reduction_tree"] = "one launch per level" if st[_lib.STAT_LAUNCH_GAP_NS] < 6000 else "fused levels (slow dependent launches on this box)"
+        out["reduction_tree"] = "one launch per level (NMX_TUNE_NO_TREE_FUSE=1)" if os.environ.get("NMX_TUNE_NO_TREE_FUSE") == "1" else "fused levels"
         if multi:
             out["combine_ms"] = round(combine_s[0] / max(args.steps, 1) * 1e3, 4)
         if world == 1 and not args.no_cpu_baseline:

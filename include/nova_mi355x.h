@@ -182,8 +182,8 @@ enum {
   NMX_STAT_CACHE_STALE = 11,  /* slice-form calls whose rolling content check caught an in-place edit of a cached
                                  array: the entry was dropped and the call repeated on a fresh upload          */
   NMX_STAT_TABLE_FALLBACKS = 12, /* keys left without window tables because the tables did not fit (budget / HBM) */
-  NMX_STAT_LAUNCH_GAP_NS = 13, /* gauge: cost of one dependent one-wave launch on this box, measured once (decides fused vs
-                                  per-level bucket-reduction tree; 0 until the first MSM)                        */
+  NMX_STAT_LAUNCH_GAP_NS = 13, /* gauge: cost of one dependent one-wave launch on this box, measured once: a box
+                                  diagnostic (slow-launch boxes of a pool show here); 0 until the first MSM       */
   NMX_STAT_COUNT = 14
 };
 int nmx_stats(uint64_t* out, int cap);

@@ -414,7 +414,7 @@ template <int FID> __global__ __launch_bounds__(512) void k_big_all(BigAllArgs a
 
 // LV levels of the bucket-reduction pair tree (ReducePairFn, msm_kernels.hpp: D' = 2 (D_2j + D_2j+1),
 // Y' = Y_2j + Y_2j+1 + D_2j+1) inside one block: a block owns S = THREADS / 4 consecutive inputs (the tree is oblivious to
-// where a bucket set ends as long as 2^LV divides the set size), the first half of its quads computes D', the second half Y'
+// where a bucket set ends as long as 2^LV divides the set size), half of its quads compute D', the other half Y'
 // (whole waves per role: the two formulas never share a wave), levels are separated by __syncthreads() with the points
 // in LDS.  16 levels = 3 launches (6 + 5 + 5) instead of 16.
 struct ReduceTreeArgs {
@@ -434,8 +434,12 @@ template <int FID, int THREADS> __global__ __launch_bounds__(THREADS) void k_red
   // two buffers (levels alternate): [0] holds H points per role, [1] S / 4
   auto bufD = [&](uint32_t b) { return lds + b * (S * 36); };
   auto bufY = [&](uint32_t b) { return lds + b * (S * 36) + (b ? (S / 4) * 36 : H * 36); };
-  const uint32_t qd = threadIdx.x >> 2, q = threadIdx.x & 3u;
-  const uint32_t role = qd >= H ? 1u : 0u, j = qd - role * H;
+  // Roles alternate wave by wave (even waves D', odd waves Y'), output j lives in wave pair j / 16: the waves that are still
+  // busy at the sparse levels -- the first of each role -- sit on different SIMDs.  (Roles by half-block put wave 0 and wave
+  // THREADS / 128 on the same SIMD: a single wave of quad additions already fills 80 % of a SIMD's issue slots
+  // (profiles/r03_msm_2p20/add_latency.txt), so the two roles ran one after the other: ~10 us per level instead of ~5.5.)
+  const uint32_t q = threadIdx.x & 3u, wave = threadIdx.x >> 6;
+  const uint32_t role = wave & 1u, j = (wave >> 1) * 16u + ((threadIdx.x & 63u) >> 2);
   const uint32_t base = blockIdx.x * S;
   const uint32_t n_in = a.n_total - base < S ? a.n_total - base : S;
   if (a.err_src && blockIdx.x == 0 && threadIdx.x == 0) *(uint32_t*)(a.Y_out + (a.n_total >> a.levels)) = *a.err_src;

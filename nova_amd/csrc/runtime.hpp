@@ -154,7 +154,8 @@ struct Global {
   std::atomic<uint32_t> horner_top{0};            // env NMX_TUNE_HORNER_TOP / option horner_top: suffix Horner's register-resident levels: 0 / 8 = 8-element chunks, 4, 1 = off
   std::atomic<uint32_t> seg_heavy_above{0};       // env NMX_TUNE_SEG_HEAVY_ABOVE / option seg_heavy_above: 0 = by pieces per bucket (8 or 12)
   std::atomic<uint32_t> no_batch_fuse{0};         // env NMX_TUNE_NO_BATCH_FUSE / option no_batch_fuse: every vector of a batch runs alone
-  std::atomic<uint32_t> no_tree_fuse{0};          // env NMX_TUNE_NO_TREE_FUSE / option no_tree_fuse: 0 = by the box's measured launch gap, 1 = one launch per reduction level, 2 = always fused
+  std::atomic<uint32_t> tree_threads{0};          // env NMX_TUNE_TREE_THREADS / option tree_threads: block size of the fused reduction tree (0 = default, 256 or 512)
+  std::atomic<uint32_t> no_tree_fuse{0};          // env NMX_TUNE_NO_TREE_FUSE / option no_tree_fuse: 0 / 2 = fused reduction tree (default), 1 = one launch per reduction level
   std::atomic<uint32_t> hist_grid{0};             // env NMX_TUNE_HIST_GRID / option hist_grid
   std::atomic<uint32_t> sync_spin_us{0};          // env NMX_SYNC_SPIN_US / option sync_spin_us: poll the stream this long before blocking
   std::atomic<int32_t> launch_gap_ns{-1};         // cost of one dependent tiny launch on this box, measured once (capi.hip launch_gap_ns)
@@ -313,18 +314,18 @@ struct DeviceBackend {
   // and keep one launch each; the others run fused, at most seven levels per launch (k_reduce_tree): 16 levels = 1 + 3
   // launches at c = 17, 15 = 3 at c = 16, 7 = 1 at c = 8.  Returns the WB sums.
   static constexpr uint32_t kTreeThreads = 512, kTreeLevels = 7, kTreeMaxInputs = 256 * 128;
-  static constexpr int32_t kFuseAboveGapNs = 6000;
   template <int FID> const XYZZW* reduce_tree(const XYZZW* buckets, const MsmShape& sh, const uint32_t* err_src, bool* err_appended) {
     const XYZZW* D = buckets;
     const XYZZW* Y = buckets;
     uint32_t n_in = sh.M, first = 1;  // M == 1 (c == 1): the bucket is the window sum
-    // Fused or one launch per level?  A level costs its two dependent quad additions either way (~10 us); what differs is the
-    // cost of the dependent launches between levels.  On boxes where those chain back to back one launch per level is 0.02 ms
-    // faster at 2^20 (0.167 against 0.185 ms: each level gets the whole chip's dispatch); on the boxes of the pool where a
-    // dependent few-wave launch costs 5-10 us extra (BENCH_r02: 0.341 ms for the same 16 launches) fusing bounds the damage.
-    // The box decides: the gap is measured once per process (16 chained one-wave launches between two events).
+    // Fused is the default (no_tree_fuse = 1 restores one launch per level).  A level is two dependent quad additions, 5.3 us
+    // for a wave that has its SIMD to itself (profiles/r03_msm_2p20/add_latency.txt); one launch per level adds the launch
+    // gap and the trip through memory (~10 us per level; 15-20 us on the boxes of the pool whose dependent launches are slow:
+    // BENCH_r02, reduce 0.341 ms), the fused levels cost 7-8 us since the two roles sit on different SIMDs
+    // (tail_ab.txt: 2^20 reduce 0.167 -> 0.152 ms, 2^13 0.067 -> 0.055).
     const uint32_t mode = G.no_tree_fuse.load(std::memory_order_relaxed);
-    const bool per_level = mode == 1 || (mode == 0 && launch_gap_ns(c.stream) < kFuseAboveGapNs);  // (same answer in the sizing pass)
+    const bool per_level = mode == 1;
+    if (!dry) (void)launch_gap_ns(c.stream);  // diagnostic only (nmx_stats: NMX_STAT_LAUNCH_GAP_NS), measured once per process
     while (n_in > 1 && (per_level || (uint64_t)sh.WB * n_in > kTreeMaxInputs)) {
       const uint32_t half = n_in / 2, pairs = sh.WB * half;
       XYZZW* Do = alloc<XYZZW>(pairs);
@@ -344,7 +345,9 @@ struct DeviceBackend {
     }
     uint32_t levels = 0;
     while ((1u << levels) < n_in) levels++;
-    const uint32_t launches = (levels + kTreeLevels - 1) / kTreeLevels;
+    const uint32_t tt = G.tree_threads.load(std::memory_order_relaxed) == 256 ? 256u : kTreeThreads;
+    const uint32_t max_lv = tt == 256 ? kTreeLevels - 1 : kTreeLevels;  // a block owns tt / 4 inputs
+    const uint32_t launches = (levels + max_lv - 1) / max_lv;
     for (uint32_t i = 0; i < launches; i++) {
       const uint32_t lv = levels / launches + (i < levels % launches ? 1u : 0u);
       const uint32_t n_total = sh.WB * n_in, n_out = n_total >> lv;
@@ -354,8 +357,8 @@ struct DeviceBackend {
       if (last) *err_appended = true;
       if (!dry) {
         const ReduceTreeArgs a{D, Y, Do, Yo, n_total, lv, first, last ? 1u : 0u, last ? err_src : nullptr};
-        const uint32_t S = kTreeThreads / 4;
-        hipLaunchKernelGGL((k_reduce_tree<FID, kTreeThreads>), dim3((n_total + S - 1) / S), dim3(kTreeThreads), 0, c.stream, a);
+        if (tt == 256) hipLaunchKernelGGL((k_reduce_tree<FID, 256>), dim3((n_total + 63) / 64), dim3(256), 0, c.stream, a);
+        else hipLaunchKernelGGL((k_reduce_tree<FID, 512>), dim3((n_total + 127) / 128), dim3(512), 0, c.stream, a);
         HIPCHK(hipGetLastError());
       }
       D = Do, Y = Yo, n_in >>= lv, first = 0;
