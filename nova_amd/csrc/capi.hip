@@ -139,6 +139,8 @@ static void ensure_init() {
   if (const char* t = getenv("NMX_TUNE_NO_BATCH_FUSE")) G.no_batch_fuse = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_NO_TREE_FUSE")) G.no_tree_fuse = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_TREE_THREADS")) G.tree_threads = (uint32_t)atoi(t);
+  if (const char* t = getenv("NMX_TUNE_BIG_SLICE")) G.big_slice = (uint32_t)atoi(t);
+  if (const char* t = getenv("NMX_TUNE_BIG_THREADS")) G.big_threads = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_HIST_GRID")) G.hist_grid = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_SYNC_SPIN_US")) G.sync_spin_us = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_HORNER_TOP")) G.horner_top = (uint32_t)atoi(t);
@@ -1652,6 +1654,8 @@ int nmx_set_option(const char* name, uint32_t value) {
     else if (n == "no_batch_fuse") G.no_batch_fuse = value;
     else if (n == "no_tree_fuse") G.no_tree_fuse = value;
     else if (n == "tree_threads") G.tree_threads = value;
+    else if (n == "big_slice") G.big_slice = value;
+    else if (n == "big_threads") G.big_threads = value;
     else if (n == "hist_grid") G.hist_grid = value;
     else if (n == "sync_spin_us") G.sync_spin_us = value;
     else if (n == "shard_min_n") G.shard_min_n.store(value ? value : 1u);

@@ -106,7 +106,7 @@ template <int CID> struct GenFn {  // P_i = (k0 + i) * G
 // ---------------------------------------------------------------------------------------------------
 static inline uint64_t shape_hash(const MsmArgs& a, const MsmCall& mc, size_t sbytes, uint32_t cid, uint32_t sbits,
                                   uint32_t seg_lanes) {
-  const uint64_t v[11] = {((uint64_t)cid << 56) | ((uint64_t)sbits << 40) | seg_lanes, a.n, a.u64_bits | ((uint64_t)G.no_tree_fuse.load(std::memory_order_relaxed) << 32) | ((uint64_t)G.tree_threads.load(std::memory_order_relaxed) << 40), a.force_c, a.force_lmax, a.force_fold_t, ((uint64_t)a.pre_stride << 8) | a.pre_c,
+  const uint64_t v[11] = {((uint64_t)cid << 56) | ((uint64_t)sbits << 40) | seg_lanes, a.n, a.u64_bits | ((uint64_t)G.no_tree_fuse.load(std::memory_order_relaxed) << 32) | ((uint64_t)G.tree_threads.load(std::memory_order_relaxed) << 40) | ((uint64_t)a.big_slice << 44), a.force_c, a.force_lmax, a.force_fold_t, ((uint64_t)a.pre_stride << 8) | a.pre_c,
                           (uint64_t)(mc.gather_host != nullptr) | (mc.all_ones ? 2u : 0u) | (mc.scalars_device ? 4u : 0u) |
                               (a.no_partition ? 8u : 0u),
                           sbytes, a.seg_min_total, G.seg_lanes_override ^ ((uint64_t)a.seg_heavy_above << 32)};
@@ -144,6 +144,7 @@ static XYZZ<CurveT<CID>::BF> run_msm(Ctx& c, const void* d_bases, size_t n, cons
   a.seg_min_total = G.seg_min_total;
   a.seg_min_len = G.seg_min_len;
   a.seg_heavy_above = G.seg_heavy_above;
+  a.big_slice = G.big_slice.load(std::memory_order_relaxed);
   a.hist_grid = G.hist_grid;
   // gathers in flight per lane: one is enough while the key's tables (W x 64 B per point) mostly hit the 256 MB Infinity Cache
   // and L2; from ~6 GiB of tables on the gather latency shows and a second row in flight pays (2^24: accumulate 17.6 ->
@@ -414,6 +415,7 @@ static void run_msm_batch(Ctx& c, const BaseSet& bs, size_t offset, const BatchI
   a.seg_min_total = G.seg_min_total;
   a.seg_min_len = G.seg_min_len;
   a.seg_heavy_above = G.seg_heavy_above;
+  a.big_slice = G.big_slice.load(std::memory_order_relaxed);
   a.hist_grid = G.hist_grid;
   {
     const uint32_t pf = G.accum_prefetch.load(std::memory_order_relaxed);

@@ -344,71 +344,82 @@ __device__ __forceinline__ Fp<FID> block_sum_quads(Fp<FID> acc, uint32_t* lds /*
   return acc;
 }
 
-// Every big bucket (more than 64 continuation pieces; SegPlan) completely, in ONE launch whatever its size.  1-D grid of two roles:
-//   blocks [0, 16 x slices)         block (g, s) walks the list with stride 16 and sums slice s of the buckets of SEVERAL slices
-//                                   (all-equal or 0/1 scalars: a whole window in one bucket); the slice sum is parked in the slice's
-//                                   own first position and the block that draws the bucket's last ticket sums the parked slices the
-//                                   same way -- no block ever waits for another;
-//   blocks [16 x slices, + n_single) walk the big list with stride n_single and finish the buckets of ONE slice (<= 4096 pieces: 128
-//                                   quads x <= 32 strided additions, a 7-level LDS tree, + bucket_raw[k], canonical store) -- e.g. the
-//                                   1023 buckets of 10-bit scalars, 127 pieces each: one block per bucket (a first version walked the
-//                                   list with 16 blocks: 1.8 ms for that input).
+// Every big bucket (more than 64 continuation pieces; SegPlan) completely, in ONE launch whatever its size.  The plan step
+// numbered the (bucket, slice) ITEMS (SegPlan: counters[6], rec.pad, big_items); a fixed grid of small blocks (128 threads = 32
+// quads, four blocks per CU) walks them with the grid's stride.  An item: 32 quads x (slice / 32) strided additions, a 5-level
+// LDS tree.  A bucket of one slice is then finished (+ bucket_raw[k], canonical store).  Otherwise the slice sum is parked in the
+// slice's own first position and the block takes a ticket of its GROUP of 32 slices; the block that draws a group's last ticket
+// sums the group's parked slices (one per quad, the same tree), parks that in the group's first position and takes a ticket of
+// the bucket; the block that draws the bucket's last ticket sums the group sums and finishes.  No block ever waits for another.
+// What it costs is the dependent chain: slice / 32 additions + three 5-level trees, whatever the input:
+//   0/1 scalars (ONE bucket of 196 608 pieces), all-equal scalars (15 buckets of 26 214), 10-bit scalars (1023 buckets of 127).
+// (Round 3's first versions used 512-thread blocks on 4096-piece slices, 16 blocks per possible slice index plus one per possible
+// bucket, every block searching the list for its work: 0.2 ms for each of these inputs, most of it idle blocks scanning and
+// seven-level trees with one block per CU -- and shorter slices, i.e. more parallel work, made it slower.)
 struct BigAllArgs {
   const uint32_t* counters;
   const HeavyRec* big;
+  const uint32_t* items;
+  const uint32_t* gbase;
   const XYZZL* bucket_raw;
   XYZZL* partial_raw;
   XYZZW* buckets;
-  uint32_t* done;  // [big capacity], zero-initialised: tickets
-  uint32_t n_single, slices;
+  uint32_t* done;   // [big capacity], zero-initialised: finished groups per bucket
+  uint32_t* gdone;  // [group capacity], zero-initialised: finished slices per group
+  uint32_t slice;   // pieces per item
 };
-static constexpr uint32_t kBigSlice = 4096, kBigThreads = 512, kBigMultiGroups = 16;
-template <int FID> __global__ __launch_bounds__(512) void k_big_all(BigAllArgs a) {
-  const uint32_t nbig = a.counters[4];
-  if (nbig == 0) return;
-  constexpr uint32_t NQ = kBigThreads / 4;
+template <int FID, int THREADS> __global__ __launch_bounds__(THREADS) void k_big_all(BigAllArgs a) {
+  const uint32_t nitems = a.counters[6];
+  constexpr uint32_t NQ = THREADS / 4, GR = SegPlan::kBigGroup;
+  static_assert(GR <= NQ, "a group's parked slices are summed one per quad");
   __shared__ uint32_t lds[NQ * 36];
   __shared__ uint32_t s_ticket;
   const uint32_t qd = threadIdx.x >> 2, q = threadIdx.x & 3u;
-  // block ids: the multi-slice role first, slice index slowest -- the blocks with work (slices 0 .. nsl-1 of the first buckets of
-  // the list) are then the first ids of the launch and start together (with them scattered over 2560 ids the last ones started
-  // ~200 us late: 0.41 ms instead of 0.21 for all-equal scalars); then one block per single-slice bucket
-  const uint32_t n_multi = kBigMultiGroups * a.slices;
-  const bool multi = blockIdx.x < n_multi;
-  const uint32_t s = multi ? blockIdx.x / kBigMultiGroups : 0u;
-  const uint32_t h0 = multi ? blockIdx.x % kBigMultiGroups : blockIdx.x - n_multi, stride = multi ? kBigMultiGroups : a.n_single;
-  for (uint32_t h = h0; h < nbig; h += stride) {
+  // parks `v` (held by quad 0) at `pos`, takes a ticket of `ctr`: true in the block that drew ticket `want` (block-uniform)
+  // (the fences are not what the hand-over costs: a build without them, and one with agent-coherent sc1 accesses instead of
+  // the L2 write-back, timed the same -- profiles/r03_msm_2p20/big_bucket_pass.txt)
+  auto park_and_ticket = [&](const Fp<FID>& v, uint32_t pos, uint32_t* ctr, uint32_t want) {
+    if (qd == 0) {
+      quad_store_raw<FID>(a.partial_raw[pos], q, v);
+      __threadfence();
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      s_ticket = atomicAdd(ctr, 1u);
+    }
+    __syncthreads();
+    const bool last = s_ticket == want;
+    __syncthreads();  // s_ticket is rewritten by the next ticket of this block
+    if (last) __threadfence();
+    return last;
+  };
+  auto load_parked = [&](uint32_t pos) { return quad_load_raw<FID>(a.partial_raw[pos], q); };
+  for (uint32_t item = blockIdx.x; item < nitems; item += gridDim.x) {  // block-uniform
+    const uint32_t h = a.items[item];
     const HeavyRec r = a.big[h];
-    const uint32_t nsl = (r.cnt + kBigSlice - 1) / kBigSlice;
-    if ((nsl > 1) != multi || s >= nsl) continue;  // block-uniform
-    const uint32_t lo = s * kBigSlice, hi = r.cnt < lo + kBigSlice ? r.cnt : lo + kBigSlice;
+    const uint32_t nsl = (r.cnt + a.slice - 1) / a.slice, s = item - r.pad;
+    const uint32_t lo = s * a.slice, hi = r.cnt < lo + a.slice ? r.cnt : lo + a.slice;
     Fp<FID> acc = Fp<FID>::zero();  // zz = 0: the identity
     for (uint32_t p = lo + qd; p < hi; p += NQ) acc = quad_add<FID>(acc, quad_load_raw<FID>(a.partial_raw[r.off + p], q), q);
     acc = block_sum_quads<FID, NQ>(acc, lds, qd, q);
     if (nsl > 1) {
-      if (qd == 0) {
-        quad_store_raw<FID>(a.partial_raw[r.off + lo], q, acc);
-        __threadfence();
-      }
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        __threadfence();
-        s_ticket = atomicAdd(&a.done[h], 1u);
-      }
-      __syncthreads();
-      const bool last = s_ticket == nsl - 1;
-      __syncthreads();  // s_ticket is rewritten by the next bucket of this block
-      if (!last) continue;
-      __threadfence();
-      acc = Fp<FID>::zero();
-      for (uint32_t t = qd; t < nsl; t += NQ) acc = quad_add<FID>(acc, quad_load_raw<FID>(a.partial_raw[r.off + t * kBigSlice], q), q);
+      const uint32_t ng = (nsl + GR - 1) / GR, g = s / GR, g_lo = g * GR, g_n = nsl - g_lo < GR ? nsl - g_lo : GR;
+      if (!park_and_ticket(acc, r.off + lo, &a.gdone[a.gbase[h] + g], g_n - 1)) continue;
+      acc = qd < g_n ? load_parked(r.off + (g_lo + qd) * a.slice) : Fp<FID>::zero();
       acc = block_sum_quads<FID, NQ>(acc, lds, qd, q);
+      if (ng > 1) {
+        if (!park_and_ticket(acc, r.off + g_lo * a.slice, &a.done[h], ng - 1)) continue;
+        acc = Fp<FID>::zero();
+        for (uint32_t t = qd; t < ng; t += NQ) acc = quad_add<FID>(acc, load_parked(r.off + t * GR * a.slice), q);
+        acc = block_sum_quads<FID, NQ>(acc, lds, qd, q);
+      }
     }
     if (qd == 0) {
       acc = quad_add<FID>(quad_load_raw<FID>(a.bucket_raw[r.bucket], q), acc, q);
       quad_store<FID>(a.buckets[r.bucket], q, acc);
     }
-    __syncthreads();  // lds is reused by the next bucket
+    __syncthreads();  // lds is reused by the next item
   }
 }
 

@@ -32,6 +32,7 @@ struct MsmArgs {
   uint32_t seg_min_len = 8;           // shortest segment a lane is given
   uint32_t accum_prefetch = 1;        // gathers in flight ahead of the addition (AccumSegFn PF)
   uint32_t hist_grid = 0;             // blocks of the first-level counting pass (0: as many as the placing pass; tuning)
+  uint32_t big_slice = 0;             // pieces per block of the big-bucket pass (< 32: SegPlan::big_slice_for)
   uint32_t seg_heavy_above = 0;       // pieces FinalSegFn sums per bucket without a pre-fold (0: SegPlan::heavy_above_for)
   // fused batch over the key's tables (DigitSrc::batch_*): n = sum of the vector lengths, `scalars` unused;
   // wsum_host[j] receives vector j's sum
@@ -149,12 +150,16 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
   const uint32_t big_cap_s = seg ? (seg_lanes / (SegPlan::kBigAbove + 1) + 1 < sh.nbuckets ? seg_lanes / (SegPlan::kBigAbove + 1) + 1 : sh.nbuckets) : 0;
   const size_t nbounds = 2 * ((size_t)sh.nbuckets + 1) + 8;
   const size_t nctr = part ? 2048 + 3 * kTabStride + 1 + 2 * (size_t)sh.nbuckets : 0;
-  const size_t nzero = nbounds + big_cap_s + nctr;
+  const uint32_t big_slice = seg ? SegPlan::big_slice_for(a.big_slice, seg_lanes) : 1;
+  const uint32_t big_items_cap = seg ? seg_lanes / big_slice + big_cap_s + 1 : 0;                      // sum of ceil(cnt / slice)
+  const uint32_t big_groups_cap = seg ? big_items_cap / SegPlan::kBigGroup + big_cap_s + 1 : 0;       // sum of ceil(slices / 32)
+  const size_t nzero = nbounds + big_cap_s + big_groups_cap + nctr;
   uint32_t* start = be.template alloc<uint32_t>(nzero);
   uint32_t* end = start + sh.nbuckets + 1;
-  uint32_t* counters = end + sh.nbuckets + 1;  // [0] extra tasks, [1] split buckets, [2] error bits, [3] max tasks, [4] big, [5] non-zero digits
+  uint32_t* counters = end + sh.nbuckets + 1;  // [0] extra tasks, [1] split buckets, [2] error bits, [3] max tasks, [4] big, [5] non-zero digits, [6] items, [7] groups of the big-bucket pass
   uint32_t* big_done = start + nbounds;
-  uint32_t* ctr = big_done + big_cap_s;
+  uint32_t* big_gdone = big_done + big_cap_s;
+  uint32_t* ctr = big_gdone + big_groups_cap;
   HeavyRec* heavy = be.template alloc<HeavyRec>(seg ? 1 : heavy_cap);
   const uint32_t big_cap = (uint32_t)(total / ((size_t)64 * sh.lmax)) + 1;
   HeavyRec* big = be.template alloc<HeavyRec>(seg ? 1 : big_cap);
@@ -264,7 +269,9 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
     // below read bucket_raw[k] for non-empty buckets only
     XYZZL* bucket_raw = be.template alloc<XYZZL>(sh.nbuckets);
     const uint32_t* total_p = counters + 5;
-    const SegPlan plan{start, end, total_p, counters, heavy_s, big_s, sh.nbuckets, seg_lanes, a.seg_min_len, heavy_above};
+    uint32_t* big_items = be.template alloc<uint32_t>(big_items_cap);
+    uint32_t* big_gbase = be.template alloc<uint32_t>(big_cap_s);
+    const SegPlan plan{start, end, total_p, counters, heavy_s, big_s, sh.nbuckets, seg_lanes, a.seg_min_len, heavy_above, big_items, big_gbase, big_slice};
     be.mark("accum");
     if (a.accum_prefetch > 1) {
       AccumSegFn<FID, 2> f{(const AffineW*)a.bases, vals1, start, end, total_p, bucket_raw, partial_raw, sh.nbuckets,
@@ -278,7 +285,7 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
     be.mark("fold");
     // big buckets (> 64 pieces) completely; then the heavy ones (> heavy_above) down to heavy_above positions; then
     // every other bucket.  On uniformly random scalars the first two launches find empty lists and exit.
-    be.template launch_big_all<FID>(counters, big_s, bucket_raw, partial_raw, buckets, big_done, seg_lanes, big_cap_s);
+    be.template launch_big_all<FID>(counters, big_s, big_items, big_gbase, bucket_raw, partial_raw, buckets, big_done, big_gdone, big_slice);
     if (heavy_above < SegPlan::kBigAbove) {
       // listed buckets number at most seg_lanes / (heavy_above + 1); when the typical bucket is not heavy (c = 17 tables:
       // 9 pieces against 12) a small grid walks whatever the input made heavy

@@ -41,6 +41,18 @@ NMX_HD uint32_t seg_len(uint32_t total, uint32_t lanes, uint32_t min_seg) {
 // [3] largest partial count among the big buckets, [4] big count.  Wave-safe on the device (one atomic per wave).
 struct SegPlan {
   static constexpr uint32_t kBigAbove = 64;
+  // The big-bucket pass works on slices of a bucket's pieces, one block per slice: every (bucket, slice) is an ITEM, numbered
+  // here (counters[6] = items so far; rec.pad = the bucket's first item; big_items[item] = its position in the big list), so that
+  // the pass is a plain strided loop over items whatever mix of bucket sizes the input produced.  Slices are summed in groups of
+  // kBigGroup (counters[7] = groups so far, big_gbase[h] = the bucket's first group): a bucket of 768 slices ends with 24 group
+  // sums, not with one block adding 768 points.
+  static constexpr uint32_t kBigGroup = 32;
+  // slice length: ~768 items when every lane's piece belongs to a big bucket (the pass keeps 1024 blocks resident)
+  static uint32_t big_slice_for(uint32_t forced, uint32_t lanes) {
+    if (forced >= 32) return forced;
+    const uint32_t s = (lanes / 768 + 31u) & ~31u;
+    return s < 64 ? 64 : s;
+  }
   // A bucket with more than `heavy_above` continuation pieces is listed for the T = heavy_above pre-fold; FinalSegFn sums up
   // to that many serially.  lanes / nbuckets pieces per bucket on uniformly random scalars: 18 at c = 16 (8: one pre-fold
   // pass halves them), 9 at c = 17 (12: no bucket is listed, no pre-fold work, FinalSegFn adds one more piece).
@@ -52,6 +64,9 @@ struct SegPlan {
   HeavyRec* heavy;  // heavy_above < pieces <= kBigAbove
   HeavyRec* big;    // pieces > kBigAbove
   uint32_t nbuckets, lanes, min_seg, heavy_above;
+  uint32_t* big_items;  // [lanes / big_slice + big capacity + 1]
+  uint32_t* big_gbase;  // [big capacity]
+  uint32_t big_slice;
   // every lane of the wave calls this together (lanes without a bucket: valid = false)
   NMX_HD void operator()(uint32_t k, bool valid) const {
     const uint32_t seg = seg_len(*total_p, lanes, min_seg);
@@ -78,11 +93,14 @@ struct SegPlan {
 #else
     if (is_heavy) slot = counters[1]++;
 #endif
-    const HeavyRec r{k, off, cnt, 0};
-    if (is_heavy) heavy[slot] = r;
+    if (is_heavy) heavy[slot] = HeavyRec{k, off, cnt, 0};
     if (is_big) {  // rare: a bucket holding more than 64 lanes' worth of entries
       nmx_atomic_max(&counters[3], cnt);
-      big[nmx_atomic_add(&counters[4], 1)] = r;
+      const uint32_t nsl = (cnt + big_slice - 1) / big_slice;
+      const uint32_t first_item = nmx_atomic_add(&counters[6], nsl), h = nmx_atomic_add(&counters[4], 1);
+      big[h] = HeavyRec{k, off, cnt, first_item};
+      big_gbase[h] = nmx_atomic_add(&counters[7], (nsl + kBigGroup - 1) / kBigGroup);
+      for (uint32_t t = 0; t < nsl; t++) big_items[first_item + t] = h;
     }
   }
 };

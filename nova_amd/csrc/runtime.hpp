@@ -154,6 +154,8 @@ struct Global {
   std::atomic<uint32_t> horner_top{0};            // env NMX_TUNE_HORNER_TOP / option horner_top: suffix Horner's register-resident levels: 0 / 8 = 8-element chunks, 4, 1 = off
   std::atomic<uint32_t> seg_heavy_above{0};       // env NMX_TUNE_SEG_HEAVY_ABOVE / option seg_heavy_above: 0 = by pieces per bucket (8 or 12)
   std::atomic<uint32_t> no_batch_fuse{0};         // env NMX_TUNE_NO_BATCH_FUSE / option no_batch_fuse: every vector of a batch runs alone
+  std::atomic<uint32_t> big_threads{0};           // env NMX_TUNE_BIG_THREADS / option big_threads: block size of the big-bucket pass (128 default, 256, 512)
+  std::atomic<uint32_t> big_slice{0};             // env NMX_TUNE_BIG_SLICE / option big_slice: pieces per block of the big-bucket pass (0 = default)
   std::atomic<uint32_t> tree_threads{0};          // env NMX_TUNE_TREE_THREADS / option tree_threads: block size of the fused reduction tree (0 = default, 256 or 512)
   std::atomic<uint32_t> no_tree_fuse{0};          // env NMX_TUNE_NO_TREE_FUSE / option no_tree_fuse: 0 / 2 = fused reduction tree (default), 1 = one launch per reduction level
   std::atomic<uint32_t> hist_grid{0};             // env NMX_TUNE_HIST_GRID / option hist_grid
@@ -297,22 +299,21 @@ struct DeviceBackend {
   }
   // every big bucket in one launch (curve_quad.hpp k_big_all); a bucket spans at most `lanes` pieces, `big_cap` buckets can be big
   template <int FID>
-  void launch_big_all(const uint32_t* counters, const HeavyRec* big, const XYZZL* bucket_raw, XYZZL* partial_raw,
-                      XYZZW* buckets, uint32_t* done, uint32_t lanes, uint32_t big_cap) {
+  void launch_big_all(const uint32_t* counters, const HeavyRec* big, const uint32_t* items, const uint32_t* gbase,
+                      const XYZZL* bucket_raw, XYZZL* partial_raw, XYZZW* buckets, uint32_t* done, uint32_t* gdone,
+                      uint32_t slice) {
     if (dry) return;
-    const uint32_t slices = (lanes + kBigSlice - 1) / kBigSlice;
-    const uint32_t n_single = big_cap < 1024u ? (big_cap ? big_cap : 1u) : 1024u;
-    const BigAllArgs a{counters, big, bucket_raw, partial_raw, buckets, done, n_single, slices};
-    hipLaunchKernelGGL((k_big_all<FID>), dim3(n_single + kBigMultiGroups * slices), dim3(kBigThreads), 0, c.stream, a);
+    const BigAllArgs a{counters, big, items, gbase, bucket_raw, partial_raw, buckets, done, gdone, slice};
+    const uint32_t bt = G.big_threads.load(std::memory_order_relaxed);  // 512 threads per CU resident either way
+    if (bt == 512) hipLaunchKernelGGL((k_big_all<FID, 512>), dim3(256), dim3(512), 0, c.stream, a);
+    else if (bt == 256) hipLaunchKernelGGL((k_big_all<FID, 256>), dim3(512), dim3(256), 0, c.stream, a);
+    else hipLaunchKernelGGL((k_big_all<FID, 128>), dim3(1024), dim3(128), 0, c.stream, a);
     HIPCHK(hipGetLastError());
   }
-  // Bucket reduction sum_k (k + 1) B_k per bucket set: the pair tree of ReducePairFn.  A level costs two dependent quad
-  // additions (~10 us) wherever it runs, so fusing levels into one launch gains nothing on a box whose launches chain
-  // back to back (measured: 16 launches 0.167 ms, fused 0.175) -- but on the boxes of the pool where every dependent
-  // launch of a few waves costs 5-10 us extra, round 2's tree took 0.34 ms.  Levels with more inputs than one round of
-  // blocks holds (256 CUs x 128 inputs: the kernel runs one 512-thread block per CU at 181 registers) are throughput-bound
-  // and keep one launch each; the others run fused, at most seven levels per launch (k_reduce_tree): 16 levels = 1 + 3
-  // launches at c = 17, 15 = 3 at c = 16, 7 = 1 at c = 8.  Returns the WB sums.
+  // Bucket reduction sum_k (k + 1) B_k per bucket set: the pair tree of ReducePairFn, two dependent quad additions per level.
+  // Levels with more inputs than one round of blocks holds (256 CUs x 128 inputs: the kernel runs one 512-thread block per CU
+  // at 181 registers) are throughput-bound and keep one launch each; the others run fused, at most seven levels per launch
+  // (k_reduce_tree): 16 levels = 1 + 3 launches at c = 17, 15 = 3 at c = 16, 7 = 1 at c = 8.  Returns the WB sums.
   static constexpr uint32_t kTreeThreads = 512, kTreeLevels = 7, kTreeMaxInputs = 256 * 128;
   template <int FID> const XYZZW* reduce_tree(const XYZZW* buckets, const MsmShape& sh, const uint32_t* err_src, bool* err_appended) {
     const XYZZW* D = buckets;

@@ -69,10 +69,27 @@ struct HostEmulBackend {
     return Y;
   }
   template <int FID>
-  void launch_big_all(const uint32_t* counters, const HeavyRec* big, const XYZZL* bucket_raw, XYZZL* partial_raw,
-                      XYZZW* buckets, uint32_t*, uint32_t lanes, uint32_t) {
+  void launch_big_all(const uint32_t* counters, const HeavyRec* big, const uint32_t* items, const uint32_t* gbase,
+                      const XYZZL* bucket_raw, XYZZL* partial_raw, XYZZW* buckets, uint32_t*, uint32_t*, uint32_t slice) {
+    // the item numbering of the plan step is checked here (the device kernel depends on it): every bucket's slices, once each
+    std::vector<uint32_t> seen(counters[4], 0);
+    for (uint32_t i = 0; i < counters[6]; i++) {
+      const uint32_t h = items[i];
+      if (h >= counters[4] || i < big[h].pad || i - big[h].pad >= (big[h].cnt + slice - 1) / slice) { fprintf(stderr, "big-bucket item %u is wrong\n", i); abort(); }
+      seen[h]++;
+    }
+    for (uint32_t h = 0; h < counters[4]; h++)
+      if (seen[h] != (big[h].cnt + slice - 1) / slice) { fprintf(stderr, "big bucket %u: %u items\n", h, seen[h]); abort(); }
+    // group numbering: disjoint ranges of ceil(slices / 32) counters per bucket, counters[7] in total
+    std::vector<uint32_t> gseen(counters[7], 0);
+    for (uint32_t h = 0; h < counters[4]; h++) {
+      const uint32_t ng = ((big[h].cnt + slice - 1) / slice + SegPlan::kBigGroup - 1) / SegPlan::kBigGroup;
+      for (uint32_t g = 0; g < ng; g++) {
+        if (gbase[h] + g >= counters[7] || gseen[gbase[h] + g]++) { fprintf(stderr, "big bucket %u: group %u is wrong\n", h, g); abort(); }
+      }
+    }
     BigBucketFn<FID> f{counters, big, bucket_raw, partial_raw, buckets};
-    launch(f, lanes / (SegPlan::kBigAbove + 1) + 1);
+    launch(f, counters[4] + 1);
   }
   // segment-balanced accumulate (msm_seg.hpp): an odd lane count so segments straddle bucket boundaries everywhere
   template <int FID> uint32_t seg_lanes(size_t) { return g_seg_lanes; }

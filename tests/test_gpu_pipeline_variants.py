@@ -19,6 +19,9 @@ VARIANTS = [
     {"seg_min_total": 1 << 22},                                    # round 2's threshold
     {"no_tree_fuse": 1},                                           # one launch per reduction level
     {"no_tree_fuse": 2, "seg_min_total": 0},                       # fused reduction tree, segments
+    {"seg_min_total": 0, "big_slice": 64},                         # big-bucket pass in short slices: groups of tickets, then the bucket's
+    {"seg_min_total": 0, "big_slice": 100, "big_threads": 512},    # a slice that is no multiple of the block's quads; 512-thread blocks
+    {"seg_min_total": 0, "big_slice": 4096, "big_threads": 256},   # one slice per bucket at these sizes
     {"no_tree_fuse": 2, "tree_threads": 256},                      # fused tree in 256-thread blocks (six levels per launch)
     {"seg_min_total": 0, "seg_lanes": 4096, "seg_min_len": 3},     # segments everywhere, few long ones
     {"seg_min_total": 0, "seg_lanes": 1 << 19, "seg_min_len": 1},  # more lanes than entries per bucket: one-entry pieces
@@ -29,7 +32,7 @@ VARIANTS = [
 ]
 DEFAULTS = {"no_partition": 0, "seg_min_total": 0xFFFFFFFE,   # 0xfffffffe = the automatic rule
              "seg_lanes": 0, "seg_min_len": 8, "no_quad_final": 0, "accum_prefetch": 0,
-            "seg_heavy_above": 0, "no_tree_fuse": 0, "tree_threads": 0}
+            "seg_heavy_above": 0, "no_tree_fuse": 0, "tree_threads": 0, "big_slice": 0, "big_threads": 0}
 
 
 @pytest.mark.parametrize("c,n", [(R.BN254_G1, 20000), (R.BN254_G1, 1 << 16), (R.PALLAS, 1 << 17)], ids=lambda v: getattr(v, "name", v))
