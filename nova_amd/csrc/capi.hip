@@ -3,7 +3,8 @@
 #include <algorithm>
 #include <array>
 #include <atomic>
-#include <future>
+#include <condition_variable>
+#include <functional>
 #include <list>
 #include <thread>
 
@@ -242,8 +243,14 @@ static inline PartRange shard_range(size_t n, uint32_t i, uint32_t k) {
   const size_t base = n / k, rem = n % k;
   return PartRange{(size_t)i * base + (i < rem ? i : rem), base + (i < rem ? 1u : 0u)};
 }
-// fn(i) for i in [0, count): i = 0 on the calling thread, the others on their own threads when `parallel`.  Nothing
-// escapes a worker thread; the first failure is rethrown here.  The calling thread ends on the primary device.
+WorkerPool& worker_pool() {
+  static WorkerPool& wp = *new WorkerPool;  // leaked on purpose (see WorkerPool)
+  return wp;
+}
+static WorkerPool& WP = worker_pool();
+
+// fn(i) for i in [0, count): i = 0 on the calling thread, the others on pool workers when `parallel`.  Nothing escapes a
+// worker; the first failure is rethrown here, after every part has finished.  The calling thread ends on the primary device.
 template <class Fn> static void run_on_parts(size_t count, bool parallel, Fn&& fn) {
   std::mutex err_mu;
   bool failed = false;
@@ -268,20 +275,40 @@ template <class Fn> static void run_on_parts(size_t count, bool parallel, Fn&& f
   if (!parallel || count <= 1) {
     for (size_t i = 0; i < count; i++) guarded_fn(i);
   } else {
-    std::vector<std::thread> th;
-    size_t started = 1;
-    {
-      JoinAll join{th};
-      try {
-        for (size_t i = 1; i < count; i++) {
-          th.emplace_back([&guarded_fn, i] { guarded_fn(i); });
-          started = i + 1;
+    std::mutex done_mu;
+    std::condition_variable done_cv;
+    size_t pending = 0, started = 1;
+    try {
+      for (size_t i = 1; i < count; i++) {
+        Worker* w = WP.acquire();
+        {
+          std::lock_guard<std::mutex> lk(done_mu);
+          pending++;
         }
-      } catch (const std::exception&) {  // std::system_error from thread creation: the rest runs on this thread
+        try {
+          WP.submit(w, [&, w, i] {
+            guarded_fn(i);
+            WP.release(w);
+            std::lock_guard<std::mutex> lk(done_mu);  // held across the notify: the waiter cannot leave (and destroy done_cv) in between
+            pending--;
+            done_cv.notify_one();
+          });
+        } catch (...) {
+          {
+            std::lock_guard<std::mutex> lk(done_mu);
+            pending--;
+          }
+          WP.release(w);
+          throw;
+        }
+        started = i + 1;
       }
-      guarded_fn(0);
-      for (size_t i = started; i < count; i++) guarded_fn(i);
+    } catch (const std::exception&) {  // std::system_error from thread creation: the rest runs on this thread
     }
+    guarded_fn(0);
+    for (size_t i = started; i < count; i++) guarded_fn(i);
+    std::unique_lock<std::mutex> lk(done_mu);
+    done_cv.wait(lk, [&] { return pending == 0; });
   }
   (void)hipSetDevice(G.device);
   if (failed) throw first;
@@ -781,15 +808,11 @@ static void with_slice(Ctx& c, const CurveOps& o, int curve, const void* bases, 
   for (int attempt = 0;; attempt++) {
     const SliceKey k = resolve_slice(c, o, curve, bases, n, flags);
     bool ok = true;
-    std::future<bool> fut;
+    PoolFuture<bool> fut;
     if (k.deep.needed()) {
       if (k.deep.count > kSyncWindow) {
-        try {
-          const DeepCheck dc = k.deep;
-          fut = std::async(std::launch::async, [dc] { return dc.run(); });
-        } catch (const std::system_error&) {
-          ok = k.deep.run();
-        }
+        const DeepCheck dc = k.deep;
+        fut = PoolFuture<bool>([dc] { return dc.run(); });
       } else {
         ok = k.deep.run();
       }
@@ -1206,31 +1229,16 @@ static void batch_impl(const BaseSet& bs, size_t base_off, size_t n_bases, const
     }
   };
   const size_t lanes = njobs < kBatchLanes ? njobs : kBatchLanes;
-  if (lanes <= 1) {
-    guarded_worker(&c);
-  } else {
-    std::vector<std::thread> th;
-    {
-      JoinAll join{th};
-      try {
-        for (size_t t = 1; t < lanes; t++)
-          th.emplace_back([&] {
-            try {
-              CtxLease L;
-              guarded_worker(L.c);
-            } catch (const Fail& f) {
-              record(f);
-            } catch (const std::exception& e) {
-              record(Fail{NMX_E_HIP, e.what()});
-            } catch (...) {
-              record(Fail{NMX_E_HIP, "unknown exception in a batch worker"});
-            }
-          });
-      } catch (const std::exception&) {  // std::system_error from thread creation: run with the lanes we have
-      }
+  // lane 0 on the calling thread with its context, the others on pool workers with a context of their own; a lane that cannot
+  // be started (no thread) is simply missing: the others drain the job list
+  run_on_parts(lanes, true, [&](size_t t) {
+    if (t == 0) {
       guarded_worker(&c);
+    } else {
+      CtxLease L;
+      guarded_worker(L.c);
     }
-  }
+  });
   if (failed) throw first_fail;
   memcpy(out, tmp.data(), 64 * k);
   if (out_is_inf) memcpy(out_is_inf, tinf.data(), k);
@@ -1286,7 +1294,7 @@ int nmx_commit(uint64_t ck_handle, const void* v, size_t n, const void* h_xy64, 
       std::array<uint8_t, 32> rb;
       memcpy(hb.data(), h_xy64, 64);
       memcpy(rb.data(), r, 32);
-      auto hr = std::async(std::launch::async, [&o, hb, rb, flags] {
+      PoolFuture<std::array<uint8_t, 128>> hr([&o, hb, rb, flags] {
         std::array<uint8_t, 128> t;
         o.blind_term(hb.data(), rb.data(), flags, t.data());
         return t;

@@ -6,7 +6,6 @@
 //   /root/reference/src/provider/pedersen.rs:263-270, hyperkzg.rs:584-591 (commit = msm + h*r)
 #pragma once
 #include <array>
-#include <future>
 
 #include "runtime.hpp"
 
@@ -538,15 +537,15 @@ template <int CID> struct CurveImpl {
     require(Fp<SF>::words_lt_p(rw), NMX_E_SCALAR_RANGE, "blinding scalar >= field modulus");
     uint32_t any = 0;
     for (int i = 0; i < 8; i++) any |= rw[i];
-    std::future<XYZZ<BF>> hr;
+    PoolFuture<XYZZ<BF>> hr;
     if (any) {
       std::array<uint8_t, 64> hb;
       std::array<uint8_t, 32> rb;
       memcpy(hb.data(), h_xy64, 64);
       memcpy(rb.data(), r, 32);
-      hr = std::async(std::launch::async, [hb, rb, flags] { return blind_point(hb.data(), rb.data(), flags); });
+      hr = PoolFuture<XYZZ<BF>>([hb, rb, flags] { return blind_point(hb.data(), rb.data(), flags); });
     }
-    auto acc = run_msm_key<CID>(c, bs, 0, n, mc);  // a failure here unwinds through hr's destructor, which joins
+    auto acc = run_msm_key<CID>(c, bs, 0, n, mc);  // a failure here unwinds through hr's destructor, which waits
     if (any) acc.add(hr.get());
     write_result<CID>(acc, flags, out, inf);
   }

@@ -10,6 +10,9 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <exception>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -110,6 +113,132 @@ using BaseRef = std::shared_ptr<const BaseSet>;
 // 2^11-pair MSM takes 0.29 ms instead of 0.98 -- one bucket set instead of 37, no 250-doubling Horner on the host.)
 static constexpr size_t kPrecompMinN = 2;  // default of Global::precomp_min_n
 // internal upload flag (never part of the ABI): the source array is a resident key already in the internal form -- no
+// ---------------------------------------------------------------------------------------------------
+// Helper threads: the shards of a multi-device call, the lanes of a batch, the host-side work that runs under a GPU MSM (the
+// rolling verification of a cached slice, the blinding term of a commitment).  Persistent: creating and joining a std::thread
+// costs 20-60 us -- seven of them per MSM on an 8-GPU node, one per slice-form call.  A worker runs one job at a time and goes
+// back to the idle list; the pool grows to the largest number of helpers ever wanted at once and lives as long as the process
+// (leaked on purpose, like G: its threads may still be parked when static destructors run).
+// ---------------------------------------------------------------------------------------------------
+struct Worker {
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  std::function<void()> job;
+  bool has_job = false;
+};
+struct WorkerPool {
+  std::mutex mu;
+  std::vector<Worker*> idle;
+  static void loop(Worker* w) {
+    for (;;) {
+      std::function<void()> j;
+      {
+        std::unique_lock<std::mutex> lk(w->m);
+        w->cv.wait(lk, [w] { return w->has_job; });
+        j = std::move(w->job);
+        w->has_job = false;
+      }
+      j();  // must not throw; ends by handing the worker back (release)
+    }
+  }
+  Worker* acquire() {  // may throw std::system_error (thread creation)
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!idle.empty()) {
+        Worker* w = idle.back();
+        idle.pop_back();
+        return w;
+      }
+    }
+    Worker* w = new Worker;
+    try {
+      w->th = std::thread(loop, w);
+    } catch (...) {
+      delete w;
+      throw;
+    }
+    return w;
+  }
+  void release(Worker* w) {
+    std::lock_guard<std::mutex> lk(mu);
+    idle.push_back(w);
+  }
+  void submit(Worker* w, std::function<void()> j) {
+    {
+      std::lock_guard<std::mutex> lk(w->m);
+      w->job = std::move(j);
+      w->has_job = true;
+    }
+    w->cv.notify_one();
+  }
+};
+WorkerPool& worker_pool();  // capi.hip
+
+// f() on a pool worker while the caller does something else; get() waits and rethrows.  Like the future of std::async, the
+// destructor waits (the task may refer to the caller's frame).  Without a thread to run on, f() runs here and now.
+template <class R> class PoolFuture {
+  struct State {
+    std::mutex m;
+    std::condition_variable cv;
+    bool done = false;
+    R value{};
+    std::exception_ptr err;
+  };
+  std::shared_ptr<State> st;
+  void wait() {
+    std::unique_lock<std::mutex> lk(st->m);
+    st->cv.wait(lk, [this] { return st->done; });
+  }
+
+ public:
+  PoolFuture() = default;
+  template <class F> explicit PoolFuture(F f) : st(std::make_shared<State>()) {
+    std::shared_ptr<State> s = st;
+    auto body = [s, f]() mutable {
+      try {
+        s->value = f();
+      } catch (...) {
+        s->err = std::current_exception();
+      }
+    };
+    WorkerPool& wp = worker_pool();
+    Worker* w = nullptr;
+    try {
+      w = wp.acquire();
+      wp.submit(w, [s, body, w, &wp]() mutable {
+        body();
+        wp.release(w);
+        std::lock_guard<std::mutex> lk(s->m);
+        s->done = true;
+        s->cv.notify_all();
+      });
+    } catch (const std::exception&) {  // no thread (or no memory for the job): compute inline
+      if (w) wp.release(w);
+      body();
+      st->done = true;
+    }
+  }
+  PoolFuture(const PoolFuture&) = delete;
+  PoolFuture& operator=(const PoolFuture&) = delete;
+  PoolFuture(PoolFuture&& o) noexcept : st(std::move(o.st)) {}
+  PoolFuture& operator=(PoolFuture&& o) noexcept {
+    if (st) wait();
+    st = std::move(o.st);
+    return *this;
+  }
+  ~PoolFuture() {
+    if (st) wait();
+  }
+  bool valid() const { return st != nullptr; }
+  R get() {
+    wait();
+    std::shared_ptr<State> s = std::move(st);
+    if (s->err) std::rethrow_exception(s->err);
+    return std::move(s->value);
+  }
+};
+
 // conversion, no validation (the slice cache adding window tables to a key it holds)
 static constexpr uint32_t NMX_BASES_INTERNAL = 1u << 30;
 struct Global {
