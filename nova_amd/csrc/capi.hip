@@ -1672,6 +1672,7 @@ int nmx_set_option(const char* name, uint32_t value) {
       SC.table_after_uses = value;
     } else if (n == "max_table_mib") G.max_table_bytes.store((size_t)value << 20);  // 0: no limit but the HBM itself
     else if (n == "horner_top") G.horner_top = value;
+    else if (n == "horner_window") G.horner_window = value ? value : 64u;
     else if (n == "seg_heavy_above") G.seg_heavy_above = value > 63u ? 63u : value;
     else throw Fail{NMX_E_ARG, "unknown option name"};
   });

@@ -348,6 +348,249 @@ template <int FID, uint32_t K> struct HornerWalkFn {
   }
 };
 
+// ----------------------------------------------------------------------------------------------------
+// Single-pass suffix Horner (round 3, second half): ONE kernel reads every coefficient once and writes every result once
+// (64 B per coefficient, all of it in whole 1 KiB wave transactions), with the carries handed from tile to tile by a
+// decoupled look-back instead of a recursion of launches.
+//
+//   tile    = 512 coefficients, owned by ONE wave (no block barrier anywhere): lane l holds coefficients 8l .. 8l+7 in
+//             registers.  The 16 KiB arrive as 16 coalesced 16-byte loads per lane and are transposed through 8.5 KiB of LDS
+//             per wave in two halves (row stride 272 B: conflict-free both ways); results leave the same way.
+//   local   : head_l = sum_k f[8l+k] u^k (8 dependent products), H_l = u^(8l) head_l (per-lane constant U_l), then a suffix
+//             SUM over the lanes -- additions, not products, because every term already carries its power of u:
+//             S_l = sum_{m >= l} H_m.  S_0 is the tile's aggregate  A = sum_k f[k] u^k  (k tile-local).
+//   carry   : the suffix value at the tile's end,  C = out[first element of the next tile], from the tiles behind:
+//             lane m looks at tile + 1 + m; tiles publish A first (status 1) and I = A + u^512 C once they know C
+//             (status 2):  C = sum_{m < j} u^(512 m) A_(tile+1+m) + u^(512 j) I_(tile+1+j)  for the first j with an inclusive
+//             value -- one product per lane with the per-lane constant W_m and a wave sum.  Tiles are numbered against the
+//             dispatch order (block 0 owns the LAST tile), so a wave only ever waits for waves dispatched before it.
+//   walk    : lane l re-walks its chunk from  c_l = u^(-8(l+1)) (S_(l+1) + u^512 C)  (per-lane constant V_l) and stores
+//             canonical values.
+// 2.5 products per coefficient (8 + 1 + 1 + 8 per lane, + 2 per wave-tile for the look-back) against 2 + recursion for the
+// two-pass kernels above, but no partial-line traffic and no dependent launches.  u = 0 is a copy (host side); the per-lane
+// constants come from a one-block kernel (k_horner_tables) that also clears the tile states.
+// Bounds (p(1 + ab/127) for a product of values < ap, < bp): head < 2.02p, H < 1.02p, S < 65.1p, W A < 1.52p, W I < 1.53p,
+// C < 97.7p (one window of 64) -- reduced to < 3.6p per further window --, u^512 C < 1.77p, S + u^512 C < 66.9p (published
+// raw as I), c_l < 1.53p; every sum is normalised before it is multiplied (limbs < 2^30 in, < 2^29 out).
+static constexpr uint32_t kScanTile = 512, kScanMin = 1024;
+static constexpr uint32_t kScanTblU = 0, kScanTblV = 64, kScanTblW = 128, kScanTblN = 193;  // W_0 .. W_64
+template <int FID> struct HornerScanArgs {
+  const uint32_t* f;
+  uint32_t* out;
+  const uint32_t* tbl;  // kScanTblN entries of 9 raw limbs (canonical internal residues)
+  uint32_t* status;     // [ntiles] 0 nothing, 1 aggregate, 2 inclusive
+  uint32_t* agg;        // [ntiles][9] raw limbs
+  uint32_t* inc;        // [ntiles][9]
+  Fp<FID> u;
+  uint32_t n, ntiles;
+  uint32_t window;  // tiles per look-back round, 1 .. 64 (64 in production; smaller values only to test the multi-round path)
+};
+template <int FID> struct HornerTblArgs {
+  uint32_t* tbl;
+  uint32_t* status;
+  Fp<FID> u8, v8, uT;  // u^8, u^-8, u^512 (internal, canonical)
+  uint32_t ntiles;
+};
+template <int FID> __global__ __launch_bounds__(256) void k_horner_tables(HornerTblArgs<FID> a) {
+  using F = Fp<FID>;
+  const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+  if (g < a.ntiles) a.status[g] = 0;
+  if (blockIdx.x != 0 || threadIdx.x >= kScanTblN) return;
+  const uint32_t t = threadIdx.x;
+  const F base = t < kScanTblV ? a.u8 : (t < kScanTblW ? a.v8 : a.uT);
+  const uint32_t e = t < kScanTblV ? t : (t < kScanTblW ? t - kScanTblV + 1 : t - kScanTblW);  // <= 64
+  F acc = F::one();
+  for (int b = 6; b >= 0; b--) {
+    acc = acc.sqr();
+    const F m = acc * base;
+    if ((e >> b) & 1u) acc = m;
+  }
+  acc = acc.canon();
+#pragma unroll
+  for (int i = 0; i < 9; i++) a.tbl[9 * t + i] = acc.l[i];
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int FID> __device__ __forceinline__ Fp<FID> fp_ld_limbs(const uint32_t* p) {
+  Fp<FID> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = p[i];
+  return r;
+}
+// value of lane + d (zero past the wave's end)
+template <int FID> __device__ __forceinline__ Fp<FID> fp_from_above(const Fp<FID>& x, uint32_t d, uint32_t lane) {
+  Fp<FID> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    const uint32_t v = (uint32_t)__shfl_down((int)x.l[i], d, 64);
+    r.l[i] = lane + d < 64u ? v : 0u;
+  }
+  return r;
+}
+// S_l = sum_{m >= l} x_m, normalised after every step (64 values of < 2^29-limbs stay far below the 32-bit limb)
+template <int FID> __device__ __forceinline__ Fp<FID> wave_suffix_sum(Fp<FID> x, uint32_t lane) {
+#pragma unroll
+  for (uint32_t d = 1; d < 64; d <<= 1) x = (x + fp_from_above<FID>(x, d, lane)).norm();
+  return x;
+}
+template <int FID> __device__ __forceinline__ Fp<FID> wave_bcast0(const Fp<FID>& x) {
+  Fp<FID> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)x.l[i]);
+  return r;
+}
+// LDS hand-over inside one wave: LDS instructions of a wave execute in order, the compiler must not move them across
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+#endif
+
+template <int FID> __global__ __launch_bounds__(256) void k_horner_scan(HornerScanArgs<FID> a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  using F = Fp<FID>;
+  __shared__ uint4 lds_all[4][32 * 17];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t r = blockIdx.x * 4u + wave;  // position in dispatch order
+  if (r >= a.ntiles) return;
+  const uint32_t tile = a.ntiles - 1u - r;
+  uint4* my = lds_all[wave];
+  const size_t e0 = (size_t)tile * kScanTile;                    // first element of the tile
+  const uint4* src = (const uint4*)a.f + 2 * e0;
+  uint4* dst = (uint4*)a.out + 2 * e0;
+  const uint32_t left = a.n - e0 < kScanTile ? (uint32_t)(a.n - e0) : kScanTile;  // elements of this tile
+
+  // ---- load + transpose: w[k] = words of coefficient 8 lane + k
+  uint32_t w[8][8];
+#pragma unroll
+  for (uint32_t p = 0; p < 2; p++) {
+    uint4 v[8];
+#pragma unroll
+    for (uint32_t qq = 0; qq < 8; qq++) {
+      const uint32_t unit = (8u * p + qq) * 64u + lane;  // 16-byte unit of the tile
+      v[qq] = (unit >> 1) < left ? src[unit] : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (uint32_t qq = 0; qq < 8; qq++) my[(4u * qq + (lane >> 4)) * 17u + (lane & 15u)] = v[qq];
+    wave_lds_sync();
+    if ((lane >> 5) == p) {
+#pragma unroll
+      for (uint32_t t = 0; t < 16; t++) {
+        const uint4 x = my[(lane & 31u) * 17u + t];
+        w[t >> 1][(t & 1u) * 4u + 0] = x.x;
+        w[t >> 1][(t & 1u) * 4u + 1] = x.y;
+        w[t >> 1][(t & 1u) * 4u + 2] = x.z;
+        w[t >> 1][(t & 1u) * 4u + 3] = x.w;
+      }
+    }
+    wave_lds_sync();
+  }
+
+  // ---- chunk head, scaled, suffix sum over the lanes
+  F t = F::zero();
+#pragma unroll
+  for (uint32_t k = 8; k-- > 0;) t = (F::from_words(w[k]) + a.u * t).norm();   // < 2.02 p
+  const F H = t * fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblU + lane));            // u^(8 lane) head
+  F S = wave_suffix_sum<FID>(H, lane);                                          // < 65.1 p
+
+  // ---- publish the aggregate, then look back for the carry
+  const bool last_tile = tile + 1u == a.ntiles;
+  if (!last_tile && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) a.agg[9 * (size_t)tile + i] = S.l[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_store(a.status + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // S waits in LDS (stride-64 words: conflict-free) while the look-back runs: the wave's registers are the 8 coefficients
+  uint32_t* park = (uint32_t*)my;
+#pragma unroll
+  for (int i = 0; i < 9; i++) park[i * 64 + lane] = S.l[i];
+  wave_lds_sync();
+  F TC = F::zero();  // u^512 C
+  if (!last_tile) {
+    F C = F::zero();
+    F scale = F::one();  // u^(512 * 64 * windows done)
+    bool first_window = true;
+    const uint64_t win_m = a.window >= 64u ? ~0ull : ((1ull << a.window) - 1ull);  // lanes that look
+    for (uint32_t base = tile + 1u;; base += a.window) {
+      const uint32_t tt = base + lane;
+      uint32_t st;
+      uint32_t fi;
+      for (;;) {
+        st = tt < a.ntiles ? __hip_atomic_load(a.status + tt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 2u;
+        const uint64_t inc_m = __ballot(st == 2u) & win_m, zero_m = __ballot(st == 0u) & win_m;
+        fi = inc_m ? (uint32_t)__ffsll((long long)inc_m) - 1u : 64u;
+        const uint64_t need = fi >= 63u ? ~0ull : ((2ull << fi) - 1ull);
+        if ((zero_m & need) == 0) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      F val = F::zero();
+      if (lane <= fi && lane < a.window && tt < a.ntiles) val = fp_ld_limbs<FID>((lane < fi ? a.agg : a.inc) + 9 * (size_t)tt);
+      const F term = val * fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblW + lane));  // u^(512 lane) * value   < 1.53 p
+      const F sum = wave_bcast0<FID>(wave_suffix_sum<FID>(term, lane));         // < 97.7 p
+      if (first_window) {
+        C = sum;
+      } else {
+        C = ((C * F::one()) + (scale * sum)).norm();  // < 1.77 p + 1.77 p
+      }
+      if (fi < 64u) break;
+      first_window = false;
+      scale = (scale * fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblW + a.window))).canon();
+    }
+    TC = fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblW + 1u)) * C;  // < 1.77 p
+    // the inclusive value of this tile for the tiles in front of it
+    if (tile != 0 && lane == 0) {
+      F S0;
+#pragma unroll
+      for (int i = 0; i < 9; i++) S0.l[i] = park[i * 64];
+      const F I = (S0 + TC).norm();
+#pragma unroll
+      for (int i = 0; i < 9; i++) a.inc[9 * (size_t)tile + i] = I.l[i];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __hip_atomic_store(a.status + tile, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  } else if (tile != 0 && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) a.inc[9 * (size_t)tile + i] = park[i * 64];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_store(a.status + tile, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+
+  // ---- walk the chunk from its carry
+  F S_next;  // S of lane + 1, zero for the last lane
+#pragma unroll
+  for (int i = 0; i < 9; i++) S_next.l[i] = lane < 63u ? park[i * 64 + lane + 1u] : 0u;
+  wave_lds_sync();  // the output transposition reuses the buffer
+  t = ((S_next + TC).norm()) * fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblV + lane));  // < 1.53 p
+#pragma unroll
+  for (uint32_t k = 8; k-- > 0;) {
+    t = (F::from_words(w[k]) + a.u * t).norm();
+    t.canon4().to_words(w[k]);
+  }
+
+  // ---- transpose back + store
+#pragma unroll
+  for (uint32_t p = 0; p < 2; p++) {
+    if ((lane >> 5) == p) {
+#pragma unroll
+      for (uint32_t t16 = 0; t16 < 16; t16++)
+        my[(lane & 31u) * 17u + t16] = make_uint4(w[t16 >> 1][(t16 & 1u) * 4u + 0], w[t16 >> 1][(t16 & 1u) * 4u + 1],
+                                                  w[t16 >> 1][(t16 & 1u) * 4u + 2], w[t16 >> 1][(t16 & 1u) * 4u + 3]);
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (uint32_t qq = 0; qq < 8; qq++) {
+      const uint32_t unit = (8u * p + qq) * 64u + lane;
+      const uint4 x = my[(4u * qq + (lane >> 4)) * 17u + (lane & 15u)];
+      if ((unit >> 1) < left) dst[unit] = x;
+    }
+    wave_lds_sync();
+  }
+#endif
+}
+
 // ---- host side ---------------------------------------------------------------------------------------
 // launch one functor over n lanes; with profiling on, bracket it with hipEvents on the context's stream
 struct VecIO;
@@ -642,10 +885,59 @@ template <int FID> static void horner_dev(Ctx& c, const uint32_t* f, uint32_t n,
   HornerFixFn<FID> ff{out, carries, pw_all + (size_t)lvl * (kHornerChunk + 1) * 8, n};
   be.launch(ff, n);
 }
+// the single-pass kernel (k_horner_scan): per-lane constants + tile states from one small launch, then the scan itself
+template <int FID> static void horner_scan_t(Ctx& c, const void* f, size_t n, const Fp<FID>& u0, bool dev, void* out) {
+  using F = Fp<FID>;
+  const uint32_t nt = (uint32_t)((n + kScanTile - 1) / kScanTile);
+  F u8 = u0;
+  for (int i = 0; i < 3; i++) u8 = u8.sqr().canon();
+  F uT = u8;
+  for (int i = 0; i < 6; i++) uT = uT.sqr().canon();
+  const F v8 = u8.inv();  // u != 0 (checked by the caller)
+  arena_reserve(c, HornerArena::pad(kScanTblN * 36) + HornerArena::pad((size_t)nt * 4) + 2 * HornerArena::pad((size_t)nt * 36) +
+                       (dev ? 0 : 2 * HornerArena::pad(n * 32)) + 256);
+  HornerArena ws{c.arena};
+  uint32_t* tbl = (uint32_t*)ws.take(kScanTblN * 36);
+  uint32_t* status = (uint32_t*)ws.take((size_t)nt * 4);
+  uint32_t* agg = (uint32_t*)ws.take((size_t)nt * 36);
+  uint32_t* inc = (uint32_t*)ws.take((size_t)nt * 36);
+  const uint32_t* df = (const uint32_t*)f;
+  uint32_t* dout = (uint32_t*)out;
+  if (!dev) {
+    void* a = ws.take(n * 32);
+    dout = (uint32_t*)ws.take(n * 32);
+    HIPCHK(hipMemcpyAsync(a, f, n * 32, hipMemcpyHostToDevice, c.stream));
+    df = (const uint32_t*)a;
+  }
+  const bool prof = G.profiling;
+  DeviceBackend be(c, false, prof);
+  be.mark("kernel");
+  HornerTblArgs<FID> ta{tbl, status, u8, v8, uT, nt};
+  be.launch_kernel(k_horner_tables<FID>, (nt + 255) / 256, 256, ta);
+  const uint32_t win = G.horner_window;
+  HornerScanArgs<FID> sa{df, dout, tbl, status, agg, inc, u0, (uint32_t)n, nt, win >= 1 && win <= 64 ? win : 64u};
+  be.launch_kernel(k_horner_scan<FID>, (nt + 3) / 4, 256, sa);
+  be.mark("end");
+  if (!dev) HIPCHK(hipMemcpyAsync(out, dout, n * 32, hipMemcpyDeviceToHost, c.stream));
+  stream_wait(c.stream);
+  if (prof && be.nmarks == 2) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
+    prof_store(&ms, 1);
+  }
+}
+
 template <int FID>
 static void horner_t(Ctx& c, const void* f, size_t n, const void* u, uint32_t flags, void* out) {
   using F = Fp<FID>;
   const bool dev = flags & NMX_SCALARS_DEVICE;
+  if (n >= kScanMin && n < (1ull << 32) && G.horner_top == 0) {
+    const F us = challenge<FID>(u, flags & NMX_SCALARS_MONT);
+    if (!us.is_zero_limbs()) {  // u = 0: out = f, left to the chunk kernels below
+      horner_scan_t<FID>(c, f, n, us, dev, out);
+      return;
+    }
+  }
 
   // per level: u_l = u^(16^l) and its powers 0..16 -- 16 host multiplications per level, at most 8 levels
   std::vector<F> u_lvl;

@@ -174,6 +174,48 @@ def test_horner_and_div_by_monomial(nmx, fid, n):
 
 
 @pytest.mark.parametrize("fid", range(4))
+@pytest.mark.parametrize("knob,value", [("horner_window", 1), ("horner_window", 3), ("horner_window", 7), ("horner_top", 8),
+                                        ("horner_top", 4), ("horner_top", 1)])
+def test_horner_variants(nmx, fid, knob, value):
+    """The single-pass scan (k_horner_scan) with 1 / 3 / 7 tiles per look-back round -- every tile then needs several
+    rounds, the path a 64-tile window takes only when no tile behind it has its inclusive value yet -- and the two-pass
+    kernels it replaced (horner_top 8 / 4 / 1), all against the oracle: tile boundaries (512), partial last tiles, edge values."""
+    from nova_amd import _lib
+    from nova_amd import fieldvec as fv
+    L = _lib.lib()
+    assert L.nmx_set_option(knob.encode(), value) == 0
+    try:
+        for n in (1024, 1025, 4097, 33 * 512, 65 * 512 + 9, 300003):
+            f = C.edge_vectors(fid, n, 5)
+            u = C.rand_vec(fid, 1, 6)
+            assert fv.suffix_horner(fid, f, u).tobytes() == cref.suffix_horner(fid, f, n, u), (knob, value, n)
+    finally:
+        assert L.nmx_set_option(knob.encode(), 64 if knob == "horner_window" else 0) == 0
+
+
+@pytest.mark.parametrize("fid", [0, 2])
+def test_horner_scan_many_tiles_and_repeat(nmx, fid):
+    """2^20 + 77 coefficients (2049 tiles) device resident, five calls in a row on the same context (the tile states are
+    cleared by every call) -- all equal to the oracle; and 5000 coefficients in the reference's Montgomery layout."""
+    import torch
+    from nova_amd import fieldvec as fv
+    p = C.FIELDS[fid]
+    Rm = 1 << 256
+    to_m = lambda v: C.vec([x * Rm % p for x in C.ints(v)])
+    from_m = lambda v: C.vec([x * pow(Rm, -1, p) % p for x in C.ints(v)])
+    g = C.edge_vectors(fid, 5000, 13)
+    v = C.rand_vec(fid, 1, 14)
+    assert from_m(fv.suffix_horner(fid, to_m(g), to_m(v), mont=True)).tobytes() == cref.suffix_horner(fid, g, 5000, v)
+    n = (1 << 20) + 77
+    f = C.rand_vec(fid, n, 11)
+    u = C.rand_vec(fid, 1, 12)
+    exp = cref.suffix_horner(fid, f, n, u)
+    d = torch.from_numpy(f.copy()).cuda()
+    for _ in range(5):
+        assert fv.suffix_horner(fid, d, u).cpu().numpy().tobytes() == exp
+
+
+@pytest.mark.parametrize("fid", range(4))
 @pytest.mark.parametrize("logn", [1, 6, 13, 18])
 def test_sumcheck_plain_sums(nmx, fid, logn):
     """compute_eval_points_{quad_prod, linear, quadratic, cubic} (sumcheck.rs:163-186, 353-443): host / device
