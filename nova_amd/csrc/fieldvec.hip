@@ -351,63 +351,77 @@ template <int FID, uint32_t K> struct HornerWalkFn {
 // ----------------------------------------------------------------------------------------------------
 // Single-pass suffix Horner (round 3, second half): ONE kernel reads every coefficient once and writes every result once
 // (64 B per coefficient, all of it in whole 1 KiB wave transactions), with the carries handed from tile to tile by a
-// decoupled look-back instead of a recursion of launches.
+// two-level decoupled look-back instead of a recursion of launches.
 //
 //   tile    = 512 coefficients, owned by ONE wave (no block barrier anywhere): lane l holds coefficients 8l .. 8l+7 in
 //             registers.  The 16 KiB arrive as 16 coalesced 16-byte loads per lane and are transposed through 8.5 KiB of LDS
 //             per wave in two halves (row stride 272 B: conflict-free both ways); results leave the same way.
 //   local   : head_l = sum_k f[8l+k] u^k (8 dependent products), H_l = u^(8l) head_l (per-lane constant U_l), then a suffix
 //             SUM over the lanes -- additions, not products, because every term already carries its power of u:
-//             S_l = sum_{m >= l} H_m.  S_0 is the tile's aggregate  A = sum_k f[k] u^k  (k tile-local).
-//   carry   : the suffix value at the tile's end,  C = out[first element of the next tile], from the tiles behind:
-//             lane m looks at tile + 1 + m; tiles publish A first (status 1) and I = A + u^512 C once they know C
-//             (status 2):  C = sum_{m < j} u^(512 m) A_(tile+1+m) + u^(512 j) I_(tile+1+j)  for the first j with an inclusive
-//             value -- one product per lane with the per-lane constant W_m and a wave sum.  Tiles are numbered against the
-//             dispatch order (block 0 owns the LAST tile), so a wave only ever waits for waves dispatched before it.
+//             S_l = sum_{m >= l} H_m.  S_0 is the tile's aggregate  A = sum_k f[k] u^k  (k tile-local), published at once.
+//   carry   : C = out[first element of the next tile], the suffix value at the tile's end.  Tiles form GROUPS of 64
+//             (32 768 coefficients).  Inside the group: C1 = sum_m u^(512 m) A_(tile+1+m) over the group's later tiles -- one
+//             product per lane with the per-lane constant W_m and a wave sum; those tiles were dispatched earlier and
+//             publish A before they wait for anything.  Across groups: the wave that draws a group's last ticket folds the 64
+//             aggregates into the group aggregate GA (status 1) and, once it knows the carry GC at the group's end, publishes
+//             the group's inclusive value GI = GA + u^32768 GC (status 2); every tile of group g gets GC by looking back over
+//             the groups behind it, lane m at group g + 1 + m:  GC = sum_{m < j} X_m GA_(g+1+m) + X_j GI_(g+1+j)  for the first j
+//             with an inclusive value (X_m = u^(32768 m)), further rounds of 64 groups if there is none.  Then
+//             C = C1 + u^(512 (63 - position in group)) GC.  (A first version looked back over TILES only: with ~3000 tiles
+//             in flight the nearest inclusive value was ~25 rounds of 64 away, each round a poll + 64 loads + product + wave sum,
+//             and the kernel was 3 x slower than the two-pass form from 2^20 on -- profiles/r03_fieldvec/horner_scan.txt.)
+//             Tiles are numbered against the dispatch order (block 0 owns the LAST tile), so a wave only ever waits for
+//             waves dispatched before it.
 //   walk    : lane l re-walks its chunk from  c_l = u^(-8(l+1)) (S_(l+1) + u^512 C)  (per-lane constant V_l) and stores
 //             canonical values.
-// 2.5 products per coefficient (8 + 1 + 1 + 8 per lane, + 2 per wave-tile for the look-back) against 2 + recursion for the
-// two-pass kernels above, but no partial-line traffic and no dependent launches.  u = 0 is a copy (host side); the per-lane
-// constants come from a one-block kernel (k_horner_tables) that also clears the tile states.
-// Bounds (p(1 + ab/127) for a product of values < ap, < bp): head < 2.02p, H < 1.02p, S < 65.1p, W A < 1.52p, W I < 1.53p,
-// C < 97.7p (one window of 64) -- reduced to < 3.6p per further window --, u^512 C < 1.77p, S + u^512 C < 66.9p (published
-// raw as I), c_l < 1.53p; every sum is normalised before it is multiplied (limbs < 2^30 in, < 2^29 out).
-static constexpr uint32_t kScanTile = 512, kScanMin = 1024;
-static constexpr uint32_t kScanTblU = 0, kScanTblV = 64, kScanTblW = 128, kScanTblN = 193;  // W_0 .. W_64
+// ~2.8 products per coefficient (8 + 1 + 1 + 8 per lane and 4-6 per wave-tile for the two look-backs) against 2 + recursion
+// for the two-pass kernels above, but no partial-line traffic and no dependent launches.  u = 0 is left to those kernels; the
+// per-lane constants come from a small kernel (k_horner_tables) that also clears the tile / group states.
+// Bounds (p(1 + ab/127) for a product of values < ap, < bp; input words may be any 256-bit value, < 5.3p): head < 7.4p,
+// H < 1.06p, S < 67.7p (published raw as A), W A < 1.54p, C1 < 96.6p, GA < 98.1p reduced to < 1.78p before it is published,
+// X GA < 1.02p, GI < 3.6p, X GI < 1.03p, GC < 66p (one round; reduced to < 3.6p per further round), W GC < 1.53p, C < 98.2p,
+// u^512 C < 1.78p, S + u^512 C < 69.5p, c_l < 1.55p; every sum is normalised before it is multiplied (limbs < 2^30 in,
+// < 2^29 out).
+static constexpr uint32_t kScanTile = 512, kScanMin = 1024, kScanGroup = 64;
+static constexpr uint32_t kScanTblU = 0, kScanTblV = 64, kScanTblW = 128, kScanTblX = 193, kScanTblP = 258, kScanTblN = 264;  // W_0..W_64, X_0..X_64, u^2..u^7
 template <int FID> struct HornerScanArgs {
   const uint32_t* f;
   uint32_t* out;
   const uint32_t* tbl;  // kScanTblN entries of 9 raw limbs (canonical internal residues)
-  uint32_t* status;     // [ntiles] 0 nothing, 1 aggregate, 2 inclusive
+  uint32_t* status;     // [ntiles] 0 nothing, 1 aggregate published
+  uint32_t* gcnt;       // [ngroups] tickets drawn
+  uint32_t* gstatus;    // [ngroups] 0 nothing, 1 aggregate, 2 inclusive
   uint32_t* agg;        // [ntiles][9] raw limbs
-  uint32_t* inc;        // [ntiles][9]
+  uint32_t* gagg;       // [ngroups][9]
+  uint32_t* ginc;       // [ngroups][9]
   Fp<FID> u;
-  uint32_t n, ntiles;
-  uint32_t window;  // tiles per look-back round, 1 .. 64 (64 in production; smaller values only to test the multi-round path)
+  uint32_t n, ntiles, ngroups;
+  uint32_t window;  // groups per look-back round, 1 .. 64 (64 in production; smaller values only to test the multi-round path)
 };
 template <int FID> struct HornerTblArgs {
   uint32_t* tbl;
-  uint32_t* status;
-  Fp<FID> u8, v8, uT;  // u^8, u^-8, u^512 (internal, canonical)
-  uint32_t ntiles;
+  uint32_t* flags;  // status | gcnt | gstatus, contiguous
+  Fp<FID> u1, u8, v8, uT, uG;  // u, u^8, u^-8, u^512, u^32768 (internal, canonical)
+  uint32_t nflags;
 };
 template <int FID> __global__ __launch_bounds__(256) void k_horner_tables(HornerTblArgs<FID> a) {
   using F = Fp<FID>;
   const uint32_t g = blockIdx.x * 256u + threadIdx.x;
-  if (g < a.ntiles) a.status[g] = 0;
-  if (blockIdx.x != 0 || threadIdx.x >= kScanTblN) return;
-  const uint32_t t = threadIdx.x;
-  const F base = t < kScanTblV ? a.u8 : (t < kScanTblW ? a.v8 : a.uT);
-  const uint32_t e = t < kScanTblV ? t : (t < kScanTblW ? t - kScanTblV + 1 : t - kScanTblW);  // <= 64
-  F acc = F::one();
-  for (int b = 6; b >= 0; b--) {
-    acc = acc.sqr();
-    const F m = acc * base;
-    if ((e >> b) & 1u) acc = m;
-  }
-  acc = acc.canon();
+  if (g < a.nflags) a.flags[g] = 0;
+  if (blockIdx.x != 0) return;
+  for (uint32_t t = threadIdx.x; t < kScanTblN; t += 256u) {
+    const F base = t < kScanTblV ? a.u8 : (t < kScanTblW ? a.v8 : (t < kScanTblX ? a.uT : (t < kScanTblP ? a.uG : a.u1)));
+    const uint32_t e = t < kScanTblV ? t : (t < kScanTblW ? t - kScanTblV + 1 : (t < kScanTblX ? t - kScanTblW : (t < kScanTblP ? t - kScanTblX : t - kScanTblP + 2)));  // <= 64
+    F acc = F::one();
+    for (int b = 6; b >= 0; b--) {
+      acc = acc.sqr();
+      const F m = acc * base;
+      if ((e >> b) & 1u) acc = m;
+    }
+    acc = acc.canon();
 #pragma unroll
-  for (int i = 0; i < 9; i++) a.tbl[9 * t + i] = acc.l[i];
+    for (int i = 0; i < 9; i++) a.tbl[9 * t + i] = acc.l[i];
+  }
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -416,6 +430,10 @@ template <int FID> __device__ __forceinline__ Fp<FID> fp_ld_limbs(const uint32_t
 #pragma unroll
   for (int i = 0; i < 9; i++) r.l[i] = p[i];
   return r;
+}
+template <int FID> __device__ __forceinline__ void fp_st_limbs(uint32_t* p, const Fp<FID>& v) {
+#pragma unroll
+  for (int i = 0; i < 9; i++) p[i] = v.l[i];
 }
 // value of lane + d (zero past the wave's end)
 template <int FID> __device__ __forceinline__ Fp<FID> fp_from_above(const Fp<FID>& x, uint32_t d, uint32_t lane) {
@@ -433,6 +451,17 @@ template <int FID> __device__ __forceinline__ Fp<FID> wave_suffix_sum(Fp<FID> x,
   for (uint32_t d = 1; d < 64; d <<= 1) x = (x + fp_from_above<FID>(x, d, lane)).norm();
   return x;
 }
+// lane 0 <- the sum of all 64 lanes (the other lanes end with partial sums or wrapped garbage: a lane past the wave's end reads
+// itself).  Normalised every second step: limbs < 2^29 -> < 2^31 -> norm.
+template <int FID> __device__ __forceinline__ Fp<FID> wave_total(Fp<FID> x) {
+#pragma unroll
+  for (uint32_t d = 32; d >= 1; d >>= 1) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) x.l[i] += (uint32_t)__shfl_down((int)x.l[i], d, 64);
+    if (d == 16 || d == 4 || d == 1) x = x.norm();
+  }
+  return x;
+}
 template <int FID> __device__ __forceinline__ Fp<FID> wave_bcast0(const Fp<FID>& x) {
   Fp<FID> r;
 #pragma unroll
@@ -445,6 +474,30 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// Hand-over between waves of different XCDs WITHOUT agent-scope fences: a release fence is an L2 write-back and an acquire
+// fence an L2 invalidate, of the whole L2 -- with every wave streaming 16 KiB of results through it, 3-5 of them per tile
+// serialised the kernel (0.53 ms at 2^22, profiles/r03_fieldvec/horner_scan.txt).  The few words that cross (aggregates,
+// flags, tickets) are agent-scope relaxed atomics instead -- sc1 accesses that bypass the non-coherent L2 -- ordered by
+// waiting for the data stores' acknowledgement before the flag store, and by issuing the data loads only after the flag
+// has been seen.
+template <int FID> __device__ __forceinline__ void desc_store(uint32_t* p, const Fp<FID>& v) {
+#pragma unroll
+  for (int i = 0; i < 9; i++) __hip_atomic_store(p + i, v.l[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int FID> __device__ __forceinline__ Fp<FID> desc_load(const uint32_t* p) {
+  Fp<FID> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return r;
+}
+__device__ __forceinline__ void publish_flag(uint32_t* flag, uint32_t v) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t poll_flag(const uint32_t* flag) {
+  return __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void seen_barrier() { asm volatile("" ::: "memory"); }
 #endif
 
 template <int FID> __global__ __launch_bounds__(256) void k_horner_scan(HornerScanArgs<FID> a) {
@@ -455,6 +508,9 @@ template <int FID> __global__ __launch_bounds__(256) void k_horner_scan(HornerSc
   const uint32_t r = blockIdx.x * 4u + wave;  // position in dispatch order
   if (r >= a.ntiles) return;
   const uint32_t tile = a.ntiles - 1u - r;
+  const uint32_t grp = tile / kScanGroup, pos = tile % kScanGroup;
+  const uint32_t gtiles = a.ntiles - grp * kScanGroup < kScanGroup ? a.ntiles - grp * kScanGroup : kScanGroup;
+  const bool last_group = grp + 1u == a.ngroups;
   uint4* my = lds_all[wave];
   const size_t e0 = (size_t)tile * kScanTile;                    // first element of the tile
   const uint4* src = (const uint4*)a.f + 2 * e0;
@@ -488,82 +544,112 @@ template <int FID> __global__ __launch_bounds__(256) void k_horner_scan(HornerSc
   }
 
   // ---- chunk head, scaled, suffix sum over the lanes
-  F t = F::zero();
-#pragma unroll
-  for (uint32_t k = 8; k-- > 0;) t = (F::from_words(w[k]) + a.u * t).norm();   // < 2.02 p
-  const F H = t * fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblU + lane));            // u^(8 lane) head
-  F S = wave_suffix_sum<FID>(H, lane);                                          // < 65.1 p
-
-  // ---- publish the aggregate, then look back for the carry
-  const bool last_tile = tile + 1u == a.ntiles;
-  if (!last_tile && lane == 0) {
-#pragma unroll
-    for (int i = 0; i < 9; i++) a.agg[9 * (size_t)tile + i] = S.l[i];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __hip_atomic_store(a.status + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // head = f0 + (f1 u + f2 u^2 + f3 u^3 + f4 u^4) + (f5 u^5 + f6 u^6 + f7 u^7): seven products, TWO reductions, no dependent chain
+  // (Fp::dot; the eight-step Horner form is 8 x 162 multiply-adds and 8 reductions, this one 7 x 81 + 2 x 81)
+  F t;
+  {
+    const F fa[4] = {F::from_words(w[1]), F::from_words(w[2]), F::from_words(w[3]), F::from_words(w[4])};
+    const F pa[4] = {a.u, fp_ld_limbs<FID>(a.tbl + 9u * kScanTblP), fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblP + 1u)),
+                     fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblP + 2u))};
+    const F fb[3] = {F::from_words(w[5]), F::from_words(w[6]), F::from_words(w[7])};
+    const F pb[3] = {fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblP + 3u)), fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblP + 4u)),
+                     fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblP + 5u))};
+    t = (F::from_words(w[0]) + F::template dot<4, true>(fa, pa) + F::template dot<3, true>(fb, pb)).norm();   // < 3.06 p (7.4 p for words >= p)
   }
-  // S waits in LDS (stride-64 words: conflict-free) while the look-back runs: the wave's registers are the 8 coefficients
-  uint32_t* park = (uint32_t*)my;
+  {
+    const F H = t * fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblU + lane));          // u^(8 lane) head   < 1.06 p
+    const F S = wave_suffix_sum<FID>(H, lane);                                  // < 67.7 p
+    // the tile's aggregate, at once; S itself waits in LDS (stride-64 words: conflict-free) while the look-backs run
+    if (lane == 0) {
+      desc_store<FID>(a.agg + 9 * (size_t)tile, S);
+      publish_flag(a.status + tile, 1u);
+    }
+    uint32_t* park = (uint32_t*)my;
 #pragma unroll
-  for (int i = 0; i < 9; i++) park[i * 64 + lane] = S.l[i];
-  wave_lds_sync();
-  F TC = F::zero();  // u^512 C
-  if (!last_tile) {
-    F C = F::zero();
-    F scale = F::one();  // u^(512 * 64 * windows done)
-    bool first_window = true;
+    for (int i = 0; i < 9; i++) park[i * 64 + lane] = S.l[i];
+    wave_lds_sync();
+  }
+
+  // ---- a ticket of the group; the wave that draws the last one folds the group's aggregates
+  uint32_t ticket = 0;
+  if (lane == 0) ticket = __hip_atomic_fetch_add(a.gcnt + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // after the aggregate's acknowledgement (publish_flag)
+  ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
+  const bool closer = ticket + 1u == gtiles;
+  seen_barrier();
+  if (closer) {
+    F val = F::zero();
+    if (lane < gtiles) val = desc_load<FID>(a.agg + 9 * ((size_t)grp * kScanGroup + lane));
+    const F term = val * fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblW + lane));      // < 1.52 p
+    const F GA = wave_total<FID>(term) * F::one();                                 // lane 0: the group's aggregate, < 1.78 p
+    if (lane == 0) {
+      desc_store<FID>((last_group ? a.ginc : a.gagg) + 9 * (size_t)grp, GA);
+      publish_flag(a.gstatus + grp, last_group ? 2u : 1u);
+    }
+  }
+
+  // ---- inside the group: the aggregates of its later tiles
+  F C = F::zero();
+  const uint32_t nlook = gtiles - 1u - pos;
+  if (nlook) {
+    for (;;) {
+      const uint32_t st = lane < nlook ? poll_flag(a.status + tile + 1u + lane) : 1u;
+      if (__ballot(st == 0u) == 0) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    seen_barrier();
+    F val = F::zero();
+    if (lane < nlook) val = desc_load<FID>(a.agg + 9 * ((size_t)tile + 1u + lane));
+    const F term = val * fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblW + lane));
+    C = wave_bcast0<FID>(wave_total<FID>(term));                                    // < 96.6 p
+  }
+
+  // ---- across groups: the carry at the group's end
+  if (!last_group) {
+    F GC = F::zero();
+    F scale = F::one();  // u^(32768 * groups skipped)
+    bool first_round = true;
     const uint64_t win_m = a.window >= 64u ? ~0ull : ((1ull << a.window) - 1ull);  // lanes that look
-    for (uint32_t base = tile + 1u;; base += a.window) {
-      const uint32_t tt = base + lane;
-      uint32_t st;
+    for (uint32_t base = grp + 1u;; base += a.window) {
+      const uint32_t gg = base + lane;
       uint32_t fi;
       for (;;) {
-        st = tt < a.ntiles ? __hip_atomic_load(a.status + tt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 2u;
+        const uint32_t st = gg < a.ngroups ? poll_flag(a.gstatus + gg) : 2u;
         const uint64_t inc_m = __ballot(st == 2u) & win_m, zero_m = __ballot(st == 0u) & win_m;
         fi = inc_m ? (uint32_t)__ffsll((long long)inc_m) - 1u : 64u;
         const uint64_t need = fi >= 63u ? ~0ull : ((2ull << fi) - 1ull);
         if ((zero_m & need) == 0) break;
         __builtin_amdgcn_s_sleep(2);
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      seen_barrier();
       F val = F::zero();
-      if (lane <= fi && lane < a.window && tt < a.ntiles) val = fp_ld_limbs<FID>((lane < fi ? a.agg : a.inc) + 9 * (size_t)tt);
-      const F term = val * fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblW + lane));  // u^(512 lane) * value   < 1.53 p
-      const F sum = wave_bcast0<FID>(wave_suffix_sum<FID>(term, lane));         // < 97.7 p
-      if (first_window) {
-        C = sum;
-      } else {
-        C = ((C * F::one()) + (scale * sum)).norm();  // < 1.77 p + 1.77 p
-      }
+      if (lane <= fi && lane < a.window && gg < a.ngroups) val = desc_load<FID>((lane < fi ? a.gagg : a.ginc) + 9 * (size_t)gg);
+      const F term = val * fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblX + lane));   // u^(32768 lane) * value   < 1.03 p
+      const F sum = wave_bcast0<FID>(wave_total<FID>(term));                     // < 66 p
+      if (first_round) GC = sum;
+      else GC = ((GC * F::one()) + (scale * sum)).norm();                        // < 1.77 p + 1.77 p
       if (fi < 64u) break;
-      first_window = false;
-      scale = (scale * fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblW + a.window))).canon();
+      first_round = false;
+      scale = (scale * fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblX + a.window))).canon();
     }
-    TC = fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblW + 1u)) * C;  // < 1.77 p
-    // the inclusive value of this tile for the tiles in front of it
-    if (tile != 0 && lane == 0) {
-      F S0;
-#pragma unroll
-      for (int i = 0; i < 9; i++) S0.l[i] = park[i * 64];
-      const F I = (S0 + TC).norm();
-#pragma unroll
-      for (int i = 0; i < 9; i++) a.inc[9 * (size_t)tile + i] = I.l[i];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      __hip_atomic_store(a.status + tile, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (only the last group can be short: the distance from this tile's end to the group's end is 63 - pos tiles)
+    C = (C + fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblW + (kScanGroup - 1u - pos))) * GC).norm();   // < 99.3 p
+    if (closer && lane == 0) {  // the group's inclusive value for the groups in front of it
+      const F GI = (desc_load<FID>(a.gagg + 9 * (size_t)grp) + fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblX + 1u)) * GC).norm();  // < 3.6 p
+      desc_store<FID>(a.ginc + 9 * (size_t)grp, GI);
+      publish_flag(a.gstatus + grp, 2u);
     }
-  } else if (tile != 0 && lane == 0) {
-#pragma unroll
-    for (int i = 0; i < 9; i++) a.inc[9 * (size_t)tile + i] = park[i * 64];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __hip_atomic_store(a.status + tile, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  const F TC = fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblW + 1u)) * C;  // u^512 C  < 1.79 p
 
   // ---- walk the chunk from its carry
-  F S_next;  // S of lane + 1, zero for the last lane
+  {
+    const uint32_t* park = (const uint32_t*)my;
+    F S_next;  // S of lane + 1, zero for the last lane
 #pragma unroll
-  for (int i = 0; i < 9; i++) S_next.l[i] = lane < 63u ? park[i * 64 + lane + 1u] : 0u;
-  wave_lds_sync();  // the output transposition reuses the buffer
-  t = ((S_next + TC).norm()) * fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblV + lane));  // < 1.53 p
+    for (int i = 0; i < 9; i++) S_next.l[i] = lane < 63u ? park[i * 64 + lane + 1u] : 0u;
+    wave_lds_sync();  // the output transposition reuses the buffer
+    t = ((S_next + TC).norm()) * fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblV + lane));  // < 1.53 p
+  }
 #pragma unroll
   for (uint32_t k = 8; k-- > 0;) {
     t = (F::from_words(w[k]) + a.u * t).norm();
@@ -888,19 +974,23 @@ template <int FID> static void horner_dev(Ctx& c, const uint32_t* f, uint32_t n,
 // the single-pass kernel (k_horner_scan): per-lane constants + tile states from one small launch, then the scan itself
 template <int FID> static void horner_scan_t(Ctx& c, const void* f, size_t n, const Fp<FID>& u0, bool dev, void* out) {
   using F = Fp<FID>;
-  const uint32_t nt = (uint32_t)((n + kScanTile - 1) / kScanTile);
+  const uint32_t nt = (uint32_t)((n + kScanTile - 1) / kScanTile), ng = (nt + kScanGroup - 1) / kScanGroup;
   F u8 = u0;
   for (int i = 0; i < 3; i++) u8 = u8.sqr().canon();
   F uT = u8;
   for (int i = 0; i < 6; i++) uT = uT.sqr().canon();
+  F uG = uT;
+  for (int i = 0; i < 6; i++) uG = uG.sqr().canon();
   const F v8 = u8.inv();  // u != 0 (checked by the caller)
-  arena_reserve(c, HornerArena::pad(kScanTblN * 36) + HornerArena::pad((size_t)nt * 4) + 2 * HornerArena::pad((size_t)nt * 36) +
-                       (dev ? 0 : 2 * HornerArena::pad(n * 32)) + 256);
+  const size_t nflags = (size_t)nt + 2 * (size_t)ng;
+  arena_reserve(c, HornerArena::pad(kScanTblN * 36) + HornerArena::pad(nflags * 4) + HornerArena::pad((size_t)nt * 36) +
+                       2 * HornerArena::pad((size_t)ng * 36) + (dev ? 0 : 2 * HornerArena::pad(n * 32)) + 256);
   HornerArena ws{c.arena};
   uint32_t* tbl = (uint32_t*)ws.take(kScanTblN * 36);
-  uint32_t* status = (uint32_t*)ws.take((size_t)nt * 4);
+  uint32_t* flags = (uint32_t*)ws.take(nflags * 4);
   uint32_t* agg = (uint32_t*)ws.take((size_t)nt * 36);
-  uint32_t* inc = (uint32_t*)ws.take((size_t)nt * 36);
+  uint32_t* gagg = (uint32_t*)ws.take((size_t)ng * 36);
+  uint32_t* ginc = (uint32_t*)ws.take((size_t)ng * 36);
   const uint32_t* df = (const uint32_t*)f;
   uint32_t* dout = (uint32_t*)out;
   if (!dev) {
@@ -912,10 +1002,11 @@ template <int FID> static void horner_scan_t(Ctx& c, const void* f, size_t n, co
   const bool prof = G.profiling;
   DeviceBackend be(c, false, prof);
   be.mark("kernel");
-  HornerTblArgs<FID> ta{tbl, status, u8, v8, uT, nt};
-  be.launch_kernel(k_horner_tables<FID>, (nt + 255) / 256, 256, ta);
+  HornerTblArgs<FID> ta{tbl, flags, u0, u8, v8, uT, uG, (uint32_t)nflags};
+  be.launch_kernel(k_horner_tables<FID>, (uint32_t)((nflags + 255) / 256), 256, ta);
   const uint32_t win = G.horner_window;
-  HornerScanArgs<FID> sa{df, dout, tbl, status, agg, inc, u0, (uint32_t)n, nt, win >= 1 && win <= 64 ? win : 64u};
+  HornerScanArgs<FID> sa{df, dout, tbl, flags, flags + nt, flags + nt + ng, agg, gagg, ginc, u0, (uint32_t)n, nt, ng,
+                         win >= 1 && win <= 64 ? win : 64u};
   be.launch_kernel(k_horner_scan<FID>, (nt + 3) / 4, 256, sa);
   be.mark("end");
   if (!dev) HIPCHK(hipMemcpyAsync(out, dout, n * 32, hipMemcpyDeviceToHost, c.stream));
