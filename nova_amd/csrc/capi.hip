@@ -145,6 +145,7 @@ static void ensure_init() {
   if (const char* t = getenv("NMX_TUNE_HIST_GRID")) G.hist_grid = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_SYNC_SPIN_US")) G.sync_spin_us = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_HORNER_TOP")) G.horner_top = (uint32_t)atoi(t);
+  if (const char* t = getenv("NMX_TUNE_HORNER_SUB")) G.horner_sub = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_SEG_HEAVY_ABOVE")) G.seg_heavy_above = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_ACCUM_PF")) G.accum_prefetch = (uint32_t)atoi(t);
   HIPCHK(hipSetDevice(dev));
@@ -1673,6 +1674,7 @@ int nmx_set_option(const char* name, uint32_t value) {
     } else if (n == "max_table_mib") G.max_table_bytes.store((size_t)value << 20);  // 0: no limit but the HBM itself
     else if (n == "horner_top") G.horner_top = value;
     else if (n == "horner_window") G.horner_window = value ? value : 64u;
+    else if (n == "horner_sub") G.horner_sub = value;
     else if (n == "seg_heavy_above") G.seg_heavy_above = value > 63u ? 63u : value;
     else throw Fail{NMX_E_ARG, "unknown option name"};
   });

@@ -382,8 +382,8 @@ template <int FID, uint32_t K> struct HornerWalkFn {
 // X GA < 1.02p, GI < 3.6p, X GI < 1.03p, GC < 66p (one round; reduced to < 3.6p per further round), W GC < 1.53p, C < 98.2p,
 // u^512 C < 1.78p, S + u^512 C < 69.5p, c_l < 1.55p; every sum is normalised before it is multiplied (limbs < 2^30 in,
 // < 2^29 out).
-static constexpr uint32_t kScanTile = 512, kScanMin = 1024, kScanGroup = 64;
-static constexpr uint32_t kScanTblU = 0, kScanTblV = 64, kScanTblW = 128, kScanTblX = 193, kScanTblP = 258, kScanTblN = 264;  // W_0..W_64, X_0..X_64, u^2..u^7
+static constexpr uint32_t kScanSub = 512, kScanMin = 1024, kScanGroup = 64;
+static constexpr uint32_t kScanTblU = 0, kScanTblV = 64, kScanTblW = 128, kScanTblX = 193, kScanTblP = 258, kScanTblS = 264, kScanTblN = 268;  // W_0..W_64, X_0..X_64, u^2..u^7, u^(512 j) j < 4
 template <int FID> struct HornerScanArgs {
   const uint32_t* f;
   uint32_t* out;
@@ -401,7 +401,7 @@ template <int FID> struct HornerScanArgs {
 template <int FID> struct HornerTblArgs {
   uint32_t* tbl;
   uint32_t* flags;  // status | gcnt | gstatus, contiguous
-  Fp<FID> u1, u8, v8, uT, uG;  // u, u^8, u^-8, u^512, u^32768 (internal, canonical)
+  Fp<FID> u1, u8, v8, uS, uT, uG;  // u, u^8, u^-8, u^512, u^T (T = coefficients per tile), u^(64 T) (internal, canonical)
   uint32_t nflags;
 };
 template <int FID> __global__ __launch_bounds__(256) void k_horner_tables(HornerTblArgs<FID> a) {
@@ -410,8 +410,8 @@ template <int FID> __global__ __launch_bounds__(256) void k_horner_tables(Horner
   if (g < a.nflags) a.flags[g] = 0;
   if (blockIdx.x != 0) return;
   for (uint32_t t = threadIdx.x; t < kScanTblN; t += 256u) {
-    const F base = t < kScanTblV ? a.u8 : (t < kScanTblW ? a.v8 : (t < kScanTblX ? a.uT : (t < kScanTblP ? a.uG : a.u1)));
-    const uint32_t e = t < kScanTblV ? t : (t < kScanTblW ? t - kScanTblV + 1 : (t < kScanTblX ? t - kScanTblW : (t < kScanTblP ? t - kScanTblX : t - kScanTblP + 2)));  // <= 64
+    const F base = t < kScanTblV ? a.u8 : (t < kScanTblW ? a.v8 : (t < kScanTblX ? a.uT : (t < kScanTblP ? a.uG : (t < kScanTblS ? a.u1 : a.uS))));
+    const uint32_t e = t < kScanTblV ? t : (t < kScanTblW ? t - kScanTblV + 1 : (t < kScanTblX ? t - kScanTblW : (t < kScanTblP ? t - kScanTblX : (t < kScanTblS ? t - kScanTblP + 2 : t - kScanTblS))));  // <= 64
     F acc = F::one();
     for (int b = 6; b >= 0; b--) {
       acc = acc.sqr();
@@ -500,10 +500,12 @@ __device__ __forceinline__ uint32_t poll_flag(const uint32_t* flag) {
 __device__ __forceinline__ void seen_barrier() { asm volatile("" ::: "memory"); }
 #endif
 
-template <int FID> __global__ __launch_bounds__(256) void k_horner_scan(HornerScanArgs<FID> a) {
+template <int FID, int J> __global__ __launch_bounds__(256) void k_horner_scan(HornerScanArgs<FID> a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using F = Fp<FID>;
+  constexpr uint32_t T = J * kScanSub;  // coefficients per tile
   __shared__ uint4 lds_all[4][32 * 17];
+  __shared__ uint32_t park_all[4][J * 9 * 64];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t r = blockIdx.x * 4u + wave;  // position in dispatch order
   if (r >= a.ntiles) return;
@@ -512,62 +514,106 @@ template <int FID> __global__ __launch_bounds__(256) void k_horner_scan(HornerSc
   const uint32_t gtiles = a.ntiles - grp * kScanGroup < kScanGroup ? a.ntiles - grp * kScanGroup : kScanGroup;
   const bool last_group = grp + 1u == a.ngroups;
   uint4* my = lds_all[wave];
-  const size_t e0 = (size_t)tile * kScanTile;                    // first element of the tile
-  const uint4* src = (const uint4*)a.f + 2 * e0;
-  uint4* dst = (uint4*)a.out + 2 * e0;
-  const uint32_t left = a.n - e0 < kScanTile ? (uint32_t)(a.n - e0) : kScanTile;  // elements of this tile
+  uint32_t* park = park_all[wave];
+  const size_t e0 = (size_t)tile * T;  // first element of the tile
+  uint32_t w[8][8];                    // words of coefficient 8 lane + k of the sub-tile in hand
 
-  // ---- load + transpose: w[k] = words of coefficient 8 lane + k
-  uint32_t w[8][8];
+  // sub-tile j (512 coefficients) -> w: 16 coalesced 16-byte loads per lane, transposed through LDS in two halves
+  auto load_sub = [&](uint32_t j) __attribute__((always_inline)) {
+    const size_t e = e0 + (size_t)j * kScanSub;
+    const uint4* src = (const uint4*)a.f + 2 * e;
+    const uint32_t left = e >= a.n ? 0u : (a.n - e < kScanSub ? (uint32_t)(a.n - e) : kScanSub);
 #pragma unroll
-  for (uint32_t p = 0; p < 2; p++) {
-    uint4 v[8];
+    for (uint32_t p = 0; p < 2; p++) {
+      uint4 v[8];
 #pragma unroll
-    for (uint32_t qq = 0; qq < 8; qq++) {
-      const uint32_t unit = (8u * p + qq) * 64u + lane;  // 16-byte unit of the tile
-      v[qq] = (unit >> 1) < left ? src[unit] : make_uint4(0, 0, 0, 0);
-    }
-#pragma unroll
-    for (uint32_t qq = 0; qq < 8; qq++) my[(4u * qq + (lane >> 4)) * 17u + (lane & 15u)] = v[qq];
-    wave_lds_sync();
-    if ((lane >> 5) == p) {
-#pragma unroll
-      for (uint32_t t = 0; t < 16; t++) {
-        const uint4 x = my[(lane & 31u) * 17u + t];
-        w[t >> 1][(t & 1u) * 4u + 0] = x.x;
-        w[t >> 1][(t & 1u) * 4u + 1] = x.y;
-        w[t >> 1][(t & 1u) * 4u + 2] = x.z;
-        w[t >> 1][(t & 1u) * 4u + 3] = x.w;
+      for (uint32_t qq = 0; qq < 8; qq++) {
+        const uint32_t unit = (8u * p + qq) * 64u + lane;  // 16-byte unit of the sub-tile
+        v[qq] = (unit >> 1) < left ? src[unit] : make_uint4(0, 0, 0, 0);
       }
+#pragma unroll
+      for (uint32_t qq = 0; qq < 8; qq++) my[(4u * qq + (lane >> 4)) * 17u + (lane & 15u)] = v[qq];
+      wave_lds_sync();
+      if ((lane >> 5) == p) {
+#pragma unroll
+        for (uint32_t t = 0; t < 16; t++) {
+          const uint4 x = my[(lane & 31u) * 17u + t];
+          w[t >> 1][(t & 1u) * 4u + 0] = x.x;
+          w[t >> 1][(t & 1u) * 4u + 1] = x.y;
+          w[t >> 1][(t & 1u) * 4u + 2] = x.z;
+          w[t >> 1][(t & 1u) * 4u + 3] = x.w;
+        }
+      }
+      wave_lds_sync();
     }
-    wave_lds_sync();
-  }
+  };
+  auto store_sub = [&](uint32_t j) __attribute__((always_inline)) {
+    const size_t e = e0 + (size_t)j * kScanSub;
+    uint4* dst = (uint4*)a.out + 2 * e;
+    const uint32_t left = e >= a.n ? 0u : (a.n - e < kScanSub ? (uint32_t)(a.n - e) : kScanSub);
+#pragma unroll
+    for (uint32_t p = 0; p < 2; p++) {
+      if ((lane >> 5) == p) {
+#pragma unroll
+        for (uint32_t t16 = 0; t16 < 16; t16++)
+          my[(lane & 31u) * 17u + t16] = make_uint4(w[t16 >> 1][(t16 & 1u) * 4u + 0], w[t16 >> 1][(t16 & 1u) * 4u + 1],
+                                                    w[t16 >> 1][(t16 & 1u) * 4u + 2], w[t16 >> 1][(t16 & 1u) * 4u + 3]);
+      }
+      wave_lds_sync();
+#pragma unroll
+      for (uint32_t qq = 0; qq < 8; qq++) {
+        const uint32_t unit = (8u * p + qq) * 64u + lane;
+        const uint4 x = my[(4u * qq + (lane >> 4)) * 17u + (lane & 15u)];
+        if ((unit >> 1) < left) dst[unit] = x;
+      }
+      wave_lds_sync();
+    }
+  };
 
-  // ---- chunk head, scaled, suffix sum over the lanes
-  // head = f0 + (f1 u + f2 u^2 + f3 u^3 + f4 u^4) + (f5 u^5 + f6 u^6 + f7 u^7): seven products, TWO reductions, no dependent chain
-  // (Fp::dot; the eight-step Horner form is 8 x 162 multiply-adds and 8 reductions, this one 7 x 81 + 2 x 81)
-  F t;
-  {
-    const F fa[4] = {F::from_words(w[1]), F::from_words(w[2]), F::from_words(w[3]), F::from_words(w[4])};
-    const F pa[4] = {a.u, fp_ld_limbs<FID>(a.tbl + 9u * kScanTblP), fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblP + 1u)),
-                     fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblP + 2u))};
-    const F fb[3] = {F::from_words(w[5]), F::from_words(w[6]), F::from_words(w[7])};
-    const F pb[3] = {fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblP + 3u)), fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblP + 4u)),
-                     fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblP + 5u))};
-    t = (F::from_words(w[0]) + F::template dot<4, true>(fa, pa) + F::template dot<3, true>(fb, pb)).norm();   // < 3.06 p (7.4 p for words >= p)
-  }
-  {
+  // ---- phase 1, sub-tile by sub-tile (the last one stays in registers): chunk heads, scaled, suffix sum over the lanes
+  F A;  // lane 0: the tile's aggregate sum_k f[k] u^k
+#pragma unroll 1
+  for (uint32_t j = 0; j < (uint32_t)J; j++) {
+    seen_barrier();  // the constants are re-read per sub-tile: hoisted out of the loop they cost ~50 registers
+    load_sub(j);
+    // head = f0 + (f1 u + f2 u^2 + f3 u^3 + f4 u^4) + (f5 u^5 + f6 u^6 + f7 u^7): seven products, TWO reductions, no dependent
+    // chain (Fp::dot; the eight-step Horner form is 8 x 162 multiply-adds and 8 reductions, this one 7 x 81 + 2 x 81)
+    F t;
+    {
+      const F fa[4] = {F::from_words(w[1]), F::from_words(w[2]), F::from_words(w[3]), F::from_words(w[4])};
+      const F pa[4] = {a.u, fp_ld_limbs<FID>(a.tbl + 9u * kScanTblP), fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblP + 1u)),
+                       fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblP + 2u))};
+      t = F::template dot<4, true>(fa, pa);
+    }
+    if constexpr (J > 1) {  // the words stay live for the walk: unpack the second batch only after the first product
+#pragma unroll
+      for (int k = 5; k < 8; k++)
+#pragma unroll
+        for (int q = 0; q < 8; q++) asm volatile("" : "+v"(w[k][q]) : "v"(t.l[0]));
+    }
+    {
+      const F fb[3] = {F::from_words(w[5]), F::from_words(w[6]), F::from_words(w[7])};
+      const F pb[3] = {fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblP + 3u)), fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblP + 4u)),
+                       fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblP + 5u))};
+      t = t + F::template dot<3, true>(fb, pb);
+    }
+    if constexpr (J > 1) {
+#pragma unroll
+      for (int q = 0; q < 8; q++) asm volatile("" : "+v"(w[0][q]) : "v"(t.l[0]));
+    }
+    t = (F::from_words(w[0]) + t).norm();   // < 3.06 p (7.4 p for words >= p)
     const F H = t * fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblU + lane));          // u^(8 lane) head   < 1.06 p
     const F S = wave_suffix_sum<FID>(H, lane);                                  // < 67.7 p
-    // the tile's aggregate, at once; S itself waits in LDS (stride-64 words: conflict-free) while the look-backs run
-    if (lane == 0) {
-      desc_store<FID>(a.agg + 9 * (size_t)tile, S);
-      publish_flag(a.status + tile, 1u);
-    }
-    uint32_t* park = (uint32_t*)my;
+    // S waits in LDS (stride-64 words: conflict-free) while the other sub-tiles and the look-backs run
 #pragma unroll
-    for (int i = 0; i < 9; i++) park[i * 64 + lane] = S.l[i];
-    wave_lds_sync();
+    for (int i = 0; i < 9; i++) park[(j * 9u + i) * 64u + lane] = S.l[i];
+    if (j == 0) A = S;
+    else A = (A + S * fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblS + j))).norm();  // + u^(512 j) S   < 67.7 p + 1.54 p (J - 1)
+  }
+  wave_lds_sync();
+  if (lane == 0) {  // the tile's aggregate, at once
+    desc_store<FID>(a.agg + 9 * (size_t)tile, A);
+    publish_flag(a.status + tile, 1u);
   }
 
   // ---- a ticket of the group; the wave that draws the last one folds the group's aggregates
@@ -579,8 +625,8 @@ template <int FID> __global__ __launch_bounds__(256) void k_horner_scan(HornerSc
   if (closer) {
     F val = F::zero();
     if (lane < gtiles) val = desc_load<FID>(a.agg + 9 * ((size_t)grp * kScanGroup + lane));
-    const F term = val * fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblW + lane));      // < 1.52 p
-    const F GA = wave_total<FID>(term) * F::one();                                 // lane 0: the group's aggregate, < 1.78 p
+    const F term = val * fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblW + lane));      // < 1.57 p
+    const F GA = wave_total<FID>(term) * F::one();                                 // lane 0: the group's aggregate, < 1.8 p
     if (lane == 0) {
       desc_store<FID>((last_group ? a.ginc : a.gagg) + 9 * (size_t)grp, GA);
       publish_flag(a.gstatus + grp, last_group ? 2u : 1u);
@@ -600,13 +646,13 @@ template <int FID> __global__ __launch_bounds__(256) void k_horner_scan(HornerSc
     F val = F::zero();
     if (lane < nlook) val = desc_load<FID>(a.agg + 9 * ((size_t)tile + 1u + lane));
     const F term = val * fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblW + lane));
-    C = wave_bcast0<FID>(wave_total<FID>(term));                                    // < 96.6 p
+    C = wave_bcast0<FID>(wave_total<FID>(term));                                    // < 99 p
   }
 
   // ---- across groups: the carry at the group's end
   if (!last_group) {
     F GC = F::zero();
-    F scale = F::one();  // u^(32768 * groups skipped)
+    F scale = F::one();  // u^(64 T * groups skipped)
     bool first_round = true;
     const uint64_t win_m = a.window >= 64u ? ~0ull : ((1ull << a.window) - 1ull);  // lanes that look
     for (uint32_t base = grp + 1u;; base += a.window) {
@@ -623,7 +669,7 @@ template <int FID> __global__ __launch_bounds__(256) void k_horner_scan(HornerSc
       seen_barrier();
       F val = F::zero();
       if (lane <= fi && lane < a.window && gg < a.ngroups) val = desc_load<FID>((lane < fi ? a.gagg : a.ginc) + 9 * (size_t)gg);
-      const F term = val * fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblX + lane));   // u^(32768 lane) * value   < 1.03 p
+      const F term = val * fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblX + lane));   // u^(64 T lane) * value   < 1.03 p
       const F sum = wave_bcast0<FID>(wave_total<FID>(term));                     // < 66 p
       if (first_round) GC = sum;
       else GC = ((GC * F::one()) + (scale * sum)).norm();                        // < 1.77 p + 1.77 p
@@ -632,47 +678,39 @@ template <int FID> __global__ __launch_bounds__(256) void k_horner_scan(HornerSc
       scale = (scale * fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblX + a.window))).canon();
     }
     // (only the last group can be short: the distance from this tile's end to the group's end is 63 - pos tiles)
-    C = (C + fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblW + (kScanGroup - 1u - pos))) * GC).norm();   // < 99.3 p
+    C = (C + fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblW + (kScanGroup - 1u - pos))) * GC).norm();   // < 100.6 p
     if (closer && lane == 0) {  // the group's inclusive value for the groups in front of it
       const F GI = (desc_load<FID>(a.gagg + 9 * (size_t)grp) + fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblX + 1u)) * GC).norm();  // < 3.6 p
       desc_store<FID>(a.ginc + 9 * (size_t)grp, GI);
       publish_flag(a.gstatus + grp, 2u);
     }
   }
-  const F TC = fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblW + 1u)) * C;  // u^512 C  < 1.79 p
 
-  // ---- walk the chunk from its carry
-  {
-    const uint32_t* park = (const uint32_t*)my;
+  // ---- phase 3: walk the sub-tiles from the top, each from the value the one above it ended with
+  F t = C;  // the suffix value at the end of the sub-tile in hand (wave-uniform)
+#pragma unroll 1
+  for (uint32_t jj = 0; jj < (uint32_t)J; jj++) {
+    const uint32_t j = (uint32_t)J - 1u - jj;
+    seen_barrier();
+    if (jj != 0) {
+      t = wave_bcast0<FID>(t);  // lane 0 ended on the first coefficient of the sub-tile above
+      load_sub(j);
+    }
+    const F TC = fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblS + 1u)) * t;  // u^512 * carry   < 1.8 p
     F S_next;  // S of lane + 1, zero for the last lane
 #pragma unroll
-    for (int i = 0; i < 9; i++) S_next.l[i] = lane < 63u ? park[i * 64 + lane + 1u] : 0u;
-    wave_lds_sync();  // the output transposition reuses the buffer
-    t = ((S_next + TC).norm()) * fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblV + lane));  // < 1.53 p
-  }
+    for (int i = 0; i < 9; i++) S_next.l[i] = lane < 63u ? park[(j * 9u + i) * 64u + lane + 1u] : 0u;
+    t = ((S_next + TC).norm()) * fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblV + lane));  // < 1.55 p
 #pragma unroll
-  for (uint32_t k = 8; k-- > 0;) {
-    t = (F::from_words(w[k]) + a.u * t).norm();
-    t.canon4().to_words(w[k]);
-  }
-
-  // ---- transpose back + store
+    for (uint32_t k = 8; k-- > 0;) {
+      if constexpr (J > 1) {  // unpack coefficient k when its turn comes: unpacked ahead of the chain, all eight cost 72 more registers
 #pragma unroll
-  for (uint32_t p = 0; p < 2; p++) {
-    if ((lane >> 5) == p) {
-#pragma unroll
-      for (uint32_t t16 = 0; t16 < 16; t16++)
-        my[(lane & 31u) * 17u + t16] = make_uint4(w[t16 >> 1][(t16 & 1u) * 4u + 0], w[t16 >> 1][(t16 & 1u) * 4u + 1],
-                                                  w[t16 >> 1][(t16 & 1u) * 4u + 2], w[t16 >> 1][(t16 & 1u) * 4u + 3]);
+        for (int q = 0; q < 8; q++) asm volatile("" : "+v"(w[k][q]) : "v"(t.l[0]));
+      }
+      t = (F::from_words(w[k]) + a.u * t).norm();  // < 2.02 p (8.4 p on a word >= p)
+      t.canon4().to_words(w[k]);
     }
-    wave_lds_sync();
-#pragma unroll
-    for (uint32_t qq = 0; qq < 8; qq++) {
-      const uint32_t unit = (8u * p + qq) * 64u + lane;
-      const uint4 x = my[(4u * qq + (lane >> 4)) * 17u + (lane & 15u)];
-      if ((unit >> 1) < left) dst[unit] = x;
-    }
-    wave_lds_sync();
+    store_sub(j);
   }
 #endif
 }
@@ -974,11 +1012,17 @@ template <int FID> static void horner_dev(Ctx& c, const uint32_t* f, uint32_t n,
 // the single-pass kernel (k_horner_scan): per-lane constants + tile states from one small launch, then the scan itself
 template <int FID> static void horner_scan_t(Ctx& c, const void* f, size_t n, const Fp<FID>& u0, bool dev, void* out) {
   using F = Fp<FID>;
-  const uint32_t nt = (uint32_t)((n + kScanTile - 1) / kScanTile), ng = (nt + kScanGroup - 1) / kScanGroup;
+  // sub-tiles per wave: two from 2^20 coefficients on (the look-backs are paid once per tile), one below (more tiles in flight)
+  uint32_t J = G.horner_sub;
+  if (J != 1 && J != 2 && J != 4) J = n >= (1u << 20) ? 2u : 1u;
+  const size_t tile = (size_t)J * kScanSub;
+  const uint32_t nt = (uint32_t)((n + tile - 1) / tile), ng = (nt + kScanGroup - 1) / kScanGroup;
   F u8 = u0;
   for (int i = 0; i < 3; i++) u8 = u8.sqr().canon();
-  F uT = u8;
-  for (int i = 0; i < 6; i++) uT = uT.sqr().canon();
+  F uS = u8;
+  for (int i = 0; i < 6; i++) uS = uS.sqr().canon();
+  F uT = uS;
+  for (uint32_t q = J; q > 1; q >>= 1) uT = uT.sqr().canon();
   F uG = uT;
   for (int i = 0; i < 6; i++) uG = uG.sqr().canon();
   const F v8 = u8.inv();  // u != 0 (checked by the caller)
@@ -1002,12 +1046,14 @@ template <int FID> static void horner_scan_t(Ctx& c, const void* f, size_t n, co
   const bool prof = G.profiling;
   DeviceBackend be(c, false, prof);
   be.mark("kernel");
-  HornerTblArgs<FID> ta{tbl, flags, u0, u8, v8, uT, uG, (uint32_t)nflags};
+  HornerTblArgs<FID> ta{tbl, flags, u0, u8, v8, uS, uT, uG, (uint32_t)nflags};
   be.launch_kernel(k_horner_tables<FID>, (uint32_t)((nflags + 255) / 256), 256, ta);
   const uint32_t win = G.horner_window;
   HornerScanArgs<FID> sa{df, dout, tbl, flags, flags + nt, flags + nt + ng, agg, gagg, ginc, u0, (uint32_t)n, nt, ng,
                          win >= 1 && win <= 64 ? win : 64u};
-  be.launch_kernel(k_horner_scan<FID>, (nt + 3) / 4, 256, sa);
+  if (J == 1) be.launch_kernel(k_horner_scan<FID, 1>, (nt + 3) / 4, 256, sa);
+  else if (J == 2) be.launch_kernel(k_horner_scan<FID, 2>, (nt + 3) / 4, 256, sa);
+  else be.launch_kernel(k_horner_scan<FID, 4>, (nt + 3) / 4, 256, sa);
   be.mark("end");
   if (!dev) HIPCHK(hipMemcpyAsync(out, dout, n * 32, hipMemcpyDeviceToHost, c.stream));
   stream_wait(c.stream);
