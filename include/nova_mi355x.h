@@ -332,8 +332,9 @@ int nmx_set_window_bits(uint32_t c);
  * 0xffffffff: never), "seg_min_len", "seg_lanes" (0: a multiple of the kernel's resident lanes), "no_quad_accum",
  * "no_quad_final", "accum_prefetch" (0: by table size; 1 or 2), "no_batch_fuse" (1: every vector of a batch call runs
  * as its own MSM), "horner_top" (suffix Horner from 1024 coefficients on: 0 = the single-pass scan with decoupled look-back; the two-pass
- * kernels: 8 = 8-coefficient chunks in registers, 4, 1 = chunk-per-lane recursion only), "horner_window" (tiles per look-back
- * round of the single-pass scan, 64; 1..63 force its multi-round path in tests),
+ * kernels: 8 = 8-coefficient chunks in registers, 4, 1 = chunk-per-lane recursion only), "horner_window" (groups per look-back
+ * round of the single-pass scan, 64; 1..63 force its multi-round path in tests), "horner_sub" (512-coefficient sub-tiles per
+ * wave of the scan: 0 = by size, 1, 2, 4),
  * "seg_heavy_above" (pieces per bucket summed without a pre-fold pass: 0 = by table width, else 1..63), "no_tree_fuse" (bucket
  * reduction: 0 = fused levels or one launch per level by the box's measured launch gap, 1 = one launch per level, 2 = fused),
  * "hist_grid" (blocks of the partition's counting pass; 0 = as the placing pass: measured flat, profiles/r03_msm_2p20/tail_ab.txt),

@@ -353,12 +353,15 @@ template <int FID, uint32_t K> struct HornerWalkFn {
 // (64 B per coefficient, all of it in whole 1 KiB wave transactions), with the carries handed from tile to tile by a
 // two-level decoupled look-back instead of a recursion of launches.
 //
-//   tile    = 512 coefficients, owned by ONE wave (no block barrier anywhere): lane l holds coefficients 8l .. 8l+7 in
-//             registers.  The 16 KiB arrive as 16 coalesced 16-byte loads per lane and are transposed through 8.5 KiB of LDS
-//             per wave in two halves (row stride 272 B: conflict-free both ways); results leave the same way.
-//   local   : head_l = sum_k f[8l+k] u^k (8 dependent products), H_l = u^(8l) head_l (per-lane constant U_l), then a suffix
+//   tile    = J sub-tiles of 512 coefficients (J = 1, 2, 4 by input size), owned by ONE wave (no block barrier anywhere); of the
+//             sub-tile in hand lane l holds coefficients 8l .. 8l+7 in registers.  Its 16 KiB arrive as 16 coalesced 16-byte
+//             loads per lane and are transposed through 8.5 KiB of LDS per wave in two halves (row stride 272 B: conflict-free
+//             both ways); results leave the same way.  With J > 1 the local phase runs over all sub-tiles first (the last one
+//             stays in registers), the look-backs run once, and the walk re-reads the lower sub-tiles (L2 / Infinity Cache).
+//   local   : head_l = sum_k f[8l+k] u^k (two dot products with one reduction each, Fp::dot), H_l = u^(8l) head_l (per-lane constant U_l), then a suffix
 //             SUM over the lanes -- additions, not products, because every term already carries its power of u:
-//             S_l = sum_{m >= l} H_m.  S_0 is the tile's aggregate  A = sum_k f[k] u^k  (k tile-local), published at once.
+//             S_l = sum_{m >= l} H_m, parked in LDS.  A = sum_j u^(512 j) S_0 of sub-tile j = sum_k f[k] u^k (k tile-local) is the
+//             tile's aggregate, published at once.
 //   carry   : C = out[first element of the next tile], the suffix value at the tile's end.  Tiles form GROUPS of 64
 //             (32 768 coefficients).  Inside the group: C1 = sum_m u^(512 m) A_(tile+1+m) over the group's later tiles -- one
 //             product per lane with the per-lane constant W_m and a wave sum; those tiles were dispatched earlier and
@@ -374,8 +377,9 @@ template <int FID, uint32_t K> struct HornerWalkFn {
 //             waves dispatched before it.
 //   walk    : lane l re-walks its chunk from  c_l = u^(-8(l+1)) (S_(l+1) + u^512 C)  (per-lane constant V_l) and stores
 //             canonical values.
-// ~2.8 products per coefficient (8 + 1 + 1 + 8 per lane and 4-6 per wave-tile for the two look-backs) against 2 + recursion
-// for the two-pass kernels above, but no partial-line traffic and no dependent launches.  u = 0 is left to those kernels; the
+// Per 512 coefficients: 3.5 product-equivalents for the heads, 8 for the walk, 3 more (H, the sub-tile's carry, V); per tile 4-6
+// for the two look-backs -- 721 VALU instructions per coefficient at J = 1 against ~700 + the recursion for the two-pass kernels
+// above, but no partial-line traffic and no dependent launches.  u = 0 is left to those kernels; the
 // per-lane constants come from a small kernel (k_horner_tables) that also clears the tile / group states.
 // Bounds (p(1 + ab/127) for a product of values < ap, < bp; input words may be any 256-bit value, < 5.3p): head < 7.4p,
 // H < 1.06p, S < 67.7p (published raw as A), W A < 1.54p, C1 < 96.6p, GA < 98.1p reduced to < 1.78p before it is published,
@@ -1012,9 +1016,10 @@ template <int FID> static void horner_dev(Ctx& c, const uint32_t* f, uint32_t n,
 // the single-pass kernel (k_horner_scan): per-lane constants + tile states from one small launch, then the scan itself
 template <int FID> static void horner_scan_t(Ctx& c, const void* f, size_t n, const Fp<FID>& u0, bool dev, void* out) {
   using F = Fp<FID>;
-  // sub-tiles per wave: two from 2^20 coefficients on (the look-backs are paid once per tile), one below (more tiles in flight)
+  // sub-tiles per wave: the look-backs are paid once per tile, so long inputs take 2 (from 2^21 coefficients) or 4 (from 2^22);
+  // short ones keep 1: more tiles in flight (profiles/r03_fieldvec/horner_scan.txt)
   uint32_t J = G.horner_sub;
-  if (J != 1 && J != 2 && J != 4) J = n >= (1u << 20) ? 2u : 1u;
+  if (J != 1 && J != 2 && J != 4) J = n >= (1u << 22) ? 4u : (n >= (1u << 21) ? 2u : 1u);
   const size_t tile = (size_t)J * kScanSub;
   const uint32_t nt = (uint32_t)((n + tile - 1) / tile), ng = (nt + kScanGroup - 1) / kScanGroup;
   F u8 = u0;

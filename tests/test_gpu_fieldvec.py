@@ -174,18 +174,19 @@ def test_horner_and_div_by_monomial(nmx, fid, n):
 
 
 @pytest.mark.parametrize("fid", range(4))
-@pytest.mark.parametrize("knob,value", [("horner_window", 1), ("horner_window", 3), ("horner_window", 7), ("horner_top", 8),
-                                        ("horner_top", 4), ("horner_top", 1)])
+@pytest.mark.parametrize("knob,value", [("horner_window", 1), ("horner_window", 3), ("horner_window", 7), ("horner_sub", 1),
+                                        ("horner_sub", 2), ("horner_sub", 4), ("horner_top", 8), ("horner_top", 4), ("horner_top", 1)])
 def test_horner_variants(nmx, fid, knob, value):
-    """The single-pass scan (k_horner_scan) with 1 / 3 / 7 tiles per look-back round -- every tile then needs several
-    rounds, the path a 64-tile window takes only when no tile behind it has its inclusive value yet -- and the two-pass
-    kernels it replaced (horner_top 8 / 4 / 1), all against the oracle: tile boundaries (512), partial last tiles, edge values."""
+    """The single-pass scan (k_horner_scan) with 1 / 3 / 7 groups per look-back round -- every tile then needs several
+    rounds, the path a 64-group window takes only when no group behind it has its inclusive value yet --, with 1 / 2 / 4
+    sub-tiles per wave at every size, and the two-pass kernels it replaced (horner_top 8 / 4 / 1), all against the oracle:
+    tile boundaries (512), partial and empty last sub-tiles, more than one group (64 tiles), edge values."""
     from nova_amd import _lib
     from nova_amd import fieldvec as fv
     L = _lib.lib()
     assert L.nmx_set_option(knob.encode(), value) == 0
     try:
-        for n in (1024, 1025, 4097, 33 * 512, 65 * 512 + 9, 300003):
+        for n in (1024, 1025, 4097, 33 * 512, 65 * 512 + 9, 300003, 64 * 4 * 512 + 1):
             f = C.edge_vectors(fid, n, 5)
             u = C.rand_vec(fid, 1, 6)
             assert fv.suffix_horner(fid, f, u).tobytes() == cref.suffix_horner(fid, f, n, u), (knob, value, n)
