@@ -32,20 +32,19 @@ template <int FID> struct Axpy2Fn {
   uint32_t* out;
   Fp<FID> r, r2;  // r * 2^261, r^2 * 2^261
   NMX_HD void operator()(uint32_t i) const {
-    st<FID>(out, i, (ld<FID>(a, i) + r * ld<FID>(b, i) + r2 * ld<FID>(c, i)).norm());
+    st<FID>(out, i, (ld<FID>(a, i) + Fp<FID>::mul_add(r, ld<FID>(b, i), r2, ld<FID>(c, i))).norm());  // one reduction for both products
   }
 };
 template <int FID> struct CrossTermFn {
   const uint32_t *az, *bz, *cz, *e;
   uint32_t* out;
-  Fp<FID> u;  // u * 2^261
+  Fp<FID> u;  // (p - u) * 2^261: the product u*cz enters negated, so that az*bz*k - u*cz is ONE reduction (mul_add)
   Fp<FID> k;  // 2^522 / F: brings (az*F)(bz*F)/2^261 back to az*bz*F  (F = 1 canonical, 2^256 Montgomery)
   NMX_HD void operator()(uint32_t i) const {
     using F = Fp<FID>;
-    F ab = (ld<FID>(az, i) * ld<FID>(bz, i)) * k;       // < 1.02 p
-    F uc = u * ld<FID>(cz, i);                          // < 1.01 p
-    F t = F::sub2(ab, uc).norm();                       // ab - uc + 2p
-    t = F::sub2(t, ld<FID>(e, i)).norm();               // - e + 2p   (e canonical)
+    F ab = ld<FID>(az, i) * ld<FID>(bz, i);              // < 1.01 p
+    F t = F::mul_add(ab, k, ld<FID>(cz, i), u);          // az bz k - u cz   < 1.02 p
+    t = F::sub2(t, ld<FID>(e, i)).norm();                // - e + 2p   (e canonical)
     st<FID>(out, i, t);
   }
 };
@@ -53,14 +52,13 @@ template <int FID> struct CrossTermFn {
 template <int FID> struct CrossTerm2Fn {
   const uint32_t *az, *bz, *cz, *e1, *e2;
   uint32_t* out;
-  Fp<FID> u, k;  // as CrossTermFn
+  Fp<FID> u, k;  // as CrossTermFn (u negated)
   NMX_HD void operator()(uint32_t i) const {
     using F = Fp<FID>;
-    F ab = (ld<FID>(az, i) * ld<FID>(bz, i)) * k;       // < 1.02 p
-    F uc = u * ld<FID>(cz, i);                          // < 1.01 p
-    F t = F::sub2(ab, uc).norm();                       // ab - uc + 2p            < 3.1 p
-    F es = (ld<FID>(e1, i) + ld<FID>(e2, i)).norm();    // e1 + e2 (canonical)     < 2 p
-    t = F::sub4(t, es).norm();                          // - (e1 + e2) + 4p        < 7.1 p  (canon() takes < 16 p)
+    F ab = ld<FID>(az, i) * ld<FID>(bz, i);              // < 1.01 p
+    F t = F::mul_add(ab, k, ld<FID>(cz, i), u);          // az bz k - u cz          < 1.02 p
+    F es = (ld<FID>(e1, i) + ld<FID>(e2, i)).norm();     // e1 + e2 (canonical)     < 2 p
+    t = F::sub4(t, es).norm();                           // - (e1 + e2) + 4p        < 5.1 p  (canon() takes < 16 p)
     st<FID>(out, i, t);
   }
 };
@@ -228,11 +226,19 @@ template <int FID> struct LinCombFn {
   uint32_t k;
   NMX_HD void operator()(uint32_t i) const {
     using F = Fp<FID>;
+    // four products under one reduction (Fp::dot: 4 x 81 + 81 multiply-adds instead of 4 x 162; the weights are wave-uniform):
+    // the kernel was multiplier-bound at k = 8 (329 us at 2^22 against a VALU floor of 314 us, profiles/r03_fieldvec/lincomb8_pmc.json)
     F acc = F::zero();
     uint32_t pending = 0;
-    for (uint32_t j = 0; j < k; j++) {
-      if (i >= lens[j]) continue;
-      acc = acc + ld<FID>(w, j) * ld<FID>((const uint32_t*)(uintptr_t)vecs[j], i);
+    for (uint32_t j = 0; j < k; j += 4) {
+      F v[4], c[4];
+#pragma unroll
+      for (uint32_t q = 0; q < 4; q++) {
+        const bool on = j + q < k && i < lens[j + q < k ? j + q : j];
+        v[q] = on ? ld<FID>((const uint32_t*)(uintptr_t)vecs[j + q], i) : F::zero();
+        c[q] = j + q < k ? ld<FID>(w, j + q) : F::zero();
+      }
+      acc = acc + F::template dot<4, true>(v, c);  // < 1.04 p each
       if (++pending == 6) {
         acc = acc.norm().canon();
         pending = 0;
@@ -800,7 +806,8 @@ template <int FID> struct FieldImpl {
     VecIO io(c, flags & NMX_SCALARS_DEVICE, n, 5);
     // canonical data: k = 2^522 (R2); Montgomery data (F = 2^256): k = 2^522 / 2^256 = 2^266 (C266)
     F k = mont ? F::from_limbs(FpParams<FID>::C266) : F::from_limbs(FpParams<FID>::R2);
-    CrossTermFn<FID> f{io.in(az, n), io.in(bz, n), io.in(cz, n), io.in(e, n), io.out(out, n), challenge<FID>(u, mont), k};
+    const F nu = F::sub2(F::zero(), challenge<FID>(u, mont)).norm().canon();  // p - u (0 for u = 0)
+    CrossTermFn<FID> f{io.in(az, n), io.in(bz, n), io.in(cz, n), io.in(e, n), io.out(out, n), nu, k};
     timed_launch(c, f, n, &io);
   }
   static void cross_term2(Ctx& c, const void* az, const void* bz, const void* cz, const void* e1, const void* e2,
@@ -808,8 +815,8 @@ template <int FID> struct FieldImpl {
     const bool mont = flags & NMX_SCALARS_MONT;
     VecIO io(c, flags & NMX_SCALARS_DEVICE, n, 6);
     F k = mont ? F::from_limbs(FpParams<FID>::C266) : F::from_limbs(FpParams<FID>::R2);
-    CrossTerm2Fn<FID> f{io.in(az, n), io.in(bz, n), io.in(cz, n), io.in(e1, n), io.in(e2, n), io.out(out, n),
-                        challenge<FID>(u, mont), k};
+    const F nu = F::sub2(F::zero(), challenge<FID>(u, mont)).norm().canon();
+    CrossTerm2Fn<FID> f{io.in(az, n), io.in(bz, n), io.in(cz, n), io.in(e1, n), io.in(e2, n), io.out(out, n), nu, k};
     timed_launch(c, f, n, &io);
   }
   static void vec_add(Ctx& c, const void* a, const void* b, size_t n, uint32_t flags, void* out) {

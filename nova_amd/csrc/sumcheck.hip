@@ -111,8 +111,8 @@ __global__ __launch_bounds__(256) void k_eq_sums(const uint32_t* A, const uint32
 // First-half rounds (both eq tables), factored by rows:  sum_hi eqL[hi] * (sum_lo term[hi, lo] * eqR[lo]).  The generic
 // kernel pays eqL * eqR and term * factor per element -- 1.75 reductions per element in mode 1
 // (MultilinearPolynomial::evaluate_with, multilinear.rs:98-129: multiplier-bound, 0.28 ms for 2^24 elements = 24 % of the HBM
-// roofline), 5 per index in mode 3.  Here eqL enters once per lane and row and two terms share a reduction:
-// 1.25 + 1/K per element in mode 1 (0.17 ms, 39 %), 4 + 2/K per index in mode 3.  A block walks whole rows (2^shift
+// roofline), 5 per index in mode 3.  Here eqL enters once per lane and row and two terms share a reduction -- four in mode 1
+// since round 3 (Fp::dot): 1 + 0.25 + 1/K reductions per element in mode 1, 4 + 2/K per index in mode 3.  A block walks whole rows (2^shift
 // consecutive indices, coalesced); rows shorter than the block share it.
 template <int FID, int MODE>
 __global__ __launch_bounds__(256) void k_eq_rows(const uint32_t* A, const uint32_t* B, const uint32_t* C, const uint32_t* eqL,
@@ -129,6 +129,25 @@ __global__ __launch_bounds__(256) void k_eq_rows(const uint32_t* A, const uint32
     const uint32_t base = hi << shift;
     F r0 = F::zero(), r1 = F::zero();
     uint32_t pend = 0, k = 0;
+    // mode 1 (evaluate_with): four indices per reduction (Fp::dot), whole groups inside the vector.  (Modes 2 / 3 would hold
+    // twelve operands -- 221 registers, two waves per SIMD -- for 6 % fewer multiply-adds: they keep the pairs below.)
+    if constexpr (MODE == 1) {
+      for (; k + 3 < K; k += 4) {
+        const uint32_t l0 = lo0 + k * P;
+        if (base + l0 + 3 * P >= h) break;
+        F e[4], fc[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+          e[j] = ldw<FID>(A, base + l0 + j * P);
+          fc[j] = ldw<FID>(eqR, l0 + j * P);
+        }
+        r0 = r0 + F::template dot<4>(e, fc);  // < 1.04 p
+        if (++pend == 6) {
+          r0 = r0.norm().canon();
+          pend = 0;
+        }
+      }
+    }
     for (; k + 1 < K; k += 2) {  // two indices per reduction
       const uint32_t l0 = lo0 + k * P, l1 = l0 + P;
       if (base + l1 < h) {
@@ -648,7 +667,28 @@ __global__ __launch_bounds__(256) void k_plain_sums(const uint32_t* A, const uin
   __shared__ uint32_t lds[9 * 256];
   F s0 = F::zero(), s1 = F::zero(), s2 = F::zero();
   uint32_t pending = 0;
-  for (uint32_t id = blockIdx.x * 256u + threadIdx.x; id < h; id += gridDim.x * 256u) {
+  const uint32_t stride = gridDim.x * 256u;
+  uint32_t id = blockIdx.x * 256u + threadIdx.x;
+  if constexpr (KIND == 1 || KIND == 3) {
+    // two indices per reduction (mul_add: 2 x 81 + 81 multiply-adds instead of 2 x 162)
+    for (; (uint64_t)id + stride < h; id += 2 * stride) {
+      const uint32_t jd = id + stride;
+      const F a0 = ldw<FID>(A, id), a1 = ldw<FID>(A, (size_t)id + h), b0 = ldw<FID>(B, id), b1 = ldw<FID>(B, (size_t)id + h);
+      const F c0 = ldw<FID>(A, jd), c1 = ldw<FID>(A, (size_t)jd + h), d0 = ldw<FID>(B, jd), d1 = ldw<FID>(B, (size_t)jd + h);
+      s0 = s0 + F::mul_add(a0, b0, c0, d0);
+      if (KIND == 1)
+        s1 = s1 + F::mul_add(F::sub2(a1, a0).norm(), F::sub2(b1, b0).norm(), F::sub2(c1, c0).norm(), F::sub2(d1, d0).norm());  // operands < 3 p -> < 1.15 p
+      else
+        s1 = s1 + F::mul_add(F::sub2(a0.dbl(), a1).norm(), F::sub2(b0.dbl(), b1).norm(), F::sub2(c0.dbl(), c1).norm(),
+                             F::sub2(d0.dbl(), d1).norm());  // operands < 4 p -> < 1.26 p
+      if (++pending == 6) {
+        s0 = s0.norm().canon();
+        s1 = s1.norm().canon();
+        pending = 0;
+      }
+    }
+  }
+  for (; id < h; id += stride) {
     const F a0 = ldw<FID>(A, id), a1 = ldw<FID>(A, (size_t)id + h);
     const F b0 = ldw<FID>(B, id), b1 = ldw<FID>(B, (size_t)id + h);
     if (KIND == 1) {
