@@ -512,7 +512,7 @@ def fieldvec_block(args, torch, L):
     entry("lincomb8", N22, 288, ms, as_bytes(o, m) == cref.lincomb_powers(fid, [v[:m].cpu().numpy().tobytes() for v in vecs], r, m))
     ms, o = kernel_ms(lambda: fv.suffix_horner(fid, A[:N22], r))
     entry("horner", N22, 64, ms, as_bytes(o) == cref.suffix_horner(fid, hA[:N22], N22, r),
-          "a scan whose operator is a field multiplication: VALU-bound (DESIGN.md 3b)")
+          "single-pass scan with decoupled look-back: bound by the dependent memory round trips per tile, not by HBM or VALU (profiles/r03_fieldvec/horner_scan.txt)")
     rng = np.random.Generator(np.random.PCG64(5))
     indptr = np.arange(0, 3 * N22 + 1, 3, dtype=np.uint64)
     indices = rng.integers(0, N22, size=3 * N22).astype(np.uint64)
