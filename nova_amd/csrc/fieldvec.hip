@@ -580,11 +580,17 @@ template <int FID, int J> __global__ __launch_bounds__(256) void k_horner_scan(H
     }
   };
 
+  // with two waves per SIMD (J > 1) there are registers to spare: the per-lane constants are loaded once, not behind an L2
+  // round trip in every sub-tile (J = 1 sits at the 168-register limit of three waves per SIMD and re-reads them)
+  F Ulane, Vlane;
+  if constexpr (J > 1) {
+    Ulane = fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblU + lane));
+    Vlane = fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblV + lane));
+  }
   // ---- phase 1, sub-tile by sub-tile (the last one stays in registers): chunk heads, scaled, suffix sum over the lanes
   F A;  // lane 0: the tile's aggregate sum_k f[k] u^k
 #pragma unroll 1
   for (uint32_t j = 0; j < (uint32_t)J; j++) {
-    seen_barrier();  // the constants are re-read per sub-tile: hoisted out of the loop they cost ~50 registers
     load_sub(j);
     // head = f0 + (f1 u + f2 u^2 + f3 u^3 + f4 u^4) + (f5 u^5 + f6 u^6 + f7 u^7): seven products, TWO reductions, no dependent
     // chain (Fp::dot; the eight-step Horner form is 8 x 162 multiply-adds and 8 reductions, this one 7 x 81 + 2 x 81)
@@ -612,7 +618,7 @@ template <int FID, int J> __global__ __launch_bounds__(256) void k_horner_scan(H
       for (int q = 0; q < 8; q++) asm volatile("" : "+v"(w[0][q]) : "v"(t.l[0]));
     }
     t = (F::from_words(w[0]) + t).norm();   // < 3.06 p (7.4 p for words >= p)
-    const F H = t * fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblU + lane));          // u^(8 lane) head   < 1.06 p
+    const F H = t * (J > 1 ? Ulane : fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblU + lane)));  // u^(8 lane) head   < 1.06 p
     const F S = wave_suffix_sum<FID>(H, lane);                                  // < 67.7 p
     // S waits in LDS (stride-64 words: conflict-free) while the other sub-tiles and the look-backs run
 #pragma unroll
@@ -701,7 +707,6 @@ template <int FID, int J> __global__ __launch_bounds__(256) void k_horner_scan(H
 #pragma unroll 1
   for (uint32_t jj = 0; jj < (uint32_t)J; jj++) {
     const uint32_t j = (uint32_t)J - 1u - jj;
-    seen_barrier();
     if (jj != 0) {
       t = wave_bcast0<FID>(t);  // lane 0 ended on the first coefficient of the sub-tile above
       load_sub(j);
@@ -710,7 +715,7 @@ template <int FID, int J> __global__ __launch_bounds__(256) void k_horner_scan(H
     F S_next;  // S of lane + 1, zero for the last lane
 #pragma unroll
     for (int i = 0; i < 9; i++) S_next.l[i] = lane < 63u ? park[(j * 9u + i) * 64u + lane + 1u] : 0u;
-    t = ((S_next + TC).norm()) * fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblV + lane));  // < 1.55 p
+    t = ((S_next + TC).norm()) * (J > 1 ? Vlane : fp_ld_limbs<FID>(a.tbl + 9u * (kScanTblV + lane)));  // < 1.55 p
 #pragma unroll
     for (uint32_t k = 8; k-- > 0;) {
       if constexpr (J > 1) {  // unpack coefficient k when its turn comes: unpacked ahead of the chain, all eight cost 72 more registers
