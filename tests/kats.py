@@ -30,3 +30,30 @@ def as_arrays(cases):
         bases[i] = np.frombuffer(R.point_to_xy64(P), np.uint8)
         sc[i] = np.frombuffer(k.to_bytes(32, "little"), np.uint8)
     return bases, sc
+
+
+SYMPY_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sympy_kats.json")
+
+
+def load_sympy():
+    """tests/golden/sympy_kats.json (SymPy's elliptic-curve arithmetic, gen_sympy_kats.py) ->
+    {curve name: {"mul": [(k, Q)], "msm": (bases [P], scalars [k], sum Q), "gen": G}} with integer coordinates."""
+    raw = json.load(open(SYMPY_PATH))
+    pt = lambda v: (int(v["x"], 16), int(v["y"], 16))
+    out = {}
+    for name, c in raw.items():
+        if name.startswith("_"):
+            continue
+        out[name] = {"p": int(c["p"], 16), "r": int(c["r"], 16), "gen": pt(c["gen"]),
+                     "mul": [(int(v["k"], 16), pt(v)) for v in c["mul"]],
+                     "msm": ([pt(v) for v in c["msm"]["bases"]], [int(k, 16) for k in c["msm"]["scalars"]], pt(c["msm"]["sum"]))}
+    return out
+
+
+def points_scalars(points, scalars):
+    bases = np.zeros((len(points), 64), np.uint8)
+    sc = np.zeros((len(points), 32), np.uint8)
+    for i, (P, k) in enumerate(zip(points, scalars)):
+        bases[i] = np.frombuffer(R.point_to_xy64(P), np.uint8)
+        sc[i] = np.frombuffer(int(k).to_bytes(32, "little"), np.uint8)
+    return bases, sc

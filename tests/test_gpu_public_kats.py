@@ -44,3 +44,43 @@ def test_eip196_vectors_through_every_entry_point(nmx):
     got = g.vartime_multiscalar_mul_small(s64, bases[3:4])
     assert got.xy == R.point_to_xy64(cases[3][3])
     ck.close()
+
+
+@pytest.mark.parametrize("name", ["bn254_g1", "grumpkin", "pallas", "vesta"])
+def test_sympy_vectors_through_the_c_abi(nmx, name):
+    """tests/golden/sympy_kats.json (SymPy's elliptic-curve arithmetic; the external anchor of Grumpkin / Pallas / Vesta):
+    every scalar multiple through the slice form with n = 1, all of them as one MSM over a repeated generator, the six-term
+    MSM through the slice form, a registered key with window tables and `commit`, and padded into a 2^13-pair MSM."""
+    from oracle import cref
+    d = kats.load_sympy()[name]
+    c = R.CURVES[name]
+    g = nmx.DlogGroup(c.cid)
+    G = (c.gx, c.gy)
+    total = R.INF
+    for k, Q in d["mul"]:
+        bases, sc = kats.points_scalars([G], [k])
+        got = g.vartime_multiscalar_mul(sc, bases)
+        assert (got.xy, got.is_inf) == (R.point_to_xy64(Q), False), (name, k)
+        total = R.add(c, total, Q)
+    bases, sc = kats.points_scalars([G] * len(d["mul"]), [k for k, _ in d["mul"]])
+    got = g.vartime_multiscalar_mul(sc, bases)                       # the same base eleven times: one bucket set, P == Q additions
+    assert (got.xy, got.is_inf) == (R.point_to_xy64(total), total is R.INF)
+    P, s, want = d["msm"]
+    bases, sc = kats.points_scalars(P, s)
+    want = (R.point_to_xy64(want), False)
+    got = g.vartime_multiscalar_mul(sc, bases)
+    assert (got.xy, got.is_inf) == want
+    ck = nmx.CommitmentKey.from_host(c.cid, bases)
+    got = g.vartime_multiscalar_mul(sc, ck)
+    assert (got.xy, got.is_inf) == want
+    got = nmx.CommitmentEngine(c.cid).commit(ck, sc)
+    assert (got.xy, got.is_inf) == want
+    ck.close()
+    n = 1 << 13
+    big = cref.sequential_bases(c, 500, n).copy()
+    bsc = np.zeros((n, 32), np.uint8)
+    for pos, i in zip([3, 999, 4095, 4096, 8000, n - 1], range(len(P))):
+        big[pos] = bases[i]
+        bsc[pos] = sc[i]
+    got = g.vartime_multiscalar_mul(bsc, big)
+    assert (got.xy, got.is_inf) == want
