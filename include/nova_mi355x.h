@@ -184,7 +184,9 @@ enum {
   NMX_STAT_TABLE_FALLBACKS = 12, /* keys left without window tables because the tables did not fit (budget / HBM) */
   NMX_STAT_LAUNCH_GAP_NS = 13, /* gauge: cost of one dependent one-wave launch on this box, measured once: a box
                                   diagnostic (slow-launch boxes of a pool show here); 0 until the first MSM       */
-  NMX_STAT_COUNT = 14
+  NMX_STAT_SCAN_TIMEOUTS = 14, /* suffix-Horner calls whose single-pass scan gave up a look-back wait and were repeated on
+                                  the two-pass kernels (never observed; the guard that turns a hang into a slower call) */
+  NMX_STAT_COUNT = 15
 };
 int nmx_stats(uint64_t* out, int cap);
 /* same, bases taken from a registered key */
@@ -334,7 +336,8 @@ int nmx_set_window_bits(uint32_t c);
  * as its own MSM), "horner_top" (suffix Horner from 1024 coefficients on: 0 = the single-pass scan with decoupled look-back; the two-pass
  * kernels: 8 = 8-coefficient chunks in registers, 4, 1 = chunk-per-lane recursion only), "horner_window" (groups per look-back
  * round of the single-pass scan, 64; 1..63 force its multi-round path in tests), "horner_sub" (512-coefficient sub-tiles per
- * wave of the scan: 0 = by size, 1, 2, 4),
+ * wave of the scan: 0 = by size, 1, 2, 4), "horner_spin_limit" (polls before a wave of the scan gives up and the call falls back
+ * to the two-pass kernels: 0 = 2^22; tests set 1),
  * "seg_heavy_above" (pieces per bucket summed without a pre-fold pass: 0 = by table width, else 1..63), "no_tree_fuse" (bucket
  * reduction: 0 = fused levels or one launch per level by the box's measured launch gap, 1 = one launch per level, 2 = fused),
  * "hist_grid" (blocks of the partition's counting pass; 0 = as the placing pass: measured flat, profiles/r03_msm_2p20/tail_ab.txt),

@@ -41,6 +41,7 @@ Global::SparseSet::~SparseSet() {
   if (data) (void)hipFree(data);
 }
 void note_table_fallback() { stat_add(NMX_STAT_TABLE_FALLBACKS); }
+void note_scan_timeout() { stat_add(NMX_STAT_SCAN_TIMEOUTS); }
 // What one dependent few-wave launch costs on this box: 16 one-wave kernels chained on a stream between two events, best of
 // three, once per process.  The fast boxes of the pool chain such launches back to back; BENCH_r02's box paid ~10 us each.
 __global__ void k_gap_probe(uint32_t* p) {
@@ -1675,6 +1676,7 @@ int nmx_set_option(const char* name, uint32_t value) {
     else if (n == "horner_top") G.horner_top = value;
     else if (n == "horner_window") G.horner_window = value ? value : 64u;
     else if (n == "horner_sub") G.horner_sub = value;
+    else if (n == "horner_spin_limit") G.horner_spin_limit = value;
     else if (n == "seg_heavy_above") G.seg_heavy_above = value > 63u ? 63u : value;
     else throw Fail{NMX_E_ARG, "unknown option name"};
   });

