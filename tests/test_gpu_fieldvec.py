@@ -194,6 +194,28 @@ def test_horner_variants(nmx, fid, knob, value):
         assert L.nmx_set_option(knob.encode(), 64 if knob == "horner_window" else 0) == 0
 
 
+@pytest.mark.parametrize("fid", range(4))
+def test_horner_scan_extreme_values(nmx, fid):
+    """The lazy-reduction bounds of the scan (sums of 64 weakly reduced terms, products of values up to ~100 p) on the worst
+    inputs the field allows: every coefficient p - 1, u in {p - 1, (p - 1) / 2, 2}; and all zero.  1, 2 and 4 sub-tiles per wave."""
+    from nova_amd import _lib
+    from nova_amd import fieldvec as fv
+    L = _lib.lib()
+    p = C.FIELDS[fid]
+    n = 70000  # 137 / 69 / 35 tiles: more than one group at one sub-tile per wave
+    f = C.vec([p - 1] * n)
+    z = C.vec([0] * n)
+    try:
+        for sub in (1, 2, 4):
+            assert L.nmx_set_option(b"horner_sub", sub) == 0
+            for uv in (p - 1, (p - 1) // 2, 2):
+                u = C.vec([uv])
+                assert fv.suffix_horner(fid, f, u).tobytes() == cref.suffix_horner(fid, f, n, u), (sub, uv)
+            assert fv.suffix_horner(fid, z, C.vec([p - 1])).tobytes() == bytes(32 * n)
+    finally:
+        assert L.nmx_set_option(b"horner_sub", 0) == 0
+
+
 def test_horner_scan_watchdog_falls_back_to_two_pass(nmx):
     """A look-back that gives up (forced: one poll allowed) must end in the right answer through the two-pass kernels, counted
     in nmx_stats -- not in a hang and not in a wrong quotient."""
