@@ -336,7 +336,7 @@ int nmx_set_window_bits(uint32_t c);
  * as its own MSM), "horner_top" (suffix Horner from 1024 coefficients on: 0 = the single-pass scan with decoupled look-back; the two-pass
  * kernels: 8 = 8-coefficient chunks in registers, 4, 1 = chunk-per-lane recursion only), "horner_window" (groups per look-back
  * round of the single-pass scan, 64; 1..63 force its multi-round path in tests), "horner_sub" (512-coefficient sub-tiles per
- * wave of the scan: 0 = by size, 1, 2, 4), "horner_spin_limit" (polls before a wave of the scan gives up and the call falls back
+ * wave of the scan: 0 = by size, 1, 2, 4), "eq_max_blocks" (grid cap of the eq-factored sum passes: 0 = 768 for evaluate_with, 2048 otherwise), "horner_spin_limit" (polls before a wave of the scan gives up and the call falls back
  * to the two-pass kernels: 0 = 2^22; tests set 1),
  * "seg_heavy_above" (pieces per bucket summed without a pre-fold pass: 0 = by table width, else 1..63), "no_tree_fuse" (bucket
  * reduction: 0 = fused levels or one launch per level by the box's measured launch gap, 1 = one launch per level, 2 = fused),

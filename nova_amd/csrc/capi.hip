@@ -147,6 +147,7 @@ static void ensure_init() {
   if (const char* t = getenv("NMX_SYNC_SPIN_US")) G.sync_spin_us = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_HORNER_TOP")) G.horner_top = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_HORNER_SUB")) G.horner_sub = (uint32_t)atoi(t);
+  if (const char* t = getenv("NMX_TUNE_EQ_MAX_BLOCKS")) G.eq_max_blocks = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_SEG_HEAVY_ABOVE")) G.seg_heavy_above = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_ACCUM_PF")) G.accum_prefetch = (uint32_t)atoi(t);
   HIPCHK(hipSetDevice(dev));
@@ -1676,6 +1677,7 @@ int nmx_set_option(const char* name, uint32_t value) {
     else if (n == "horner_top") G.horner_top = value;
     else if (n == "horner_window") G.horner_window = value ? value : 64u;
     else if (n == "horner_sub") G.horner_sub = value;
+    else if (n == "eq_max_blocks") G.eq_max_blocks = value;
     else if (n == "horner_spin_limit") G.horner_spin_limit = value;
     else if (n == "seg_heavy_above") G.seg_heavy_above = value > 63u ? 63u : value;
     else throw Fail{NMX_E_ARG, "unknown option name"};

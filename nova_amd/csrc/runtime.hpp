@@ -281,6 +281,7 @@ struct Global {
   std::atomic<uint32_t> no_quad_final{0};         // env NMX_TUNE_NO_QUAD_FINAL
   std::atomic<uint32_t> accum_prefetch{0};        // env NMX_TUNE_ACCUM_PF / option accum_prefetch: 0 = by table size, 1, 2
   std::atomic<uint32_t> horner_top{0};            // env NMX_TUNE_HORNER_TOP / option horner_top: suffix Horner from 1024 coefficients: 0 = single-pass scan (k_horner_scan); the two-pass kernels: 8 = 8-element chunks in registers, 4, 1 = chunk-per-lane recursion only
+  std::atomic<uint32_t> eq_max_blocks{0};         // option eq_max_blocks: grid cap of the eq-factored sum passes (0 = 2048)
   std::atomic<uint32_t> horner_sub{0};            // option horner_sub: 512-coefficient sub-tiles per wave of the single-pass scan (0 = by size, 1, 2, 4)
   std::atomic<uint32_t> horner_spin_limit{0};     // option horner_spin_limit: polls before a wave of the scan gives up (0 = 2^22; tests set 1 to force the fall-back)
   std::atomic<uint32_t> horner_window{64};        // option horner_window: tiles per look-back round of the single-pass scan (tests: 1 .. 63 force the multi-round path)

@@ -41,6 +41,47 @@ template <int FID> __device__ __forceinline__ Fp<FID> block_sum(Fp<FID> v, uint3
   return v;
 }
 
+// Both sums of a pass at once, the first six levels inside the wave: shuffles instead of LDS round trips and barriers, limbs
+// normalised every second step (inputs canonical), a wave's sum < 64 p brought back below 2 p by one product with 1; then the
+// four wave sums through LDS.  Result valid in thread 0.  The two eight-level LDS trees it replaces in k_eq_rows were ~10 % of a
+// block's time at two rows per block.
+template <int FID> __device__ __forceinline__ void block_sum_pair(Fp<FID>& g0, Fp<FID>& g1, uint32_t* lds /* >= 72 words */) {
+  using F = Fp<FID>;
+  const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+  F x[2] = {g0, g1};
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+#pragma unroll
+    for (uint32_t d = 32; d >= 1; d >>= 1) {
+#pragma unroll
+      for (int i = 0; i < 9; i++) x[j].l[i] += (uint32_t)__shfl_down((int)x[j].l[i], d, 64);
+      if (d == 16 || d == 4 || d == 1) x[j] = x[j].norm();
+    }
+    x[j] = (x[j] * F::one()).canon4();  // lane 0: the wave's sum, < p
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 9; i++) lds[(j * 9 + i) * 4 + wave] = x[j].l[i];
+    }
+  }
+  __syncthreads();
+  if (t == 0) {
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      F acc = F::zero();
+#pragma unroll
+      for (int w = 0; w < 4; w++) {
+        F o;
+#pragma unroll
+        for (int i = 0; i < 9; i++) o.l[i] = lds[(j * 9 + i) * 4 + w];
+        acc = acc + o;
+      }
+      x[j] = acc.norm().canon();  // < 4 p -> < p
+    }
+    g0 = x[0];
+    g1 = x[1];
+  }
+}
+
 // The terms of one index: e0 = a0*b0 - c0 (at product scale) and q = (a1-a0)*(b1-b0), with the eq factor.
 template <int FID, int MODE> struct EqTerm {
   Fp<FID> e0, q, fac;
@@ -114,8 +155,11 @@ __global__ __launch_bounds__(256) void k_eq_sums(const uint32_t* A, const uint32
 // roofline), 5 per index in mode 3.  Here eqL enters once per lane and row and two terms share a reduction -- four in mode 1
 // since round 3 (Fp::dot): 1 + 0.25 + 1/K reductions per element in mode 1, 4 + 2/K per index in mode 3.  A block walks whole rows (2^shift
 // consecutive indices, coalesced); rows shorter than the block share it.
+#ifndef NMX_EQROWS_MINWAVES
+#define NMX_EQROWS_MINWAVES 1  // A/B knob: 4 forces 128 registers (modes 2 / 3 then spill 16)
+#endif
 template <int FID, int MODE>
-__global__ __launch_bounds__(256) void k_eq_rows(const uint32_t* A, const uint32_t* B, const uint32_t* C, const uint32_t* eqL,
+__global__ __launch_bounds__(256, NMX_EQROWS_MINWAVES) void k_eq_rows(const uint32_t* A, const uint32_t* B, const uint32_t* C, const uint32_t* eqL,
                                                  const uint32_t* eqR, uint32_t shift, uint32_t h, Fp<FID> nk,
                                                  uint32_t* partial) {
   using F = Fp<FID>;
@@ -183,11 +227,9 @@ __global__ __launch_bounds__(256) void k_eq_rows(const uint32_t* A, const uint32
       pend_g = 0;
     }
   }
-  g0 = block_sum<FID>(g0.norm().canon(), lds);
-  if (MODE != 1) {
-    __syncthreads();
-    g1 = block_sum<FID>(g1.norm().canon(), lds);
-  }
+  g0 = g0.norm().canon();
+  g1 = g1.norm().canon();
+  block_sum_pair<FID>(g0, g1, lds);
   if (threadIdx.x == 0) {
     g0.to_words(partial + 16 * blockIdx.x);
     g1.to_words(partial + 16 * blockIdx.x + 8);
@@ -278,7 +320,11 @@ static void eq_sums_t(Ctx& c, const void* A, const void* B, const void* C, size_
   const uint32_t h = (uint32_t)(len / 2);
   // >= 8 indices per lane before the (comparatively expensive) LDS tree, at most 2048 blocks
   const uint32_t want = (h + 256 * 8 - 1) / (256 * 8);
-  const uint32_t blocks = want < 1 ? 1 : (want > 2048 ? 2048 : want);
+  // grid cap: the chip holds 768 blocks of these kernels at three waves per SIMD; mode 1 (evaluate_with) runs best with exactly
+  // that many (2^24: 0.140 ms against 0.150 at 2048, 0.168 at 4096), modes 2 / 3 are flat from 768 to 3072 (0.404-0.413 ms) and
+  // keep 2048 (measured on one lease, second half of round 3; NMX_TUNE_EQ_MAX_BLOCKS / option eq_max_blocks)
+  const uint32_t cap = G.eq_max_blocks ? (uint32_t)G.eq_max_blocks : (MODE == 1 ? 768u : 2048u);
+  const uint32_t blocks = want < 1 ? 1 : (want > cap ? cap : want);
   // staging (host operands) + partials + result
   size_t need = (size_t)blocks * 64 + 64 + 512;
   auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
