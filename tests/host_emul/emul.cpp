@@ -252,6 +252,10 @@ template <int FID> static void fp_op_t(int op, const uint8_t* a, const uint8_t* 
     case 13: { F u = F::template mulx<true>(x, y), v = x * y; for (int i = 0; i < 9; i++) if (u.l[i] != v.l[i]) u = F::zero(); r = u.canon(); } break;
     case 14: { F u = F::template sqrx<true>(x), v = x.sqr(); for (int i = 0; i < 9; i++) if (u.l[i] != v.l[i]) u = F::zero(); r = u.canon(); } break;
     case 15: { F u = F::template mul_addx<true>(x, y, y, x), v = F::mul_add(x, y, y, x); for (int i = 0; i < 9; i++) if (u.l[i] != v.l[i]) u = F::zero(); r = u.canon(); } break;
+    // Fp::dot (round 3): up to four products under one reduction, against the same products one by one
+    case 16: { const F a4[4] = {x, y, x, y}, b4[4] = {y, x, x, y}; r = F::template dot<4>(a4, b4).canon(); } break;   // 2xy + x^2 + y^2
+    case 17: { const F a3[3] = {x, x, y}, b3[3] = {y, x, y}; r = F::template dot<3>(a3, b3).canon(); } break;          // xy + x^2 + y^2
+    case 18: { const F a1[1] = {x}, b1[1] = {y}; F u = F::template dot<1>(a1, b1), v = x * y; for (int i = 0; i < 9; i++) if (u.l[i] != v.l[i]) u = F::zero(); r = u.canon(); } break;
     default: r = F::zero();
   }
   fp_to_bytes(r, out);

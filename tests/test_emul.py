@@ -114,6 +114,10 @@ def test_field_ops(emul, fid):
                 assert op(13, a, b) == a * b * Ri % p                     # sos_mul: limb-identical to the chained product
             if 2 * (a // p + 1) * (b // p + 1) < 127:
                 assert op(15, a, b) == 2 * a * b * Ri % p                 # a*b + b*a with one reduction
+            if (a // p + 1 + b // p + 1) ** 2 < 127 and max(a, b) < 1 << 255:  # Fp::dot: normalised limbs, sum of products < 127 p^2
+                assert op(16, a, b) == (a + b) ** 2 * Ri % p              # four products, one reduction
+                assert op(17, a, b) == (a * b + a * a + b * b) * Ri % p   # three
+                assert op(18, a, b) == a * b * Ri % p                     # one: limb-identical to the product
             assert op(1, a, b % (1 << 255)) == (a + b % (1 << 255)) % p
             if b < 2 * p - (1 << 233):
                 assert op(2, a, b) == (a - b) % p
