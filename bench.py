@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--dist", default="random", help="scalar distribution: random | u1 | u10 | u16 | u32 | u64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--window-bits", type=int, default=0)
+    ap.add_argument("--no-tables", action="store_true",
+                    help="register the key WITHOUT window tables: the plain path (W bucket sets) that first / second sight of a "
+                         "cached array, IPA's per-round keys and keys whose tables do not fit take")
     ap.add_argument("--iters", type=int, default=65536, help="prove_step_replay: MinRoot iterations per step")
     ap.add_argument("--workload", default="msm", choices=["msm", "axpy", "cross_term", "bind", "sumcheck3", "round3", "quad_prod", "lincomb8", "horner", "mle_eval", "spmv", "prove_step_replay", "hyperkzg_replay"],
                     help="msm = the headline (default); the others time one HBM-bound field-vector kernel of "
@@ -175,7 +178,7 @@ def main():
         k0 = 1 + rank * n
     ce = nova_amd.CommitmentEngine(cid)
     group = ce.group
-    ck = nova_amd.CommitmentKey.generate(cid, n, k0=k0)
+    ck = nova_amd.CommitmentKey.generate(cid, n, k0=k0, precompute=not args.no_tables)
     # two scalar vectors per rank, alternated between steps, resident in HBM before timing starts
     host_sc = [util.scalar_set(cid, n, args.dist, seed=util.SEED + 1000 * rank + j) for j in range(2)]
     dev_sc = [torch.from_numpy(s.copy()).cuda() for s in host_sc]
@@ -313,21 +316,28 @@ def main():
 
 
 def inprocess_multi(args, torch):
-    """BASELINE.json configs[2] from ONE process: a key of 2^total_log2n points sharded over the GPUs by the library
-    itself (nmx_init_devices: shard i and its window tables resident on GPU i), every step one synchronous
-    nmx_msm_handle call that fans out a host thread + stream per GPU and sums the 128-byte partials on the host.
-    Fewer GPUs visible than asked for: says so on stderr and in the JSON, and runs on what there is."""
+    """BASELINE.json configs[2] from ONE process (what `python bench.py --gpus N` without a launcher runs): a key of
+    2^total_log2n points sharded over the GPUs by the library itself (nmx_init_devices: shard i and its window tables resident
+    on GPU i) and the scalars SHARD-RESIDENT -- piece i drawn on GPU i, handed over as NMX_SCALARS_SHARDED, the way the reference
+    chunks coefficients and bases together (src/provider/msm.rs:564-574).  Every step is one synchronous nmx_msm_handle call
+    that fans out a host thread + stream per GPU; the 128-byte partials are all-gathered over RCCL (one rank per GPU) and
+    summed.  One result is compared with the CPU oracle at FULL size.  Fewer GPUs visible than asked for: says so on stderr
+    and in the JSON, and runs on what there is."""
     import nova_amd
     from nova_amd import _lib
-    from tests import util
     L = _lib.lib()
     assert L.nmx_init(0) == 0, L.nmx_last_error().decode()
     visible = L.nmx_device_count()
-    k = min(args.gpus, visible)
+    oversub = os.environ.get("NMX_BENCH_OVERSUB") == "1"   # builder's 1-GPU boxes: N logical devices on the GPUs there are
+    k = args.gpus if oversub else min(args.gpus, visible)
     if k < args.gpus:
         print(f"bench.py: WARNING --gpus {args.gpus} requested but only {visible} HIP device(s) visible: running the "
               f"in-process sharded MSM on {k} device(s)", file=sys.stderr, flush=True)
-    assert nova_amd.init_devices(k) == k, L.nmx_last_error().decode()
+    assert nova_amd.init_devices(k, oversubscribe=oversub) == k, L.nmx_last_error().decode()
+    if oversub:
+        assert L.nmx_set_option(b"shard_min_n", 1024) == 0
+    if os.environ.get("NMX_BENCH_COMBINE"):           # 1 = host sum, 2 = RCCL required (also with one GPU)
+        assert L.nmx_set_option(b"combine", int(os.environ["NMX_BENCH_COMBINE"])) == 0
     cid = args.curve
     total = 1 << args.inproc_log2n
     torch.cuda.set_device(0)
@@ -335,30 +345,57 @@ def inprocess_multi(args, torch):
     ck = nova_amd.CommitmentKey.generate(cid, total, k0=1)   # P_i = (1 + i) G, cut into k contiguous shards
     t_key = time.perf_counter() - t0
     group = nova_amd.DlogGroup(cid)
-    # 2^22 random scalars tiled: drawing 2^24 by rejection sampling on the host takes longer than the whole run
-    base = util.scalar_set(cid, min(total, 1 << 22), args.dist, seed=util.SEED + 7)
-    host = np.tile(base, (total // len(base), 1)) if total > len(base) else base
-    dev_sc = [torch.from_numpy(host.copy()).cuda(), torch.from_numpy(np.ascontiguousarray(host[::-1])).cuda()]
+    plan = nova_amd.shard_plan(total, k, 0, total)            # [(logical device, offset in the shard, count)]
+    assert args.dist == "random", "the in-process mode draws its scalars on the devices: --dist random only"
+
+    def draw(dev, cnt, seed):
+        """cnt uniformly random 253-bit scalars (all below the 254 / 255-bit moduli), drawn ON GPU `dev`."""
+        dev = dev % visible
+        g = torch.Generator(device=f"cuda:{dev}")
+        g.manual_seed(seed)
+        w = torch.randint(0, 1 << 31, (cnt, 8), dtype=torch.int64, device=f"cuda:{dev}", generator=g)
+        w = (w * 2 + torch.randint(0, 2, (cnt, 8), dtype=torch.int64, device=f"cuda:{dev}", generator=g)).to(torch.int32)
+        w[:, 7] &= 0x1FFFFFFF
+        return w.view(torch.uint8).reshape(cnt, 32).contiguous()
+
+    # two scalar vectors, alternated between steps; piece i of each lives in the HBM of GPU i (logical device i = HIP device i)
+    sets = [[draw(dev, cnt, 1000 * j + dev + 1) for dev, _off, cnt in plan] for j in range(2)]
+    ndev_sync = min(k, visible)
+    for d in range(ndev_sync):
+        torch.cuda.synchronize(d)
     for j in range(args.warmup):
-        group.vartime_multiscalar_mul(dev_sc[j & 1], ck)
+        group.vartime_multiscalar_mul(sets[j & 1], ck)
     before = _lib.stats()[_lib.STAT_SHARDED_CALLS]
-    for d in range(k):
+    L.nmx_set_profiling(1)
+    import ctypes
+    prof = (ctypes.c_float * 16)()
+    shard_sum, combine_sum, ranks, branches = None, 0.0, 0, None
+    stage_sum = np.zeros(len(STAGES))
+    for d in range(ndev_sync):
         torch.cuda.synchronize(d)
     t0 = time.perf_counter()
     res = None
+    per_call = []
     for j in range(args.steps):
-        res = group.vartime_multiscalar_mul(dev_sc[j & 1], ck)   # synchronous: returns the affine point
-    for d in range(k):
+        tj = time.perf_counter()
+        res = group.vartime_multiscalar_mul(sets[j & 1], ck)   # synchronous: returns the affine point
+        per_call.append(time.perf_counter() - tj)
+        nst = L.nmx_profile_last(prof, 16)
+        stage_sum[:min(nst, len(STAGES))] += np.array(prof[:min(nst, len(STAGES))])
+        if k > 1:
+            rec = _lib.profile_last_sharded()
+            m = np.array([s["stages_ms"] for s in rec["shards"]])
+            shard_sum = m if shard_sum is None else shard_sum + m
+            combine_sum += rec["combine_ms"]
+            ranks, branches = rec["rccl_ranks"], [s["branch"] for s in rec["shards"]]
+    for d in range(ndev_sync):
         torch.cuda.synchronize(d)
     dt = time.perf_counter() - t0
+    L.nmx_set_profiling(0)
     sharded_calls = _lib.stats()[_lib.STAT_SHARDED_CALLS] - before
-    # size-independent check at full size: the two halves of the key (which straddle the shards differently) add up
-    half = total // 2
-    a = group.vartime_multiscalar_mul(dev_sc[0][:half], ck, partial=True)
-    b = group.vartime_multiscalar_mul(dev_sc[0][half:], ck, partial=True, offset=half)
-    whole = group.vartime_multiscalar_mul(dev_sc[0], ck)
-    halves_ok = group.point_sum([a.xy, b.xy]) == whole
+    last = sets[(args.steps - 1) & 1]
     name = nova_amd.CURVE_NAMES[cid]
+    steps = max(args.steps, 1)
     out = {
         "metric": "BN254 MSM scalar-point pairs/sec" if cid == 0 else f"{name} MSM scalar-point pairs/sec",
         "value": total * args.steps / dt,
@@ -367,7 +404,7 @@ def inprocess_multi(args, torch):
         "requested_gpus": args.gpus,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3,
+        "ms_per_step": dt / steps * 1e3,
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
@@ -375,21 +412,74 @@ def inprocess_multi(args, torch):
         "data": "synthetic",
         "config": {
             "workload": f"{name} Pippenger MSM, 2^{total.bit_length() - 1} pairs of one key sharded contiguously over {k} "
-                        f"GPU(s) by ONE host process (nmx_init_devices; BASELINE.json configs[2]), {args.dist} scalars "
-                        "(2^22 drawn, tiled) resident in the HBM of GPU 0 -- the other shards pull their slice over xGMI "
-                        "inside the call --, one 128-byte partial per shard summed on the host",
+                        f"GPU(s) by ONE host process (nmx_init_devices; BASELINE.json configs[2]), 2^{total.bit_length() - 1} "
+                        "distinct uniformly random 253-bit scalars SHARD-RESIDENT (piece i drawn in the HBM of GPU i, "
+                        "NMX_SCALARS_SHARDED: nothing crosses xGMI or PCIe inside the call), one 128-byte partial per shard, "
+                        "all-gathered over RCCL and summed",
             "pairs_total": total,
             "pairs_per_gpu": total // k,
             "parallelism": f"in-process shard{k}" if k > 1 else "single (in-process mode, one device visible)",
-            "combine": "host sum of 128-byte partials (nmx_point_sum)" if k > 1 else "none",
+            "combine": ("rccl all_gather of 128-byte partials (one rank per GPU) + host point sum" if ranks
+                        else "host sum of 128-byte partials (nmx_point_sum)") if k > 1 else "none",
         },
+        "per_call_ms": {"median": round(float(np.median(per_call)) * 1e3, 4), "min": round(min(per_call) * 1e3, 4)},
+        "stages_ms": {s: round(float(v) / steps, 4) for s, v in zip(STAGES, stage_sum)},
+        "rccl_ranks": ranks,
+        "combine_ms": round(combine_sum / steps, 4),
         "sharded_calls": sharded_calls,
         "key_generation_s": round(t_key, 3),
-        "halves_sum_to_whole": bool(halves_ok),
         "last_result_is_inf": bool(res.is_inf),
     }
+    if k > 1 and shard_sum is not None:
+        out["stages_ms"]["_what"] = "per stage, the slowest shard (the call waits for all of them)"
+        out["shards"] = [{"gpu": plan[i][0], "pairs": plan[i][2], "scalars": branches[i],
+                          "stages_ms": {s: round(float(v) / steps, 4) for s, v in zip(STAGES, shard_sum[i])}}
+                         for i in range(len(plan))]
+    accum_ms = out["stages_ms"]["accum"]
+    per_gpu = max(c for _d, _o, c in plan)
+    if accum_ms > 0:
+        ach = BYTES_PER_PAIR * per_gpu / (accum_ms * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "k_launch<AccumSegFn> (bucket accumulation, segment-balanced), slowest shard",
+                           "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "note": "96 B/pair x pairs of one shard / that shard's accumulate-kernel time (hipEvents on the library "
+                                   "stream); the MSM is integer-VALU-bound, not HBM-bound (DESIGN.md section 5)"}
+    # contrast: the same call with ONE HBM array on GPU 0 (NMX_SCALARS_DEVICE), every other shard pulling its slice over xGMI
+    # inside the call -- what round 3 timed
+    if k > 1 and not args.no_extras:
+        try:
+            one = torch.cat([p.to("cuda:0") for p in last]).contiguous()
+            torch.cuda.synchronize(0)
+            group.vartime_multiscalar_mul(one, ck)
+            ts = []
+            for _ in range(3):
+                tj = time.perf_counter()
+                r1 = group.vartime_multiscalar_mul(one, ck)
+                ts.append(time.perf_counter() - tj)
+            out["scalars_on_gpu0"] = {"ms": round(float(np.median(ts)) * 1e3, 4), "matches": r1 == res,
+                                      "branches": [s["branch"] for s in _lib.profile_last_sharded()["shards"]],
+                                      "what": "same pairs, scalars in ONE array on GPU 0: every other shard pulls its slice peer-to-peer inside the call"}
+            del one
+        except (RuntimeError, nova_amd.NmxError) as e:
+            out["scalars_on_gpu0"] = {"error": str(e)}
+    # the CPU oracle at FULL size on the last timed input: the baseline and the bit-exact check in one pass
+    if not args.no_cpu_baseline:
+        from oracle import cref
+        threads = effective_cpus()
+        cref.set_threads(threads)
+        host_sc = np.concatenate([p.cpu().numpy() for p in last])
+        host_b = ck.read(0, total)
+        t1 = time.perf_counter()
+        exp = cref.msm(cid, host_sc, host_b, total)
+        t_cpu = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": total / t_cpu, "unit": "pairs/s", "cores": threads, "kind": "port",
+                               "sample": f"the whole workload once (2^{total.bit_length() - 1} pairs), oracle/nova_ref.c (C restatement of "
+                                         "msm.rs + Pippenger in the msm_best role; the Rust reference cannot be built here)",
+                               "seconds": round(t_cpu, 3), "gpu_matches_cpu": (res.xy, int(res.is_inf)) == exp}
+        del host_sc, host_b
     if k < args.gpus:
         out["fallback"] = f"{args.gpus} GPUs requested, {visible} visible"
+    if oversub:
+        out["oversubscribed"] = f"{k} logical devices on {visible} GPU(s) (NMX_BENCH_OVERSUB=1): a functional run, not a scaling point"
     ck.close()
     return out
 

@@ -44,6 +44,13 @@ enum {
                                 /* MSMs over >= 4096 points of such a key run all windows into one bucket set. */
   NMX_BASES_NOCACHE = 1u << 7,  /* slice-form calls (nmx_msm, nmx_msm_u64, nmx_msm_batch): do not look the base  */
                                 /* array up in / insert it into the slice cache (one-shot arrays)               */
+  NMX_SCALARS_SHARDED = 1u << 8, /* shard-resident scalars (nmx_msm_handle, nmx_msm_u64_handle with an explicit max_num_bits,
+                                    nmx_commit, nmx_msm_batch_handle): `scalars` is a HOST array of device pointers, one per
+                                    piece that nmx_shard_plan(key length, nmx_devices_in_use(), offset, n) reports, in its
+                                    order; piece j = the `count_j` scalars of the pairs whose bases live on `device_j`, in
+                                    the HBM of THAT device -- the reference chunks coefficients and bases together
+                                    (src/provider/msm.rs:564-574), so nothing crosses xGMI or PCIe inside the call.  A key on
+                                    one device has one piece.  nmx_svec_* allocates vectors in this layout.          */
   NMX_OUT_PARTIAL = 1u << 4     /* write a 128-byte partial sum instead of an affine point: the per-GPU   */
                                 /* result of a sharded MSM, input of nmx_point_sum.  Format: extended     */
                                 /* Jacobian (X, Y, ZZ, ZZZ), x = X/ZZ, y = Y/ZZZ, each coordinate the     */
@@ -83,10 +90,15 @@ int nmx_device_count(void);
  * nmx_bases_generate, and the slice cache behind nmx_msm / nmx_msm_u64 / nmx_msm_batch -- is cut into k contiguous shards
  * (shard i = points [i*n/k ...), exactly nova_amd/dist.py shard_range), shard i resident on device i with its own window
  * tables.  An MSM / commit over such a key runs one host thread + stream per shard touched, each producing a 128-byte
- * partial, summed on the host (the G-term combine of nmx_point_sum): no bucket array crosses devices, and the call is
- * still one synchronous C call.  HBM-resident scalars (NMX_SCALARS_DEVICE) live on logical device 0; a shard on another
- * GPU pulls its slice peer-to-peer over xGMI.  Field-vector kernels, keys below the threshold and keys registered from a
- * device pointer stay on logical device 0.  Without this call (or env NMX_DEVICES=k) the library uses one device, as
+ * partial.  The combine step: with the shards on two or more GPUs ONE ncclAllGather of the 128-byte
+ * partials over xGMI (RCCL, bound at run time; one rank per GPU, issued by the calling thread inside a group call) followed by
+ * the G-term point sum on the host from rank 0's copy; on one GPU, without RCCL, or with nmx_set_option("combine", 1): the
+ * host sum of the partials (nmx_point_sum).  No bucket array crosses devices, and the call is still one synchronous C call.
+ * Scalars: shard-resident (NMX_SCALARS_SHARDED, nmx_svec_*: each piece already in the HBM of the GPU that holds its bases --
+ * the intended form), or one HBM array on logical device 0 (NMX_SCALARS_DEVICE: a shard on another GPU pulls its slice
+ * peer-to-peer over xGMI inside the call), or host memory (each GPU pulls its slice over its own PCIe link).
+ * Field-vector kernels on plain pointers, keys below the threshold and keys registered from a device pointer stay on logical
+ * device 0; nmx_svec_map runs the NIFS kernels shard by shard.  Without this call (or env NMX_DEVICES=k) the library uses one device, as
  * before.  May be called again to change k (keys keep the layout they were registered with). */
 #define NMX_DEVICES_OVERSUBSCRIBE 1u
 int nmx_init_devices(int count, uint32_t flags);
@@ -227,6 +239,34 @@ int nmx_msm_batch_handle(uint64_t handle, const void* const* scalar_vecs, const 
 int nmx_commit(uint64_t ck_handle, const void* v, size_t n, const void* h_xy64, const void* r,
                uint32_t flags, uint8_t* out, uint8_t* out_is_inf);
 
+/* ---- shard-resident vectors (multi-device keys) ----------------------------
+ * A field vector laid out like the key it will be committed against: element i lives in the HBM of the device that holds
+ * point i of a key of `n_key` points (nmx_shard_plan(n_key, nmx_devices_in_use(), 0, n)), so W, E, T are BORN on the shard
+ * that commits them -- the reference chunks coefficients and bases together (src/provider/msm.rs:564-574).  Elements are raw
+ * 32-byte words (canonical or Montgomery: the caller's choice, stated per call with NMX_SCALARS_MONT as everywhere else).
+ *   nmx_svec_alloc / free / write (host -> shards) / read (shards -> host)
+ *   nmx_svec_parts: the pieces (device pointer, element count, HIP device ordinal) for hosts that fill them with their own
+ *     kernels; returns the number of pieces
+ *   nmx_svec_map: the element-wise NIFS kernels shard by shard, every GPU on its own piece at the same time --
+ *     NMX_OP_AXPY  out = in0 + r*in1                       RelaxedR1CSWitness::fold   src/r1cs/mod.rs:1058-1067
+ *     NMX_OP_AXPY2 out = in0 + r*in1 + r^2*in2             fold_relaxed               src/r1cs/mod.rs:1096-1101
+ *     NMX_OP_CROSS_TERM  out = in0*in1 - u*in2 - in3       commit_T                   src/r1cs/mod.rs:614-620
+ *     NMX_OP_CROSS_TERM2 out = in0*in1 - u*in2 - in3 - in4 commit_T_relaxed           src/r1cs/mod.rs:652-659
+ *     NMX_OP_VEC_ADD out = in0 + in1                       Z = Z1 + Z2                src/r1cs/mod.rs:590-609
+ *     (`challenge` = r or u, host pointer; operands and `out` must share one layout; out may be an operand)
+ *   nmx_msm_svec / nmx_commit_svec: nmx_msm_handle(key, 0, ..) / nmx_commit over the first n elements, the scalars taken
+ *     shard by shard from the vector (it must have been allocated with n_key = the key's length). */
+enum { NMX_OP_AXPY = 0, NMX_OP_AXPY2 = 1, NMX_OP_CROSS_TERM = 2, NMX_OP_CROSS_TERM2 = 3, NMX_OP_VEC_ADD = 4 };
+int nmx_svec_alloc(size_t n_key, size_t n, uint64_t* svec);
+int nmx_svec_free(uint64_t svec);
+int nmx_svec_write(uint64_t svec, const void* host_elems32);
+int nmx_svec_read(uint64_t svec, void* host_elems32);
+int nmx_svec_parts(uint64_t svec, void** dev_ptrs, size_t* counts, int* hip_devices, int cap);
+int nmx_svec_map(int field, int op, const uint64_t* in, int n_in, const void* challenge, uint32_t flags, uint64_t out);
+int nmx_msm_svec(uint64_t key_handle, uint64_t svec, size_t n, uint32_t flags, uint8_t* out, uint8_t* out_is_inf);
+int nmx_commit_svec(uint64_t ck_handle, uint64_t svec, size_t n, const void* h_xy64, const void* r, uint32_t flags,
+                    uint8_t* out, uint8_t* out_is_inf);
+
 /* Sum of `count` 128-byte partials (NMX_OUT_PARTIAL results gathered from the ranks of a sharded MSM) into one
  * affine point: the G-term combine of SURVEY.md 8(e) (the reference's rayon `reduce(identity, +)`,
  * src/provider/msm.rs:566-571,667-673). */
@@ -326,6 +366,18 @@ int nmx_spmv_apply_pair(uint64_t handle, const void* z1, const void* z2, size_t 
  * stage order: digits, sort, bounds+plan, accum, fold, reduce, tail(D2H+host Horner) ; returns #stages. */
 int nmx_set_profiling(int on);
 int nmx_profile_last(float* ms, int cap);
+/* The calling thread's last MSM over a multi-device key, shard by shard: returns the number of shards; for shard j < cap
+ * ms[j * NMX_PROF_STAGES + s] = its stage times (profiling on; same stage order), dev[j] = its logical device, branch[j] =
+ * where its scalars came from (NMX_BRANCH_*); *combine_ms = the combine step alone (all-gather + point sum), *rccl_ranks =
+ * ranks of the RCCL communicator it used (0: host sum).  After such a call nmx_profile_last gives the per-stage maximum
+ * over the shards. */
+#define NMX_PROF_STAGES 12
+enum { NMX_BRANCH_HOST = 0,          /* host scalars: the shard's GPU pulled its slice over its own PCIe link            */
+       NMX_BRANCH_LOCAL = 1,         /* one HBM array on device 0, this shard is on device 0: used in place              */
+       NMX_BRANCH_PEER_COPY = 2,     /* one HBM array on device 0, this shard elsewhere: hipMemcpyPeerAsync over xGMI    */
+       NMX_BRANCH_SHARD_RESIDENT = 3,/* NMX_SCALARS_SHARDED: the piece was already in this GPU's HBM                     */
+       NMX_BRANCH_NONE = 4 };        /* no scalar array (all-ones sparse form)                                           */
+int nmx_profile_last_sharded(float* ms, int* dev, int* branch, int cap, float* combine_ms, int* rccl_ranks);
 /* forces the window width (0 = heuristic) -- tuning / tests only */
 int nmx_set_window_bits(uint32_t c);
 /* Pipeline selection knobs for A/B measurements and tests (the same ones the NMX_TUNE_* environment variables set at
@@ -341,7 +393,11 @@ int nmx_set_window_bits(uint32_t c);
  * "seg_heavy_above" (pieces per bucket summed without a pre-fold pass: 0 = by table width, else 1..63), "no_tree_fuse" (bucket
  * reduction: 0 = fused levels or one launch per level by the box's measured launch gap, 1 = one launch per level, 2 = fused),
  * "hist_grid" (blocks of the partition's counting pass; 0 = as the placing pass: measured flat, profiles/r03_msm_2p20/tail_ab.txt),
- * "shard_min_n", "cache_table_after", "max_table_mib" (see the sections above).
+ * "shard_min_n", "cache_table_after", "max_table_mib" (see the sections above), "force_peer_copy" (1: the HBM-resident scalars of
+ * a sharded call are staged through hipMemcpyPeerAsync even when the shard sits on the source GPU: exercises the cross-device
+ * branch on a one-GPU box), "combine" (0: RCCL all-gather when the shards sit on two or more GPUs, else the host sum; 1: host
+ * sum; 2: RCCL required -- also with one GPU, an error if it cannot be loaded), "cache_verify" (0: every slice-cache hit
+ * re-hashes the caller's whole slice; 1: rolling window, for callers that register immutable keys).
  * Unknown name: NMX_E_ARG. */
 int nmx_set_option(const char* name, uint32_t value);
 

@@ -8,5 +8,5 @@ tests and bench.py; it never computes a group operation itself.
 from . import _lib  # noqa: F401
 from .provider import (  # noqa: F401
     BN254_G1, GRUMPKIN, PALLAS, VESTA, CURVE_NAMES, Commitment, CommitmentEngine, CommitmentKey, DlogGroup,
-    NmxError, init_devices, shard_plan,
+    NmxError, ShardedVector, init_devices, shard_plan, svec_map,
 )

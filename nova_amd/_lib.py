@@ -8,6 +8,10 @@ SO_PATH = os.environ.get("NMX_SO") or os.path.join(_HERE, "libnova_mi355x.so")  
 # flags / error codes (include/nova_mi355x.h)
 SCALARS_MONT, BASES_MONT, SCALARS_DEVICE, BASES_DEVICE, OUT_PARTIAL, BASES_PRECOMPUTE, BASES_VALIDATE = 1, 2, 4, 8, 16, 32, 64
 BASES_NOCACHE = 128
+SCALARS_SHARDED = 256
+OP_AXPY, OP_AXPY2, OP_CROSS_TERM, OP_CROSS_TERM2, OP_VEC_ADD = range(5)
+BRANCH_NAMES = {0: "host", 1: "local", 2: "peer_copy", 3: "shard_resident", 4: "none"}
+PROF_STAGES = 12
 # nmx_stats indices
 (STAT_CACHE_HITS, STAT_CACHE_UPLOADS, STAT_CACHE_REGROWS, STAT_CACHE_EVICTIONS, STAT_CACHE_ENTRIES, STAT_CACHE_BYTES,
  STAT_UNCACHED_CALLS, STAT_BASE_BYTES_H2D, STAT_MSM_CALLS, STAT_FUSED_RUNS, STAT_SHARDED_CALLS, STAT_CACHE_STALE,
@@ -61,6 +65,15 @@ def lib():
     L.nmx_msm_batch_handle.argtypes = [u64, vp, vp, sz, u32, vp, vp]
     L.nmx_commit.argtypes = [u64, vp, sz, vp, vp, u32, vp, vp]
     L.nmx_point_sum.argtypes = [i, vp, sz, vp, vp]
+    L.nmx_svec_alloc.argtypes = [sz, sz, ctypes.POINTER(u64)]
+    L.nmx_svec_free.argtypes = [u64]
+    L.nmx_svec_write.argtypes = [u64, vp]
+    L.nmx_svec_read.argtypes = [u64, vp]
+    L.nmx_svec_parts.argtypes = [u64, vp, vp, vp, i]
+    L.nmx_svec_map.argtypes = [i, i, vp, i, vp, u32, u64]
+    L.nmx_msm_svec.argtypes = [u64, u64, sz, u32, vp, vp]
+    L.nmx_commit_svec.argtypes = [u64, u64, sz, vp, vp, u32, vp, vp]
+    L.nmx_profile_last_sharded.argtypes = [vp, vp, vp, i, vp, vp]
     L.nmx_field_axpy.argtypes = [i, vp, vp, vp, sz, u32, vp]
     L.nmx_field_axpy2.argtypes = [i, vp, vp, vp, vp, sz, u32, vp]
     L.nmx_field_cross_term.argtypes = [i, vp, vp, vp, vp, vp, sz, u32, vp]
@@ -94,6 +107,19 @@ def lib():
     L.nmx_stats.argtypes = [ctypes.POINTER(u64), i]
     _lib = L
     return L
+
+
+def profile_last_sharded(cap=64):
+    """nmx_profile_last_sharded of the calling thread -> {"shards": [{"dev", "branch", "stages_ms"}], "combine_ms", "rccl_ranks"}."""
+    ms = (ctypes.c_float * (PROF_STAGES * cap))()
+    dev = (ctypes.c_int * cap)()
+    br = (ctypes.c_int * cap)()
+    cms = ctypes.c_float(0)
+    ranks = ctypes.c_int(0)
+    n = lib().nmx_profile_last_sharded(ms, dev, br, cap, ctypes.byref(cms), ctypes.byref(ranks))
+    return {"shards": [{"dev": dev[j], "branch": BRANCH_NAMES.get(br[j], str(br[j])),
+                        "stages_ms": [round(ms[j * PROF_STAGES + q], 4) for q in range(7)]} for j in range(min(n, cap))],
+            "combine_ms": round(cms.value, 4), "rccl_ranks": ranks.value}
 
 
 def stats():

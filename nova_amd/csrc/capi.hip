@@ -9,6 +9,7 @@
 #include <thread>
 
 #include "runtime.hpp"
+#include "combine.hpp"
 
 namespace nmx {
 
@@ -75,6 +76,16 @@ int32_t launch_gap_ns(hipStream_t stream) {
 static thread_local std::string t_err;
 static thread_local float t_prof[kMaxMarks];
 static thread_local int t_prof_n = 0;
+static RcclCombine& RC = *new RcclCombine;  // never destroyed (see G); nmx_shutdown releases its communicators
+// Record of the calling thread's last MSM over a multi-device key (nmx_profile_last_sharded): where every shard's scalars came
+// from, its stage times (profiling on) and what the combine step cost.
+struct ShardRec {
+  int dev = 0, branch = 0, nst = 0;
+  float ms[kMaxMarks] = {0};
+};
+static thread_local std::vector<ShardRec> t_shards;
+static thread_local float t_combine_ms = 0;
+static thread_local int t_rccl_ranks = 0;
 
 void prof_store(const float* ms, int n) {
   t_prof_n = n < kMaxMarks ? n : kMaxMarks;
@@ -220,15 +231,11 @@ static uint64_t publish(std::shared_ptr<BaseSet> bs) {
 // key[offset, offset + n) inside the registered key?  Written so that offset + n cannot wrap (the Rust slice would
 // have panicked; a C caller must get an error, not an out-of-bounds HBM read).
 static inline bool slice_ok(const BaseSet& bs, size_t offset, size_t n) { return offset <= bs.n && n <= bs.n - offset; }
-struct JoinAll {  // unwinding must never destroy a joinable std::thread (std::terminate)
-  std::vector<std::thread>& th;
-  ~JoinAll() {
-    for (auto& t : th)
-      if (t.joinable()) t.join();
-  }
-};
+static_assert(kMaxMarks == NMX_PROF_STAGES, "nmx_profile_last_sharded's row length");
 static MsmCall field_call(const void* scalars, uint32_t flags) {
-  return MsmCall{scalars, (flags & NMX_SCALARS_DEVICE) != 0, (flags & NMX_SCALARS_MONT) != 0, 0, false};
+  MsmCall m{scalars, (flags & (NMX_SCALARS_DEVICE | NMX_SCALARS_SHARDED)) != 0, (flags & NMX_SCALARS_MONT) != 0, 0, false};
+  m.scalars_sharded = (flags & NMX_SCALARS_SHARDED) != 0;
+  return m;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -356,38 +363,137 @@ static std::vector<PartJob> parts_of(const BaseSet& bs, size_t offset, size_t n)
   }
   return jobs;
 }
-// out = sum scalars[i] * key[offset + i] for any key: one device, or one partial per shard touched + a host sum
+// The combine step of a sharded call: `cnt` 128-byte partials, partial i computed on logical device devs[i].  With the shards
+// on two or more GPUs: one slot per GPU (shards that share a GPU under NMX_DEVICES_OVERSUBSCRIBE are summed first; a GPU the
+// call did not touch sends the identity), ONE ncclAllGather over xGMI, then the G-term point sum on the host from rank 0's
+// copy -- k <= 8 additions of ~0.5 us each: a one-wave device kernel would pay ~2.6 us of latency per dependent addition
+// (profiles/r03_msm_2p20/add_latency.txt).  Otherwise (one GPU, option combine = 1, RCCL not loadable): the host sum of
+// the partials the shard workers already hold.
+enum { NMX_COMBINE_AUTO = 0, NMX_COMBINE_HOST = 1, NMX_COMBINE_RCCL = 2 };
+static void combine_partials(const CurveOps& o, const uint8_t* partials, const std::vector<int>& devs, uint32_t flags,
+                             uint8_t* out, uint8_t* inf) {
+  const auto t0 = std::chrono::steady_clock::now();
+  const size_t cnt = devs.size();
+  const uint32_t mode = G.combine_mode.load(std::memory_order_relaxed);
+  int used_ranks = 0;
+  std::vector<int> phys;  // distinct GPUs of the ACTIVE logical devices, in logical order: the communicator's ranks
+  {
+    const uint32_t nd = G.ndev_active.load(std::memory_order_relaxed);
+    for (uint32_t i = 0; i < nd; i++) {
+      const int h = hip_device_of((int)i);
+      if (std::find(phys.begin(), phys.end(), h) == phys.end()) phys.push_back(h);
+    }
+  }
+  const bool want = mode == NMX_COMBINE_RCCL || (mode == NMX_COMBINE_AUTO && phys.size() >= 2);
+  bool done = false;
+  if (want && cnt >= 1) {
+    std::lock_guard<std::mutex> lk(RC.mu);
+    if (RC.ensure_locked(phys)) {
+      try {
+        const size_t R = phys.size();
+        std::vector<uint8_t> slots(R * kCombineSlot, 0), gathered(R * kCombineSlot);  // zero bytes: ZZ = 0, the identity
+        for (size_t r = 0; r < R; r++) {
+          std::vector<uint8_t> mine;
+          for (size_t i = 0; i < cnt; i++)
+            if (hip_device_of(devs[i]) == phys[r]) mine.insert(mine.end(), partials + 128 * i, partials + 128 * i + 128);
+          if (mine.size() == 128) memcpy(slots.data() + r * kCombineSlot, mine.data(), 128);
+          else if (!mine.empty()) o.point_sum(mine.data(), mine.size() / 128, NMX_OUT_PARTIAL, slots.data() + r * kCombineSlot, nullptr);
+        }
+        RC.all_gather_locked(slots.data(), gathered.data());
+        o.point_sum(gathered.data(), R, flags, out, inf);
+        used_ranks = (int)R;
+        done = true;
+      } catch (const Fail&) {
+        (void)hipGetLastError();
+        if (mode == NMX_COMBINE_RCCL) {
+          (void)hipSetDevice(G.device);
+          throw;
+        }
+      }
+    } else if (mode == NMX_COMBINE_RCCL) {
+      (void)hipSetDevice(G.device);
+      throw Fail{NMX_E_HIP, "option combine = 2 (RCCL required): " + RC.why};
+    }
+    (void)hipSetDevice(G.device);
+  }
+  if (!done) o.point_sum(partials, cnt, flags, out, inf);
+  t_rccl_ranks = used_ranks;
+  t_combine_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+// out = sum scalars[i] * key[offset + i] for any key: one device, or one partial per shard touched + the combine step
 static void key_msm(Ctx& c0, const BaseSet& bs, size_t offset, size_t n, const MsmCall& mc, uint32_t flags, uint8_t* out,
                     uint8_t* inf) {
   const CurveOps& o = ops(bs.curve);
   if (bs.parts.empty()) {
+    if (mc.scalars_sharded) {  // one piece: the pointer array has one entry, on the key's device
+      MsmCall m = mc;
+      m.scalars = n ? ((const void* const*)mc.scalars)[0] : nullptr;
+      m.scalars_device = true;
+      m.scalars_sharded = false;
+      require(m.scalars || n == 0, NMX_E_ARG, "null shard pointer");
+      o.msm_key(c0, bs, offset, n, m, flags, out, inf);
+      return;
+    }
     o.msm_key(c0, bs, offset, n, mc, flags, out, inf);
     return;
   }
   require(!mc.gather_host, NMX_E_ARG, "internal: sparse calls over a sharded key go through key_msm_sparse");
   const std::vector<PartJob> jobs = parts_of(bs, offset, n);
   std::vector<uint8_t> partials(128 * (jobs.size() ? jobs.size() : 1));
+  std::vector<ShardRec> recs(jobs.size());
   const size_t sbytes = mc.u64_mode ? 8 : 32;
+  const bool force_peer = G.force_peer_copy.load(std::memory_order_relaxed) != 0;
+  if (mc.scalars_sharded)
+    for (size_t i = 0; i < jobs.size(); i++)
+      require(((const void* const*)mc.scalars)[i] != nullptr, NMX_E_ARG, "null shard pointer");
   run_on_parts(jobs.size(), true, [&](size_t i) {
     const PartJob& j = jobs[i];
     CtxLease L(j.part->dev);
     MsmCall m = mc;
-    if (mc.scalars) {
+    m.scalars_sharded = false;
+    recs[i].dev = j.part->dev;
+    recs[i].branch = NMX_BRANCH_NONE;
+    if (mc.scalars_sharded) {
+      // shard-resident operands (the reference chunks coefficients and bases together, msm.rs:564-574): piece i of the
+      // scalars already lives on this shard's GPU -- nothing crosses xGMI or PCIe inside the call
+      m.scalars = ((const void* const*)mc.scalars)[i];
+      m.scalars_device = true;
+      recs[i].branch = NMX_BRANCH_SHARD_RESIDENT;
+    } else if (mc.scalars) {
       const char* src = (const char*)mc.scalars + j.goff * sbytes;
-      if (mc.scalars_device && hip_device_of(j.part->dev) != G.device) {
+      if (mc.scalars_device && (hip_device_of(j.part->dev) != G.device || force_peer)) {
         // HBM-resident scalars live on the primary device: this shard's slice crosses xGMI once, peer to peer
         aux_reserve(*L.c, j.cnt * sbytes);
         HIPCHK(hipMemcpyPeerAsync(L.c->aux, hip_device_of(j.part->dev), src, G.device, j.cnt * sbytes, L.c->stream));
         m.scalars = L.c->aux;
+        recs[i].branch = NMX_BRANCH_PEER_COPY;
       } else {
         m.scalars = src;
+        recs[i].branch = mc.scalars_device ? NMX_BRANCH_LOCAL : NMX_BRANCH_HOST;
       }
     }
     o.msm_key(*L.c, *j.part, j.poff, j.cnt, m, (flags & ~(uint32_t)NMX_OUT_PARTIAL) | NMX_OUT_PARTIAL,
               partials.data() + 128 * i, nullptr);
+    if (G.profiling.load(std::memory_order_relaxed)) {  // this worker's stage times, handed to the calling thread below
+      recs[i].nst = t_prof_n;
+      for (int q = 0; q < t_prof_n; q++) recs[i].ms[q] = t_prof[q];
+    }
   });
   stat_add(NMX_STAT_SHARDED_CALLS, 1);
-  o.point_sum(partials.data(), jobs.size(), flags, out, inf);
+  std::vector<int> devs(jobs.size());
+  for (size_t i = 0; i < jobs.size(); i++) devs[i] = jobs[i].part->dev;
+  combine_partials(o, partials.data(), devs, flags, out, inf);
+  t_shards.swap(recs);
+  // nmx_profile_last on the calling thread: the slowest shard stage by stage (the call waits for all of them)
+  if (G.profiling.load(std::memory_order_relaxed) && !t_shards.empty()) {
+    float mx[kMaxMarks] = {0};
+    int ns = 0;
+    for (const ShardRec& r : t_shards) {
+      ns = r.nst > ns ? r.nst : ns;
+      for (int q = 0; q < r.nst; q++) mx[q] = r.ms[q] > mx[q] ? r.ms[q] : mx[q];
+    }
+    prof_store(mx, ns);
+  }
 }
 // sparse forms over any key: indices are positions in the whole key; scalars == nullptr: all ones
 static void key_msm_sparse(Ctx& c0, const BaseSet& bs, const uint32_t* idx, const void* scalars, size_t k, uint32_t flags,
@@ -400,7 +506,7 @@ static void key_msm_sparse(Ctx& c0, const BaseSet& bs, const uint32_t* idx, cons
     o.msm_key(c0, bs, 0, k, mc, flags, out, inf);
     return;
   }
-  require(!(flags & NMX_SCALARS_DEVICE), NMX_E_ARG, "sparse MSM over a multi-device key takes host scalars");
+  require(!(flags & (NMX_SCALARS_DEVICE | NMX_SCALARS_SHARDED)), NMX_E_ARG, "sparse MSM over a multi-device key takes host scalars");
   const size_t np = bs.parts.size();
   std::vector<std::vector<uint32_t>> pidx(np);
   std::vector<std::vector<uint8_t>> psc(np);
@@ -423,7 +529,9 @@ static void key_msm_sparse(Ctx& c0, const BaseSet& bs, const uint32_t* idx, cons
               partials.data() + 128 * i, nullptr);
   });
   stat_add(NMX_STAT_SHARDED_CALLS, 1);
-  o.point_sum(partials.data(), used.size(), flags, out, inf);
+  std::vector<int> devs(used.size());
+  for (size_t i = 0; i < used.size(); i++) devs[i] = bs.parts[used[i]]->dev;
+  combine_partials(o, partials.data(), devs, flags, out, inf);
 }
 
 struct OrFn {  // OR of all u64 scalars -> bit length of the maximum
@@ -479,54 +587,64 @@ template <class Fn> static int guarded(Fn&& fn) {
 // The reference passes `&ck.ck[..n]` (pedersen.rs:267, hyperkzg.rs:588) -- the address of element 0 of one long-lived
 // Vec for every n -- so (curve, layout, address) names the key and sampled content fingerprints confirm it.
 // ---------------------------------------------------------------------------------------------------
-static inline uint32_t point_hash(const void* p64) {  // 32 bits of a 64-bit multiply-xor hash of the 64 point bytes
+static inline uint64_t point_hash(const void* p64) {  // 64-bit multiply-xor hash of the 64 point bytes
   uint64_t w[8], h = 0x9e3779b97f4a7c15ull;
   memcpy(w, p64, 64);
   for (int i = 0; i < 8; i++) {
     h = (h ^ w[i]) * 0xff51afd7ed558ccdull;
     h ^= h >> 29;
   }
-  return (uint32_t)(h >> 32);
+  return h;
+}
+// f(t) for t in [0, parts) on pool workers (part 0 on the calling thread), all joined before returning
+template <class Fn> static void pool_for(size_t parts, Fn f) {
+  std::vector<PoolFuture<bool>> futs;
+  futs.reserve(parts);
+  for (size_t t = 1; t < parts; t++) futs.emplace_back([f, t] { f(t); return true; });
+  f(0);
+  for (auto& x : futs) (void)x.get();
 }
 // hashes of points [lo, hi) of a host array into out[lo, hi), on up to 8 threads for long ranges (2^20 points: ~1 ms)
-static void hash_points(const uint8_t* host, size_t lo, size_t hi, uint32_t* out) {
+static void hash_points(const uint8_t* host, size_t lo, size_t hi, uint64_t* out) {
   const size_t n = hi - lo;
   const size_t nth = n < ((size_t)1 << 16) ? 1 : std::min<size_t>(8, n >> 15);
-  auto work = [&](size_t a, size_t b) {
-    for (size_t i = a; i < b; i++) out[i] = point_hash(host + 64 * i);
-  };
-  if (nth <= 1) {
-    work(lo, hi);
-    return;
-  }
-  std::vector<std::thread> th;
-  JoinAll join{th};
-  size_t started = 1;
-  try {
-    for (size_t t = 1; t < nth; t++) {
-      th.emplace_back(work, lo + n * t / nth, lo + n * (t + 1) / nth);
-      started = t + 1;
-    }
-  } catch (const std::system_error&) {  // no more threads: the remaining chunks on this one
-  }
-  work(lo, lo + n / nth);
-  for (size_t t = started; t < nth; t++) work(lo + n * t / nth, lo + n * (t + 1) / nth);
+  pool_for(nth, [=](size_t t) {
+    for (size_t i = lo + n * t / nth; i < lo + n * (t + 1) / nth; i++) out[i] = point_hash(host + 64 * i);
+  });
 }
-// Arrays (and slices) up to this many points are verified in full on every call; longer ones by the first and the last
-// point used, eight probes that move from call to call, and a ROLLING WINDOW of consecutive points that walks through
-// the whole array in at most 16 calls -- so a caller that rewrites even one point of a cached array in place (against the
-// documented contract) is caught within a bounded number of calls, and a freed-and-reused address at once.
+// Verification of a hit, from the caller's bytes against the 64-bit hashes of ALL points recorded at upload.
+//  * default (option cache_verify = 0): EVERY point of the slice on EVERY call -- the trait is a pure function of the
+//    slice's contents (/root/reference/src/provider/traits.rs:79), so an in-place edit of a single point must change the
+//    very next result.  Slices up to 2048 points are hashed at once; longer ones get a quick look (first, last, eight
+//    moving probes: a freed-and-reused address fails here, before anything is launched) and the full pass runs on pool
+//    workers WHILE the GPU computes the MSM (2^20 points: 64 MiB, ~1 ms on 8 threads, under a 2.2 ms call); the result
+//    is handed out only after it has passed, otherwise the entry is dropped and the call repeated on a fresh upload.
+//  * cache_verify = 1 (callers that register immutable keys): the quick look + a ROLLING WINDOW of max(4096, n/16) points
+//    that continues where the previous call stopped -- an in-place edit is then caught within 16 calls, not at once.
 static constexpr size_t kFullVerifyBelow = 2048, kSyncWindow = 4096, kWindowFraction = 16;
-struct DeepCheck {  // the rolling-window part of a hit's verification; run() needs the caller's slice to stay valid
-  std::shared_ptr<const std::vector<uint32_t>> ph;
+struct DeepCheck {  // the part of a hit's verification that may run beside the MSM; needs the caller's slice to stay valid
+  std::shared_ptr<const std::vector<uint64_t>> ph;
   const uint8_t* slice = nullptr;
   size_t off = 0, start = 0, count = 0;  // points [start, start + count) of the slice against ph[off + ...]
   bool needed() const { return count != 0; }
-  bool run() const {
-    const uint32_t* h = ph->data() + off;
-    for (size_t i = start; i < start + count; i++)
+  bool run_range(size_t a, size_t b) const {
+    const uint64_t* h = ph->data() + off;
+    for (size_t i = a; i < b; i++)
       if (point_hash(slice + 64 * i) != h[i]) return false;
     return true;
+  }
+  bool run() const { return run_range(start, start + count); }
+  // on pool workers, up to 8 of them; every future must be joined before the slice goes away
+  std::vector<PoolFuture<bool>> run_async() const {
+    const size_t nth = std::max<size_t>(1, std::min<size_t>(8, count >> 15));
+    std::vector<PoolFuture<bool>> futs;
+    futs.reserve(nth);
+    const DeepCheck dc = *this;
+    for (size_t t = 0; t < nth; t++) {
+      const size_t a = start + count * t / nth, b = start + count * (t + 1) / nth;
+      futs.emplace_back([dc, a, b] { return dc.run_range(a, b); });
+    }
+    return futs;
   }
 };
 struct SliceEntry {
@@ -534,17 +652,17 @@ struct SliceEntry {
   uint32_t mont;
   const uint8_t* host;  // address of element 0 (identity only; dereferenced solely through a live caller slice)
   size_t n;
-  std::shared_ptr<std::vector<uint32_t>> ph;  // ph[i] = hash(point i), all n points
+  std::shared_ptr<std::vector<uint64_t>> ph;  // ph[i] = hash(point i), all n points
   std::shared_ptr<BaseSet> bs;
   bool tables = false;   // bs carries window tables (built once the array has proved long-lived: third use)
   uint32_t uses = 0;
   uint64_t tick = 0, probes = 0;
-  size_t cursor = 0;     // rolling window position (array coordinates)
+  size_t cursor = 0;     // rolling window position (array coordinates; cache_verify = 1)
   // Cheap part, under the cache lock: do the caller's bytes for points [off, off + m) still match?
   bool matches(const uint8_t* slice, size_t off, size_t m, DeepCheck* deep) {
     deep->count = 0;
     if (m == 0) return true;
-    const uint32_t* h = ph->data() + off;
+    const uint64_t* h = ph->data() + off;
     auto ok = [&](size_t i) { return point_hash(slice + 64 * i) == h[i]; };
     if (m <= kFullVerifyBelow) {  // <= 128 KiB: every point, ~10 us
       for (size_t i = 0; i < m; i++)
@@ -557,15 +675,20 @@ struct SliceEntry {
       x ^= x >> 12, x ^= x << 25, x ^= x >> 27;
       if (!ok((size_t)((x * 0x2545f4914f6cdd1dull) >> 33) % m)) return false;
     }
+    deep->ph = ph;
+    deep->slice = slice;
+    deep->off = off;
+    if (G.cache_verify.load(std::memory_order_relaxed) == 0) {  // the whole slice, beside the MSM
+      deep->start = 0;
+      deep->count = m;
+      return true;
+    }
     // the rolling window: continues where the last call stopped, clipped to this call's range
     size_t w = std::max(kSyncWindow, m / kWindowFraction);
     if (w > m) w = m;
     size_t st = cursor >= off && cursor < off + m ? cursor - off : 0;
     if (st + w > m) w = m - st;
     cursor = off + st + w >= off + m ? off : off + st + w;
-    deep->ph = ph;
-    deep->slice = slice;
-    deep->off = off;
     deep->start = st;
     deep->count = w;
     return true;
@@ -741,7 +864,7 @@ static SliceKey slice_key(Ctx& c, const CurveOps& o, int curve, const void* base
   e.mont = mont;
   e.host = b;
   e.n = n;
-  e.ph = std::make_shared<std::vector<uint32_t>>(n);
+  e.ph = std::make_shared<std::vector<uint64_t>>(n);
   hash_points(b, 0, n, e.ph->data());
   // First sight: the key only (upload + conversion).  Tables cost W - 1 more copies of it and ~13 ms per 2^20 points;
   // arrays seen once or twice (IPA's folded keys, src/provider/pedersen.rs:484-497: a fresh n/2-point key per round,
@@ -811,17 +934,13 @@ static void with_slice(Ctx& c, const CurveOps& o, int curve, const void* bases, 
   for (int attempt = 0;; attempt++) {
     const SliceKey k = resolve_slice(c, o, curve, bases, n, flags);
     bool ok = true;
-    PoolFuture<bool> fut;
+    std::vector<PoolFuture<bool>> futs;
     if (k.deep.needed()) {
-      if (k.deep.count > kSyncWindow) {
-        const DeepCheck dc = k.deep;
-        fut = PoolFuture<bool>([dc] { return dc.run(); });
-      } else {
-        ok = k.deep.run();
-      }
+      if (k.deep.count > kSyncWindow) futs = k.deep.run_async();
+      else ok = k.deep.run();
     }
-    if (ok) run(k);  // (an exception unwinds through fut's destructor, which waits for the check)
-    if (fut.valid()) ok = fut.get();
+    if (ok) run(k);  // (an exception unwinds through the futures' destructors, which wait for the check)
+    for (auto& f : futs) ok = f.get() && ok;
     if (ok) {
       commit();
       return;
@@ -838,6 +957,72 @@ static void with_slice(Ctx& c, const CurveOps& o, int curve, const void* bases, 
     }
     require(attempt < 2, NMX_E_ARG, "the base array keeps changing while the call runs");
   }
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Shard-resident vectors (nmx_svec_*): a field vector laid out like the key it will be committed against -- element i on
+// the device that holds key point i -- so that W, E, T are BORN on the shard that commits them (the reference chunks
+// coefficients and bases together, /root/reference/src/provider/msm.rs:564-574) and the NIFS fold / cross-term kernels
+// (src/r1cs/mod.rs:1044-1107,614-620) run shard by shard, each on its own GPU.
+// ---------------------------------------------------------------------------------------------------
+struct SVec {
+  size_t n_key = 0, n = 0;
+  uint32_t k = 1;  // devices of the layout
+  struct Piece {
+    int dev;
+    size_t begin, cnt;
+    void* d;
+  };
+  std::vector<Piece> pieces;  // nmx_shard_plan(n_key, k, 0, n) order
+  SVec() = default;
+  SVec(const SVec&) = delete;
+  SVec& operator=(const SVec&) = delete;
+  ~SVec() {
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    for (Piece& p : pieces)
+      if (p.d) {
+        (void)hipSetDevice(hip_device_of(p.dev));
+        (void)hipFree(p.d);
+      }
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+  bool same_layout(const SVec& o) const {
+    if (n != o.n || pieces.size() != o.pieces.size()) return false;
+    for (size_t i = 0; i < pieces.size(); i++)
+      if (pieces[i].dev != o.pieces[i].dev || pieces[i].begin != o.pieces[i].begin || pieces[i].cnt != o.pieces[i].cnt) return false;
+    return true;
+  }
+};
+static std::unordered_map<uint64_t, std::shared_ptr<SVec>>& svecs() {
+  static auto& m = *new std::unordered_map<uint64_t, std::shared_ptr<SVec>>;
+  return m;
+}
+static std::shared_ptr<SVec> svec_lookup(uint64_t h) {
+  std::lock_guard<std::mutex> lk(G.mu);
+  auto it = svecs().find(h);
+  if (it == svecs().end()) throw Fail{NMX_E_HANDLE, "unknown sharded-vector handle"};
+  return it->second;
+}
+// the number of devices a key of n_key points is (or would be) cut over: build_key's rule
+static uint32_t shard_count_for(size_t n_key) {
+  const uint32_t k = G.ndev_active.load(std::memory_order_relaxed);
+  return (k <= 1 || n_key < G.shard_min_n.load(std::memory_order_relaxed) || n_key < k) ? 1u : k;
+}
+// the pieces of a sharded-scalar call must be the pieces of the key range it addresses
+static void check_svec_against_key(const SVec& v, const BaseSet& bs, size_t n) {
+  require(n <= v.n, NMX_E_ARG, "sharded vector shorter than the call");
+  if (bs.parts.empty()) {
+    require(v.pieces.size() <= 1 && (v.pieces.empty() || v.pieces[0].dev == bs.dev), NMX_E_ARG,
+            "sharded vector laid out for a multi-device key, the key is on one device");
+    return;
+  }
+  const std::vector<PartJob> jobs = parts_of(bs, 0, n);
+  require(jobs.size() <= v.pieces.size(), NMX_E_ARG, "sharded vector layout does not match the key's shards");
+  for (size_t i = 0; i < jobs.size(); i++)
+    require(jobs[i].part->dev == v.pieces[i].dev && jobs[i].goff == v.pieces[i].begin && jobs[i].cnt <= v.pieces[i].cnt, NMX_E_ARG,
+            "sharded vector layout does not match the key's shards (allocate it with the key's length as n_key)");
 }
 
 }  // namespace nmx
@@ -865,6 +1050,8 @@ int nmx_shutdown(void) {
     (void)hipSetDevice(G.device);
     G.bases.clear();  // the shared_ptr destructors free the HBM
     G.sparse.clear();
+    svecs().clear();
+    RC.destroy();
     {
       std::lock_guard<std::mutex> ck(SC.mu);
       SC.entries.clear();
@@ -923,6 +1110,7 @@ int nmx_init_devices(int count, uint32_t flags) {
     }
     (void)hipSetDevice(G.device);
     G.ndev_active.store((uint32_t)count);
+    RC.destroy();  // the communicator follows the device set: rebuilt by the next sharded call
   });
 }
 int nmx_devices_in_use(void) { return (int)G.ndev_active.load(); }
@@ -1091,9 +1279,12 @@ int nmx_msm_u64_handle(uint64_t handle, size_t offset, const uint64_t* scalars, 
     auto bs = lookup(handle);
     require(slice_ok(*bs, offset, n), NMX_E_HANDLE, "offset + n beyond the registered key");
     CtxLease L;
+    const bool sharded = (flags & NMX_SCALARS_SHARDED) != 0;
+    require(!sharded || max_num_bits != NMX_BITS_AUTO, NMX_E_ARG, "sharded small scalars need an explicit max_num_bits");
     bool dev = (flags & NMX_SCALARS_DEVICE) != 0;
     uint32_t bits = resolve_u64_bits(*L.c, scalars, n, dev, max_num_bits);
-    MsmCall mc{scalars, dev, false, bits, true};
+    MsmCall mc{scalars, dev || sharded, false, bits, true};
+    mc.scalars_sharded = sharded;
     stat_add(NMX_STAT_MSM_CALLS);
     key_msm(*L.c, *bs, offset, n, mc, flags, out, out_is_inf);
   });
@@ -1280,34 +1471,193 @@ int nmx_msm_batch(int curve, const void* const* scalar_vecs, const size_t* lens,
   });
 }
 
+static void commit_impl(const BaseSet& bs, MsmCall mc, size_t n, const void* h_xy64, const void* r, uint32_t flags, uint8_t* out,
+                        uint8_t* out_is_inf) {
+  require(n <= bs.n, NMX_E_HANDLE, "ck shorter than v");  // assert!(ck.ck.len() >= v.len()), pedersen.rs:264
+  CtxLease L;
+  stat_add(NMX_STAT_MSM_CALLS);
+  const CurveOps& o = ops(bs.curve);
+  if (bs.parts.empty()) {
+    if (mc.scalars_sharded) {  // one piece, on the key's device
+      mc.scalars = n ? ((const void* const*)mc.scalars)[0] : nullptr;
+      require(mc.scalars || n == 0, NMX_E_ARG, "null shard pointer");
+      mc.scalars_device = true;
+      mc.scalars_sharded = false;
+    }
+    o.commit(*L.c, bs, n, mc, h_xy64, r, flags, out, out_is_inf);
+  } else {  // sharded key: the blinding term is one more partial, computed on the host under the device MSMs
+    uint8_t two[256];
+    std::array<uint8_t, 64> hb;
+    std::array<uint8_t, 32> rb;
+    memcpy(hb.data(), h_xy64, 64);
+    memcpy(rb.data(), r, 32);
+    PoolFuture<std::array<uint8_t, 128>> hr([&o, hb, rb, flags] {
+      std::array<uint8_t, 128> t;
+      o.blind_term(hb.data(), rb.data(), flags, t.data());
+      return t;
+    });
+    key_msm(*L.c, bs, 0, n, mc, flags | NMX_OUT_PARTIAL, two, nullptr);
+    const auto t = hr.get();  // (an out-of-range r surfaces here, NMX_E_SCALAR_RANGE, before anything is written)
+    memcpy(two + 128, t.data(), 128);
+    o.point_sum(two, 2, flags, out, out_is_inf);
+  }
+}
 int nmx_commit(uint64_t ck_handle, const void* v, size_t n, const void* h_xy64, const void* r,
                uint32_t flags, uint8_t* out, uint8_t* out_is_inf) {
   return guarded([&] {
     require(out && (v || n == 0) && h_xy64 && r, NMX_E_ARG, "null argument");
     auto bs = lookup(ck_handle);
-    require(n <= bs->n, NMX_E_HANDLE, "ck shorter than v");  // assert!(ck.ck.len() >= v.len()), pedersen.rs:264
-    CtxLease L;
-    stat_add(NMX_STAT_MSM_CALLS);
-    const CurveOps& o = ops(bs->curve);
-    if (bs->parts.empty()) {
-      o.commit(*L.c, *bs, n, field_call(v, flags), h_xy64, r, flags, out, out_is_inf);
-    } else {  // sharded key: the blinding term is one more partial, computed on the host under the device MSMs
-      uint8_t two[256];
-      std::array<uint8_t, 64> hb;
-      std::array<uint8_t, 32> rb;
-      memcpy(hb.data(), h_xy64, 64);
-      memcpy(rb.data(), r, 32);
-      PoolFuture<std::array<uint8_t, 128>> hr([&o, hb, rb, flags] {
-        std::array<uint8_t, 128> t;
-        o.blind_term(hb.data(), rb.data(), flags, t.data());
-        return t;
-      });
-      key_msm(*L.c, *bs, 0, n, field_call(v, flags), flags | NMX_OUT_PARTIAL, two, nullptr);
-      const auto t = hr.get();  // (an out-of-range r surfaces here, NMX_E_SCALAR_RANGE, before anything is written)
-      memcpy(two + 128, t.data(), 128);
-      o.point_sum(two, 2, flags, out, out_is_inf);
+    commit_impl(*bs, field_call(v, flags), n, h_xy64, r, flags, out, out_is_inf);
+  });
+}
+
+// ---- shard-resident vectors ---------------------------------------------------------------------------
+int nmx_svec_alloc(size_t n_key, size_t n, uint64_t* handle) {
+  return guarded([&] {
+    require(handle != nullptr, NMX_E_ARG, "null argument");
+    require(n <= n_key && n_key < (1ull << 31), NMX_E_ARG, "n must be <= n_key < 2^31");
+    ensure_init();
+    auto v = std::make_shared<SVec>();
+    v->n_key = n_key;
+    v->n = n;
+    v->k = shard_count_for(n_key);
+    for (uint32_t i = 0; i < v->k; i++) {
+      const PartRange r = shard_range(n_key, i, v->k);
+      const size_t lo = r.begin, hi = r.begin + r.n < n ? r.begin + r.n : n;
+      if (lo < hi) v->pieces.push_back(SVec::Piece{(int)i, lo, hi - lo, nullptr});
+    }
+    for (SVec::Piece& p : v->pieces) {  // (a failure frees what was allocated: ~SVec)
+      HIPCHK(hipSetDevice(hip_device_of(p.dev)));
+      HIPCHK(hipMalloc(&p.d, p.cnt * 32));
+    }
+    (void)hipSetDevice(G.device);
+    std::lock_guard<std::mutex> lk(G.mu);
+    const uint64_t h = G.next_handle++;
+    svecs()[h] = std::move(v);
+    *handle = h;
+  });
+}
+int nmx_svec_free(uint64_t handle) {
+  return guarded([&] {
+    std::shared_ptr<SVec> v;  // freed outside the lock, when the last in-flight call lets go
+    {
+      std::lock_guard<std::mutex> lk(G.mu);
+      auto it = svecs().find(handle);
+      if (it == svecs().end()) throw Fail{NMX_E_HANDLE, "unknown sharded-vector handle"};
+      v = std::move(it->second);
+      svecs().erase(it);
     }
   });
+}
+// raw 32-byte elements in / out: no conversion (the field kernels work on canonical or Montgomery data alike)
+static void svec_copy(const SVec& v, void* host, bool to_device) {
+  run_on_parts(v.pieces.size(), true, [&](size_t i) {
+    const SVec::Piece& p = v.pieces[i];
+    CtxLease L(p.dev);
+    char* h = (char*)host + 32 * p.begin;
+    if (to_device) HIPCHK(hipMemcpyAsync(p.d, h, p.cnt * 32, hipMemcpyHostToDevice, L.c->stream));
+    else HIPCHK(hipMemcpyAsync(h, p.d, p.cnt * 32, hipMemcpyDeviceToHost, L.c->stream));
+    HIPCHK(hipStreamSynchronize(L.c->stream));
+  });
+}
+int nmx_svec_write(uint64_t handle, const void* host) {
+  return guarded([&] {
+    auto v = svec_lookup(handle);
+    require(host || v->n == 0, NMX_E_ARG, "null argument");
+    svec_copy(*v, const_cast<void*>(host), true);
+  });
+}
+int nmx_svec_read(uint64_t handle, void* host) {
+  return guarded([&] {
+    auto v = svec_lookup(handle);
+    require(host || v->n == 0, NMX_E_ARG, "null argument");
+    svec_copy(*v, host, false);
+  });
+}
+int nmx_svec_parts(uint64_t handle, void** dev_ptrs, size_t* counts, int* devices, int cap) {
+  int cnt = 0;
+  const int rc = guarded([&] {
+    auto v = svec_lookup(handle);
+    cnt = (int)v->pieces.size();
+    for (int i = 0; i < cnt && i < cap; i++) {
+      if (dev_ptrs) dev_ptrs[i] = v->pieces[(size_t)i].d;
+      if (counts) counts[i] = v->pieces[(size_t)i].cnt;
+      if (devices) devices[i] = hip_device_of(v->pieces[(size_t)i].dev);
+    }
+  });
+  return rc == NMX_OK ? cnt : rc;
+}
+int nmx_svec_map(int field, int op, const uint64_t* in, int n_in, const void* challenge, uint32_t flags, uint64_t out) {
+  return guarded([&] {
+    static const int need_in[] = {2, 3, 4, 5, 2};  // AXPY, AXPY2, CROSS_TERM, CROSS_TERM2, VEC_ADD
+    require(op >= 0 && op <= NMX_OP_VEC_ADD && in && n_in == need_in[op], NMX_E_ARG, "bad operation / operand count");
+    require(challenge || op == NMX_OP_VEC_ADD, NMX_E_ARG, "null challenge");
+    require(!(flags & ~(uint32_t)NMX_SCALARS_MONT), NMX_E_ARG, "only NMX_SCALARS_MONT applies");
+    std::vector<std::shared_ptr<SVec>> v((size_t)n_in);
+    for (int j = 0; j < n_in; j++) v[(size_t)j] = svec_lookup(in[j]);
+    auto o = svec_lookup(out);
+    for (auto& x : v) require(x->same_layout(*o), NMX_E_ARG, "operands with different shard layouts");
+    const uint32_t fl = flags | NMX_SCALARS_DEVICE;
+    run_on_parts(o->pieces.size(), true, [&](size_t i) {
+      const size_t m = o->pieces[i].cnt;
+      CtxLease L(o->pieces[i].dev);
+      auto d = [&](int j) { return v[(size_t)j]->pieces[i].d; };
+      void* od = o->pieces[i].d;
+      switch (op) {
+        case NMX_OP_AXPY: fv_axpy(*L.c, field, d(0), d(1), challenge, m, fl, od); break;
+        case NMX_OP_AXPY2: fv_axpy2(*L.c, field, d(0), d(1), d(2), challenge, m, fl, od); break;
+        case NMX_OP_CROSS_TERM: fv_cross_term(*L.c, field, d(0), d(1), d(2), d(3), challenge, m, fl, od); break;
+        case NMX_OP_CROSS_TERM2: fv_cross_term2(*L.c, field, d(0), d(1), d(2), d(3), d(4), challenge, m, fl, od); break;
+        default: fv_vec_add(*L.c, field, d(0), d(1), m, fl, od); break;
+      }
+    });
+  });
+}
+// the pointer array a sharded-scalar call takes, from a sharded vector (checked against the key's shards)
+static std::vector<const void*> svec_pointers(const SVec& v, const BaseSet& bs, size_t n) {
+  check_svec_against_key(v, bs, n);
+  std::vector<const void*> p;
+  for (const SVec::Piece& q : v.pieces) p.push_back(q.d);
+  if (p.empty()) p.push_back(nullptr);
+  return p;
+}
+int nmx_msm_svec(uint64_t key_handle, uint64_t svec, size_t n, uint32_t flags, uint8_t* out, uint8_t* out_is_inf) {
+  return guarded([&] {
+    require(out != nullptr, NMX_E_ARG, "null argument");
+    auto bs = lookup(key_handle);
+    auto v = svec_lookup(svec);
+    require(slice_ok(*bs, 0, n), NMX_E_HANDLE, "n beyond the registered key");
+    const std::vector<const void*> ptrs = svec_pointers(*v, *bs, n);
+    const uint32_t fl = (flags & ~(uint32_t)NMX_SCALARS_DEVICE) | NMX_SCALARS_SHARDED;
+    CtxLease L;
+    stat_add(NMX_STAT_MSM_CALLS);
+    key_msm(*L.c, *bs, 0, n, field_call(ptrs.data(), fl), fl, out, out_is_inf);
+  });
+}
+int nmx_commit_svec(uint64_t ck_handle, uint64_t svec, size_t n, const void* h_xy64, const void* r, uint32_t flags,
+                    uint8_t* out, uint8_t* out_is_inf) {
+  return guarded([&] {
+    require(out && h_xy64 && r, NMX_E_ARG, "null argument");
+    auto bs = lookup(ck_handle);
+    auto v = svec_lookup(svec);
+    require(n <= bs->n, NMX_E_HANDLE, "ck shorter than v");
+    const std::vector<const void*> ptrs = svec_pointers(*v, *bs, n);
+    const uint32_t fl = (flags & ~(uint32_t)NMX_SCALARS_DEVICE) | NMX_SCALARS_SHARDED;
+    commit_impl(*bs, field_call(ptrs.data(), fl), n, h_xy64, r, fl, out, out_is_inf);
+  });
+}
+int nmx_profile_last_sharded(float* ms, int* dev, int* branch, int cap, float* combine_ms, int* rccl_ranks) {
+  const int n = (int)t_shards.size();
+  for (int i = 0; i < n && i < cap; i++) {
+    const ShardRec& r = t_shards[(size_t)i];
+    if (ms)
+      for (int q = 0; q < kMaxMarks; q++) ms[i * kMaxMarks + q] = q < r.nst ? r.ms[q] : 0.0f;
+    if (dev) dev[i] = r.dev;
+    if (branch) branch[i] = r.branch;
+  }
+  if (combine_ms) *combine_ms = t_combine_ms;
+  if (rccl_ranks) *rccl_ranks = t_rccl_ranks;
+  return n;
 }
 
 int nmx_point_sum(int curve, const uint8_t* partials128, size_t count, uint8_t* out, uint8_t* out_is_inf) {
@@ -1680,6 +2030,14 @@ int nmx_set_option(const char* name, uint32_t value) {
     else if (n == "eq_max_blocks") G.eq_max_blocks = value;
     else if (n == "horner_spin_limit") G.horner_spin_limit = value;
     else if (n == "seg_heavy_above") G.seg_heavy_above = value > 63u ? 63u : value;
+    else if (n == "force_peer_copy") G.force_peer_copy = value;
+    else if (n == "combine") {
+      require(value <= 2, NMX_E_ARG, "combine: 0 auto, 1 host sum, 2 RCCL required");
+      G.combine_mode = value;
+    } else if (n == "cache_verify") {
+      require(value <= 1, NMX_E_ARG, "cache_verify: 0 full, 1 rolling window");
+      G.cache_verify = value;
+    }
     else throw Fail{NMX_E_ARG, "unknown option name"};
   });
 }

@@ -138,6 +138,9 @@ template <int SFID> struct DigitSrc {
     }
     return ok;
   }
+  // first bucket of window w's digits: with window tables every window shares the bucket set kbase (0, or vector j's set in a
+  // fused batch); plain keys keep one bucket set per window
+  NMX_HD uint32_t key_base(uint32_t w, uint32_t kbase) const { return pre_stride ? kbase : w * sh.M; }
   // signed digit of window w: |d| in [0, 2^(c-1)], neg = sign; carry threads through the windows low to high
   NMX_HD void digit(const uint32_t (&s)[9], uint32_t w, uint32_t& carry, uint32_t& d, uint32_t& neg) const {
     const uint32_t bit = w * sh.c, word = bit >> 5, off = bit & 31;

@@ -1,4 +1,4 @@
-// msm_partition.hpp -- hand-written bucket partition of the MSM pipeline (table mode, window width c <= 16).
+// msm_partition.hpp -- hand-written bucket partition of the MSM pipeline (keys with window tables, and since round 4 plain keys too).
 //
 // Replaces, on the hot path, the generic (key, value) radix sort of round 1 (rocPRIM onesweep: DigitsFn wrote
 // 8 * W bytes per pair that two 8-bit sort passes re-read and re-wrote, then BoundsFn re-read the keys).  Bucket keys
@@ -90,12 +90,17 @@ static constexpr uint32_t kTileThreads = 1024;
 static constexpr uint32_t kBinAlign = 16;
 static constexpr uint32_t kTabStride = 1025;  // tab = 3 arrays of nhi + 1 <= 1025 words
 
-// Geometry for a table-mode shape; false when the hand-written partition does not cover it (the generic sort path runs).
-// Keys are bucket indices in [0, WB * M): c - 1 bits for one vector, up to 20 with the bucket sets of a fused batch.
+// Geometry for a shape; false when the hand-written partition does not cover it (the generic sort path runs).
+// Keys are bucket indices in [0, WB * M).  Table mode: c - 1 bits for one vector, up to 20 with the bucket sets of a fused
+// batch (WB a power of two).  Plain keys (round 4: first / second sight of a cached array, IPA's per-round keys, one-shot
+// uploads, keys whose tables did not fit -- /root/reference/src/provider/msm.rs:577-661 is the per-window bucket method they
+// replace): WB = W bucket sets, key = w * M + |d| - 1, the same two-level counting scatter over ceil(log2(W * M)) key bits; the
+// bins past the last bucket stay empty.
 inline bool make_part_shape(const MsmShape& sh, bool table_mode, PartShape* out) {
-  if (!(table_mode && sh.c >= 2 && sh.c <= 20 && sh.WB >= 1 && (sh.WB & (sh.WB - 1)) == 0)) return false;
-  uint32_t kb = sh.c - 1;
-  for (uint32_t v = sh.WB; v > 1; v >>= 1) kb++;
+  if (!(sh.c >= 2 && sh.c <= 20 && sh.WB >= 1)) return false;
+  if (table_mode && (sh.WB & (sh.WB - 1)) != 0) return false;
+  uint32_t kb = 0;
+  while (((uint64_t)1 << kb) < (uint64_t)sh.WB * sh.M) kb++;
   if (kb > 20) return false;
   PartShape p;
   p.big = kb > 16 ? 1u : 0u;
@@ -109,7 +114,7 @@ inline bool make_part_shape(const MsmShape& sh, bool table_mode, PartShape* out)
   // and the block also scans the nhi bins (block_excl_scan needs a thread per bin)
   uint32_t bs = (stage / sh.W) & ~63u;
   if (bs > 1024) bs = 1024;
-  if (bs < 256 || bs < p.nhi) return false;
+  if (bs < (table_mode ? 256u : 64u) || bs < p.nhi) return false;  // (tiny plain MSMs, c = 3: 85 windows -> 128-thread chunks)
   p.bs1 = bs;
   const uint32_t chunks = (sh.n + bs - 1) / bs;
   p.grid1 = chunks < 1024 ? chunks : 1024;
@@ -122,9 +127,9 @@ inline bool partition_supported(const MsmShape& sh, bool table_mode) {
   PartShape p;
   return make_part_shape(sh, table_mode, &p);
 }
-inline PartShape make_part_shape(const MsmShape& sh) {
+inline PartShape make_part_shape(const MsmShape& sh, bool table_mode) {
   PartShape p{};
-  (void)make_part_shape(sh, true, &p);
+  (void)make_part_shape(sh, table_mode, &p);
   return p;
 }
 
@@ -274,7 +279,7 @@ template <int SFID, int C, bool BIG> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_h
     if (i < n) {
       uint32_t s[9], bi, kbase;
       if (a.src.load(i, s, bi, kbase, true))
-        for_each_digit<SFID, C>(a.src, s, [&](uint32_t, uint32_t d, uint32_t) { lds_count(cnt, (kbase + d - 1) >> LB); });
+        for_each_digit<SFID, C>(a.src, s, [&](uint32_t w, uint32_t d, uint32_t) { lds_count(cnt, (a.src.key_base(w, kbase) + d - 1) >> LB); });
     }
   }
   NMX_SYNC();
@@ -306,15 +311,24 @@ template <bool BIG> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_tiles(PartBufs b) 
     b.tab[kTabStride + j] = o2[j];
     b.tab[2 * kTabStride + j] = o3[j];
   }
-  // No tile will ever visit an empty bin: its buckets are empty, placed at the bin's offset.  The block walks the bucket
-  // array with consecutive threads on consecutive buckets (a thread per bin writing its nlo buckets one by one was 0.15 ms
-  // of uncoalesced stores for the sparse bucket sets of a fused batch of short vectors; a serial walk over the bins cost
-  // 18 us of dependent LDS reads on every call).
-  for (uint32_t k = t; any_empty && k < (nhi << b.ps.LB); k += NMX_BDIM) {  // uniform random scalars: no empty bin, no walk
-    const uint32_t bin = k >> b.ps.LB;
-    if (h[bin] == 0) {
-      b.start[k] = o2[bin];
-      b.end[k] = o2[bin];
+  // No tile will ever visit an empty bin: its buckets are empty, placed at the bin's offset.  The empty bins are listed (a
+  // scan of their flags) and the block walks THEIR buckets only, consecutive threads on consecutive buckets (a thread per bin
+  // writing its nlo buckets one by one was 0.15 ms of uncoalesced stores for the sparse bucket sets of a fused batch of short
+  // vectors; a serial walk over the bins cost 18 us of dependent LDS reads on every call; a walk over ALL buckets whenever one
+  // bin is empty would be paid by every plain-key MSM, whose top window never fills its upper bins).
+  if (any_empty) {  // block-uniform; uniform random scalars over window tables: no empty bin, nothing to do
+    al[t] = (t < nhi && c == 0) ? 1u : 0u;
+    NMX_SYNC();
+    block_excl_scan(al, o1, nhi, wtot);
+    if (t < nhi && c == 0) tl[o1[t]] = t;
+    NMX_SYNC();
+    const uint32_t ne = o1[nhi], LB = b.ps.LB, nlo = b.ps.nlo;
+    for (uint32_t idx = t; idx < (ne << LB); idx += NMX_BDIM) {
+      const uint32_t bin = tl[idx >> LB], k = (bin << LB) + (idx & (nlo - 1u));
+      if (k < b.nbuckets) {  // plain keys: W * M need not fill the last bins
+        b.start[k] = o2[bin];
+        b.end[k] = o2[bin];
+      }
     }
   }
   if (t == 0) {
@@ -350,8 +364,9 @@ template <int SFID, int C, bool BIG> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_p
     }
     if (live)
       for_each_digit<SFID, C>(a.src, s, [&](uint32_t w, uint32_t d, uint32_t neg) {
-        lds_count(cnt, (kbase + d - 1) >> LB);
-        if constexpr (C != 0) dig[w] = (kbase + d - 1) | (neg << 31);
+        const uint32_t key = a.src.key_base(w, kbase) + d - 1;
+        lds_count(cnt, key >> LB);
+        if constexpr (C != 0) dig[w] = key | (neg << 31);
       });
     NMX_SYNC();
     block_excl_scan(cnt, lbase, nhi, wtot);
@@ -370,7 +385,7 @@ template <int SFID, int C, bool BIG> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_p
         for (uint32_t w = 0; w < WinMax<C>::value; w++)
           if (dig[w] != 0xffffffffu) place(w, dig[w] & 0x7fffffffu, dig[w] >> 31);
       } else {
-        for_each_digit<SFID, C>(a.src, s, [&](uint32_t w, uint32_t d, uint32_t neg) { place(w, kbase + d - 1, neg); });
+        for_each_digit<SFID, C>(a.src, s, [&](uint32_t w, uint32_t d, uint32_t neg) { place(w, a.src.key_base(w, kbase) + d - 1, neg); });
       }
     }
     NMX_SYNC();
@@ -453,12 +468,12 @@ template <bool BIG> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_part_lo(PartBufs b
   const uint32_t t = NMX_TID, bs = NMX_BDIM, nlo = b.ps.nlo, k0 = bin << b.ps.LB;
   if (t < Cfg::kMaxLo) {
     cnt[t] = 0;
-    bcnt[t] = t < nlo ? b.bucket_cnt[k0 + t] : 0;
+    bcnt[t] = (t < nlo && k0 + t < b.nbuckets) ? b.bucket_cnt[k0 + t] : 0;
   }
   NMX_SYNC();
   block_excl_scan(bcnt, bstart, nlo, wtot);  // the bin's buckets inside the bin's region of the final array
   const uint32_t region = b.tab[kTabStride + bin];
-  if (j == 0 && t < nlo) {  // first tile of the bin: publish [start, end) of its buckets
+  if (j == 0 && t < nlo && k0 + t < b.nbuckets) {  // first tile of the bin: publish [start, end) of its buckets
     b.start[k0 + t] = region + bstart[t];
     b.end[k0 + t] = region + bstart[t + 1];
   }

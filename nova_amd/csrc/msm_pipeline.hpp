@@ -189,7 +189,7 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
     PartArgs<SFID> pa;
     pa.src = src;
     PartBufs& pb = pa.b;
-    pb.ps = make_part_shape(sh);
+    pb.ps = make_part_shape(sh, a.pre_stride != 0);
     pb.nbuckets = sh.nbuckets;
     pb.hist_hi = ctr;
     pb.cur_hi = ctr + 1024;

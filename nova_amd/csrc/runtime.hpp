@@ -293,6 +293,9 @@ struct Global {
   std::atomic<uint32_t> no_tree_fuse{0};          // env NMX_TUNE_NO_TREE_FUSE / option no_tree_fuse: 0 / 2 = fused reduction tree (default), 1 = one launch per reduction level
   std::atomic<uint32_t> hist_grid{0};             // env NMX_TUNE_HIST_GRID / option hist_grid
   std::atomic<uint32_t> sync_spin_us{0};          // env NMX_SYNC_SPIN_US / option sync_spin_us: poll the stream this long before blocking
+  std::atomic<uint32_t> force_peer_copy{0};       // option force_peer_copy: HBM-resident scalars of a sharded call take the staging + hipMemcpyPeerAsync branch even when source and destination are the same GPU (tests on a 1-GPU box)
+  std::atomic<uint32_t> combine_mode{0};          // option combine: 0 = RCCL all-gather when the shards sit on >= 2 GPUs, host sum otherwise; 1 = host sum; 2 = RCCL required (also with one GPU: tests)
+  std::atomic<uint32_t> cache_verify{0};          // option cache_verify: 0 = every hit re-hashes the caller's whole slice (on pool workers, under the MSM); 1 = rolling window (callers that register immutable keys)
   std::atomic<int32_t> launch_gap_ns{-1};         // cost of one dependent tiny launch on this box, measured once (capi.hip launch_gap_ns)
 };
 extern Global& G;                // capi.hip (heap singleton, never destroyed)
@@ -574,6 +577,9 @@ struct MsmCall {
   const uint32_t* gather_host = nullptr;
   bool all_ones = false;
   bool bases_clean = false;  // the key holds no identity point
+  // NMX_SCALARS_SHARDED: `scalars` is a host array of device pointers, one per piece of the call (nmx_shard_plan order), each
+  // on the device that holds that piece of the key (resolved by key_msm before the per-curve code sees the call)
+  bool scalars_sharded = false;
 };
 
 // one vector of a fused batch (msm_key_batch): n field scalars, host or device as the shared MsmCall says

@@ -48,6 +48,61 @@ def shard_plan(n_key, k, offset, n):
     return [(buf[3 * i], buf[3 * i + 1], buf[3 * i + 2]) for i in range(cnt)]
 
 
+class ShardedVector:
+    """A field vector resident shard by shard in the HBM of the devices that hold the matching points of a key of `n_key`
+    points (nmx_svec_*): the layout the reference's own decomposition uses -- coefficients and bases chunked together,
+    /root/reference/src/provider/msm.rs:564-574.  Elements are raw 32-byte words."""
+
+    def __init__(self, n_key, n):
+        h = ctypes.c_uint64(0)
+        _check(L.lib().nmx_svec_alloc(n_key, n, ctypes.byref(h)))
+        self.handle, self.n_key, self.n = h.value, n_key, n
+
+    @classmethod
+    def from_host(cls, n_key, elems):
+        a = _host_u8(elems, 32)
+        v = cls(n_key, a.size // 32)
+        _check(L.lib().nmx_svec_write(v.handle, a.ctypes.data))
+        return v
+
+    def parts(self):
+        """[(device pointer, element count, HIP device ordinal)] in shard order."""
+        cap = 64
+        ptrs, cnts, devs = (ctypes.c_void_p * cap)(), (ctypes.c_size_t * cap)(), (ctypes.c_int * cap)()
+        k = L.lib().nmx_svec_parts(self.handle, ptrs, cnts, devs, cap)
+        if k < 0:
+            raise NmxError(k, L.lib().nmx_last_error().decode())
+        return [(ptrs[i] or 0, cnts[i], devs[i]) for i in range(k)]
+
+    def to_host(self):
+        out = np.zeros((self.n, 32), dtype=np.uint8)
+        _check(L.lib().nmx_svec_read(self.handle, out.ctypes.data))
+        return out
+
+    def __len__(self):
+        return self.n
+
+    def close(self):
+        if self.handle:
+            _check(L.lib().nmx_svec_free(self.handle))
+            self.handle = 0
+
+
+def svec_map(field, op, ins, challenge=None, out=None, mont=False):
+    """nmx_svec_map: an element-wise NIFS kernel (L.OP_*) over sharded vectors, every device on its own piece."""
+    if out is None:
+        out = ShardedVector(ins[0].n_key, ins[0].n)
+    hs = (ctypes.c_uint64 * len(ins))(*[v.handle for v in ins])
+    ch = None if challenge is None else _host_u8(challenge, 32)
+    _check(L.lib().nmx_svec_map(field, op, hs, len(ins), None if ch is None else ch.ctypes.data,
+                                L.SCALARS_MONT if mont else 0, out.handle))
+    return out
+
+
+def _is_sharded_list(x):
+    return isinstance(x, (list, tuple)) and len(x) > 0 and all(_is_device_tensor(t) for t in x)
+
+
 def _is_device_tensor(x):
     return hasattr(x, "data_ptr") and getattr(x, "is_cuda", False)
 
@@ -190,7 +245,24 @@ class DlogGroup:
         """offset: with a CommitmentKey, use bases[offset .. offset + n) of it (`&ck.ck[offset..][..n]`).
         With a host array (the trait's slice form) the library's slice cache makes the array resident on first
         sight -- pass the SAME array object (or a prefix view of it) again and no bases move; nocache=True uploads
-        for this call only."""
+        for this call only.
+        Shard-resident scalars over a multi-device key: a ShardedVector, or a list of CUDA tensors -- one per piece of
+        shard_plan(len(key), devices, offset, n), each on that piece's device (NMX_SCALARS_SHARDED)."""
+        if isinstance(scalars, ShardedVector):
+            assert isinstance(bases, CommitmentKey) and offset == 0
+            out = _Out(partial=partial)
+            flags = (L.SCALARS_MONT if mont else 0) | (L.OUT_PARTIAL if partial else 0)
+            _check(L.lib().nmx_msm_svec(bases.handle, scalars.handle, len(scalars), flags, *out.p))
+            return out.get()
+        if _is_sharded_list(scalars):
+            assert isinstance(bases, CommitmentKey)
+            ptrs = (ctypes.c_void_p * len(scalars))(*[t.data_ptr() for t in scalars])
+            n = sum(t.numel() * t.element_size() for t in scalars) // 32
+            assert offset + n <= bases.n
+            out = _Out(partial=partial)
+            flags = L.SCALARS_SHARDED | (L.SCALARS_MONT if mont else 0) | (L.OUT_PARTIAL if partial else 0)
+            _check(L.lib().nmx_msm_handle(bases.handle, offset, ptrs, n, flags, *out.p))
+            return out.get()
         sp, n, dev, _k = _scalar_arg(scalars, 32)
         flags = dev | (L.SCALARS_MONT if mont else 0) | (L.OUT_PARTIAL if partial else 0) | (L.BASES_NOCACHE if nocache else 0)
         out = _Out(partial=partial)
@@ -259,7 +331,14 @@ class CommitmentEngine:
         return CommitmentKey.generate(self.group.curve, n, k0)
 
     def commit(self, ck, v, r=None, mont=False, partial=False):
-        """msm(v, ck[..len v]) + h*r  (pedersen.rs:263-270, hyperkzg.rs:584-591)."""
+        """msm(v, ck[..len v]) + h*r  (pedersen.rs:263-270, hyperkzg.rs:584-591).  v may be a ShardedVector."""
+        if isinstance(v, ShardedVector):
+            rr = _host_u8(bytes(32) if r is None else r, 32)
+            hh = _host_u8(ck.h, 64)
+            flags = (L.SCALARS_MONT if mont else 0) | (L.BASES_MONT if ck.mont else 0) | (L.OUT_PARTIAL if partial else 0)
+            out = _Out(partial=partial)
+            _check(L.lib().nmx_commit_svec(ck.handle, v.handle, len(v), hh.ctypes.data, rr.ctypes.data, flags, *out.p))
+            return out.get()
         sp, n, dev, _k = _scalar_arg(v, 32)
         assert len(ck) >= n, "assert!(ck.ck.len() >= v.len())"
         rr = _host_u8(bytes(32) if r is None else r, 32)

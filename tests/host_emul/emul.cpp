@@ -20,6 +20,7 @@
 
 using namespace nmx;
 
+static unsigned long long g_block_kernel_launches = 0;
 static uint32_t g_seg_lanes = 37;             // emul_set_seg_lanes
 static uint32_t g_seg_min_total = 1u << 21;  // emul_set_seg_min_total: lower it to route small MSMs through msm_seg.hpp
 
@@ -39,6 +40,7 @@ struct HostEmulBackend {
   }
   template <class A> void launch_kernel(void (*k)(A), uint32_t grid, uint32_t block, const A& a) {
     if (grid == 0) return;
+    g_block_kernel_launches++;
     simt::launch(grid, block, [&] { k(a); });  // one fiber per thread, real barriers (tests/host_emul/simt.hpp)
   }
   template <int FID>
@@ -267,12 +269,13 @@ static int partition_check(const uint8_t* scalars, size_t n, uint32_t c, uint32_
                            uint32_t stride, uint32_t offset, uint32_t ct_width) {
   constexpr int SF = F_BN254_FR;
   const uint32_t bits = u64_bits ? u64_bits : (uint32_t)FpParams<SF>::BITS;
-  MsmShape sh = make_shape((uint32_t)n, bits, 0, c);
-  if (!partition_supported(sh, true)) return -2;
+  const bool table_mode = stride != 0;  // stride 0: plain keys, one bucket set per window (key = w * M + |d| - 1)
+  MsmShape sh = table_mode ? make_shape((uint32_t)n, bits, 0, c) : make_shape((uint32_t)n, bits, c, 0);
+  if (!partition_supported(sh, table_mode)) return -2;
   const size_t total = sh.total;
   PartArgs<SF> pa;
   PartBufs& pb = pa.b;
-  pb.ps = make_part_shape(sh);
+  pb.ps = make_part_shape(sh, table_mode);
   if (grid_override) pb.ps.grid1 = grid_override;
   pb.nbuckets = sh.nbuckets;
   std::vector<uint32_t> start(sh.nbuckets + 1), end(sh.nbuckets + 1), ctr(2048 + 3 * kTabStride + 1 + 2 * (size_t)sh.nbuckets),
@@ -390,6 +393,7 @@ int emul_precomp_check(int curve, const uint8_t* key_xy64, size_t n, uint32_t c)
   return -2;
 }
 
+unsigned long long emul_block_kernel_launches() { return g_block_kernel_launches; }  // the partition's kernels (tests: which path ran)
 void emul_set_seg_min_total(uint32_t v) { g_seg_min_total = v; }
 void emul_set_seg_lanes(uint32_t v) { g_seg_lanes = v; }
 

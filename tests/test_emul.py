@@ -280,6 +280,36 @@ def test_emul_partition_kernels(emul, c, n, grid):
     assert emul.emul_partition_check(s64.ctypes.data, n, c, 33, grid, n, 0, 1) == 0
 
 
+@pytest.mark.parametrize("c,n,grid", [(12, 5000, 0), (16, 3000, 2), (9, 1000, 1), (5, 300, 0), (3, 100, 0), (13, 1, 0)])
+def test_emul_partition_kernels_plain_keys(emul, c, n, grid):
+    """Round 4: the same two-level counting scatter for keys WITHOUT window tables -- W bucket sets, key =
+    w * M + |d| - 1 over ceil(log2(W * M)) bits (19 for the c = 16 / W = 16 of a 2^20-pair plain MSM: the wide geometry; W * M
+    need not be a power of two, the bins past the last bucket stay empty) -- against DigitsFn + a sort.  stride = 0 selects
+    the plain layout (the value word is the base index itself)."""
+    # (the wide geometry launches ~1000 mostly idle 1024-thread blocks per level: two scalar sets keep its emulation short)
+    for kind in (["random", "equal", "zero_rm1", "u1"] if c < 16 else ["random", "zero_rm1"]):
+        sc = np.ascontiguousarray(util.scalar_set(0, n, kind))
+        for ct in (1, 0):
+            rc = emul.emul_partition_check(sc.ctypes.data, n, c, 0, grid, 0, 0, ct)
+            assert rc == 0, (c, n, grid, kind, ct, rc)
+    s64 = np.ascontiguousarray(util.small_scalars(n, 33))
+    assert emul.emul_partition_check(s64.ctypes.data, n, c, 33, grid, 0, 0, 1) == 0
+
+
+def test_emul_plain_msm_runs_the_partition_not_the_sort(emul):
+    """A plain-key MSM through msm_pipeline takes the hand-written partition (block-level kernels) for every default window
+    width, down to the 85-window shapes of tiny inputs."""
+    emul.emul_block_kernel_launches.restype = ctypes.c_ulonglong
+    c = R.GRUMPKIN
+    for n in (2, 40, 300, 5000):
+        bases = cref.sequential_bases(c, 7 + n, n)
+        sc = util.scalar_set(c.cid, n, "random")
+        before = emul.emul_block_kernel_launches()
+        rc, got, inf = run(emul, c.cid, sc, bases, n)
+        assert rc == 0 and (got, inf) == cref.msm(c.cid, sc, bases, n)
+        assert emul.emul_block_kernel_launches() - before == 5, n    # hist_hi, tiles, part_hi, hist_lo, part_lo
+
+
 @pytest.mark.parametrize("lanes", [37, 700, 5000])
 def test_emul_segment_balanced_accumulate(emul, lanes):
     """msm_seg.hpp (AccumSegFn / PlanSegFn / FoldRawFn / FinalSegFn) on the table path: segments that straddle bucket

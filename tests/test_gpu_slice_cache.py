@@ -119,11 +119,12 @@ def test_reused_address_with_new_content_is_detected(nmx, fresh, n):
 
 
 @pytest.mark.parametrize("n,where", [(50000, 0.37), (1 << 17, 0.999), (50000, 0.0001)])
-def test_single_point_edit_without_invalidate_is_caught_within_bounded_calls(nmx, fresh, n, where):
-    """... and WITHOUT the invalidate (a caller breaking the contract): every call fully verifies a rolling
-    window of max(4096, n/16) consecutive points of the caller's bytes -- concurrently with the MSM -- so one edited point
-    anywhere in a long array is noticed within 16 calls; the call that notices drops the entry, re-uploads and returns the
-    RIGHT point.  Until then the answers are those of the resident (old) key, never anything else."""
+def test_single_point_edit_without_invalidate_first_call_is_right(nmx, fresh, n, where):
+    """The trait is a pure function of the slice's CONTENTS (/root/reference/src/provider/traits.rs:79): a caller that rewrites
+    ONE point of a long cached array in place -- without nmx_cache_invalidate -- must get the new answer from the VERY NEXT
+    call (the rolling window let up to 15 calls return the old key's commitment).  Default verification
+    re-hashes the caller's whole slice on pool workers while the GPU runs the MSM; the stale result is discarded, the entry
+    dropped, the call repeated on a fresh upload."""
     S = fresh
     c = R.BN254_G1
     g = nmx.DlogGroup(c.cid)
@@ -131,23 +132,55 @@ def test_single_point_edit_without_invalidate_is_caught_within_bounded_calls(nmx
     sc = util.random_scalars(c.cid, n, seed=19)
     old = cref.msm(c.cid, sc, bases, n)
     assert as_pair(g.vartime_multiscalar_mul(sc, bases)) == old
-    j = min(n - 2, max(1, int(n * where)))          # not the first / last point (those are checked on every call)
+    assert as_pair(g.vartime_multiscalar_mul(sc, bases)) == old
+    j = min(n - 2, max(1, int(n * where)))          # not the first / last point (those are in the quick look of every call)
     bases[j] = cref.sequential_bases(c, 987654, 1)[0]
     new = cref.msm(c.cid, sc, bases, n)
     assert new != old
     before = S.stats()
-    seen_new = None
-    for call in range(1, 18):
-        got = as_pair(g.vartime_multiscalar_mul(sc, bases))
-        assert got in (old, new), call
-        if got == new:
-            seen_new = call
-            break
-    assert seen_new is not None and seen_new <= 17, "the rolling check never reached the edited point"
+    assert as_pair(g.vartime_multiscalar_mul(sc, bases)) == new, "the first call after the edit returned the old key's commitment"
     d = delta(S, before)
     assert d[S.STAT_CACHE_STALE] == 1 and d[S.STAT_CACHE_UPLOADS] == 1
-    for _ in range(3):                              # and it stays right
+    # an interior slice that contains the edited point, and one that does not, both right at once
+    lo, hi = max(0, j - 3000), min(n, j + 3000)
+    assert as_pair(g.vartime_multiscalar_mul(sc[:hi - lo], bases[lo:hi])) == cref.msm(c.cid, sc[:hi - lo], bases[lo:hi], hi - lo)
+    for _ in range(3):                              # and it stays right, served from the cache again
         assert as_pair(g.vartime_multiscalar_mul(sc, bases)) == new
+    assert delta(S, before)[S.STAT_CACHE_UPLOADS] == 1
+
+
+@pytest.mark.parametrize("n,where", [(50000, 0.37), (1 << 17, 0.999)])
+def test_rolling_verification_option_catches_an_edit_within_bounded_calls(nmx, fresh, n, where):
+    """nmx_set_option("cache_verify", 1) -- for callers that register immutable keys: a rolling window of max(4096, n/16)
+    consecutive points per call instead of the whole slice; one edited point anywhere in a long array is then noticed within
+    16 calls (the call that notices drops the entry, re-uploads and returns the RIGHT point); until then the answers are those
+    of the resident (old) key, never anything else."""
+    S = fresh
+    L = S.lib()
+    assert L.nmx_set_option(b"cache_verify", 1) == 0
+    try:
+        c = R.BN254_G1
+        g = nmx.DlogGroup(c.cid)
+        bases = cref.sequential_bases(c, 4242, n).copy()
+        sc = util.random_scalars(c.cid, n, seed=19)
+        old = cref.msm(c.cid, sc, bases, n)
+        assert as_pair(g.vartime_multiscalar_mul(sc, bases)) == old
+        j = min(n - 2, max(1, int(n * where)))
+        bases[j] = cref.sequential_bases(c, 987654, 1)[0]
+        new = cref.msm(c.cid, sc, bases, n)
+        before = S.stats()
+        seen_new = None
+        for call in range(1, 18):
+            got = as_pair(g.vartime_multiscalar_mul(sc, bases))
+            assert got in (old, new), call
+            if got == new:
+                seen_new = call
+                break
+        assert seen_new is not None and seen_new <= 17, "the rolling check never reached the edited point"
+        d = delta(S, before)
+        assert d[S.STAT_CACHE_STALE] == 1 and d[S.STAT_CACHE_UPLOADS] == 1
+    finally:
+        assert L.nmx_set_option(b"cache_verify", 0) == 0
 
 
 def test_interior_slice_after_address_reuse(nmx, fresh):
