@@ -345,7 +345,9 @@ def inprocess_multi(args, torch):
     ck = nova_amd.CommitmentKey.generate(cid, total, k0=1)   # P_i = (1 + i) G, cut into k contiguous shards
     t_key = time.perf_counter() - t0
     group = nova_amd.DlogGroup(cid)
-    plan = nova_amd.shard_plan(total, k, 0, total)            # [(logical device, offset in the shard, count)]
+    # [(logical device, offset in the shard, count)] from the layout the REGISTERED key has: the generated key carries its
+    # blinding point behind ck (total + 1 points), so the cut is not at total / k
+    plan = ck.shard_plan(0, total)
     assert args.dist == "random", "the in-process mode draws its scalars on the devices: --dist random only"
 
     def draw(dev, cnt, seed):

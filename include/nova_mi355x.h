@@ -46,8 +46,9 @@ enum {
                                 /* array up in / insert it into the slice cache (one-shot arrays)               */
   NMX_SCALARS_SHARDED = 1u << 8, /* shard-resident scalars (nmx_msm_handle, nmx_msm_u64_handle with an explicit max_num_bits,
                                     nmx_commit, nmx_msm_batch_handle): `scalars` is a HOST array of device pointers, one per
-                                    piece that nmx_shard_plan(key length, nmx_devices_in_use(), offset, n) reports, in its
-                                    order; piece j = the `count_j` scalars of the pairs whose bases live on `device_j`, in
+                                    piece that nmx_bases_shard_plan(handle, offset, n) reports (= nmx_shard_plan(REGISTERED key
+                                    length, devices, offset, n)), in its order; every piece must be device memory on its shard's
+                                    GPU and at least count_j scalars long (checked: NMX_E_ARG otherwise); piece j = the `count_j` scalars of the pairs whose bases live on `device_j`, in
                                     the HBM of THAT device -- the reference chunks coefficients and bases together
                                     (src/provider/msm.rs:564-574), so nothing crosses xGMI or PCIe inside the call.  A key on
                                     one device has one piece.  nmx_svec_* allocates vectors in this layout.          */
@@ -107,6 +108,12 @@ int nmx_devices_in_use(void); /* logical devices new keys are sharded over (1 = 
  * writes up to cap triples (device, offset inside the shard, count) and returns how many the call needs.  Pure host
  * arithmetic (no device needed): the rule the library itself uses. */
 int nmx_shard_plan(size_t n_key, int k, size_t offset, size_t n, size_t* out_triples, int cap);
+/* The same triples for a REGISTERED key, from the layout it actually has (a key keeps the layout of the device set it was
+ * registered under; an unsharded key answers one triple), plus its registered length in *n_key (may be NULL).  This is the
+ * plan to cut NMX_SCALARS_SHARDED pieces by: a plan computed from a length that is not the registered one (e.g. a key
+ * registered with its blinding point appended has n + 1 points) puts the cut in the wrong place.  Returns the number of
+ * triples or a negative error. */
+int nmx_bases_shard_plan(uint64_t handle, size_t offset, size_t n, size_t* out_triples, int cap, size_t* n_key);
 const char* nmx_last_error(void);
 const char* nmx_version(void);
 

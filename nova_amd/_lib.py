@@ -48,6 +48,7 @@ def lib():
     L.nmx_init_devices.argtypes = [i, u32]
     L.nmx_devices_in_use.argtypes = []
     L.nmx_shard_plan.argtypes = [sz, i, sz, sz, vp, i]
+    L.nmx_bases_shard_plan.argtypes = [u64, sz, sz, vp, i, ctypes.POINTER(sz)]
     L.nmx_last_error.restype = ctypes.c_char_p
     L.nmx_version.restype = ctypes.c_char_p
     L.nmx_bases_register.argtypes = [i, vp, sz, u32, ctypes.POINTER(u64)]

@@ -420,6 +420,32 @@ static void combine_partials(const CurveOps& o, const uint8_t* partials, const s
   t_rccl_ranks = used_ranks;
   t_combine_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
+// A piece of a raw NMX_SCALARS_SHARDED call carries no length: the caller cut the vector by a plan, and a plan made for the
+// wrong key length (the classic: a key registered with its blinding point behind it has n + 1 points) would make the digit
+// kernels read past the piece -- a GPU memory fault that ends the process.  Two driver queries per piece (~1 us each) turn
+// that into an error: the piece must be device memory on the shard's GPU, and [p, p + bytes) must lie inside one allocation.
+static void check_shard_piece(const void* p, size_t bytes, int logical_dev) {
+  require(p != nullptr, NMX_E_ARG, "null shard pointer");
+  hipPointerAttribute_t at;
+  memset(&at, 0, sizeof at);
+  if (hipPointerGetAttributes(&at, p) != hipSuccess || (at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeManaged)) {
+    (void)hipGetLastError();
+    throw Fail{NMX_E_ARG, "NMX_SCALARS_SHARDED: a piece is not a device pointer"};
+  }
+  if (at.device != hip_device_of(logical_dev))
+    throw Fail{NMX_E_ARG, "NMX_SCALARS_SHARDED: piece on HIP device " + std::to_string(at.device) + ", its shard lives on device " +
+                              std::to_string(hip_device_of(logical_dev)) + " (cut the vector with nmx_bases_shard_plan)"};
+  hipDeviceptr_t base = nullptr;
+  size_t size = 0;
+  if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) != hipSuccess) {
+    (void)hipGetLastError();
+    return;  // (not every allocator answers this query: the device check above stands)
+  }
+  const size_t inside = (size_t)((const char*)p - (const char*)base);
+  require(inside <= size && bytes <= size - inside, NMX_E_ARG,
+          "NMX_SCALARS_SHARDED: a piece is shorter than its shard's share of the call (cut the vector with nmx_bases_shard_plan: "
+          "the plan must be made for the REGISTERED key length)");
+}
 // out = sum scalars[i] * key[offset + i] for any key: one device, or one partial per shard touched + the combine step
 static void key_msm(Ctx& c0, const BaseSet& bs, size_t offset, size_t n, const MsmCall& mc, uint32_t flags, uint8_t* out,
                     uint8_t* inf) {
@@ -430,7 +456,7 @@ static void key_msm(Ctx& c0, const BaseSet& bs, size_t offset, size_t n, const M
       m.scalars = n ? ((const void* const*)mc.scalars)[0] : nullptr;
       m.scalars_device = true;
       m.scalars_sharded = false;
-      require(m.scalars || n == 0, NMX_E_ARG, "null shard pointer");
+      if (n) check_shard_piece(m.scalars, n * (mc.u64_mode ? 8 : 32), bs.dev);
       o.msm_key(c0, bs, offset, n, m, flags, out, inf);
       return;
     }
@@ -445,7 +471,7 @@ static void key_msm(Ctx& c0, const BaseSet& bs, size_t offset, size_t n, const M
   const bool force_peer = G.force_peer_copy.load(std::memory_order_relaxed) != 0;
   if (mc.scalars_sharded)
     for (size_t i = 0; i < jobs.size(); i++)
-      require(((const void* const*)mc.scalars)[i] != nullptr, NMX_E_ARG, "null shard pointer");
+      check_shard_piece(((const void* const*)mc.scalars)[i], jobs[i].cnt * sbytes, jobs[i].part->dev);
   run_on_parts(jobs.size(), true, [&](size_t i) {
     const PartJob& j = jobs[i];
     CtxLease L(j.part->dev);
@@ -1130,6 +1156,29 @@ int nmx_shard_plan(size_t n_key, int k, size_t offset, size_t n, size_t* out_tri
     cnt++;
   }
   return cnt;
+}
+
+int nmx_bases_shard_plan(uint64_t handle, size_t offset, size_t n, size_t* out_triples, int cap, size_t* n_key) {
+  int cnt = 0;
+  const int rc = guarded([&] {
+    auto bs = lookup(handle);
+    if (n_key) *n_key = bs->n;
+    require(slice_ok(*bs, offset, n), NMX_E_HANDLE, "offset + n beyond the registered key");
+    auto put = [&](size_t dev, size_t poff, size_t c) {
+      if (out_triples && cnt < cap) {
+        out_triples[3 * cnt] = dev;
+        out_triples[3 * cnt + 1] = poff;
+        out_triples[3 * cnt + 2] = c;
+      }
+      cnt++;
+    };
+    if (bs->parts.empty()) {
+      if (n) put((size_t)bs->dev, offset, n);
+      return;
+    }
+    for (const PartJob& j : parts_of(*bs, offset, n)) put((size_t)j.part->dev, j.poff, j.cnt);
+  });
+  return rc ? rc : cnt;
 }
 
 const char* nmx_last_error(void) { return t_err.c_str(); }

@@ -59,6 +59,11 @@ class ShardedVector:
         self.handle, self.n_key, self.n = h.value, n_key, n
 
     @classmethod
+    def for_key(cls, ck, elems):
+        """Laid out like the registered key `ck` (its registered length, not len(ck): see CommitmentKey.shard_plan)."""
+        return cls.from_host(ck.registered_len(), elems)
+
+    @classmethod
     def from_host(cls, n_key, elems):
         a = _host_u8(elems, 32)
         v = cls(n_key, a.size // 32)
@@ -212,6 +217,25 @@ class CommitmentKey:
         key = cls(curve, h.value, n, bytes(64))
         key.h = key.read(n, 1).tobytes()
         return key
+
+    def shard_plan(self, offset=0, n=None):
+        """[(device, offset inside the shard, count)] for a call over key[offset, offset + n), from the layout the
+        REGISTERED key has (nmx_bases_shard_plan) -- the plan to cut shard-resident scalar pieces by.  (A generated key is
+        registered with its blinding point h behind it: n + 1 points, so shard_plan(len(key), ...) would cut elsewhere.)"""
+        n = self.n - offset if n is None else n
+        buf = (ctypes.c_size_t * (3 * 64))()
+        cnt = L.lib().nmx_bases_shard_plan(self.handle, offset, n, buf, 64, None)
+        if cnt < 0:
+            raise NmxError(cnt, L.lib().nmx_last_error().decode())
+        return [(buf[3 * i], buf[3 * i + 1], buf[3 * i + 2]) for i in range(cnt)]
+
+    def registered_len(self):
+        """Number of points registered under the handle (len(self) + 1 for a generated key: h sits behind ck)."""
+        nk = ctypes.c_size_t(0)
+        cnt = L.lib().nmx_bases_shard_plan(self.handle, 0, 0, None, 0, ctypes.byref(nk))
+        if cnt < 0:
+            raise NmxError(cnt, L.lib().nmx_last_error().decode())
+        return nk.value
 
     def read(self, offset, n):
         out = np.zeros((n, 64), dtype=np.uint8)
