@@ -40,7 +40,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 
 BYTES_PER_PAIR = 96            # 32 B scalar + 64 B affine base, each read once
 STAGES = ["digits", "sort", "bounds_plan", "accum", "fold", "reduce", "tail"]
 DTYPE = "9x29-bit limbs (256-bit modular integer, Montgomery R = 2^261)"
-MAD_PEAK_T = 28.8              # measured v_mad_u64_u32 rate, T/s (bench/ubench.hip)
+VOP3_RATE_T = 30.0             # measured full-rate VOP3 issue of this chip, T lane-ops/s (same file: 29.4-36 by instruction)
+MAD_RATE_T = 29.4              # measured v_mad_u64_u32 issue rate of this chip, T/s (profiles/r01_ubench_instruction_rates.jsonl)
 # multiply-adds per XYZZ mixed addition (curve.hpp add_affine: 6 products, 2 squarings, 1 two-product sum with one
 # reduction) by base field: BN254 Fq / Fr 6 x 162 + 2 x 126 + 243 = 1467 (the static count of the kernel agrees:
 # profiles/r03_msm_2p20/accum_isa_hist.txt); the Pasta moduli have three zero limbs of nine, whose reduction terms are
@@ -273,10 +274,14 @@ def main():
                 "note": "algorithmic bytes = 96 B/pair x pairs per launch / accum-kernel time (hipEvents on the "
                         "library stream); the MSM is integer-VALU-bound, not HBM-bound (DESIGN.md). traffic = HBM bytes "
                         "per launch from the separate rocprofv3 --pmc passes in profiles/ (null for other configs).",
-                # the roofline that actually binds this kernel: 32x32+64 multiply-adds against the measured
-                # v_mad_u64_u32 rate (profiles/r01_ubench_instruction_rates.jsonl)
+                # the multiply-adds alone (1 467 of the ~2 150 VALU instructions of a mixed addition) against the rate the chip
+                # issues v_mad_u64_u32 at when it issues nothing else (measured, profiles/r01_ubench_instruction_rates.jsonl):
+                # the share of that ceiling the kernel's USEFUL arithmetic reaches.  The ceiling of the whole instruction stream
+                # (lanes x clock) is `valu_issue` below.
                 "valu_mad": {"achieved_T_per_s": MADS_PER_MADD * madds_per_launch(n, args) / (accum_ms * 1e-3) / 1e12 if accum_ms > 0 else 0.0,
-                             "peak_T_per_s": VALU_PEAK_T, "frac": (MADS_PER_MADD * madds_per_launch(n, args) / (accum_ms * 1e-3) / 1e12) / VALU_PEAK_T if accum_ms > 0 else 0.0,
+                             "peak_T_per_s": MAD_RATE_T,
+                             "peak_is": "measured v_mad_u64_u32-only issue rate (micro-benchmark), not lanes x clock",
+                             "frac": (MADS_PER_MADD * madds_per_launch(n, args) / (accum_ms * 1e-3) / 1e12) / MAD_RATE_T if accum_ms > 0 else 0.0,
                              "mads_per_mixed_add": MADS_PER_MADD},
             },
         }
@@ -597,7 +602,7 @@ def fieldvec_block(args, torch, L):
     ms, o = kernel_ms(lambda: fv.mle_evaluate(fid, A, point))
     entry("mle_eval", N24, 32, ms, as_bytes(o) == cref.mle_evaluate(fid, hA, 24, point))
     ms, o = kernel_ms(lambda: fv.mle_evaluate(fid, A[:N20], point[:20]))
-    entry("mle_eval_2p20", N20, 32, ms, as_bytes(o) == cref.mle_evaluate(fid, hA[:N20], 20, point[:20]), "launch floor: three launches")
+    entry("mle_eval_2p20", N20, 32, ms, as_bytes(o) == cref.mle_evaluate(fid, hA[:N20], 20, point[:20]), "launch floor: one launch for both eq tables, then the pass and its one-block final sum")
     # 2^22: lincomb of 8, suffix Horner, SpMV
     vecs = [p[j * N22:(j + 1) * N22] for p in (A, B) for j in range(4)]
     ms, o = kernel_ms(lambda: fv.lincomb_powers(fid, vecs, r))
@@ -619,9 +624,24 @@ def fieldvec_block(args, torch, L):
     entry("spmv", N22, 3 * 68 + 40, ms, as_bytes(o, m) == cref.spmv(fid, indptr[: m + 1], indices, data, m, hA[:N22]),
           "CSR, 3 non-zeros per row, 9 of 10 coefficients +-1 (R1CS-like)")
     mat.close()
+    # The multiplier ceiling of each kernel, from the counters: VALU wave-instructions per launch (rocprofv3 --pmc SQ_INSTS_VALU,
+    # a separate pass, committed under profiles/) x 64 lanes / the chip's measured VOP3 issue rate = the time the arithmetic
+    # alone takes.  A kernel whose valu_floor_ms is close to kernel_ms is multiplier-bound: on a slower-clocked lease its HBM
+    # fraction drops with the clock and no memory-side change can lift it.
+    try:
+        floors = json.load(open(os.path.join(ROOT, "profiles", "r04_fieldvec", "valu_insts.json")))
+    except (OSError, ValueError):
+        floors = {}
+    for name, e in res.items():
+        f = floors.get(name)
+        if isinstance(e, dict) and f and f.get("log2n") == e["log2n"]:
+            e["valu_floor_ms"] = round(f["SQ_INSTS_VALU"] * 64 / VOP3_RATE_T / 1e12 * 1e3, 4)
+            e["valu_floor_share"] = round(e["valu_floor_ms"] / e["kernel_ms"], 3) if e["kernel_ms"] > 0 else None
+    res["_valu_floor"] = ("valu_floor_ms = SQ_INSTS_VALU per launch (profiles/r04_fieldvec/valu_insts.json, rocprofv3 --pmc, separate pass) "
+                          f"x 64 / {VOP3_RATE_T} T lane-ops/s (measured VOP3 issue rate, profiles/r01_ubench_instruction_rates.jsonl)")
     res["_what"] = ("bn254_fr vectors resident in HBM; kernel_ms = hipEvents on the library stream, mean of 5 launches; frac = "
                     "algorithmic bytes / kernel time / 8000 GB/s; gpu_matches_cpu = oracle/nova_ref.c on the same inputs")
-    res["_min_frac"] = min(v["frac"] for k, v in res.items() if isinstance(v, dict) and k != "mle_eval_2p20")
+    res["_min_frac"] = min(v["frac"] for k, v in res.items() if isinstance(v, dict))
     return res
 
 
@@ -710,6 +730,7 @@ def extras(out, args, torch, L, ck, host_scalars, dev_scalars):
     ps = prove_step_replay(a2, torch)
     out["prove_step_replay_ms"] = {"ms": round(ps["value"], 4), "iters_per_step": 65536, "cpu_ms": round(ps["cpu_baseline"]["value"], 2),
                                    "cpu_cores": ps["cpu_baseline"]["cores"], "gpu_matches_cpu": ps["cpu_baseline"]["gpu_matches_cpu"],
+                                   "breakdown_ms": ps.get("breakdown_ms"),
                                    "what": ps["config"]["workload"]}
     # (5) configs[4]: HyperKZG prove replay at n = 2^20
     a3 = argparse.Namespace(**vars(args))
@@ -800,23 +821,33 @@ def prove_step_replay(args, torch):
     rT = {k: util.random_scalars(c[0], 1, seed=33) for k, c in cur.items()}
     uS = util.random_scalars(1, 1, seed=34)
 
+    spans = None                     # per-call wall times of the instrumented passes (every call is synchronous)
+
+    def call(name, fn):
+        if spans is None:
+            return fn()
+        t = time.perf_counter()
+        v = fn()
+        spans.setdefault(name, []).append(time.perf_counter() - t)
+        return v
+
     def nifs(k, uu):
         cid, fid, n = cur[k]
         d = dev[k]
-        Z = fv.vec_add(fid, d["W1"], d["W"])                                  # r1cs/mod.rs:590-609
-        AZ, BZ, CZ = (m.multiply_vec(Z) for m in mats[k])                     # r1cs/mod.rs:612
-        T = fv.cross_term(fid, AZ, BZ, CZ, d["E1"], uu)                       # r1cs/mod.rs:614-620
-        comT = ce[k].commit(ck[k], T, rT[k])                                  # r1cs/mod.rs:622
-        W = fv.axpy(fid, d["W1"], d["W"], r[k])                               # r1cs/mod.rs:1058-1062
-        E = fv.axpy(fid, d["E1"], T, r[k])                                    # r1cs/mod.rs:1063-1067
+        Z = call(f"{k}.vec_add", lambda: fv.vec_add(fid, d["W1"], d["W"]))                       # r1cs/mod.rs:590-609
+        AZ, BZ, CZ = (call(f"{k}.spmv_x3", lambda m=m: m.multiply_vec(Z)) for m in mats[k])      # r1cs/mod.rs:612
+        T = call(f"{k}.cross_term", lambda: fv.cross_term(fid, AZ, BZ, CZ, d["E1"], uu))         # r1cs/mod.rs:614-620
+        comT = call(f"{k}.commit_T", lambda: ce[k].commit(ck[k], T, rT[k]))                      # r1cs/mod.rs:622
+        W = call(f"{k}.fold_x2", lambda: fv.axpy(fid, d["W1"], d["W"], r[k]))                    # r1cs/mod.rs:1058-1062
+        E = call(f"{k}.fold_x2", lambda: fv.axpy(fid, d["E1"], T, r[k]))                         # r1cs/mod.rs:1063-1067
         return comT, W, E
 
     def step():
         out = []
         out.append(nifs("S", uS)[0])                                          # nova/mod.rs:464  NIFS on the secondary
-        out.append(ce["P"].commit(ck["P"], dev["P"]["W"]))                    # nova/mod.rs:477-496 primary witness commit
+        out.append(call("P.commit_W", lambda: ce["P"].commit(ck["P"], dev["P"]["W"])))   # nova/mod.rs:477-496 primary witness commit
         out.append(nifs("P", u)[0])                                           # nova/mod.rs:502  NIFS on the primary
-        out.append(ce["S"].commit(ck["S"], dev["S"]["W"]))                    # nova/mod.rs:515-541 secondary witness commit
+        out.append(call("S.commit_W", lambda: ce["S"].commit(ck["S"], dev["S"]["W"])))   # nova/mod.rs:515-541 secondary witness commit
         return out
 
     for _ in range(args.warmup):
@@ -827,6 +858,15 @@ def prove_step_replay(args, torch):
         res = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
+    # the same step again with every provider call timed on its own (wall clock around the synchronous C call, so each span
+    # carries its launch + wake-up latency; P = primary BN254, S = secondary Grumpkin; x2 / x3 = sum over that many calls)
+    spans = {}
+    passes = 5
+    for _ in range(passes):
+        step()
+    breakdown = {k: round(sum(v) / passes * 1e3, 4) for k, v in sorted(spans.items())}
+    breakdown["_sum"] = round(sum(v for v in breakdown.values()), 4)
+    spans = None
     outj = {
         "metric": "RecursiveSNARK prove_step provider-call REPLAY ms (minroot, BN254/Grumpkin)", "value": dt * 1e3, "unit": "ms",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": False,
@@ -835,6 +875,7 @@ def prove_step_replay(args, torch):
                                "(Grumpkin); 4 MSMs + 6 SpMVs + 2 vector adds + 2 cross terms + 4 folds; no synthesis / Poseidon "
                                "(BASELINE.json configs[3])"},
         "roofline": None,
+        "breakdown_ms": breakdown,
     }
     if not args.no_cpu_baseline:
         from oracle import cref

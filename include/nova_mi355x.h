@@ -339,7 +339,9 @@ int nmx_field_lincomb_powers(int field, const void* const* vecs, const size_t* l
 
 /* out[i] = sum_{k >= i} f[k] * u^(k-i), i < n (coefficient form).  out[0] is `poly_eval(f, u)` (Horner,
  * src/provider/hyperkzg.rs:1011-1020); out[1..n) is the quotient h of `div_by_monomial(f, u)`
- * (src/provider/hyperkzg.rs:961-999, h[i-1] = f[i] + h[i]*u) that kzg_open commits to. */
+ * (src/provider/hyperkzg.rs:961-999, h[i-1] = f[i] + h[i]*u) that kzg_open commits to.  `f` and `out` must NOT overlap
+ * (NMX_E_ARG for device-resident vectors that do: every out[i] depends on all later coefficients while other waves still
+ * read them).  Coefficients may be any 256-bit words; the outputs are canonical (< p). */
 int nmx_poly_suffix_horner(int field, const void* f, size_t n, const void* u, uint32_t flags, void* out);
 /* HyperKZG's evaluation matrix (src/provider/hyperkzg.rs:1011-1020 `poly_eval`, called for every folded polynomial at
  * the three points r, -r, r^2, :1049-1056): out[i * m + j] = polys[i](points[j]) for k polynomials of any lengths

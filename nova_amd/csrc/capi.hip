@@ -158,6 +158,7 @@ static void ensure_init() {
   if (const char* t = getenv("NMX_SYNC_SPIN_US")) G.sync_spin_us = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_HORNER_TOP")) G.horner_top = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_HORNER_SUB")) G.horner_sub = (uint32_t)atoi(t);
+  if (const char* t = getenv("NMX_TUNE_HORNER_ORDER")) G.horner_order = atoi(t) ? 1u : 0u;
   if (const char* t = getenv("NMX_TUNE_EQ_MAX_BLOCKS")) G.eq_max_blocks = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_SEG_HEAVY_ABOVE")) G.seg_heavy_above = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_ACCUM_PF")) G.accum_prefetch = (uint32_t)atoi(t);
@@ -1865,8 +1866,7 @@ struct EvalScratch {
     eqL = (uint32_t*)c.aux;
     eqR = (uint32_t*)(c.aux + bl);
     z = bz ? c.aux + bl + br : nullptr;
-    fv_eq_evals(c, field, r, (uint32_t)s_left, flags, eqL);
-    fv_eq_evals(c, field, (const uint8_t*)r + 32 * s_left, (uint32_t)s_right, flags, eqR);
+    fv_eq_evals_pair(c, field, r, (uint32_t)s_left, (uint32_t)s_right, flags, eqL, eqR);
   }
   // sum_id z[id] * eqL[id >> s_right] * eqR[id & (2^s_right - 1)]: the mode-1 sum over "half" = len
   void evaluate(Ctx& c, int field, const void* zp, size_t len, uint32_t flags, uint8_t* out32) {
@@ -1886,7 +1886,13 @@ int nmx_poly_suffix_horner(int field, const void* f, size_t n, const void* u, ui
   return guarded([&] {
     require(f && u && out, NMX_E_ARG, "null argument");
     require(n >= 1 && n < (1ull << 31), NMX_E_ARG, "assert!(!f.is_empty())");
-    require(!((flags & NMX_SCALARS_DEVICE) && out == f), NMX_E_ARG, "cannot run in place");
+    // never in place, never overlapping: out[i] depends on every f[k >= i] while other waves are still reading them -- and the
+    // two-pass kernels the call repeats on after a scan time-out re-read f after the aborted scan has written to out
+    {
+      const char *fb = (const char*)f, *ob = (const char*)out;
+      require(!((flags & NMX_SCALARS_DEVICE) && fb < ob + n * 32 && ob < fb + n * 32), NMX_E_ARG,
+              "nmx_poly_suffix_horner cannot run in place (f and out overlap)");
+    }
     CtxLease L;
     fv_suffix_horner(*L.c, field, f, n, u, flags, out);
   });
@@ -2068,6 +2074,8 @@ int nmx_set_option(const char* name, uint32_t value) {
     else if (n == "big_threads") G.big_threads = value;
     else if (n == "hist_grid") G.hist_grid = value;
     else if (n == "sync_spin_us") G.sync_spin_us = value;
+    else if (n == "horner_order") G.horner_order = value ? 1u : 0u;
+
     else if (n == "shard_min_n") G.shard_min_n.store(value ? value : 1u);
     else if (n == "cache_table_after") {  // slice cache: window tables from the (value + 1)-th use of an array on (0: at upload)
       std::lock_guard<std::mutex> ck(SC.mu);

@@ -110,6 +110,22 @@ template <int FID> struct EqDirectFn {
   }
 };
 
+// Both sqrt-size tables of an evaluation (multilinear.rs:141-147) in ONE launch: lanes [0, 2^ellL) build the left table, the rest
+// the right one (a 2^20 evaluation was four launches -- two tables, the pass, the final sum -- for 28 us; now two).
+template <int FID> struct EqDirect2Fn {
+  uint32_t *outL, *outR;
+  Fp<FID> r[2 * EqDirectFn<FID>::kMaxEll], nr[2 * EqDirectFn<FID>::kMaxEll];  // left challenges, then the right ones
+  Fp<FID> one;
+  uint32_t ellL, ellR;
+  NMX_HD void operator()(uint32_t g) const {
+    const bool right = g >= (1u << ellL);
+    const uint32_t x = right ? g - (1u << ellL) : g, ell = right ? ellR : ellL, o = right ? ellL : 0u;
+    Fp<FID> acc = one;
+    for (uint32_t i = 0; i < ell; i++) acc = acc * (((x >> (ell - 1 - i)) & 1u) ? r[o + i] : nr[o + i]);
+    st<FID>(right ? outR : outL, x, acc);
+  }
+};
+
 // Coefficient classes, the GPU form of the reference's PrecomputedSparseMatrix (src/r1cs/sparse.rs:19-199: +-1 entries
 // are added / subtracted, |k| <= 7 by repeated doubling, the rest multiplied).  R1CS matrices are almost all +-1: here
 // the class rides in the top four bits of the 32-bit column index (columns < 2^28), so a unit or small entry costs
@@ -256,6 +272,13 @@ template <int FID> struct LinCombFn {
 // 16-element chunks (one lane each: the chains are pure latency, so they are short -- 64-element chunks took 0.20 ms
 // for 2^20 coefficients, 16-element ones 0.12 ms) and the carry phase applied recursively.
 static constexpr uint32_t kHornerChunk = 16;
+// a coefficient as the chains want it: below p.  Any 256-bit word is accepted (as by the other field kernels); one >= p -- up
+// to 5.3 p -- is reduced here, behind one compare chain, so that f + u t stays below the 4 p of the stored copies' canon4.
+template <int FID> NMX_HD Fp<FID> horner_coeff(const uint32_t* w) {
+  Fp<FID> v = Fp<FID>::from_words(w);
+  if (!Fp<FID>::words_lt_p(w)) v = v.canon();
+  return v;
+}
 template <int FID> struct HornerLocalFn {
   const uint32_t* f;
   uint32_t* out;    // local suffix values
@@ -269,7 +292,7 @@ template <int FID> struct HornerLocalFn {
     // stored copy is canonicalised, with the two subtractions a value below 4p needs
     F t = F::zero();
     for (uint32_t i = hi; i-- > lo;) {
-      t = (ld<FID>(f, i) + u * t).norm();
+      t = (horner_coeff<FID>(f + 8 * (size_t)i) + u * t).norm();
       t.canon4().to_words(out + 8 * (size_t)i);
     }
     t.canon4().to_words(heads + 8 * (size_t)c);
@@ -313,9 +336,9 @@ template <int FID, uint32_t K> struct HornerHeadFn {
 #pragma unroll
         for (int j = 0; j < 8; j++) w[k][j] = f[8 * (size_t)(lo + k) + j];
 #pragma unroll
-      for (uint32_t k = K; k-- > 0;) t = (F::from_words(w[k]) + u * t).norm();
+      for (uint32_t k = K; k-- > 0;) t = (horner_coeff<FID>(w[k]) + u * t).norm();
     } else {
-      for (uint32_t k = cnt; k-- > 0;) t = (ld<FID>(f, lo + k) + u * t).norm();
+      for (uint32_t k = cnt; k-- > 0;) t = (horner_coeff<FID>(f + 8 * (size_t)(lo + k)) + u * t).norm();
     }
     t.canon4().to_words(heads + 8 * (size_t)c);  // t < 2.02 p
   }
@@ -338,7 +361,7 @@ template <int FID, uint32_t K> struct HornerWalkFn {
         for (int j = 0; j < 8; j++) w[k][j] = f[8 * (size_t)(lo + k) + j];
 #pragma unroll
       for (uint32_t k = K; k-- > 0;) {  // t < 2.02 p (carry canonical): the chain stays weakly reduced
-        t = (F::from_words(w[k]) + u * t).norm();
+        t = (horner_coeff<FID>(w[k]) + u * t).norm();
         t.canon4().to_words(w[k]);
       }
 #pragma unroll
@@ -347,7 +370,7 @@ template <int FID, uint32_t K> struct HornerWalkFn {
         for (int j = 0; j < 8; j++) out[8 * (size_t)(lo + k) + j] = w[k][j];
     } else {
       for (uint32_t k = cnt; k-- > 0;) {
-        t = (ld<FID>(f, lo + k) + u * t).norm();
+        t = (horner_coeff<FID>(f + 8 * (size_t)(lo + k)) + u * t).norm();
         t.canon4().to_words(out + 8 * (size_t)(lo + k));
       }
     }
@@ -407,8 +430,10 @@ template <int FID> struct HornerScanArgs {
   Fp<FID> u;
   uint32_t n, ntiles, ngroups;
   uint32_t window;  // groups per look-back round, 1 .. 64 (64 in production; smaller values only to test the multi-round path)
-  uint32_t* watchdog;  // pinned host word: set by a wave that polled kScanSpinLimit times in vain (see horner_scan_t)
+  uint32_t* watchdog;  // two pinned host words: [0] set by a wave that polled kScanSpinLimit times in vain, [1] by a coefficient >= p (see horner_scan_t)
   uint32_t spin_limit;
+  uint32_t* ticket;    // start-order counter of the waves (cleared with the flags)
+  uint32_t order;      // 1: tiles by start-order ticket; 0: by block id (option horner_order)
 };
 template <int FID> struct HornerTblArgs {
   uint32_t* tbl;
@@ -519,7 +544,17 @@ template <int FID, int J> __global__ __launch_bounds__(256) void k_horner_scan(H
   __shared__ uint4 lds_all[4][32 * 17];
   __shared__ uint32_t park_all[4][J * 9 * 64];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  const uint32_t r = blockIdx.x * 4u + wave;  // position in dispatch order
+  // Position in START order, drawn from a ticket counter when the wave starts (as CUB's decoupled look-back does), not taken
+  // from blockIdx: a wave then only ever waits for waves that were already RUNNING when it drew its ticket, whatever order the
+  // dispatcher places blocks in -- forward progress no longer rests on "lower block ids become resident first", and the
+  // watchdog below is a backstop for a fault, not for a scheduling assumption.
+  uint32_t r = blockIdx.x * 4u + wave;  // order == 0: position in dispatch order (see HornerScanArgs::order)
+  if (a.order) {  // one ticket per BLOCK (a ticket per wave -- 2048 same-address device atomics at 2^20 -- cost 15-19 us)
+    __shared__ uint32_t blk;
+    if (threadIdx.x == 0) blk = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    r = blk * 4u + wave;
+  }
   if (r >= a.ntiles) return;
   const uint32_t tile = a.ntiles - 1u - r;
   const uint32_t grp = tile / kScanGroup, pos = tile % kScanGroup;
@@ -594,6 +629,18 @@ template <int FID, int J> __global__ __launch_bounds__(256) void k_horner_scan(H
 #pragma unroll 1
   for (uint32_t j = 0; j < (uint32_t)J; j++) {
     load_sub(j);
+    // Coefficients must be below p for the walk's stored copies (canon4: two subtractions, valid below 4 p) to come out
+    // canonical.  A word whose top 64 bits reach p's makes the whole call repeat on the two-pass kernels, which reduce such
+    // words first (horner_coeff): any 256-bit input ends in canonical outputs, the hot path pays ~4 instructions per
+    // coefficient and no cold block (an exact compare in a rarely taken branch cost 18 registers -- a wave per SIMD at J = 1).
+    // A canonical element trips the test with probability < 2^-62 (its top two words equal p's).
+    {
+      constexpr uint32_t P7 = FpParams<FID>::PW[7], P6 = FpParams<FID>::PW[6];
+      uint32_t sus = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) sus |= ((w[k][7] > P7) || (w[k][7] == P7 && w[k][6] >= P6)) ? 1u : 0u;
+      if (sus) __hip_atomic_store(a.watchdog + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (a plain store: no PCIe atomics needed)
+    }
     // head = f0 + (f1 u + f2 u^2 + f3 u^3 + f4 u^4) + (f5 u^5 + f6 u^6 + f7 u^7): seven products, TWO reductions, no dependent
     // chain (Fp::dot; the eight-step Horner form is 8 x 162 multiply-adds and 8 reductions, this one 7 x 81 + 2 x 81)
     F t;
@@ -737,7 +784,7 @@ template <int FID, int J> __global__ __launch_bounds__(256) void k_horner_scan(H
 #pragma unroll
         for (int q = 0; q < 8; q++) asm volatile("" : "+v"(w[k][q]) : "v"(t.l[0]));
       }
-      t = (F::from_words(w[k]) + a.u * t).norm();  // < 2.02 p (8.4 p on a word >= p)
+      t = (F::from_words(w[k]) + a.u * t).norm();  // < 2.02 p (coefficients below p: checked in phase 1)
       t.canon4().to_words(w[k]);
     }
     store_sub(j);
@@ -897,6 +944,38 @@ template <int FID> static void eq_evals_t(Ctx& c, const void* r_host, uint32_t e
     be.launch(f, size);
     size *= 2;
   }
+}
+
+template <int FID> static void eq_evals_pair_t(Ctx& c, const void* r_host, uint32_t ellL, uint32_t ellR, uint32_t flags, uint32_t* d_outL,
+                                               uint32_t* d_outR) {
+  using F = Fp<FID>;
+  if (ellL > EqDirectFn<FID>::kMaxEll || ellR > EqDirectFn<FID>::kMaxEll) {
+    eq_evals_t<FID>(c, r_host, ellL, flags, d_outL);
+    eq_evals_t<FID>(c, (const uint8_t*)r_host + 32 * (size_t)ellL, ellR, flags, d_outR);
+    return;
+  }
+  const bool mont = flags & NMX_SCALARS_MONT;
+  EqDirect2Fn<FID> f;
+  f.outL = d_outL, f.outR = d_outR, f.ellL = ellL, f.ellR = ellR;
+  uint32_t w[8];
+  if (mont) {  // ONE in the vectors' form, as in eq_evals_t
+    F two5 = F::zero();
+    two5.l[0] = 32;
+    two5.to_internal().canon().inv().canon().to_words(w);
+  } else {
+    F one = F::zero();
+    one.l[0] = 1;
+    one.to_words(w);
+  }
+  f.one = F::from_words(w);
+  const F one_i = F::one();
+  for (uint32_t i = 0; i < 2 * EqDirectFn<FID>::kMaxEll; i++) f.r[i] = f.nr[i] = F::zero();
+  for (uint32_t i = 0; i < ellL + ellR; i++) {
+    f.r[i] = challenge<FID>((const uint8_t*)r_host + 32 * (size_t)i, mont);
+    f.nr[i] = F::sub2(one_i, f.r[i]).norm().canon();
+  }
+  DeviceBackend be(c, false, false);
+  be.launch(f, (1u << ellL) + (1u << ellR));
 }
 
 template <int FID> static void spmv_convert_t(Ctx& c, uint32_t* d_data, size_t nnz, uint32_t flags) {
@@ -1060,7 +1139,7 @@ template <int FID> static bool horner_scan_t(Ctx& c, const void* f, size_t n, co
   F uG = uT;
   for (int i = 0; i < 6; i++) uG = uG.sqr().canon();
   const F v8 = u8.inv();  // u != 0 (checked by the caller)
-  const size_t nflags = (size_t)nt + 2 * (size_t)ng;
+  const size_t nflags = (size_t)nt + 2 * (size_t)ng + 1;  // tile states, group tickets, group states, the start-order counter
   arena_reserve(c, HornerArena::pad(kScanTblN * 36) + HornerArena::pad(nflags * 4) + HornerArena::pad((size_t)nt * 36) +
                        2 * HornerArena::pad((size_t)ng * 36) + (dev ? 0 : 2 * HornerArena::pad(n * 32)) + 256);
   HornerArena ws{c.arena};
@@ -1085,18 +1164,19 @@ template <int FID> static bool horner_scan_t(Ctx& c, const void* f, size_t n, co
   const uint32_t win = G.horner_window;
   if (!c.pinned) HIPCHK(hipHostMalloc((void**)&c.pinned, DeviceBackend::kPinnedBytes, hipHostMallocDefault));
   volatile uint32_t* wd = (volatile uint32_t*)(c.pinned + DeviceBackend::kPinnedBytes - 64);  // past every landing zone
-  *wd = 0;
+  wd[0] = 0, wd[1] = 0;
   const uint32_t limit = G.horner_spin_limit ? (uint32_t)G.horner_spin_limit : kScanSpinLimit;
   HornerScanArgs<FID> sa{df, dout, tbl, flags, flags + nt, flags + nt + ng, agg, gagg, ginc, u0, (uint32_t)n, nt, ng,
-                         win >= 1 && win <= 64 ? win : 64u, (uint32_t*)wd, limit};
+                         win >= 1 && win <= 64 ? win : 64u, (uint32_t*)wd, limit, flags + nt + 2 * (size_t)ng,
+                         (uint32_t)G.horner_order.load(std::memory_order_relaxed)};
   if (J == 1) be.launch_kernel(k_horner_scan<FID, 1>, (nt + 3) / 4, 256, sa);
   else if (J == 2) be.launch_kernel(k_horner_scan<FID, 2>, (nt + 3) / 4, 256, sa);
   else be.launch_kernel(k_horner_scan<FID, 4>, (nt + 3) / 4, 256, sa);
   be.mark("end");
   if (!dev) HIPCHK(hipMemcpyAsync(out, dout, n * 32, hipMemcpyDeviceToHost, c.stream));
   stream_wait(c.stream);
-  if (*wd) {
-    note_scan_timeout();
+  if (wd[0] | wd[1]) {  // [0]: a wave gave up waiting; [1]: a coefficient word >= p -- either way the two-pass kernels take the call
+    if (wd[0]) note_scan_timeout();
     return false;
   }
   if (prof && be.nmarks == 2) {
@@ -1221,6 +1301,16 @@ void fv_eq_evals(Ctx& c, int field, const void* r_host, uint32_t ell, uint32_t f
     case 1: eq_evals_t<1>(c, r_host, ell, flags, d_out); break;
     case 2: eq_evals_t<2>(c, r_host, ell, flags, d_out); break;
     case 3: eq_evals_t<3>(c, r_host, ell, flags, d_out); break;
+    default: throw Fail{NMX_E_ARG, "bad field id"};
+  }
+}
+void fv_eq_evals_pair(Ctx& c, int field, const void* r_host, uint32_t ellL, uint32_t ellR, uint32_t flags, uint32_t* d_outL,
+                      uint32_t* d_outR) {
+  switch (field) {
+    case 0: eq_evals_pair_t<0>(c, r_host, ellL, ellR, flags, d_outL, d_outR); break;
+    case 1: eq_evals_pair_t<1>(c, r_host, ellL, ellR, flags, d_outL, d_outR); break;
+    case 2: eq_evals_pair_t<2>(c, r_host, ellL, ellR, flags, d_outL, d_outR); break;
+    case 3: eq_evals_pair_t<3>(c, r_host, ellL, ellR, flags, d_outL, d_outR); break;
     default: throw Fail{NMX_E_ARG, "bad field id"};
   }
 }

@@ -292,6 +292,7 @@ struct Global {
   std::atomic<uint32_t> tree_threads{0};          // env NMX_TUNE_TREE_THREADS / option tree_threads: block size of the fused reduction tree (0 = default, 256 or 512)
   std::atomic<uint32_t> no_tree_fuse{0};          // env NMX_TUNE_NO_TREE_FUSE / option no_tree_fuse: 0 / 2 = fused reduction tree (default), 1 = one launch per reduction level
   std::atomic<uint32_t> hist_grid{0};             // env NMX_TUNE_HIST_GRID / option hist_grid
+  std::atomic<uint32_t> horner_order{1};          // option horner_order: 1 = tiles of k_horner_scan by start-order ticket, 0 = by block id
   std::atomic<uint32_t> sync_spin_us{0};          // env NMX_SYNC_SPIN_US / option sync_spin_us: poll the stream this long before blocking
   std::atomic<uint32_t> force_peer_copy{0};       // option force_peer_copy: HBM-resident scalars of a sharded call take the staging + hipMemcpyPeerAsync branch even when source and destination are the same GPU (tests on a 1-GPU box)
   std::atomic<uint32_t> combine_mode{0};          // option combine: 0 = RCCL all-gather when the shards sit on >= 2 GPUs, host sum otherwise; 1 = host sum; 2 = RCCL required (also with one GPU: tests)
@@ -633,6 +634,8 @@ void fv_bind(Ctx&, int field, const void* z, size_t z_len, size_t lo_off, size_t
 
 void fv_suffix_horner(Ctx&, int field, const void* f, size_t n, const void* u, uint32_t flags, void* out);
 void fv_eq_evals(Ctx&, int field, const void* r_host, uint32_t ell, uint32_t flags, uint32_t* d_out);
+void fv_eq_evals_pair(Ctx&, int field, const void* r_host, uint32_t ellL, uint32_t ellR, uint32_t flags, uint32_t* d_outL,
+                      uint32_t* d_outR);  // both tables of an evaluation, one launch when both fit the direct kernel
 void fv_spmv_convert(Ctx&, int field, uint32_t* d_data, size_t nnz, uint32_t flags);
 void fv_spmv_classify(Ctx&, int field, const uint32_t* d_data, uint32_t* d_indices, size_t nnz, size_t cols);
 void fv_spmv_apply(Ctx&, int field, const uint32_t* indptr, const uint32_t* indices, const uint32_t* data, size_t rows,

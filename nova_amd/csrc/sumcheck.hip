@@ -45,12 +45,11 @@ template <int FID> __device__ __forceinline__ Fp<FID> block_sum(Fp<FID> v, uint3
 // normalised every second step (inputs canonical), a wave's sum < 64 p brought back below 2 p by one product with 1; then the
 // four wave sums through LDS.  Result valid in thread 0.  The two eight-level LDS trees it replaces in k_eq_rows were ~10 % of a
 // block's time at two rows per block.
-template <int FID> __device__ __forceinline__ void block_sum_pair(Fp<FID>& g0, Fp<FID>& g1, uint32_t* lds /* >= 72 words */) {
+template <int FID, int J> __device__ __forceinline__ void block_sum_waves(Fp<FID> (&x)[J], uint32_t* lds /* >= 36 J words */) {
   using F = Fp<FID>;
   const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-  F x[2] = {g0, g1};
 #pragma unroll
-  for (int j = 0; j < 2; j++) {
+  for (int j = 0; j < J; j++) {
 #pragma unroll
     for (uint32_t d = 32; d >= 1; d >>= 1) {
 #pragma unroll
@@ -66,7 +65,7 @@ template <int FID> __device__ __forceinline__ void block_sum_pair(Fp<FID>& g0, F
   __syncthreads();
   if (t == 0) {
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
+    for (int j = 0; j < J; j++) {
       F acc = F::zero();
 #pragma unroll
       for (int w = 0; w < 4; w++) {
@@ -77,8 +76,48 @@ template <int FID> __device__ __forceinline__ void block_sum_pair(Fp<FID>& g0, F
       }
       x[j] = acc.norm().canon();  // < 4 p -> < p
     }
+  }
+}
+template <int FID> __device__ __forceinline__ void block_sum_pair(Fp<FID>& g0, Fp<FID>& g1, uint32_t* lds /* >= 72 words */) {
+  Fp<FID> x[2] = {g0, g1};
+  block_sum_waves<FID, 2>(x, lds);
+  if (threadIdx.x == 0) {
     g0 = x[0];
     g1 = x[1];
+  }
+}
+
+// Final sums of the per-block partials: one block behind the pass.  Round 4 measured the alternative -- the block that draws the
+// last of gridDim tickets adds the partials up inside the pass itself (partials published as agent-scope relaxed atomics after
+// s_waitcnt vmcnt(0), one acquire fence in the last block) -- on one box against this form: sumcheck3 2^24 0.419 / 0.389 ms
+// against 0.422 / 0.422, round3 0.617 / 0.623 against 0.637 / 0.626, but quad_prod 0.226 / 0.231 against 0.214 / 0.225 and a
+// 2^20 evaluation 29.9 / 29.5 us against 27.4 / 27.8 (profiles/r04_fieldvec/final_sum_ab.txt): a wash -- the dependent launch
+// costs 2-3 us of gap, the ticket + fence + the same serial tail cost as much -- so the simpler form, whose ordering is a
+// kernel boundary, stays.  (With agent-scope acq_rel on the ticket in EVERY block the passes were 8-20 % slower: a release /
+// acquire pair is a write-back + invalidate of the whole L2.)  The sum itself now runs six levels in shuffles and one LDS hop
+// (block_sum_waves) instead of an eight-level LDS tree.
+template <int FID, int J, int STRIDE> __global__ __launch_bounds__(256) void k_sum_partials_n(const uint32_t* partial, uint32_t nparts, uint32_t* out) {
+  using F = Fp<FID>;
+  __shared__ uint32_t lds[36 * J];
+  F s[J];
+#pragma unroll
+  for (int j = 0; j < J; j++) s[j] = F::zero();
+  uint32_t pending = 0;
+  for (uint32_t i = threadIdx.x; i < nparts; i += 256) {
+#pragma unroll
+    for (int j = 0; j < J; j++) s[j] = (s[j] + ldw<FID>(partial, STRIDE * (size_t)i + j)).norm();
+    if (++pending == 8) {
+#pragma unroll
+      for (int j = 0; j < J; j++) s[j] = s[j].canon();
+      pending = 0;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < J; j++) s[j] = s[j].canon();
+  block_sum_waves<FID, J>(s, lds);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int j = 0; j < J; j++) s[j].to_words(out + 8 * j);
   }
 }
 
@@ -236,61 +275,6 @@ __global__ __launch_bounds__(256, NMX_EQROWS_MINWAVES) void k_eq_rows(const uint
   }
 }
 
-// Final sums of the per-block partials, one block.  This launch is pure latency behind a multiplier-bound pass (24 us of a
-// 0.41 ms sum-check pass in round 2: profiles/r03_fieldvec/): the adds run lazily (one canonicalisation per 8 terms: values stay
-// < 9p < canon()'s 16p), and the J sums go through ONE tree -- 8 levels, the canonicalisation of a level's sum (< 2p) is the
-// two-subtraction form.
-template <int FID, int J> __device__ __forceinline__ void block_sum_multi(Fp<FID> (&v)[J], uint32_t* lds /* J x 256 x 9 */) {
-  const uint32_t t = threadIdx.x;
-#pragma unroll
-  for (int j = 0; j < J; j++)
-#pragma unroll
-    for (int i = 0; i < 9; i++) lds[(j * 9 + i) * 256 + t] = v[j].l[i];
-  __syncthreads();
-  for (uint32_t s = 128; s >= 1; s >>= 1) {
-    if (t < s) {
-#pragma unroll
-      for (int j = 0; j < J; j++) {
-        Fp<FID> o;
-#pragma unroll
-        for (int i = 0; i < 9; i++) o.l[i] = lds[(j * 9 + i) * 256 + t + s];
-        v[j] = (v[j] + o).norm().canon4();  // < 2p -> < p
-#pragma unroll
-        for (int i = 0; i < 9; i++) lds[(j * 9 + i) * 256 + t] = v[j].l[i];
-      }
-    }
-    __syncthreads();
-  }
-}
-template <int FID, int J, int STRIDE>
-__device__ __forceinline__ void sum_partials_body(const uint32_t* partial, uint32_t nparts, uint32_t* out, uint32_t* lds) {
-  using F = Fp<FID>;
-  F s[J];
-#pragma unroll
-  for (int j = 0; j < J; j++) s[j] = F::zero();
-  uint32_t pending = 0;
-  for (uint32_t i = threadIdx.x; i < nparts; i += 256) {
-#pragma unroll
-    for (int j = 0; j < J; j++) s[j] = (s[j] + ldw<FID>(partial, STRIDE * (size_t)i + j)).norm();
-    if (++pending == 8) {
-#pragma unroll
-      for (int j = 0; j < J; j++) s[j] = s[j].canon();
-      pending = 0;
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < J; j++) s[j] = s[j].canon();
-  block_sum_multi<FID, J>(s, lds);
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int j = 0; j < J; j++) s[j].to_words(out + 8 * j);
-  }
-}
-template <int FID> __global__ __launch_bounds__(256) void k_sum_partials(const uint32_t* partial, uint32_t nparts, uint32_t* out) {
-  __shared__ uint32_t lds[2 * 9 * 256];
-  sum_partials_body<FID, 2, 2>(partial, nparts, out, lds);
-}
-
 template <int FID> static Fp<FID> challenge_internal(const void* r, bool mont) {
   uint32_t w[8];
   memcpy(w, r, 32);
@@ -372,8 +356,7 @@ static void eq_sums_t(Ctx& c, const void* A, const void* B, const void* C, size_
                        nk, partial);
   }
   HIPCHK(hipGetLastError());
-  hipLaunchKernelGGL((k_sum_partials<FID>), dim3(1), dim3(256), 0, c.stream, partial, blocks, dout);
-  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL((k_sum_partials_n<FID, 2, 2>), dim3(1), dim3(256), 0, c.stream, partial, blocks, dout);
   be.mark("end");
   uint32_t res[16];
   be.d2h(res, dout, 64);  // through the context's pinned landing buffer
@@ -487,8 +470,7 @@ static void bind_eq_sums_t(Ctx& c, const void* A, const void* B, const void* C, 
                      (const uint32_t*)B, (const uint32_t*)C, (uint32_t*)oA, (uint32_t*)oB, (uint32_t*)oC, ri,
                      (const uint32_t*)eqL, (const uint32_t*)eqR, shift, mask, hq, nk, partial);
   HIPCHK(hipGetLastError());
-  hipLaunchKernelGGL((k_sum_partials<FID>), dim3(1), dim3(256), 0, c.stream, partial, blocks, dout);
-  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL((k_sum_partials_n<FID, 2, 2>), dim3(1), dim3(256), 0, c.stream, partial, blocks, dout);
   be.mark("end");
   uint32_t res[16];
   be.d2h(res, dout, 64);  // through the context's pinned landing buffer
@@ -774,11 +756,6 @@ __global__ __launch_bounds__(256) void k_plain_sums(const uint32_t* A, const uin
   }
 }
 
-template <int FID> __global__ __launch_bounds__(256) void k_sum_partials3(const uint32_t* partial, uint32_t nparts, uint32_t* out) {
-  __shared__ uint32_t lds[3 * 9 * 256];
-  sum_partials_body<FID, 3, 4>(partial, nparts, out, lds);
-}
-
 template <int FID, int KIND>
 static void plain_sums_t(Ctx& c, const void* A, const void* B, const void* C, size_t len, uint32_t flags, uint8_t* out) {
   using F = Fp<FID>;
@@ -809,8 +786,7 @@ static void plain_sums_t(Ctx& c, const void* A, const void* B, const void* C, si
   be.mark("k");
   hipLaunchKernelGGL((k_plain_sums<FID, KIND>), dim3(blocks), dim3(256), 0, c.stream, dA, dB, dC, h, partial);
   HIPCHK(hipGetLastError());
-  hipLaunchKernelGGL((k_sum_partials3<FID>), dim3(1), dim3(256), 0, c.stream, partial, blocks, dout);
-  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL((k_sum_partials_n<FID, 3, 4>), dim3(1), dim3(256), 0, c.stream, partial, blocks, dout);
   be.mark("end");
   uint32_t res[24];
   be.d2h(res, dout, 96);

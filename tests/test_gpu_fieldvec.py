@@ -175,7 +175,8 @@ def test_horner_and_div_by_monomial(nmx, fid, n):
 
 @pytest.mark.parametrize("fid", range(4))
 @pytest.mark.parametrize("knob,value", [("horner_window", 1), ("horner_window", 3), ("horner_window", 7), ("horner_sub", 1),
-                                        ("horner_sub", 2), ("horner_sub", 4), ("horner_top", 8), ("horner_top", 4), ("horner_top", 1)])
+                                        ("horner_sub", 2), ("horner_sub", 4), ("horner_top", 8), ("horner_top", 4), ("horner_top", 1),
+                                        ("horner_order", 0), ("horner_order", 1)])
 def test_horner_variants(nmx, fid, knob, value):
     """The single-pass scan (k_horner_scan) with 1 / 3 / 7 groups per look-back round -- every tile then needs several
     rounds, the path a 64-group window takes only when no group behind it has its inclusive value yet --, with 1 / 2 / 4
@@ -191,7 +192,7 @@ def test_horner_variants(nmx, fid, knob, value):
             u = C.rand_vec(fid, 1, 6)
             assert fv.suffix_horner(fid, f, u).tobytes() == cref.suffix_horner(fid, f, n, u), (knob, value, n)
     finally:
-        assert L.nmx_set_option(knob.encode(), 64 if knob == "horner_window" else 0) == 0
+        assert L.nmx_set_option(knob.encode(), 64 if knob == "horner_window" else 1 if knob == "horner_order" else 0) == 0
 
 
 @pytest.mark.parametrize("fid", range(4))
@@ -235,6 +236,59 @@ def test_horner_scan_watchdog_falls_back_to_two_pass(nmx):
         assert L.nmx_set_option(b"horner_spin_limit", 0) == 0
     assert fv.suffix_horner(fid, f, u).tobytes() == exp
     assert _lib.stats()[_lib.STAT_SCAN_TIMEOUTS] >= before  # (a lease where no wave ever had to poll twice counts none)
+
+
+def test_horner_rejects_overlap_and_survives_a_timeout_on_device_vectors(nmx):
+    """the time-out fallback re-reads f after the aborted scan has written to out, so an in-place call could
+    return a wrong quotient.  In-place and partially overlapping device vectors are an NMX_E_ARG error (the header says so);
+    a forced time-out on disjoint DEVICE vectors still ends in the oracle's answer and leaves f untouched."""
+    import ctypes
+    import torch
+    from nova_amd import _lib
+    from nova_amd import fieldvec as fv
+    L = _lib.lib()
+    fid, n = 1, 200000
+    f = C.edge_vectors(fid, n, 31)
+    u = C.rand_vec(fid, 1, 32)
+    exp = cref.suffix_horner(fid, f, n, u)
+    buf = torch.zeros((2 * n, 32), dtype=torch.uint8, device="cuda")
+    buf[:n] = torch.from_numpy(f)
+    torch.cuda.synchronize()
+    uu = np.ascontiguousarray(u)
+    flags = _lib.SCALARS_DEVICE
+    base = buf.data_ptr()
+    for off in (0, 32, 32 * (n - 101), -32 * 5):        # in place, shifted by one element, one-element overlap at the end, shifted back
+        rc = L.nmx_poly_suffix_horner(fid, base + 32 * 100, n - 100, uu.ctypes.data, flags, base + 32 * 100 + off)
+        assert rc == _lib.E_ARG, off
+    assert L.nmx_set_option(b"horner_spin_limit", 1) == 0
+    try:
+        for _ in range(2):
+            assert L.nmx_poly_suffix_horner(fid, base, n, uu.ctypes.data, flags, base + 32 * n) == 0   # adjacent, disjoint
+            torch.cuda.synchronize()
+            assert buf[n:].cpu().numpy().tobytes() == exp
+            assert buf[:n].cpu().numpy().tobytes() == f.tobytes()
+    finally:
+        assert L.nmx_set_option(b"horner_spin_limit", 0) == 0
+
+
+@pytest.mark.parametrize("fid", range(4))
+def test_horner_outputs_are_canonical_for_any_input_words(nmx, fid):
+    """the stored copy went through canon4 (valid below 4 p); a coefficient word >= p (any 256-bit value is accepted,
+    as by the other field kernels) left a residue that was congruent but not canonical -- a later MSM over it would fail
+    with NMX_E_SCALAR_RANGE.  Words >= p are reduced before they enter the chain: every output is the canonical residue."""
+    from nova_amd import fieldvec as fv
+    p = C.FIELDS[fid]
+    n = 5000
+    rng = np.random.Generator(np.random.PCG64(77 + fid))
+    vals = [int.from_bytes(rng.bytes(32), "little") for _ in range(n)]
+    vals[0], vals[1], vals[n - 1], vals[513] = (1 << 256) - 1, p, p + 1, 2 * p + 5
+    raw = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in vals), dtype=np.uint8).reshape(n, 32).copy()
+    red = C.vec([v % p for v in vals])
+    u = C.rand_vec(fid, 1, 6)
+    exp = cref.suffix_horner(fid, red, n, u)
+    got = fv.suffix_horner(fid, raw, u)
+    assert got.tobytes() == exp
+    assert all(int.from_bytes(got[i].tobytes(), "little") < p for i in range(n))
 
 
 @pytest.mark.parametrize("fid", [0, 2])
