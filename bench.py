@@ -114,6 +114,8 @@ def main():
                     help="register the key WITHOUT window tables: the plain path (W bucket sets) that first / second sight of a "
                          "cached array, IPA's per-round keys and keys whose tables do not fit take")
     ap.add_argument("--iters", type=int, default=65536, help="prove_step_replay: MinRoot iterations per step")
+    ap.add_argument("--separate-field-ops", action="store_true", help="prove_step replay: vec_add, 3 x SpMV, cross term and the two folds as separate (stream-ordered) calls")
+    ap.add_argument("--sync-field-ops", action="store_true", help="prove_step replay: every field-vector call waits for its kernel (round 3's form)")
     ap.add_argument("--workload", default="msm", choices=["msm", "axpy", "cross_term", "bind", "sumcheck3", "round3", "quad_prod", "lincomb8", "horner", "mle_eval", "spmv", "prove_step_replay", "hyperkzg_replay"],
                     help="msm = the headline (default); the others time one HBM-bound field-vector kernel of "
                          "SURVEY.md 8(f) at 2^log2n elements per GPU")
@@ -834,16 +836,30 @@ def prove_step_replay(args, torch):
     def nifs(k, uu):
         cid, fid, n = cur[k]
         d = dev[k]
-        Z = call(f"{k}.vec_add", lambda: fv.vec_add(fid, d["W1"], d["W"]))                       # r1cs/mod.rs:590-609
-        AZ, BZ, CZ = (call(f"{k}.spmv_x3", lambda m=m: m.multiply_vec(Z)) for m in mats[k])      # r1cs/mod.rs:612
-        T = call(f"{k}.cross_term", lambda: fv.cross_term(fid, AZ, BZ, CZ, d["E1"], uu))         # r1cs/mod.rs:614-620
-        comT = call(f"{k}.commit_T", lambda: ce[k].commit(ck[k], T, rT[k]))                      # r1cs/mod.rs:622
-        W = call(f"{k}.fold_x2", lambda: fv.axpy(fid, d["W1"], d["W"], r[k]))                    # r1cs/mod.rs:1058-1062
-        E = call(f"{k}.fold_x2", lambda: fv.axpy(fid, d["E1"], T, r[k]))                         # r1cs/mod.rs:1063-1067
+        # the field kernels between two commitments are stream-ordered calls (NMX_ASYNC): nothing on the host looks at Z, AZ,
+        # BZ, CZ, T, W, E before the next commitment, which is synchronous and ordered behind them
+        a = not args.sync_field_ops
+        if a and not args.separate_field_ops:
+            # one call per reference function: commit_T's chain (nmx_r1cs_cross_term) and the fold (nmx_nifs_fold)
+            T = call(f"{k}.cross_term", lambda: fv.r1cs_cross_term(mats[k][0], mats[k][1], mats[k][2], d["W1"], d["W"], d["E1"], uu, async_=True))
+            comT = call(f"{k}.commit_T", lambda: ce[k].commit(ck[k], T, rT[k]))
+            W, E = call(f"{k}.fold_x2", lambda: fv.nifs_fold(fid, d["W1"], d["W"], d["E1"], T, r[k], async_=True))
+            keep.extend((T, W, E))
+            return comT, W, E
+        Z = call(f"{k}.vec_add", lambda: fv.vec_add(fid, d["W1"], d["W"], async_=a))                       # r1cs/mod.rs:590-609
+        AZ, BZ, CZ = (call(f"{k}.spmv_x3", lambda m=m: m.multiply_vec(Z, async_=a)) for m in mats[k])      # r1cs/mod.rs:612
+        T = call(f"{k}.cross_term", lambda: fv.cross_term(fid, AZ, BZ, CZ, d["E1"], uu, async_=a))         # r1cs/mod.rs:614-620
+        comT = call(f"{k}.commit_T", lambda: ce[k].commit(ck[k], T, rT[k]))                                # r1cs/mod.rs:622
+        W = call(f"{k}.fold_x2", lambda: fv.axpy(fid, d["W1"], d["W"], r[k], async_=a))                    # r1cs/mod.rs:1058-1062
+        E = call(f"{k}.fold_x2", lambda: fv.axpy(fid, d["E1"], T, r[k], async_=a))                         # r1cs/mod.rs:1063-1067
+        keep.extend((Z, AZ, BZ, CZ, T, W, E))      # alive until the step's last (synchronous) call has returned
         return comT, W, E
+
+    keep = []
 
     def step():
         out = []
+        keep.clear()
         out.append(nifs("S", uS)[0])                                          # nova/mod.rs:464  NIFS on the secondary
         out.append(call("P.commit_W", lambda: ce["P"].commit(ck["P"], dev["P"]["W"])))   # nova/mod.rs:477-496 primary witness commit
         out.append(nifs("P", u)[0])                                           # nova/mod.rs:502  NIFS on the primary
@@ -858,8 +874,9 @@ def prove_step_replay(args, torch):
         res = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
-    # the same step again with every provider call timed on its own (wall clock around the synchronous C call, so each span
-    # carries its launch + wake-up latency; P = primary BN254, S = secondary Grumpkin; x2 / x3 = sum over that many calls)
+    # the same step again with every provider call timed on its own (wall clock around the C call; the field-vector calls are
+    # stream-ordered unless --sync-field-ops, so their spans are enqueue times and their kernels run under the next commitment's
+    # span; P = primary BN254, S = secondary Grumpkin; x2 / x3 = sum over that many calls)
     spans = {}
     passes = 5
     for _ in range(passes):
@@ -872,7 +889,7 @@ def prove_step_replay(args, torch):
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": False,
         "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
         "config": {"workload": f"prove_step replay: minroot {args.iters} iterations/step -> primary N={N} (BN254), secondary n={n2} "
-                               "(Grumpkin); 4 MSMs + 6 SpMVs + 2 vector adds + 2 cross terms + 4 folds; no synthesis / Poseidon "
+                               "(Grumpkin); 4 MSMs + 6 SpMVs + 2 vector adds + 2 cross terms + 4 folds (stream-ordered: commit_T's chain and the fold one call each); no synthesis / Poseidon "
                                "(BASELINE.json configs[3])"},
         "roofline": None,
         "breakdown_ms": breakdown,

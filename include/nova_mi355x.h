@@ -52,6 +52,16 @@ enum {
                                     the HBM of THAT device -- the reference chunks coefficients and bases together
                                     (src/provider/msm.rs:564-574), so nothing crosses xGMI or PCIe inside the call.  A key on
                                     one device has one piece.  nmx_svec_* allocates vectors in this layout.          */
+  NMX_ASYNC = 1u << 9,          /* element-wise field kernels and SpMV on HBM-resident vectors (nmx_field_axpy / _axpy2 /
+                                   _cross_term / _cross_term2 / _vec_add, nmx_spmv_apply[_pair], nmx_r1cs_cross_term, nmx_nifs_fold; ignored elsewhere and with
+                                   host operands): return once the kernel is ENQUEUED.  The calling host thread's later calls
+                                   -- any entry point -- are ordered behind it, and every call that is synchronous (all MSMs
+                                   and commitments, all reductions, anything with a host operand) still returns with
+                                   everything the thread enqueued before it complete; nmx_sync() waits explicitly.  A vector
+                                   written by an asynchronous call must not be handed to ANOTHER host thread, freed or
+                                   read by the host before one of the two.  The NIFS chain between two commitments --
+                                   Z = W1 + W2, AZ / BZ / CZ, T (src/r1cs/mod.rs:590-622), the folds (1044-1107) -- is the
+                                   intended use: five dependent launches with no host wake-up between them.          */
   NMX_OUT_PARTIAL = 1u << 4     /* write a 128-byte partial sum instead of an affine point: the per-GPU   */
                                 /* result of a sharded MSM, input of nmx_point_sum.  Format: extended     */
                                 /* Jacobian (X, Y, ZZ, ZZZ), x = X/ZZ, y = Y/ZZZ, each coordinate the     */
@@ -82,6 +92,7 @@ enum {
 int nmx_init(int device);
 int nmx_shutdown(void);
 int nmx_device_count(void);
+int nmx_sync(void); /* waits for the calling thread's NMX_ASYNC calls (no-op when there are none) */
 /* Several GPUs behind ONE host process (the reference is one address space: its own MSM decomposition is in-process,
  * `par_chunks` + `reduce(identity, +)`, src/provider/msm.rs:564-574,664-676).  After
  * nmx_init_devices(k, flags) the process owns logical devices 0 .. k-1 (HIP devices 0 .. k-1; k == 0: every visible
@@ -365,6 +376,17 @@ int nmx_spmv_register(int field, const uint64_t* indptr, const uint64_t* indices
                       size_t cols, uint32_t flags, uint64_t* handle);
 int nmx_spmv_unregister(uint64_t handle);
 int nmx_spmv_apply(uint64_t handle, const void* z, size_t z_len, uint32_t flags, void* out);
+/* NIFS::prove's provider work between two commitments as ONE call each (HBM-resident vectors only; NMX_ASYNC applies):
+ *  - nmx_r1cs_cross_term: the body of commit_T (src/r1cs/mod.rs:590-620): Z = z1 + z2 (z2 NULL: Z = z1), then for every row
+ *    T = (A Z)(B Z) - u (C Z) - E in one pass -- AZ, BZ, CZ never reach HBM.  A, B, C: matrices of one shape and field
+ *    (nmx_spmv_register); z1, z2: z_len = cols elements; e, out: rows elements.  Bit-identical to nmx_field_vec_add +
+ *    3 x nmx_spmv_apply + nmx_field_cross_term.
+ *  - nmx_nifs_fold: R1CSWitness::fold (src/r1cs/mod.rs:1044-1067): w = w1 + r w2 (n_w elements) and e = e1 + r t (n_e
+ *    elements) in one launch.  Outputs must not alias inputs other than element-wise in place (w == w1 is fine). */
+int nmx_r1cs_cross_term(uint64_t A, uint64_t B, uint64_t C, const void* z1, const void* z2, size_t z_len, const void* e,
+                        const void* u, uint32_t flags, void* out);
+int nmx_nifs_fold(int field, const void* w1, const void* w2, size_t n_w, const void* e1, const void* t, size_t n_e, const void* r,
+                  uint32_t flags, void* w, void* e);
 /* (M*z1, M*z2) in one pass over the matrix: PrecomputedSparseMatrix::multiply_vec_pair (src/r1cs/sparse.rs:215-229) */
 int nmx_spmv_apply_pair(uint64_t handle, const void* z1, const void* z2, size_t z_len, uint32_t flags, void* out1,
                         void* out2);

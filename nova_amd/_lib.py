@@ -9,6 +9,7 @@ SO_PATH = os.environ.get("NMX_SO") or os.path.join(_HERE, "libnova_mi355x.so")  
 SCALARS_MONT, BASES_MONT, SCALARS_DEVICE, BASES_DEVICE, OUT_PARTIAL, BASES_PRECOMPUTE, BASES_VALIDATE = 1, 2, 4, 8, 16, 32, 64
 BASES_NOCACHE = 128
 SCALARS_SHARDED = 256
+ASYNC = 512
 OP_AXPY, OP_AXPY2, OP_CROSS_TERM, OP_CROSS_TERM2, OP_VEC_ADD = range(5)
 BRANCH_NAMES = {0: "host", 1: "local", 2: "peer_copy", 3: "shard_resident", 4: "none"}
 PROF_STAGES = 12
@@ -45,6 +46,7 @@ def lib():
     L.nmx_init.argtypes = [i]
     L.nmx_shutdown.argtypes = []
     L.nmx_device_count.argtypes = []
+    L.nmx_sync.argtypes = []
     L.nmx_init_devices.argtypes = [i, u32]
     L.nmx_devices_in_use.argtypes = []
     L.nmx_shard_plan.argtypes = [sz, i, sz, sz, vp, i]
@@ -89,6 +91,8 @@ def lib():
     L.nmx_spmv_register.argtypes = [i, vp, vp, vp, sz, sz, u32, ctypes.POINTER(u64)]
     L.nmx_spmv_unregister.argtypes = [u64]
     L.nmx_spmv_apply.argtypes = [u64, vp, sz, u32, vp]
+    L.nmx_r1cs_cross_term.argtypes = [u64, u64, u64, vp, vp, sz, vp, vp, u32, vp]
+    L.nmx_nifs_fold.argtypes = [i, vp, vp, sz, vp, vp, sz, vp, u32, vp, vp]
     L.nmx_spmv_apply_pair.argtypes = [u64, vp, vp, sz, u32, vp, vp]
     L.nmx_sumcheck_plain_sums.argtypes = [i, i, vp, vp, vp, sz, u32, vp]
     L.nmx_poly_eval_multi.argtypes = [i, vp, vp, sz, vp, sz, u32, vp]

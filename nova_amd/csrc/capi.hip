@@ -173,6 +173,24 @@ static void ensure_init() {
   G.inited = true;
 }
 
+// Stream-ordered calls (NMX_ASYNC): the element-wise field kernels and SpMV on HBM-resident vectors may return as soon as their
+// kernel is enqueued -- between the MSMs of a prove_step the reference's host does nothing with W, E, T but hand them to the
+// next provider call (src/r1cs/mod.rs:590-622, 1044-1107), so the 12 us wake-up of a blocking wait per call bought nothing.
+// Ordering: a host thread's calls normally lease the same context (the pool is LIFO) and so share a stream; when they do not,
+// the lease makes the new context's stream wait for the event recorded behind the thread's last asynchronous call.  Every
+// synchronous call (all MSMs, all reductions, anything with a host operand) therefore still returns with everything the thread
+// enqueued before it complete.  Vectors handed to ANOTHER host thread need nmx_sync() first.
+static thread_local Ctx* t_async_ctx = nullptr;
+static thread_local uint64_t t_async_epoch = 0;
+static std::atomic<uint64_t> g_ctx_epoch{1};  // bumped by nmx_shutdown: contexts remembered by other threads are gone
+static inline Ctx* async_pending() { return (t_async_ctx && t_async_epoch == g_ctx_epoch.load(std::memory_order_acquire)) ? t_async_ctx : nullptr; }
+void async_mark(Ctx& c) {
+  if (!c.async_ev) HIPCHK(hipEventCreateWithFlags(&c.async_ev, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(c.async_ev, c.stream));
+  t_async_ctx = &c;
+  t_async_epoch = g_ctx_epoch.load(std::memory_order_acquire);
+}
+
 // One context per in-flight call: concurrent callers (rayon workers on the reference side) never share a stream
 // or a workspace, so a small MSM does not queue behind a 2^20 one.
 // The lease also makes the context's device current on the calling thread (hipSetDevice is per thread).
@@ -188,14 +206,26 @@ struct CtxLease {
       if (!pool.empty()) {
         c = pool.back();
         pool.pop_back();
-        return;
+      } else {
+        c = nullptr;
       }
     }
-    c = new Ctx();
-    c->dev = dev;
-    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    std::lock_guard<std::mutex> lk(G.mu);
-    G.all_ctx.push_back(c);
+    if (!c) {
+      c = new Ctx();
+      c->dev = dev;
+      HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+      std::lock_guard<std::mutex> lk(G.mu);
+      G.all_ctx.push_back(c);
+    }
+    // behind this thread's last asynchronous call (same context: the stream already orders it)
+    if (Ctx* p = async_pending(); p && p != c && p->async_ev) {
+      const hipError_t e = hipStreamWaitEvent(c->stream, p->async_ev, 0);
+      if (e != hipSuccess) {
+        std::lock_guard<std::mutex> lk(G.mu);
+        G.free_ctx[(size_t)c->dev].push_back(c);
+        throw Fail{NMX_E_HIP, std::string("hipStreamWaitEvent: ") + hipGetErrorString(e)};
+      }
+    }
   }
   CtxLease(const CtxLease&) = delete;
   CtxLease& operator=(const CtxLease&) = delete;
@@ -266,7 +296,15 @@ template <class Fn> static void run_on_parts(size_t count, bool parallel, Fn&& f
   std::mutex err_mu;
   bool failed = false;
   Fail first{0, ""};
+  Ctx* const pend = async_pending();  // the caller's last asynchronous call: leases on the helper threads must wait for it too
+  const uint64_t pend_epoch = t_async_epoch;
   auto guarded_fn = [&](size_t i) {
+    struct Restore {
+      Ctx* v;
+      uint64_t e;
+      ~Restore() { t_async_ctx = v, t_async_epoch = e; }
+    } restore{t_async_ctx, t_async_epoch};
+    t_async_ctx = pend, t_async_epoch = pend_epoch;
     try {
       fn(i);
     } catch (const Fail& f) {
@@ -1092,14 +1130,24 @@ int nmx_shutdown(void) {
       if (c->pinned) (void)hipHostFree(c->pinned);
       if (c->have_ev)
         for (int i = 0; i < kMaxMarks; i++) (void)hipEventDestroy(c->ev[i]);
+      if (c->async_ev) (void)hipEventDestroy(c->async_ev);
       if (c->stream) (void)hipStreamDestroy(c->stream);
       delete c;
     }
     G.all_ctx.clear();
+    g_ctx_epoch.fetch_add(1, std::memory_order_acq_rel);
+    t_async_ctx = nullptr;
     G.free_ctx.clear();
     G.hip_dev.clear();
     G.ndev_active.store(1);
     G.inited = false;
+  });
+}
+
+int nmx_sync(void) {
+  return guarded([&] {
+    if (Ctx* p = async_pending(); p && p->async_ev) HIPCHK(hipEventSynchronize(p->async_ev));
+    t_async_ctx = nullptr;
   });
 }
 
@@ -2017,6 +2065,46 @@ int nmx_spmv_apply(uint64_t handle, const void* z, size_t z_len, uint32_t flags,
     if (ss.rows == 0) return;
     CtxLease L;
     fv_spmv_apply(*L.c, ss.field, ss.indptr, ss.indices, ss.data, ss.rows, ss.cols, z, flags, out);
+  });
+}
+
+int nmx_r1cs_cross_term(uint64_t hA, uint64_t hB, uint64_t hC, const void* z1, const void* z2, size_t z_len, const void* e,
+                        const void* u, uint32_t flags, void* out) {
+  return guarded([&] {
+    require(z1 && e && u && out, NMX_E_ARG, "null argument");
+    require(flags & NMX_SCALARS_DEVICE, NMX_E_ARG, "nmx_r1cs_cross_term works on HBM-resident vectors");
+    std::shared_ptr<Global::SparseSet> sp[3];
+    {
+      std::lock_guard<std::mutex> lk(G.mu);
+      const uint64_t hs[3] = {hA, hB, hC};
+      for (int j = 0; j < 3; j++) {
+        auto it = G.sparse.find(hs[j]);
+        if (it == G.sparse.end()) throw Fail{NMX_E_HANDLE, "unknown matrix handle"};
+        sp[j] = it->second;
+      }
+    }
+    for (int j = 0; j < 3; j++)
+      require(sp[j]->field == sp[0]->field && sp[j]->rows == sp[0]->rows && sp[j]->cols == sp[0]->cols, NMX_E_ARG,
+              "A, B, C must share field and shape");
+    require(z_len == sp[0]->cols, NMX_E_ARG, "invalid shape");
+    if (sp[0]->rows == 0) return;
+    const uint32_t* ip[3] = {sp[0]->indptr, sp[1]->indptr, sp[2]->indptr};
+    const uint32_t* ix[3] = {sp[0]->indices, sp[1]->indices, sp[2]->indices};
+    const uint32_t* dt[3] = {sp[0]->data, sp[1]->data, sp[2]->data};
+    CtxLease L;
+    fv_r1cs_cross_term(*L.c, sp[0]->field, ip, ix, dt, sp[0]->rows, sp[0]->cols, z1, z2, e, u, flags, out);
+  });
+}
+
+int nmx_nifs_fold(int field, const void* w1, const void* w2, size_t n_w, const void* e1, const void* t, size_t n_e, const void* r,
+                  uint32_t flags, void* w, void* e) {
+  return guarded([&] {
+    require(((w1 && w2 && w) || n_w == 0) && ((e1 && t && e) || n_e == 0) && r, NMX_E_ARG, "null argument");
+    require(flags & NMX_SCALARS_DEVICE, NMX_E_ARG, "nmx_nifs_fold works on HBM-resident vectors");
+    require(n_w + n_e < (1ull << 31), NMX_E_TOO_LARGE, "vectors too long");
+    if (n_w + n_e == 0) return;
+    CtxLease L;
+    fv_nifs_fold(*L.c, field, w1, w2, n_w, e1, t, n_e, r, flags, w, e);
   });
 }
 

@@ -173,6 +173,24 @@ template <int FID> NMX_HD Fp<FID> spmv_small_term(uint32_t cls, const Fp<FID>& z
 
 // CSR sparse matrix x vector, one row per lane (src/r1cs/sparse.rs:201-229 multiply_vec).  Matrix values are stored in
 // internal form at registration, so data * z comes out in z's own form with no correction.
+// one row of M z, normalised (< 16 p: canon() brings it to the stored form)
+template <int FID>
+NMX_HD Fp<FID> spmv_row(const uint32_t* indptr, const uint32_t* indices, const uint32_t* data, const uint32_t* z, uint32_t colmask,
+                        uint32_t row) {
+  using F = Fp<FID>;
+  F acc = F::zero();
+  uint32_t pending = 0;
+  for (uint32_t k = indptr[row]; k < indptr[row + 1]; k++) {
+    const uint32_t w = indices[k], cls = (w & ~colmask) >> kSpmvColBits;
+    const F zf = ld<FID>(z, w & colmask);
+    acc = acc + (cls ? spmv_small_term<FID>(cls, zf) : ld<FID>(data, k) * zf);
+    if (++pending == 6) {
+      acc = acc.norm().canon();
+      pending = 0;
+    }
+  }
+  return acc.norm();
+}
 template <int FID> struct SpmvFn {
   const uint32_t* indptr;   // rows + 1
   const uint32_t* indices;  // nnz: column | class << 28 (class 0 everywhere when the matrix is not tagged)
@@ -180,20 +198,38 @@ template <int FID> struct SpmvFn {
   const uint32_t* z;        // cols x 8
   uint32_t* out;            // rows x 8
   uint32_t colmask;         // 2^28 - 1 (tagged) or all ones
+  NMX_HD void operator()(uint32_t row) const { st<FID>(out, row, spmv_row<FID>(indptr, indices, data, z, colmask, row)); }
+};
+
+// commit_T in one pass over the rows (src/r1cs/mod.rs:612-620): T[row] = (A z)[row] (B z)[row] - u (C z)[row] - E[row].  The
+// three products and the cross term of CrossTermFn without AZ, BZ, CZ ever reaching HBM, and one launch instead of four;
+// bit-identical to the separate calls (each row product is canonicalised exactly as SpmvFn's store does).
+template <int FID> struct SpmvCrossFn {
+  const uint32_t *ipA, *ixA, *dA, *ipB, *ixB, *dB, *ipC, *ixC, *dC;
+  const uint32_t *z, *e;
+  uint32_t* out;
+  uint32_t colmask;
+  Fp<FID> u, k;  // as CrossTermFn: (p - u) * 2^261, and 2^522 / F
   NMX_HD void operator()(uint32_t row) const {
     using F = Fp<FID>;
-    F acc = F::zero();
-    uint32_t pending = 0;
-    for (uint32_t k = indptr[row]; k < indptr[row + 1]; k++) {
-      const uint32_t w = indices[k], cls = (w & ~colmask) >> kSpmvColBits;
-      const F zf = ld<FID>(z, w & colmask);
-      acc = acc + (cls ? spmv_small_term<FID>(cls, zf) : ld<FID>(data, k) * zf);
-      if (++pending == 6) {
-        acc = acc.norm().canon();
-        pending = 0;
-      }
-    }
-    st<FID>(out, row, acc.norm());
+    const F az = spmv_row<FID>(ipA, ixA, dA, z, colmask, row).canon();
+    const F bz = spmv_row<FID>(ipB, ixB, dB, z, colmask, row).canon();
+    const F cz = spmv_row<FID>(ipC, ixC, dC, z, colmask, row).canon();
+    const F ab = az * bz;
+    F t = F::mul_add(ab, k, cz, u);
+    t = F::sub2(t, ld<FID>(e, row)).norm();
+    st<FID>(out, row, t);
+  }
+};
+// NIFS fold in one launch (src/r1cs/mod.rs:1058-1067): W = W1 + r W2 over n_w elements, E = E1 + r T over n_e
+template <int FID> struct FoldPairFn {
+  const uint32_t *w1, *w2, *e1, *t;
+  uint32_t *w, *e;
+  uint32_t n_w;
+  Fp<FID> r;
+  NMX_HD void operator()(uint32_t i) const {
+    if (i < n_w) st<FID>(w, i, (ld<FID>(w1, i) + r * ld<FID>(w2, i)).norm());
+    else st<FID>(e, i - n_w, (ld<FID>(e1, i - n_w) + r * ld<FID>(t, i - n_w)).norm());
   }
 };
 
@@ -808,10 +844,12 @@ template <int FID> static Fp<FID> challenge(const void* r, bool mont) {
 struct VecIO {  // stages host vectors through the context arena; device vectors are used in place
   Ctx& c;
   bool dev;
+  bool async = false;  // NMX_ASYNC on device-resident operands: the call returns once its kernel is enqueued (runtime.hpp async_mark)
   size_t n;
   size_t used = 0;
   std::vector<std::pair<void*, const void*>> outs;  // (device, host)
-  VecIO(Ctx& ctx, bool device, size_t n_, int n_vecs) : c(ctx), dev(device), n(n_) {
+  VecIO(Ctx& ctx, uint32_t flags, size_t n_, int n_vecs)
+      : c(ctx), dev((flags & NMX_SCALARS_DEVICE) != 0), async((flags & NMX_ASYNC) && (flags & NMX_SCALARS_DEVICE)), n(n_) {
     if (!dev) arena_reserve(c, (size_t)n_vecs * ((n * 32 + 255) & ~(size_t)255) + 256);
   }
   const uint32_t* in(const void* p, size_t elems) {
@@ -833,6 +871,10 @@ struct VecIO {  // stages host vectors through the context arena; device vectors
   void finish() {
     for (auto& o : outs)
       HIPCHK(hipMemcpyAsync((void*)o.second, o.first, out_elems * 32, hipMemcpyDeviceToHost, c.stream));
+    if (async && outs.empty()) {
+      async_mark(c);  // no wait: the next call of this host thread is ordered behind this one
+      return;
+    }
     stream_wait(c.stream);
   }
 };
@@ -844,7 +886,7 @@ template <class Fn> static void timed_launch(Ctx& c, const Fn& f, size_t n, VecI
   be.launch(f, (uint32_t)n);
   be.mark("end");
   io->finish();
-  if (prof && be.nmarks == 2) {
+  if (prof && be.nmarks == 2 && !(io->async && io->outs.empty())) {  // (an asynchronous call has no kernel time to report yet)
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
     prof_store(&ms, 1);
@@ -855,14 +897,14 @@ template <int FID> struct FieldImpl {
   using F = Fp<FID>;
   static void axpy(Ctx& c, const void* a, const void* b, const void* r, size_t n, uint32_t flags, void* out) {
     const bool mont = flags & NMX_SCALARS_MONT;
-    VecIO io(c, flags & NMX_SCALARS_DEVICE, n, 3);
+    VecIO io(c, flags, n, 3);
     AxpyFn<FID> f{io.in(a, n), io.in(b, n), io.out(out, n), challenge<FID>(r, mont)};
     timed_launch(c, f, n, &io);
   }
   static void axpy2(Ctx& c, const void* a, const void* b, const void* cc, const void* r, size_t n, uint32_t flags,
                     void* out) {
     const bool mont = flags & NMX_SCALARS_MONT;
-    VecIO io(c, flags & NMX_SCALARS_DEVICE, n, 4);
+    VecIO io(c, flags, n, 4);
     F ri = challenge<FID>(r, mont);
     Axpy2Fn<FID> f{io.in(a, n), io.in(b, n), io.in(cc, n), io.out(out, n), ri, (ri * ri).canon()};
     timed_launch(c, f, n, &io);
@@ -870,7 +912,7 @@ template <int FID> struct FieldImpl {
   static void cross_term(Ctx& c, const void* az, const void* bz, const void* cz, const void* e, const void* u, size_t n,
                          uint32_t flags, void* out) {
     const bool mont = flags & NMX_SCALARS_MONT;
-    VecIO io(c, flags & NMX_SCALARS_DEVICE, n, 5);
+    VecIO io(c, flags, n, 5);
     // canonical data: k = 2^522 (R2); Montgomery data (F = 2^256): k = 2^522 / 2^256 = 2^266 (C266)
     F k = mont ? F::from_limbs(FpParams<FID>::C266) : F::from_limbs(FpParams<FID>::R2);
     const F nu = F::sub2(F::zero(), challenge<FID>(u, mont)).norm().canon();  // p - u (0 for u = 0)
@@ -880,14 +922,14 @@ template <int FID> struct FieldImpl {
   static void cross_term2(Ctx& c, const void* az, const void* bz, const void* cz, const void* e1, const void* e2,
                           const void* u, size_t n, uint32_t flags, void* out) {
     const bool mont = flags & NMX_SCALARS_MONT;
-    VecIO io(c, flags & NMX_SCALARS_DEVICE, n, 6);
+    VecIO io(c, flags, n, 6);
     F k = mont ? F::from_limbs(FpParams<FID>::C266) : F::from_limbs(FpParams<FID>::R2);
     const F nu = F::sub2(F::zero(), challenge<FID>(u, mont)).norm().canon();
     CrossTerm2Fn<FID> f{io.in(az, n), io.in(bz, n), io.in(cz, n), io.in(e1, n), io.in(e2, n), io.out(out, n), nu, k};
     timed_launch(c, f, n, &io);
   }
   static void vec_add(Ctx& c, const void* a, const void* b, size_t n, uint32_t flags, void* out) {
-    VecIO io(c, flags & NMX_SCALARS_DEVICE, n, 3);
+    VecIO io(c, flags, n, 3);
     VecAddFn<FID> f{io.in(a, n), io.in(b, n), io.out(out, n)};
     timed_launch(c, f, n, &io);
   }
@@ -896,7 +938,7 @@ template <int FID> struct FieldImpl {
                    size_t n_out, uint32_t flags, void* out) {
     const bool mont = flags & NMX_SCALARS_MONT;
     const bool dev = flags & NMX_SCALARS_DEVICE;
-    VecIO io(c, dev, z_len + n_out, 2);
+    VecIO io(c, flags & ~(uint32_t)NMX_ASYNC, z_len + n_out, 2);
     const uint32_t* zd = io.in(z, z_len);
     uint32_t* od = (dev && out == z) ? (uint32_t*)out : io.out(out, n_out);
     BindTopFn<FID> f{zd + 8 * lo_off, zd + 8 * hi_off, od, challenge<FID>(r, mont), (uint32_t)stride};
@@ -999,7 +1041,7 @@ template <int FID> static void spmv_classify_t(Ctx& c, const uint32_t* d_data, u
 template <int FID>
 static void spmv_apply_t(Ctx& c, const uint32_t* indptr, const uint32_t* indices, const uint32_t* data, size_t rows,
                          size_t cols, const void* z, uint32_t flags, void* out) {
-  VecIO io(c, flags & NMX_SCALARS_DEVICE, rows + cols, 2);
+  VecIO io(c, flags, rows + cols, 2);
   const uint32_t* dz = io.in(z, cols);
   uint32_t* dout = io.out(out, rows);
   SpmvFn<FID> f{indptr, indices, data, dz, dout, cols <= ((size_t)1 << kSpmvColBits) ? (1u << kSpmvColBits) - 1u : 0xffffffffu};
@@ -1009,13 +1051,45 @@ static void spmv_apply_t(Ctx& c, const uint32_t* indptr, const uint32_t* indices
 template <int FID>
 static void spmv_apply_pair_t(Ctx& c, const uint32_t* indptr, const uint32_t* indices, const uint32_t* data, size_t rows,
                               size_t cols, const void* z1, const void* z2, uint32_t flags, void* out1, void* out2) {
-  VecIO io(c, flags & NMX_SCALARS_DEVICE, rows + cols, 4);
+  VecIO io(c, flags, rows + cols, 4);
   const uint32_t* d1 = io.in(z1, cols);
   const uint32_t* d2 = io.in(z2, cols);
   uint32_t* o1 = io.out(out1, rows);
   uint32_t* o2 = io.out(out2, rows);
   SpmvPairFn<FID> f{indptr, indices, data, d1, d2, o1, o2, cols <= ((size_t)1 << kSpmvColBits) ? (1u << kSpmvColBits) - 1u : 0xffffffffu};
   timed_launch(c, f, rows, &io);
+}
+
+// commit_T's chain (src/r1cs/mod.rs:590-620) on HBM-resident vectors: Z = z1 + z2 (z2 may be null: Z = z1), then SpmvCrossFn.
+// Z lives in the context arena; with NMX_ASYNC nothing waits (the arena is only re-carved by later calls on the same stream).
+template <int FID>
+static void r1cs_cross_term_t(Ctx& c, const uint32_t* const* ip, const uint32_t* const* ix, const uint32_t* const* dt, size_t rows,
+                              size_t cols, const void* z1, const void* z2, const void* e, const void* u, uint32_t flags, void* out) {
+  using F = Fp<FID>;
+  const bool mont = flags & NMX_SCALARS_MONT;
+  VecIO io(c, flags, rows, 0);
+  const uint32_t* dz = (const uint32_t*)z1;
+  DeviceBackend be(c, false, false);
+  if (z2) {
+    arena_reserve(c, cols * 32 + 256);
+    uint32_t* zsum = (uint32_t*)c.arena;
+    VecAddFn<FID> add{(const uint32_t*)z1, (const uint32_t*)z2, zsum};
+    be.launch(add, (uint32_t)cols);
+    dz = zsum;
+  }
+  const F k = mont ? F::from_limbs(FpParams<FID>::C266) : F::from_limbs(FpParams<FID>::R2);
+  const F nu = F::sub2(F::zero(), challenge<FID>(u, mont)).norm().canon();
+  SpmvCrossFn<FID> f{ip[0], ix[0], dt[0], ip[1], ix[1], dt[1], ip[2], ix[2], dt[2], dz, (const uint32_t*)e, (uint32_t*)out,
+                     cols <= ((size_t)1 << kSpmvColBits) ? (1u << kSpmvColBits) - 1u : 0xffffffffu, nu, k};
+  timed_launch(c, f, rows, &io);
+}
+template <int FID>
+static void nifs_fold_t(Ctx& c, const void* w1, const void* w2, size_t n_w, const void* e1, const void* t, size_t n_e, const void* r,
+                        uint32_t flags, void* w, void* e) {
+  VecIO io(c, flags, n_w + n_e, 0);
+  FoldPairFn<FID> f{(const uint32_t*)w1, (const uint32_t*)w2, (const uint32_t*)e1, (const uint32_t*)t, (uint32_t*)w, (uint32_t*)e,
+                    (uint32_t)n_w, challenge<FID>(r, flags & NMX_SCALARS_MONT)};
+  timed_launch(c, f, n_w + n_e, &io);
 }
 
 template <int FID>
@@ -1351,6 +1425,26 @@ void fv_spmv_apply_pair(Ctx& c, int field, const uint32_t* indptr, const uint32_
     case 1: spmv_apply_pair_t<1>(c, indptr, indices, data, rows, cols, z1, z2, flags, out1, out2); break;
     case 2: spmv_apply_pair_t<2>(c, indptr, indices, data, rows, cols, z1, z2, flags, out1, out2); break;
     case 3: spmv_apply_pair_t<3>(c, indptr, indices, data, rows, cols, z1, z2, flags, out1, out2); break;
+    default: throw Fail{NMX_E_ARG, "bad field id"};
+  }
+}
+void fv_r1cs_cross_term(Ctx& c, int field, const uint32_t* const* ip, const uint32_t* const* ix, const uint32_t* const* dt, size_t rows,
+                        size_t cols, const void* z1, const void* z2, const void* e, const void* u, uint32_t flags, void* out) {
+  switch (field) {
+    case 0: r1cs_cross_term_t<0>(c, ip, ix, dt, rows, cols, z1, z2, e, u, flags, out); break;
+    case 1: r1cs_cross_term_t<1>(c, ip, ix, dt, rows, cols, z1, z2, e, u, flags, out); break;
+    case 2: r1cs_cross_term_t<2>(c, ip, ix, dt, rows, cols, z1, z2, e, u, flags, out); break;
+    case 3: r1cs_cross_term_t<3>(c, ip, ix, dt, rows, cols, z1, z2, e, u, flags, out); break;
+    default: throw Fail{NMX_E_ARG, "bad field id"};
+  }
+}
+void fv_nifs_fold(Ctx& c, int field, const void* w1, const void* w2, size_t n_w, const void* e1, const void* t, size_t n_e,
+                  const void* r, uint32_t flags, void* w, void* e) {
+  switch (field) {
+    case 0: nifs_fold_t<0>(c, w1, w2, n_w, e1, t, n_e, r, flags, w, e); break;
+    case 1: nifs_fold_t<1>(c, w1, w2, n_w, e1, t, n_e, r, flags, w, e); break;
+    case 2: nifs_fold_t<2>(c, w1, w2, n_w, e1, t, n_e, r, flags, w, e); break;
+    case 3: nifs_fold_t<3>(c, w1, w2, n_w, e1, t, n_e, r, flags, w, e); break;
     default: throw Fail{NMX_E_ARG, "bad field id"};
   }
 }

@@ -73,6 +73,7 @@ struct Ctx {
   size_t aux_cap = 0;
   hipEvent_t ev[kMaxMarks];
   bool have_ev = false;
+  hipEvent_t async_ev = nullptr;  // behind the last NMX_ASYNC call enqueued on this context
   std::vector<XYZZW> wsum;  // landing buffer of the per-window sums (off the caller's stack)
   uint64_t shape_key = 0;   // shape of the last MSM sized on this context and the workspace it needs
   size_t shape_bytes = 0;
@@ -307,6 +308,9 @@ void prof_store(const float* ms, int n);   // last call's stage times of this th
 void prof_add_tail(float ms);
 void arena_reserve(Ctx& c, size_t bytes);  // capi.hip
 void aux_reserve(Ctx& c, size_t bytes);    // capi.hip
+// NMX_ASYNC (capi.hip): records an event behind the work just enqueued on c.stream and remembers it for the calling host
+// thread; the thread's next lease of ANY context waits for it on that context's stream (CtxLease), nmx_sync waits on the host.
+void async_mark(Ctx& c);
 // rocPRIM radix sort of (key, value) pairs, its own TU (sort.hip).  tmp == nullptr: size query.
 void device_sort_pairs(void* tmp, size_t& tmp_bytes, uint32_t* k_in, uint32_t* k_out, uint32_t* v_in,
                        uint32_t* v_out, size_t total, uint32_t bits, hipStream_t stream);
@@ -633,6 +637,10 @@ void fv_bind(Ctx&, int field, const void* z, size_t z_len, size_t lo_off, size_t
              size_t n_out, uint32_t flags, void* out);
 
 void fv_suffix_horner(Ctx&, int field, const void* f, size_t n, const void* u, uint32_t flags, void* out);
+void fv_r1cs_cross_term(Ctx&, int field, const uint32_t* const* indptr, const uint32_t* const* indices, const uint32_t* const* data,
+                        size_t rows, size_t cols, const void* z1, const void* z2, const void* e, const void* u, uint32_t flags, void* out);
+void fv_nifs_fold(Ctx&, int field, const void* w1, const void* w2, size_t n_w, const void* e1, const void* t, size_t n_e, const void* r,
+                  uint32_t flags, void* w, void* e);
 void fv_eq_evals(Ctx&, int field, const void* r_host, uint32_t ell, uint32_t flags, uint32_t* d_out);
 void fv_eq_evals_pair(Ctx&, int field, const void* r_host, uint32_t ellL, uint32_t ellR, uint32_t flags, uint32_t* d_outL,
                       uint32_t* d_outR);  // both tables of an evaluation, one launch when both fit the direct kernel

@@ -43,32 +43,40 @@ def _chal(r):
     return a
 
 
-def _flags(dev, mont):
-    return (L.SCALARS_DEVICE if dev else 0) | (L.SCALARS_MONT if mont else 0)
+def _flags(dev, mont, async_=False):
+    """async_ (NMX_ASYNC): device-resident operands only -- the call returns once its kernel is enqueued; the calling thread's
+    next synchronous call (any MSM / commitment / reduction) or sync() completes it.  Keep the operand tensors alive until then:
+    torch's allocator knows nothing about the library's stream."""
+    return (L.SCALARS_DEVICE if dev else 0) | (L.SCALARS_MONT if mont else 0) | (L.ASYNC if (async_ and dev) else 0)
 
 
-def axpy(field, a, b, r, mont=False):
+def sync():
+    """nmx_sync: wait for this thread's asynchronous calls."""
+    _check(L.lib().nmx_sync())
+
+
+def axpy(field, a, b, r, mont=False, async_=False):
     pa, n, dev, _ka = _vec(a)
     pb, nb, devb, _kb = _vec(b)
     assert n == nb and dev == devb, "InvalidWitnessLength (r1cs/mod.rs:1054-1056)"
     po, out = _out_like(dev, n, a)
     rr = _chal(r)
-    _check(L.lib().nmx_field_axpy(field, pa, pb, rr.ctypes.data, n, _flags(dev, mont), po))
+    _check(L.lib().nmx_field_axpy(field, pa, pb, rr.ctypes.data, n, _flags(dev, mont, async_), po))
     return out
 
 
-def axpy2(field, a, b, c, r, mont=False):
+def axpy2(field, a, b, c, r, mont=False, async_=False):
     pa, n, dev, _ka = _vec(a)
     pb, nb, _d1, _kb = _vec(b)
     pc, nc, _d2, _kc = _vec(c)
     assert n == nb == nc
     po, out = _out_like(dev, n, a)
     rr = _chal(r)
-    _check(L.lib().nmx_field_axpy2(field, pa, pb, pc, rr.ctypes.data, n, _flags(dev, mont), po))
+    _check(L.lib().nmx_field_axpy2(field, pa, pb, pc, rr.ctypes.data, n, _flags(dev, mont, async_), po))
     return out
 
 
-def cross_term(field, az, bz, cz, e, u, mont=False):
+def cross_term(field, az, bz, cz, e, u, mont=False, async_=False):
     p1, n, dev, _k1 = _vec(az)
     p2, n2, _d2, _k2 = _vec(bz)
     p3, n3, _d3, _k3 = _vec(cz)
@@ -76,27 +84,27 @@ def cross_term(field, az, bz, cz, e, u, mont=False):
     assert n == n2 == n3 == n4
     po, out = _out_like(dev, n, az)
     uu = _chal(u)
-    _check(L.lib().nmx_field_cross_term(field, p1, p2, p3, p4, uu.ctypes.data, n, _flags(dev, mont), po))
+    _check(L.lib().nmx_field_cross_term(field, p1, p2, p3, p4, uu.ctypes.data, n, _flags(dev, mont, async_), po))
     return out
 
 
-def cross_term2(field, az, bz, cz, e1, e2, u, mont=False):
+def cross_term2(field, az, bz, cz, e1, e2, u, mont=False, async_=False):
     """T = AZ o BZ - u*CZ - E1 - E2, u = U1.u + U2.u (commit_T_relaxed, src/r1cs/mod.rs:652-659)."""
     ps = [_vec(x) for x in (az, bz, cz, e1, e2)]
     n, dev = ps[0][1], ps[0][2]
     assert all(q[1] == n for q in ps)
     po, out = _out_like(dev, n, az)
     uu = _chal(u)
-    _check(L.lib().nmx_field_cross_term2(field, *[q[0] for q in ps], uu.ctypes.data, n, _flags(dev, mont), po))
+    _check(L.lib().nmx_field_cross_term2(field, *[q[0] for q in ps], uu.ctypes.data, n, _flags(dev, mont, async_), po))
     return out
 
 
-def vec_add(field, a, b, mont=False):
+def vec_add(field, a, b, mont=False, async_=False):
     pa, n, dev, _ka = _vec(a)
     pb, nb, _d, _kb = _vec(b)
     assert n == nb
     po, out = _out_like(dev, n, a)
-    _check(L.lib().nmx_field_vec_add(field, pa, pb, n, _flags(dev, mont), po))
+    _check(L.lib().nmx_field_vec_add(field, pa, pb, n, _flags(dev, mont, async_), po))
     return out
 
 
@@ -238,6 +246,33 @@ def mle_multi_evaluate(field, zs, r, mont=False):
     return [out[32 * j: 32 * j + 32].tobytes() for j in range(k)]
 
 
+def r1cs_cross_term(A, B, C, z1, z2, e, u, mont=False, async_=False):
+    """commit_T's chain as one call (nmx_r1cs_cross_term; src/r1cs/mod.rs:590-620): T = (A Z)(B Z) - u (C Z) - E with Z = z1 + z2
+    (z2 None: Z = z1).  A, B, C: SparseMatrix of one shape; CUDA tensors only."""
+    p1, n, dev, _k1 = _vec(z1)
+    p2 = _vec(z2)[0] if z2 is not None else None
+    pe, ne, _de, _ke = _vec(e)
+    assert dev and n == A.cols and ne == A.rows
+    po, out = _out_like(dev, A.rows, z1)
+    uu = _chal(u)
+    _check(L.lib().nmx_r1cs_cross_term(A.handle, B.handle, C.handle, p1, p2, n, pe, uu.ctypes.data, _flags(dev, mont, async_), po))
+    return out
+
+
+def nifs_fold(field, w1, w2, e1, t, r, mont=False, async_=False):
+    """R1CSWitness::fold as one launch (nmx_nifs_fold; src/r1cs/mod.rs:1044-1067): (w1 + r w2, e1 + r t).  CUDA tensors only."""
+    pw1, nw, dev, _a = _vec(w1)
+    pw2, nw2, _d, _b = _vec(w2)
+    pe1, ne, _d2, _c = _vec(e1)
+    pt, nt, _d3, _e = _vec(t)
+    assert dev and nw == nw2 and ne == nt
+    pw, w = _out_like(dev, nw, w1)
+    pe, e = _out_like(dev, ne, e1)
+    rr = _chal(r)
+    _check(L.lib().nmx_nifs_fold(field, pw1, pw2, nw, pe1, pt, ne, rr.ctypes.data, _flags(dev, mont, async_), pw, pe))
+    return w, e
+
+
 class SparseMatrix:
     """CSR matrix resident in HBM (src/r1cs/sparse.rs:232-260); multiply_vec = sparse.rs:201-229."""
 
@@ -252,21 +287,21 @@ class SparseMatrix:
                                          L.SCALARS_MONT if mont else 0, ctypes.byref(h)))
         self.handle = h.value
 
-    def multiply_vec(self, z, mont=False):
+    def multiply_vec(self, z, mont=False, async_=False):
         pz, n, dev, _kz = _vec(z)
         assert n == self.cols, "invalid shape"
         po, out = _out_like(dev, self.rows, z)
-        _check(L.lib().nmx_spmv_apply(self.handle, pz, n, _flags(dev, mont), po))
+        _check(L.lib().nmx_spmv_apply(self.handle, pz, n, _flags(dev, mont, async_), po))
         return out
 
-    def multiply_vec_pair(self, z1, z2, mont=False):
+    def multiply_vec_pair(self, z1, z2, mont=False, async_=False):
         """(M*z1, M*z2) in one pass (sparse.rs:215-229)."""
         p1, n1, dev, _k1 = _vec(z1)
         p2, n2, dev2, _k2 = _vec(z2)
         assert n1 == self.cols and n2 == self.cols and dev == dev2, "invalid shape"
         po1, out1 = _out_like(dev, self.rows, z1)
         po2, out2 = _out_like(dev, self.rows, z1)
-        _check(L.lib().nmx_spmv_apply_pair(self.handle, p1, p2, n1, _flags(dev, mont), po1, po2))
+        _check(L.lib().nmx_spmv_apply_pair(self.handle, p1, p2, n1, _flags(dev, mont, async_), po1, po2))
         return out1, out2
 
     def close(self):

@@ -528,3 +528,58 @@ def test_poly_eval_multi(nmx, fid):
     got = fv.poly_eval_multi(fid, [to_m(f) for f in polys[6:]], to_m(pts), mont=True)
     want = [[cref.suffix_horner(fid, f, len(f), pts[j])[:32] for j in range(3)] for f in polys[6:]]
     assert [[(int.from_bytes(g, "little") * pow(Rm, -1, p) % p).to_bytes(32, "little") for g in row] for row in got] == want
+
+
+@pytest.mark.parametrize("k", [1, 2])
+def test_async_nifs_chain_is_ordered_before_the_commitment(nmx, k):
+    """NMX_ASYNC: Z = W1 + W2, AZ / BZ / CZ, T = AZ o BZ - u CZ - E (src/r1cs/mod.rs:590-620) enqueued without a host wait
+    between them, then commit(T) -- synchronous, ordered behind the chain on whatever context (and, over a sharded key, on
+    whatever helper threads) it runs -- and the folds (1044-1107) completed by nmx_sync.  Same bytes as the synchronous calls."""
+    import torch
+    from nova_amd import _lib
+    from nova_amd import fieldvec as fv
+    L = _lib.lib()
+    cid, fid, n = 0, fv.SCALAR_FIELD_OF_CURVE[0], 60000
+    assert nmx.init_devices(k, oversubscribe=True) == k
+    assert L.nmx_set_option(b"shard_min_n", 1000) == 0
+    try:
+        ck = nmx.CommitmentKey.generate(cid, n, k0=5)
+        ce = nmx.CommitmentEngine(cid)
+        hW1, hW2, hE = (C.rand_vec(fid, n, s) for s in (41, 42, 43))
+        u, r = C.rand_vec(fid, 1, 44), C.rand_vec(fid, 1, 45)
+        mats = [fv.SparseMatrix(fid, *C.random_csr(fid, n, n, 50 + j), n) for j in range(3)]
+        W1, W2, E = (torch.from_numpy(h.copy()).cuda() for h in (hW1, hW2, hE))
+        torch.cuda.synchronize()
+        # synchronous reference run
+        Z0 = fv.vec_add(fid, W1, W2)
+        P0 = [m.multiply_vec(Z0) for m in mats]
+        T0 = fv.cross_term(fid, P0[0], P0[1], P0[2], E, u)
+        c0 = ce.commit(ck, T0, r)
+        F0 = fv.axpy(fid, E, T0, r)
+        for _ in range(3):
+            Z = fv.vec_add(fid, W1, W2, async_=True)
+            P = [m.multiply_vec(Z, async_=True) for m in mats]
+            T = fv.cross_term(fid, P[0], P[1], P[2], E, u, async_=True)
+            c1 = ce.commit(ck, T, r)                       # synchronous: everything before it is complete on return
+            assert (c1.xy, c1.is_inf) == (c0.xy, c0.is_inf)
+            assert torch.equal(T, T0) and torch.equal(Z, Z0)
+            F = fv.axpy(fid, E, T, r, async_=True)
+            fv.sync()
+            assert torch.equal(F, F0)
+        # the compound calls: commit_T's chain and the fold, one call each, synchronous and stream-ordered
+        hT = fv.r1cs_cross_term(mats[0], mats[1], mats[2], W1, W2, E, u)
+        assert torch.equal(hT, T0)
+        assert torch.equal(fv.r1cs_cross_term(mats[0], mats[1], mats[2], Z0, None, E, u), T0)
+        for _ in range(2):
+            T = fv.r1cs_cross_term(mats[0], mats[1], mats[2], W1, W2, E, u, async_=True)
+            c2 = ce.commit(ck, T, r)
+            assert (c2.xy, c2.is_inf) == (c0.xy, c0.is_inf) and torch.equal(T, T0)
+            Wf, Ef = fv.nifs_fold(fid, W1, W2, E, T, r, async_=True)
+            fv.sync()
+            assert torch.equal(Ef, F0) and torch.equal(Wf, fv.axpy(fid, W1, W2, r))
+        for m in mats:
+            m.close()
+        ck.close()
+    finally:
+        assert nmx.init_devices(1) == 1
+        assert L.nmx_set_option(b"shard_min_n", 1 << 20) == 0
