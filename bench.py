@@ -114,6 +114,8 @@ def main():
                     help="register the key WITHOUT window tables: the plain path (W bucket sets) that first / second sight of a "
                          "cached array, IPA's per-round keys and keys whose tables do not fit take")
     ap.add_argument("--iters", type=int, default=65536, help="prove_step_replay: MinRoot iterations per step")
+    ap.add_argument("--opens", default="batch", choices=["batch", "threads", "serial"],
+                    help="hyperkzg replay: the three kzg_open commitments as one batch_commit (default), three host threads (the reference's par_iter), or one after the other")
     ap.add_argument("--separate-field-ops", action="store_true", help="prove_step replay: vec_add, 3 x SpMV, cross term and the two folds as separate (stream-ordered) calls")
     ap.add_argument("--sync-field-ops", action="store_true", help="prove_step replay: every field-vector call waits for its kernel (round 3's form)")
     ap.add_argument("--workload", default="msm", choices=["msm", "axpy", "cross_term", "bind", "sumcheck3", "round3", "quad_prod", "lincomb8", "horner", "mle_eval", "spmv", "prove_step_replay", "hyperkzg_replay"],
@@ -956,8 +958,8 @@ def hyperkzg_replay(args, torch, ck=None):
 
     def step():
         polys, cur = [dP], dP
-        for i in range(ell - 1):
-            cur = fv.fold_pairs(fid, cur, xs[ell - i - 1])
+        for i in range(ell - 1):   # stream-ordered: the host looks at none of the folded polynomials before they are committed
+            cur = fv.fold_pairs(fid, cur, xs[ell - i - 1], async_=not args.sync_field_ops)
             polys.append(cur)
         coms = ce.batch_commit(ck, polys[1:])
         evals = fv.poly_eval_multi(fid, polys, us)   # the whole v matrix (hyperkzg.rs:1049-1056) in one launch
@@ -967,7 +969,13 @@ def hyperkzg_replay(args, torch, ck=None):
 
         def open_at(j):
             opens[j] = ce.commit(ck, fv.div_by_monomial(fid, B, us[j]).contiguous())
-        if os.environ.get("NMX_REPLAY_SERIAL_OPENS"):
+        if args.opens == "batch":
+            # the three quotients committed by ONE batch_commit over the key (a fused run: one partition / accumulate / reduction
+            # pass, a bucket set per quotient) instead of three concurrent commits -- on the reference side kzg_open's
+            # `u.into_par_iter()` of three commits becomes three divisions + one CE::batch_commit
+            hs = [fv.div_by_monomial(fid, B, us[j]).contiguous() for j in range(3)]
+            opens = ce.batch_commit(ck, hs)
+        elif args.opens == "serial":
             for j in range(3):
                 open_at(j)
         else:

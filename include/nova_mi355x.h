@@ -53,7 +53,8 @@ enum {
                                     (src/provider/msm.rs:564-574), so nothing crosses xGMI or PCIe inside the call.  A key on
                                     one device has one piece.  nmx_svec_* allocates vectors in this layout.          */
   NMX_ASYNC = 1u << 9,          /* element-wise field kernels and SpMV on HBM-resident vectors (nmx_field_axpy / _axpy2 /
-                                   _cross_term / _cross_term2 / _vec_add, nmx_spmv_apply[_pair], nmx_r1cs_cross_term, nmx_nifs_fold; ignored elsewhere and with
+                                   _cross_term / _cross_term2 / _vec_add, nmx_mle_bind_top, nmx_poly_fold_pairs, nmx_spmv_apply[_pair],
+                                   nmx_r1cs_cross_term, nmx_nifs_fold; ignored elsewhere and with
                                    host operands): return once the kernel is ENQUEUED.  The calling host thread's later calls
                                    -- any entry point -- are ordered behind it, and every call that is synchronous (all MSMs
                                    and commitments, all reductions, anything with a host operand) still returns with

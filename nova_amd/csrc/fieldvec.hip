@@ -938,7 +938,7 @@ template <int FID> struct FieldImpl {
                    size_t n_out, uint32_t flags, void* out) {
     const bool mont = flags & NMX_SCALARS_MONT;
     const bool dev = flags & NMX_SCALARS_DEVICE;
-    VecIO io(c, flags & ~(uint32_t)NMX_ASYNC, z_len + n_out, 2);
+    VecIO io(c, flags, z_len + n_out, 2);
     const uint32_t* zd = io.in(z, z_len);
     uint32_t* od = (dev && out == z) ? (uint32_t*)out : io.out(out, n_out);
     BindTopFn<FID> f{zd + 8 * lo_off, zd + 8 * hi_off, od, challenge<FID>(r, mont), (uint32_t)stride};

@@ -108,26 +108,26 @@ def vec_add(field, a, b, mont=False, async_=False):
     return out
 
 
-def bind_poly_var_top(field, z, r, mont=False, in_place=False):
+def bind_poly_var_top(field, z, r, mont=False, in_place=False, async_=False):
     """Returns the bound polynomial (len/2 evaluations).  in_place (device tensors only) overwrites z[:len/2]."""
     pz, n, dev, _kz = _vec(z)
     assert n >= 2 and n % 2 == 0, "assert!(self.num_vars > 0)"
     rr = _chal(r)
     if in_place:
         assert dev
-        _check(L.lib().nmx_mle_bind_top(field, pz, n, rr.ctypes.data, _flags(dev, mont), pz))
+        _check(L.lib().nmx_mle_bind_top(field, pz, n, rr.ctypes.data, _flags(dev, mont, async_), pz))
         return z.view(-1)[: (n // 2) * 32].view(n // 2, 32)
     po, out = _out_like(dev, n // 2, z)
-    _check(L.lib().nmx_mle_bind_top(field, pz, n, rr.ctypes.data, _flags(dev, mont), po))
+    _check(L.lib().nmx_mle_bind_top(field, pz, n, rr.ctypes.data, _flags(dev, mont, async_), po))
     return out
 
 
-def fold_pairs(field, p, x, mont=False):
+def fold_pairs(field, p, x, mont=False, async_=False):
     pp, n, dev, _kp = _vec(p)
     assert n >= 2 and n % 2 == 0
     xx = _chal(x)
     po, out = _out_like(dev, n // 2, p)
-    _check(L.lib().nmx_poly_fold_pairs(field, pp, n, xx.ctypes.data, _flags(dev, mont), po))
+    _check(L.lib().nmx_poly_fold_pairs(field, pp, n, xx.ctypes.data, _flags(dev, mont, async_), po))
     return out
 
 
