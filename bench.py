@@ -840,8 +840,8 @@ def prove_step_replay(args, torch):
         d = dev[k]
         # the field kernels between two commitments are stream-ordered calls (NMX_ASYNC): nothing on the host looks at Z, AZ,
         # BZ, CZ, T, W, E before the next commitment, which is synchronous and ordered behind them
-        a = not args.sync_field_ops
-        if a and not args.separate_field_ops:
+        a = not getattr(args, "sync_field_ops", False)
+        if a and not getattr(args, "separate_field_ops", False):
             # one call per reference function: commit_T's chain (nmx_r1cs_cross_term) and the fold (nmx_nifs_fold)
             T = call(f"{k}.cross_term", lambda: fv.r1cs_cross_term(mats[k][0], mats[k][1], mats[k][2], d["W1"], d["W"], d["E1"], uu, async_=True))
             comT = call(f"{k}.commit_T", lambda: ce[k].commit(ck[k], T, rT[k]))
@@ -959,7 +959,7 @@ def hyperkzg_replay(args, torch, ck=None):
     def step():
         polys, cur = [dP], dP
         for i in range(ell - 1):   # stream-ordered: the host looks at none of the folded polynomials before they are committed
-            cur = fv.fold_pairs(fid, cur, xs[ell - i - 1], async_=not args.sync_field_ops)
+            cur = fv.fold_pairs(fid, cur, xs[ell - i - 1], async_=not getattr(args, "sync_field_ops", False))
             polys.append(cur)
         coms = ce.batch_commit(ck, polys[1:])
         evals = fv.poly_eval_multi(fid, polys, us)   # the whole v matrix (hyperkzg.rs:1049-1056) in one launch
@@ -969,13 +969,14 @@ def hyperkzg_replay(args, torch, ck=None):
 
         def open_at(j):
             opens[j] = ce.commit(ck, fv.div_by_monomial(fid, B, us[j]).contiguous())
-        if args.opens == "batch":
+        opens_mode = getattr(args, "opens", "batch")
+        if opens_mode == "batch":
             # the three quotients committed by ONE batch_commit over the key (a fused run: one partition / accumulate / reduction
             # pass, a bucket set per quotient) instead of three concurrent commits -- on the reference side kzg_open's
             # `u.into_par_iter()` of three commits becomes three divisions + one CE::batch_commit
             hs = [fv.div_by_monomial(fid, B, us[j]).contiguous() for j in range(3)]
             opens = ce.batch_commit(ck, hs)
-        elif args.opens == "serial":
+        elif opens_mode == "serial":
             for j in range(3):
                 open_at(j)
         else:

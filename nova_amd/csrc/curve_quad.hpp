@@ -53,8 +53,14 @@ template <int FID> __device__ __forceinline__ XYZZ<FID> quad_gather(const Fp<FID
   p.zzz = qperm<QP_L3>(c);
   return p;
 }
+// limb by limb: `q == 0 ? p.x : ...` on the structs selects an ADDRESS, which keeps the whole point in scratch memory
+// (148 bytes of private segment in every quad kernel, found in round 4's ISA scan; only the rare P == +-Q path touched it: no
+// measurable change in the tail's stage times, profiles/r04_msm_2p20/digit_ab.txt)
 template <int FID> __device__ __forceinline__ Fp<FID> quad_pick(const XYZZ<FID>& p, uint32_t q) {
-  return q == 0 ? p.x : q == 1 ? p.y : q == 2 ? p.zz : p.zzz;
+  Fp<FID> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = q == 0 ? p.x.l[i] : q == 1 ? p.y.l[i] : q == 2 ? p.zz.l[i] : p.zzz.l[i];
+  return r;
 }
 
 // dbl-2008-s-1 (curve.hpp dbl_in_place), three steps.  c = this lane's coordinate; returns the new one.

@@ -232,15 +232,43 @@ template <int SFID> struct PartArgs {
 template <int C> struct WinMax {
   static constexpr uint32_t value = C ? (256 + C - 1) / C : 64;
 };
+// (hi:lo >> off)[31:0], off < 32
+NMX_HD uint32_t funnel_shr(uint32_t hi, uint32_t lo, uint32_t off) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_alignbit(hi, lo, off);
+#else
+  return off ? (lo >> off) | (hi << (32 - off)) : lo;
+#endif
+}
 // calls f(w, |d|, neg) for every window with a non-zero digit
 template <int SFID, int C, class Fn> NMX_HD void for_each_digit(const DigitSrc<SFID>& src, const uint32_t (&s)[9], Fn&& f) {
   const MsmShape& sh = src.sh;
   uint32_t carry = 0;
   if constexpr (C == 0) {
-    for (uint32_t w = 0; w < sh.W; w++) {
-      uint32_t d, neg;
-      src.digit(s, w, carry, d, neg);
-      if (d) f(w, d, neg);
+    // run-time width: walk the WORDS (constant indices: the scalar stays in registers) and peel windows off a 64-bit bit
+    // buffer.  Indexing s[] by a run-time word number -- src.digit -- kept the array in memory: 36 KB of LDS per block in
+    // k_hist_hi, scratch in k_part_hi, two dependent reads per digit.  c <= 20, so the buffer never holds more than 51 bits.
+    const uint32_t c = sh.c, mask = (1u << c) - 1u, half = sh.M;
+    uint64_t acc = 0;
+    uint32_t have = 0, w = 0;
+#pragma unroll
+    for (int j = 0; j < 9; j++) {  // s[8] = 0: the padding the top window reads
+      acc |= (uint64_t)s[j] << have;
+      have += 32;
+      while (have >= c && w < sh.W) {
+        uint32_t d = ((uint32_t)acc & mask) + carry, neg = 0;
+        acc >>= c;
+        have -= c;
+        if (d > half) {
+          d = (1u << c) - d;
+          neg = 1;
+          carry = 1;
+        } else {
+          carry = 0;
+        }
+        if (d) f(w, d, neg);
+        w++;
+      }
     }
   } else {
     constexpr uint32_t mask = (1u << C) - 1u, half = 1u << (C - 1);
@@ -248,8 +276,12 @@ template <int SFID, int C, class Fn> NMX_HD void for_each_digit(const DigitSrc<S
     for (uint32_t w = 0; w < WinMax<C>::value; w++) {
       if (w < sh.W) {
         const uint32_t bit = w * C, word = bit >> 5, off = bit & 31;  // constants after unrolling
-        const uint64_t two = ((uint64_t)s[word < 8 ? word + 1 : 8] << 32) | s[word < 8 ? word : 8];  // s[8] = 0
-        uint32_t d = (uint32_t)((two >> off) & mask) + carry;
+        // a 32-bit funnel shift (v_alignbit_b32), NOT a 64-bit value built from two words: the optimiser turns that into one
+        // 64-bit load of the ARRAY, and an array read that way is never scalarised -- it stayed in memory, promoted to LDS
+        // (36 KB per block in k_hist_hi) or spilled to scratch (k_part_hi), two dependent memory reads per digit (round 4,
+        // found in the kernels' ISA; same-box A/B at 2^20: k_hist_hi + k_tiles 53 -> 43 us, the scatter passes 138 -> 123 us,
+        // profiles/r04_msm_2p20/digit_ab.txt)
+        uint32_t d = (funnel_shr(s[word < 8 ? word + 1 : 8], s[word < 8 ? word : 8], off) & mask) + carry;  // s[8] = 0
         uint32_t neg = 0;
         if (d > half) {
           d = (1u << C) - d;
