@@ -251,6 +251,14 @@ int nmx_msm_batch(int curve, const void* const* scalar_vecs, const size_t* lens,
                   const void* bases_xy64, size_t n_bases, uint32_t flags, uint8_t* out, uint8_t* out_is_inf);
 int nmx_msm_batch_handle(uint64_t handle, const void* const* scalar_vecs, const size_t* lens, size_t k,
                          uint32_t flags, uint8_t* out, uint8_t* out_is_inf);
+/* DlogGroupExt::batch_vartime_multiscalar_mul_small (src/provider/traits.rs:109-117; CommitmentEngineTrait::batch_commit_small,
+ * src/traits/commitment.rs:139-150): k vectors of u64 scalars over prefixes of one base array, the j-th using
+ * bases[..lens[j]]; max_num_bits as nmx_msm_u64 (NMX_BITS_AUTO: per vector, from the data; 0: every result is the identity,
+ * msm.rs:489).  Vector by vector over the resident key, several in flight. */
+int nmx_msm_u64_batch(int curve, const uint64_t* const* scalar_vecs, const size_t* lens, size_t k, const void* bases_xy64,
+                      size_t n_bases, uint32_t max_num_bits, uint32_t flags, uint8_t* out_xy64, uint8_t* out_is_inf);
+int nmx_msm_u64_batch_handle(uint64_t handle, const uint64_t* const* scalar_vecs, const size_t* lens, size_t k,
+                             uint32_t max_num_bits, uint32_t flags, uint8_t* out_xy64, uint8_t* out_is_inf);
 
 /* CommitmentEngineTrait::commit (src/traits/commitment.rs:52-195; Pedersen src/provider/pedersen.rs:263-270,
  * HyperKZG src/provider/hyperkzg.rs:584-591):  out = msm(v, ck[..n]) + h * r.  `h_xy64` / `r` follow the same

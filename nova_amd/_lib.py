@@ -66,6 +66,8 @@ def lib():
     L.nmx_msm_sparse_handle.argtypes = [u64, vp, vp, sz, u32, vp, vp]
     L.nmx_msm_batch.argtypes = [i, vp, vp, sz, vp, sz, u32, vp, vp]
     L.nmx_msm_batch_handle.argtypes = [u64, vp, vp, sz, u32, vp, vp]
+    L.nmx_msm_u64_batch.argtypes = [i, vp, vp, sz, vp, sz, u32, u32, vp, vp]
+    L.nmx_msm_u64_batch_handle.argtypes = [u64, vp, vp, sz, u32, u32, vp, vp]
     L.nmx_commit.argtypes = [u64, vp, sz, vp, vp, u32, vp, vp]
     L.nmx_point_sum.argtypes = [i, vp, sz, vp, vp]
     L.nmx_svec_alloc.argtypes = [sz, sz, ctypes.POINTER(u64)]

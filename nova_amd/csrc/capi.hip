@@ -1433,8 +1433,11 @@ int nmx_msm_sparse_handle(uint64_t handle, const uint64_t* indices, const void* 
 // own context (stream + workspace): independent runs overlap on the GPU -- the latency-bound fold / reduction passes
 // of one under the accumulate kernel of another.
 static constexpr size_t kBatchLanes = 4;
+// small_bits: 0 = field scalars; otherwise every vector holds u64 scalars of at most that many bits (NMX_BITS_AUTO: per vector,
+// from the data) -- batch_vartime_multiscalar_mul_small, traits.rs:109-117: vector by vector over the resident key, on up to
+// kBatchLanes streams (the fused run carries field scalars only).
 static void batch_impl(const BaseSet& bs, size_t base_off, size_t n_bases, const void* const* vecs, const size_t* lens,
-                       size_t k, uint32_t flags, uint8_t* out, uint8_t* out_is_inf, Ctx& c) {
+                       size_t k, uint32_t flags, uint8_t* out, uint8_t* out_is_inf, Ctx& c, uint32_t small_bits = 0) {
   require((vecs && lens && out) || k == 0, NMX_E_ARG, "null argument");
   require(!(flags & NMX_OUT_PARTIAL), NMX_E_ARG, "NMX_OUT_PARTIAL is not supported for batches");
   const CurveOps& o = ops(bs.curve);
@@ -1442,11 +1445,17 @@ static void batch_impl(const BaseSet& bs, size_t base_off, size_t n_bases, const
     require(lens[j] <= n_bases, NMX_E_ARG, "vector longer than the base array");  // traits.rs:88 slices bases[..len]
     require(vecs[j] || lens[j] == 0, NMX_E_ARG, "null scalar vector");
   }
+  auto call_for = [&](Ctx& cx, size_t j) -> MsmCall {
+    if (!small_bits) return field_call(vecs[j], flags);
+    const bool dev = (flags & NMX_SCALARS_DEVICE) != 0;
+    const uint32_t bits = resolve_u64_bits(cx, (const uint64_t*)vecs[j], lens[j], dev, small_bits);
+    return MsmCall{vecs[j], dev, false, bits, true};
+  };
   if (!bs.parts.empty()) {  // multi-device key: every vector is a sharded MSM of its own, all devices busy with each
     std::vector<uint8_t> tmp(64 * (k ? k : 1)), tinf(k ? k : 1);
     for (size_t j = 0; j < k; j++) {
       stat_add(NMX_STAT_MSM_CALLS);
-      key_msm(c, bs, base_off, lens[j], field_call(vecs[j], flags), flags, tmp.data() + 64 * j, tinf.data() + j);
+      key_msm(c, bs, base_off, lens[j], call_for(c, j), flags, tmp.data() + 64 * j, tinf.data() + j);
     }
     memcpy(out, tmp.data(), 64 * k);
     if (out_is_inf) memcpy(out_is_inf, tinf.data(), k);
@@ -1463,7 +1472,7 @@ static void batch_impl(const BaseSet& bs, size_t base_off, size_t n_bases, const
   };
   std::vector<Job> jobs;
   {
-    const size_t limit = k >= 2 ? o.batch_limit(bs) : 0;
+    const size_t limit = (k >= 2 && !small_bits) ? o.batch_limit(bs) : 0;
     size_t hi = k;
     while (hi > 0) {
       size_t lo = hi - 1;
@@ -1510,7 +1519,7 @@ static void batch_impl(const BaseSet& bs, size_t base_off, size_t n_bases, const
         }
         const size_t j = order[job.first];
         stat_add(NMX_STAT_MSM_CALLS);
-        o.msm_key(*ctx, bs, base_off, lens[j], field_call(vecs[j], flags), flags, tmp.data() + 64 * j, tinf.data() + j);
+        o.msm_key(*ctx, bs, base_off, lens[j], call_for(*ctx, j), flags, tmp.data() + 64 * j, tinf.data() + j);
       }
     } catch (const Fail& f) {
       record(f);
@@ -1561,6 +1570,51 @@ int nmx_msm_batch(int curve, const void* const* scalar_vecs, const size_t* lens,
     with_slice(*L.c, o, curve, bases, n_bases, flags,
                [&](const SliceKey& key) {
                  batch_impl(*key.bs, key.offset, n_bases, scalar_vecs, lens, k, flags, res.data(), rinf.data(), *L.c);
+               },
+               [&] {
+                 memcpy(out, res.data(), 64 * k);
+                 if (out_is_inf) memcpy(out_is_inf, rinf.data(), k);
+               });
+  });
+}
+
+int nmx_msm_u64_batch_handle(uint64_t handle, const uint64_t* const* scalar_vecs, const size_t* lens, size_t k, uint32_t max_num_bits,
+                             uint32_t flags, uint8_t* out, uint8_t* out_is_inf) {
+  return guarded([&] {
+    require(max_num_bits == NMX_BITS_AUTO || max_num_bits <= 64, NMX_E_ARG, "max_num_bits must be <= 64");
+    require(!(flags & NMX_SCALARS_SHARDED), NMX_E_ARG, "batches of small scalars take plain pointers");
+    auto bs = lookup(handle);
+    CtxLease L;
+    if (max_num_bits == 0) {  // msm.rs:489: every result is the identity
+      require((out && lens) || k == 0, NMX_E_ARG, "null argument");
+      for (size_t j = 0; j < k; j++) require(lens[j] <= bs->n, NMX_E_ARG, "vector longer than the base array");
+      memset(out, 0, 64 * k);
+      if (out_is_inf) memset(out_is_inf, 1, k);
+      return;
+    }
+    batch_impl(*bs, 0, bs->n, (const void* const*)scalar_vecs, lens, k, flags, out, out_is_inf, *L.c, max_num_bits);
+  });
+}
+
+int nmx_msm_u64_batch(int curve, const uint64_t* const* scalar_vecs, const size_t* lens, size_t k, const void* bases, size_t n_bases,
+                      uint32_t max_num_bits, uint32_t flags, uint8_t* out, uint8_t* out_is_inf) {
+  return guarded([&] {
+    require(bases || n_bases == 0, NMX_E_ARG, "null argument");
+    require(max_num_bits == NMX_BITS_AUTO || max_num_bits <= 64, NMX_E_ARG, "max_num_bits must be <= 64");
+    require((out && lens) || k == 0, NMX_E_ARG, "null argument");
+    const CurveOps& o = ops(curve);
+    CtxLease L;
+    if (n_bases == 0 || max_num_bits == 0) {
+      for (size_t j = 0; j < k; j++) require(lens[j] <= n_bases, NMX_E_ARG, "vector longer than the base array");
+      if (k) memset(out, 0, 64 * k);
+      if (out_is_inf) memset(out_is_inf, 1, k);
+      return;
+    }
+    std::vector<uint8_t> res(64 * (k ? k : 1)), rinf(k ? k : 1);
+    with_slice(*L.c, o, curve, bases, n_bases, flags,
+               [&](const SliceKey& key) {
+                 batch_impl(*key.bs, key.offset, n_bases, (const void* const*)scalar_vecs, lens, k, flags, res.data(), rinf.data(), *L.c,
+                            max_num_bits);
                },
                [&] {
                  memcpy(out, res.data(), 64 * k);

@@ -560,7 +560,9 @@ __global__ __launch_bounds__(256) void k_eval_multi(const EvalPoly* polys, uint3
     for (uint32_t j = 0; j < kEvalMaxPts; j++)
       if (j < m) h[j] = (h[j] * ldw<FID>(pw16, (size_t)j * 256 + threadIdx.x)).canon();
   }
-  for (uint32_t j = 0; j < m; j++) {
+#pragma unroll  // (constant indices: h[] stays in registers -- as a rolled loop over j < m it lived in 160 B of scratch)
+  for (uint32_t j = 0; j < kEvalMaxPts; j++) {
+    if (j >= m) break;  // block-uniform
     F sum = block_sum<FID>(h[j], lds);
     if (threadIdx.x == 0) {
       // times u^(4096 * lb): product over the set bits of lb

@@ -318,6 +318,24 @@ class DlogGroup:
                                          flags | (L.BASES_MONT if mont else 0), *out.p))
         return [out.get(j) for j in range(k)]
 
+    # -- batch_vartime_multiscalar_mul_small (traits.rs:109-117) --------------------------------------------
+    def batch_vartime_multiscalar_mul_small(self, scalar_vecs, bases, max_num_bits=None):
+        k = len(scalar_vecs)
+        args = [_scalar_arg(v, 8) for v in scalar_vecs]
+        dev = {a[2] for a in args}
+        assert len(dev) <= 1, "all vectors must live on the same side"
+        flags = dev.pop() if dev else 0
+        bits = L.BITS_AUTO if max_num_bits is None else int(max_num_bits)
+        ptrs = (ctypes.c_void_p * max(k, 1))(*[a[0] for a in args])
+        lens = (ctypes.c_size_t * max(k, 1))(*[a[1] for a in args])
+        out = _Out(k)
+        if isinstance(bases, CommitmentKey):
+            _check(L.lib().nmx_msm_u64_batch_handle(bases.handle, ptrs, lens, k, bits, flags, *out.p))
+        else:
+            b = _host_u8(bases, 64)
+            _check(L.lib().nmx_msm_u64_batch(self.curve, ptrs, lens, k, b.ctypes.data, b.size // 64, bits, flags, *out.p))
+        return [out.get(j) for j in range(k)]
+
     # -- vartime_multiscalar_mul_small* (traits.rs:93-106; msm.rs:469-503) ---------------------------------
     def vartime_multiscalar_mul_small(self, scalars, bases, partial=False):
         return self.vartime_multiscalar_mul_small_with_max_num_bits(scalars, bases, None, partial)
@@ -419,6 +437,8 @@ class CommitmentEngine:
         """commitment.rs:139-150 / hyperkzg.rs:626-645: commit_small per vector."""
         rs = [None] * len(vs) if rs is None else rs
         assert len(vs) == len(rs)
+        if all(r is None for r in rs):   # no blinding terms: one batch call (nmx_msm_u64_batch_handle)
+            return self.group.batch_vartime_multiscalar_mul_small(vs, ck)
         return [self.commit_small(ck, v, r, mont) for v, r in zip(vs, rs)]
 
     def commit_small(self, ck, v_u64, r=None, mont=False):

@@ -115,6 +115,33 @@ def test_msm_small(nmx, bits):
             assert as_pair(g.vartime_multiscalar_mul(util.u64_to_le32(s), bases)) == exp
 
 
+def test_batch_msm_small(nmx):
+    """DlogGroupExt::batch_vartime_multiscalar_mul_small (src/provider/traits.rs:109-117; batch_commit_small,
+    src/traits/commitment.rs:139-150): ragged vectors of u64 scalars over prefixes of one base array -- slice form and
+    registered key, explicit and automatic bit widths, an empty vector, the max_num_bits = 0 rule (msm.rs:489), a value beyond
+    the declared width in one vector (the whole call fails)."""
+    from nova_amd import _lib
+    for c in (R.BN254_G1, R.VESTA):
+        g, ce = nmx.DlogGroup(c.cid), nmx.CommitmentEngine(c.cid)
+        n = 5000
+        bases = cref.sequential_bases(c, 77, n)
+        ck = nmx.CommitmentKey.from_host(c.cid, bases)
+        for bits in (None, 1, 10, 33, 64):
+            lens = [n, 2500, 17, 1, 0, 4097]
+            vs = [util.small_scalars(m, bits or 23, seed=m + 3) if m else np.zeros(0, np.uint64) for m in lens]
+            exp = [cref.msm_u64(c.cid, v, bases[:len(v)], len(v), bits or 23) if len(v) else (bytes(64), 1) for v in vs]
+            assert [as_pair(x) for x in g.batch_vartime_multiscalar_mul_small(vs, ck, bits)] == exp
+            assert [as_pair(x) for x in g.batch_vartime_multiscalar_mul_small(vs, bases, bits)] == exp
+        assert [as_pair(x) for x in ce.batch_commit_small(ck, vs)] == exp
+        assert [as_pair(x) for x in g.batch_vartime_multiscalar_mul_small(vs, ck, 0)] == [(bytes(64), 1)] * len(vs)
+        bad = [v.copy() for v in vs]
+        bad[1][7] = 1 << 12
+        with pytest.raises(nmx.NmxError) as e:
+            g.batch_vartime_multiscalar_mul_small(bad, ck, 10)
+        assert e.value.code == _lib.E_SMALL_RANGE
+        ck.close()
+
+
 def test_error_paths(nmx):
     from nova_amd import _lib
     c = R.BN254_G1
