@@ -71,8 +71,12 @@ def pmc_valu(args, world):
     if not (world == 1 and args.curve == 0 and args.log2n == 20 and args.dist == "random" and not args.window_bits):
         return None
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r03_msm_2p20", "pmc_traffic.json")))["accum"]
-        return d["SQ_INSTS_VALU"], d.get("effective_clock_GHz")
+        for rnd in ("r04_msm_2p20", "r03_msm_2p20"):
+            path = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
+            if os.path.exists(path):
+                d = json.load(open(path))["accum"]
+                return d["SQ_INSTS_VALU"], d.get("effective_clock_GHz")
+        return None
     except (OSError, KeyError, ValueError):
         return None
 
@@ -82,7 +86,7 @@ def pmc_traffic(args, world):
     collected on (BN254, 2^20, random scalars, one GPU); everything else reports null."""
     if not (world == 1 and args.curve == 0 and args.log2n == 20 and args.dist == "random" and not args.window_bits):
         return None
-    for rnd in ("r03_msm_2p20", "r02_msm_2p20", "r01_msm_2p20"):
+    for rnd in ("r04_msm_2p20", "r03_msm_2p20", "r02_msm_2p20", "r01_msm_2p20"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")))["accum"]
             return d["hbm_read_bytes_corrected"] + d["hbm_write_bytes"]
@@ -304,7 +308,7 @@ def main():
                 "achieved_T_lane_ops_per_s": ach,
                 "peak_T_lane_ops_per_s": VALU_PEAK_T,
                 "frac": ach / VALU_PEAK_T,
-                "source": "profiles/r03_msm_2p20/pmc_traffic.json (rocprofv3 --pmc SQ_INSTS_VALU, separate pass) / accum-kernel time of this run",
+                "source": "profiles/r04_msm_2p20/pmc_traffic.json (rocprofv3 --pmc SQ_INSTS_VALU, separate pass) / accum-kernel time of this run",
             }
             if gui:   # GRBM_GUI_ACTIVE / 8 XCDs / the kernel's duration in the same counter pass
                 out["roofline"]["valu_issue"]["effective_clock_GHz_profiled_pass"] = round(gui, 2)
@@ -613,7 +617,7 @@ def fieldvec_block(args, torch, L):
     entry("lincomb8", N22, 288, ms, as_bytes(o, m) == cref.lincomb_powers(fid, [v[:m].cpu().numpy().tobytes() for v in vecs], r, m))
     ms, o = kernel_ms(lambda: fv.suffix_horner(fid, A[:N22], r))
     entry("horner", N22, 64, ms, as_bytes(o) == cref.suffix_horner(fid, hA[:N22], N22, r),
-          "single-pass scan with decoupled look-back: bound by the dependent memory round trips per tile, not by HBM or VALU (profiles/r03_fieldvec/horner_scan.txt)")
+          "single-pass scan with decoupled look-back: 670 VALU instructions per coefficient (valu_floor_ms) and 40 % of wave cycles waiting on its look-back round trips (profiles/r03_fieldvec/horner_scan.txt, profiles/r04_fieldvec/horner_22_pmc.json)")
     rng = np.random.Generator(np.random.PCG64(5))
     indptr = np.arange(0, 3 * N22 + 1, 3, dtype=np.uint64)
     indices = rng.integers(0, N22, size=3 * N22).astype(np.uint64)

@@ -297,12 +297,14 @@ static void upload_bases(Ctx& c, BaseSet& bs, const void* src, uint32_t flags, c
   // keys up to 2^28 points, README.md:130-138 -- 13 table copies of those are ~208 GiB): over the configured limit, or
   // hipMalloc out of memory -> the key alone, and MSMs over it take the plain path (W bucket sets, no tables).
   apply_table_limit(n, pre_c, pre_W);
-  hipError_t me = hipMalloc(&d, n * 64 * (*pre_W ? *pre_W : 1));
+  size_t alloc = n * 64 * (*pre_W ? *pre_W : 1);
+  hipError_t me = hipMalloc(&d, alloc);
   if (me == hipErrorOutOfMemory && *pre_W) {
     (void)hipGetLastError();
     *pre_c = *pre_W = 0;
     note_table_fallback();
-    me = hipMalloc(&d, n * 64);
+    alloc = n * 64;
+    me = hipMalloc(&d, alloc);
   }
   if (me != hipSuccess) {
     (void)hipGetLastError();
@@ -345,6 +347,7 @@ static void upload_bases(Ctx& c, BaseSet& bs, const void* src, uint32_t flags, c
     throw;
   }
   bs.d = d;
+  bs.alloc_bytes = alloc;  // what the cache budget must count: the table area stays allocated when build_tables fell back
 }
 
 // MSM over bs[offset, offset + n): through the key's window tables when it has them and n is large enough

@@ -100,8 +100,9 @@ struct BaseSet {
   BaseSet(int curve_, size_t n_) : curve(curve_), n(n_) {}
   BaseSet(const BaseSet&) = delete;
   BaseSet& operator=(const BaseSet&) = delete;
+  size_t alloc_bytes = 0;  // bytes behind `d` (0: derive from pre_W -- wrapped one-shot uploads)
   size_t bytes() const {
-    size_t b = d ? n * 64 * (pre_W ? pre_W : 1) : 0;
+    size_t b = d ? (alloc_bytes ? alloc_bytes : n * 64 * (pre_W ? pre_W : 1)) : 0;
     for (const auto& p : parts) b += p->bytes();
     return b;
   }

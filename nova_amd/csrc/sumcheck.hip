@@ -102,18 +102,27 @@ template <int FID, int J, int STRIDE> __global__ __launch_bounds__(256) void k_s
   F s[J];
 #pragma unroll
   for (int j = 0; j < J; j++) s[j] = F::zero();
-  uint32_t pending = 0;
-  for (uint32_t i = threadIdx.x; i < nparts; i += 256) {
+  // This launch is pure latency behind the pass (14-21 us for 2048 partials under rocprofv3, round 4): its loads were issued
+  // one iteration at a time, each a full memory round trip.  Now a thread's up to eight partials are all in flight before the
+  // first is used (canonical values: eight lazily added terms stay below canon()'s 16 p).
+  constexpr uint32_t kBatch = 8;
+  for (uint32_t i0 = threadIdx.x; i0 < nparts; i0 += 256 * kBatch) {
+    uint32_t w[kBatch][J][8];
 #pragma unroll
-    for (int j = 0; j < J; j++) s[j] = (s[j] + ldw<FID>(partial, STRIDE * (size_t)i + j)).norm();
-    if (++pending == 8) {
+    for (uint32_t b = 0; b < kBatch; b++) {
+      const uint32_t i = i0 + 256 * b;
 #pragma unroll
-      for (int j = 0; j < J; j++) s[j] = s[j].canon();
-      pending = 0;
+      for (int j = 0; j < J; j++)
+#pragma unroll
+        for (int q = 0; q < 8; q++) w[b][j][q] = i < nparts ? partial[8 * (STRIDE * (size_t)i + j) + q] : 0u;
     }
-  }
 #pragma unroll
-  for (int j = 0; j < J; j++) s[j] = s[j].canon();
+    for (uint32_t b = 0; b < kBatch; b++)
+#pragma unroll
+      for (int j = 0; j < J; j++) s[j] = (s[j] + F::from_words(w[b][j])).norm();
+#pragma unroll
+    for (int j = 0; j < J; j++) s[j] = s[j].canon();
+  }
   block_sum_waves<FID, J>(s, lds);
   if (threadIdx.x == 0) {
 #pragma unroll
