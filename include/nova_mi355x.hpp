@@ -153,6 +153,24 @@ template <int CURVE> struct DlogGroupExt {
     p.is_inf = inf != 0;
     return p;
   }
+  // traits.rs:109-117: batch_vartime_multiscalar_mul_small -- the j-th vector uses bases[..len_j]
+  static std::vector<Point> batch_vartime_multiscalar_mul_small(const std::vector<std::vector<uint64_t>>& scalars,
+                                                                const CommitmentKey& ck, uint32_t max_num_bits = NMX_BITS_AUTO) {
+    std::vector<const uint64_t*> ptrs;
+    std::vector<size_t> lens;
+    for (auto& v : scalars) {
+      ptrs.push_back(v.data());
+      lens.push_back(v.size());
+    }
+    std::vector<uint8_t> out(64 * scalars.size() + 1), inf(scalars.size() + 1);
+    check(nmx_msm_u64_batch_handle(ck.handle(), ptrs.data(), lens.data(), scalars.size(), max_num_bits, 0u, out.data(), inf.data()));
+    std::vector<Point> r(scalars.size());
+    for (size_t j = 0; j < scalars.size(); j++) {
+      std::copy(out.begin() + 64 * j, out.begin() + 64 * j + 64, r[j].xy.begin());
+      r[j].is_inf = inf[j] != 0;
+    }
+    return r;
+  }
 };
 
 // `CommitmentEngineTrait` restricted to the hot path.

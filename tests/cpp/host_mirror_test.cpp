@@ -73,6 +73,33 @@ template <int CURVE> static int run(const uint8_t gen[64], int topmask) {
     exp.is_inf = inf;
     if (!(res[j] == exp)) return 1;
   }
+  // batch of small scalars (traits.rs:109-117): every vector equals the field-scalar MSM of the widened values
+  {
+    std::vector<std::vector<uint64_t>> us;
+    std::vector<std::vector<Scalar>> wide;
+    for (size_t L : {0ul, 5ul, 64ul, 100ul}) {
+      std::vector<uint64_t> u(L);
+      std::vector<Scalar> w(L);
+      for (size_t i = 0; i < L; i++) {
+        u[i] = rng() & 0xFFFFFFFFFFull;  // 40 bits
+        w[i].fill(0);
+        memcpy(w[i].data(), &u[i], 8);
+      }
+      us.push_back(u);
+      wide.push_back(w);
+    }
+    auto small = DlogGroupExt<CURVE>::batch_vartime_multiscalar_mul_small(us, ck, 40);
+    auto small_auto = DlogGroupExt<CURVE>::batch_vartime_multiscalar_mul_small(us, ck);
+    for (size_t j = 0; j < us.size(); j++) {
+      if (wide[j].empty()) {
+        if (!small[j].is_inf || !small_auto[j].is_inf) return 1;
+        continue;
+      }
+      ref_msm(CURVE, wide[j][0].data(), bases[0].data(), wide[j].size(), exp.xy.data(), &inf);
+      exp.is_inf = inf;
+      if (!(small[j] == exp) || !(small_auto[j] == exp)) return 1;
+    }
+  }
   // load_setup from a PEDERSEN_KEY file written by the harness: h = bases[n], ck = the same sequence (pedersen.rs:318-340)
   if (const char* dir = getenv("NMX_TEST_KEYDIR")) {
     CommitmentKey fk = CommitmentKey::load_keyfile(CURVE, std::string(dir) + "/curve" + std::to_string(CURVE) + ".key", n);
