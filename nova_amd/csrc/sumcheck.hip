@@ -102,27 +102,21 @@ template <int FID, int J, int STRIDE> __global__ __launch_bounds__(256) void k_s
   F s[J];
 #pragma unroll
   for (int j = 0; j < J; j++) s[j] = F::zero();
-  // This launch is pure latency behind the pass (14-21 us for 2048 partials under rocprofv3, round 4): its loads were issued
-  // one iteration at a time, each a full memory round trip.  Now a thread's up to eight partials are all in flight before the
-  // first is used (canonical values: eight lazily added terms stay below canon()'s 16 p).
-  constexpr uint32_t kBatch = 8;
-  for (uint32_t i0 = threadIdx.x; i0 < nparts; i0 += 256 * kBatch) {
-    uint32_t w[kBatch][J][8];
+  // This launch is pure latency behind the pass (7-21 us for 512-2048 partials under rocprofv3).  Issuing all of a thread's
+  // loads before the first use (eight 16-byte pairs in flight, 208 registers) was measured against this loop on one box and is no
+  // faster (mle_eval 2^20 29.1 against 28.2 us, sumcheck3 2^24 0.414-0.431 against 0.413-0.436 ms): the loop stays.
+  uint32_t pending = 0;
+  for (uint32_t i = threadIdx.x; i < nparts; i += 256) {
 #pragma unroll
-    for (uint32_t b = 0; b < kBatch; b++) {
-      const uint32_t i = i0 + 256 * b;
+    for (int j = 0; j < J; j++) s[j] = (s[j] + ldw<FID>(partial, STRIDE * (size_t)i + j)).norm();
+    if (++pending == 8) {
 #pragma unroll
-      for (int j = 0; j < J; j++)
-#pragma unroll
-        for (int q = 0; q < 8; q++) w[b][j][q] = i < nparts ? partial[8 * (STRIDE * (size_t)i + j) + q] : 0u;
+      for (int j = 0; j < J; j++) s[j] = s[j].canon();
+      pending = 0;
     }
-#pragma unroll
-    for (uint32_t b = 0; b < kBatch; b++)
-#pragma unroll
-      for (int j = 0; j < J; j++) s[j] = (s[j] + F::from_words(w[b][j])).norm();
-#pragma unroll
-    for (int j = 0; j < J; j++) s[j] = s[j].canon();
   }
+#pragma unroll
+  for (int j = 0; j < J; j++) s[j] = s[j].canon();
   block_sum_waves<FID, J>(s, lds);
   if (threadIdx.x == 0) {
 #pragma unroll
