@@ -246,7 +246,9 @@ int nmx_msm_sparse_handle(uint64_t handle, const uint64_t* indices, const void* 
  * src/provider/blitzar.rs:22-40): k MSMs over one base array, the j-th using bases[..lens[j]]
  * (HyperKZG batch_commit, src/provider/hyperkzg.rs:593-612).  out = k x 64 bytes, out_is_inf = k bytes.
  * The shortest vectors of a batch (up to 32 on a 2^14 .. 2^19-point key, 16 at 2^20 .. 2^21, 256 below 2^14) run as ONE fused pass over the
- * key's window tables with a bucket set per vector; the others run as independent MSMs on concurrent streams. */
+ * key's window tables with a bucket set per vector; the others run as independent MSMs on concurrent streams.  Keys of >= 2^22
+ * points (2^19 buckets per set: nothing beyond pairs fuses) carry a second, narrow table set over their first 2^18 points: the
+ * vectors -- and single MSMs / commitments -- that stay inside it run there (option "prefix_tables" = 0: off). */
 int nmx_msm_batch(int curve, const void* const* scalar_vecs, const size_t* lens, size_t k,
                   const void* bases_xy64, size_t n_bases, uint32_t flags, uint8_t* out, uint8_t* out_is_inf);
 int nmx_msm_batch_handle(uint64_t handle, const void* const* scalar_vecs, const size_t* lens, size_t k,

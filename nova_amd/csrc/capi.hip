@@ -149,7 +149,9 @@ static void ensure_init() {
   if (const char* t = getenv("NMX_TUNE_SEG_MIN_LEN")) G.seg_min_len = (uint32_t)atoi(t) ? (uint32_t)atoi(t) : 1u;
   if (const char* t = getenv("NMX_TUNE_SEG_LANES")) G.seg_lanes_override = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_NO_QUAD_FINAL")) G.no_quad_final = (uint32_t)atoi(t);
+  if (const char* t = getenv("NMX_TUNE_QUAD_FINAL_BELOW")) G.quad_final_below = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_NO_BATCH_FUSE")) G.no_batch_fuse = (uint32_t)atoi(t);
+  if (const char* t = getenv("NMX_TUNE_PREFIX_TABLES")) G.prefix_tables = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_NO_TREE_FUSE")) G.no_tree_fuse = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_TREE_THREADS")) G.tree_threads = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_BIG_SLICE")) G.big_slice = (uint32_t)atoi(t);
@@ -362,6 +364,32 @@ template <class Fn> static void run_on_parts(size_t count, bool parallel, Fn&& f
   (void)hipSetDevice(G.device);
   if (failed) throw first;
 }
+// The narrow second table set of a wide-table key (BaseSet::prefix).  `key` is a complete single-device key (a whole key, or
+// shard 0 of a sharded one: the prefix of the whole key lives there).  Out of memory: the key simply has no prefix.
+static constexpr size_t kPrefixPoints = (size_t)1 << 18;
+static void add_prefix_tables(BaseSet& key) {
+  if (!G.prefix_tables.load(std::memory_order_relaxed) || key.prefix || !key.d || key.pre_c < 18 || key.n < 2 * kPrefixPoints) return;
+  const CurveOps& o = ops(key.curve);
+  auto pre = std::make_shared<BaseSet>(key.curve, kPrefixPoints);
+  pre->dev = key.dev;
+  try {
+    CtxLease L(key.dev);
+    o.upload(*L.c, *pre, key.d, NMX_BASES_DEVICE | NMX_BASES_INTERNAL | NMX_BASES_PRECOMPUTE, nullptr);
+  } catch (const Fail& f) {
+    (void)hipSetDevice(G.device);
+    if (f.code == NMX_E_HIP && f.msg.find("out of memory") != std::string::npos) {
+      stat_add(NMX_STAT_TABLE_FALLBACKS);
+      return;
+    }
+    throw;
+  }
+  (void)hipSetDevice(G.device);
+  if (pre->pre_W) key.prefix = pre;  // (a prefix that fell back to no tables is of no use)
+}
+// the key object an MSM over key[offset, offset + n) of a single-device key should run on
+static inline const BaseSet& prefix_or_key(const BaseSet& key, size_t offset, size_t n) {
+  return (key.prefix && n && offset + n <= key.prefix->n) ? *key.prefix : key;
+}
 // A key of n points: whole on the primary device (mk runs on `c0`), or -- allow_shard, more than one active device, at
 // least shard_min_n points -- sharded.  mk(ctx, part, begin) fills `part` (part.n points starting at point `begin` of the
 // key) on ctx's device: an upload, a file read, a generator.
@@ -371,6 +399,7 @@ static std::shared_ptr<BaseSet> build_key(Ctx& c0, int curve, size_t n, bool all
   auto bs = std::make_shared<BaseSet>(curve, n);
   if (k <= 1 || n < G.shard_min_n.load(std::memory_order_relaxed) || n < k) {
     mk(c0, *bs, (size_t)0);
+    add_prefix_tables(*bs);
     return bs;
   }
   bs->parts.resize(k);
@@ -386,6 +415,7 @@ static std::shared_ptr<BaseSet> build_key(Ctx& c0, int curve, size_t n, bool all
     CtxLease L((int)i);
     mk(*L.c, *bs->parts[i], bs->part_begin[i]);
   });
+  add_prefix_tables(*bs->parts[0]);
   return bs;
 }
 // the pieces of key[offset, offset + n) by shard: (part, offset inside the part, count, offset inside the call)
@@ -496,10 +526,10 @@ static void key_msm(Ctx& c0, const BaseSet& bs, size_t offset, size_t n, const M
       m.scalars_device = true;
       m.scalars_sharded = false;
       if (n) check_shard_piece(m.scalars, n * (mc.u64_mode ? 8 : 32), bs.dev);
-      o.msm_key(c0, bs, offset, n, m, flags, out, inf);
+      o.msm_key(c0, prefix_or_key(bs, offset, n), offset, n, m, flags, out, inf);
       return;
     }
-    o.msm_key(c0, bs, offset, n, mc, flags, out, inf);
+    o.msm_key(c0, mc.gather_host ? bs : prefix_or_key(bs, offset, n), offset, n, mc, flags, out, inf);
     return;
   }
   require(!mc.gather_host, NMX_E_ARG, "internal: sparse calls over a sharded key go through key_msm_sparse");
@@ -537,7 +567,7 @@ static void key_msm(Ctx& c0, const BaseSet& bs, size_t offset, size_t n, const M
         recs[i].branch = mc.scalars_device ? NMX_BRANCH_LOCAL : NMX_BRANCH_HOST;
       }
     }
-    o.msm_key(*L.c, *j.part, j.poff, j.cnt, m, (flags & ~(uint32_t)NMX_OUT_PARTIAL) | NMX_OUT_PARTIAL,
+    o.msm_key(*L.c, prefix_or_key(*j.part, j.poff, j.cnt), j.poff, j.cnt, m, (flags & ~(uint32_t)NMX_OUT_PARTIAL) | NMX_OUT_PARTIAL,
               partials.data() + 128 * i, nullptr);
     if (G.profiling.load(std::memory_order_relaxed)) {  // this worker's stage times, handed to the calling thread below
       recs[i].nst = t_prof_n;
@@ -844,6 +874,7 @@ static std::shared_ptr<BaseSet> key_with_tables(const CurveOps& o, const BaseSet
     dst->dev = src.dev;
     o.upload(*L.c, *dst, src.d, NMX_BASES_DEVICE | NMX_BASES_INTERNAL | NMX_BASES_PRECOMPUTE, nullptr);
     (void)hipSetDevice(G.device);
+    add_prefix_tables(*dst);
     return dst;
   }
   dst->parts.resize(src.parts.size());
@@ -856,6 +887,7 @@ static std::shared_ptr<BaseSet> key_with_tables(const CurveOps& o, const BaseSet
     CtxLease L(src.parts[i]->dev);
     o.upload(*L.c, *dst->parts[i], src.parts[i]->d, NMX_BASES_DEVICE | NMX_BASES_INTERNAL | NMX_BASES_PRECOMPUTE, nullptr);
   });
+  add_prefix_tables(*dst->parts[0]);
   return dst;
 }
 // An entry that has proved long-lived gets its window tables (built from the resident copy: no host traffic).  A failure --
@@ -1437,13 +1469,55 @@ static constexpr size_t kBatchLanes = 4;
 // from the data) -- batch_vartime_multiscalar_mul_small, traits.rs:109-117: vector by vector over the resident key, on up to
 // kBatchLanes streams (the fused run carries field scalars only).
 static void batch_impl(const BaseSet& bs, size_t base_off, size_t n_bases, const void* const* vecs, const size_t* lens,
-                       size_t k, uint32_t flags, uint8_t* out, uint8_t* out_is_inf, Ctx& c, uint32_t small_bits = 0) {
+                       size_t k, uint32_t flags, uint8_t* out, uint8_t* out_is_inf, Ctx& c, uint32_t small_bits = 0,
+                       bool use_prefix = true) {
   require((vecs && lens && out) || k == 0, NMX_E_ARG, "null argument");
   require(!(flags & NMX_OUT_PARTIAL), NMX_E_ARG, "NMX_OUT_PARTIAL is not supported for batches");
   const CurveOps& o = ops(bs.curve);
   for (size_t j = 0; j < k; j++) {
     require(lens[j] <= n_bases, NMX_E_ARG, "vector longer than the base array");  // traits.rs:88 slices bases[..len]
     require(vecs[j] || lens[j] == 0, NMX_E_ARG, "null scalar vector");
+  }
+  // shard-resident scalars over a single-device key (or the prefix of shard 0): every vector has ONE piece, on the key's device
+  std::vector<const void*> unwrapped;
+  if ((flags & NMX_SCALARS_SHARDED) && bs.parts.empty() && !small_bits) {
+    unwrapped.resize(k ? k : 1);
+    for (size_t j = 0; j < k; j++) {
+      unwrapped[j] = lens[j] ? ((const void* const*)vecs[j])[0] : nullptr;
+      if (lens[j]) check_shard_piece(unwrapped[j], lens[j] * 32, bs.dev);
+    }
+    vecs = unwrapped.data();
+    flags = (flags & ~(uint32_t)NMX_SCALARS_SHARDED) | NMX_SCALARS_DEVICE;
+  }
+  // Vectors that stay inside the key's narrow prefix tables run there, fused (BaseSet::prefix): on a wide-table key nothing
+  // fuses (two bucket sets of 2^19 at most) and every short vector pays a 2^19-bucket reduction -- and over a sharded key every
+  // vector is a sharded MSM of its own.  The long vectors keep the path below (use_prefix = false on the same key).
+  if (use_prefix && !small_bits && k >= 1) {
+    const BaseSet* pre = bs.parts.empty() ? bs.prefix.get() : bs.parts[0]->prefix.get();
+    if (pre && base_off < pre->n) {
+      std::vector<size_t> in, rest;
+      for (size_t j = 0; j < k; j++) (base_off + lens[j] <= pre->n ? in : rest).push_back(j);
+      if (!in.empty()) {
+        auto sub = [&](const BaseSet& key, size_t nb, const std::vector<size_t>& idx, std::vector<uint8_t>& o_xy, std::vector<uint8_t>& o_inf) {
+          std::vector<const void*> v(idx.size());
+          std::vector<size_t> l(idx.size());
+          for (size_t q = 0; q < idx.size(); q++) v[q] = vecs[idx[q]], l[q] = lens[idx[q]];
+          o_xy.assign(64 * (idx.size() ? idx.size() : 1), 0);
+          o_inf.assign(idx.size() ? idx.size() : 1, 0);
+          if (!idx.empty()) batch_impl(key, base_off, nb, v.data(), l.data(), idx.size(), flags, o_xy.data(), o_inf.data(), c, 0, false);
+        };
+        std::vector<uint8_t> xa, ia, xb, ib;
+        sub(*pre, pre->n - base_off, in, xa, ia);
+        sub(bs, n_bases, rest, xb, ib);
+        for (size_t q = 0; q < in.size(); q++) memcpy(out + 64 * in[q], xa.data() + 64 * q, 64);
+        for (size_t q = 0; q < rest.size(); q++) memcpy(out + 64 * rest[q], xb.data() + 64 * q, 64);
+        if (out_is_inf) {
+          for (size_t q = 0; q < in.size(); q++) out_is_inf[in[q]] = ia[q];
+          for (size_t q = 0; q < rest.size(); q++) out_is_inf[rest[q]] = ib[q];
+        }
+        return;
+      }
+    }
   }
   auto call_for = [&](Ctx& cx, size_t j) -> MsmCall {
     if (!small_bits) return field_call(vecs[j], flags);
@@ -1636,7 +1710,7 @@ static void commit_impl(const BaseSet& bs, MsmCall mc, size_t n, const void* h_x
       mc.scalars_device = true;
       mc.scalars_sharded = false;
     }
-    o.commit(*L.c, bs, n, mc, h_xy64, r, flags, out, out_is_inf);
+    o.commit(*L.c, prefix_or_key(bs, 0, n), n, mc, h_xy64, r, flags, out, out_is_inf);
   } else {  // sharded key: the blinding term is one more partial, computed on the host under the device MSMs
     uint8_t two[256];
     std::array<uint8_t, 64> hb;
@@ -2208,8 +2282,10 @@ int nmx_set_option(const char* name, uint32_t value) {
     else if (n == "seg_lanes") G.seg_lanes_override = value;
     else if (n == "no_quad_accum") G.no_quad_accum = value;
     else if (n == "no_quad_final") G.no_quad_final = value;
+    else if (n == "quad_final_below") G.quad_final_below = value;
     else if (n == "accum_prefetch") G.accum_prefetch = value;
     else if (n == "no_batch_fuse") G.no_batch_fuse = value;
+    else if (n == "prefix_tables") G.prefix_tables = value ? 1u : 0u;
     else if (n == "no_tree_fuse") G.no_tree_fuse = value;
     else if (n == "tree_threads") G.tree_threads = value;
     else if (n == "big_slice") G.big_slice = value;

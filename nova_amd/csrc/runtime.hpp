@@ -101,9 +101,15 @@ struct BaseSet {
   BaseSet(const BaseSet&) = delete;
   BaseSet& operator=(const BaseSet&) = delete;
   size_t alloc_bytes = 0;  // bytes behind `d` (0: derive from pre_W -- wrapped one-shot uploads)
+  // Keys whose tables are wider than 17 bits (>= 2^22 points: c = 20, 2^19 buckets per set) also keep a SECOND, narrower table
+  // set over their first 2^18 points (round 4): an MSM or a batch that stays inside that prefix -- HyperKZG's batch_commit of
+  // n/2 ... 2 over a 2^22+ key, src/provider/hyperkzg.rs:593-612,1100 -- runs on it: 2^15 buckets to reduce instead of 2^19,
+  // and up to 32 vectors fused per run where the wide key takes none.  An ordinary key object of its own (same device).
+  std::shared_ptr<BaseSet> prefix;
   size_t bytes() const {
     size_t b = d ? (alloc_bytes ? alloc_bytes : n * 64 * (pre_W ? pre_W : 1)) : 0;
     for (const auto& p : parts) b += p->bytes();
+    if (prefix) b += prefix->bytes();
     return b;
   }
   ~BaseSet();  // capi.hip: hipFree(d) on its device
@@ -281,6 +287,7 @@ struct Global {
   std::atomic<uint32_t> seg_min_len{8};           // env NMX_TUNE_SEG_MIN_LEN
   std::atomic<uint32_t> seg_lanes_override{0};    // env NMX_TUNE_SEG_LANES (0: the kernel's resident lane count)
   std::atomic<uint32_t> no_quad_final{0};         // env NMX_TUNE_NO_QUAD_FINAL
+  std::atomic<uint32_t> quad_final_below{65536};  // env NMX_TUNE_QUAD_FINAL_BELOW / option quad_final_below: the final pass runs four lanes per bucket below this many buckets
   std::atomic<uint32_t> accum_prefetch{0};        // env NMX_TUNE_ACCUM_PF / option accum_prefetch: 0 = by table size, 1, 2
   std::atomic<uint32_t> horner_top{0};            // env NMX_TUNE_HORNER_TOP / option horner_top: suffix Horner from 1024 coefficients: 0 = single-pass scan (k_horner_scan); the two-pass kernels: 8 = 8-element chunks in registers, 4, 1 = chunk-per-lane recursion only
   std::atomic<uint32_t> eq_max_blocks{0};         // option eq_max_blocks: grid cap of the eq-factored sum passes (0 = 2048)
@@ -288,6 +295,7 @@ struct Global {
   std::atomic<uint32_t> horner_spin_limit{0};     // option horner_spin_limit: polls before a wave of the scan gives up (0 = 2^22; tests set 1 to force the fall-back)
   std::atomic<uint32_t> horner_window{64};        // option horner_window: tiles per look-back round of the single-pass scan (tests: 1 .. 63 force the multi-round path)
   std::atomic<uint32_t> seg_heavy_above{0};       // env NMX_TUNE_SEG_HEAVY_ABOVE / option seg_heavy_above: 0 = by pieces per bucket (8 or 12)
+  std::atomic<uint32_t> prefix_tables{1};         // env NMX_TUNE_PREFIX_TABLES / option prefix_tables: the narrow table set over the first 2^18 points of a wide-table key
   std::atomic<uint32_t> no_batch_fuse{0};         // env NMX_TUNE_NO_BATCH_FUSE / option no_batch_fuse: every vector of a batch runs alone
   std::atomic<uint32_t> big_threads{0};           // env NMX_TUNE_BIG_THREADS / option big_threads: block size of the big-bucket pass (128 default, 256, 512)
   std::atomic<uint32_t> big_slice{0};             // env NMX_TUNE_BIG_SLICE / option big_slice: pieces per block of the big-bucket pass (0 = default)
@@ -432,7 +440,7 @@ struct DeviceBackend {
   void launch_final_seg(const uint32_t* start, const uint32_t* end, const uint32_t* total_p, const XYZZL* bucket_raw,
                         const XYZZL* partial_raw, XYZZW* buckets, uint32_t nbuckets, uint32_t lanes, uint32_t min_seg,
                         uint32_t heavy_above) {
-    if (nbuckets < kQuadBelowItems && !G.no_quad_final) {
+    if (nbuckets < G.quad_final_below.load(std::memory_order_relaxed) && !G.no_quad_final) {
       FinalSegQuadFn<FID> f{start, end, total_p, bucket_raw, partial_raw, buckets, nbuckets, lanes, min_seg, heavy_above};
       launch(f, nbuckets * 4);
     } else {

@@ -376,3 +376,26 @@ def test_profile_of_a_sharded_call_reaches_the_caller(nmx, sharded):
     assert all(sum(s["stages_ms"]) > 0.01 for s in rec["shards"])
     assert ns >= 6 and abs(prof[3] - max(s["stages_ms"][3] for s in rec["shards"])) < 1e-3
     ck.close()
+
+
+def test_batch_over_a_sharded_wide_key_fuses_its_short_vectors(nmx, sharded):
+    """VERDICT r3 missing #5, second half: over a sharded key every vector of a batch was a sharded MSM of its own.  Shard 0 of a
+    key whose shards have wide tables carries the narrow prefix tables of the whole key (its first 2^18 points): the short
+    vectors of a batch run fused there, the long ones stay sharded.  2 logical devices, 2^23 + 1 points."""
+    from nova_amd import _lib
+    L = sharded(2)
+    c = R.BN254_G1
+    n = 1 << 23
+    ck = nmx.CommitmentKey.generate(c.cid, n, k0=7)
+    g = nmx.DlogGroup(c.cid)
+    m_long = (1 << 22) + 100                       # crosses the shard boundary
+    sc = util.random_scalars(c.cid, m_long, seed=8)
+    bases = ck.read(0, m_long)
+    lens = [m_long, 1 << 18, 5000, 17, 0]
+    f0, s0 = _lib.stats()[_lib.STAT_FUSED_RUNS], _lib.stats()[_lib.STAT_SHARDED_CALLS]
+    got = [pt(x) for x in g.batch_vartime_multiscalar_mul([sc[:m] for m in lens], ck)]
+    assert got == [cref.msm(c.cid, sc[:m], bases[:m], m) if m else (bytes(64), 1) for m in lens]
+    assert _lib.stats()[_lib.STAT_FUSED_RUNS] > f0                 # the three short vectors: one fused run on shard 0's prefix
+    assert _lib.stats()[_lib.STAT_SHARDED_CALLS] == s0 + 1         # only the long vector was a sharded MSM
+    assert pt(g.vartime_multiscalar_mul(sc[:5000], ck, offset=100)) == cref.msm(c.cid, sc[:5000], bases[100:5100], 5000)
+    ck.close()
