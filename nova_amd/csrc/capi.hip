@@ -364,13 +364,27 @@ template <class Fn> static void run_on_parts(size_t count, bool parallel, Fn&& f
   (void)hipSetDevice(G.device);
   if (failed) throw first;
 }
-// The narrow second table set of a wide-table key (BaseSet::prefix).  `key` is a complete single-device key (a whole key, or
-// shard 0 of a sharded one: the prefix of the whole key lives there).  Out of memory: the key simply has no prefix.
-static constexpr size_t kPrefixPoints = (size_t)1 << 18;
+// Narrower table sets over a key's first points (BaseSet::prefix, a chain).  `key` is a complete single-device key (a whole key,
+// or shard 0 of a sharded one: the prefix of the whole key lives there).  Levels: 2^18 points (c = 16), 2^16 (c = 15), 2^13
+// (c = 8); a level is added when it is at most half the key and at least two bits narrower than the key's own tables:
+//   >= 2^22 points (c = 20) -> 2^18 -> 2^13        2^20 .. 2^21 (c = 17) -> 2^16 -> 2^13        2^14 .. 2^19 (c = 15 / 16) -> 2^13
+// Single MSMs / commitments use the first level of a WIDE key only (2^15 buckets to reduce instead of 2^19); batches walk the
+// whole chain with option prefix_tables = 2: every vector runs, fused with its peers, on the narrowest level that holds it
+// (a fused run reduces sets x 2^(c-1) buckets: sixteen sets of a c = 17 key are 2^20 buckets for a handful of pairs).
+// Out of memory: the key simply has no (further) prefix.
 static void add_prefix_tables(BaseSet& key) {
-  if (!G.prefix_tables.load(std::memory_order_relaxed) || key.prefix || !key.d || key.pre_c < 18 || key.n < 2 * kPrefixPoints) return;
+  const uint32_t mode = G.prefix_tables.load(std::memory_order_relaxed);
+  if (!mode || key.prefix || !key.d || !key.pre_W) return;
+  static const struct { size_t n; uint32_t c; } kLevels[3] = {{(size_t)1 << 18, 16}, {(size_t)1 << 16, 15}, {(size_t)1 << 13, 8}};
+  size_t want = 0;
+  for (const auto& lv : kLevels)
+    if (2 * lv.n <= key.n && lv.c + 2 <= key.pre_c && (mode >= 2 || key.pre_c >= 18)) {
+      want = lv.n;
+      break;
+    }
+  if (!want) return;
   const CurveOps& o = ops(key.curve);
-  auto pre = std::make_shared<BaseSet>(key.curve, kPrefixPoints);
+  auto pre = std::make_shared<BaseSet>(key.curve, want);
   pre->dev = key.dev;
   try {
     CtxLease L(key.dev);
@@ -384,11 +398,13 @@ static void add_prefix_tables(BaseSet& key) {
     throw;
   }
   (void)hipSetDevice(G.device);
-  if (pre->pre_W) key.prefix = pre;  // (a prefix that fell back to no tables is of no use)
+  if (!pre->pre_W) return;  // (a prefix that fell back to no tables is of no use)
+  if (mode >= 2) add_prefix_tables(*pre);
+  key.prefix = pre;
 }
-// the key object an MSM over key[offset, offset + n) of a single-device key should run on
+// the key object an MSM over key[offset, offset + n) of a single-device key should run on: the first prefix level of a wide key
 static inline const BaseSet& prefix_or_key(const BaseSet& key, size_t offset, size_t n) {
-  return (key.prefix && n && offset + n <= key.prefix->n) ? *key.prefix : key;
+  return (key.prefix && key.pre_c >= 18 && n && offset + n <= key.prefix->n) ? *key.prefix : key;
 }
 // A key of n points: whole on the primary device (mk runs on `c0`), or -- allow_shard, more than one active device, at
 // least shard_min_n points -- sharded.  mk(ctx, part, begin) fills `part` (part.n points starting at point `begin` of the
@@ -1498,17 +1514,26 @@ static void batch_impl(const BaseSet& bs, size_t base_off, size_t n_bases, const
       std::vector<size_t> in, rest;
       for (size_t j = 0; j < k; j++) (base_off + lens[j] <= pre->n ? in : rest).push_back(j);
       if (!in.empty()) {
-        auto sub = [&](const BaseSet& key, size_t nb, const std::vector<size_t>& idx, std::vector<uint8_t>& o_xy, std::vector<uint8_t>& o_inf) {
+        auto sub = [&](Ctx& cx, const BaseSet& key, size_t nb, const std::vector<size_t>& idx, std::vector<uint8_t>& o_xy, std::vector<uint8_t>& o_inf) {
           std::vector<const void*> v(idx.size());
           std::vector<size_t> l(idx.size());
           for (size_t q = 0; q < idx.size(); q++) v[q] = vecs[idx[q]], l[q] = lens[idx[q]];
           o_xy.assign(64 * (idx.size() ? idx.size() : 1), 0);
           o_inf.assign(idx.size() ? idx.size() : 1, 0);
-          if (!idx.empty()) batch_impl(key, base_off, nb, v.data(), l.data(), idx.size(), flags, o_xy.data(), o_inf.data(), c, 0, false);
+          if (!idx.empty()) batch_impl(key, base_off, nb, v.data(), l.data(), idx.size(), flags, o_xy.data(), o_inf.data(), cx, 0, &key != &bs);
         };
         std::vector<uint8_t> xa, ia, xb, ib;
-        sub(*pre, pre->n - base_off, in, xa, ia);
-        sub(bs, n_bases, rest, xb, ib);
+        // the two halves are independent: the vectors of the prefix (which may descend further) on a helper thread with a context
+        // of its own, the long ones here
+        run_on_parts(rest.empty() ? 1 : 2, true, [&](size_t t) {
+          if (t == 0) {
+            if (rest.empty()) sub(c, *pre, pre->n - base_off, in, xa, ia);
+            else sub(c, bs, n_bases, rest, xb, ib);
+          } else {
+            CtxLease L2(pre->dev);
+            sub(*L2.c, *pre, pre->n - base_off, in, xa, ia);
+          }
+        });
         for (size_t q = 0; q < in.size(); q++) memcpy(out + 64 * in[q], xa.data() + 64 * q, 64);
         for (size_t q = 0; q < rest.size(); q++) memcpy(out + 64 * rest[q], xb.data() + 64 * q, 64);
         if (out_is_inf) {
@@ -2285,7 +2310,7 @@ int nmx_set_option(const char* name, uint32_t value) {
     else if (n == "quad_final_below") G.quad_final_below = value;
     else if (n == "accum_prefetch") G.accum_prefetch = value;
     else if (n == "no_batch_fuse") G.no_batch_fuse = value;
-    else if (n == "prefix_tables") G.prefix_tables = value ? 1u : 0u;
+    else if (n == "prefix_tables") G.prefix_tables = value > 2 ? 2u : (uint32_t)value;
     else if (n == "no_tree_fuse") G.no_tree_fuse = value;
     else if (n == "tree_threads") G.tree_threads = value;
     else if (n == "big_slice") G.big_slice = value;

@@ -295,7 +295,7 @@ struct Global {
   std::atomic<uint32_t> horner_spin_limit{0};     // option horner_spin_limit: polls before a wave of the scan gives up (0 = 2^22; tests set 1 to force the fall-back)
   std::atomic<uint32_t> horner_window{64};        // option horner_window: tiles per look-back round of the single-pass scan (tests: 1 .. 63 force the multi-round path)
   std::atomic<uint32_t> seg_heavy_above{0};       // env NMX_TUNE_SEG_HEAVY_ABOVE / option seg_heavy_above: 0 = by pieces per bucket (8 or 12)
-  std::atomic<uint32_t> prefix_tables{1};         // env NMX_TUNE_PREFIX_TABLES / option prefix_tables: the narrow table set over the first 2^18 points of a wide-table key
+  std::atomic<uint32_t> prefix_tables{2};         // env NMX_TUNE_PREFIX_TABLES / option prefix_tables: narrower table sets over a key's first points (capi.hip add_prefix_tables): 0 none, 1 the 2^18-point set of wide-table keys only, 2 the whole chain (batches descend it)
   std::atomic<uint32_t> no_batch_fuse{0};         // env NMX_TUNE_NO_BATCH_FUSE / option no_batch_fuse: every vector of a batch runs alone
   std::atomic<uint32_t> big_threads{0};           // env NMX_TUNE_BIG_THREADS / option big_threads: block size of the big-bucket pass (128 default, 256, 512)
   std::atomic<uint32_t> big_slice{0};             // env NMX_TUNE_BIG_SLICE / option big_slice: pieces per block of the big-bucket pass (0 = default)

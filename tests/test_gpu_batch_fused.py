@@ -46,7 +46,9 @@ def test_hyperkzg_batch_shape(nmx, lg):
     exp = expected(c, vecs, host)
     got, fused, calls = fused_delta(lambda: [as_pair(x) for x in g.batch_vartime_multiscalar_mul(vecs, ck)])
     assert got == exp
-    assert fused == 1   # 11, 17 and 18 vectors: one run each (a c = 15 / 16 key takes 32 vectors per run)
+    # 11, 17 and 18 vectors: one run on a key below 2^14 points; above, the vectors of <= 2^13 pairs run fused on the key's
+    # c = 8 prefix tables (2^7 buckets per set instead of 2^14 / 2^15) and the longer ones fused on the key itself: two runs
+    assert fused == (1 if lg < 14 else 2)
     assert calls == len(vecs)
     assert _lib.lib().nmx_set_option(b"no_batch_fuse", 1) == 0
     try:
@@ -92,8 +94,9 @@ def test_ragged_sets_identity_points_and_layouts(nmx, c):
 
 
 def test_more_vectors_than_one_run_takes(nmx):
-    """A c = 16 key leaves 5 key bits for vector ids: 40 vectors -> fused runs of 32 and 8; a c = 8 key takes 256:
-    300 tiny vectors -> 256 + 44."""
+    """A c = 16 key leaves 5 key bits for vector ids: 40 vectors would be fused runs of 32 and 8 -- but vectors of <= 2^13 pairs
+    run on the key's c = 8 prefix tables, which take 256 per run: ONE run (with option prefix_tables = 0: 32 + 8); a c = 8 key
+    takes 256: 300 tiny vectors -> 256 + 44."""
     c = R.BN254_G1
     g = nmx.DlogGroup(c.cid)
     n = 1 << 17
@@ -102,8 +105,19 @@ def test_more_vectors_than_one_run_takes(nmx):
     lens = [(j * 7919) % 5000 + 1 for j in range(40)]
     vecs = [util.random_scalars(c.cid, m, seed=900 + j) for j, m in enumerate(lens)]
     got, fused, calls = fused_delta(lambda: [as_pair(x) for x in g.batch_vartime_multiscalar_mul(vecs, ck)])
-    assert got == expected(c, vecs, host) and fused == 2 and calls == 40
+    assert got == expected(c, vecs, host)
+    assert fused == 1 and calls == 40
     ck.close()
+    L = _lib.lib()
+    assert L.nmx_set_option(b"prefix_tables", 0) == 0
+    try:
+        ck = nmx.CommitmentKey.from_host(c.cid, host)
+        got, fused, calls = fused_delta(lambda: [as_pair(x) for x in g.batch_vartime_multiscalar_mul(vecs, ck)])
+        assert got == expected(c, vecs, host)
+        assert fused == 2 and calls == 40
+        ck.close()
+    finally:
+        assert L.nmx_set_option(b"prefix_tables", 2) == 0
     n = 512
     host = cref.sequential_bases(c, 6, n)
     ck = nmx.CommitmentKey.from_host(c.cid, host)
@@ -153,7 +167,8 @@ def test_fused_run_on_the_segment_path(nmx):
     prep = cref.Prepared(c.cid, host, n)
     exp = [prep.msm(np.ascontiguousarray(v), len(v)) if len(v) else (bytes(64), 1) for v in vecs]
     got, fused, calls = fused_delta(lambda: [as_pair(x) for x in g.batch_vartime_multiscalar_mul(vecs, ck)])
-    assert got == exp and fused == 1 and calls == 6
+    assert got == exp
+    assert fused == 2 and calls == 6   # the four long vectors fused on the key, the 5-pair one (and the empty one) on its c = 8 prefix tables
     ck.close()
 
 

@@ -118,7 +118,7 @@ def test_prefix_tables_serve_short_calls_and_fused_batches_on_a_wide_key(nmx):
         got2, _ = run(ck2, bases)
         ck2.close()
     finally:
-        assert L.nmx_set_option(b"prefix_tables", 1) == 0
+        assert L.nmx_set_option(b"prefix_tables", 2) == 0
     for key in ("batch", "single", "inside", "across", "commit"):
         assert got2[key] == got[key], key
 
