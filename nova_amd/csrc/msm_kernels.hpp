@@ -167,14 +167,32 @@ template <int SFID> struct DigitsFn {
     const MsmShape& sh = src.sh;
     uint32_t s[9], bi, kbase;
     const bool skip = !src.load(i, s, bi, kbase, true);
-    uint32_t carry = 0;
-    for (uint32_t w = 0; w < sh.W; w++) {
-      uint32_t d, neg;
-      src.digit(s, w, carry, d, neg);
-      const uint32_t key = (d == 0 || skip) ? sh.nbuckets : ((src.pre_stride ? kbase : w * sh.M) + d - 1);
-      const size_t o = (size_t)w * sh.n + i;
-      keys[o] = key;
-      vals[o] = (w * src.pre_stride + bi) | (neg << 31);
+    // the words are walked with constant indices and the windows peeled off a 64-bit bit buffer (c <= 20): indexing s[] by a
+    // run-time word number keeps the array in memory -- promoted to LDS, 9 KB per block (msm_partition.hpp, for_each_digit)
+    const uint32_t c = sh.c, mask = (1u << c) - 1u;
+    uint64_t acc = 0;
+    uint32_t have = 0, w = 0, carry = 0;
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+      acc |= (uint64_t)s[j] << have;
+      have += 32;
+      while (have >= c && w < sh.W) {
+        uint32_t d = ((uint32_t)acc & mask) + carry, neg = 0;
+        acc >>= c;
+        have -= c;
+        if (d > sh.M) {
+          d = (1u << c) - d;
+          neg = 1;
+          carry = 1;
+        } else {
+          carry = 0;
+        }
+        const uint32_t key = (d == 0 || skip) ? sh.nbuckets : ((src.pre_stride ? kbase : w * sh.M) + d - 1);
+        const size_t o = (size_t)w * sh.n + i;
+        keys[o] = key;
+        vals[o] = (w * src.pre_stride + bi) | (neg << 31);
+        w++;
+      }
     }
   }
 };
