@@ -190,3 +190,59 @@ def test_sharded_keys_and_long_cached_arrays_from_many_threads(nmx):
         assert nmx.init_devices(1) == 1
         assert L.nmx_set_option(b"shard_min_n", 1 << 20) == 0
         assert L.nmx_cache_clear() == 0
+
+
+def test_async_nifs_chains_from_several_threads(nmx):
+    """NMX_ASYNC under concurrency: four host threads (rayon workers: the primary and the secondary NIFS of src/nova/mod.rs:862-881
+    run side by side) each enqueue commit_T's chain and the fold without waiting, commit in between and compare with the
+    synchronous results -- contexts are leased and returned with work still pending on their streams all the time, the arena
+    that holds Z is re-carved by whoever leases the context next, and every thread's ordering is its own."""
+    import torch
+    from nova_amd import fieldvec as fv
+    from tests import fv_common as C
+    cid = 0
+    fid = fv.SCALAR_FIELD_OF_CURVE[cid]
+    n = 30000
+    ck = nmx.CommitmentKey.generate(cid, n, k0=11)
+    ce = nmx.CommitmentEngine(cid)
+    mats = [fv.SparseMatrix(fid, *C.random_csr(fid, n, n, 70 + j), n) for j in range(3)]
+    data = []
+    for t in range(4):
+        hW1, hW2, hE = (C.rand_vec(fid, n, 100 * t + s) for s in (1, 2, 3))
+        u, r = C.rand_vec(fid, 1, 100 * t + 4), C.rand_vec(fid, 1, 100 * t + 5)
+        W1, W2, E = (torch.from_numpy(h.copy()).cuda() for h in (hW1, hW2, hE))
+        torch.cuda.synchronize()
+        T0 = fv.r1cs_cross_term(mats[0], mats[1], mats[2], W1, W2, E, u)
+        c0 = ce.commit(ck, T0, r)
+        Wf0, Ef0 = fv.nifs_fold(fid, W1, W2, E, T0, r)
+        data.append((W1, W2, E, u, r, T0, (c0.xy, c0.is_inf), Wf0, Ef0))
+    errors = []
+
+    def worker(t):
+        W1, W2, E, u, r, T0, c0, Wf0, Ef0 = data[t]
+        try:
+            for it in range(25):
+                T = fv.r1cs_cross_term(mats[0], mats[1], mats[2], W1, W2, E, u, async_=True)
+                cm = ce.commit(ck, T, r)
+                if (cm.xy, cm.is_inf) != c0 or not torch.equal(T, T0):
+                    errors.append((t, it, "commit_T"))
+                Wf, Ef = fv.nifs_fold(fid, W1, W2, E, T, r, async_=True)
+                if it % 3 == 0:
+                    small = ce.commit(ck, T[:100].contiguous(), r)      # a synchronous call behind the fold: orders it as well
+                    assert small is not None
+                else:
+                    fv.sync()
+                if not (torch.equal(Wf, Wf0) and torch.equal(Ef, Ef0)):
+                    errors.append((t, it, "fold"))
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errors, errors[:5]
+    for m in mats:
+        m.close()
+    ck.close()
