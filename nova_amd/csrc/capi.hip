@@ -157,6 +157,7 @@ static void ensure_init() {
   if (const char* t = getenv("NMX_TUNE_BIG_SLICE")) G.big_slice = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_BIG_THREADS")) G.big_threads = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_HIST_GRID")) G.hist_grid = (uint32_t)atoi(t);
+  if (const char* t = getenv("NMX_TUNE_HIST_BS")) G.hist_bs = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_SYNC_SPIN_US")) G.sync_spin_us = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_HORNER_TOP")) G.horner_top = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_HORNER_SUB")) G.horner_sub = (uint32_t)atoi(t);
@@ -2316,6 +2317,7 @@ int nmx_set_option(const char* name, uint32_t value) {
     else if (n == "big_slice") G.big_slice = value;
     else if (n == "big_threads") G.big_threads = value;
     else if (n == "hist_grid") G.hist_grid = value;
+    else if (n == "hist_bs") G.hist_bs = value;
     else if (n == "sync_spin_us") G.sync_spin_us = value;
     else if (n == "horner_order") G.horner_order = value ? 1u : 0u;
 

@@ -145,6 +145,7 @@ static XYZZ<CurveT<CID>::BF> run_msm(Ctx& c, const void* d_bases, size_t n, cons
   a.seg_heavy_above = G.seg_heavy_above;
   a.big_slice = G.big_slice.load(std::memory_order_relaxed);
   a.hist_grid = G.hist_grid;
+  a.hist_bs = G.hist_bs;
   // gathers in flight per lane: one is enough while the key's tables (W x 64 B per point) mostly hit the 256 MB Infinity Cache
   // and L2; from ~6 GiB of tables on the gather latency shows and a second row in flight pays (2^24: accumulate 17.6 ->
   // 16.0 ms; neutral at 2^22, slightly worse at 2^20 / 2^21: profiles/r02_msm_2p20/prefetch_depth.txt)
@@ -419,6 +420,7 @@ static void run_msm_batch(Ctx& c, const BaseSet& bs, size_t offset, const BatchI
   a.seg_heavy_above = G.seg_heavy_above;
   a.big_slice = G.big_slice.load(std::memory_order_relaxed);
   a.hist_grid = G.hist_grid;
+  a.hist_bs = G.hist_bs;
   {
     const uint32_t pf = G.accum_prefetch.load(std::memory_order_relaxed);
     a.accum_prefetch = pf ? pf : 1u;

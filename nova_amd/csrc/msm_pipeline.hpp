@@ -32,6 +32,7 @@ struct MsmArgs {
   uint32_t seg_min_len = 8;           // shortest segment a lane is given
   uint32_t accum_prefetch = 1;        // gathers in flight ahead of the addition (AccumSegFn PF)
   uint32_t hist_grid = 0;             // blocks of the first-level counting pass (0: as many as the placing pass; tuning)
+  uint32_t hist_bs = 0;               // threads per block of the counting pass (0: as the placing pass; it stages nothing, so any multiple of 64 >= the bin count works)
   uint32_t big_slice = 0;             // pieces per block of the big-bucket pass (< 32: SegPlan::big_slice_for)
   uint32_t seg_heavy_above = 0;       // pieces FinalSegFn sums per bucket without a pre-fold (0: SegPlan::heavy_above_for)
   // fused batch over the key's tables (DigitSrc::batch_*): n = sum of the vector lengths, `scalars` unused;
@@ -207,7 +208,16 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
     auto level1 = [&](auto hist, auto part) {
       be.mark("digits");
       // the counting pass ends with one global atomic per block and bin: fewer, longer-lived blocks (a.hist_grid) contend less
-      be.launch_kernel(hist, a.hist_grid && a.hist_grid < pb.ps.grid1 ? a.hist_grid : pb.ps.grid1, pb.ps.bs1, pa);
+      {
+        uint32_t hbs = pb.ps.bs1, hgrid = pb.ps.grid1;
+        if (a.hist_bs >= 64 && a.hist_bs <= 1024 && (a.hist_bs & 63u) == 0) {
+          hbs = a.hist_bs;
+          const uint32_t chunks = (sh.n + hbs - 1) / hbs;
+          hgrid = chunks < 4096 ? chunks : 4096;
+        }
+        if (a.hist_grid && a.hist_grid < hgrid) hgrid = a.hist_grid;
+        be.launch_kernel(hist, hgrid, hbs, pa);
+      }
       if (pb.ps.big) be.launch_kernel(&k_tiles<true>, 1u, 1024u, pb);
       else be.launch_kernel(&k_tiles<false>, 1u, 1024u, pb);
       be.mark("sort");

@@ -302,6 +302,7 @@ struct Global {
   std::atomic<uint32_t> tree_threads{0};          // env NMX_TUNE_TREE_THREADS / option tree_threads: block size of the fused reduction tree (0 = default, 256 or 512)
   std::atomic<uint32_t> no_tree_fuse{0};          // env NMX_TUNE_NO_TREE_FUSE / option no_tree_fuse: 0 / 2 = fused reduction tree (default), 1 = one launch per reduction level
   std::atomic<uint32_t> hist_grid{0};             // env NMX_TUNE_HIST_GRID / option hist_grid
+  std::atomic<uint32_t> hist_bs{0};               // env NMX_TUNE_HIST_BS / option hist_bs: threads per block of k_hist_hi (0: as k_part_hi)
   std::atomic<uint32_t> horner_order{1};          // option horner_order: 1 = tiles of k_horner_scan by start-order ticket, 0 = by block id
   std::atomic<uint32_t> sync_spin_us{0};          // env NMX_SYNC_SPIN_US / option sync_spin_us: poll the stream this long before blocking
   std::atomic<uint32_t> force_peer_copy{0};       // option force_peer_copy: HBM-resident scalars of a sharded call take the staging + hipMemcpyPeerAsync branch even when source and destination are the same GPU (tests on a 1-GPU box)
