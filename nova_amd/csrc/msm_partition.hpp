@@ -220,6 +220,11 @@ struct PartBufs {
   uint32_t* end;         // [nbuckets + 1]
   uint32_t* vals;        // [n * W] final: words of bucket k at [start[k], end[k])
   uint32_t* total_out;   // number of non-zero digits of the whole MSM
+  // ONE high bin (keys of up to 7 bits: a single vector over c = 8 tables -- every key below 2^14 points, the secondary circuit's
+  // commitments, the narrow prefix tables): the counting pass has nothing to decide -- the bin's region starts at 0 and its size is
+  // what the placing pass's cursor ends at.  The pipeline then runs k_part_hi FIRST (reporting range errors itself), k_tiles reads
+  // the count from cur_hi, and k_hist_hi is not launched at all: one dependent launch less on MSMs that are pure latency.
+  uint32_t single_bin = 0;
 };
 template <int SFID> struct PartArgs {
   DigitSrc<SFID> src;
@@ -386,7 +391,7 @@ template <int SFID, int C, bool BIG> NMX_KERNEL void NMX_LAUNCH_BOUNDS(1024) k_p
     NMX_SYNC();
     const uint32_t i = base + t;
     uint32_t s[9], bi = 0, kbase = 0;
-    const bool live = i < n && a.src.load(i, s, bi, kbase, false);
+    const bool live = i < n && a.src.load(i, s, bi, kbase, a.b.single_bin != 0);
     // phase A: this chunk's entries per bin.  With a compile-time width the digits stay in registers for phase B
     // (key | neg << 31, all ones = none); at run-time width they are extracted again.
     uint32_t dig[C ? WinMax<C>::value : 1];

@@ -205,7 +205,18 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
     pb.end = end;
     pb.total_out = counters + 5;
     // the widths the tables are built with get their own instantiation (constant bit positions); BIG = keys wider than 15 bits
+    pb.single_bin = pb.ps.nhi == 1 ? 1u : 0u;
     auto level1 = [&](auto hist, auto part) {
+      if (pb.single_bin) {  // (PartBufs::single_bin) placing pass first, the tile table from its cursor, no counting pass
+        be.mark("digits");
+        be.mark("sort");
+        be.launch_kernel(part, pb.ps.grid1, pb.ps.bs1, pa);
+        PartBufs pt = pb;
+        pt.hist_hi = pb.cur_hi;
+        if (pb.ps.big) be.launch_kernel(&k_tiles<true>, 1u, 1024u, pt);
+        else be.launch_kernel(&k_tiles<false>, 1u, 1024u, pt);
+        return;
+      }
       be.mark("digits");
       // the counting pass ends with one global atomic per block and bin: fewer, longer-lived blocks (a.hist_grid) contend less
       {

@@ -296,7 +296,17 @@ static int partition_check(const uint8_t* scalars, size_t n, uint32_t c, uint32_
   pb.vals = vals.data();
   pb.total_out = &tot;
   HostEmulBackend be;
+  pb.single_bin = pb.ps.nhi == 1 ? 1u : 0u;
+  pa.b.single_bin = pb.single_bin;
   auto l1 = [&](auto hist, auto part) {
+    if (pb.single_bin) {  // as msm_pipeline.hpp: placing pass first, the tile table from its cursor, no counting pass
+      be.launch_kernel(part, pb.ps.grid1, pb.ps.bs1, pa);
+      PartBufs pt = pb;
+      pt.hist_hi = pb.cur_hi;
+      if (pb.ps.big) be.launch_kernel(&k_tiles<true>, 1u, 1024u, pt);
+      else be.launch_kernel(&k_tiles<false>, 1u, 1024u, pt);
+      return;
+    }
     be.launch_kernel(hist, pb.ps.grid1, pb.ps.bs1, pa);
     if (pb.ps.big) be.launch_kernel(&k_tiles<true>, 1u, 1024u, pb);
     else be.launch_kernel(&k_tiles<false>, 1u, 1024u, pb);
