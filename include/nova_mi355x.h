@@ -103,10 +103,13 @@ int nmx_sync(void); /* waits for the calling thread's NMX_ASYNC calls (no-op whe
  * nmx_bases_generate, and the slice cache behind nmx_msm / nmx_msm_u64 / nmx_msm_batch -- is cut into k contiguous shards
  * (shard i = points [i*n/k ...), exactly nova_amd/dist.py shard_range), shard i resident on device i with its own window
  * tables.  An MSM / commit over such a key runs one host thread + stream per shard touched, each producing a 128-byte
- * partial.  The combine step: with the shards on two or more GPUs ONE ncclAllGather of the 128-byte
- * partials over xGMI (RCCL, bound at run time; one rank per GPU, issued by the calling thread inside a group call) followed by
- * the G-term point sum on the host from rank 0's copy; on one GPU, without RCCL, or with nmx_set_option("combine", 1): the
- * host sum of the partials (nmx_point_sum).  No bucket array crosses devices, and the call is still one synchronous C call.
+ * partial.  The combine step: inside ONE process every shard worker hands its partial to the calling thread
+ * in host memory, so the default is the host sum of the k partials (nmx_point_sum: <= 8 additions of ~0.5 us, nothing on a
+ * stream).  nmx_set_option("combine", 2) routes it through RCCL instead -- ONE ncclAllGather of the 128-byte partials over
+ * xGMI (bound at run time; one rank per GPU, issued by the calling thread inside a group call), then the G-term sum from rank
+ * 0's copy -- which exercises the communicator but adds two copies and k stream syncs; the all-gather is the real exchange
+ * step in the one-process-per-GPU deployment (nova_amd/dist.py).  No bucket array crosses devices, and the call is still one
+ * synchronous C call.
  * Scalars: shard-resident (NMX_SCALARS_SHARDED, nmx_svec_*: each piece already in the HBM of the GPU that holds its bases --
  * the intended form), or one HBM array on logical device 0 (NMX_SCALARS_DEVICE: a shard on another GPU pulls its slice
  * peer-to-peer over xGMI inside the call), or host memory (each GPU pulls its slice over its own PCIe link).
@@ -171,15 +174,22 @@ int nmx_bases_generate(int curve, uint64_t k0, size_t n, uint32_t flags, uint64_
  * per-round Vecs, ipa_pc.rs:212-230 -- never pay for them; nmx_set_option("cache_table_after")).  Tables that do not
  * fit the cache budget or the HBM left: the key stays resident without them (plain GPU path).
  * The trait is a pure function of the slice, and the cache keeps it one: identity of an array = (curve, layout flag, host
- * address), confirmed on EVERY call by 32-bit hashes of the caller's bytes against the hashes of all points recorded at
- * upload -- every point for slices up to 2048 points; otherwise the first and the last point used, eight probes that move from
- * call to call, and a rolling window of max(4096, n/16) consecutive points that continues where the previous call stopped,
- * hashed on a second host thread while the GPU runs.  A freed-and-reused address is caught at once; a caller that rewrites
- * even ONE point of a long cached array in place is caught within 16 calls (the entry is dropped, the call repeated on a fresh
- * upload, the stale result discarded: NMX_STAT_CACHE_STALE) -- nmx_cache_invalidate makes that immediate, and is the
- * documented contract for in-place edits.  Arrays shorter than the cache's min_n (default 128 points) and calls with
- * NMX_BASES_NOCACHE are uploaded for the call only.  LRU eviction under a byte budget (default: a quarter of the device's HBM),
- * also when an upload runs out of HBM; evicted or invalidated keys stay alive until the calls using them return. */
+ * address), confirmed on EVERY call from the caller's bytes against the 64-bit hashes of ALL points recorded at upload.
+ * Default (option "cache_verify" = 0): every point of the slice is re-hashed on every hit -- slices up to 2048 points before
+ * anything is launched; longer ones get a quick look first (first point, last point, eight probes that move from call to call:
+ * a freed-and-reused address fails here) and the full pass runs on host pool threads WHILE the GPU computes the MSM (2^20
+ * points = 64 MiB, ~1 ms on 8 threads, under a ~2 ms call); the result is handed out only after the pass succeeded, otherwise
+ * the entry is dropped, the call repeated on a fresh upload and the stale result discarded (NMX_STAT_CACHE_STALE).  So an
+ * in-place edit of even ONE point changes the very next result.  Host cost: one read of the slice per call; the library never
+ * runs more than 8 verification workers at a time across ALL callers (concurrent rayon callers share them, the surplus
+ * verifies on its calling thread's share only) -- INTEGRATION.md section 2 has the numbers.
+ * Opt-in "cache_verify" = 1 (callers whose keys are immutable, which is every caller in the reference tree): the quick look
+ * plus a rolling window of max(4096, n/16) consecutive points that continues where the previous call stopped; an in-place edit
+ * is then caught within 16 calls instead of at once, and nmx_cache_invalidate is the contract for in-place edits.
+ * Arrays shorter than the cache's min_n (default 128 points) and calls with NMX_BASES_NOCACHE are uploaded for the call only.
+ * LRU eviction under a byte budget (default: a quarter of the device's HBM), also when an upload runs out of HBM; evicted or
+ * invalidated keys stay alive until the calls using them return.  Keys that must never be re-hashed: register them
+ * (nmx_bases_register) and call the *_handle forms. */
 int nmx_msm(int curve, const void* scalars, const void* bases_xy64, size_t n, uint32_t flags,
             uint8_t* out, uint8_t* out_is_inf);
 /* Slice-cache control.  nmx_cache_configure: max_bytes / min_n / max_entries, 0 = leave unchanged. */
@@ -437,8 +447,8 @@ int nmx_set_window_bits(uint32_t c);
  * "hist_grid" (blocks of the partition's counting pass; 0 = as the placing pass: measured flat, profiles/r03_msm_2p20/tail_ab.txt),
  * "shard_min_n", "cache_table_after", "max_table_mib" (see the sections above), "force_peer_copy" (1: the HBM-resident scalars of
  * a sharded call are staged through hipMemcpyPeerAsync even when the shard sits on the source GPU: exercises the cross-device
- * branch on a one-GPU box), "combine" (0: RCCL all-gather when the shards sit on two or more GPUs, else the host sum; 1: host
- * sum; 2: RCCL required -- also with one GPU, an error if it cannot be loaded), "cache_verify" (0: every slice-cache hit
+ * branch on a one-GPU box), "combine" (0 and 1: host sum of the partials, the default; 2: RCCL all-gather required -- also with
+ * one GPU, an error if it cannot be loaded), "cache_verify" (0: every slice-cache hit
  * re-hashes the caller's whole slice; 1: rolling window, for callers that register immutable keys).
  * Unknown name: NMX_E_ARG. */
 int nmx_set_option(const char* name, uint32_t value);

@@ -301,13 +301,20 @@ template <class Fn> static void run_on_parts(size_t count, bool parallel, Fn&& f
   Fail first{0, ""};
   Ctx* const pend = async_pending();  // the caller's last asynchronous call: leases on the helper threads must wait for it too
   const uint64_t pend_epoch = t_async_epoch;
+  const std::thread::id caller = std::this_thread::get_id();
   auto guarded_fn = [&](size_t i) {
+    // helper threads borrow the caller's pending asynchronous mark for the duration of fn(i) and get their own state back;
+    // on the CALLING thread nothing is restored: an asynchronous mark fn(i) records there must survive the call, or the
+    // thread's next lease / nmx_sync would not wait for it
     struct Restore {
+      bool on;
       Ctx* v;
       uint64_t e;
-      ~Restore() { t_async_ctx = v, t_async_epoch = e; }
-    } restore{t_async_ctx, t_async_epoch};
-    t_async_ctx = pend, t_async_epoch = pend_epoch;
+      ~Restore() {
+        if (on) t_async_ctx = v, t_async_epoch = e;
+      }
+    } restore{std::this_thread::get_id() != caller, t_async_ctx, t_async_epoch};
+    if (restore.on) t_async_ctx = pend, t_async_epoch = pend_epoch;
     try {
       fn(i);
     } catch (const Fail& f) {
@@ -470,7 +477,13 @@ static void combine_partials(const CurveOps& o, const uint8_t* partials, const s
       if (std::find(phys.begin(), phys.end(), h) == phys.end()) phys.push_back(h);
     }
   }
-  const bool want = mode == NMX_COMBINE_RCCL || (mode == NMX_COMBINE_AUTO && phys.size() >= 2);
+  // Inside one process the shard workers hand their partials to the calling thread in HOST memory (the window sums are finished
+  // by the host tail of every MSM), so the host sum is the default: k x 128 bytes, <= 8 additions of ~0.5 us, nothing on a
+  // stream.  RCCL here would be host -> device -> all-gather -> device -> host for the same bytes (2 copies + k stream syncs on
+  // the critical path), so it is opt-in ("combine" = 2: the communicator, the collective and the xGMI route get exercised);
+  // the deployment where the all-gather IS the exchange step is one process per GPU (nova_amd/dist.py, bench.py --gpus N under
+  // torch.distributed.run), where no rank can see another rank's partial.
+  const bool want = mode == NMX_COMBINE_RCCL;
   bool done = false;
   if (want && cnt >= 1) {
     std::lock_guard<std::mutex> lk(RC.mu);
@@ -536,6 +549,7 @@ static void check_shard_piece(const void* p, size_t bytes, int logical_dev) {
 static void key_msm(Ctx& c0, const BaseSet& bs, size_t offset, size_t n, const MsmCall& mc, uint32_t flags, uint8_t* out,
                     uint8_t* inf) {
   const CurveOps& o = ops(bs.curve);
+  t_shards.clear(), t_combine_ms = 0, t_rccl_ranks = 0;  // nmx_profile_last_sharded describes THIS call (no shards: single device)
   if (bs.parts.empty()) {
     if (mc.scalars_sharded) {  // one piece: the pointer array has one entry, on the key's device
       MsmCall m = mc;
@@ -613,6 +627,7 @@ static void key_msm_sparse(Ctx& c0, const BaseSet& bs, const uint32_t* idx, cons
   const CurveOps& o = ops(bs.curve);
   MsmCall mc = scalars ? field_call(scalars, flags) : MsmCall{nullptr, false, false, 1, true};
   mc.all_ones = scalars == nullptr;
+  t_shards.clear(), t_combine_ms = 0, t_rccl_ranks = 0;
   if (bs.parts.empty()) {
     mc.gather_host = idx;
     o.msm_key(c0, bs, 0, k, mc, flags, out, inf);
@@ -631,15 +646,23 @@ static void key_msm_sparse(Ctx& c0, const BaseSet& bs, const uint32_t* idx, cons
   for (size_t p = 0; p < np; p++)
     if (!pidx[p].empty()) used.push_back(p);
   std::vector<uint8_t> partials(128 * (used.size() ? used.size() : 1));
+  std::vector<ShardRec> recs(used.size());
   run_on_parts(used.size(), true, [&](size_t i) {
     const size_t p = used[i];
     CtxLease L(bs.parts[p]->dev);
     MsmCall m = mc;
     m.scalars = scalars ? psc[p].data() : nullptr;
     m.gather_host = pidx[p].data();
+    recs[i].dev = bs.parts[p]->dev;
+    recs[i].branch = scalars ? NMX_BRANCH_HOST : NMX_BRANCH_NONE;
     o.msm_key(*L.c, *bs.parts[p], 0, pidx[p].size(), m, (flags & ~(uint32_t)NMX_OUT_PARTIAL) | NMX_OUT_PARTIAL,
               partials.data() + 128 * i, nullptr);
+    if (G.profiling.load(std::memory_order_relaxed)) {
+      recs[i].nst = t_prof_n;
+      for (int q = 0; q < t_prof_n; q++) recs[i].ms[q] = t_prof[q];
+    }
   });
+  t_shards.swap(recs);
   stat_add(NMX_STAT_SHARDED_CALLS, 1);
   std::vector<int> devs(used.size());
   for (size_t i = 0; i < used.size(); i++) devs[i] = bs.parts[used[i]]->dev;
@@ -746,15 +769,29 @@ struct DeepCheck {  // the part of a hit's verification that may run beside the 
     return true;
   }
   bool run() const { return run_range(start, start + count); }
-  // on pool workers, up to 8 of them; every future must be joined before the slice goes away
+  // on pool workers, up to 8 of them ACROSS ALL CALLERS (concurrent rayon callers hitting cached keys share the 8: a caller
+  // that finds them taken verifies on one worker -- still every point, still joined before the result is handed out -- so
+  // the check costs at most 8 host threads and their memory bandwidth, whatever the number of callers); every future must be
+  // joined before the slice goes away
+  static std::atomic<int>& inflight() {
+    static std::atomic<int> v{0};
+    return v;
+  }
   std::vector<PoolFuture<bool>> run_async() const {
-    const size_t nth = std::max<size_t>(1, std::min<size_t>(8, count >> 15));
+    size_t nth = std::max<size_t>(1, std::min<size_t>(8, count >> 15));
+    const int busy = inflight().load(std::memory_order_relaxed);
+    if ((size_t)busy + nth > 8) nth = busy >= 7 ? 1 : (size_t)(8 - busy);
+    inflight().fetch_add((int)nth, std::memory_order_relaxed);
     std::vector<PoolFuture<bool>> futs;
     futs.reserve(nth);
     const DeepCheck dc = *this;
     for (size_t t = 0; t < nth; t++) {
       const size_t a = start + count * t / nth, b = start + count * (t + 1) / nth;
-      futs.emplace_back([dc, a, b] { return dc.run_range(a, b); });
+      futs.emplace_back([dc, a, b] {
+        const bool ok = dc.run_range(a, b);
+        inflight().fetch_sub(1, std::memory_order_relaxed);
+        return ok;
+      });
     }
     return futs;
   }
@@ -1701,6 +1738,7 @@ int nmx_msm_u64_batch(int curve, const uint64_t* const* scalar_vecs, const size_
   return guarded([&] {
     require(bases || n_bases == 0, NMX_E_ARG, "null argument");
     require(max_num_bits == NMX_BITS_AUTO || max_num_bits <= 64, NMX_E_ARG, "max_num_bits must be <= 64");
+    require(!(flags & NMX_SCALARS_SHARDED), NMX_E_ARG, "batches of small scalars take plain pointers");
     require((out && lens) || k == 0, NMX_E_ARG, "null argument");
     const CurveOps& o = ops(curve);
     CtxLease L;
@@ -1733,6 +1771,7 @@ static void commit_impl(const BaseSet& bs, MsmCall mc, size_t n, const void* h_x
     if (mc.scalars_sharded) {  // one piece, on the key's device
       mc.scalars = n ? ((const void* const*)mc.scalars)[0] : nullptr;
       require(mc.scalars || n == 0, NMX_E_ARG, "null shard pointer");
+      if (n) check_shard_piece(mc.scalars, n * (mc.u64_mode ? 8u : 32u), bs.dev);  // as key_msm / batch_impl: NMX_E_ARG, not a GPU fault
       mc.scalars_device = true;
       mc.scalars_sharded = false;
     }

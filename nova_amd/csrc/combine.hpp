@@ -127,8 +127,24 @@ struct RcclCombine {
     return true;
   }
   // all-gather of one slot per rank; gathered[ranks * kCombineSlot] <- every rank's slot, read back from rank 0.
-  // Throws Fail on a HIP / RCCL error in flight (the caller falls back to the host sum of what it holds).
+  // Throws Fail on a HIP / RCCL error in flight (the caller falls back to the host sum of what it holds).  An error never
+  // leaves this thread inside an open ncclGroupStart (later collectives of the thread -- torch's too, the dlopen'ed librccl
+  // is shared -- would queue into it and hang): the group is closed by a guard before the exception travels, and the
+  // communicators are torn down and `failed` set, so that every later call of the process takes the host sum.
   void all_gather_locked(const uint8_t* slots /* ranks * kCombineSlot, host */, uint8_t* gathered) {
+    try {
+      all_gather_impl(slots, gathered);
+    } catch (const Fail& f) {
+      (void)hipGetLastError();
+      destroy_locked();
+      failed = true;
+      why = "RCCL combine failed in flight: " + f.msg;
+      throw;
+    }
+  }
+
+ private:
+  void all_gather_impl(const uint8_t* slots, uint8_t* gathered) {
     const size_t n = comms.size();
     memcpy(pinned, slots, n * kCombineSlot);
     for (size_t r = 0; r < n; r++) {
@@ -139,11 +155,24 @@ struct RcclCombine {
       if (rc != 0) throw Fail{NMX_E_HIP, std::string(what) + ": " + (api.GetErrorString ? api.GetErrorString(rc) : "RCCL error")};
     };
     chk(api.GroupStart(), "ncclGroupStart");
-    for (size_t r = 0; r < n; r++) {
-      HIPCHK(hipSetDevice(hip_devs[r]));
-      chk(api.AllGather(send[r], recv[r], kCombineSlot, 1 /* ncclUint8 */, comms[r], streams[r]), "ncclAllGather");
+    {
+      struct GroupGuard {  // ncclGroupEnd on every path out of the bracket
+        RcclApi& api;
+        bool open = true;
+        int end() {
+          open = false;
+          return api.GroupEnd();
+        }
+        ~GroupGuard() {
+          if (open) (void)api.GroupEnd();
+        }
+      } guard{api};
+      for (size_t r = 0; r < n; r++) {
+        HIPCHK(hipSetDevice(hip_devs[r]));
+        chk(api.AllGather(send[r], recv[r], kCombineSlot, 1 /* ncclUint8 */, comms[r], streams[r]), "ncclAllGather");
+      }
+      chk(guard.end(), "ncclGroupEnd");
     }
-    chk(api.GroupEnd(), "ncclGroupEnd");
     HIPCHK(hipSetDevice(hip_devs[0]));
     HIPCHK(hipMemcpyAsync(pinned + n * kCombineSlot, recv[0], n * kCombineSlot, hipMemcpyDeviceToHost, streams[0]));
     for (size_t r = 0; r < n; r++) {  // every rank's collective has completed before the buffers are reused

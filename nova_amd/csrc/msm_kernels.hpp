@@ -158,7 +158,9 @@ template <int SFID> struct DigitSrc {
 };
 
 
-// Generic path (plain keys, c = 20 tables): materialises (key, val) pairs for the radix sort.
+// Generic path (rocPRIM radix sort): only for shapes the hand-written partition does not cover (msm_pipeline.hpp
+// partition_supported) and under the `no_partition` option -- since round 4 plain keys and c = 20 tables take the partition.
+// Materialises (key, val) pairs for the sort.
 template <int SFID> struct DigitsFn {
   DigitSrc<SFID> src;
   uint32_t* keys;  // W x n

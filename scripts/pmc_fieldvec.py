@@ -1,4 +1,4 @@
-"""Per-kernel summary of the PMC passes + kernel trace of one field-vector workload (scripts/gpu_r3_profile.sh): launches,
+"""Per-kernel summary of the PMC passes + kernel trace of one field-vector workload (scripts/archive/gpu_r3_profile.sh): launches,
 mean duration, VALU instructions, wave cycles, HBM bytes -- and the VALU-issue ceiling they imply."""
 import collections, csv, glob, json, sys
 src, dst = sys.argv[1], sys.argv[2]

@@ -36,7 +36,7 @@ def pt(c):
     return (c.xy, int(c.is_inf))
 
 
-@pytest.mark.parametrize("k", [2, 3])
+@pytest.mark.parametrize("k", [2, 3, 8])
 @pytest.mark.parametrize("c", [R.BN254_G1, R.PALLAS], ids=lambda c: c.name)
 def test_sharded_key_every_entry_point(nmx, sharded, c, k):
     from nova_amd import _lib
@@ -144,7 +144,7 @@ def _branches(_lib):
     return [s["branch"] for s in _lib.profile_last_sharded()["shards"]]
 
 
-@pytest.mark.parametrize("k", [1, 2, 3])
+@pytest.mark.parametrize("k", [1, 2, 3, 8])
 def test_shard_resident_scalars_and_field_kernels(nmx, sharded, k):
     """VERDICT r3 missing #1: coefficients and bases chunked TOGETHER (/root/reference/src/provider/msm.rs:564-574).  A
     ShardedVector is laid out like the key (element i on the device of point i); MSM / commit take it shard by shard
@@ -218,7 +218,7 @@ def test_shard_resident_scalars_and_field_kernels(nmx, sharded, k):
     ck.close()
 
 
-@pytest.mark.parametrize("k", [1, 2, 3])
+@pytest.mark.parametrize("k", [1, 2, 3, 8])
 def test_pieces_follow_the_registered_layout(nmx, sharded, k):
     """Round 4 finding: a generated key is registered with its blinding point behind ck (n + 1 points), so its shards are
     cut at (n + 1) / k -- pieces cut by shard_plan(len(ck), ...) sit in the wrong place (bench.py --gpus 2 returned a wrong
@@ -398,4 +398,46 @@ def test_batch_over_a_sharded_wide_key_fuses_its_short_vectors(nmx, sharded):
     assert _lib.stats()[_lib.STAT_FUSED_RUNS] > f0                 # the three short vectors: one fused run on shard 0's prefix
     assert _lib.stats()[_lib.STAT_SHARDED_CALLS] == s0 + 1         # only the long vector was a sharded MSM
     assert pt(g.vartime_multiscalar_mul(sc[:5000], ck, offset=100)) == cref.msm(c.cid, sc[:5000], bases[100:5100], 5000)
+    ck.close()
+
+
+def test_eight_way_config3_shape(nmx, sharded):
+    """BASELINE.json configs[2] is an 8-way shard ("BN254 MSM 2^24 sharded across 8 x MI355X"): the same decomposition at a size
+    the oracle finishes in seconds -- 2^17 pairs of ONE BN254 key cut into 8 contiguous shards (2^14 per shard, each with its own
+    tables, stream, workspace and host thread; oversubscribed onto the box's one GPU), scalars shard-resident, through the
+    host-sum combine (the default) and the RCCL all-gather (option combine = 2), against the oracle and against the
+    reference's own decomposition rule (src/provider/msm.rs:564-574: the sum of the per-chunk MSMs)."""
+    import torch
+    from nova_amd import _lib
+    L = sharded(8)
+    c = R.BN254_G1
+    n = 1 << 17
+    ck = nmx.CommitmentEngine(c.cid).setup_synthetic(n, k0=77)
+    g = nmx.DlogGroup(c.cid)
+    bases = ck.read(0, n)
+    sc = util.random_scalars(c.cid, n, seed=88)
+    exp = cref.msm(c.cid, sc, bases, n)
+    plan = ck.shard_plan(0, n)
+    assert len(plan) == 8 and sum(t[2] for t in plan) == n
+    sv = nmx.ShardedVector.for_key(ck, sc)                  # W born on the shards that commit it (msm.rs:564-574)
+    for combine in (0, 2):
+        assert L.nmx_set_option(b"combine", combine) == 0
+        try:
+            assert pt(g.vartime_multiscalar_mul(sc, ck)) == exp
+            rec = _lib.profile_last_sharded()
+            assert len(rec["shards"]) == 8 and sorted(s["dev"] for s in rec["shards"]) == list(range(8))
+            assert rec["rccl_ranks"] == (1 if combine == 2 else 0)
+            assert pt(g.vartime_multiscalar_mul(sv, ck)) == exp
+            assert _branches(_lib) == ["shard_resident"] * 8
+            d = torch.from_numpy(sc).cuda()
+            assert pt(g.vartime_multiscalar_mul(d, ck)) == exp
+        finally:
+            assert L.nmx_set_option(b"combine", 0) == 0
+    # the reference's rule: per-chunk partial sums, then reduce(identity, +)
+    parts, off = [], 0
+    for _dev, _poff, cnt in plan:
+        parts.append(g.vartime_multiscalar_mul(sc[off:off + cnt], ck, offset=off, partial=True).xy)
+        off += cnt
+    assert pt(g.point_sum(parts)) == exp
+    sv.close()
     ck.close()
