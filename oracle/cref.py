@@ -8,6 +8,10 @@ import subprocess
 
 import numpy as np
 
+# the transcript's side of a sum-check round: (ctx, round polynomial coefficients, how many, challenge out) -> 0
+TRANSCRIPT_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_size_t,
+                                 ctypes.POINTER(ctypes.c_uint8))
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libnova_ref.so")
 _lib = None
@@ -53,6 +57,10 @@ def lib():
         L.ref_sumcheck_plain_sums.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, sz, vp]
         L.ref_lincomb_powers.argtypes = [ctypes.c_int, vp, vp, sz, vp, sz, vp]
         L.ref_mle_multi_evaluate.argtypes = [ctypes.c_int, vp, sz, sz, vp, vp]
+        L.ref_spmv_transposed.argtypes = [ctypes.c_int, vp, vp, vp, sz, sz, vp, vp]
+        L.ref_sumcheck_prove_cubic3.argtypes = [ctypes.c_int, vp, vp, sz, vp, vp, vp, TRANSCRIPT_FN, vp, vp, vp, vp]
+        L.ref_sumcheck_prove_quad_prod.argtypes = [ctypes.c_int, vp, sz, vp, vp, TRANSCRIPT_FN, vp, vp, vp, vp]
+        L.ref_sumcheck_prove_batch_eval.argtypes = [ctypes.c_int, vp, vp, vp, vp, vp, sz, TRANSCRIPT_FN, vp, vp, vp, vp]
         _lib = L
     return _lib
 
@@ -295,3 +303,83 @@ def mle_multi_evaluate(fid, zs, ell, r):
     out = np.zeros(32 * max(k, 1), dtype=np.uint8)
     lib().ref_mle_multi_evaluate(fid, ptrs, k, ell, pr, out.ctypes.data)
     return [out[32 * j: 32 * j + 32].tobytes() for j in range(k)]
+
+
+def spmv_transposed(fid, indptr, indices, data, rows, cols, rx):
+    """compute_eval_table_sparse's inner (src/spartan/mod.rs:506-512): out[col] = sum_row rx[row] * M[row, col]."""
+    ip = np.ascontiguousarray(indptr, dtype=np.uint64)
+    ix = np.ascontiguousarray(indices, dtype=np.uint64)
+    pd, _d = _buf(data)
+    px, _x = _buf(rx)
+    out = np.zeros(32 * max(cols, 1), dtype=np.uint8)
+    rc = lib().ref_spmv_transposed(fid, ip.ctypes.data, ix.ctypes.data, pd, rows, cols, px, out.ctypes.data)
+    assert rc == 0
+    return out[: 32 * cols].tobytes()
+
+
+def make_transcript(fn):
+    """Wrap fn(list of 32-byte coefficient strings) -> 32-byte challenge as the C callback of the sum-check provers (the same
+    callback type serves the product's nmx_sumcheck_prove_* entry points)."""
+    def cb(_ctx, coeffs, n, out):
+        try:
+            cs = [bytes(coeffs[32 * i: 32 * i + 32]) for i in range(n)]
+            ch = fn(cs)
+            ctypes.memmove(out, ch, 32)
+            return 0
+        except Exception:          # never let an exception cross the C frame
+            import traceback
+            traceback.print_exc()
+            return 1
+    return TRANSCRIPT_FN(cb)
+
+
+def sumcheck_prove_cubic3(fid, claim, taus, A, B, C, transcript):
+    """SumcheckProof::prove_cubic_with_three_inputs (src/spartan/sumcheck.rs:446-507).  Returns (polys [rounds][4], r [rounds],
+    claims [3]) as 32-byte strings; `transcript` = make_transcript(...)."""
+    tp, _t = _buf(taus)
+    nr = len(_t.reshape(-1)) // 32
+    ps = [_buf(x) for x in (claim, A, B, C)]
+    polys = np.zeros(128 * max(nr, 1), np.uint8)
+    r = np.zeros(32 * max(nr, 1), np.uint8)
+    cl = np.zeros(96, np.uint8)
+    rc = lib().ref_sumcheck_prove_cubic3(fid, ps[0][0], tp, nr, ps[1][0], ps[2][0], ps[3][0], transcript, None, polys.ctypes.data,
+                                         r.ctypes.data, cl.ctypes.data)
+    assert rc == 0
+    pb, rb, cb = polys.tobytes(), r.tobytes(), cl.tobytes()
+    return ([[pb[128 * j + 32 * i: 128 * j + 32 * i + 32] for i in range(4)] for j in range(nr)],
+            [rb[32 * j: 32 * j + 32] for j in range(nr)], [cb[32 * i: 32 * i + 32] for i in range(3)])
+
+
+def sumcheck_prove_quad_prod(fid, claim, num_rounds, A, B, transcript):
+    """SumcheckProof::prove_quad_prod (src/spartan/sumcheck.rs:199-249): (polys [rounds][3], r, [A(r), B(r)])."""
+    ps = [_buf(x) for x in (claim, A, B)]
+    nr = num_rounds
+    polys = np.zeros(96 * max(nr, 1), np.uint8)
+    r = np.zeros(32 * max(nr, 1), np.uint8)
+    cl = np.zeros(64, np.uint8)
+    rc = lib().ref_sumcheck_prove_quad_prod(fid, ps[0][0], nr, ps[1][0], ps[2][0], transcript, None, polys.ctypes.data,
+                                            r.ctypes.data, cl.ctypes.data)
+    assert rc == 0
+    pb, rb, cb = polys.tobytes(), r.tobytes(), cl.tobytes()
+    return ([[pb[96 * j + 32 * i: 96 * j + 32 * i + 32] for i in range(3)] for j in range(nr)],
+            [rb[32 * j: 32 * j + 32] for j in range(nr)], [cb[:32], cb[32:]])
+
+
+def sumcheck_prove_batch_eval(fid, claims, num_rounds, polys, eq_points, coeffs, transcript):
+    """SumcheckProof::prove_batch_eval (src/spartan/sumcheck.rs:251-353): (polys [max rounds][3], r, [P_i final])."""
+    k = len(polys)
+    nmax = max(num_rounds)
+    pp, _kp = _ptr_table(polys)
+    qp, _kq = _ptr_table(eq_points)
+    nr = (ctypes.c_size_t * k)(*num_rounds)
+    pc, _c = _buf(b"".join(claims) if isinstance(claims, (list, tuple)) else claims)
+    pw, _w = _buf(b"".join(coeffs) if isinstance(coeffs, (list, tuple)) else coeffs)
+    out_p = np.zeros(96 * max(nmax, 1), np.uint8)
+    r = np.zeros(32 * max(nmax, 1), np.uint8)
+    fin = np.zeros(32 * k, np.uint8)
+    rc = lib().ref_sumcheck_prove_batch_eval(fid, pc, nr, pp, qp, pw, k, transcript, None, out_p.ctypes.data, r.ctypes.data,
+                                             fin.ctypes.data)
+    assert rc == 0
+    pb, rb, fb = out_p.tobytes(), r.tobytes(), fin.tobytes()
+    return ([[pb[96 * j + 32 * i: 96 * j + 32 * i + 32] for i in range(3)] for j in range(nmax)],
+            [rb[32 * j: 32 * j + 32] for j in range(nmax)], [fb[32 * i: 32 * i + 32] for i in range(k)])

@@ -948,3 +948,338 @@ int ref_poly_suffix_horner(int field, const uint8_t* f, size_t n, const uint8_t*
   }
   return 0;
 }
+
+/* ======================================================================================================================
+ * Spartan's sum-check provers and compute_eval_table_sparse (round 5: BASELINE.json configs[4], the sum-check half).
+ * Restated from /root/reference/src/spartan/sumcheck.rs and src/spartan/mod.rs; the transcript (Keccak, src/provider/keccak.rs)
+ * is NOT restated: every prover takes a callback that plays `transcript.absorb(b"p", &poly); transcript.squeeze(b"c")`
+ * (sumcheck.rs:224-227,481-484,315-318) -- it receives the round polynomial's coefficients (UniPoly, little endian, canonical
+ * 32-byte elements) and returns the round challenge.  All vectors canonical in / out.  OpenMP over the N-scaling sums
+ * (the reference uses rayon there).
+ * ====================================================================================================================== */
+typedef int (*ref_transcript_fn)(void* ctx, const uint8_t* coeffs, size_t n_coeffs, uint8_t* challenge32);
+
+/* compute_eval_table_sparse's inner (src/spartan/mod.rs:506-512): M_evals[col] += rx[row] * val, i.e. out = M^T rx.
+ * rows = rx.len() = num_cons, out has `cols` entries (2 * num_vars in the caller). */
+int ref_spmv_transposed(int field, const uint64_t* indptr, const uint64_t* indices, const uint8_t* data, size_t rows, size_t cols,
+                        const uint8_t* rx, uint8_t* out) {
+  const field_t* F = field_by_id(field); if (!F) return -1;
+  fe* acc = (fe*)calloc(cols ? cols : 1, sizeof(fe));
+  for (size_t rw = 0; rw < rows; rw++) {
+    fe x; ld_mont(F, &x, rx + 32 * rw);
+    for (uint64_t k = indptr[rw]; k < indptr[rw + 1]; k++) {
+      fe d, t; ld_mont(F, &d, data + 32 * k);
+      fe_mul(F, &t, &x, &d); fe_add(F, &acc[indices[k]], &acc[indices[k]], &t);
+    }
+  }
+  for (size_t i = 0; i < cols; i++) st_canon(F, out + 32 * i, &acc[i]);
+  free(acc);
+  return 0;
+}
+
+static fe* load_vec_mont(const field_t* F, const uint8_t* v, size_t n) {
+  fe* o = (fe*)malloc((n ? n : 1) * sizeof(fe));
+#pragma omp parallel for num_threads(nthreads())
+  for (long i = 0; i < (long)n; i++) ld_mont(F, &o[i], v + 32 * i);
+  return o;
+}
+/* MultilinearPolynomial::bind_poly_var_top (src/spartan/polys/multilinear.rs:65-84), in place on Montgomery values */
+static void bind_top_fe(const field_t* F, fe* z, size_t len, const fe* r) {
+  size_t n = len / 2;
+#pragma omp parallel for num_threads(nthreads())
+  for (long i = 0; i < (long)n; i++) {
+    fe t; fe_sub(F, &t, &z[i + n], &z[i]); fe_mul(F, &t, r, &t); fe_add(F, &z[i], &z[i], &t);
+  }
+}
+static void fe_from_u64(const field_t* F, fe* r, uint64_t v) { fe t; memset(&t, 0, sizeof t); t.l[0] = v; fe_to_mont(F, r, &t); }
+static void fe_pow2(const field_t* F, fe* r, size_t e) { /* Scalar::from(2).pow_vartime([e]) */
+  fe two; fe_from_u64(F, &two, 2); *r = F->r1;
+  for (size_t i = 0; i < e; i++) fe_mul(F, r, r, &two);
+}
+/* UniPoly::evaluate (src/spartan/polys/univariate.rs:140-149) */
+static void unipoly_eval(const field_t* F, fe* out, const fe* coeffs, size_t n, const fe* r) {
+  fe eval = coeffs[0], power = *r, t;
+  for (size_t i = 1; i < n; i++) { fe_mul(F, &t, &power, &coeffs[i]); fe_add(F, &eval, &eval, &t); fe_mul(F, &power, &power, r); }
+  *out = eval;
+}
+/* transcript round trip: coefficients out (canonical), challenge in */
+static int ask_challenge(const field_t* F, ref_transcript_fn cb, void* ctx, const fe* coeffs, size_t n, fe* r, uint8_t* polys_out,
+                         uint8_t* r_out) {
+  uint8_t buf[4 * 32], ch[32];
+  for (size_t i = 0; i < n; i++) st_canon(F, buf + 32 * i, &coeffs[i]);
+  if (polys_out) memcpy(polys_out, buf, 32 * n);
+  if (cb(ctx, buf, n, ch) != 0) return -1;
+  if (r_out) memcpy(r_out, ch, 32);
+  ld_mont(F, r, ch);
+  return 0;
+}
+
+/* EqSumCheckInstance (src/spartan/sumcheck.rs:593-677) */
+typedef struct {
+  size_t init_num_vars, first_half, second_half, round;
+  fe* taus;
+  fe eval_eq_left;
+  fe** poly_eq_left;  size_t n_left;   /* poly_eq_left[i] has 2^i entries, i in [0, n_left) */
+  fe** poly_eq_right; size_t n_right;
+  fe *eq0, *eq_slope, *eq_m1;          /* eq_tau_0_a_inf */
+} eq_inst;
+/* compute_eq_polynomials (sumcheck.rs:612-632): result[i + 1] = [prev - prev * tau_i, prev * tau_i] */
+static fe** compute_eq_polynomials(const field_t* F, const fe* const* taus, size_t len) {
+  fe** res = (fe**)malloc((len + 1) * sizeof(fe*));
+  res[0] = (fe*)malloc(sizeof(fe)); res[0][0] = F->r1;
+  for (size_t i = 0; i < len; i++) {
+    size_t pl = (size_t)1 << i;
+    res[i + 1] = (fe*)malloc(2 * pl * sizeof(fe));
+    for (size_t j = 0; j < pl; j++) {
+      fe y; fe_mul(F, &y, &res[i][j], taus[i]);
+      res[i + 1][pl + j] = y;
+      fe_sub(F, &res[i + 1][j], &res[i][j], &y);
+    }
+  }
+  return res;
+}
+static eq_inst* eq_new(const field_t* F, const uint8_t* taus_le, size_t l) {
+  eq_inst* q = (eq_inst*)calloc(1, sizeof(eq_inst));
+  q->init_num_vars = l; q->first_half = l / 2; q->second_half = l - q->first_half; q->round = 1;
+  q->taus = load_vec_mont(F, taus_le, l);
+  q->eval_eq_left = F->r1;
+  /* left_taus = taus[..first_half].iter().skip(1).rev(); right_taus = taus[first_half..].iter().rev()  (:634-636) */
+  size_t nl = q->first_half > 0 ? q->first_half - 1 : 0, nr = q->second_half;
+  const fe** lt = (const fe**)malloc((nl + 1) * sizeof(fe*));
+  const fe** rt = (const fe**)malloc((nr + 1) * sizeof(fe*));
+  for (size_t i = 0; i < nl; i++) lt[i] = &q->taus[q->first_half - 1 - i];
+  for (size_t i = 0; i < nr; i++) rt[i] = &q->taus[l - 1 - i];
+  q->poly_eq_left = compute_eq_polynomials(F, lt, nl); q->n_left = nl + 1;
+  q->poly_eq_right = compute_eq_polynomials(F, rt, nr); q->n_right = nr + 1;
+  free(lt); free(rt);
+  q->eq0 = (fe*)malloc((l ? l : 1) * sizeof(fe)); q->eq_slope = (fe*)malloc((l ? l : 1) * sizeof(fe)); q->eq_m1 = (fe*)malloc((l ? l : 1) * sizeof(fe));
+  for (size_t i = 0; i < l; i++) {   /* (:643-652) eq(tau, 0), 2 tau - 1, eq(tau, -1) */
+    fe_sub(F, &q->eq0[i], &F->r1, &q->taus[i]);
+    fe_sub(F, &q->eq_slope[i], &q->taus[i], &q->eq0[i]);
+    fe_sub(F, &q->eq_m1[i], &q->eq0[i], &q->eq_slope[i]);
+  }
+  return q;
+}
+static void eq_free(eq_inst* q) {
+  for (size_t i = 0; i < q->n_left; i++) free(q->poly_eq_left[i]);
+  for (size_t i = 0; i < q->n_right; i++) free(q->poly_eq_right[i]);
+  free(q->poly_eq_left); free(q->poly_eq_right); free(q->taus); free(q->eq0); free(q->eq_slope); free(q->eq_m1); free(q);
+}
+static void eq_bound(const field_t* F, eq_inst* q, const fe* r) { /* (:1226-1231) */
+  fe t, u; const fe* tau = &q->taus[q->round - 1];
+  fe_sub(F, &t, &F->r1, tau); fe_sub(F, &t, &t, r); fe_mul(F, &u, r, tau); fe_dbl(F, &u, &u); fe_add(F, &t, &t, &u);
+  fe_mul(F, &q->eval_eq_left, &q->eval_eq_left, &t);
+  q->round++;
+}
+/* the eq factor of index id in the current round (:1233-1253) */
+static inline void eq_factor(const field_t* F, const eq_inst* q, size_t id, fe* fac) {
+  if (q->round < q->first_half) {
+    const fe* L = q->poly_eq_left[q->first_half - q->round];
+    const fe* R = q->poly_eq_right[q->second_half];
+    fe_mul(F, fac, &L[id >> q->second_half], &R[id & (((size_t)1 << q->second_half) - 1)]);
+  } else {
+    *fac = q->poly_eq_right[q->init_num_vars - q->round][id];
+  }
+}
+/* N-scaling sums of one round: which = 0: (t_0, t_inf) of evaluation_points_* (:918-958, :1052-1075); which = 1: t(-1), the
+ * third sum of the fallback_eval_inf_* paths (:1104-1130, :1204-1222).  mode 3: A*B - C; mode 1: A alone. */
+static void eq_round_sums(const field_t* F, const eq_inst* q, int mode, int which, const fe* A, const fe* B, const fe* C, size_t len,
+                          fe* o0, fe* o1) {
+  size_t h = len / 2;
+  int T = nthreads();
+  fe* part = (fe*)calloc(2 * (size_t)T, sizeof(fe));
+#pragma omp parallel num_threads(T)
+  {
+#ifdef _OPENMP
+    int t = omp_get_thread_num(), nt = omp_get_num_threads();
+#else
+    int t = 0, nt = 1;
+#endif
+    fe s0, s1; memset(&s0, 0, sizeof s0); memset(&s1, 0, sizeof s1);
+    for (size_t id = h * t / nt; id < h * (t + 1) / nt; id++) {
+      fe fac, x, y, e;
+      eq_factor(F, q, id, &fac);
+      if (which == 0) {
+        if (mode == 1) { fe_mul(F, &x, &A[id], &fac); fe_add(F, &s0, &s0, &x); continue; }
+        fe_mul(F, &e, &A[id], &B[id]); fe_sub(F, &e, &e, &C[id]);
+        fe_sub(F, &x, &A[id + h], &A[id]); fe_sub(F, &y, &B[id + h], &B[id]); fe_mul(F, &x, &x, &y);
+        fe_mul(F, &e, &e, &fac); fe_add(F, &s0, &s0, &e);
+        fe_mul(F, &x, &x, &fac); fe_add(F, &s1, &s1, &x);
+      } else {
+        fe ma, mb, mc;
+        fe_dbl(F, &ma, &A[id]); fe_sub(F, &ma, &ma, &A[id + h]);
+        if (mode == 1) { fe_mul(F, &x, &ma, &fac); fe_add(F, &s0, &s0, &x); continue; }
+        fe_dbl(F, &mb, &B[id]); fe_sub(F, &mb, &mb, &B[id + h]);
+        fe_dbl(F, &mc, &C[id]); fe_sub(F, &mc, &mc, &C[id + h]);
+        fe_mul(F, &e, &ma, &mb); fe_sub(F, &e, &e, &mc); fe_mul(F, &e, &e, &fac); fe_add(F, &s0, &s0, &e);
+      }
+    }
+    part[2 * t] = s0; part[2 * t + 1] = s1;
+  }
+  memset(o0, 0, sizeof *o0); if (o1) memset(o1, 0, sizeof *o1);
+  for (int t = 0; t < T; t++) { fe_add(F, o0, o0, &part[2 * t]); if (o1) fe_add(F, o1, o1, &part[2 * t + 1]); }
+  free(part);
+}
+/* evaluation_points_cubic_with_three_inputs (:900-970) / quadratic_with_one_input (:1039-1083): (s(0), cubic coeff, s(-1)) */
+static void eq_eval_points(const field_t* F, const eq_inst* q, int mode, const fe* A, const fe* B, const fe* C, size_t len, const fe* claim,
+                           fe* s0, fe* s_lead, fe* s_m1) {
+  fe t0, tinf; memset(&tinf, 0, sizeof tinf);
+  eq_round_sums(F, q, mode, 0, A, B, C, len, &t0, mode == 1 ? NULL : &tinf);
+  const fe *eq0 = &q->eq0[q->round - 1], *slope = &q->eq_slope[q->round - 1], *eqm1 = &q->eq_m1[q->round - 1];
+  const fe* p = &q->eval_eq_left;
+  fe l0p, l1p, t;
+  fe_mul(F, &l0p, eq0, p);
+  fe_add(F, &t, eq0, slope); fe_mul(F, &l1p, &t, p);
+  fe_mul(F, s0, &l0p, &t0);                                   /* s(0) = l(0) p t(0) */
+  if (mode == 1) memset(s_lead, 0, sizeof *s_lead);
+  else { fe_mul(F, s_lead, slope, p); fe_mul(F, s_lead, s_lead, &tinf); }
+  fe tm1;
+  if (!fe_is_zero(&l1p)) {                                     /* derive_from_claim_deg2 / _deg1 (:680-753) */
+    fe inv, s1, t1; fe_inv(F, &inv, &l1p);
+    fe_sub(F, &s1, claim, s0); fe_mul(F, &t1, &s1, &inv);
+    fe_dbl(F, &tm1, &t0);
+    if (mode != 1) { fe_dbl(F, &t, &tinf); fe_add(F, &tm1, &tm1, &t); }
+    fe_sub(F, &tm1, &tm1, &t1);                                /* t(-1) = 2 t(inf) + 2 t(0) - t(1) */
+  } else {                                                      /* tau = 0: the third N-scaling sum (:1085-1222) */
+    eq_round_sums(F, q, mode, 1, A, B, C, len, &tm1, NULL);
+  }
+  fe_mul(F, s_m1, eqm1, p); fe_mul(F, s_m1, s_m1, &tm1);
+}
+static fe two_inv(const field_t* F) { fe two, r; fe_from_u64(F, &two, 2); fe_inv(F, &r, &two); return r; }
+
+/* SumcheckProof::prove_cubic_with_three_inputs (src/spartan/sumcheck.rs:446-507).  A, B, C: 2^num_rounds canonical elements each
+ * (not modified: the reference binds its own copies in place).  out_polys: num_rounds x 4 coefficients (UniPoly, constant term
+ * first); out_r: the challenges; out_claims: [A(r), B(r), C(r)]. */
+int ref_sumcheck_prove_cubic3(int field, const uint8_t* claim, const uint8_t* taus, size_t num_rounds, const uint8_t* A, const uint8_t* B,
+                              const uint8_t* C, ref_transcript_fn cb, void* ctx, uint8_t* out_polys, uint8_t* out_r, uint8_t* out_claims) {
+  const field_t* F = field_by_id(field); if (!F) return -1;
+  size_t len = (size_t)1 << num_rounds;
+  fe *a = load_vec_mont(F, A, len), *b = load_vec_mont(F, B, len), *c = load_vec_mont(F, C, len);
+  eq_inst* q = eq_new(F, taus, num_rounds);
+  fe claim_per_round; ld_mont(F, &claim_per_round, claim);
+  const fe tinv = two_inv(F);
+  int rc = 0;
+  for (size_t j = 0; j < num_rounds && rc == 0; j++) {
+    fe s0, lead, sm1, s1;
+    eq_eval_points(F, q, 3, a, b, c, len, &claim_per_round, &s0, &lead, &sm1);
+    fe_sub(F, &s1, &claim_per_round, &s0);                     /* evals = [s0, claim - s0, lead, s(-1)] */
+    fe co[4], t;                                               /* UniPoly::from_evals_deg3 (univariate.rs:103-113) */
+    co[0] = s0; co[3] = lead;
+    fe_add(F, &t, &s1, &sm1); fe_mul(F, &co[2], &t, &tinv); fe_sub(F, &co[2], &co[2], &s0);      /* b = (s1 + s(-1)) / 2 - d */
+    fe_sub(F, &co[1], &s1, &lead); fe_sub(F, &co[1], &co[1], &s0); fe_sub(F, &co[1], &co[1], &co[2]);
+    fe r;
+    rc = ask_challenge(F, cb, ctx, co, 4, &r, out_polys ? out_polys + 128 * j : NULL, out_r ? out_r + 32 * j : NULL);
+    if (rc) break;
+    unipoly_eval(F, &claim_per_round, co, 4, &r);
+    bind_top_fe(F, a, len, &r); bind_top_fe(F, b, len, &r); bind_top_fe(F, c, len, &r); eq_bound(F, q, &r);
+    len /= 2;
+  }
+  if (rc == 0 && out_claims) { st_canon(F, out_claims, &a[0]); st_canon(F, out_claims + 32, &b[0]); st_canon(F, out_claims + 64, &c[0]); }
+  eq_free(q); free(a); free(b); free(c);
+  return rc;
+}
+
+/* SumcheckProof::prove_quad_prod (src/spartan/sumcheck.rs:199-249) with compute_eval_points_quad_prod (:163-186).
+ * out_polys: num_rounds x 3 coefficients; out_claims: [A(r), B(r)]. */
+int ref_sumcheck_prove_quad_prod(int field, const uint8_t* claim, size_t num_rounds, const uint8_t* A, const uint8_t* B, ref_transcript_fn cb,
+                                 void* ctx, uint8_t* out_polys, uint8_t* out_r, uint8_t* out_claims) {
+  const field_t* F = field_by_id(field); if (!F) return -1;
+  size_t len = (size_t)1 << num_rounds;
+  fe *a = load_vec_mont(F, A, len), *b = load_vec_mont(F, B, len);
+  fe claim_per_round; ld_mont(F, &claim_per_round, claim);
+  int rc = 0, T = nthreads();
+  fe* part = (fe*)calloc(2 * (size_t)T, sizeof(fe));
+  for (size_t j = 0; j < num_rounds && rc == 0; j++) {
+    size_t h = len / 2;
+    memset(part, 0, 2 * (size_t)T * sizeof(fe));
+#pragma omp parallel num_threads(T)
+    {
+#ifdef _OPENMP
+      int t = omp_get_thread_num(), nt = omp_get_num_threads();
+#else
+      int t = 0, nt = 1;
+#endif
+      fe s0, s1; memset(&s0, 0, sizeof s0); memset(&s1, 0, sizeof s1);
+      for (size_t i = h * t / nt; i < h * (t + 1) / nt; i++) {
+        fe x, da, db; fe_mul(F, &x, &a[i], &b[i]); fe_add(F, &s0, &s0, &x);
+        fe_sub(F, &da, &a[i + h], &a[i]); fe_sub(F, &db, &b[i + h], &b[i]); fe_mul(F, &x, &da, &db); fe_add(F, &s1, &s1, &x);
+      }
+      part[2 * t] = s0; part[2 * t + 1] = s1;
+    }
+    fe e0, bc; memset(&e0, 0, sizeof e0); memset(&bc, 0, sizeof bc);
+    for (int t = 0; t < T; t++) { fe_add(F, &e0, &e0, &part[2 * t]); fe_add(F, &bc, &bc, &part[2 * t + 1]); }
+    fe co[3], s1;                                              /* from_evals_deg2([e0, claim - e0, bc]) (univariate.rs:90-99) */
+    fe_sub(F, &s1, &claim_per_round, &e0);
+    co[0] = e0; co[2] = bc; fe_sub(F, &co[1], &s1, &bc); fe_sub(F, &co[1], &co[1], &e0);
+    fe r;
+    rc = ask_challenge(F, cb, ctx, co, 3, &r, out_polys ? out_polys + 96 * j : NULL, out_r ? out_r + 32 * j : NULL);
+    if (rc) break;
+    unipoly_eval(F, &claim_per_round, co, 3, &r);
+    bind_top_fe(F, a, len, &r); bind_top_fe(F, b, len, &r);
+    len = h;
+  }
+  if (rc == 0 && out_claims) { st_canon(F, out_claims, &a[0]); st_canon(F, out_claims + 32, &b[0]); }
+  free(part); free(a); free(b);
+  return rc;
+}
+
+/* SumcheckProof::prove_batch_eval (src/spartan/sumcheck.rs:251-353): k claims e_i = sum_x P_i(x) eq(x_i, x), polynomial i over
+ * num_rounds[i] variables.  polys[i]: 2^num_rounds[i] canonical elements; eq_points[i]: num_rounds[i] elements; coeffs: k
+ * elements.  out_polys: max-rounds x 3 coefficients; out_finals: [P_i(r_suffix)]. */
+int ref_sumcheck_prove_batch_eval(int field, const uint8_t* claims, const size_t* num_rounds, const uint8_t* const* polys,
+                                  const uint8_t* const* eq_points, const uint8_t* coeffs, size_t k, ref_transcript_fn cb, void* ctx,
+                                  uint8_t* out_polys, uint8_t* out_r, uint8_t* out_finals) {
+  const field_t* F = field_by_id(field); if (!F || k == 0) return -1;
+  size_t nmax = 0;
+  for (size_t i = 0; i < k; i++) if (num_rounds[i] > nmax) nmax = num_rounds[i];
+  fe** P = (fe**)malloc(k * sizeof(fe*));
+  eq_inst** Q = (eq_inst**)malloc(k * sizeof(eq_inst*));
+  size_t* len = (size_t*)malloc(k * sizeof(size_t));
+  fe *cl = load_vec_mont(F, claims, k), *run = load_vec_mont(F, claims, k), *co = load_vec_mont(F, coeffs, k);
+  for (size_t i = 0; i < k; i++) { len[i] = (size_t)1 << num_rounds[i]; P[i] = load_vec_mont(F, polys[i], len[i]); Q[i] = eq_new(F, eq_points[i], num_rounds[i]); }
+  fe e; memset(&e, 0, sizeof e);
+  for (size_t i = 0; i < k; i++) {                             /* (:281-289) e = sum claim_i 2^(nmax - n_i) coeff_i */
+    fe sc, t; fe_pow2(F, &sc, nmax - num_rounds[i]); fe_mul(F, &t, &cl[i], &sc); fe_mul(F, &t, &t, &co[i]); fe_add(F, &e, &e, &t);
+  }
+  const fe tinv = two_inv(F);
+  fe (*ev)[3] = (fe(*)[3])malloc(k * sizeof(fe[3]));
+  int rc = 0;
+  for (size_t round = 0; round < nmax && rc == 0; round++) {
+    size_t remaining = nmax - round;
+    for (size_t i = 0; i < k; i++) {
+      if (remaining <= num_rounds[i]) {                        /* (:301-305) */
+        fe lead; eq_eval_points(F, Q[i], 1, P[i], NULL, NULL, len[i], &run[i], &ev[i][0], &lead, &ev[i][2]);
+        memset(&ev[i][1], 0, sizeof(fe));
+      } else {                                                 /* not yet started: constant (:306-312) */
+        fe sc; fe_pow2(F, &sc, remaining - num_rounds[i] - 1); fe_mul(F, &ev[i][0], &sc, &cl[i]);
+        memset(&ev[i][1], 0, sizeof(fe)); ev[i][2] = ev[i][0];
+      }
+    }
+    fe c0, cm1, c1, qc, t; memset(&c0, 0, sizeof c0); memset(&cm1, 0, sizeof cm1);
+    for (size_t i = 0; i < k; i++) { fe_mul(F, &t, &ev[i][0], &co[i]); fe_add(F, &c0, &c0, &t); fe_mul(F, &t, &ev[i][2], &co[i]); fe_add(F, &cm1, &cm1, &t); }
+    fe_sub(F, &c1, &e, &c0);
+    fe_add(F, &qc, &c1, &cm1); fe_dbl(F, &t, &c0); fe_sub(F, &qc, &qc, &t); fe_mul(F, &qc, &qc, &tinv);   /* (S(1) + S(-1) - 2 S(0)) / 2 */
+    fe poly[3]; poly[0] = c0; poly[2] = qc; fe_sub(F, &poly[1], &c1, &qc); fe_sub(F, &poly[1], &poly[1], &c0);
+    fe r;
+    rc = ask_challenge(F, cb, ctx, poly, 3, &r, out_polys ? out_polys + 96 * round : NULL, out_r ? out_r + 32 * round : NULL);
+    if (rc) break;
+    for (size_t i = 0; i < k; i++) {
+      if (remaining <= num_rounds[i]) {
+        /* update_claim (:68-75) with evals = [e0, c3 = 0, em1]: a1 = (e1 - em1)/2 - c3, a2 = (e1 + em1)/2 - e0,
+         * claim' = e0 + r (a1 + r (a2 + r c3)) */
+        fe s0 = ev[i][0], sm1 = ev[i][2], s1, b2, cc[3];
+        fe_sub(F, &s1, &run[i], &s0);
+        fe_sub(F, &b2, &s1, &sm1); fe_mul(F, &cc[1], &b2, &tinv);
+        fe_add(F, &b2, &s1, &sm1); fe_mul(F, &cc[2], &b2, &tinv); fe_sub(F, &cc[2], &cc[2], &s0);
+        cc[0] = s0;
+        unipoly_eval(F, &run[i], cc, 3, &r);
+        bind_top_fe(F, P[i], len[i], &r); len[i] /= 2; eq_bound(F, Q[i], &r);
+      }
+    }
+    unipoly_eval(F, &e, poly, 3, &r);
+  }
+  if (rc == 0 && out_finals) for (size_t i = 0; i < k; i++) st_canon(F, out_finals + 32 * i, &P[i][0]);
+  for (size_t i = 0; i < k; i++) { free(P[i]); eq_free(Q[i]); }
+  free(P); free(Q); free(len); free(cl); free(run); free(co); free(ev);
+  return rc;
+}

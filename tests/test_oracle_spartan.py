@@ -1,0 +1,86 @@
+"""CPU: the oracle's restatement of Spartan's sum-check provers (oracle/nova_ref.c, round 5) against the reference's verifier
+and the definition of every round polynomial (tests/spartan_common.py), and its compute_eval_table_sparse inner against the
+reference's sparse-matrix known answer read transposed."""
+import numpy as np
+import pytest
+
+from oracle import cref
+from tests import fv_common as fc
+from tests import spartan_common as sp
+
+
+def o_cubic3(fid, claim, taus, A, B, C, tr):
+    return cref.sumcheck_prove_cubic3(fid, claim, taus, A, B, C, cref.make_transcript(tr))
+
+
+def o_quad(fid, claim, nr, A, B, tr):
+    return cref.sumcheck_prove_quad_prod(fid, claim, nr, A, B, cref.make_transcript(tr))
+
+
+def o_batch(fid, claims, nrs, polys, pts, coeffs, tr):
+    return cref.sumcheck_prove_batch_eval(fid, claims, nrs, [p.tobytes() for p in polys], [x.tobytes() for x in pts], coeffs,
+                                          cref.make_transcript(tr))
+
+
+@pytest.mark.parametrize("fid", [0, 1, 2, 3])
+@pytest.mark.parametrize("l", [1, 2, 3, 4, 5, 8])
+def test_cubic_with_three_inputs_against_the_verifier_and_the_definition(fid, l):
+    sp.check_cubic3(o_cubic3, fid, l, seed=300 + l)
+
+
+@pytest.mark.parametrize("l", [2, 3, 4, 5, 6])
+def test_cubic_fallback_when_tau_is_zero(l):
+    """tau_i = 0 makes l(1) = 0: derive_from_claim_deg2 returns None and the third N-scaling sum runs
+    (sumcheck.rs:695-697, 1085-1136); also a challenge that zeroes eval_eq_left for every later round (r = 1 after tau = 0:
+    1 - tau - r + 2 r tau = 0)."""
+    p = fc.FIELDS[1]
+    base = fc.ints(fc.rand_vec(1, l, 55))
+    for zero_at in range(l):
+        taus = list(base)
+        taus[zero_at] = 0
+        sp.check_cubic3(o_cubic3, 1, l, seed=400 + zero_at, taus=taus)
+        sp.check_cubic3(o_cubic3, 1, l, seed=500 + zero_at, taus=taus, force={zero_at: 1})
+    sp.check_cubic3(o_cubic3, 1, l, seed=77, taus=[0] * l)
+    sp.check_cubic3(o_cubic3, 1, l, seed=78, taus=[1] * l, force={0: 0, l - 1: p - 1})
+
+
+@pytest.mark.parametrize("fid", [0, 1, 2, 3])
+@pytest.mark.parametrize("l", [1, 2, 5, 9])
+def test_quad_prod(fid, l):
+    sp.check_quad_prod(o_quad, fid, l, seed=600 + l)
+    sp.check_quad_prod(o_quad, fid, l, seed=700 + l, force={0: 0, l - 1: 1})
+
+
+@pytest.mark.parametrize("fid", [1, 3])
+@pytest.mark.parametrize("nrs", [[4], [5, 5], [3, 6], [6, 3], [7, 2, 5], [1, 4]])
+def test_batch_eval_with_polynomials_of_different_sizes(fid, nrs):
+    sp.check_batch_eval(o_batch, fid, nrs, seed=800 + sum(nrs))
+
+
+def test_batch_eval_fallback_when_an_evaluation_point_has_a_zero():
+    p = fc.FIELDS[1]
+    sp.check_batch_eval(o_batch, 1, [4, 6], seed=900, force={0: 0, 3: 1, 5: p - 1})
+
+
+@pytest.mark.parametrize("fid", [0, 1, 2, 3])
+def test_transposed_product(fid):
+    k = sp.transposed_kat()
+    got = cref.spmv_transposed(fid, k["indptr"], k["indices"], fc.vec(k["data"]), k["rows"], k["cols"], fc.vec(k["x"]))
+    assert sp.ints(got) == k["out"]
+    p = fc.FIELDS[fid]
+    for rows, cols, seed in ((50, 30, 1), (300, 64, 2), (64, 300, 3)):
+        ip, ix, dt = sp.heavy_column_csr(fid, rows, cols, seed, heavy_cols=(0, cols - 1))
+        x = fc.edge_vectors(fid, rows, seed + 10)
+        got = cref.spmv_transposed(fid, ip, ix, dt, rows, cols, x)
+        assert sp.ints(got) == sp.dense_transposed(p, ip, ix, dt, cols, x)
+    # eval tables as snark.rs:181-190 uses them: M^T eq(r_x) == sum_row eq(r_x)[row] * M[row, :] and the identity the verifier
+    # relies on (snark.rs:325-338): sum_col (M^T eq(r_x))[col] * eq(r_y)[col] == sum_{row, col} eq_x[row] eq_y[col] M[row, col]
+    rows, cols = 32, 16
+    ip, ix, dt = fc.random_csr(fid, rows, cols, 9)
+    rx, ry = fc.rand_vec(fid, 5, 20), fc.rand_vec(fid, 4, 21)
+    ex = np.frombuffer(cref.eq_evals(fid, rx, 5), np.uint8).reshape(-1, 32)
+    ey = sp.ints(cref.eq_evals(fid, ry, 4))
+    t = sp.ints(cref.spmv_transposed(fid, ip, ix, dt, rows, cols, ex))
+    d, exi = sp.ints(dt), sp.ints(ex)
+    exp = sum(exi[r] * ey[int(ix[k])] * d[k] for r in range(rows) for k in range(int(ip[r]), int(ip[r + 1]))) % p
+    assert sum(a * b for a, b in zip(t, ey)) % p == exp
