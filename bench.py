@@ -122,7 +122,7 @@ def main():
                     help="hyperkzg replay: the three kzg_open commitments as one batch_commit (default), three host threads (the reference's par_iter), or one after the other")
     ap.add_argument("--separate-field-ops", action="store_true", help="prove_step replay: vec_add, 3 x SpMV, cross term and the two folds as separate (stream-ordered) calls")
     ap.add_argument("--sync-field-ops", action="store_true", help="prove_step replay: every field-vector call waits for its kernel (round 3's form)")
-    ap.add_argument("--workload", default="msm", choices=["msm", "axpy", "cross_term", "bind", "sumcheck3", "round3", "quad_prod", "lincomb8", "horner", "mle_eval", "spmv", "prove_step_replay", "hyperkzg_replay"],
+    ap.add_argument("--workload", default="msm", choices=["msm", "axpy", "cross_term", "bind", "sumcheck3", "round3", "quad_prod", "lincomb8", "horner", "mle_eval", "spmv", "prove_step_replay", "hyperkzg_replay", "spartan_replay"],
                     help="msm = the headline (default); the others time one HBM-bound field-vector kernel of "
                          "SURVEY.md 8(f) at 2^log2n elements per GPU")
     args = ap.parse_args()
@@ -172,6 +172,9 @@ def main():
     if args.workload == "hyperkzg_replay":
         assert world == 1
         return emit(hyperkzg_replay(args, torch), False, dist)
+    if args.workload == "spartan_replay":
+        assert world == 1
+        return emit(spartan_replay(args, torch), False, dist)
     if args.workload != "msm":
         return field_workload(args, world, rank, L, torch, dist)
 
@@ -744,6 +747,16 @@ def extras(out, args, torch, L, ck, host_scalars, dev_scalars):
     a3 = argparse.Namespace(**vars(args))
     a3.log2n, a3.steps, a3.warmup = 20, 3, 1
     hk = hyperkzg_replay(a3, torch, ck=ck)
+    # (5b) configs[4], the sum-check half: Spartan prove replay at num_cons = 2^20 (the three provers as one call each)
+    try:
+        a4 = argparse.Namespace(**vars(args))
+        a4.log2n, a4.steps, a4.warmup = 20, 3, 1
+        sr = spartan_replay(a4, torch)
+        out["spartan_replay_ms"] = {"ms": round(sr["value"], 3), "log2n": 20, "cpu_ms": round(sr["cpu_baseline"]["value"], 1),
+                                    "cpu_cores": sr["cpu_baseline"]["cores"], "gpu_matches_cpu": sr["cpu_baseline"]["gpu_matches_cpu"],
+                                    "breakdown_ms": sr["breakdown_ms"], "provers": sr["provers"], "what": sr["config"]["workload"]}
+    except Exception as e:                                 # never lose the headline to an auxiliary block
+        out["spartan_replay_ms"] = {"error": repr(e)}
     # (6) the field-vector kernels' rooflines (north_star: >= 40 % of HBM is about THESE kernels)
     try:
         out["fieldvec"] = fieldvec_block(args, torch, L)
@@ -1034,6 +1047,270 @@ def hyperkzg_replay(args, torch, ck=None):
                                           "single-threaded there)", "gpu_matches_cpu": ok}
     if own_ck:
         ck.close()
+    return outj
+
+
+def spartan_like_matrices(fid, n, seed):
+    """A, B, C of a padded Spartan shape (num_cons = num_vars = n, z = [W | u | X | 0...] of 2 n entries): minroot-like rows over
+    the live columns [0, n + 2), and -- what a real R1CS matrix has and uniformly random columns lack -- the constant column
+    (index n, the `u` entry of z) in one row in eight of A: a column of ~n/8 entries that the transposed product must split."""
+    mats = minroot_like_matrices(fid, n, n + 2, seed)
+    ip, ix, dt = mats[0]
+    rng = np.random.Generator(np.random.PCG64(seed + 7))
+    heavy = rng.random(len(ix)) < 0.125
+    ix = ix.copy()
+    ix[heavy] = n
+    mats[0] = (ip, ix, dt)
+    return mats
+
+
+SPARTAN_SEED = 2025
+
+
+def spartan_instance(fid, ell, seed=None):
+    """Host data of the replayed instance: the three matrices, W (witness-like), u, one public input, z = [W | u | X | 0...]."""
+    from tests import util
+    n = 1 << ell
+    cid = {1: 0, 0: 1, 3: 2, 2: 3}[fid]
+    csr = spartan_like_matrices(fid, n, seed=(700 + ell) if seed is None else seed)
+    hW = witness_like(cid, n, 71)
+    u, x0 = util.random_scalars(cid, 1, seed=73), util.random_scalars(cid, 1, seed=74)
+    hz = np.zeros((2 * n, 32), np.uint8)
+    hz[:n], hz[n], hz[n + 1] = hW, u[0], x0[0]
+    return csr, hW, u, hz
+
+
+def spartan_sequence(be, ell, p, u, call=lambda name, fn: fn()):
+    """The provider calls of `RelaxedR1CSSNARK::prove` up to the evaluation argument, in the reference's order
+    (src/spartan/snark.rs:133-233), against a provider `be` (the HIP path or the oracle behind one interface)."""
+    from tests import standin
+    le = lambda v: int(v).to_bytes(32, "little")
+    num = lambda b: int.from_bytes(bytes(b), "little")
+    tr = standin.Transcript(seed=SPARTAN_SEED)
+    tau = [tr.squeeze() for _ in range(ell)]                                  # snark.rs:141-143
+    zc = call("z_concat", lambda: be.clone(be.z))                             # :133
+    Az, Bz, Cz = (call("spmv_x3", lambda j=j: be.spmv(j, zc)) for j in range(3))        # :146
+    uCzE = call("uCz_E", lambda: be.axpy(be.E, Cz, u))                        # :147-149
+    outer = call("sumcheck_outer", lambda: be.cubic3(le(0), b"".join(tau), Az, Bz, uCzE, tr))     # :158-165
+    r_x = outer[1]
+    claim_Az, claim_Bz = outer[2][0], outer[2][1]
+    claim_Cz, eval_E = call("evaluate_Cz_E", lambda: be.multi_evaluate([Cz, be.E], b"".join(r_x)))  # :169-170
+    tr.absorb(claim_Az + claim_Bz + claim_Cz + eval_E)                         # :171-174
+    r = tr.squeeze()                                                           # :177
+    rr = num(r)
+    claim_inner = (num(claim_Az) + rr * num(claim_Bz) + rr * rr * num(claim_Cz)) % p
+    evals_rx = call("eq_evals", lambda: be.eq_evals(b"".join(r_x)))            # :182
+    eA, eB, eC = (call("spmv_T_x3", lambda j=j: be.spmv_t(j, evals_rx)) for j in range(3))   # :184
+    ABC = call("poly_ABC", lambda: be.axpy2(eA, eB, eC, r))                    # :188-190
+    inner = call("sumcheck_inner", lambda: be.quad(le(claim_inner), ell + 1, ABC, zc, tr))   # :199-205
+    r_y = inner[1]
+    eval_W = call("evaluate_W", lambda: be.evaluate(be.W, b"".join(r_y[1:])))  # :215
+    tr.absorb(eval_W)
+    rho = tr.squeeze()                                                         # spartan/mod.rs:395
+    Wc, Ec = call("clone_W_E", lambda: (be.clone(be.W), be.clone(be.E)))       # spartan/mod.rs:407-410
+    batch = call("sumcheck_batch", lambda: be.batch([eval_W, eval_E], [ell, ell], [Wc, Ec], [b"".join(r_y[1:]), b"".join(r_x)],
+                                                    [le(1), rho], tr))         # spartan/mod.rs:414-421
+    tr.absorb(b"".join(batch[2]))
+    c = tr.squeeze()                                                           # spartan/mod.rs:425
+    w_joint = call("batch_witness", lambda: be.lincomb([be.W, be.E], c))       # spartan/mod.rs:429
+    return {"outer": outer, "inner": inner, "batch": batch, "evaluations": (claim_Cz, eval_E, eval_W), "batch_witness": be.host(w_joint),
+            "tau": tau, "r": r, "rho": rho}
+
+
+def spartan_verify(p, u, res):
+    """The reference's verifier equations on a replayed proof (snark.rs:276-289 outer, :303-345 inner with the prover's own
+    evaluations of ABC and z standing in for the verifier's matrix evaluations, spartan/mod.rs:440-470 batch)."""
+    from tests import spartan_common as spc
+    num = lambda b: int.from_bytes(bytes(b), "little")
+    ival = lambda rows: [[num(c) for c in row] for row in rows]
+    tau_i = [num(t) for t in res["tau"]]
+    rx_i, ry_i, rb_i = ([num(r) for r in res[k][1]] for k in ("outer", "inner", "batch"))
+    cAz, cBz, cT = (num(c) for c in res["outer"][2])
+    claim_Cz, eval_E, eval_W = (num(c) for c in res["evaluations"])
+    e_out = spc.verify_rounds(p, 0, ival(res["outer"][0]), rx_i, 3)
+    ok_outer = e_out == spc.eq_eval(p, tau_i, rx_i) * (cAz * cBz - cT) % p and cT == (num(u.tobytes()) * claim_Cz + eval_E) % p
+    rr = num(res["r"])
+    e_in = spc.verify_rounds(p, (cAz + rr * cBz + rr * rr * claim_Cz) % p, ival(res["inner"][0]), ry_i, 2)
+    ok_inner = e_in == num(res["inner"][2][0]) * num(res["inner"][2][1]) % p
+    rho = num(res["rho"])
+    e_b = spc.verify_rounds(p, (eval_W + rho * eval_E) % p, ival(res["batch"][0]), rb_i, 2)
+    fW, fE = (num(c) for c in res["batch"][2])
+    ok_batch = e_b == (spc.eq_eval(p, ry_i[1:], rb_i) * fW + rho * spc.eq_eval(p, rx_i, rb_i) * fE) % p
+    return {"proof_verifies_outer": ok_outer, "proof_verifies_inner": ok_inner, "proof_verifies_batch": ok_batch}
+
+
+class SpartanCpu:
+    """the oracle behind spartan_sequence's provider interface (the checker / cpu_baseline leg)"""
+
+    def __init__(self, fid, csr, n, hW, hE, hz):
+        from oracle import cref
+        self.cref, self.fid, self.csr, self.n, self.W, self.E, self.z = cref, fid, csr, n, hW, hE, hz
+
+    def _np(self, b, m):
+        return np.frombuffer(b, np.uint8).reshape(m, 32)
+
+    def clone(self, v):
+        return v.copy()
+
+    def spmv(self, j, v):
+        return self._np(self.cref.spmv(self.fid, *self.csr[j], self.n, v), self.n)
+
+    def spmv_t(self, j, v):
+        return self._np(self.cref.spmv_transposed(self.fid, *self.csr[j], self.n, 2 * self.n, v), 2 * self.n)
+
+    def axpy(self, a, b, r):
+        return self._np(self.cref.field_axpy(self.fid, a, b, r, len(a)), len(a))
+
+    def axpy2(self, a, b, c, r):
+        return self._np(self.cref.field_axpy2(self.fid, a, b, c, r, len(a)), len(a))
+
+    def multi_evaluate(self, zs, r):
+        return self.cref.mle_multi_evaluate(self.fid, [z.tobytes() for z in zs], len(r) // 32, r)
+
+    def evaluate(self, z, r):
+        return self.cref.mle_evaluate(self.fid, z, len(r) // 32, r)
+
+    def eq_evals(self, r):
+        return self._np(self.cref.eq_evals(self.fid, r, len(r) // 32), 1 << (len(r) // 32))
+
+    def lincomb(self, vs, s):
+        return self.cref.lincomb_powers(self.fid, [v.tobytes() for v in vs], s, max(len(v) for v in vs))
+
+    def host(self, v):
+        return bytes(v)
+
+    def cubic3(self, claim, taus, A, B, C, tr):
+        return self.cref.sumcheck_prove_cubic3(self.fid, claim, taus, A, B, C, tr.fn(self.cref.TRANSCRIPT_FN), ctx=tr.ctx)
+
+    def quad(self, claim, nr, A, B, tr):
+        return self.cref.sumcheck_prove_quad_prod(self.fid, claim, nr, A, B, tr.fn(self.cref.TRANSCRIPT_FN), ctx=tr.ctx)
+
+    def batch(self, claims, nrs, polys, pts, coeffs, tr):
+        return self.cref.sumcheck_prove_batch_eval(self.fid, claims, nrs, [q.tobytes() for q in polys], pts, coeffs,
+                                                   tr.fn(self.cref.TRANSCRIPT_FN), ctx=tr.ctx)
+
+
+def spartan_replay(args, torch):
+    """REPLAY of the provider-side work of `RelaxedR1CSSNARK::prove` up to the evaluation argument (src/spartan/snark.rs:113-260;
+    BASELINE.json configs[4], the sum-check half -- the HyperKZG half is `hyperkzg_replay`) for num_cons = num_vars = 2^log2n on
+    BN254's scalar field, every vector resident in HBM, in the reference's order (spartan_sequence):
+      z = [W, u, X] (:133)                                              one device copy (the reference's concat)
+      Az, Bz, Cz = S.multiply_vec(z) (:146)                             3 x nmx_spmv_apply
+      uCz_E = u Cz + E (:147-149)                                       nmx_field_axpy
+      outer sum-check, prove_cubic_with_three_inputs (:158-165)         ONE call: nmx_sumcheck_prove_cubic_with_three_inputs
+      claim_Cz = Cz(r_x), eval_E = E(r_x) (:169-170)                    nmx_mle_multi_evaluate
+      evals_rx = eq(r_x, .) (:182); compute_eval_table_sparse (:184)    nmx_eq_evals_from_points + 3 x nmx_spmv_apply_transposed
+      poly_ABC = A + r B + r^2 C (:188-190)                             nmx_field_axpy2
+      inner sum-check, prove_quad_prod over (poly_ABC, z) (:199-205)    ONE call: nmx_sumcheck_prove_quad_prod
+      eval_W = W(r_y[1..]) (:215)                                       nmx_mle_evaluate
+      batch_eval_reduce (:232-233; src/spartan/mod.rs:377-437): prove_batch_eval over clones of W and E, then W + c E
+                                                                        ONE call: nmx_sumcheck_prove_batch_eval, nmx_field_lincomb_powers
+    The instance is SATISFIED (E := Az o Bz - u Cz, built with the product's own kernels), so the replayed proof verifies: the
+    reference's verifier equations are checked on it (spartan_verify).  NOT replayed: the Keccak transcript -- a native stand-in
+    (tests/standin) answers the provers' per-round callback and the squeezes between them, on both sides alike --, the
+    commitment side of batch_eval_reduce (a two-term group combination) and EE::prove.  A replay, not `prove`: the Rust
+    reference cannot be built here."""
+    import ctypes
+    from nova_amd import _lib, fieldvec as fv
+    ell = args.log2n
+    n = 1 << ell
+    fid = fv.SCALAR_FIELD_OF_CURVE[0]
+    p = util_modulus(fid)
+    L = _lib.lib()
+    csr, hW, u, hz = spartan_instance(fid, ell)
+    mats = [fv.SparseMatrix(fid, ip, ix, dt, 2 * n) for ip, ix, dt in csr]
+    dW, dz = (torch.from_numpy(v).cuda() for v in (hW, hz))
+    dE = fv.r1cs_cross_term(mats[0], mats[1], mats[2], dz, None, torch.zeros((n, 32), dtype=torch.uint8, device="cuda"), u)
+    hE = dE.cpu().numpy()
+    spans, prof = None, None
+
+    def call(name, fn):
+        if spans is None:
+            return fn()
+        t = time.perf_counter()
+        v = fn()
+        spans.setdefault(name, []).append(time.perf_counter() - t)
+        if prof is not None and name.startswith("sumcheck"):
+            buf = (ctypes.c_float * 8)()
+            if L.nmx_profile_last(buf, 8) >= 6:
+                prof.setdefault(name, []).append([buf[i] for i in range(6)])
+        return v
+
+    class Gpu:
+        W, E, z = dW, dE, dz
+        clone = staticmethod(lambda v: v.clone())
+        spmv = staticmethod(lambda j, v: mats[j].multiply_vec(v, async_=True))
+        spmv_t = staticmethod(lambda j, v: mats[j].multiply_vec_transposed(v, async_=True))
+        axpy = staticmethod(lambda a, b, r: fv.axpy(fid, a, b, r, async_=True))
+        axpy2 = staticmethod(lambda a, b, c, r: fv.axpy2(fid, a, b, c, r, async_=True))
+        multi_evaluate = staticmethod(lambda zs, r: fv.mle_multi_evaluate(fid, zs, r))
+        evaluate = staticmethod(lambda z, r: fv.mle_evaluate(fid, z, r))
+        eq_evals = staticmethod(lambda r: fv.eq_evals_from_points(fid, r, device=True))
+        lincomb = staticmethod(lambda vs, s: fv.lincomb_powers(fid, vs, s))
+        host = staticmethod(lambda v: v.cpu().numpy().tobytes())
+
+        @staticmethod
+        def cubic3(claim, taus, A, B, C, tr):
+            return fv.sumcheck_prove_cubic_with_three_inputs(fid, claim, taus, A, B, C, tr.fn(_lib.TRANSCRIPT_FN), ctx=tr.ctx)
+
+        @staticmethod
+        def quad(claim, nr, A, B, tr):
+            return fv.sumcheck_prove_quad_prod(fid, claim, nr, A, B, tr.fn(_lib.TRANSCRIPT_FN), ctx=tr.ctx)
+
+        @staticmethod
+        def batch(claims, nrs, polys, pts, coeffs, tr):
+            return fv.sumcheck_prove_batch_eval(fid, claims, nrs, polys, pts, coeffs, tr.fn(_lib.TRANSCRIPT_FN), ctx=tr.ctx)
+
+    for _ in range(args.warmup):
+        spartan_sequence(Gpu, ell, p, u)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = spartan_sequence(Gpu, ell, p, u)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    # the same sequence with every provider call timed on its own and the provers' own split (profiling on): per prover
+    # [total ms, waiting for a round's result (GPU + latency), host algebra, transcript callback, launches, rounds]
+    spans, prof = {}, {}
+    L.nmx_set_profiling(1)
+    passes = 3
+    for _ in range(passes):
+        spartan_sequence(Gpu, ell, p, u, call)
+    L.nmx_set_profiling(0)
+    breakdown = {k: round(sum(v) / passes * 1e3, 4) for k, v in sorted(spans.items())}
+    breakdown["_sum"] = round(sum(breakdown.values()), 4)
+    provers = {k: {"ms": round(float(np.mean([q[0] for q in v])), 4), "wait_ms": round(float(np.mean([q[1] for q in v])), 4),
+                   "host_algebra_ms": round(float(np.mean([q[2] for q in v])), 4), "transcript_ms": round(float(np.mean([q[3] for q in v])), 4),
+                   "launches": int(v[-1][4]), "rounds": int(v[-1][5])} for k, v in prof.items()}
+    spans, prof = None, None
+    outj = {
+        "metric": "Spartan RelaxedR1CSSNARK prove (sum-check half) provider-call REPLAY ms (BN254 Fr)", "value": dt * 1e3, "unit": "ms",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": False, "scaling": "weak",
+        "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+        "config": {"workload": f"Spartan prove replay, num_cons = num_vars = 2^{ell}: 3 SpMV, outer cubic sum-check ({ell} rounds, one call), "
+                               f"2 evaluations, eq table, 3 transposed SpMV, inner quad_prod sum-check ({ell + 1} rounds, one call), 1 evaluation, "
+                               f"batch_eval sum-check over W and E ({ell} rounds, one call), batch witness (BASELINE.json configs[4], sum-check half); "
+                               "stand-in transcript",
+                   "rounds": [ell, ell + 1, ell]},
+        "roofline": None, "breakdown_ms": breakdown, "provers": provers,
+        "proof_verifies": spartan_verify(p, u, res),
+    }
+    if not args.no_cpu_baseline:
+        from oracle import cref
+        threads = effective_cpus()
+        cref.set_threads(threads)
+        cpu = SpartanCpu(fid, csr, n, hW, hE, hz)
+        t1 = time.perf_counter()
+        exp = spartan_sequence(cpu, ell, p, u)
+        t_cpu = time.perf_counter() - t1
+        checks = {k: res[k] == exp[k] for k in ("outer", "inner", "batch", "evaluations", "batch_witness")}
+        checks.update(outj["proof_verifies"])
+        outj["cpu_baseline"] = {"value": t_cpu * 1e3, "unit": "ms", "cores": threads, "kind": "port",
+                                "sample": "the same call sequence once through oracle/nova_ref.c (OpenMP over the N-scaling sums; the "
+                                          "transposed product, evaluations and batch witness are single-threaded there)",
+                                "gpu_matches_cpu": all(checks.values()), "checks": checks}
+    for m in mats:
+        m.close()
     return outj
 
 

@@ -363,6 +363,39 @@ int nmx_sumcheck_bind_eq_sums(int field, int mode, const void* A, const void* B,
  * out96 = three field elements (the third is zero for kinds 1-3), host pointer, in the vectors' own form. */
 int nmx_sumcheck_plain_sums(int field, int kind, const void* A, const void* B, const void* C, size_t len, uint32_t flags,
                             uint8_t* out96);
+/* ---- Spartan's sum-check provers, ONE call each (BASELINE.json configs[4]; src/spartan/snark.rs:113-260) -------------------
+ * A sum-check round is a streaming pass whose size halves every round, followed by a challenge only the host's transcript can
+ * produce; at 2^20 the passes are ~0.1 ms and the rest is per-round latency.  So the round LOOP lives behind the boundary: the
+ * tables (HBM-resident, NMX_SCALARS_DEVICE required) are bound in place, the bind of a round is fused with the next round's
+ * sums, results reach the host through a polled mailbox in pinned memory, rounds that fit one block are one launch, and the
+ * O(1) algebra of a round (derive_from_claim_deg2/1, UniPoly::from_evals_deg3/2, evaluate, EqSumCheckInstance::bound --
+ * src/spartan/sumcheck.rs:680-753, 1226-1231, polys/univariate.rs:90-149) runs in the library.  The one thing that stays on the
+ * caller's side is the transcript step `transcript.absorb(b"p", &poly); transcript.squeeze(b"c")` (sumcheck.rs:224-227,
+ * 481-484, 315-318): the callback receives the round polynomial as UniPoly coefficients (constant term first; the shim builds
+ * `UniPoly { coeffs }`, whose to_transcript_bytes drops the linear term itself) and returns the challenge; elements in the
+ * vectors' own form (NMX_SCALARS_MONT as everywhere).  A non-zero return aborts the proof (NMX_E_ARG); a challenge >= p is
+ * NMX_E_SCALAR_RANGE.  Outputs (any may be NULL): out_polys = rounds x n_coeffs x 32 bytes (what SumcheckProof compresses),
+ * out_r = rounds x 32 (the challenges), final evaluations as listed.  option "sc_poll_us": how long a round's mailbox is
+ * polled before the stream is synchronised instead (default 2000; 0: always synchronise).
+ *  - nmx_sumcheck_prove_cubic_with_three_inputs == SumcheckProof::prove_cubic_with_three_inputs (sumcheck.rs:446-507) with its
+ *    EqSumCheckInstance (sumcheck.rs:593-1253; all sqrt-size eq tables built by one launch): A, B, C of 2^num_rounds elements,
+ *    taus = num_rounds elements (host), 4 coefficients per round, out_claims = [A(r), B(r), C(r)].  A tau of zero (or a
+ *    challenge that zeroes eq's running product) takes the reference's third-sum fallback (sumcheck.rs:1085-1136).
+ *  - nmx_sumcheck_prove_quad_prod == prove_quad_prod (sumcheck.rs:199-249): A, B of 2^num_rounds elements, 3 coefficients per
+ *    round, out_claims = [A(r), B(r)].
+ *  - nmx_sumcheck_prove_batch_eval == prove_batch_eval (sumcheck.rs:251-353; batch_eval_reduce, src/spartan/mod.rs:377-437):
+ *    k <= 16 claims e_i = P_i(x_i), polys[i] of 2^num_rounds[i] elements (BOUND IN PLACE: the reference binds clones,
+ *    spartan/mod.rs:407-410 -- pass copies to keep the originals), eq_points[i] = num_rounds[i] elements (host), claims and
+ *    coeffs = k elements each (host), 3 coefficients per round over max(num_rounds) rounds, out_finals = [P_i(r_i)]. */
+typedef int (*nmx_transcript_fn)(void* ctx, const uint8_t* coeffs32, size_t n_coeffs, uint8_t* challenge32_out);
+int nmx_sumcheck_prove_cubic_with_three_inputs(int field, const void* claim, const void* taus, size_t num_rounds, void* A, void* B,
+                                               void* C, uint32_t flags, nmx_transcript_fn transcript, void* ctx, uint8_t* out_polys,
+                                               uint8_t* out_r, uint8_t* out_claims);
+int nmx_sumcheck_prove_quad_prod(int field, const void* claim, size_t num_rounds, void* A, void* B, uint32_t flags,
+                                 nmx_transcript_fn transcript, void* ctx, uint8_t* out_polys, uint8_t* out_r, uint8_t* out_claims);
+int nmx_sumcheck_prove_batch_eval(int field, const void* claims, const size_t* num_rounds, void* const* polys,
+                                  const void* const* eq_points, const void* coeffs, size_t k, uint32_t flags,
+                                  nmx_transcript_fn transcript, void* ctx, uint8_t* out_polys, uint8_t* out_r, uint8_t* out_finals);
 /* PolyEvalWitness::batch / batch_diff_size (src/spartan/mod.rs:165-277): out[i] = sum_j s^j * vecs[j][i], i < n_out,
  * vectors shorter than n_out read as zero-padded; every lens[j] <= n_out.  `vecs`, `lens`, `s` are host arrays; the
  * vectors themselves and `out` follow NMX_SCALARS_DEVICE. */
@@ -408,6 +441,11 @@ int nmx_r1cs_cross_term(uint64_t A, uint64_t B, uint64_t C, const void* z1, cons
                         const void* u, uint32_t flags, void* out);
 int nmx_nifs_fold(int field, const void* w1, const void* w2, size_t n_w, const void* e1, const void* t, size_t n_e, const void* r,
                   uint32_t flags, void* w, void* e);
+/* compute_eval_table_sparse's product (src/spartan/mod.rs:497-533: `M_evals[col] += rx[row] * val` over every entry), i.e.
+ * out[cols] = M^T * x with x_len == rows -- Spartan's inner sum-check needs it for A, B and C with x = eq(r_x, .)
+ * (src/spartan/snark.rs:181-190).  The transposed form (CSC cut into lanes; a column as long as the constant-one column of an
+ * R1CS matrix is split so that no lane walks it alone) is built from the resident matrix on the first call and kept with it. */
+int nmx_spmv_apply_transposed(uint64_t handle, const void* x, size_t x_len, uint32_t flags, void* out);
 /* (M*z1, M*z2) in one pass over the matrix: PrecomputedSparseMatrix::multiply_vec_pair (src/r1cs/sparse.rs:215-229) */
 int nmx_spmv_apply_pair(uint64_t handle, const void* z1, const void* z2, size_t z_len, uint32_t flags, void* out1,
                         void* out2);

@@ -22,6 +22,10 @@ E_ARG, E_NO_DEVICE, E_HIP, E_SCALAR_RANGE, E_SMALL_RANGE, E_HANDLE, E_TOO_LARGE 
 E_IO, E_FORMAT, E_POINT = -8, -9, -10
 BITS_AUTO = 0xFFFFFFFF
 
+# nmx_transcript_fn: (ctx, round polynomial coefficients, how many, challenge out) -> 0
+TRANSCRIPT_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_size_t,
+                                 ctypes.POINTER(ctypes.c_uint8))
+
 _lib = None
 
 
@@ -101,6 +105,10 @@ def lib():
     L.nmx_sumcheck_bind_eq_sums.argtypes = [i, i, vp, vp, vp, sz, vp, vp, sz, vp, sz, u32, u32, vp, vp, vp, vp]
     L.nmx_field_lincomb_powers.argtypes = [i, vp, vp, sz, vp, sz, u32, vp]
     L.nmx_mle_multi_evaluate.argtypes = [i, vp, sz, sz, vp, sz, u32, vp]
+    L.nmx_spmv_apply_transposed.argtypes = [u64, vp, sz, u32, vp]
+    L.nmx_sumcheck_prove_cubic_with_three_inputs.argtypes = [i, vp, vp, sz, vp, vp, vp, u32, TRANSCRIPT_FN, vp, vp, vp, vp]
+    L.nmx_sumcheck_prove_quad_prod.argtypes = [i, vp, sz, vp, vp, u32, TRANSCRIPT_FN, vp, vp, vp, vp]
+    L.nmx_sumcheck_prove_batch_eval.argtypes = [i, vp, vp, vp, vp, vp, sz, u32, TRANSCRIPT_FN, vp, vp, vp, vp]
     L.nmx_set_profiling.argtypes = [i]
     L.nmx_profile_last.argtypes = [ctypes.POINTER(ctypes.c_float), i]
     L.nmx_set_window_bits.argtypes = [u32]

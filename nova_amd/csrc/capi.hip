@@ -41,6 +41,11 @@ Global::SparseSet::~SparseSet() {
   if (indices) (void)hipFree(indices);
   if (data) (void)hipFree(data);
 }
+Global::SparseSet::Transposed::~Transposed() {
+  (void)hipSetDevice(G.device);
+  for (uint32_t* q : {vptr, indices, data, vout, hrow, hstart})
+    if (q) (void)hipFree(q);
+}
 void note_table_fallback() { stat_add(NMX_STAT_TABLE_FALLBACKS); }
 void note_scan_timeout() { stat_add(NMX_STAT_SCAN_TIMEOUTS); }
 // What one dependent few-wave launch costs on this box: 16 one-wave kernels chained on a stream between two events, best of
@@ -159,6 +164,7 @@ static void ensure_init() {
   if (const char* t = getenv("NMX_TUNE_HIST_GRID")) G.hist_grid = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_HIST_BS")) G.hist_bs = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_SYNC_SPIN_US")) G.sync_spin_us = (uint32_t)atoi(t);
+  if (const char* t = getenv("NMX_SC_POLL_US")) G.sc_poll_us = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_HORNER_TOP")) G.horner_top = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_HORNER_SUB")) G.horner_sub = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_HORNER_ORDER")) G.horner_order = atoi(t) ? 1u : 0u;
@@ -1214,6 +1220,7 @@ int nmx_shutdown(void) {
       if (c->arena) (void)hipFree(c->arena);
       if (c->aux) (void)hipFree(c->aux);
       if (c->pinned) (void)hipHostFree(c->pinned);
+      if (c->mail) (void)hipHostFree(c->mail);
       if (c->have_ev)
         for (int i = 0; i < kMaxMarks; i++) (void)hipEventDestroy(c->ev[i]);
       if (c->async_ev) (void)hipEventDestroy(c->async_ev);
@@ -2261,6 +2268,127 @@ int nmx_spmv_apply(uint64_t handle, const void* z, size_t z_len, uint32_t flags,
   });
 }
 
+// M^T in virtual rows, built once per matrix from the resident CSR (Global::SparseSet::Transposed): counting sort of the entries
+// by column on the host, columns longer than 64 entries cut into chunks of max(64, sqrt(length))
+static std::shared_ptr<Global::SparseSet::Transposed> transposed_of(Ctx& c, Global::SparseSet& ss) {
+  std::lock_guard<std::mutex> lk(ss.t_mu);
+  if (ss.tr) return ss.tr;
+  const size_t rows = ss.rows, cols = ss.cols, nnz = ss.nnz;
+  std::vector<uint32_t> ip(rows + 1), ix(nnz ? nnz : 1);
+  std::vector<uint8_t> dt((nnz ? nnz : 1) * 32);
+  HIPCHK(hipMemcpyAsync(ip.data(), ss.indptr, (rows + 1) * 4, hipMemcpyDeviceToHost, c.stream));
+  if (nnz) {
+    HIPCHK(hipMemcpyAsync(ix.data(), ss.indices, nnz * 4, hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipMemcpyAsync(dt.data(), ss.data, nnz * 32, hipMemcpyDeviceToHost, c.stream));
+  }
+  HIPCHK(hipStreamSynchronize(c.stream));
+  const bool tagged_in = cols <= ((size_t)1 << 28), tagged_out = rows <= ((size_t)1 << 28);
+  const uint32_t cmask = tagged_in ? (1u << 28) - 1u : 0xffffffffu;
+  std::vector<uint32_t> cnt(cols + 1, 0);
+  for (size_t k = 0; k < nnz; k++) cnt[(ix[k] & cmask) + 1]++;
+  for (size_t j = 0; j < cols; j++) cnt[j + 1] += cnt[j];
+  std::vector<uint32_t> tix(nnz ? nnz : 1), pos(cnt.begin(), cnt.end() - 1);
+  std::vector<uint8_t> tdt((nnz ? nnz : 1) * 32);
+  for (size_t r = 0; r < rows; r++)
+    for (uint32_t k = ip[r]; k < ip[r + 1]; k++) {
+      const uint32_t col = ix[k] & cmask, cls = tagged_in ? ix[k] >> 28 : 0u, q = pos[col]++;
+      tix[q] = (uint32_t)r | (tagged_out ? cls << 28 : 0u);  // the class rides along (same coefficient); none if rows need all 32 bits
+      memcpy(tdt.data() + 32 * (size_t)q, dt.data() + 32 * (size_t)k, 32);
+    }
+  std::vector<uint32_t> vptr{0}, vout, hrow, hstart{0};
+  size_t nparts = 0;
+  for (size_t j = 0; j < cols; j++) {
+    const uint32_t b = cnt[j], e = cnt[j + 1], L = e - b;
+    if (L <= 64) {
+      vptr.push_back(e);
+      vout.push_back((uint32_t)j);
+      continue;
+    }
+    uint32_t T = 64;
+    while ((uint64_t)T * T < L) T++;
+    for (uint32_t a = b; a < e; a += T) {
+      vptr.push_back(a + T < e ? a + T : e);
+      vout.push_back(0x80000000u | (uint32_t)nparts++);
+    }
+    hrow.push_back((uint32_t)j);
+    hstart.push_back((uint32_t)nparts);
+  }
+  require(nparts < (1ull << 31), NMX_E_TOO_LARGE, "matrix too large");
+  auto tr = std::make_shared<Global::SparseSet::Transposed>();
+  auto up = [&](uint32_t** d, const void* h, size_t bytes) {
+    HIPCHK(hipMalloc((void**)d, bytes ? bytes : 4));
+    if (bytes) HIPCHK(hipMemcpyAsync(*d, h, bytes, hipMemcpyHostToDevice, c.stream));
+  };
+  up(&tr->vptr, vptr.data(), vptr.size() * 4);
+  up(&tr->indices, tix.data(), nnz * 4);
+  up(&tr->data, tdt.data(), nnz * 32);
+  up(&tr->vout, vout.data(), vout.size() * 4);
+  up(&tr->hrow, hrow.data(), hrow.size() * 4);
+  up(&tr->hstart, hstart.data(), hstart.size() * 4);
+  HIPCHK(hipStreamSynchronize(c.stream));  // the host vectors go away
+  tr->nvirt = vout.size(), tr->nheavy = hrow.size(), tr->nparts = nparts;
+  ss.tr = tr;
+  return tr;
+}
+int nmx_spmv_apply_transposed(uint64_t handle, const void* x, size_t x_len, uint32_t flags, void* out) {
+  return guarded([&] {
+    require(x && out, NMX_E_ARG, "null argument");
+    std::shared_ptr<Global::SparseSet> sp;
+    {
+      std::lock_guard<std::mutex> lk(G.mu);
+      auto it = G.sparse.find(handle);
+      if (it == G.sparse.end()) throw Fail{NMX_E_HANDLE, "unknown matrix handle"};
+      sp = it->second;
+    }
+    Global::SparseSet& ss = *sp;
+    require(x_len == ss.rows, NMX_E_ARG, "invalid shape");  // assert_eq!(rx.len(), S.num_cons()), spartan/mod.rs:504
+    if (ss.cols == 0) return;
+    CtxLease L;
+    auto tr = transposed_of(*L.c, ss);
+    fv_spmv_apply_transposed(*L.c, ss.field, tr->vptr, tr->indices, tr->data, tr->vout, tr->hrow, tr->hstart, tr->nvirt, tr->nheavy,
+                             tr->nparts, ss.rows, ss.cols, x, flags, out);
+  });
+}
+
+// Spartan's sum-check provers as one call each (sumcheck_prove.hpp)
+static void check_sc_args(int field, size_t num_rounds, uint32_t flags, nmx_transcript_fn cb) {
+  require(field >= 0 && field < 4, NMX_E_ARG, "bad field id");
+  require(cb != nullptr, NMX_E_ARG, "null transcript callback");
+  require(num_rounds < 31, NMX_E_TOO_LARGE, "too many rounds");
+  require(flags & NMX_SCALARS_DEVICE, NMX_E_ARG, "the sum-check provers work on HBM-resident tables (NMX_SCALARS_DEVICE)");
+}
+int nmx_sumcheck_prove_cubic_with_three_inputs(int field, const void* claim, const void* taus, size_t num_rounds, void* A, void* B, void* C,
+                                               uint32_t flags, nmx_transcript_fn transcript, void* ctx, uint8_t* out_polys, uint8_t* out_r,
+                                               uint8_t* out_claims) {
+  return guarded([&] {
+    check_sc_args(field, num_rounds, flags, transcript);
+    require(claim && (taus || num_rounds == 0) && A && B && C, NMX_E_ARG, "null argument");
+    CtxLease L;
+    fv_sumcheck_prove(*L.c, field, 3, claim, taus, num_rounds, A, B, C, flags, transcript, ctx, out_polys, out_r, out_claims);
+  });
+}
+int nmx_sumcheck_prove_quad_prod(int field, const void* claim, size_t num_rounds, void* A, void* B, uint32_t flags,
+                                 nmx_transcript_fn transcript, void* ctx, uint8_t* out_polys, uint8_t* out_r, uint8_t* out_claims) {
+  return guarded([&] {
+    check_sc_args(field, num_rounds, flags, transcript);
+    require(claim && A && B, NMX_E_ARG, "null argument");
+    CtxLease L;
+    fv_sumcheck_prove(*L.c, field, 4, claim, nullptr, num_rounds, A, B, nullptr, flags, transcript, ctx, out_polys, out_r, out_claims);
+  });
+}
+int nmx_sumcheck_prove_batch_eval(int field, const void* claims, const size_t* num_rounds, void* const* polys, const void* const* eq_points,
+                                  const void* coeffs, size_t k, uint32_t flags, nmx_transcript_fn transcript, void* ctx, uint8_t* out_polys,
+                                  uint8_t* out_r, uint8_t* out_finals) {
+  return guarded([&] {
+    check_sc_args(field, 0, flags, transcript);
+    require(claims && num_rounds && polys && eq_points && coeffs && k >= 1, NMX_E_ARG, "null argument");
+    for (size_t i = 0; i < k; i++) require(polys[i] && eq_points[i], NMX_E_ARG, "null polynomial / evaluation point");
+    CtxLease L;
+    fv_sumcheck_prove_batch(*L.c, field, (const uint8_t*)claims, num_rounds, polys, (const uint8_t* const*)eq_points, (const uint8_t*)coeffs, k,
+                            flags, transcript, ctx, out_polys, out_r, out_finals);
+  });
+}
+
 int nmx_r1cs_cross_term(uint64_t hA, uint64_t hB, uint64_t hC, const void* z1, const void* z2, size_t z_len, const void* e,
                         const void* u, uint32_t flags, void* out) {
   return guarded([&] {
@@ -2358,6 +2486,7 @@ int nmx_set_option(const char* name, uint32_t value) {
     else if (n == "hist_grid") G.hist_grid = value;
     else if (n == "hist_bs") G.hist_bs = value;
     else if (n == "sync_spin_us") G.sync_spin_us = value;
+    else if (n == "sc_poll_us") G.sc_poll_us = value;
     else if (n == "horner_order") G.horner_order = value ? 1u : 0u;
 
     else if (n == "shard_min_n") G.shard_min_n.store(value ? value : 1u);

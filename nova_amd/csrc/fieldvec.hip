@@ -201,6 +201,44 @@ template <int FID> struct SpmvFn {
   NMX_HD void operator()(uint32_t row) const { st<FID>(out, row, spmv_row<FID>(indptr, indices, data, z, colmask, row)); }
 };
 
+// M^T x over VIRTUAL rows (compute_eval_table_sparse, /root/reference/src/spartan/mod.rs:497-533: M_evals[col] += rx[row] * val
+// for every entry -- a scatter-add on the reference's side, a gather over the transposed matrix here).  The CSC arrays are cut
+// into virtual rows at registration of the transposed form (Global::SparseSet::Transposed): short columns are one virtual row
+// that writes its output element; a long column (the constant-one column of an R1CS matrix has an entry per constraint) is
+// several, each writing a partial that SpmvHeavyFn adds up -- no lane walks more than max(64, sqrt(column length)) entries.
+template <int FID> struct SpmvSegFn {
+  const uint32_t* vptr;     // nvirt + 1
+  const uint32_t* indices;  // nnz: row of M | class << 28
+  const uint32_t* data;     // nnz x 8, internal form
+  const uint32_t* x;        // rows of M x 8
+  const uint32_t* vout;     // nvirt: output row, or 2^31 | partial index
+  uint32_t *out, *partial;
+  uint32_t colmask;
+  NMX_HD void operator()(uint32_t v) const {
+    const Fp<FID> acc = spmv_row<FID>(vptr, indices, data, x, colmask, v);
+    const uint32_t o = vout[v];
+    if (o & 0x80000000u) st<FID>(partial, o & 0x7fffffffu, acc);
+    else st<FID>(out, o, acc);
+  }
+};
+template <int FID> struct SpmvHeavyFn {  // one split column per lane: the sum of its partials (additions only)
+  const uint32_t *hrow, *hstart, *partial;
+  uint32_t* out;
+  NMX_HD void operator()(uint32_t hdx) const {
+    using F = Fp<FID>;
+    F acc = F::zero();
+    uint32_t pending = 0;
+    for (uint32_t k = hstart[hdx]; k < hstart[hdx + 1]; k++) {
+      acc = acc + ld<FID>(partial, k);
+      if (++pending == 6) {
+        acc = acc.norm().canon();
+        pending = 0;
+      }
+    }
+    st<FID>(out, hrow[hdx], acc.norm());
+  }
+};
+
 // commit_T in one pass over the rows (src/r1cs/mod.rs:612-620): T[row] = (A z)[row] (B z)[row] - u (C z)[row] - E[row].  The
 // three products and the cross term of CrossTermFn without AZ, BZ, CZ ever reaching HBM, and one launch instead of four;
 // bit-identical to the separate calls (each row product is canonicalised exactly as SpmvFn's store does).
@@ -1048,6 +1086,46 @@ static void spmv_apply_t(Ctx& c, const uint32_t* indptr, const uint32_t* indices
   timed_launch(c, f, rows, &io);
 }
 
+// x: rows of M; out: cols of M.  tr_*: the virtual-row form of M^T (capi.hip builds it).
+template <int FID>
+static void spmv_apply_transposed_t(Ctx& c, const uint32_t* vptr, const uint32_t* indices, const uint32_t* data, const uint32_t* vout,
+                                    const uint32_t* hrow, const uint32_t* hstart, size_t nvirt, size_t nheavy, size_t nparts, size_t rows,
+                                    size_t cols, const void* x, uint32_t flags, void* out) {
+  const bool dev = (flags & NMX_SCALARS_DEVICE) != 0, async = dev && (flags & NMX_ASYNC);
+  auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t pb = pad((nparts ? nparts : 1) * 32);
+  arena_reserve(c, pb + (dev ? 0 : pad(rows * 32) + pad(cols * 32)) + 256);
+  uint32_t* partial = (uint32_t*)c.arena;
+  const uint32_t* dx = (const uint32_t*)x;
+  uint32_t* dout = (uint32_t*)out;
+  if (!dev) {
+    HIPCHK(hipMemcpyAsync(c.arena + pb, x, rows * 32, hipMemcpyHostToDevice, c.stream));
+    dx = (const uint32_t*)(c.arena + pb);
+    dout = (uint32_t*)(c.arena + pb + pad(rows * 32));
+  }
+  const bool prof = G.profiling;
+  DeviceBackend be(c, false, prof);
+  be.mark("kernel");
+  SpmvSegFn<FID> f{vptr, indices, data, dx, vout, dout, partial, rows <= ((size_t)1 << kSpmvColBits) ? (1u << kSpmvColBits) - 1u : 0xffffffffu};
+  be.launch(f, (uint32_t)nvirt);
+  if (nheavy) {
+    SpmvHeavyFn<FID> g{hrow, hstart, partial, dout};
+    be.launch(g, (uint32_t)nheavy);
+  }
+  be.mark("end");
+  if (!dev) HIPCHK(hipMemcpyAsync(out, dout, cols * 32, hipMemcpyDeviceToHost, c.stream));
+  if (async) {
+    async_mark(c);
+    return;
+  }
+  stream_wait(c.stream);
+  if (prof && be.nmarks == 2) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
+    prof_store(&ms, 1);
+  }
+}
+
 template <int FID>
 static void spmv_apply_pair_t(Ctx& c, const uint32_t* indptr, const uint32_t* indices, const uint32_t* data, size_t rows,
                               size_t cols, const void* z1, const void* z2, uint32_t flags, void* out1, void* out2) {
@@ -1414,6 +1492,18 @@ void fv_spmv_apply(Ctx& c, int field, const uint32_t* indptr, const uint32_t* in
     case 1: spmv_apply_t<1>(c, indptr, indices, data, rows, cols, z, flags, out); break;
     case 2: spmv_apply_t<2>(c, indptr, indices, data, rows, cols, z, flags, out); break;
     case 3: spmv_apply_t<3>(c, indptr, indices, data, rows, cols, z, flags, out); break;
+    default: throw Fail{NMX_E_ARG, "bad field id"};
+  }
+}
+
+void fv_spmv_apply_transposed(Ctx& c, int field, const uint32_t* vptr, const uint32_t* indices, const uint32_t* data, const uint32_t* vout,
+                              const uint32_t* hrow, const uint32_t* hstart, size_t nvirt, size_t nheavy, size_t nparts, size_t rows, size_t cols,
+                              const void* x, uint32_t flags, void* out) {
+  switch (field) {
+    case 0: spmv_apply_transposed_t<0>(c, vptr, indices, data, vout, hrow, hstart, nvirt, nheavy, nparts, rows, cols, x, flags, out); break;
+    case 1: spmv_apply_transposed_t<1>(c, vptr, indices, data, vout, hrow, hstart, nvirt, nheavy, nparts, rows, cols, x, flags, out); break;
+    case 2: spmv_apply_transposed_t<2>(c, vptr, indices, data, vout, hrow, hstart, nvirt, nheavy, nparts, rows, cols, x, flags, out); break;
+    case 3: spmv_apply_transposed_t<3>(c, vptr, indices, data, vout, hrow, hstart, nvirt, nheavy, nparts, rows, cols, x, flags, out); break;
     default: throw Fail{NMX_E_ARG, "bad field id"};
   }
 }

@@ -71,6 +71,10 @@ struct Ctx {
   char* pinned = nullptr;  // 64 KiB of pinned host memory: landing zone of the small device->host result copies
   char* aux = nullptr;  // second, small arena: data that must outlive calls which re-carve `arena` (eq tables)
   size_t aux_cap = 0;
+  // mailbox of the sum-check provers (sumcheck_prove.hpp): coherent pinned host memory the round kernels write their sums
+  // into, sequence word last, and the host polls -- mail = host address, mail_dev = the same bytes as the device sees them
+  char *mail = nullptr, *mail_dev = nullptr;
+  uint32_t mail_seq = 0;
   hipEvent_t ev[kMaxMarks];
   bool have_ev = false;
   hipEvent_t async_ev = nullptr;  // behind the last NMX_ASYNC call enqueued on this context
@@ -268,6 +272,18 @@ struct Global {
     int field = 0;
     size_t rows = 0, cols = 0, nnz = 0;
     uint32_t *indptr = nullptr, *indices = nullptr, *data = nullptr;
+    // M^T for compute_eval_table_sparse (nmx_spmv_apply_transposed), built from the resident CSR on first use: the CSC arrays
+    // cut into VIRTUAL rows (a column of an R1CS matrix can hold one entry per constraint -- the constant-one column does --
+    // so a column longer than 64 entries is split into chunks of max(64, sqrt(length)) entries, each its own lane), the slot
+    // every virtual row writes (an output row, or 2^31 | index of a partial), and the (row, first partial) list of the split rows
+    struct Transposed {
+      uint32_t *vptr = nullptr, *indices = nullptr, *data = nullptr, *vout = nullptr, *hrow = nullptr, *hstart = nullptr;
+      size_t nvirt = 0, nheavy = 0, nparts = 0;
+      int dev = 0;
+      ~Transposed();  // capi.hip
+    };
+    std::mutex t_mu;
+    std::shared_ptr<Transposed> tr;
     SparseSet() = default;
     SparseSet(const SparseSet&) = delete;
     SparseSet& operator=(const SparseSet&) = delete;
@@ -304,6 +320,7 @@ struct Global {
   std::atomic<uint32_t> hist_grid{0};             // env NMX_TUNE_HIST_GRID / option hist_grid
   std::atomic<uint32_t> hist_bs{0};               // env NMX_TUNE_HIST_BS / option hist_bs: threads per block of k_hist_hi (0: as k_part_hi)
   std::atomic<uint32_t> horner_order{1};          // option horner_order: 1 = tiles of k_horner_scan by start-order ticket, 0 = by block id
+  std::atomic<uint32_t> sc_poll_us{2000};         // option sc_poll_us: the sum-check provers poll a round's mailbox this long before they synchronise the stream (0: always synchronise)
   std::atomic<uint32_t> sync_spin_us{0};          // env NMX_SYNC_SPIN_US / option sync_spin_us: poll the stream this long before blocking
   std::atomic<uint32_t> force_peer_copy{0};       // option force_peer_copy: HBM-resident scalars of a sharded call take the staging + hipMemcpyPeerAsync branch even when source and destination are the same GPU (tests on a 1-GPU box)
   std::atomic<uint32_t> combine_mode{0};          // option combine: 0 = RCCL all-gather when the shards sit on >= 2 GPUs, host sum otherwise; 1 = host sum; 2 = RCCL required (also with one GPU: tests)
@@ -671,6 +688,16 @@ void fv_bind_eq_sums(Ctx&, int field, int mode, const void* A, const void* B, co
                      void* oB, void* oC, uint8_t* out);  // sumcheck.hip
 void fv_eq_sums(Ctx&, int field, int mode, const void* A, const void* B, const void* C, size_t len, const void* eqL,
                 size_t nL, const void* eqR, size_t nR, uint32_t shift, uint32_t flags, uint8_t* out);  // sumcheck.hip
+void fv_spmv_apply_transposed(Ctx&, int field, const uint32_t* vptr, const uint32_t* indices, const uint32_t* data, const uint32_t* vout,
+                              const uint32_t* hrow, const uint32_t* hstart, size_t nvirt, size_t nheavy, size_t nparts, size_t rows, size_t cols,
+                              const void* x, uint32_t flags, void* out);
+// Spartan's sum-check provers, one call each (sumcheck_prove.hpp); which = 3: cubic with three inputs, 4: quad_prod
+using TranscriptFn = int (*)(void* ctx, const uint8_t* coeffs, size_t n_coeffs, uint8_t* challenge32);
+void fv_sumcheck_prove(Ctx&, int field, int which, const void* claim, const void* taus, size_t num_rounds, void* A, void* B, void* C,
+                       uint32_t flags, TranscriptFn cb, void* cb_ctx, uint8_t* out_polys, uint8_t* out_r, uint8_t* out_claims);
+void fv_sumcheck_prove_batch(Ctx&, int field, const uint8_t* claims, const size_t* num_rounds, void* const* polys,
+                             const uint8_t* const* eq_points, const uint8_t* coeffs, size_t k, uint32_t flags, TranscriptFn cb, void* cb_ctx,
+                             uint8_t* out_polys, uint8_t* out_r, uint8_t* out_finals);
 
 const CurveOps& curve_ops_bn254_g1();
 const CurveOps& curve_ops_grumpkin();

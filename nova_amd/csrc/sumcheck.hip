@@ -860,3 +860,5 @@ void fv_eq_sums(Ctx& c, int field, int mode, const void* A, const void* B, const
 }
 
 }  // namespace nmx
+
+#include "sumcheck_prove.hpp"

@@ -211,10 +211,16 @@ def lincomb_powers(field, vecs, s, n_out=None, mont=False):
     return out
 
 
-def eq_evals_from_points(field, r, mont=False):
-    """EqPolynomial::evals_from_points (src/spartan/polys/eq.rs:54-73): (2^ell, 32) table, r[0] most significant."""
+def eq_evals_from_points(field, r, mont=False, device=False):
+    """EqPolynomial::evals_from_points (src/spartan/polys/eq.rs:54-73): (2^ell, 32) table, r[0] most significant.  device=True: the
+    table is built and left in HBM (a CUDA tensor) -- compute_eval_table_sparse's operand, src/spartan/snark.rs:182-184."""
     rr = _host_u8(r, 32)
     ell = rr.size // 32
+    if device:
+        import torch
+        out = torch.empty((1 << ell, 32), dtype=torch.uint8, device="cuda")
+        _check(L.lib().nmx_eq_evals_from_points(field, rr.ctypes.data, ell, _flags(True, mont), out.data_ptr()))
+        return out
     out = np.zeros((1 << ell, 32), dtype=np.uint8)
     _check(L.lib().nmx_eq_evals_from_points(field, rr.ctypes.data, ell, L.SCALARS_MONT if mont else 0, out.ctypes.data))
     return out
@@ -304,6 +310,14 @@ class SparseMatrix:
         _check(L.lib().nmx_spmv_apply_pair(self.handle, p1, p2, n1, _flags(dev, mont, async_), po1, po2))
         return out1, out2
 
+    def multiply_vec_transposed(self, x, mont=False, async_=False):
+        """M^T x: compute_eval_table_sparse's product (src/spartan/mod.rs:497-533), x over the rows, result over the columns."""
+        px, n, dev, _kx = _vec(x)
+        assert n == self.rows, "assert_eq!(rx.len(), S.num_cons())"
+        po, out = _out_like(dev, self.cols, x)
+        _check(L.lib().nmx_spmv_apply_transposed(self.handle, px, n, _flags(dev, mont, async_), po))
+        return out
+
     def close(self):
         if self.handle:
             _check(L.lib().nmx_spmv_unregister(self.handle))
@@ -346,3 +360,81 @@ def poly_eval(field, f, u, mont=False):
 
 def div_by_monomial(field, f, u, mont=False):
     return suffix_horner(field, f, u, mont)[1:]
+
+
+# ---- Spartan's sum-check provers, one call each (nmx_sumcheck_prove_*; src/spartan/sumcheck.rs:199-507) ---------------------
+def as_transcript(fn):
+    """fn(list of 32-byte coefficient strings) -> 32-byte challenge, wrapped as nmx_transcript_fn.  The transcript (Keccak on
+    the reference's side, src/provider/keccak.rs) is the caller's: `absorb(b"p", &poly); squeeze(b"c")`."""
+    import ctypes
+    if isinstance(fn, L.TRANSCRIPT_FN):
+        return fn
+
+    def cb(_ctx, coeffs, n, out):
+        try:
+            ch = fn([bytes(coeffs[32 * i: 32 * i + 32]) for i in range(n)])
+            ctypes.memmove(out, ch, 32)
+            return 0
+        except Exception:                   # an exception must not cross the C frame: the call fails with NMX_E_ARG
+            import traceback
+            traceback.print_exc()
+            return 1
+    return L.TRANSCRIPT_FN(cb)
+
+
+def _rows(buf, n, w):
+    b = buf.tobytes()
+    return [[b[32 * (w * j + i): 32 * (w * j + i) + 32] for i in range(w)] for j in range(n)]
+
+
+def sumcheck_prove_cubic_with_three_inputs(field, claim, taus, A, B, C, transcript, mont=False, ctx=None):
+    """SumcheckProof::prove_cubic_with_three_inputs (src/spartan/sumcheck.rs:446-507) over HBM-resident tables, bound IN PLACE.
+    Returns (round polynomials [rounds][4], challenges [rounds], [A(r), B(r), C(r)]) as 32-byte strings."""
+    pa, n, dev, _a = _vec(A)
+    pb, nb, _d1, _b = _vec(B)
+    pc, nc, _d2, _c = _vec(C)
+    t = _host_u8(taus, 32)
+    nr = t.size // 32
+    assert dev and n == nb == nc == (1 << nr)
+    cl = _chal(claim)
+    polys, r, out = np.zeros(128 * max(nr, 1), np.uint8), np.zeros(32 * max(nr, 1), np.uint8), np.zeros(96, np.uint8)
+    cb = as_transcript(transcript)
+    _check(L.lib().nmx_sumcheck_prove_cubic_with_three_inputs(field, cl.ctypes.data, t.ctypes.data, nr, pa, pb, pc, _flags(True, mont),
+                                                             cb, ctx, polys.ctypes.data, r.ctypes.data, out.ctypes.data))
+    return _rows(polys, nr, 4), [x[0] for x in _rows(r, nr, 1)], _rows(out, 1, 3)[0]
+
+
+def sumcheck_prove_quad_prod(field, claim, num_rounds, A, B, transcript, mont=False, ctx=None):
+    """SumcheckProof::prove_quad_prod (src/spartan/sumcheck.rs:199-249): (polys [rounds][3], challenges, [A(r), B(r)])."""
+    pa, n, dev, _a = _vec(A)
+    pb, nb, _d1, _b = _vec(B)
+    nr = num_rounds
+    assert dev and n == nb == (1 << nr)
+    cl = _chal(claim)
+    polys, r, out = np.zeros(96 * max(nr, 1), np.uint8), np.zeros(32 * max(nr, 1), np.uint8), np.zeros(64, np.uint8)
+    cb = as_transcript(transcript)
+    _check(L.lib().nmx_sumcheck_prove_quad_prod(field, cl.ctypes.data, nr, pa, pb, _flags(True, mont), cb, ctx, polys.ctypes.data,
+                                               r.ctypes.data, out.ctypes.data))
+    return _rows(polys, nr, 3), [x[0] for x in _rows(r, nr, 1)], _rows(out, 1, 2)[0]
+
+
+def sumcheck_prove_batch_eval(field, claims, num_rounds, polys, eq_points, coeffs, transcript, mont=False, ctx=None):
+    """SumcheckProof::prove_batch_eval (src/spartan/sumcheck.rs:251-353).  polys: CUDA tensors, bound IN PLACE (the reference binds
+    clones: pass copies to keep the originals).  Returns (polys [max rounds][3], challenges, [P_i final])."""
+    import ctypes
+    k = len(polys)
+    parts = [_vec(p) for p in polys]
+    assert all(pt[2] for pt in parts) and all(pt[1] == (1 << nr) for pt, nr in zip(parts, num_rounds))
+    nmax = max(num_rounds)
+    pts = [_host_u8(x, 32) for x in eq_points]
+    assert all(x.size // 32 == nr for x, nr in zip(pts, num_rounds))
+    pp = (ctypes.c_void_p * k)(*[pt[0] for pt in parts])
+    qp = (ctypes.c_void_p * k)(*[x.ctypes.data for x in pts])
+    nrs = (ctypes.c_size_t * k)(*num_rounds)
+    cl = _host_u8(b"".join(claims) if isinstance(claims, (list, tuple)) else claims, 32)
+    co = _host_u8(b"".join(coeffs) if isinstance(coeffs, (list, tuple)) else coeffs, 32)
+    out_p, r, fin = np.zeros(96 * nmax, np.uint8), np.zeros(32 * nmax, np.uint8), np.zeros(32 * k, np.uint8)
+    cb = as_transcript(transcript)
+    _check(L.lib().nmx_sumcheck_prove_batch_eval(field, cl.ctypes.data, nrs, pp, qp, co.ctypes.data, k, _flags(True, mont), cb, ctx,
+                                                out_p.ctypes.data, r.ctypes.data, fin.ctypes.data))
+    return _rows(out_p, nmax, 3), [x[0] for x in _rows(r, nmax, 1)], [x[0] for x in _rows(fin, k, 1)]

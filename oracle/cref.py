@@ -333,7 +333,7 @@ def make_transcript(fn):
     return TRANSCRIPT_FN(cb)
 
 
-def sumcheck_prove_cubic3(fid, claim, taus, A, B, C, transcript):
+def sumcheck_prove_cubic3(fid, claim, taus, A, B, C, transcript, ctx=None):
     """SumcheckProof::prove_cubic_with_three_inputs (src/spartan/sumcheck.rs:446-507).  Returns (polys [rounds][4], r [rounds],
     claims [3]) as 32-byte strings; `transcript` = make_transcript(...)."""
     tp, _t = _buf(taus)
@@ -342,7 +342,7 @@ def sumcheck_prove_cubic3(fid, claim, taus, A, B, C, transcript):
     polys = np.zeros(128 * max(nr, 1), np.uint8)
     r = np.zeros(32 * max(nr, 1), np.uint8)
     cl = np.zeros(96, np.uint8)
-    rc = lib().ref_sumcheck_prove_cubic3(fid, ps[0][0], tp, nr, ps[1][0], ps[2][0], ps[3][0], transcript, None, polys.ctypes.data,
+    rc = lib().ref_sumcheck_prove_cubic3(fid, ps[0][0], tp, nr, ps[1][0], ps[2][0], ps[3][0], transcript, ctx, polys.ctypes.data,
                                          r.ctypes.data, cl.ctypes.data)
     assert rc == 0
     pb, rb, cb = polys.tobytes(), r.tobytes(), cl.tobytes()
@@ -350,14 +350,14 @@ def sumcheck_prove_cubic3(fid, claim, taus, A, B, C, transcript):
             [rb[32 * j: 32 * j + 32] for j in range(nr)], [cb[32 * i: 32 * i + 32] for i in range(3)])
 
 
-def sumcheck_prove_quad_prod(fid, claim, num_rounds, A, B, transcript):
+def sumcheck_prove_quad_prod(fid, claim, num_rounds, A, B, transcript, ctx=None):
     """SumcheckProof::prove_quad_prod (src/spartan/sumcheck.rs:199-249): (polys [rounds][3], r, [A(r), B(r)])."""
     ps = [_buf(x) for x in (claim, A, B)]
     nr = num_rounds
     polys = np.zeros(96 * max(nr, 1), np.uint8)
     r = np.zeros(32 * max(nr, 1), np.uint8)
     cl = np.zeros(64, np.uint8)
-    rc = lib().ref_sumcheck_prove_quad_prod(fid, ps[0][0], nr, ps[1][0], ps[2][0], transcript, None, polys.ctypes.data,
+    rc = lib().ref_sumcheck_prove_quad_prod(fid, ps[0][0], nr, ps[1][0], ps[2][0], transcript, ctx, polys.ctypes.data,
                                             r.ctypes.data, cl.ctypes.data)
     assert rc == 0
     pb, rb, cb = polys.tobytes(), r.tobytes(), cl.tobytes()
@@ -365,7 +365,7 @@ def sumcheck_prove_quad_prod(fid, claim, num_rounds, A, B, transcript):
             [rb[32 * j: 32 * j + 32] for j in range(nr)], [cb[:32], cb[32:]])
 
 
-def sumcheck_prove_batch_eval(fid, claims, num_rounds, polys, eq_points, coeffs, transcript):
+def sumcheck_prove_batch_eval(fid, claims, num_rounds, polys, eq_points, coeffs, transcript, ctx=None):
     """SumcheckProof::prove_batch_eval (src/spartan/sumcheck.rs:251-353): (polys [max rounds][3], r, [P_i final])."""
     k = len(polys)
     nmax = max(num_rounds)
@@ -377,7 +377,7 @@ def sumcheck_prove_batch_eval(fid, claims, num_rounds, polys, eq_points, coeffs,
     out_p = np.zeros(96 * max(nmax, 1), np.uint8)
     r = np.zeros(32 * max(nmax, 1), np.uint8)
     fin = np.zeros(32 * k, np.uint8)
-    rc = lib().ref_sumcheck_prove_batch_eval(fid, pc, nr, pp, qp, pw, k, transcript, None, out_p.ctypes.data, r.ctypes.data,
+    rc = lib().ref_sumcheck_prove_batch_eval(fid, pc, nr, pp, qp, pw, k, transcript, ctx, out_p.ctypes.data, r.ctypes.data,
                                              fin.ctypes.data)
     assert rc == 0
     pb, rb, fb = out_p.tobytes(), r.tobytes(), fin.tobytes()

@@ -1,0 +1,191 @@
+"""-m gpu: Spartan's sum-check provers as single C calls (nmx_sumcheck_prove_*, nova_amd/csrc/sumcheck_prove.hpp) and
+compute_eval_table_sparse's transposed product (nmx_spmv_apply_transposed) against (1) the reference's verifier and the definition
+of every round polynomial (tests/spartan_common.py), (2) the oracle's restatement round by round -- same stand-in transcript, so the
+challenge sequences coincide iff every round polynomial does -- and (3) the replay of `RelaxedR1CSSNARK::prove`
+(/root/reference/src/spartan/snark.rs:113-260) as bench.py runs it, at a size the oracle finishes in seconds."""
+import numpy as np
+import pytest
+
+from oracle import cref
+from tests import fv_common as fc
+from tests import spartan_common as sp
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(x):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(x).copy()).cuda()
+
+
+def g_cubic3(mont=False):
+    def prove(fid, claim, taus, A, B, C, tr):
+        from nova_amd import fieldvec as fv
+        return fv.sumcheck_prove_cubic_with_three_inputs(fid, claim, taus, dev(A), dev(B), dev(C), tr, mont=mont)
+    return prove
+
+
+def g_quad(fid, claim, nr, A, B, tr):
+    from nova_amd import fieldvec as fv
+    return fv.sumcheck_prove_quad_prod(fid, claim, nr, dev(A), dev(B), tr)
+
+
+def g_batch(fid, claims, nrs, polys, pts, coeffs, tr):
+    from nova_amd import fieldvec as fv
+    return fv.sumcheck_prove_batch_eval(fid, claims, nrs, [dev(p) for p in polys], pts, coeffs, tr)
+
+
+def both(check, g_prove, o_prove, *args, **kw):
+    """the same instance through the HIP path and the oracle: identical round polynomials, challenges and final claims"""
+    got = check(g_prove, *args, **kw)
+    exp = check(o_prove, *args, **kw)
+    assert got == exp
+    return got
+
+
+def o_cubic3(fid, claim, taus, A, B, C, tr):
+    return cref.sumcheck_prove_cubic3(fid, claim, taus, A, B, C, cref.make_transcript(tr))
+
+
+def o_quad(fid, claim, nr, A, B, tr):
+    return cref.sumcheck_prove_quad_prod(fid, claim, nr, A, B, cref.make_transcript(tr))
+
+
+def o_batch(fid, claims, nrs, polys, pts, coeffs, tr):
+    return cref.sumcheck_prove_batch_eval(fid, claims, nrs, [p.tobytes() for p in polys], [x.tobytes() for x in pts], coeffs,
+                                          cref.make_transcript(tr))
+
+
+@pytest.mark.parametrize("fid", [0, 1, 2, 3])
+@pytest.mark.parametrize("l", [1, 2, 3, 5, 8])
+def test_cubic_with_three_inputs_small(nmx, fid, l):
+    both(sp.check_cubic3, g_cubic3(), o_cubic3, fid, l, seed=300 + l)
+
+
+@pytest.mark.parametrize("l", [10, 11, 12, 13, 16])
+def test_cubic_with_three_inputs_across_the_kernel_forms(nmx, l):
+    """l = 10: every round in one block; 11-13: the first rounds as pass + final sum (k_eq_rows with both eq tables, then the
+    last-half form), the block form below 512 indices; 16: several blocks per pass."""
+    both(sp.check_cubic3, g_cubic3(), o_cubic3, 1, l, seed=40 + l, brute=False)
+
+
+@pytest.mark.parametrize("l", [2, 3, 5, 6, 11])
+def test_cubic_fallback_when_tau_is_zero(nmx, l):
+    """tau_i = 0 (l(1) = 0) and a challenge that zeroes eq's running product: the reference's third N-scaling sum
+    (sumcheck.rs:1085-1136); here t(1) from a pass over the swapped halves."""
+    base = fc.ints(fc.rand_vec(1, l, 55))
+    for zero_at in sorted({0, l // 2, l - 1}):
+        taus = list(base)
+        taus[zero_at] = 0
+        both(sp.check_cubic3, g_cubic3(), o_cubic3, 1, l, seed=400 + zero_at, taus=taus, brute=l <= 5)
+        both(sp.check_cubic3, g_cubic3(), o_cubic3, 1, l, seed=500 + zero_at, taus=taus, force={zero_at: 1}, brute=l <= 5)
+    both(sp.check_cubic3, g_cubic3(), o_cubic3, 1, l, seed=77, taus=[0] * l, brute=l <= 5)
+
+
+@pytest.mark.parametrize("fid", [1, 3])
+def test_cubic_montgomery_layout(nmx, fid):
+    """NMX_SCALARS_MONT: tables, taus, claim, round polynomials and challenges all as R = 2^256 Montgomery limbs (what the Rust shim
+    passes zero-copy); converted in and out here, the proof must be the canonical one."""
+    p = fc.FIELDS[fid]
+    Rm = 1 << 256
+    to_m = lambda v: fc.vec([x * Rm % p for x in fc.ints(v)])
+    un_m = lambda b: int(int.from_bytes(b, "little") * pow(Rm, -1, p) % p).to_bytes(32, "little")
+
+    def prove_m(fid_, claim, taus, A, B, C, tr):
+        from nova_amd import fieldvec as fv
+
+        def tr_m(coeffs):                               # the stand-in transcript sees canonical coefficients
+            ch = tr([un_m(c) for c in coeffs])
+            return int(int.from_bytes(ch, "little") * Rm % p).to_bytes(32, "little")
+        polys, rs, claims = fv.sumcheck_prove_cubic_with_three_inputs(fid_, to_m(np.frombuffer(claim, np.uint8)), to_m(taus), dev(to_m(A)),
+                                                                      dev(to_m(B)), dev(to_m(C)), tr_m, mont=True)
+        return [[un_m(c) for c in row] for row in polys], [un_m(r) for r in rs], [un_m(c) for c in claims]
+    for l in (4, 12):
+        both(sp.check_cubic3, prove_m, o_cubic3, fid, l, seed=900 + l, brute=False)
+
+
+@pytest.mark.parametrize("fid", [0, 1, 2, 3])
+@pytest.mark.parametrize("l", [1, 2, 5, 9, 12, 15])
+def test_quad_prod(nmx, fid, l):
+    both(sp.check_quad_prod, g_quad, o_quad, fid, l, seed=600 + l)
+    if l <= 9:
+        both(sp.check_quad_prod, g_quad, o_quad, fid, l, seed=700 + l, force={0: 0, l - 1: 1})
+
+
+@pytest.mark.parametrize("fid", [1, 3])
+@pytest.mark.parametrize("nrs", [[4], [5, 5], [3, 6], [6, 3], [7, 2, 5], [1, 4], [13, 12], [12, 14]])
+def test_batch_eval_with_polynomials_of_different_sizes(nmx, fid, nrs):
+    both(sp.check_batch_eval, g_batch, o_batch, fid, nrs, seed=800 + sum(nrs))
+
+
+def test_batch_eval_fallback(nmx):
+    p = fc.FIELDS[1]
+    both(sp.check_batch_eval, g_batch, o_batch, 1, [4, 6], seed=900, force={0: 0, 3: 1, 5: p - 1})
+
+
+def test_a_failing_transcript_aborts_the_proof(nmx):
+    from nova_amd import fieldvec as fv
+    import nova_amd
+    A, B = fc.rand_vec(1, 16, 1), fc.rand_vec(1, 16, 2)
+
+    def bad(_coeffs):
+        raise RuntimeError("transcript refused")
+    with pytest.raises(nova_amd.NmxError):
+        fv.sumcheck_prove_quad_prod(1, sp.le(5), 4, dev(A), dev(B), bad)
+    with pytest.raises(nova_amd.NmxError):               # a challenge >= p: from_repr would reject it
+        fv.sumcheck_prove_quad_prod(1, sp.le(5), 4, dev(A), dev(B), lambda c: b"\xff" * 32)
+    # host tables are not accepted: the provers work on HBM-resident tables (straight through the C ABI)
+    from nova_amd import _lib
+    cb = fv.as_transcript(lambda c: sp.le(1))
+    rc = _lib.lib().nmx_sumcheck_prove_quad_prod(1, np.frombuffer(sp.le(5), np.uint8).ctypes.data, 4, A.ctypes.data, B.ctypes.data, 0, cb,
+                                                None, None, None, None)
+    assert rc == _lib.E_ARG
+    # and the library still works afterwards
+    both(sp.check_quad_prod, g_quad, o_quad, 1, 4, seed=1)
+
+
+def test_polling_and_synchronising_agree(nmx):
+    from nova_amd import _lib
+    L = _lib.lib()
+    try:
+        for us in (0, 1, 2000):
+            assert L.nmx_set_option(b"sc_poll_us", us) == 0
+            both(sp.check_cubic3, g_cubic3(), o_cubic3, 1, 12, seed=5, brute=False)
+    finally:
+        assert L.nmx_set_option(b"sc_poll_us", 2000) == 0
+
+
+@pytest.mark.parametrize("fid", [0, 1, 2, 3])
+def test_transposed_product(nmx, fid):
+    from nova_amd import fieldvec as fv
+    k = sp.transposed_kat()
+    m = fv.SparseMatrix(fid, k["indptr"], k["indices"], fc.vec(k["data"]), k["cols"])
+    assert sp.ints(m.multiply_vec_transposed(fc.vec(k["x"])).tobytes()) == k["out"]
+    m.close()
+    for rows, cols, seed, heavy in ((50, 30, 1, (0, 29)), (3000, 640, 2, (0, 639)), (640, 3000, 3, (7,)), (20000, 4096, 4, (0, 1, 4095))):
+        ip, ix, dt = sp.heavy_column_csr(fid, rows, cols, seed, heavy_cols=heavy)
+        x = fc.edge_vectors(fid, rows, seed + 10)
+        m = fv.SparseMatrix(fid, ip, ix, dt, cols)
+        exp = cref.spmv_transposed(fid, ip, ix, dt, rows, cols, x)
+        assert m.multiply_vec_transposed(x).tobytes() == exp                         # host operands
+        got = m.multiply_vec_transposed(dev(x))                                      # HBM-resident, twice (the form is cached)
+        assert got.cpu().numpy().tobytes() == exp
+        assert m.multiply_vec_transposed(dev(x), async_=True).cpu().numpy().tobytes() == exp
+        # the forward product of the same registered matrix is untouched
+        z = fc.edge_vectors(fid, cols, seed + 20)
+        assert m.multiply_vec(z).tobytes() == cref.spmv(fid, ip, ix, dt, rows, z)
+        m.close()
+
+
+def test_spartan_prove_replay_matches_the_oracle(nmx):
+    """bench.py's `spartan_replay` (snark.rs:113-260 as provider calls) at num_cons = 2^12: every commitment-free step of `prove`
+    on HBM-resident vectors against the oracle run in the same order, round polynomials included."""
+    import argparse
+    import torch
+    import bench
+    args = argparse.Namespace(log2n=12, steps=1, warmup=1, no_cpu_baseline=False)
+    out = bench.spartan_replay(args, torch)
+    assert out["cpu_baseline"]["gpu_matches_cpu"] is True, out["cpu_baseline"]["checks"]
+    assert all(out["proof_verifies"].values())
+    assert out["config"]["rounds"] == [12, 13, 12]
+    assert set(out["provers"]) == {"sumcheck_outer", "sumcheck_inner", "sumcheck_batch"}

@@ -84,3 +84,23 @@ def test_transposed_product(fid):
     d, exi = sp.ints(dt), sp.ints(ex)
     exp = sum(exi[r] * ey[int(ix[k])] * d[k] for r in range(rows) for k in range(int(ip[r]), int(ip[r + 1]))) % p
     assert sum(a * b for a, b in zip(t, ey)) % p == exp
+
+
+@pytest.mark.parametrize("ell", [3, 6, 10])
+def test_the_replayed_prove_sequence_verifies_on_the_oracle(ell):
+    """bench.py's spartan_sequence (snark.rs:133-233 as provider calls) through the oracle alone: on a satisfied relaxed instance
+    (E = Az o Bz - u Cz) the three sum-check proofs pass the reference's verifier equations (bench.spartan_verify)."""
+    import bench
+    fid = 1
+    p = fc.FIELDS[fid]
+    n = 1 << ell
+    csr, hW, u, hz = bench.spartan_instance(fid, ell)
+    az, bz, cz = (cref.spmv(fid, *m, n, hz) for m in csr)
+    hE = np.frombuffer(cref.field_cross_term(fid, az, bz, cz, np.zeros((n, 32), np.uint8), u, n), np.uint8).reshape(n, 32)
+    res = bench.spartan_sequence(bench.SpartanCpu(fid, csr, n, hW, hE, hz), ell, p, u)
+    assert all(bench.spartan_verify(p, u, res).values())
+    # an unsatisfied instance must NOT verify (the check has teeth)
+    bad = hE.copy()
+    bad[0, 0] ^= 1
+    res = bench.spartan_sequence(bench.SpartanCpu(fid, csr, n, hW, bad, hz), ell, p, u)
+    assert not bench.spartan_verify(p, u, res)["proof_verifies_outer"]
