@@ -1088,7 +1088,7 @@ def spartan_sequence(be, ell, p, u, call=lambda name, fn: fn()):
     num = lambda b: int.from_bytes(bytes(b), "little")
     tr = standin.Transcript(seed=SPARTAN_SEED)
     tau = [tr.squeeze() for _ in range(ell)]                                  # snark.rs:141-143
-    zc = call("z_concat", lambda: be.clone(be.z))                             # :133
+    zc = call("z_concat", lambda: be.concat_z())                              # :133, :193-196
     Az, Bz, Cz = (call("spmv_x3", lambda j=j: be.spmv(j, zc)) for j in range(3))        # :146
     uCzE = call("uCz_E", lambda: be.axpy(be.E, Cz, u))                        # :147-149
     outer = call("sumcheck_outer", lambda: be.cubic3(le(0), b"".join(tau), Az, Bz, uCzE, tr))     # :158-165
@@ -1113,7 +1113,8 @@ def spartan_sequence(be, ell, p, u, call=lambda name, fn: fn()):
     tr.absorb(b"".join(batch[2]))
     c = tr.squeeze()                                                           # spartan/mod.rs:425
     w_joint = call("batch_witness", lambda: be.lincomb([be.W, be.E], c))       # spartan/mod.rs:429
-    return {"outer": outer, "inner": inner, "batch": batch, "evaluations": (claim_Cz, eval_E, eval_W), "batch_witness": be.host(w_joint),
+    # (the batched witness stays where it is -- it is EE::prove's input; the caller brings it to the host outside the timed region)
+    return {"outer": outer, "inner": inner, "batch": batch, "evaluations": (claim_Cz, eval_E, eval_W), "batch_witness": w_joint,
             "tau": tau, "r": r, "rho": rho}
 
 
@@ -1151,6 +1152,9 @@ class SpartanCpu:
 
     def clone(self, v):
         return v.copy()
+
+    def concat_z(self):
+        return self.z.copy()
 
     def spmv(self, j, v):
         return self._np(self.cref.spmv(self.fid, *self.csr[j], self.n, v), self.n)
@@ -1218,6 +1222,7 @@ def spartan_replay(args, torch):
     p = util_modulus(fid)
     L = _lib.lib()
     csr, hW, u, hz = spartan_instance(fid, ell)
+    x0 = hz[n + 1:n + 2].copy()
     mats = [fv.SparseMatrix(fid, ip, ix, dt, 2 * n) for ip, ix, dt in csr]
     dW, dz = (torch.from_numpy(v).cuda() for v in (hW, hz))
     dE = fv.r1cs_cross_term(mats[0], mats[1], mats[2], dz, None, torch.zeros((n, 32), dtype=torch.uint8, device="cuda"), u)
@@ -1232,13 +1237,14 @@ def spartan_replay(args, torch):
         spans.setdefault(name, []).append(time.perf_counter() - t)
         if prof is not None and name.startswith("sumcheck"):
             buf = (ctypes.c_float * 8)()
-            if L.nmx_profile_last(buf, 8) >= 6:
-                prof.setdefault(name, []).append([buf[i] for i in range(6)])
+            if L.nmx_profile_last(buf, 8) >= 7:
+                prof.setdefault(name, []).append([buf[i] for i in range(7)])
         return v
 
     class Gpu:
         W, E, z = dW, dE, dz
-        clone = staticmethod(lambda v: v.clone())
+        clone = staticmethod(lambda v: fv.concat(fid, [v], async_=True))        # on the library's stream (torch's clone is not ordered with it)
+        concat_z = staticmethod(lambda: fv.concat(fid, [dW, u, x0], n_out=2 * n))
         spmv = staticmethod(lambda j, v: mats[j].multiply_vec(v, async_=True))
         spmv_t = staticmethod(lambda j, v: mats[j].multiply_vec_transposed(v, async_=True))
         axpy = staticmethod(lambda a, b, r: fv.axpy(fid, a, b, r, async_=True))
@@ -1270,7 +1276,8 @@ def spartan_replay(args, torch):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     # the same sequence with every provider call timed on its own and the provers' own split (profiling on): per prover
-    # [total ms, waiting for a round's result (GPU + latency), host algebra, transcript callback, launches, rounds]
+    # [total ms, waiting for a round's result (GPU + latency), host algebra + launches + tail rounds, transcript callback, launches,
+    #  rounds run on the device, rounds finished on the host]
     spans, prof = {}, {}
     L.nmx_set_profiling(1)
     passes = 3
@@ -1281,7 +1288,7 @@ def spartan_replay(args, torch):
     breakdown["_sum"] = round(sum(breakdown.values()), 4)
     provers = {k: {"ms": round(float(np.mean([q[0] for q in v])), 4), "wait_ms": round(float(np.mean([q[1] for q in v])), 4),
                    "host_algebra_ms": round(float(np.mean([q[2] for q in v])), 4), "transcript_ms": round(float(np.mean([q[3] for q in v])), 4),
-                   "launches": int(v[-1][4]), "rounds": int(v[-1][5])} for k, v in prof.items()}
+                   "launches": int(v[-1][4]), "rounds": int(v[-1][5]), "host_tail_rounds": int(v[-1][6])} for k, v in prof.items()}
     spans, prof = None, None
     outj = {
         "metric": "Spartan RelaxedR1CSSNARK prove (sum-check half) provider-call REPLAY ms (BN254 Fr)", "value": dt * 1e3, "unit": "ms",
@@ -1295,6 +1302,7 @@ def spartan_replay(args, torch):
         "roofline": None, "breakdown_ms": breakdown, "provers": provers,
         "proof_verifies": spartan_verify(p, u, res),
     }
+    res["batch_witness"] = Gpu.host(res["batch_witness"])
     if not args.no_cpu_baseline:
         from oracle import cref
         threads = effective_cpus()
@@ -1303,6 +1311,7 @@ def spartan_replay(args, torch):
         t1 = time.perf_counter()
         exp = spartan_sequence(cpu, ell, p, u)
         t_cpu = time.perf_counter() - t1
+        exp["batch_witness"] = cpu.host(exp["batch_witness"])
         checks = {k: res[k] == exp[k] for k in ("outer", "inner", "batch", "evaluations", "batch_witness")}
         checks.update(outj["proof_verifies"])
         outj["cpu_baseline"] = {"value": t_cpu * 1e3, "unit": "ms", "cores": threads, "kind": "port",

@@ -331,6 +331,13 @@ int nmx_field_cross_term2(int field, const void* az, const void* bz, const void*
                           const void* u, size_t n, uint32_t flags, void* out);
 /* out = a + b : Z = Z1 + Z2 (src/r1cs/mod.rs:590-609) */
 int nmx_field_vec_add(int field, const void* a, const void* b, size_t n, uint32_t flags, void* out);
+/* out[n_out] = parts[0] || parts[1] || ... || 0 ... 0 for vectors that live in HBM: Spartan's `z = [W.W, vec![U.u], U.X].concat()`
+ * then `z.resize(2 * num_vars, 0)` (src/spartan/snark.rs:133, 193-196), and -- with one part -- the clones batch_eval_reduce
+ * takes of W and E before it binds them (src/spartan/mod.rs:407-410).  Bit i of device_mask: parts[i] is an HBM pointer (else a
+ * host pointer: u and X are host scalars); `out` is HBM (NMX_SCALARS_DEVICE required).  Copies on the library's stream, ordered
+ * with the calling thread's other calls; NMX_ASYNC applies when every part is in HBM.  k <= 64. */
+int nmx_field_concat(int field, const void* const* parts, const size_t* lens, uint64_t device_mask, size_t k, size_t n_out,
+                     uint32_t flags, void* out);
 /* MultilinearPolynomial::bind_poly_var_top (src/spartan/polys/multilinear.rs:65-84):
  * out[i] = z[i] + r*(z[i + len/2] - z[i]), i < len/2.  `out` may equal `z` (in place, as the reference does). */
 int nmx_mle_bind_top(int field, const void* z, size_t len, const void* r, uint32_t flags, void* out);
@@ -375,7 +382,10 @@ int nmx_sumcheck_plain_sums(int field, int kind, const void* A, const void* B, c
  * `UniPoly { coeffs }`, whose to_transcript_bytes drops the linear term itself) and returns the challenge; elements in the
  * vectors' own form (NMX_SCALARS_MONT as everywhere).  A non-zero return aborts the proof (NMX_E_ARG); a challenge >= p is
  * NMX_E_SCALAR_RANGE.  Outputs (any may be NULL): out_polys = rounds x n_coeffs x 32 bytes (what SumcheckProof compresses),
- * out_r = rounds x 32 (the challenges), final evaluations as listed.  option "sc_poll_us": how long a round's mailbox is
+ * out_r = rounds x 32 (the challenges), final evaluations as listed.  The tables' contents after a call are unspecified (partly
+ * bound: the reference's are consumed too).  Once the tables hold <= 2^"sc_host_tail" elements (option, default 6 = 64
+ * elements, 0..8) the remaining rounds run on the HOST -- a few hundred field products take the host 1-8 us, any kernel round
+ * trip 20-25 us; the last device bind lands the tables in pinned memory.  Option "sc_poll_us": how long a round's mailbox is
  * polled before the stream is synchronised instead (default 2000; 0: always synchronise).
  *  - nmx_sumcheck_prove_cubic_with_three_inputs == SumcheckProof::prove_cubic_with_three_inputs (sumcheck.rs:446-507) with its
  *    EqSumCheckInstance (sumcheck.rs:593-1253; all sqrt-size eq tables built by one launch): A, B, C of 2^num_rounds elements,

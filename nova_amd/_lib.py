@@ -106,6 +106,7 @@ def lib():
     L.nmx_field_lincomb_powers.argtypes = [i, vp, vp, sz, vp, sz, u32, vp]
     L.nmx_mle_multi_evaluate.argtypes = [i, vp, sz, sz, vp, sz, u32, vp]
     L.nmx_spmv_apply_transposed.argtypes = [u64, vp, sz, u32, vp]
+    L.nmx_field_concat.argtypes = [i, vp, vp, u64, sz, sz, u32, vp]
     L.nmx_sumcheck_prove_cubic_with_three_inputs.argtypes = [i, vp, vp, sz, vp, vp, vp, u32, TRANSCRIPT_FN, vp, vp, vp, vp]
     L.nmx_sumcheck_prove_quad_prod.argtypes = [i, vp, sz, vp, vp, u32, TRANSCRIPT_FN, vp, vp, vp, vp]
     L.nmx_sumcheck_prove_batch_eval.argtypes = [i, vp, vp, vp, vp, vp, sz, u32, TRANSCRIPT_FN, vp, vp, vp, vp]

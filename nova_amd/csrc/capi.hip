@@ -165,6 +165,7 @@ static void ensure_init() {
   if (const char* t = getenv("NMX_TUNE_HIST_BS")) G.hist_bs = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_SYNC_SPIN_US")) G.sync_spin_us = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_SC_POLL_US")) G.sc_poll_us = (uint32_t)atoi(t);
+  if (const char* t = getenv("NMX_SC_HOST_TAIL")) G.sc_host_tail = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_HORNER_TOP")) G.horner_top = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_HORNER_SUB")) G.horner_sub = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_HORNER_ORDER")) G.horner_order = atoi(t) ? 1u : 0u;
@@ -2269,7 +2270,7 @@ int nmx_spmv_apply(uint64_t handle, const void* z, size_t z_len, uint32_t flags,
 }
 
 // M^T in virtual rows, built once per matrix from the resident CSR (Global::SparseSet::Transposed): counting sort of the entries
-// by column on the host, columns longer than 64 entries cut into chunks of max(64, sqrt(length))
+// by column on the host, columns longer than 64 entries cut into chunks of 64
 static std::shared_ptr<Global::SparseSet::Transposed> transposed_of(Ctx& c, Global::SparseSet& ss) {
   std::lock_guard<std::mutex> lk(ss.t_mu);
   if (ss.tr) return ss.tr;
@@ -2304,8 +2305,7 @@ static std::shared_ptr<Global::SparseSet::Transposed> transposed_of(Ctx& c, Glob
       vout.push_back((uint32_t)j);
       continue;
     }
-    uint32_t T = 64;
-    while ((uint64_t)T * T < L) T++;
+    const uint32_t T = 64;  // every lane walks at most 64 entries; a split column's partials are summed by a block (SpmvHeavyFn)
     for (uint32_t a = b; a < e; a += T) {
       vptr.push_back(a + T < e ? a + T : e);
       vout.push_back(0x80000000u | (uint32_t)nparts++);
@@ -2347,6 +2347,42 @@ int nmx_spmv_apply_transposed(uint64_t handle, const void* x, size_t x_len, uint
     auto tr = transposed_of(*L.c, ss);
     fv_spmv_apply_transposed(*L.c, ss.field, tr->vptr, tr->indices, tr->data, tr->vout, tr->hrow, tr->hstart, tr->nvirt, tr->nheavy,
                              tr->nparts, ss.rows, ss.cols, x, flags, out);
+  });
+}
+
+// z = [W, u, X] zero-padded (snark.rs:133, 193-196) and the clones of batch_eval_reduce (spartan/mod.rs:407-410) for vectors that
+// live in HBM: copies on the library's stream, so that they are ordered with the kernels that read them
+int nmx_field_concat(int field, const void* const* parts, const size_t* lens, uint64_t device_mask, size_t k, size_t n_out, uint32_t flags,
+                     void* out) {
+  return guarded([&] {
+    require(field >= 0 && field < 4, NMX_E_ARG, "bad field id");
+    require((parts && lens) || k == 0, NMX_E_ARG, "null argument");
+    require(out || n_out == 0, NMX_E_ARG, "null argument");
+    require(flags & NMX_SCALARS_DEVICE, NMX_E_ARG, "nmx_field_concat writes an HBM-resident vector (NMX_SCALARS_DEVICE)");
+    require(k <= 64, NMX_E_ARG, "at most 64 parts");
+    size_t total = 0;
+    for (size_t i = 0; i < k; i++) {
+      require(parts[i] || lens[i] == 0, NMX_E_ARG, "null part");
+      total += lens[i];
+    }
+    require(total <= n_out, NMX_E_ARG, "parts longer than the output");
+    if (n_out == 0) return;
+    CtxLease L;
+    size_t off = 0;
+    bool host_part = false;
+    for (size_t i = 0; i < k; i++) {
+      if (!lens[i]) continue;
+      const bool dev = (device_mask >> i) & 1u;
+      host_part |= !dev;
+      HIPCHK(hipMemcpyAsync((char*)out + off * 32, parts[i], lens[i] * 32, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, L.c->stream));
+      off += lens[i];
+    }
+    if (off < n_out) HIPCHK(hipMemsetAsync((char*)out + off * 32, 0, (n_out - off) * 32, L.c->stream));
+    if ((flags & NMX_ASYNC) && !host_part) {
+      async_mark(*L.c);
+      return;
+    }
+    stream_wait(L.c->stream);
   });
 }
 
@@ -2487,6 +2523,10 @@ int nmx_set_option(const char* name, uint32_t value) {
     else if (n == "hist_bs") G.hist_bs = value;
     else if (n == "sync_spin_us") G.sync_spin_us = value;
     else if (n == "sc_poll_us") G.sc_poll_us = value;
+    else if (n == "sc_host_tail") {
+      require(value <= 8, NMX_E_ARG, "sc_host_tail: log2 of the table length the host takes over, 0..8");
+      G.sc_host_tail = value;
+    }
     else if (n == "horner_order") G.horner_order = value ? 1u : 0u;
 
     else if (n == "shard_min_n") G.shard_min_n.store(value ? value : 1u);

@@ -126,6 +126,30 @@ template <int FID> struct EqDirect2Fn {
   }
 };
 
+// Large eq tables (13 <= ell <= 24) in TWO launches instead of ell doubling steps (a 2^20 table was 20 dependent launches,
+// ~130 us, for 32 MB of output: profiles/r05_spartan): the sqrt-size tables of the two halves of the point -- the left one in the
+// INTERNAL form, so that one product per entry gives out[x] = L[x >> ellR] * R[x & mask] in the vectors' own form -- and the
+// product pass.  compute_eval_table_sparse's operand (src/spartan/snark.rs:182) is such a table.
+template <int FID> struct EqSplit2Fn {
+  uint32_t *outL, *outR;
+  Fp<FID> r[2 * EqDirectFn<FID>::kMaxEll], nr[2 * EqDirectFn<FID>::kMaxEll];
+  Fp<FID> oneL, oneR;
+  uint32_t ellL, ellR;
+  NMX_HD void operator()(uint32_t g) const {
+    const bool right = g >= (1u << ellL);
+    const uint32_t x = right ? g - (1u << ellL) : g, ell = right ? ellR : ellL, o = right ? ellL : 0u;
+    Fp<FID> acc = right ? oneR : oneL;
+    for (uint32_t i = 0; i < ell; i++) acc = acc * (((x >> (ell - 1 - i)) & 1u) ? r[o + i] : nr[o + i]);
+    st<FID>(right ? outR : outL, x, acc);
+  }
+};
+template <int FID> struct EqProductFn {
+  const uint32_t *L, *R;
+  uint32_t* out;
+  uint32_t shift, mask;
+  NMX_HD void operator()(uint32_t x) const { st<FID>(out, x, ld<FID>(L, x >> shift) * ld<FID>(R, x & mask)); }
+};
+
 // Coefficient classes, the GPU form of the reference's PrecomputedSparseMatrix (src/r1cs/sparse.rs:19-199: +-1 entries
 // are added / subtracted, |k| <= 7 by repeated doubling, the rest multiplied).  R1CS matrices are almost all +-1: here
 // the class rides in the top four bits of the 32-bit column index (columns < 2^28), so a unit or small entry costs
@@ -205,7 +229,7 @@ template <int FID> struct SpmvFn {
 // for every entry -- a scatter-add on the reference's side, a gather over the transposed matrix here).  The CSC arrays are cut
 // into virtual rows at registration of the transposed form (Global::SparseSet::Transposed): short columns are one virtual row
 // that writes its output element; a long column (the constant-one column of an R1CS matrix has an entry per constraint) is
-// several, each writing a partial that SpmvHeavyFn adds up -- no lane walks more than max(64, sqrt(column length)) entries.
+// several, each writing a partial that k_spmv_heavy adds up (one block per split column) -- no lane walks more than 64 entries.
 template <int FID> struct SpmvSegFn {
   const uint32_t* vptr;     // nvirt + 1
   const uint32_t* indices;  // nnz: row of M | class << 28
@@ -221,23 +245,38 @@ template <int FID> struct SpmvSegFn {
     else st<FID>(out, o, acc);
   }
 };
-template <int FID> struct SpmvHeavyFn {  // one split column per lane: the sum of its partials (additions only)
-  const uint32_t *hrow, *hstart, *partial;
-  uint32_t* out;
-  NMX_HD void operator()(uint32_t hdx) const {
-    using F = Fp<FID>;
-    F acc = F::zero();
-    uint32_t pending = 0;
-    for (uint32_t k = hstart[hdx]; k < hstart[hdx + 1]; k++) {
-      acc = acc + ld<FID>(partial, k);
-      if (++pending == 6) {
-        acc = acc.norm().canon();
-        pending = 0;
-      }
+// one split column per BLOCK: 256 lanes add up its partials (the constant-one column of a 2^20-constraint matrix leaves thousands),
+// a shuffle / LDS tree joins them.  Additions only.
+template <int FID> __global__ __launch_bounds__(256) void k_spmv_heavy(const uint32_t* hrow, const uint32_t* hstart, const uint32_t* partial, uint32_t* out) {
+  using F = Fp<FID>;
+  __shared__ uint32_t lds[9 * 256];
+  const uint32_t b = hstart[blockIdx.x], e = hstart[blockIdx.x + 1], t = threadIdx.x;
+  F acc = F::zero();
+  uint32_t pending = 0;
+  for (uint32_t k = b + t; k < e; k += 256u) {
+    acc = acc + ld<FID>(partial, k);
+    if (++pending == 6) {
+      acc = acc.norm().canon();
+      pending = 0;
     }
-    st<FID>(out, hrow[hdx], acc.norm());
   }
-};
+  acc = acc.norm().canon();
+#pragma unroll
+  for (int i = 0; i < 9; i++) lds[i * 256 + t] = acc.l[i];
+  __syncthreads();
+  for (uint32_t s = 128; s >= 1; s >>= 1) {
+    if (t < s) {
+      F o;
+#pragma unroll
+      for (int i = 0; i < 9; i++) o.l[i] = lds[i * 256 + t + s];
+      acc = (acc + o).norm().canon();
+#pragma unroll
+      for (int i = 0; i < 9; i++) lds[i * 256 + t] = acc.l[i];
+    }
+    __syncthreads();
+  }
+  if (t == 0) st<FID>(out, hrow[blockIdx.x], acc);
+}
 
 // commit_T in one pass over the rows (src/r1cs/mod.rs:612-620): T[row] = (A z)[row] (B z)[row] - u (C z)[row] - E[row].  The
 // three products and the cross term of CrossTermFn without AZ, BZ, CZ ever reaching HBM, and one launch instead of four;
@@ -1016,6 +1055,24 @@ template <int FID> static void eq_evals_t(Ctx& c, const void* r_host, uint32_t e
     be.launch(f, 1u << ell);
     return;
   }
+  if (ell <= 2 * EqDirectFn<FID>::kMaxEll) {  // two sqrt-size tables + one product per entry (EqSplit2Fn / EqProductFn)
+    const uint32_t ellR = ell / 2, ellL = ell - ellR;
+    auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    arena_reserve(c, pad(((size_t)1 << ellL) * 32) + pad(((size_t)1 << ellR) * 32) + 256);
+    EqSplit2Fn<FID> f;
+    f.outL = (uint32_t*)c.arena, f.outR = (uint32_t*)(c.arena + pad(((size_t)1 << ellL) * 32));
+    f.ellL = ellL, f.ellR = ellR, f.oneL = F::one(), f.oneR = F::from_words(w);
+    const F one_i = F::one();
+    for (uint32_t i = 0; i < 2 * EqDirectFn<FID>::kMaxEll; i++) f.r[i] = f.nr[i] = F::zero();
+    for (uint32_t i = 0; i < ell; i++) {
+      f.r[i] = challenge<FID>((const uint8_t*)r_host + 32 * (size_t)i, mont);
+      f.nr[i] = F::sub2(one_i, f.r[i]).norm().canon();
+    }
+    be.launch(f, (1u << ellL) + (1u << ellR));
+    EqProductFn<FID> g{f.outL, f.outR, d_out, ellR, (1u << ellR) - 1u};
+    be.launch(g, 1u << ell);
+    return;
+  }
   HIPCHK(hipMemcpyAsync(d_out, w, 32, hipMemcpyHostToDevice, c.stream));
   stream_wait(c.stream);  // w is a stack buffer
   uint32_t size = 1;
@@ -1109,8 +1166,8 @@ static void spmv_apply_transposed_t(Ctx& c, const uint32_t* vptr, const uint32_t
   SpmvSegFn<FID> f{vptr, indices, data, dx, vout, dout, partial, rows <= ((size_t)1 << kSpmvColBits) ? (1u << kSpmvColBits) - 1u : 0xffffffffu};
   be.launch(f, (uint32_t)nvirt);
   if (nheavy) {
-    SpmvHeavyFn<FID> g{hrow, hstart, partial, dout};
-    be.launch(g, (uint32_t)nheavy);
+    hipLaunchKernelGGL((k_spmv_heavy<FID>), dim3((uint32_t)nheavy), dim3(256), 0, c.stream, hrow, hstart, (const uint32_t*)partial, dout);
+    HIPCHK(hipGetLastError());
   }
   be.mark("end");
   if (!dev) HIPCHK(hipMemcpyAsync(out, dout, cols * 32, hipMemcpyDeviceToHost, c.stream));

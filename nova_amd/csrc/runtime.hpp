@@ -274,7 +274,7 @@ struct Global {
     uint32_t *indptr = nullptr, *indices = nullptr, *data = nullptr;
     // M^T for compute_eval_table_sparse (nmx_spmv_apply_transposed), built from the resident CSR on first use: the CSC arrays
     // cut into VIRTUAL rows (a column of an R1CS matrix can hold one entry per constraint -- the constant-one column does --
-    // so a column longer than 64 entries is split into chunks of max(64, sqrt(length)) entries, each its own lane), the slot
+    // so a column longer than 64 entries is split into chunks of 64 entries, each its own lane; a block sums a column's partials), the slot
     // every virtual row writes (an output row, or 2^31 | index of a partial), and the (row, first partial) list of the split rows
     struct Transposed {
       uint32_t *vptr = nullptr, *indices = nullptr, *data = nullptr, *vout = nullptr, *hrow = nullptr, *hstart = nullptr;
@@ -320,6 +320,7 @@ struct Global {
   std::atomic<uint32_t> hist_grid{0};             // env NMX_TUNE_HIST_GRID / option hist_grid
   std::atomic<uint32_t> hist_bs{0};               // env NMX_TUNE_HIST_BS / option hist_bs: threads per block of k_hist_hi (0: as k_part_hi)
   std::atomic<uint32_t> horner_order{1};          // option horner_order: 1 = tiles of k_horner_scan by start-order ticket, 0 = by block id
+  std::atomic<uint32_t> sc_host_tail{6};          // option sc_host_tail: the sum-check provers finish on the host once the tables hold <= 2^this elements (0: only the final values come over; max 8)
   std::atomic<uint32_t> sc_poll_us{2000};         // option sc_poll_us: the sum-check provers poll a round's mailbox this long before they synchronise the stream (0: always synchronise)
   std::atomic<uint32_t> sync_spin_us{0};          // env NMX_SYNC_SPIN_US / option sync_spin_us: poll the stream this long before blocking
   std::atomic<uint32_t> force_peer_copy{0};       // option force_peer_copy: HBM-resident scalars of a sharded call take the staging + hipMemcpyPeerAsync branch even when source and destination are the same GPU (tests on a 1-GPU box)

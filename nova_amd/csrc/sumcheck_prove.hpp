@@ -23,12 +23,15 @@
 // All sqrt-size eq tables of an instance (poly_eq_left[k], poly_eq_right[k], sumcheck.rs:608-641) are built by one launch into a
 // heap layout (table k at offset 2^k) in the context's aux arena.
 #pragma once
+#include <array>
+
+#include "sc_host.hpp"
 
 namespace nmx {
 
 // ---- mailbox ----------------------------------------------------------------------------------------------------------
 static constexpr uint32_t kMailSlots = 16, kMailSlotWords = 64;  // slot = 256 bytes: word 0 sequence, words 8..31 three field elements
-static constexpr uint32_t kScSmallHq = 512;                       // bound halves up to this many indices run as one block
+static constexpr uint32_t kScSmallHq = 256;                       // bound halves up to this many indices run as one block (one index per thread)
 
 __device__ __forceinline__ void mail_publish(uint32_t* slot, uint32_t seq) {
   __threadfence_system();  // the result words (plain stores into host memory) before the sequence word
@@ -166,24 +169,33 @@ template <int FID, int MODE> __global__ __launch_bounds__(256) void k_sc_small(S
   }
 }
 
-// ---- the last bind: tables of two elements -> one; the values ARE the final claims (poly_A[0], ..., sumcheck.rs:241-248) ---
-struct ScFinalArgs {
+// ---- the bind that hands the tables to the host: bound values (or, bind = 0, the tables as they are) into pinned memory ------
+// The tail rounds run on the host (sc_host.hpp); with half == 1 this is the LAST bind and the values are the final claims
+// (poly_A[0], ..., sumcheck.rs:241-248, 499-506).
+template <int FID> struct ScBindOutArgs {
   uint32_t* X[3];
-  uint32_t n, seq;
+  uint32_t* host[3];  // pinned, device-visible: `half` elements each
+  Fp<FID> r;
+  uint32_t n, half, bind, seq;
   uint32_t* slot;
 };
-template <int FID> __global__ __launch_bounds__(64) void k_sc_final(ScFinalArgs a, Fp<FID> r) {
+template <int FID> __global__ __launch_bounds__(256) void k_sc_bind_to_host(ScBindOutArgs<FID> a) {
   using F = Fp<FID>;
-  const uint32_t t = threadIdx.x;
-  if (t < a.n) {
-    const F x0 = ldw<FID>(a.X[t], 0), x1 = ldw<FID>(a.X[t], 1);
-    const F y = (x0 + r * F::sub2(x1, x0).norm()).norm().canon();
-    y.to_words(a.X[t]);
-    y.to_words(a.slot + 8 + 8 * t);
-    __threadfence_system();
+  for (uint32_t id = threadIdx.x; id < a.half; id += 256u) {
+    for (uint32_t t = 0; t < a.n; t++) {
+      const F x0 = ldw<FID>(a.X[t], id);
+      F y = x0.canon();
+      if (a.bind) {
+        const F x1 = ldw<FID>(a.X[t], (size_t)id + a.half);
+        y = (x0 + a.r * F::sub2(x1, x0).norm()).norm().canon();
+        y.to_words(a.X[t] + 8 * (size_t)id);
+      }
+      y.to_words(a.host[t] + 8 * (size_t)id);
+    }
   }
+  __threadfence_system();
   __syncthreads();
-  if (t == 0) mail_publish(a.slot, a.seq);
+  if (threadIdx.x == 0) mail_publish(a.slot, a.seq);
 }
 
 // ---- all eq tables of one instance in one launch ---------------------------------------------------------------------
@@ -235,63 +247,60 @@ template <int FID> struct EqHalveFn {
 };
 
 // ---- host side ----------------------------------------------------------------------------------------------------------
-// the transcript's side of a round: TranscriptFn (runtime.hpp; include/nova_mi355x.h nmx_transcript_fn)
 struct ScProf {  // wall-clock split of one prover call (profiling on): where a round's time goes
-  double wait = 0, host = 0, cb = 0;
-  uint32_t launches = 0, rounds = 0;
+  double wait = 0, cb = 0;
+  uint32_t launches = 0, rounds = 0, host_rounds = 0;
 };
+static constexpr uint32_t kTailMaxLog2 = 8, kTailMax = 1u << kTailMaxLog2;  // the longest table the tail takes over
+static constexpr size_t kMailBytes = kMailSlots * kMailSlotWords * 4, kTailSlotBytes = (size_t)kTailMax * 32;
 
-template <int FID> struct ScHost {
+template <int FID> struct ScDev {
   using F = Fp<FID>;
+  using H = HostFp4<FID>;
   Ctx& c;
   bool mont;
-  F corr[5];   // raw device sums -> the vectors' own form, by the number of stored factors per term (eq_sums_t's constants)
-  F to_mont;   // 2^256 as a plain residue: internal -> Montgomery words
+  ScAlg<FID> alg;
   ScProf prof;
   bool profiling;
-  ScHost(Ctx& ctx, uint32_t flags) : c(ctx), mont((flags & NMX_SCALARS_MONT) != 0), profiling(G.profiling) {
-    for (uint32_t k = 1; k <= 4; k++) corr[k] = pow2_plain<FID>(261u * k - (mont ? 256u * (k - 1) : 0u));
-    to_mont = pow2_plain<FID>(256);
+  uint32_t tail_len;  // tables of at most this many elements finish on the host (1: only the final values come over)
+  ScDev(Ctx& ctx, uint32_t flags) : c(ctx), mont((flags & NMX_SCALARS_MONT) != 0), alg(mont), profiling(G.profiling) {
+    const uint32_t t = G.sc_host_tail.load(std::memory_order_relaxed);
+    tail_len = 1u << (t > kTailMaxLog2 ? kTailMaxLog2 : t);
     mail_init();
   }
-  // --- canonical host arithmetic on internal residues (every value < p after every operation)
-  static F add(const F& a, const F& b) { return (a + b).norm().canon(); }
-  static F sub(const F& a, const F& b) { return F::sub2(a, b).norm().canon(); }
-  static F mul(const F& a, const F& b) { return (a * b).canon(); }
-  static F dbl(const F& a) { return add(a, a); }
-  static bool is_zero(const F& a) { return a.canon().is_zero_limbs(); }
-  F in(const void* p) const { return challenge_internal<FID>(p, mont); }
-  void out(const F& v, uint8_t* p) const {
-    uint32_t w[8];
-    (mont ? (v * to_mont).canon() : v.to_canonical()).to_words(w);
-    memcpy(p, w, 32);
+  // raw device sums -> elements: a sum of terms with k stored factors is x Fm^k / R'^(k-1) (eq_sums_t); as an element that is
+  // (raw words) x 2^(261 (k - 1) + 256 - 256 k [mont]) / 2^256: ONE Montgomery product with a cached constant
+  H raw(const uint32_t* words, uint32_t k) const {
+    static const std::array<H, 5> tab[2] = {make_corr(false), make_corr(true)};
+    return H::from_plain_times(words, tab[mont ? 1 : 0][k]);
   }
-  // a raw device sum of terms with k stored factors -> internal residue
-  F raw(const uint32_t* words, uint32_t k) const {
-    const F v = (F::from_words(words) * corr[k]).canon();  // x * Fm: the vectors' own form
-    return (mont ? v.mont256_to_internal() : v.to_internal()).canon();
+  static std::array<H, 5> make_corr(bool m) {
+    std::array<H, 5> t;
+    t[0] = H::one();
+    for (uint32_t k = 1; k <= 4; k++) t[k] = H::pow2(261u * (k - 1) + 256u - (m ? 256u * k : 0u));
+    return t;
   }
-  // a stored element (the vectors' own form) read back from the device -> internal
-  F stored(const uint32_t* words) const {
-    const F v = F::from_words(words);
-    return (mont ? v.mont256_to_internal() : v.to_internal()).canon();
-  }
+  // a stored element (the vectors' own form) -> element
+  H stored(const uint32_t* words) const { return mont ? H::from_mont256(words) : H::from_canonical(words); }
 
-  // --- mailbox
+  // --- mailbox: [slots: kMailBytes][tail areas: kMailSlots x kTailSlotBytes]
   void mail_init() {
     if (c.mail) return;
     void* p = nullptr;
-    HIPCHK(hipHostMalloc(&p, kMailSlots * kMailSlotWords * 4, hipHostMallocCoherent | hipHostMallocMapped));
-    memset(p, 0, kMailSlots * kMailSlotWords * 4);
+    const size_t bytes = kMailBytes + kMailSlots * kTailSlotBytes;
+    HIPCHK(hipHostMalloc(&p, bytes, hipHostMallocCoherent | hipHostMallocMapped));
+    memset(p, 0, bytes);
     void* d = nullptr;
     HIPCHK(hipHostGetDevicePointer(&d, p, 0));
     c.mail = (char*)p;
     c.mail_dev = (char*)d;
   }
   uint32_t* slot_dev(uint32_t s) const { return (uint32_t*)c.mail_dev + (size_t)s * kMailSlotWords; }
+  uint32_t* tail_dev(uint32_t s) const { return (uint32_t*)(c.mail_dev + kMailBytes + (size_t)s * kTailSlotBytes); }
+  const uint32_t* tail_host(uint32_t s) const { return (const uint32_t*)(c.mail + kMailBytes + (size_t)s * kTailSlotBytes); }
   uint32_t next_seq() { return ++c.mail_seq ? c.mail_seq : ++c.mail_seq; }  // never 0 (a fresh mailbox reads 0)
-  // waits until slot s carries `seq`; returns its three result words blocks.  Polling the sequence word costs a PCIe read
-  // of host memory by the host itself (none); the stream is only synchronised when the poll gives up or polling is off.
+  // waits until slot s carries `seq`; returns its result words.  The sequence word is polled in host memory; the stream is only
+  // synchronised when the poll gives up (option sc_poll_us) or polling is off.
   const uint32_t* wait(uint32_t s, uint32_t seq) {
     const auto t0 = std::chrono::steady_clock::now();
     uint32_t* host = (uint32_t*)c.mail + (size_t)s * kMailSlotWords;
@@ -314,101 +323,63 @@ template <int FID> struct ScHost {
     return host + 8;
   }
   void launched(uint32_t n = 1) { prof.launches += n; }
-  // transcript step: coefficients out (the vectors' own form), challenge in
-  F ask(TranscriptFn cb, void* ctx, const F* coeffs, uint32_t n, uint8_t* polys_out, uint8_t* r_out) {
-    uint8_t buf[4 * 32], ch[32];
-    for (uint32_t i = 0; i < n; i++) out(coeffs[i], buf + 32 * i);
-    if (polys_out) memcpy(polys_out, buf, 32 * (size_t)n);
+  // the transcript step, timed
+  H ask(TranscriptFn cb, void* ctx, const H* co, uint32_t n, uint8_t* polys_out, uint8_t* r_out) {
+    if (!profiling) return alg.ask(cb, ctx, co, n, polys_out, r_out);
     const auto t0 = std::chrono::steady_clock::now();
-    const int rc = cb(ctx, buf, n, ch);
-    if (profiling) prof.cb += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    if (rc != 0) throw Fail{NMX_E_ARG, "sum-check: the transcript callback failed (" + std::to_string(rc) + ")"};
-    if (r_out) memcpy(r_out, ch, 32);
-    return in(ch);  // NMX_E_SCALAR_RANGE for a challenge >= p
-  }
-  // UniPoly::evaluate (univariate.rs:140-149)
-  static F poly_eval(const F* co, uint32_t n, const F& r) {
-    F eval = co[0], power = r;
-    for (uint32_t i = 1; i < n; i++) {
-      eval = add(eval, mul(power, co[i]));
-      power = mul(power, r);
-    }
-    return eval;
-  }
-  F two_inv() const {
-    F two = F::zero();
-    two.l[0] = 2;
-    return two.to_internal().canon().inv().canon();
-  }
-  F pow2(uint32_t e) const {  // Scalar::from(2).pow_vartime([e]), internal
-    F two = F::zero();
-    two.l[0] = 2;
-    const F t = two.to_internal().canon();
-    F acc = F::one();
-    for (uint32_t i = 0; i < e; i++) acc = mul(acc, t);
-    return acc;
+    const H r = alg.ask(cb, ctx, co, n, polys_out, r_out);
+    prof.cb += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();  // (includes two conversions)
+    return r;
   }
   void finish_profile(double total_ms) {
     if (!profiling) return;
-    float v[6] = {(float)total_ms, (float)prof.wait, (float)(total_ms - prof.wait - prof.cb), (float)prof.cb, (float)prof.launches,
-                  (float)prof.rounds};
-    prof_store(v, 6);
+    float v[7] = {(float)total_ms, (float)prof.wait, (float)(total_ms - prof.wait - prof.cb), (float)prof.cb, (float)prof.launches,
+                  (float)prof.rounds, (float)prof.host_rounds};
+    prof_store(v, 7);
   }
 };
+static void rethrow(const ScFail& f) { throw Fail{f.code == 2 ? NMX_E_SCALAR_RANGE : NMX_E_ARG, "sum-check: " + f.msg}; }
 
-// grids of the passes (the rules of eq_sums_t / bind_eq_sums_t / plain_sums_t)
+// grids: the first round's sums keep the rules of eq_sums_t / plain_sums_t (tuned at 2^24); the fused bind + sums passes run ONE
+// index per thread -- at the sizes a prover sees (<= 2^20 indices) a pass is a latency chain of ~10 products per index, and
+// four indices per thread (bind_eq_sums_t's rule, right for 2^24) made every pass from 2^10 to 2^18 indices take 45-59 us
+// (profiles/r05_spartan: one block per CU at 2^18)
 static inline uint32_t sc_blocks_sums(uint32_t h, bool mode1) {
   const uint32_t want = (h + 256 * 8 - 1) / (256 * 8), cap = G.eq_max_blocks ? (uint32_t)G.eq_max_blocks : (mode1 ? 768u : 2048u);
   return want < 1 ? 1 : (want > cap ? cap : want);
 }
 static inline uint32_t sc_blocks_bind(uint32_t hq) {
-  const uint32_t want = (hq + 256 * 4 - 1) / (256 * 4);
+  const uint32_t want = (hq + 255) / 256;
   return want < 1 ? 1 : (want > 4096 ? 4096 : want);
 }
 static constexpr size_t kScPartialBytes = 4096 * 128;  // per mailbox slot: 4096 blocks x up to 32 words
 
-// EqSumCheckInstance (sumcheck.rs:593-677, 1226-1253): host scalars + the device heaps of eq tables
-template <int FID> struct ScEq {
+// the device heaps of eq tables of one EqSumCheckInstance (sumcheck.rs:608-641; scalars: ScAlg::Eq)
+template <int FID> struct ScEqDev {
   using F = Fp<FID>;
-  using H = ScHost<FID>;
-  uint32_t l = 0, first_half = 0, second_half = 0, round = 1;
-  std::vector<F> taus, eq0, slope, eqm1;
-  F eval_eq_left;
-  uint32_t *heapL = nullptr, *heapR = nullptr;  // device
-  uint32_t KL = 0, KR = 0;
+  using H = HostFp4<FID>;
+  uint32_t l = 0, first_half = 0, second_half = 0, KL = 0, KR = 0;
+  uint32_t *heapL = nullptr, *heapR = nullptr;
   static size_t heap_bytes(uint32_t l_) {
     const uint32_t fh = l_ / 2, sh = l_ - fh, kl = fh > 0 ? fh - 1 : 0;
-    return (((size_t)2 << kl) + ((size_t)2 << sh)) * 32 + 512;
+    return ((((size_t)2 << kl) * 32 + 255) & ~(size_t)255) + ((size_t)2 << sh) * 32 + 512;
   }
-  // builds the tables on c.stream (no wait) into [mem, mem + heap_bytes(l))
-  void init(H& h, const uint8_t* taus_bytes, uint32_t l_, char* mem, uint32_t flags) {
-    l = l_, first_half = l / 2, second_half = l - first_half, round = 1;
+  // builds the tables on the stream (no wait) into [mem, mem + heap_bytes(l))
+  void init(ScDev<FID>& h, const typename ScAlg<FID>::Eq& eq, char* mem) {
+    l = eq.l, first_half = eq.first_half, second_half = eq.second_half;
     KL = first_half > 0 ? first_half - 1 : 0, KR = second_half;
-    taus.resize(l), eq0.resize(l), slope.resize(l), eqm1.resize(l);
-    const F one = F::one();
-    for (uint32_t i = 0; i < l; i++) {
-      taus[i] = h.in(taus_bytes + 32 * (size_t)i);
-      eq0[i] = H::sub(one, taus[i]);              // eq(tau, 0)
-      slope[i] = H::sub(taus[i], eq0[i]);         // 2 tau - 1
-      eqm1[i] = H::sub(eq0[i], slope[i]);         // eq(tau, -1) = 2 - 3 tau
-    }
-    eval_eq_left = one;
     heapL = (uint32_t*)mem;
     heapR = (uint32_t*)(mem + ((((size_t)2 << KL) * 32 + 255) & ~(size_t)255));
     DeviceBackend be(h.c, false, false);
-    // ONE in the vectors' form (as eq_evals_t)
-    uint32_t w[8];
-    F onev = F::zero();
-    onev.l[0] = 1;
-    if (h.mont) h.to_mont.to_words(w);
-    else onev.to_words(w);
+    uint32_t w[8] = {1, 0, 0, 0, 0, 0, 0, 0};  // ONE in the vectors' form
+    if (h.mont) H::one().to_mont256(w);
     if (KL <= EqHeapFn<FID>::kMaxEll && KR <= EqHeapFn<FID>::kMaxEll) {
       EqHeapFn<FID> f;
       f.heapL = heapL, f.heapR = heapR, f.KL = KL, f.KR = KR, f.one = F::from_words(w);
       for (uint32_t i = 0; i < 2 * EqHeapFn<FID>::kMaxEll; i++) f.r[i] = f.nr[i] = F::zero();
       // left side: taus[1 .. first_half) (sumcheck.rs:634-635: skip(1)); right side: taus[first_half .. l)
-      for (uint32_t i = 0; i < KL; i++) f.r[i] = taus[1 + i], f.nr[i] = eq0[1 + i];
-      for (uint32_t i = 0; i < KR; i++) f.r[KL + i] = taus[first_half + i], f.nr[KL + i] = eq0[first_half + i];
+      for (uint32_t i = 0; i < KL; i++) f.r[i] = eq.taus[1 + i].to_device(), f.nr[i] = eq.eq0[1 + i].to_device();
+      for (uint32_t i = 0; i < KR; i++) f.r[KL + i] = eq.taus[first_half + i].to_device(), f.nr[KL + i] = eq.eq0[first_half + i].to_device();
       be.launch(f, (2u << KL) + (2u << KR));
       h.launched();
     } else {  // long sides: the largest table by doubling (eq.rs:54-73), the others by pairwise sums
@@ -420,7 +391,7 @@ template <int FID> struct ScEq {
         HIPCHK(hipMemcpyAsync(top, heap + 8, 32, hipMemcpyDeviceToDevice, h.c.stream));
         uint32_t size = 1;
         for (int j = (int)K - 1; j >= 0; j--) {
-          ScEqStepFn<FID> f{top, taus[first_tau + (uint32_t)j], size};
+          ScEqStepFn<FID> f{top, eq.taus[first_tau + (uint32_t)j].to_device(), size};
           be.launch(f, size);
           size *= 2;
         }
@@ -445,40 +416,20 @@ template <int FID> struct ScEq {
     }
     return Tables{nullptr, heapR + 8 * ((size_t)1 << (l - rnd)), 0, 0xffffffffu};
   }
-  // derive_from_claim_deg2 / _deg1 (sumcheck.rs:680-753); third() computes t(1) on the device when l(1) p = 0 (tau = 0 or a
-  // challenge that zeroed eval_eq_left: the fallback_eval_inf_* paths, sumcheck.rs:1085-1222, whose third N-scaling sum is
-  // t(-1) = 2 t(inf) + 2 t(0) - t(1) -- the same value from a sum over the HIGH halves).
-  template <class Third> void derive(const F& t0, const F& tinf, const F& claim, bool deg1, F& s0, F& lead, F& sm1, Third&& third) const {
-    const F& p = eval_eq_left;
-    const F l0p = H::mul(eq0[round - 1], p), l1p = H::mul(H::add(eq0[round - 1], slope[round - 1]), p);
-    s0 = H::mul(l0p, t0);
-    lead = deg1 ? F::zero() : H::mul(H::mul(slope[round - 1], p), tinf);
-    F t1;
-    if (!H::is_zero(l1p)) t1 = H::mul(H::sub(claim, s0), l1p.inv().canon());
-    else t1 = third();
-    F tm1 = H::sub(H::dbl(t0), t1);
-    if (!deg1) tm1 = H::add(tm1, H::dbl(tinf));
-    sm1 = H::mul(H::mul(eqm1[round - 1], p), tm1);
-  }
-  void bound(const F& r) {  // sumcheck.rs:1226-1231
-    const F& tau = taus[round - 1];
-    F t = H::sub(H::sub(F::one(), tau), r);
-    t = H::add(t, H::dbl(H::mul(r, tau)));
-    eval_eq_left = H::mul(eval_eq_left, t);
-    round++;
-  }
 };
 
 // the launches of one eq-factored instance (MODE 1 or 3) or of quad_prod (MODE 4) over in-place tables
 template <int FID, int MODE> struct ScPass {
   using F = Fp<FID>;
-  using H = ScHost<FID>;
-  H& h;
+  using H = HostFp4<FID>;
+  using Tables = typename ScEqDev<FID>::Tables;
+  ScDev<FID>& h;
   uint32_t *A, *B, *C;
   uint32_t* partial;  // device scratch of this instance (kScPartialBytes)
-  uint32_t slot;
+  uint32_t slot;      // mailbox slot of the sums; tail areas slot, slot + 1, slot + 2 take the tables
   F nk;
-  ScPass(H& h_, void* a, void* b, void* cc, uint32_t* partial_, uint32_t slot_)
+  static constexpr uint32_t NT = MODE == 3 ? 3u : MODE == 4 ? 2u : 1u;
+  ScPass(ScDev<FID>& h_, void* a, void* b, void* cc, uint32_t* partial_, uint32_t slot_)
       : h(h_), A((uint32_t*)a), B((uint32_t*)b), C((uint32_t*)cc), partial(partial_), slot(slot_) {
     F fconst = F::zero();
     if (MODE == 3) {
@@ -487,10 +438,10 @@ template <int FID, int MODE> struct ScPass {
     }
     nk = MODE == 3 ? F::sub2(F::zero(), fconst.canon()).norm().canon() : F::zero();  // p - k, as eq_sums_t
   }
-  static constexpr uint32_t kFactors = MODE == 1 ? 2u : MODE == 3 ? 3u : 2u;  // stored factors per term without eqL
-  uint32_t factors(const typename ScEq<FID>::Tables& t) const { return kFactors + (MODE != 4 && t.eqL ? 1u : 0u); }
+  static constexpr uint32_t kFactors = MODE == 3 ? 3u : 2u;  // stored factors per term without eqL
+  uint32_t factors(const Tables& t) const { return kFactors + (MODE != 4 && t.eqL ? 1u : 0u); }
   // sums only over tables of `len` elements (round 1, and the high-half sum of the fallback)
-  uint32_t sums(const uint32_t* a, const uint32_t* b, const uint32_t* cc, size_t len, const typename ScEq<FID>::Tables& t) {
+  uint32_t sums(const uint32_t* a, const uint32_t* b, const uint32_t* cc, size_t len, const Tables& t) {
     const uint32_t hh = (uint32_t)(len / 2), seq = h.next_seq();
     hipStream_t s = h.c.stream;
     if (hh <= kScSmallHq) {
@@ -498,14 +449,22 @@ template <int FID, int MODE> struct ScPass {
       hipLaunchKernelGGL((k_sc_small<FID, MODE>), dim3(1), dim3(256), 0, s, x);
       h.launched();
     } else {
-      const uint32_t blocks = sc_blocks_sums(hh, MODE == 1);
+      uint32_t blocks = sc_blocks_sums(hh, MODE == 1);
       if (MODE == 4) {
         hipLaunchKernelGGL((k_plain_sums<FID, 1>), dim3(blocks), dim3(256), 0, s, a, b, (const uint32_t*)nullptr, hh, partial);
         hipLaunchKernelGGL((k_sum_partials_mail<FID, 2, 4>), dim3(1), dim3(256), 0, s, partial, blocks, h.slot_dev(slot), seq);
       } else {
         constexpr int M = MODE == 4 ? 1 : MODE;
-        if (t.eqL && t.shift < 31) hipLaunchKernelGGL((k_eq_rows<FID, M>), dim3(blocks), dim3(256), 0, s, a, b, cc, t.eqL, t.eqR, t.shift, hh, nk, partial);
-        else hipLaunchKernelGGL((k_eq_sums<FID, M>), dim3(blocks), dim3(256), 0, s, a, b, cc, t.eqL, t.eqR, t.shift, t.mask, hh, nk, partial);
+        if (t.eqL && t.shift < 31) {
+          // k_eq_rows walks whole rows of 2^shift indices: below 2^24 one row (or one block's worth of short rows) per block
+          // fills more of the chip than the 8-indices-per-lane rule
+          const uint32_t row = 1u << t.shift, rpb = row < 256u ? 256u / row : 1u, nrows = (uint32_t)(((uint64_t)hh + row - 1) >> t.shift);
+          const uint32_t by_rows = (nrows + rpb - 1) / rpb;
+          if (by_rows > blocks) blocks = by_rows < 2048u ? by_rows : 2048u;
+          hipLaunchKernelGGL((k_eq_rows<FID, M>), dim3(blocks), dim3(256), 0, s, a, b, cc, t.eqL, t.eqR, t.shift, hh, nk, partial);
+        } else {
+          hipLaunchKernelGGL((k_eq_sums<FID, M>), dim3(blocks), dim3(256), 0, s, a, b, cc, t.eqL, t.eqR, t.shift, t.mask, hh, nk, partial);
+        }
         hipLaunchKernelGGL((k_sum_partials_mail<FID, 2, 2>), dim3(1), dim3(256), 0, s, partial, blocks, h.slot_dev(slot), seq);
       }
       h.launched(2);
@@ -514,8 +473,9 @@ template <int FID, int MODE> struct ScPass {
     return seq;
   }
   // bind the tables (len elements each) with r in place AND the sums of the next round over the bound halves
-  uint32_t bind_sums(size_t len, const F& r, const typename ScEq<FID>::Tables& t) {
+  uint32_t bind_sums(size_t len, const H& rh, const Tables& t) {
     const uint32_t hq = (uint32_t)(len / 4), seq = h.next_seq();
+    const F r = rh.to_device();
     hipStream_t s = h.c.stream;
     if (hq <= kScSmallHq) {
       ScSmallArgs<FID> x{A, B, C, A, B, C, t.eqL, t.eqR, r, nk, t.shift, t.mask, hq, 1u, seq, h.slot_dev(slot)};
@@ -537,22 +497,39 @@ template <int FID, int MODE> struct ScPass {
     HIPCHK(hipGetLastError());
     return seq;
   }
+  // the hand-over: bind with r (rp == nullptr: no bind) and land the tables of `half` elements in the tail areas; fills out[]
+  void to_host(size_t half, const H* rp, std::vector<H>* out[3]) {
+    require(half <= kTailMax && slot + NT <= kMailSlots, NMX_E_HIP, "sum-check: tail hand-over out of range");
+    ScBindOutArgs<FID> a;
+    uint32_t* X[3] = {A, B, C};
+    for (uint32_t t = 0; t < 3; t++) a.X[t] = t < NT ? X[t] : nullptr, a.host[t] = t < NT ? h.tail_dev(slot + t) : nullptr;
+    a.r = rp ? rp->to_device() : F::zero();
+    a.n = NT, a.half = (uint32_t)half, a.bind = rp ? 1u : 0u, a.seq = h.next_seq(), a.slot = h.slot_dev(slot);
+    hipLaunchKernelGGL((k_sc_bind_to_host<FID>), dim3(1), dim3(256), 0, h.c.stream, a);
+    HIPCHK(hipGetLastError());
+    h.launched();
+    (void)h.wait(slot, a.seq);
+    for (uint32_t t = 0; t < NT; t++) {
+      const uint32_t* src = h.tail_host(slot + t);
+      out[t]->resize(half);
+      for (size_t i = 0; i < half; i++) (*out[t])[i] = h.stored(src + 8 * i);
+    }
+  }
   // t(1) of the current round: the sums pass over a copy of the tables with the halves swapped (the fallback; never on
-  // transcript-derived challenges).  Returns the raw first sum.
-  F high_half_sum(size_t len, const typename ScEq<FID>::Tables& t) {
+  // transcript-derived challenges)
+  H high_half_sum(size_t len, const Tables& t) {
     const size_t hb = len / 2 * 32;
-    const int nt = MODE == 1 ? 1 : MODE == 3 ? 3 : 2;
     char* tmp = nullptr;
-    HIPCHK(hipMalloc((void**)&tmp, (size_t)nt * len * 32));
+    HIPCHK(hipMalloc((void**)&tmp, (size_t)NT * len * 32));
     const uint32_t* src[3] = {A, B, C};
     try {
-      for (int i = 0; i < nt; i++) {
+      for (uint32_t i = 0; i < NT; i++) {
         HIPCHK(hipMemcpyAsync(tmp + (size_t)i * len * 32, (const char*)src[i] + hb, hb, hipMemcpyDeviceToDevice, h.c.stream));
         HIPCHK(hipMemcpyAsync(tmp + (size_t)i * len * 32 + hb, src[i], hb, hipMemcpyDeviceToDevice, h.c.stream));
       }
       const uint32_t* ta = (const uint32_t*)tmp;
-      const uint32_t seq = sums(ta, nt > 1 ? ta + 8 * len : nullptr, nt > 2 ? ta + 16 * len : nullptr, len, t);
-      const F v = h.raw(h.wait(slot, seq), factors(t));
+      const uint32_t seq = sums(ta, NT > 1 ? ta + 8 * len : nullptr, NT > 2 ? ta + 16 * len : nullptr, len, t);
+      const H v = h.raw(h.wait(slot, seq), factors(t));
       stream_wait(h.c.stream);
       (void)hipFree(tmp);
       return v;
@@ -564,171 +541,153 @@ template <int FID, int MODE> struct ScPass {
   }
 };
 
-template <int FID> static uint32_t sc_final(ScHost<FID>& h, uint32_t* const* X, uint32_t n, const Fp<FID>& r, uint32_t slot) {
-  ScFinalArgs a;
-  for (uint32_t i = 0; i < 3; i++) a.X[i] = i < n ? X[i] : nullptr;
-  a.n = n, a.seq = h.next_seq(), a.slot = h.slot_dev(slot);
-  hipLaunchKernelGGL((k_sc_final<FID>), dim3(1), dim3(64), 0, h.c.stream, a, r);
-  HIPCHK(hipGetLastError());
-  h.launched();
-  return a.seq;
-}
-
-// SumcheckProof::prove_cubic_with_three_inputs (sumcheck.rs:446-507) / prove_quad_prod (sumcheck.rs:199-249)
+// SumcheckProof::prove_cubic_with_three_inputs (MODE 3, sumcheck.rs:446-507) / prove_quad_prod (MODE 4, sumcheck.rs:199-249)
 template <int FID, int MODE>
 static void sc_prove_t(Ctx& c, const void* claim, const void* taus, size_t num_rounds, void* A, void* B, void* C, uint32_t flags,
                        TranscriptFn cb, void* cb_ctx, uint8_t* out_polys, uint8_t* out_r, uint8_t* out_claims) {
-  using F = Fp<FID>;
-  using H = ScHost<FID>;
+  using H = HostFp4<FID>;
   const auto T0 = std::chrono::steady_clock::now();
   constexpr uint32_t NCO = MODE == 3 ? 4u : 3u, NT = MODE == 3 ? 3u : 2u;
   const uint32_t l = (uint32_t)num_rounds;
-  H h(c, flags);
-  arena_reserve(c, kScPartialBytes + 512);
-  ScEq<FID> eq;
-  if (MODE == 3) {
-    aux_reserve(c, ScEq<FID>::heap_bytes(l));
-    eq.init(h, (const uint8_t*)taus, l, c.aux, flags);
-  }
-  ScPass<FID, MODE> pass(h, A, B, C, (uint32_t*)c.arena, 0);
-  F claim_i = h.in(claim);
-  const F tinv = h.two_inv();
-  size_t len = (size_t)1 << l;
-  typename ScEq<FID>::Tables tb = MODE == 3 ? eq.tables(1) : typename ScEq<FID>::Tables{nullptr, nullptr, 0, 0};
-  uint32_t seq = l ? pass.sums(pass.A, pass.B, pass.C, len, tb) : 0u;
-  for (uint32_t j = 1; j <= l; j++) {
-    const uint32_t* res = h.wait(0, seq);
-    const F t0 = h.raw(res, pass.factors(tb)), t1 = h.raw(res + 8, pass.factors(tb));
-    F co[4];
+  try {
+    ScDev<FID> h(c, flags);
+    arena_reserve(c, kScPartialBytes + 512);
+    typename ScAlg<FID>::Eq eq;
+    ScEqDev<FID> eqd;
+    size_t len = (size_t)1 << l;
     if (MODE == 3) {
-      F s0, lead, sm1;
-      eq.derive(t0, t1, claim_i, false, s0, lead, sm1, [&] { return pass.high_half_sum(len, tb); });
-      const F s1 = H::sub(claim_i, s0);  // evals = [s(0), claim - s(0), cubic coefficient, s(-1)]
-      co[0] = s0, co[3] = lead;          // UniPoly::from_evals_deg3 (univariate.rs:103-113)
-      co[2] = H::sub(H::mul(H::add(s1, sm1), tinv), s0);
-      co[1] = H::sub(H::sub(H::sub(s1, lead), s0), co[2]);
-    } else {
-      const F s1 = H::sub(claim_i, t0);  // evals = [e0, claim - e0, bound coefficient]; from_evals_deg2 (univariate.rs:90-99)
-      co[0] = t0, co[2] = t1;
-      co[1] = H::sub(H::sub(s1, t1), t0);
+      eq.init(h.alg, (const uint8_t*)taus, l);
+      if (len > h.tail_len) {
+        aux_reserve(c, ScEqDev<FID>::heap_bytes(l));
+        eqd.init(h, eq, c.aux);
+      }
     }
-    const F r = h.ask(cb, cb_ctx, co, NCO, out_polys ? out_polys + 32 * NCO * (size_t)(j - 1) : nullptr, out_r ? out_r + 32 * (size_t)(j - 1) : nullptr);
-    claim_i = H::poly_eval(co, NCO, r);
-    if (MODE == 3) eq.bound(r);
-    h.prof.rounds++;
-    if (j < l) {
-      if (MODE == 3) tb = eq.tables(j + 1);
-      seq = pass.bind_sums(len, r, tb);
-      len /= 2;
+    ScPass<FID, MODE> pass(h, A, B, C, (uint32_t*)c.arena, 0);
+    H cl = h.alg.in(claim);
+    std::vector<H> hA, hB, hC;
+    std::vector<H>* tabs[3] = {&hA, &hB, &hC};
+    uint32_t j = 1;
+    if (len <= h.tail_len) {
+      pass.to_host(len, nullptr, tabs);  // the whole instance fits the tail
     } else {
-      uint32_t* X[3] = {pass.A, pass.B, pass.C};
-      seq = sc_final<FID>(h, X, NT, r, 0);
-      const uint32_t* fin = h.wait(0, seq);
-      if (out_claims)
-        for (uint32_t i = 0; i < NT; i++) memcpy(out_claims + 32 * i, fin + 8 * i, 32);  // stored elements: already the vectors' form
+      typename ScEqDev<FID>::Tables tb = MODE == 3 ? eqd.tables(1) : typename ScEqDev<FID>::Tables{nullptr, nullptr, 0, 0};
+      uint32_t seq = pass.sums(pass.A, pass.B, pass.C, len, tb);
+      for (;; j++) {
+        const uint32_t* res = h.wait(0, seq);
+        const H t0 = h.raw(res, pass.factors(tb)), t1 = h.raw(res + 8, pass.factors(tb));
+        H co[4];
+        if (MODE == 3) {
+          H s0, lead, sm1;
+          eq.derive(t0, t1, cl, false, s0, lead, sm1, [&] { return t0.dbl() + t1.dbl() - pass.high_half_sum(len, tb); });
+          ScAlg<FID>::from_evals_deg3(s0, cl, lead, sm1, co);
+        } else {
+          ScAlg<FID>::from_evals_deg2(t0, cl, t1, co);
+        }
+        const H r = h.ask(cb, cb_ctx, co, NCO, out_polys ? out_polys + 32 * NCO * (size_t)(j - 1) : nullptr, out_r ? out_r + 32 * (size_t)(j - 1) : nullptr);
+        cl = ScAlg<FID>::poly_eval(co, NCO, r);
+        if (MODE == 3) eq.bound(r);
+        h.prof.rounds++;
+        if (len / 2 <= h.tail_len) {  // the bound tables go to the host: the remaining rounds (none if they are the final values) run there
+          pass.to_host(len / 2, &r, tabs);
+          len /= 2;
+          j++;
+          break;
+        }
+        if (MODE == 3) tb = eqd.tables(j + 1);
+        seq = pass.bind_sums(len, r, tb);
+        len /= 2;
+      }
     }
+    if (j <= l) {
+      h.prof.host_rounds += l - j + 1;
+      sc_tail_rounds<FID, MODE>(h.alg, &eq, l, j, cl, hA, hB, hC, cb, cb_ctx, out_polys, out_r);
+    }
+    if (out_claims) {
+      h.alg.out(hA[0], out_claims), h.alg.out(hB[0], out_claims + 32);
+      if (NT == 3) h.alg.out(hC[0], out_claims + 64);
+    }
+    stream_wait(c.stream);  // the (partly bound) tables are the caller's again
+    h.finish_profile(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count());
+  } catch (const ScFail& f) {
+    (void)hipStreamSynchronize(c.stream);
+    rethrow(f);
   }
-  if (l == 0 && out_claims) {  // no rounds: the tables are their own evaluations
-    stream_wait(c.stream);
-    uint32_t* X[3] = {pass.A, pass.B, pass.C};
-    for (uint32_t i = 0; i < NT; i++) HIPCHK(hipMemcpy(out_claims + 32 * i, X[i], 32, hipMemcpyDeviceToHost));
-  }
-  stream_wait(c.stream);  // the bound tables are the caller's again
-  h.finish_profile(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count());
 }
 
 // SumcheckProof::prove_batch_eval (sumcheck.rs:251-353): k claims P_i(x_i) = e_i over polynomials of different sizes; the
 // polynomials are bound in place (the reference binds clones, spartan/mod.rs:407-410: hand in copies to keep the originals).
+// The round loop is sc_batch_rounds (sc_host.hpp); this supplies the device's side of it.
+template <int FID> struct ScBatchDev {
+  using H = HostFp4<FID>;
+  ScDev<FID>& h;
+  std::vector<ScBatchClaim<FID>>& claims;
+  std::vector<ScPass<FID, 1>> pass;
+  std::vector<ScEqDev<FID>> eqd;
+  std::vector<size_t> len;
+  std::vector<uint32_t> seq;
+  std::vector<typename ScEqDev<FID>::Tables> tb;
+  std::vector<H> last_t0;
+  ScBatchDev(ScDev<FID>& h_, std::vector<ScBatchClaim<FID>>& c_) : h(h_), claims(c_) {}
+  void start(size_t i) {
+    tb[i] = eqd[i].tables(1);
+    seq[i] = pass[i].sums(pass[i].A, nullptr, nullptr, len[i], tb[i]);
+  }
+  H t0(size_t i) { return last_t0[i] = h.raw(h.wait((uint32_t)i, seq[i]), pass[i].factors(tb[i])); }
+  H t_m1(size_t i) { return last_t0[i].dbl() - pass[i].high_half_sum(len[i], tb[i]); }  // t(-1) = 2 t(0) - t(1)
+  void bind(size_t i, const H& r) {
+    if (len[i] / 2 <= h.tail_len) {
+      std::vector<H>* out[3] = {&claims[i].host, nullptr, nullptr};
+      pass[i].to_host(len[i] / 2, &r, out);
+    } else {
+      tb[i] = eqd[i].tables(claims[i].eq.round + 1);
+      seq[i] = pass[i].bind_sums(len[i], r, tb[i]);
+    }
+    len[i] /= 2;
+  }
+};
 template <int FID>
-static void sc_prove_batch_t(Ctx& c, const uint8_t* claims, const size_t* num_rounds, void* const* polys, const uint8_t* const* eq_points,
+static void sc_prove_batch_t(Ctx& c, const uint8_t* claims_b, const size_t* num_rounds, void* const* polys, const uint8_t* const* eq_points,
                              const uint8_t* coeffs, size_t k, uint32_t flags, TranscriptFn cb, void* cb_ctx, uint8_t* out_polys,
                              uint8_t* out_r, uint8_t* out_finals) {
-  using F = Fp<FID>;
-  using H = ScHost<FID>;
+  using H = HostFp4<FID>;
   const auto T0 = std::chrono::steady_clock::now();
   require(k >= 1 && k <= kMailSlots, NMX_E_ARG, "prove_batch_eval: between 1 and 16 claims");
-  H h(c, flags);
-  uint32_t nmax = 0;
-  size_t heap_total = 0;
-  for (size_t i = 0; i < k; i++) {
-    require(num_rounds[i] >= 1 && num_rounds[i] < 31, NMX_E_ARG, "prove_batch_eval: 1 <= num_rounds < 31");
-    nmax = num_rounds[i] > nmax ? (uint32_t)num_rounds[i] : nmax;
-    heap_total += (ScEq<FID>::heap_bytes((uint32_t)num_rounds[i]) + 255) & ~(size_t)255;
-  }
-  arena_reserve(c, k * kScPartialBytes + 512);
-  aux_reserve(c, heap_total);
-  std::vector<ScEq<FID>> eq(k);
-  std::vector<ScPass<FID, 1>> pass;
-  pass.reserve(k);
-  std::vector<F> cl(k), run(k), co(k);
-  std::vector<size_t> len(k);
-  std::vector<uint32_t> seq(k, 0);
-  std::vector<typename ScEq<FID>::Tables> tb(k);
-  size_t off = 0;
-  for (size_t i = 0; i < k; i++) {
-    eq[i].init(h, eq_points[i], (uint32_t)num_rounds[i], c.aux + off, flags);
-    off += (ScEq<FID>::heap_bytes((uint32_t)num_rounds[i]) + 255) & ~(size_t)255;
-    pass.emplace_back(h, polys[i], nullptr, nullptr, (uint32_t*)(c.arena + i * kScPartialBytes), (uint32_t)i);
-    cl[i] = run[i] = h.in(claims + 32 * i);
-    co[i] = h.in(coeffs + 32 * i);
-    len[i] = (size_t)1 << num_rounds[i];
-  }
-  F e = F::zero();  // (:281-289) e = sum claim_i 2^(nmax - n_i) coeff_i
-  for (size_t i = 0; i < k; i++) e = H::add(e, H::mul(H::mul(cl[i], h.pow2(nmax - (uint32_t)num_rounds[i])), co[i]));
-  const F tinv = h.two_inv();
-  // the first sums of every polynomial that starts in round 0
-  for (size_t i = 0; i < k; i++)
-    if (num_rounds[i] == nmax) {
-      tb[i] = eq[i].tables(1);
-      seq[i] = pass[i].sums(pass[i].A, nullptr, nullptr, len[i], tb[i]);
-    }
-  std::vector<F> e0(k), em1(k);
-  for (uint32_t round = 0; round < nmax; round++) {
-    const uint32_t remaining = nmax - round;
+  try {
+    ScDev<FID> h(c, flags);
+    size_t heap_total = 0;
     for (size_t i = 0; i < k; i++) {
-      if (remaining <= num_rounds[i]) {  // (:301-305)
-        const F t0 = h.raw(h.wait((uint32_t)i, seq[i]), pass[i].factors(tb[i]));
-        F lead;
-        eq[i].derive(t0, F::zero(), run[i], true, e0[i], lead, em1[i], [&] { return pass[i].high_half_sum(len[i], tb[i]); });
-      } else {  // not yet started: constant (:306-312)
-        e0[i] = em1[i] = H::mul(h.pow2(remaining - (uint32_t)num_rounds[i] - 1), cl[i]);
+      require(num_rounds[i] >= 1 && num_rounds[i] < 31, NMX_E_ARG, "prove_batch_eval: 1 <= num_rounds < 31");
+      heap_total += (ScEqDev<FID>::heap_bytes((uint32_t)num_rounds[i]) + 255) & ~(size_t)255;
+    }
+    arena_reserve(c, k * kScPartialBytes + 512);
+    aux_reserve(c, heap_total);
+    std::vector<ScBatchClaim<FID>> cs(k);
+    ScBatchDev<FID> dev(h, cs);
+    dev.pass.reserve(k);
+    dev.eqd.resize(k), dev.len.resize(k), dev.seq.assign(k, 0), dev.tb.resize(k), dev.last_t0.resize(k);
+    size_t off = 0;
+    for (size_t i = 0; i < k; i++) {
+      cs[i].num_rounds = (uint32_t)num_rounds[i];
+      cs[i].eq.init(h.alg, eq_points[i], cs[i].num_rounds);
+      cs[i].claim0 = cs[i].running = h.alg.in(claims_b + 32 * i);
+      cs[i].coeff = h.alg.in(coeffs + 32 * i);
+      dev.len[i] = (size_t)1 << num_rounds[i];
+      dev.pass.emplace_back(h, polys[i], nullptr, nullptr, (uint32_t*)(c.arena + i * kScPartialBytes), (uint32_t)i);
+      if (dev.len[i] <= h.tail_len) {  // fits the tail as it is
+        std::vector<H>* out[3] = {&cs[i].host, nullptr, nullptr};
+        dev.pass[i].to_host(dev.len[i], nullptr, out);
+      } else {
+        dev.eqd[i].init(h, cs[i].eq, c.aux + off);
+        off += (ScEqDev<FID>::heap_bytes((uint32_t)num_rounds[i]) + 255) & ~(size_t)255;
       }
     }
-    F c0 = F::zero(), cm1 = F::zero();
-    for (size_t i = 0; i < k; i++) c0 = H::add(c0, H::mul(e0[i], co[i])), cm1 = H::add(cm1, H::mul(em1[i], co[i]));
-    const F c1 = H::sub(e, c0);
-    const F qc = H::mul(H::sub(H::add(c1, cm1), H::dbl(c0)), tinv);  // (S(1) + S(-1) - 2 S(0)) / 2
-    F poly[3] = {c0, H::sub(H::sub(c1, qc), c0), qc};               // from_evals_deg2([S(0), S(1), quad])
-    const F r = h.ask(cb, cb_ctx, poly, 3, out_polys ? out_polys + 96 * (size_t)round : nullptr, out_r ? out_r + 32 * (size_t)round : nullptr);
-    h.prof.rounds++;
-    for (size_t i = 0; i < k; i++) {
-      if (remaining <= num_rounds[i]) {
-        // update_claim (:68-75) with evals [e0, 0, em1]: a1 = (e1 - em1)/2, a2 = (e1 + em1)/2 - e0, claim' = e0 + r (a1 + r a2)
-        const F e1 = H::sub(run[i], e0[i]);
-        const F a1 = H::mul(H::sub(e1, em1[i]), tinv), a2 = H::sub(H::mul(H::add(e1, em1[i]), tinv), e0[i]);
-        run[i] = H::add(e0[i], H::mul(r, H::add(a1, H::mul(r, a2))));
-        eq[i].bound(r);
-        if (len[i] > 2) {
-          tb[i] = eq[i].tables(eq[i].round);
-          seq[i] = pass[i].bind_sums(len[i], r, tb[i]);
-        } else {
-          uint32_t* X[3] = {pass[i].A, nullptr, nullptr};
-          seq[i] = sc_final<FID>(h, X, 1, r, (uint32_t)i);
-        }
-        len[i] /= 2;
-      } else if (remaining - 1 == num_rounds[i]) {  // joins in the next round: its first sums, unbound
-        tb[i] = eq[i].tables(1);
-        seq[i] = pass[i].sums(pass[i].A, nullptr, nullptr, len[i], tb[i]);
-      }
-    }
-    e = H::poly_eval(poly, 3, r);
+    sc_batch_rounds<FID>(h.alg, cs, dev, cb, cb_ctx, out_polys, out_r, out_finals, &h.prof.rounds);
+    stream_wait(c.stream);
+    h.finish_profile(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count());
+  } catch (const ScFail& f) {
+    (void)hipStreamSynchronize(c.stream);
+    rethrow(f);
   }
-  for (size_t i = 0; i < k; i++) {  // poly_finals (:347-349)
-    const uint32_t* fin = h.wait((uint32_t)i, seq[i]);
-    if (out_finals) memcpy(out_finals + 32 * i, fin, 32);
-  }
-  stream_wait(c.stream);
-  h.finish_profile(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count());
 }
 
 void fv_sumcheck_prove(Ctx& c, int field, int which, const void* claim, const void* taus, size_t num_rounds, void* A, void* B, void* C,

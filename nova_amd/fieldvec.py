@@ -108,6 +108,23 @@ def vec_add(field, a, b, mont=False, async_=False):
     return out
 
 
+def concat(field, parts, n_out=None, async_=False):
+    """nmx_field_concat: an HBM-resident vector = the parts (CUDA tensors or host arrays) one after the other, zero-padded to n_out.
+    Spartan's z = [W, u, X] (src/spartan/snark.rs:133, 193-196); with one part, a clone ordered on the library's stream."""
+    import ctypes
+    import torch
+    k = len(parts)
+    ps = [_vec(p) for p in parts]
+    total = sum(q[1] for q in ps)
+    n = total if n_out is None else n_out
+    mask = sum(1 << i for i, q in enumerate(ps) if q[2])
+    ptrs = (ctypes.c_void_p * max(k, 1))(*[q[0] for q in ps])
+    lens = (ctypes.c_size_t * max(k, 1))(*[q[1] for q in ps])
+    out = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
+    _check(L.lib().nmx_field_concat(field, ptrs, lens, mask, k, n, _flags(True, False, async_), out.data_ptr()))
+    return out
+
+
 def bind_poly_var_top(field, z, r, mont=False, in_place=False, async_=False):
     """Returns the bound polynomial (len/2 evaluations).  in_place (device tensors only) overwrites z[:len/2]."""
     pz, n, dev, _kz = _vec(z)

@@ -155,6 +155,41 @@ def test_polling_and_synchronising_agree(nmx):
         assert L.nmx_set_option(b"sc_poll_us", 2000) == 0
 
 
+@pytest.mark.parametrize("tail", [0, 1, 3, 6, 8])
+def test_every_host_tail_threshold_gives_the_same_proof(nmx, tail):
+    """option sc_host_tail: tables of <= 2^tail elements finish on the host (sc_host.hpp; 0 = only the final values come over).  The
+    proof is the same wherever the hand-over happens -- including instances that fit the tail from the start and batch claims that
+    reach it in different rounds."""
+    from nova_amd import _lib
+    L = _lib.lib()
+    assert L.nmx_set_option(b"sc_host_tail", 9) == _lib.E_ARG
+    try:
+        assert L.nmx_set_option(b"sc_host_tail", tail) == 0
+        for l in (1, 3, 7, 9, 12):
+            both(sp.check_cubic3, g_cubic3(), o_cubic3, 1, l, seed=20 + l, brute=False)
+            both(sp.check_quad_prod, g_quad, o_quad, 1, l, seed=30 + l)
+        both(sp.check_cubic3, g_cubic3(), o_cubic3, 1, 9, seed=4, taus=[0] * 9, brute=False)
+        for nrs in ([2, 11], [12, 5, 9], [7, 7]):
+            both(sp.check_batch_eval, g_batch, o_batch, 1, nrs, seed=3 + sum(nrs))
+        both(sp.check_batch_eval, g_batch, o_batch, 1, [5, 10], seed=901, force={0: 0, 4: 1, 9: 0})
+    finally:
+        assert L.nmx_set_option(b"sc_host_tail", 6) == 0
+
+
+def test_concat_builds_z_on_the_device(nmx):
+    import torch
+    from nova_amd import fieldvec as fv
+    W, X = fc.rand_vec(1, 1000, 1), fc.rand_vec(1, 3, 2)
+    u = fc.rand_vec(1, 1, 3)
+    z = fv.concat(1, [dev(W), u, X], n_out=2048)
+    exp = np.zeros((2048, 32), np.uint8)
+    exp[:1000], exp[1000], exp[1001:1004] = W, u[0], X
+    assert np.array_equal(z.cpu().numpy(), exp)
+    c = fv.concat(1, [z], async_=True)                     # a clone on the library's stream
+    fv.sync()
+    assert torch.equal(c.cpu(), z.cpu()) and c.data_ptr() != z.data_ptr()
+
+
 @pytest.mark.parametrize("fid", [0, 1, 2, 3])
 def test_transposed_product(nmx, fid):
     from nova_amd import fieldvec as fv
@@ -170,7 +205,10 @@ def test_transposed_product(nmx, fid):
         assert m.multiply_vec_transposed(x).tobytes() == exp                         # host operands
         got = m.multiply_vec_transposed(dev(x))                                      # HBM-resident, twice (the form is cached)
         assert got.cpu().numpy().tobytes() == exp
-        assert m.multiply_vec_transposed(dev(x), async_=True).cpu().numpy().tobytes() == exp
+        dx = dev(x)
+        ga = m.multiply_vec_transposed(dx, async_=True)                              # stream-ordered: complete after fv.sync()
+        fv.sync()
+        assert ga.cpu().numpy().tobytes() == exp
         # the forward product of the same registered matrix is untouched
         z = fc.edge_vectors(fid, cols, seed + 20)
         assert m.multiply_vec(z).tobytes() == cref.spmv(fid, ip, ix, dt, rows, z)
