@@ -385,7 +385,8 @@ int nmx_sumcheck_plain_sums(int field, int kind, const void* A, const void* B, c
  * out_r = rounds x 32 (the challenges), final evaluations as listed.  The tables' contents after a call are unspecified (partly
  * bound: the reference's are consumed too).  Once the tables hold <= 2^"sc_host_tail" elements (option, default 6 = 64
  * elements, 0..8) the remaining rounds run on the HOST -- a few hundred field products take the host 1-8 us, any kernel round
- * trip 20-25 us; the last device bind lands the tables in pinned memory.  Option "sc_poll_us": how long a round's mailbox is
+ * trip 20-25 us; the last device bind lands the tables in pinned memory.  Option "sc_fused_sum" (default 1): a round is one
+ * launch, the block that finishes last adds the per-block partials up; 0: pass + one-block sum.  Option "sc_poll_us": how long a round's mailbox is
  * polled before the stream is synchronised instead (default 2000; 0: always synchronise).
  *  - nmx_sumcheck_prove_cubic_with_three_inputs == SumcheckProof::prove_cubic_with_three_inputs (sumcheck.rs:446-507) with its
  *    EqSumCheckInstance (sumcheck.rs:593-1253; all sqrt-size eq tables built by one launch): A, B, C of 2^num_rounds elements,
@@ -490,6 +491,8 @@ int nmx_set_window_bits(uint32_t c);
  * round of the single-pass scan, 64; 1..63 force its multi-round path in tests), "horner_sub" (512-coefficient sub-tiles per
  * wave of the scan: 0 = by size, 1, 2, 4), "eq_max_blocks" (grid cap of the eq-factored sum passes: 0 = 768 for evaluate_with, 2048 otherwise), "horner_spin_limit" (polls before a wave of the scan gives up and the call falls back
  * to the two-pass kernels: 0 = 2^22; tests set 1),
+ * "small_blocks" (MSMs with at most 1024 buckets -- keys below 2^14 points: bucket sums in two block-level launches, this many
+ * entries per four-lane group, default 8; 0 = the task path: plan, expand, accumulate, strided folds),
  * "seg_heavy_above" (pieces per bucket summed without a pre-fold pass: 0 = by table width, else 1..63), "no_tree_fuse" (bucket
  * reduction: 0 = fused levels or one launch per level by the box's measured launch gap, 1 = one launch per level, 2 = fused),
  * "hist_grid" (blocks of the partition's counting pass; 0 = as the placing pass: measured flat, profiles/r03_msm_2p20/tail_ab.txt),

@@ -154,6 +154,7 @@ static void ensure_init() {
   if (const char* t = getenv("NMX_TUNE_SEG_MIN_LEN")) G.seg_min_len = (uint32_t)atoi(t) ? (uint32_t)atoi(t) : 1u;
   if (const char* t = getenv("NMX_TUNE_SEG_LANES")) G.seg_lanes_override = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_NO_QUAD_FINAL")) G.no_quad_final = (uint32_t)atoi(t);
+  if (const char* t = getenv("NMX_TUNE_SMALL_BLOCKS")) G.small_blocks = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_QUAD_FINAL_BELOW")) G.quad_final_below = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_NO_BATCH_FUSE")) G.no_batch_fuse = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_PREFIX_TABLES")) G.prefix_tables = (uint32_t)atoi(t);
@@ -166,6 +167,7 @@ static void ensure_init() {
   if (const char* t = getenv("NMX_SYNC_SPIN_US")) G.sync_spin_us = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_SC_POLL_US")) G.sc_poll_us = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_SC_HOST_TAIL")) G.sc_host_tail = (uint32_t)atoi(t);
+  if (const char* t = getenv("NMX_SC_FUSED_SUM")) G.sc_fused_sum = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_HORNER_TOP")) G.horner_top = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_HORNER_SUB")) G.horner_sub = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_HORNER_ORDER")) G.horner_order = atoi(t) ? 1u : 0u;
@@ -2511,6 +2513,7 @@ int nmx_set_option(const char* name, uint32_t value) {
     else if (n == "seg_lanes") G.seg_lanes_override = value;
     else if (n == "no_quad_accum") G.no_quad_accum = value;
     else if (n == "no_quad_final") G.no_quad_final = value;
+    else if (n == "small_blocks") G.small_blocks = value;
     else if (n == "quad_final_below") G.quad_final_below = value;
     else if (n == "accum_prefetch") G.accum_prefetch = value;
     else if (n == "no_batch_fuse") G.no_batch_fuse = value;
@@ -2523,6 +2526,7 @@ int nmx_set_option(const char* name, uint32_t value) {
     else if (n == "hist_bs") G.hist_bs = value;
     else if (n == "sync_spin_us") G.sync_spin_us = value;
     else if (n == "sc_poll_us") G.sc_poll_us = value;
+    else if (n == "sc_fused_sum") G.sc_fused_sum = value ? 1u : 0u;
     else if (n == "sc_host_tail") {
       require(value <= 8, NMX_E_ARG, "sc_host_tail: log2 of the table length the host takes over, 0..8");
       G.sc_host_tail = value;

@@ -157,6 +157,7 @@ template <int FID, bool LAT = kLatTail> __device__ __forceinline__ Fp<FID> quad_
 
 #if defined(__HIPCC__) || defined(__HIP__)
 #include "msm_kernels.hpp"
+#include "msm_partition.hpp"
 #include "msm_seg.hpp"
 namespace nmx {
 
@@ -482,6 +483,99 @@ template <int FID, int THREADS> __global__ __launch_bounds__(THREADS) void k_red
     }
     __syncthreads();
   }
+}
+
+// ----------------------------------------------------------------------------------------------------
+// Small MSMs (round 5): bucket sums in TWO launches.  An MSM over a key of fewer than 2^14 points runs on c = 8 tables: 128
+// buckets of ~W n / 128 entries each (10 538 pairs: 2 634 per bucket).  The task path spent nine launches on them -- plan,
+// expand, accumulate (8-entry tasks), six strided fold passes of which three find work -- for a chain of 8 + 5 + 8 + 8
+// dependent additions: 0.135 of the 0.25 ms such an MSM takes (profiles/r05_small_msm/stages_before.txt), which is what
+// prove_step's secondary-curve commitments cost.  Here a BLOCK of 64 quads takes `chunk` consecutive entries of ONE bucket
+// (the partition left every bucket's entries contiguous: start[k] .. end[k]), each quad adds its chunk / 64 entries and an
+// LDS tree joins the 64 quad sums (block_sum_quads): one partial per block; a second launch adds a bucket's partials up the
+// same way.  Which (bucket, chunk) a block owns follows from the bucket sizes alone, so every block derives it from start[]
+// / end[] itself (a scan over <= 1024 buckets in LDS): no plan kernel, no lists.  A bucket that collects everything (0 / 1
+// or all-equal scalars) simply gets more blocks, and the second launch walks its partials 64 at a time.
+// Chain: chunk / 64 + 6 additions, then ceil(partials / 64) + 6 (identity operands skip the arithmetic).
+// ----------------------------------------------------------------------------------------------------
+static constexpr uint32_t kSmallMaxBuckets = 1024;
+struct SmallAccArgs {
+  const AffineW* bases;
+  const uint32_t* vals;
+  const uint32_t* start;
+  const uint32_t* end;
+  XYZZW* part;     // one partial per block of k_small_accum
+  XYZZW* buckets;  // k_small_combine's output
+  uint32_t nbuckets, chunk;
+};
+// first block of every bucket into s_off[0 .. nbuckets] (s_off[nbuckets] = all blocks); every thread of a 256-thread block calls it
+__device__ __forceinline__ void small_plan(const SmallAccArgs& a, uint32_t* s_off, uint32_t* s_nb /* 256 */, uint32_t* s_sc /* 257 */,
+                                           uint32_t* s_w /* 16 */) {
+  const uint32_t t = threadIdx.x, M = a.nbuckets, per = (M + 255u) / 256u;  // <= 4 buckets per thread
+  uint32_t loc[4], sum = 0;
+#pragma unroll
+  for (uint32_t i = 0; i < 4; i++) {
+    const uint32_t k = t * per + i;
+    uint32_t nb = 0;
+    if (i < per && k < M) nb = (a.end[k] - a.start[k] + a.chunk - 1u) / a.chunk;
+    loc[i] = nb;
+    sum += nb;
+  }
+  s_nb[t] = sum;
+  __syncthreads();
+  block_excl_scan(s_nb, s_sc, 256u, s_w);
+  uint32_t run = s_sc[t];
+#pragma unroll
+  for (uint32_t i = 0; i < 4; i++) {
+    const uint32_t k = t * per + i;
+    if (i < per && k < M) s_off[k] = run;
+    run += loc[i];
+  }
+  if (t == 0) s_off[M] = s_sc[256];
+  __syncthreads();
+}
+template <int FID> __global__ __launch_bounds__(256) void k_small_accum(SmallAccArgs a) {
+  using F = Fp<FID>;
+  __shared__ uint32_t s_off[kSmallMaxBuckets + 1], s_nb[256], s_sc[257], s_w[16];
+  __shared__ uint32_t lds[64 * 36];
+  small_plan(a, s_off, s_nb, s_sc, s_w);
+  const uint32_t b = blockIdx.x;
+  if (b >= s_off[a.nbuckets]) return;  // block-uniform
+  const uint32_t k = find_bin(s_off, a.nbuckets, b), j = b - s_off[k];
+  const uint32_t e_lo = a.start[k] + j * a.chunk, e_end = a.end[k];
+  const uint32_t len = e_end - e_lo < a.chunk ? e_end - e_lo : a.chunk;
+  const uint32_t qd = threadIdx.x >> 2, q = threadIdx.x & 3u;
+  const uint32_t q_lo = e_lo + (uint32_t)((uint64_t)len * qd / 64u), q_hi = e_lo + (uint32_t)((uint64_t)len * (qd + 1u) / 64u);
+  // this lane's half of an entry's base (even lanes x, odd lanes y with the digit's sign applied): AccumQuadFn::half
+  auto half = [&](uint32_t v) {
+    const F h = F::from_words(a.bases[v & 0x7fffffffu].w + 8 * (q & 1u));
+    const F nh = F::sub2(F::zero(), h).norm();
+    return fsel((q & 1u) && (v >> 31), nh, h);
+  };
+  F acc = F::zero();  // zz = 0: the identity
+  if (q_hi > q_lo) {
+    F cur = half(a.vals[q_lo]);
+    for (uint32_t e = q_lo; e < q_hi; e++) {
+      F nxt = cur;
+      if (e + 1 < q_hi) nxt = half(a.vals[e + 1]);  // in flight during the addition
+      acc = quad_madd<FID>(acc, cur, q);
+      cur = nxt;
+    }
+  }
+  acc = block_sum_quads<FID, 64>(acc, lds, qd, q);
+  if (qd == 0) quad_store<FID>(a.part[b], q, acc);
+}
+template <int FID> __global__ __launch_bounds__(256) void k_small_combine(SmallAccArgs a) {
+  using F = Fp<FID>;
+  __shared__ uint32_t s_off[kSmallMaxBuckets + 1], s_nb[256], s_sc[257], s_w[16];
+  __shared__ uint32_t lds[64 * 36];
+  small_plan(a, s_off, s_nb, s_sc, s_w);
+  const uint32_t k = blockIdx.x, base = s_off[k], n = s_off[k + 1] - base;
+  const uint32_t qd = threadIdx.x >> 2, q = threadIdx.x & 3u;
+  F acc = F::zero();
+  for (uint32_t p = qd; p < n; p += 64u) acc = quad_add<FID>(acc, quad_load<FID>(a.part[base + p], q), q);
+  acc = block_sum_quads<FID, 64>(acc, lds, qd, q);
+  if (qd == 0) quad_store<FID>(a.buckets[k], q, acc);
 }
 
 }  // namespace nmx

@@ -317,6 +317,16 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
     }
     be.template launch_final_seg<FID>(start, end, total_p, bucket_raw, partial_raw, buckets, sh.nbuckets, seg_lanes,
                                       a.seg_min_len, heavy_above);
+  } else if (sh.nbuckets <= 1024 && be.small_chunk() != 0) {
+    // small MSM (c = 8 tables of keys below 2^14 points, plain keys of a few hundred pairs): two block-level launches
+    // instead of plan + expand + accumulate + six strided folds (curve_quad.hpp k_small_accum)
+    const uint32_t chunk = be.small_chunk();
+    const uint32_t blocks = (uint32_t)(total / chunk) + sh.nbuckets + 1;  // sum of ceil(bucket / chunk) stays below this
+    XYZZW* part_s = be.template alloc<XYZZW>(blocks);
+    be.mark("accum");
+    be.template launch_small_accum<FID>((const AffineW*)a.bases, vals1, start, end, part_s, buckets, sh.nbuckets, chunk, blocks);
+    be.mark("fold");
+    be.template launch_small_combine<FID>((const AffineW*)a.bases, vals1, start, end, part_s, buckets, sh.nbuckets, chunk);
   } else {
   {
     PlanFn f{start, end, counters, heavy, big, sh};

@@ -302,6 +302,7 @@ struct Global {
   std::atomic<uint32_t> seg_min_total{kSegMinTotalAuto};  // env NMX_TUNE_SEG_MIN_TOTAL (profiles/r02_msm_2p20/seg_threshold.txt): msm_seg.hpp from this many sorted entries (0xffffffff: never)
   std::atomic<uint32_t> seg_min_len{8};           // env NMX_TUNE_SEG_MIN_LEN
   std::atomic<uint32_t> seg_lanes_override{0};    // env NMX_TUNE_SEG_LANES (0: the kernel's resident lane count)
+  std::atomic<uint32_t> small_blocks{8};          // option small_blocks / env NMX_TUNE_SMALL_BLOCKS: bucket sums of MSMs with <= 1024 buckets in two block-level launches (curve_quad.hpp k_small_accum), this many entries per quad; 0: the task path (plan, expand, accumulate, strided folds)
   std::atomic<uint32_t> no_quad_final{0};         // env NMX_TUNE_NO_QUAD_FINAL
   std::atomic<uint32_t> quad_final_below{65536};  // env NMX_TUNE_QUAD_FINAL_BELOW / option quad_final_below: the final pass runs four lanes per bucket below this many buckets
   std::atomic<uint32_t> accum_prefetch{0};        // env NMX_TUNE_ACCUM_PF / option accum_prefetch: 0 = by table size, 1, 2
@@ -320,6 +321,7 @@ struct Global {
   std::atomic<uint32_t> hist_grid{0};             // env NMX_TUNE_HIST_GRID / option hist_grid
   std::atomic<uint32_t> hist_bs{0};               // env NMX_TUNE_HIST_BS / option hist_bs: threads per block of k_hist_hi (0: as k_part_hi)
   std::atomic<uint32_t> horner_order{1};          // option horner_order: 1 = tiles of k_horner_scan by start-order ticket, 0 = by block id
+  std::atomic<uint32_t> sc_fused_sum{1};          // option sc_fused_sum: 1 = a sum-check round is ONE launch (the last block sums the partials, k_sc_pass); 0 = pass + final-sum launch
   std::atomic<uint32_t> sc_host_tail{6};          // option sc_host_tail: the sum-check provers finish on the host once the tables hold <= 2^this elements (0: only the final values come over; max 8)
   std::atomic<uint32_t> sc_poll_us{2000};         // option sc_poll_us: the sum-check provers poll a round's mailbox this long before they synchronise the stream (0: always synchronise)
   std::atomic<uint32_t> sync_spin_us{0};          // env NMX_SYNC_SPIN_US / option sync_spin_us: poll the stream this long before blocking
@@ -466,6 +468,27 @@ struct DeviceBackend {
       FinalSegFn<FID> f{start, end, total_p, bucket_raw, partial_raw, buckets, nbuckets, lanes, min_seg, heavy_above};
       launch(f, nbuckets);
     }
+  }
+  // small MSMs: the bucket sums in two block-level launches (curve_quad.hpp k_small_accum / k_small_combine); 0: not enabled
+  uint32_t small_chunk() const {
+    const uint32_t per_quad = G.small_blocks.load(std::memory_order_relaxed);
+    return per_quad ? 64u * (per_quad > 64u ? 64u : per_quad) : 0u;
+  }
+  template <int FID>
+  void launch_small_accum(const AffineW* bases, const uint32_t* vals, const uint32_t* start, const uint32_t* end, XYZZW* part, XYZZW* buckets,
+                          uint32_t nbuckets, uint32_t chunk, uint32_t blocks) {
+    if (dry) return;
+    const SmallAccArgs a{bases, vals, start, end, part, buckets, nbuckets, chunk};
+    hipLaunchKernelGGL((k_small_accum<FID>), dim3(blocks), dim3(256), 0, c.stream, a);
+    HIPCHK(hipGetLastError());
+  }
+  template <int FID>
+  void launch_small_combine(const AffineW* bases, const uint32_t* vals, const uint32_t* start, const uint32_t* end, XYZZW* part,
+                            XYZZW* buckets, uint32_t nbuckets, uint32_t chunk) {
+    if (dry) return;
+    const SmallAccArgs a{bases, vals, start, end, part, buckets, nbuckets, chunk};
+    hipLaunchKernelGGL((k_small_combine<FID>), dim3(nbuckets), dim3(256), 0, c.stream, a);
+    HIPCHK(hipGetLastError());
   }
   // every big bucket in one launch (curve_quad.hpp k_big_all); a bucket spans at most `lanes` pieces, `big_cap` buckets can be big
   template <int FID>

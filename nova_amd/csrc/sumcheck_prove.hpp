@@ -11,17 +11,21 @@
 // left is 20 x (launch + result + host algebra + transcript).  The per-round C calls (nmx_sumcheck_eq_sums / _bind_eq_sums) pay a
 // context lease, two launches, a device-to-host copy and a stream synchronisation each -- and the caller's FFI crossing.  Here
 // the round loop lives behind the boundary:
-//   * the tables are bound IN PLACE and the bind of round j is fused with the sums of round j + 1 (k_bind_eq_sums and its
-//     two-vector sibling below): every table is read once per round;
-//   * the sums land in a MAILBOX -- a few words of coherent pinned host memory the last block writes with system scope, sequence
-//     word last -- which the host polls: no copy engine, no stream synchronisation in a round;
-//   * rounds whose bound half fits one block (<= 512 indices) run as ONE launch (k_sc_small) instead of pass + final sum;
+//   * the tables are bound IN PLACE and the bind of round j is fused with the sums of round j + 1: every table is read once per
+//     round, ONE launch per round (k_sc_pass: one index per thread, the block that draws the last ticket adds the partials up);
+//   * the sums land in a MAILBOX -- a few words of coherent pinned host memory written with system scope, sequence word last --
+//     which the host polls: no copy engine, no stream synchronisation in a round;
 //   * the O(1) algebra of a round (derive_from_claim_deg2/1, UniPoly::from_evals_deg3/2, evaluate, EqSumCheckInstance::bound)
-//     runs on the host in the library's own field arithmetic; the only thing that leaves the library is the transcript step:
-//     a callback receives the round polynomial's coefficients and returns the challenge
-//     (`transcript.absorb(b"p", &poly); transcript.squeeze(b"c")`, sumcheck.rs:224-227,481-484,315-318 -- Keccak stays in Rust).
+//     runs on the host in 4 x 64-bit Montgomery arithmetic (host_fp4.hpp, sc_host.hpp: ~1 us per round); the only thing that
+//     leaves the library is the transcript step: a callback receives the round polynomial's coefficients and returns the
+//     challenge (`transcript.absorb(b"p", &poly); transcript.squeeze(b"c")`, sumcheck.rs:224-227,481-484,315-318);
+//   * once the tables hold <= 64 elements (option sc_host_tail) the last device bind lands them in pinned memory and the
+//     remaining rounds run on the host (sc_host.hpp sc_tail_rounds): ~300 products against a 20-25 us kernel round trip.
 // All sqrt-size eq tables of an instance (poly_eq_left[k], poly_eq_right[k], sumcheck.rs:608-641) are built by one launch into a
 // heap layout (table k at offset 2^k) in the context's aux arena.
+// Measured at num_cons = 2^20 (profiles/r05_spartan): the three provers 1.08 / 2.15 / 1.02 ms as first written (9 x 29-bit host
+// products, four indices per thread, pass + final sum) -> 0.77 / 0.91 / 0.74 ms with the host arithmetic, the tail and one
+// index per thread.
 #pragma once
 #include <array>
 
@@ -165,6 +169,91 @@ template <int FID, int MODE> __global__ __launch_bounds__(256) void k_sc_small(S
   if (threadIdx.x == 0) {
     s0.to_words(a.slot + 8);
     s1.to_words(a.slot + 16);
+    mail_publish(a.slot, a.seq);
+  }
+}
+
+// ---- the same pass over ANY number of blocks, the final sum inside it (option sc_fused_sum) ------------------------------------
+// The block that draws the last of gridDim.x tickets adds the per-block partials up and writes the mailbox: one launch per round
+// instead of pass + final sum -- a round's cost at these sizes is launches (5 us of host time and ~8 us of GPU gap + run time
+// for the one-block sum: profiles/r05_spartan), not bytes.  Ordering without a device-wide release in every block (an L2
+// write-back per block made round 4's passes 8-20 % slower, sumcheck.hip): a block publishes its 16 partial words with
+// agent-scope ATOMIC stores (they go through to memory), waits for them (s_waitcnt vmcnt(0)), then takes its ticket with a
+// relaxed agent-scope add; the last block reads the partials with agent-scope atomic loads.  The ticket word returns to zero.
+template <int FID> struct ScPassArgs {
+  ScSmallArgs<FID> s;
+  uint32_t* partial;  // 16 words per block
+  uint32_t* ticket;
+};
+template <int FID, int MODE> __global__ __launch_bounds__(256) void k_sc_pass(ScPassArgs<FID> p) {
+  using F = Fp<FID>;
+  const ScSmallArgs<FID>& a = p.s;
+  __shared__ uint32_t lds[72];
+  __shared__ uint32_t s_last;
+  F s0 = F::zero(), s1 = F::zero();
+  uint32_t pending = 0;
+  for (uint32_t id = blockIdx.x * 256u + threadIdx.x; id < a.hq; id += gridDim.x * 256u) {
+    F a0, a1, b0 = F::zero(), b1 = F::zero(), c0 = F::zero(), c1;
+    sc_bind2<FID>(a.A, a.oA, a.r, id, a.hq, a0, a1);
+    if (MODE >= 3) sc_bind2<FID>(a.B, a.oB, a.r, id, a.hq, b0, b1);
+    if (MODE == 3) sc_bind2<FID>(a.C, a.oC, a.r, id, a.hq, c0, c1);
+    if (MODE == 4) {
+      s0 = s0 + a0 * b0;
+      s1 = s1 + F::sub2(a1, a0).norm() * F::sub2(b1, b0).norm();
+    } else {
+      F fac = ldw<FID>(a.eqR, a.eqL ? (id & a.mask) : id);
+      if (a.eqL) fac = ldw<FID>(a.eqL, id >> a.shift) * fac;
+      if (MODE == 1) {
+        s0 = s0 + a0 * fac;
+      } else {
+        const F e0 = F::mul_add(a0, b0, c0, a.nk);
+        const F q = F::sub2(a1, a0).norm() * F::sub2(b1, b0).norm();
+        s0 = s0 + e0 * fac;
+        s1 = s1 + q * fac;
+      }
+    }
+    if (++pending == 6) {
+      s0 = s0.norm().canon();
+      s1 = s1.norm().canon();
+      pending = 0;
+    }
+  }
+  s0 = s0.norm().canon();
+  s1 = s1.norm().canon();
+  block_sum_pair<FID>(s0, s1, lds);
+  if (threadIdx.x == 0) {
+    uint32_t w[16];
+    s0.to_words(w), s1.to_words(w + 8);
+    uint32_t* mine = p.partial + 16 * (size_t)blockIdx.x;
+#pragma unroll
+    for (int i = 0; i < 16; i++) __hip_atomic_store(mine + i, w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_last = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;  // block-uniform
+  F t0 = F::zero(), t1 = F::zero();
+  pending = 0;
+  for (uint32_t i = threadIdx.x; i < gridDim.x; i += 256u) {
+    uint32_t w[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) w[j] = __hip_atomic_load(p.partial + 16 * (size_t)i + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t0 = (t0 + F::from_words(w)).norm();
+    t1 = (t1 + F::from_words(w + 8)).norm();
+    if (++pending == 8) {
+      t0 = t0.canon();
+      t1 = t1.canon();
+      pending = 0;
+    }
+  }
+  t0 = t0.canon();
+  t1 = t1.canon();
+  __syncthreads();  // lds is reused
+  block_sum_pair<FID>(t0, t1, lds);
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t0.to_words(a.slot + 8);
+    t1.to_words(a.slot + 16);
     mail_publish(a.slot, a.seq);
   }
 }
@@ -481,6 +570,12 @@ template <int FID, int MODE> struct ScPass {
       ScSmallArgs<FID> x{A, B, C, A, B, C, t.eqL, t.eqR, r, nk, t.shift, t.mask, hq, 1u, seq, h.slot_dev(slot)};
       hipLaunchKernelGGL((k_sc_small<FID, MODE>), dim3(1), dim3(256), 0, s, x);
       h.launched();
+    } else if (G.sc_fused_sum.load(std::memory_order_relaxed)) {
+      const uint32_t blocks = sc_blocks_bind(hq);
+      ScPassArgs<FID> x{ScSmallArgs<FID>{A, B, C, A, B, C, t.eqL, t.eqR, r, nk, t.shift, t.mask, hq, 1u, seq, h.slot_dev(slot)}, partial,
+                        partial + kScPartialBytes / 4 - 64};  // the ticket: a zero word at the end of this instance's scratch
+      hipLaunchKernelGGL((k_sc_pass<FID, MODE>), dim3(blocks), dim3(256), 0, s, x);
+      h.launched();
     } else {
       const uint32_t blocks = sc_blocks_bind(hq);
       if (MODE == 4) {
@@ -552,6 +647,7 @@ static void sc_prove_t(Ctx& c, const void* claim, const void* taus, size_t num_r
   try {
     ScDev<FID> h(c, flags);
     arena_reserve(c, kScPartialBytes + 512);
+    HIPCHK(hipMemsetAsync(c.arena + kScPartialBytes - 256, 0, 256, c.stream));  // k_sc_pass's ticket
     typename ScAlg<FID>::Eq eq;
     ScEqDev<FID> eqd;
     size_t len = (size_t)1 << l;
@@ -660,6 +756,7 @@ static void sc_prove_batch_t(Ctx& c, const uint8_t* claims_b, const size_t* num_
       heap_total += (ScEqDev<FID>::heap_bytes((uint32_t)num_rounds[i]) + 255) & ~(size_t)255;
     }
     arena_reserve(c, k * kScPartialBytes + 512);
+    for (size_t i = 0; i < k; i++) HIPCHK(hipMemsetAsync(c.arena + (i + 1) * kScPartialBytes - 256, 0, 256, c.stream));  // the tickets
     aux_reserve(c, heap_total);
     std::vector<ScBatchClaim<FID>> cs(k);
     ScBatchDev<FID> dev(h, cs);

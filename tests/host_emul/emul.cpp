@@ -50,6 +50,12 @@ struct HostEmulBackend {
     AccumFn<FID> f{bases, vals, start, end, counters, extra, buckets, partials, sh};
     launch(f, slots);
   }
+  // the block-level small-MSM path (curve_quad.hpp k_small_accum) is device-only: the emulation keeps the task path
+  uint32_t small_chunk() const { return 0; }
+  template <int FID>
+  void launch_small_accum(const AffineW*, const uint32_t*, const uint32_t*, const uint32_t*, XYZZW*, XYZZW*, uint32_t, uint32_t, uint32_t) {}
+  template <int FID>
+  void launch_small_combine(const AffineW*, const uint32_t*, const uint32_t*, const uint32_t*, XYZZW*, XYZZW*, uint32_t, uint32_t) {}
   template <int FID>
   void launch_fold(const uint32_t* counters, const HeavyRec* heavy, XYZZW* partials, XYZZW* buckets, uint32_t T,
                    uint32_t cap, uint32_t groups) {

@@ -67,3 +67,38 @@ def test_variants_agree_with_oracle(nmx, c, n):
         assert L.nmx_set_option(b"no_such_knob", 1) == _lib.E_ARG
     ck.close()
     clean.close()
+
+
+@pytest.mark.parametrize("c", [R.BN254_G1, R.GRUMPKIN], ids=lambda c: c.name)
+@pytest.mark.parametrize("n", [1, 17, 200, 1000, 5000, 10538, 13058])
+def test_small_msm_block_path_agrees_with_the_task_path_and_the_oracle(nmx, c, n):
+    """Round 5: MSMs with at most 1024 buckets (keys below 2^14 points: c = 8 tables; plain keys of a few hundred pairs) sum their
+    buckets in two block-level launches (curve_quad.hpp k_small_accum / k_small_combine; option small_blocks = entries per
+    four-lane group, 0 = the task path).  Every scalar set of the reference's matrix -- including the ones that put everything into
+    one bucket (u1, equal) -- at one entry per group (many partials per bucket), the default and 64 (one block per bucket), on a
+    key with tables, a plain key, and a key with identity points."""
+    from nova_amd import _lib
+    L = _lib.lib()
+    bases = cref.sequential_bases(c, 77 + n, n).copy()
+    if n > 20:
+        bases[n // 3] = 0
+    prep = cref.Prepared(c.cid, bases, n)
+    keys = [nmx.CommitmentKey.from_host(c.cid, bases), nmx.CommitmentKey.from_host(c.cid, bases, precompute=False)]
+    g = nmx.DlogGroup(c.cid)
+    scs = {k: util.scalar_set(c.cid, n, k) for k in KINDS}
+    exp = {k: prep.msm(s, n) for k, s in scs.items()}
+    s64 = util.small_scalars(n, 33)
+    exp64 = cref.msm_u64(c.cid, s64, bases, n, 33)
+    try:
+        for sb in (0, 1, 8, 64):
+            assert L.nmx_set_option(b"small_blocks", sb) == 0
+            for ck in keys:
+                for kind in KINDS:
+                    got = g.vartime_multiscalar_mul(scs[kind], ck)
+                    assert (got.xy, int(got.is_inf)) == exp[kind], (sb, kind)
+                got = g.vartime_multiscalar_mul_small(s64, ck)
+                assert (got.xy, int(got.is_inf)) == exp64, sb
+    finally:
+        assert L.nmx_set_option(b"small_blocks", 8) == 0
+    for ck in keys:
+        ck.close()

@@ -155,6 +155,22 @@ def test_polling_and_synchronising_agree(nmx):
         assert L.nmx_set_option(b"sc_poll_us", 2000) == 0
 
 
+def test_one_launch_rounds_and_two_launch_rounds_agree(nmx):
+    """option sc_fused_sum: the pass whose last block sums the partials (agent-scope tickets) against pass + final-sum launch, at
+    sizes where a round runs on 4 .. 4096 blocks, all three provers, repeated (the ticket word must come back to zero)."""
+    from nova_amd import _lib
+    L = _lib.lib()
+    try:
+        for fused in (1, 0, 1):
+            assert L.nmx_set_option(b"sc_fused_sum", fused) == 0
+            for l in (11, 14, 17):
+                both(sp.check_cubic3, g_cubic3(), o_cubic3, 1, l, seed=60 + l, brute=False)
+            both(sp.check_quad_prod, g_quad, o_quad, 1, 16, seed=61)
+            both(sp.check_batch_eval, g_batch, o_batch, 1, [15, 13, 16], seed=62)
+    finally:
+        assert L.nmx_set_option(b"sc_fused_sum", 1) == 0
+
+
 @pytest.mark.parametrize("tail", [0, 1, 3, 6, 8])
 def test_every_host_tail_threshold_gives_the_same_proof(nmx, tail):
     """option sc_host_tail: tables of <= 2^tail elements finish on the host (sc_host.hpp; 0 = only the final values come over).  The
