@@ -492,11 +492,11 @@ template <int FID, int THREADS> __global__ __launch_bounds__(THREADS) void k_red
 // dependent additions: 0.135 of the 0.25 ms such an MSM takes (profiles/r05_small_msm/stages_before.txt), which is what
 // prove_step's secondary-curve commitments cost.  Here a BLOCK of 64 quads takes `chunk` consecutive entries of ONE bucket
 // (the partition left every bucket's entries contiguous: start[k] .. end[k]), each quad adds its chunk / 64 entries and an
-// LDS tree joins the 64 quad sums (block_sum_quads): one partial per block; a second launch adds a bucket's partials up the
-// same way.  Which (bucket, chunk) a block owns follows from the bucket sizes alone, so every block derives it from start[]
+// one partial per quad comes out; a second launch, one block per BUCKET, adds the bucket's partials up (64 quads striding over
+// them, then a six-level LDS tree: block_sum_quads).  Which (bucket, chunk) a block owns follows from the bucket sizes alone, so every block derives it from start[]
 // / end[] itself (a scan over <= 1024 buckets in LDS): no plan kernel, no lists.  A bucket that collects everything (0 / 1
 // or all-equal scalars) simply gets more blocks, and the second launch walks its partials 64 at a time.
-// Chain: chunk / 64 + 6 additions, then ceil(partials / 64) + 6 (identity operands skip the arithmetic).
+// Chain: chunk / 64 mixed additions, then blocks-of-the-bucket + 6 additions (identity operands skip the arithmetic).
 // ----------------------------------------------------------------------------------------------------
 static constexpr uint32_t kSmallMaxBuckets = 1024;
 struct SmallAccArgs {
@@ -504,7 +504,7 @@ struct SmallAccArgs {
   const uint32_t* vals;
   const uint32_t* start;
   const uint32_t* end;
-  XYZZW* part;     // one partial per block of k_small_accum
+  XYZZW* part;     // 64 partials per block of k_small_accum (one per quad)
   XYZZW* buckets;  // k_small_combine's output
   uint32_t nbuckets, chunk;
 };
@@ -537,7 +537,6 @@ __device__ __forceinline__ void small_plan(const SmallAccArgs& a, uint32_t* s_of
 template <int FID> __global__ __launch_bounds__(256) void k_small_accum(SmallAccArgs a) {
   using F = Fp<FID>;
   __shared__ uint32_t s_off[kSmallMaxBuckets + 1], s_nb[256], s_sc[257], s_w[16];
-  __shared__ uint32_t lds[64 * 36];
   small_plan(a, s_off, s_nb, s_sc, s_w);
   const uint32_t b = blockIdx.x;
   if (b >= s_off[a.nbuckets]) return;  // block-uniform
@@ -562,18 +561,20 @@ template <int FID> __global__ __launch_bounds__(256) void k_small_accum(SmallAcc
       cur = nxt;
     }
   }
-  acc = block_sum_quads<FID, 64>(acc, lds, qd, q);
-  if (qd == 0) quad_store<FID>(a.part[b], q, acc);
+  // one partial per QUAD, no tree here: joining the 64 quad sums inside this block (a six-level LDS tree) kept three blocks per
+  // CU resident through levels in which one wave works -- accumulate 90 us instead of 45 (profiles/r05_small_msm/stages.txt);
+  // the second launch, with one block per BUCKET, does the joining
+  quad_store<FID>(a.part[(size_t)b * 64u + qd], q, acc);
 }
 template <int FID> __global__ __launch_bounds__(256) void k_small_combine(SmallAccArgs a) {
   using F = Fp<FID>;
   __shared__ uint32_t s_off[kSmallMaxBuckets + 1], s_nb[256], s_sc[257], s_w[16];
   __shared__ uint32_t lds[64 * 36];
   small_plan(a, s_off, s_nb, s_sc, s_w);
-  const uint32_t k = blockIdx.x, base = s_off[k], n = s_off[k + 1] - base;
+  const uint32_t k = blockIdx.x, base = s_off[k] * 64u, n = (s_off[k + 1] - s_off[k]) * 64u;  // 64 partials per block of the bucket
   const uint32_t qd = threadIdx.x >> 2, q = threadIdx.x & 3u;
   F acc = F::zero();
-  for (uint32_t p = qd; p < n; p += 64u) acc = quad_add<FID>(acc, quad_load<FID>(a.part[base + p], q), q);
+  for (uint32_t p = qd; p < n; p += 64u) acc = quad_add<FID>(acc, quad_load<FID>(a.part[(size_t)base + p], q), q);
   acc = block_sum_quads<FID, 64>(acc, lds, qd, q);
   if (qd == 0) quad_store<FID>(a.buckets[k], q, acc);
 }

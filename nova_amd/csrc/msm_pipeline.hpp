@@ -322,7 +322,7 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
     // instead of plan + expand + accumulate + six strided folds (curve_quad.hpp k_small_accum)
     const uint32_t chunk = be.small_chunk();
     const uint32_t blocks = (uint32_t)(total / chunk) + sh.nbuckets + 1;  // sum of ceil(bucket / chunk) stays below this
-    XYZZW* part_s = be.template alloc<XYZZW>(blocks);
+    XYZZW* part_s = be.template alloc<XYZZW>((size_t)blocks * 64);  // one partial per quad
     be.mark("accum");
     be.template launch_small_accum<FID>((const AffineW*)a.bases, vals1, start, end, part_s, buckets, sh.nbuckets, chunk, blocks);
     be.mark("fold");
