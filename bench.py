@@ -635,6 +635,62 @@ def fieldvec_block(args, torch, L):
     entry("spmv", N22, 3 * 68 + 40, ms, as_bytes(o, m) == cref.spmv(fid, indptr[: m + 1], indices, data, m, hA[:N22]),
           "CSR, 3 non-zeros per row, 9 of 10 coefficients +-1 (R1CS-like)")
     mat.close()
+    # The same kernels at 2^20 elements -- the size BASELINE.json configs[4] runs them at: a few microseconds of
+    # HBM time each, so what these entries show is the launch floor (kernel_ms is the hipEvent bracket of ONE call's launches)
+    a20, b20, c20, d20, e20 = (p_[:N20] for p_ in pool)
+    h20 = [host(j, N20) for j in range(5)]
+    main = res
+    res = {}
+    ms, o = kernel_ms(lambda: fv.axpy(fid, a20, b20, r))
+    entry("axpy", N20, 96, ms, as_bytes(o) == cref.field_axpy(fid, h20[0], h20[1], r, N20))
+    ms, o = kernel_ms(lambda: fv.axpy2(fid, a20, b20, c20, r))
+    entry("axpy2", N20, 128, ms, as_bytes(o) == cref.field_axpy2(fid, h20[0], h20[1], h20[2], r, N20))
+    ms, o = kernel_ms(lambda: fv.cross_term(fid, a20, b20, c20, d20, r))
+    entry("cross_term", N20, 160, ms, as_bytes(o) == cref.field_cross_term(fid, h20[0], h20[1], h20[2], h20[3], r, N20))
+    ms, o = kernel_ms(lambda: fv.cross_term2(fid, a20, b20, c20, d20, e20, r))
+    entry("cross_term2", N20, 192, ms, as_bytes(o) == cref.field_cross_term2(fid, h20[0], h20[1], h20[2], h20[3], h20[4], r, N20))
+    ms, o = kernel_ms(lambda: fv.bind_poly_var_top(fid, a20, r))
+    entry("bind", N20, 48, ms, as_bytes(o) == cref.field_bind(fid, h20[0], 0, N20 // 2, 1, r, N20 // 2))
+    sh20 = (20 - 1) // 2
+    eqR20, eqL20 = rand_vec(1 << sh20), rand_vec((N20 // 2) >> sh20)
+    torch.cuda.synchronize()
+    ms, o = kernel_ms(lambda: fv.sumcheck_eq_sums(fid, 3, a20, b20, c20, eqR20, eqL20, sh20))
+    entry("sumcheck3", N20, 80, ms, as_bytes(o) == b"".join(cref.sumcheck_eq_sums(fid, 3, h20[0], h20[1], h20[2], N20, eqR20.cpu().numpy(),
+                                                                                    eqL20.cpu().numpy(), sh20)))
+    ms, o = kernel_ms(lambda: fv.sumcheck_plain_sums(fid, 1, a20, b20))
+    entry("quad_prod", N20, 64, ms, as_bytes(o)[:64] == b"".join(cref.sumcheck_plain_sums(fid, 1, h20[0], h20[1], None, N20)[:2]))
+    sh203 = (20 - 2) // 2
+    eqR203, eqL203 = rand_vec(1 << sh203), rand_vec((N20 // 4) >> sh203)
+    work = [torch.empty_like(t) for t in (a20, b20, c20)]
+
+    def refresh20():
+        for w, t in zip(work, (a20, b20, c20)):
+            w.copy_(t)
+        torch.cuda.synchronize()
+    ms, o = kernel_ms(lambda: fv.sumcheck_bind_eq_sums(fid, 3, work[0], work[1], work[2], r, eqR203, eqL203, sh203)[3], pre=refresh20)
+    bound = [cref.field_bind(fid, h, 0, N20 // 2, 1, r, N20 // 2) for h in h20[:3]]
+    entry("round3", N20, 144, ms, as_bytes(o) == b"".join(cref.sumcheck_eq_sums(fid, 3, bound[0], bound[1], bound[2], N20 // 2,
+                                                                                 eqR203.cpu().numpy(), eqL203.cpu().numpy(), sh203)))
+    del work, bound
+    vecs20 = [p_[j * N20:(j + 1) * N20] for p_ in (A, B) for j in range(4)]
+    ms, o = kernel_ms(lambda: fv.lincomb_powers(fid, vecs20, r))
+    entry("lincomb8", N20, 288, ms, as_bytes(o) == cref.lincomb_powers(fid, [v.cpu().numpy().tobytes() for v in vecs20], r, N20))
+    ms, o = kernel_ms(lambda: fv.suffix_horner(fid, a20, r))
+    entry("horner", N20, 64, ms, as_bytes(o) == cref.suffix_horner(fid, h20[0], N20, r))
+    ms, o = kernel_ms(lambda: fv.mle_evaluate(fid, a20, point[:20]))
+    entry("mle_eval", N20, 32, ms, as_bytes(o) == cref.mle_evaluate(fid, h20[0], 20, point[:20]))
+    ip20 = np.arange(0, 3 * N20 + 1, 3, dtype=np.uint64)
+    ix20 = rng.integers(0, N20, size=3 * N20).astype(np.uint64)
+    mat = fv.SparseMatrix(fid, ip20, ix20, data[:3 * N20], N20)
+    ms, o = kernel_ms(lambda: mat.multiply_vec(a20))
+    entry("spmv", N20, 3 * 68 + 40, ms, as_bytes(o) == cref.spmv(fid, ip20, ix20, data[:3 * N20], N20, h20[0]))
+    ms, o = kernel_ms(lambda: mat.multiply_vec_transposed(a20))
+    entry("spmv_transposed", N20, 3 * 68 + 40, ms, as_bytes(o) == cref.spmv_transposed(fid, ip20, ix20, data[:3 * N20], N20, N20, h20[0]),
+          "compute_eval_table_sparse's product (src/spartan/mod.rs:497-533) over the same matrix")
+    mat.close()
+    at20 = res
+    at20["_min_frac"] = min(v["frac"] for v in at20.values() if isinstance(v, dict))
+    res = main
     # The multiplier ceiling of each kernel, from the counters: VALU wave-instructions per launch (rocprofv3 --pmc SQ_INSTS_VALU,
     # a separate pass, committed under profiles/) x 64 lanes / the chip's measured VOP3 issue rate = the time the arithmetic
     # alone takes.  A kernel whose valu_floor_ms is close to kernel_ms is multiplier-bound: on a slower-clocked lease its HBM
@@ -653,6 +709,7 @@ def fieldvec_block(args, torch, L):
     res["_what"] = ("bn254_fr vectors resident in HBM; kernel_ms = hipEvents on the library stream, mean of 5 launches; frac = "
                     "algorithmic bytes / kernel time / 8000 GB/s; gpu_matches_cpu = oracle/nova_ref.c on the same inputs")
     res["_min_frac"] = min(v["frac"] for k, v in res.items() if isinstance(v, dict))
+    res["at_2p20"] = at20
     return res
 
 

@@ -165,6 +165,7 @@ static void ensure_init() {
   if (const char* t = getenv("NMX_TUNE_HIST_GRID")) G.hist_grid = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_HIST_BS")) G.hist_bs = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_SYNC_SPIN_US")) G.sync_spin_us = (uint32_t)atoi(t);
+  if (const char* t = getenv("NMX_HOST_SPLIT")) G.host_split = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_SC_POLL_US")) G.sc_poll_us = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_SC_HOST_TAIL")) G.sc_host_tail = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_SC_FUSED_SUM")) G.sc_fused_sum = (uint32_t)atoi(t);
@@ -567,6 +568,52 @@ static void key_msm(Ctx& c0, const BaseSet& bs, size_t offset, size_t n, const M
       m.scalars_sharded = false;
       if (n) check_shard_piece(m.scalars, n * (mc.u64_mode ? 8 : 32), bs.dev);
       o.msm_key(c0, prefix_or_key(bs, offset, n), offset, n, m, flags, out, inf);
+      return;
+    }
+    // Host scalars of a large call (the trait's own form: `vartime_multiscalar_mul(&[Scalar], &ck[..n])`, bn256_grumpkin.rs:45-47):
+    // the upload (32 MiB at 2^20: ~0.6 ms over PCIe) cannot overlap an MSM that needs every scalar before its buckets are
+    // cut -- but it can overlap ANOTHER MSM.  The call is cut into `host_split` contiguous pieces (the reference's own
+    // decomposition: chunks + reduce(identity, +), msm.rs:564-574), piece i's scalars cross PCIe while piece i - 1 computes;
+    // the copies take turns (two copies at once would share the link and both finish late), each piece runs on its own
+    // context and stream, the 128-byte partials are summed on the host.
+    const uint32_t split = G.host_split.load(std::memory_order_relaxed);
+    if (split > 1 && mc.scalars && !mc.scalars_device && !mc.gather_host && !mc.all_ones && n >= G.host_split_min_n.load(std::memory_order_relaxed) &&
+        n / split >= 4096) {
+      const size_t sb = mc.u64_mode ? 8 : 32;
+      std::vector<uint8_t> partials(128 * (size_t)split);
+      std::mutex turn_mu;
+      std::condition_variable turn_cv;
+      uint32_t turn = 0;
+      run_on_parts(split, true, [&](size_t i) {
+        const PartRange r = shard_range(n, (uint32_t)i, split);
+        CtxLease L(bs.dev);
+        bool copied = false;
+        auto pass_turn = [&] {  // whatever happens, the next piece must not wait for ever
+          std::lock_guard<std::mutex> lk(turn_mu);
+          if (turn == i) turn++;
+          turn_cv.notify_all();
+        };
+        try {
+          aux_reserve(*L.c, r.n * sb);
+          {
+            std::unique_lock<std::mutex> lk(turn_mu);
+            turn_cv.wait(lk, [&] { return turn >= i; });
+          }
+          HIPCHK(hipMemcpyAsync(L.c->aux, (const char*)mc.scalars + r.begin * sb, r.n * sb, hipMemcpyHostToDevice, L.c->stream));
+          HIPCHK(hipStreamSynchronize(L.c->stream));
+          copied = true;
+          pass_turn();
+          MsmCall m = mc;
+          m.scalars = L.c->aux;
+          m.scalars_device = true;
+          o.msm_key(*L.c, prefix_or_key(bs, offset + r.begin, r.n), offset + r.begin, r.n, m, (flags & ~(uint32_t)NMX_OUT_PARTIAL) | NMX_OUT_PARTIAL,
+                    partials.data() + 128 * i, nullptr);
+        } catch (...) {
+          if (!copied) pass_turn();
+          throw;
+        }
+      });
+      o.point_sum(partials.data(), split, flags, out, inf);
       return;
     }
     o.msm_key(c0, mc.gather_host ? bs : prefix_or_key(bs, offset, n), offset, n, mc, flags, out, inf);
@@ -2526,6 +2573,10 @@ int nmx_set_option(const char* name, uint32_t value) {
     else if (n == "hist_bs") G.hist_bs = value;
     else if (n == "sync_spin_us") G.sync_spin_us = value;
     else if (n == "sc_poll_us") G.sc_poll_us = value;
+    else if (n == "host_split") {
+      require(value <= 16, NMX_E_ARG, "host_split: pieces a large host-scalar call is cut into, 0 / 1 = off, at most 16");
+      G.host_split = value;
+    } else if (n == "host_split_min_n") G.host_split_min_n = value;
     else if (n == "sc_fused_sum") G.sc_fused_sum = value ? 1u : 0u;
     else if (n == "sc_host_tail") {
       require(value <= 8, NMX_E_ARG, "sc_host_tail: log2 of the table length the host takes over, 0..8");

@@ -321,6 +321,8 @@ struct Global {
   std::atomic<uint32_t> hist_grid{0};             // env NMX_TUNE_HIST_GRID / option hist_grid
   std::atomic<uint32_t> hist_bs{0};               // env NMX_TUNE_HIST_BS / option hist_bs: threads per block of k_hist_hi (0: as k_part_hi)
   std::atomic<uint32_t> horner_order{1};          // option horner_order: 1 = tiles of k_horner_scan by start-order ticket, 0 = by block id
+  std::atomic<uint32_t> host_split{2};            // option host_split: a call with HOST scalars over >= host_split_min_n pairs of a single-device key is cut into this many pieces whose uploads overlap the previous piece's MSM (0 / 1: off)
+  std::atomic<size_t> host_split_min_n{(size_t)1 << 19};
   std::atomic<uint32_t> sc_fused_sum{1};          // option sc_fused_sum: 1 = a sum-check round is ONE launch (the last block sums the partials, k_sc_pass); 0 = pass + final-sum launch
   std::atomic<uint32_t> sc_host_tail{6};          // option sc_host_tail: the sum-check provers finish on the host once the tables hold <= 2^this elements (0: only the final values come over; max 8)
   std::atomic<uint32_t> sc_poll_us{2000};         // option sc_poll_us: the sum-check provers poll a round's mailbox this long before they synchronise the stream (0: always synchronise)

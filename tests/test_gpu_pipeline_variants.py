@@ -102,3 +102,52 @@ def test_small_msm_block_path_agrees_with_the_task_path_and_the_oracle(nmx, c, n
         assert L.nmx_set_option(b"small_blocks", 8) == 0
     for ck in keys:
         ck.close()
+
+
+def test_host_scalar_calls_cut_into_overlapping_pieces(nmx):
+    """Round 5 (option host_split): an MSM with HOST scalars over a long range is cut into contiguous pieces whose uploads overlap
+    the previous piece's MSM (the reference's chunk + reduce decomposition, src/provider/msm.rs:564-574); the result is the
+    unsplit one, for prefixes and interior slices, canonical and Montgomery scalars, small scalars; a scalar >= r in any piece
+    fails the whole call."""
+    from nova_amd import _lib
+    L = _lib.lib()
+    c = R.BN254_G1
+    n = 30000
+    bases = cref.sequential_bases(c, 4242, n).copy()
+    bases[n // 2 + 3] = 0
+    prep = cref.Prepared(c.cid, bases, n)
+    ck = nmx.CommitmentKey.from_host(c.cid, bases)
+    g = nmx.DlogGroup(c.cid)
+    sc = util.random_scalars(c.cid, n, seed=77)
+    exp = prep.msm(sc, n)
+    s64 = util.small_scalars(n, 40)
+    exp64 = cref.msm_u64(c.cid, s64, bases, n, 40)
+    off, m = 1234, 20001
+    exp_mid = cref.msm(c.cid, sc[:m], bases[off:off + m], m)
+    try:
+        assert L.nmx_set_option(b"host_split_min_n", 8192) == 0
+        assert L.nmx_set_option(b"host_split", 17) == _lib.E_ARG
+        for k in (2, 0, 3, 4, 7, 1):
+            assert L.nmx_set_option(b"host_split", k) == 0
+            got = g.vartime_multiscalar_mul(sc, ck)
+            assert (got.xy, int(got.is_inf)) == exp, k
+            got = g.vartime_multiscalar_mul(sc[:m], ck, offset=off)
+            assert (got.xy, int(got.is_inf)) == exp_mid, k
+            got = g.vartime_multiscalar_mul(util.to_mont_scalars(c.cid, sc), ck, mont=True)
+            assert (got.xy, int(got.is_inf)) == exp, k
+            got = g.vartime_multiscalar_mul_small(s64, ck)
+            assert (got.xy, int(got.is_inf)) == exp64, k
+            part = g.vartime_multiscalar_mul(sc, ck, partial=True)
+            assert (lambda r: (r.xy, int(r.is_inf)))(g.point_sum([part.xy])) == exp, k
+        assert L.nmx_set_option(b"host_split", 3) == 0
+        bad = sc.copy()
+        bad[n - 5] = 0xFF                                    # >= r, in the last piece
+        with pytest.raises(nmx.NmxError) as e:
+            g.vartime_multiscalar_mul(bad, ck)
+        assert e.value.code == _lib.E_SCALAR_RANGE
+        got = g.vartime_multiscalar_mul(sc, ck)                # and the library is fine afterwards
+        assert (got.xy, int(got.is_inf)) == exp
+    finally:
+        assert L.nmx_set_option(b"host_split", 2) == 0
+        assert L.nmx_set_option(b"host_split_min_n", 1 << 19) == 0
+    ck.close()
