@@ -35,6 +35,17 @@ using namespace nmx;
   } while (0)
 
 static constexpr uint64_t M52 = (1ull << 52) - 1;
+// FP64 rounding mode (MODE register bits [3:2]) <- toward zero / back to nearest.  The operands pass THROUGH the asm statement:
+// the compiler knows nothing about the mode register and would otherwise be free to schedule the FMAs ahead of the switch (the
+// first build of this file did exactly that: 198 of 200 products wrong, profiles/r05_ubench_dpf.jsonl).
+__device__ __forceinline__ void round_toward_zero(double (&x)[5], double (&y)[5]) {
+  asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 3\n\ts_nop 1"
+               : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]), "+v"(y[4]));
+}
+__device__ __forceinline__ void round_to_nearest(uint64_t (&p)[10]) {
+  asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 0\n\ts_nop 1"
+               : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]), "+v"(p[8]), "+v"(p[9]));
+}
 __device__ __forceinline__ uint64_t dbits(double d) { return (uint64_t)__double_as_longlong(d); }
 __device__ __forceinline__ double limb_to_double(uint64_t l) {  // 52-bit integer -> double: OR into the mantissa of 2^52, subtract 2^52
   return __longlong_as_double((long long)(l | 0x4330000000000000ull)) - 4503599627370496.0;
@@ -68,12 +79,11 @@ __device__ __forceinline__ void dpf_mul5(const double (&a)[5], const double (&b)
   }
 }
 __global__ __launch_bounds__(256) void k_dpf_mul(uint64_t* io, int iters) {
-  // FP64 rounding mode <- toward zero: MODE register bits [3:2]  (hwreg id 1, offset 2, size 2)
-  __builtin_amdgcn_s_setreg((1 << 11) | (2 << 6) | 1, 3);
   const int t = blockIdx.x * 256 + threadIdx.x;
   double x[5], y[5];
 #pragma unroll
   for (int i = 0; i < 5; i++) x[i] = limb_to_double(io[10 * (size_t)t + i]), y[i] = limb_to_double(io[10 * (size_t)t + 5 + i]);
+  round_toward_zero(x, y);
   uint64_t p[10];
   for (int it = 0; it < iters; it++) {
     // all ten limbs feed the next operand (low half + high half, limb by limb): nothing of the 25 products is dead code, and
@@ -86,18 +96,20 @@ __global__ __launch_bounds__(256) void k_dpf_mul(uint64_t* io, int iters) {
     for (int i = 0; i < 5; i++) y[i] = limb_to_double((p[i] + p[i + 5]) & M52);
   }
 #pragma unroll
-  for (int i = 0; i < 5; i++) io[10 * (size_t)t + i] = (uint64_t)x[i], io[10 * (size_t)t + 5 + i] = (uint64_t)y[i];
-  __builtin_amdgcn_s_setreg((1 << 11) | (2 << 6) | 1, 0);
+  for (int i = 0; i < 5; i++) p[i] = dbits(x[i] + 4503599627370496.0) & M52, p[5 + i] = dbits(y[i] + 4503599627370496.0) & M52;
+  round_to_nearest(p);
+#pragma unroll
+  for (int i = 0; i < 10; i++) io[10 * (size_t)t + i] = p[i];
 }
 // one product, all ten limbs out (verification)
 __global__ void k_dpf_once(const uint64_t* in, uint64_t* out) {
-  __builtin_amdgcn_s_setreg((1 << 11) | (2 << 6) | 1, 3);
   double x[5], y[5];
   for (int i = 0; i < 5; i++) x[i] = limb_to_double(in[i]), y[i] = limb_to_double(in[5 + i]);
+  round_toward_zero(x, y);
   uint64_t p[10];
   dpf_mul5(x, y, p);
+  round_to_nearest(p);
   for (int i = 0; i < 10; i++) out[i] = p[i];
-  __builtin_amdgcn_s_setreg((1 << 11) | (2 << 6) | 1, 0);
 }
 template <int FID> __global__ __launch_bounds__(256) void k_modmul(uint32_t* io, int iters) {
   int t = blockIdx.x * 256 + threadIdx.x;

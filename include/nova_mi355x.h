@@ -492,8 +492,9 @@ int nmx_set_window_bits(uint32_t c);
  * wave of the scan: 0 = by size, 1, 2, 4), "eq_max_blocks" (grid cap of the eq-factored sum passes: 0 = 768 for evaluate_with, 2048 otherwise), "horner_spin_limit" (polls before a wave of the scan gives up and the call falls back
  * to the two-pass kernels: 0 = 2^22; tests set 1),
  * "host_split" / "host_split_min_n" (an MSM with HOST scalars over at least host_split_min_n = 2^19 pairs of a key on one device is cut
- * into host_split = 2 contiguous pieces -- the reference's own chunk + reduce decomposition, src/provider/msm.rs:564-574 -- so that
- * piece i's scalars cross PCIe while piece i - 1 computes; 0 / 1: one upload, then one MSM),
+ * into contiguous pieces (host_split = 255, the default: 2 / 3 / 4 pieces from 2^19 / 2^20 / 2^21 pairs; 2..16: that many) -- the
+ * reference's own chunk + reduce decomposition, src/provider/msm.rs:564-574 -- so that piece i's scalars cross PCIe while piece
+ * i - 1 computes; 0 / 1: one upload, then one MSM),
  * "small_blocks" (MSMs with at most 1024 buckets -- keys below 2^14 points: bucket sums in two block-level launches, this many
  * entries per four-lane group, default 8; 0 = the task path: plan, expand, accumulate, strided folds),
  * "seg_heavy_above" (pieces per bucket summed without a pre-fold pass: 0 = by table width, else 1..63), "no_tree_fuse" (bucket

@@ -576,7 +576,9 @@ static void key_msm(Ctx& c0, const BaseSet& bs, size_t offset, size_t n, const M
     // decomposition: chunks + reduce(identity, +), msm.rs:564-574), piece i's scalars cross PCIe while piece i - 1 computes;
     // the copies take turns (two copies at once would share the link and both finish late), each piece runs on its own
     // context and stream, the 128-byte partials are summed on the host.
-    const uint32_t split = G.host_split.load(std::memory_order_relaxed);
+    uint32_t split = G.host_split.load(std::memory_order_relaxed);
+    // automatic (the default, 255): two pieces from 2^19 pairs, three from 2^20, four from 2^21 (measured: profiles/r05_msm_2p20/host_split.txt)
+    if (split == 255u) split = n >= ((size_t)1 << 21) ? 4u : n >= ((size_t)1 << 20) ? 3u : 2u;
     if (split > 1 && mc.scalars && !mc.scalars_device && !mc.gather_host && !mc.all_ones && n >= G.host_split_min_n.load(std::memory_order_relaxed) &&
         n / split >= 4096) {
       const size_t sb = mc.u64_mode ? 8 : 32;
@@ -2319,7 +2321,7 @@ int nmx_spmv_apply(uint64_t handle, const void* z, size_t z_len, uint32_t flags,
 }
 
 // M^T in virtual rows, built once per matrix from the resident CSR (Global::SparseSet::Transposed): counting sort of the entries
-// by column on the host, columns longer than 64 entries cut into chunks of 64
+// by column on the host, columns longer than 32 entries cut into chunks of 16
 static std::shared_ptr<Global::SparseSet::Transposed> transposed_of(Ctx& c, Global::SparseSet& ss) {
   std::lock_guard<std::mutex> lk(ss.t_mu);
   if (ss.tr) return ss.tr;
@@ -2349,12 +2351,15 @@ static std::shared_ptr<Global::SparseSet::Transposed> transposed_of(Ctx& c, Glob
   size_t nparts = 0;
   for (size_t j = 0; j < cols; j++) {
     const uint32_t b = cnt[j], e = cnt[j + 1], L = e - b;
-    if (L <= 64) {
+    if (L <= 32) {
       vptr.push_back(e);
       vout.push_back((uint32_t)j);
       continue;
     }
-    const uint32_t T = 64;  // every lane walks at most 64 entries; a split column's partials are summed by a block (SpmvHeavyFn)
+    // every lane walks at most 16 entries of a split column -- each step is a gather whose latency nothing hides, 64-entry chunks
+    // made the lanes of ONE long column the longest thing in the launch (profiles/r05_spartan: 214 us against 62 for a matrix
+    // without such a column); a split column's partials are summed by a block (k_spmv_heavy)
+    const uint32_t T = 16;
     for (uint32_t a = b; a < e; a += T) {
       vptr.push_back(a + T < e ? a + T : e);
       vout.push_back(0x80000000u | (uint32_t)nparts++);
@@ -2574,7 +2579,7 @@ int nmx_set_option(const char* name, uint32_t value) {
     else if (n == "sync_spin_us") G.sync_spin_us = value;
     else if (n == "sc_poll_us") G.sc_poll_us = value;
     else if (n == "host_split") {
-      require(value <= 16, NMX_E_ARG, "host_split: pieces a large host-scalar call is cut into, 0 / 1 = off, at most 16");
+      require(value <= 16 || value == 255, NMX_E_ARG, "host_split: pieces a large host-scalar call is cut into, 0 / 1 = off, at most 16; 255 = by size");
       G.host_split = value;
     } else if (n == "host_split_min_n") G.host_split_min_n = value;
     else if (n == "sc_fused_sum") G.sc_fused_sum = value ? 1u : 0u;

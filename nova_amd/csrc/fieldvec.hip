@@ -229,7 +229,7 @@ template <int FID> struct SpmvFn {
 // for every entry -- a scatter-add on the reference's side, a gather over the transposed matrix here).  The CSC arrays are cut
 // into virtual rows at registration of the transposed form (Global::SparseSet::Transposed): short columns are one virtual row
 // that writes its output element; a long column (the constant-one column of an R1CS matrix has an entry per constraint) is
-// several, each writing a partial that k_spmv_heavy adds up (one block per split column) -- no lane walks more than 64 entries.
+// several, each writing a partial that k_spmv_heavy adds up (one block per split column) -- no lane walks more than 32 entries.
 template <int FID> struct SpmvSegFn {
   const uint32_t* vptr;     // nvirt + 1
   const uint32_t* indices;  // nnz: row of M | class << 28

@@ -274,7 +274,7 @@ struct Global {
     uint32_t *indptr = nullptr, *indices = nullptr, *data = nullptr;
     // M^T for compute_eval_table_sparse (nmx_spmv_apply_transposed), built from the resident CSR on first use: the CSC arrays
     // cut into VIRTUAL rows (a column of an R1CS matrix can hold one entry per constraint -- the constant-one column does --
-    // so a column longer than 64 entries is split into chunks of 64 entries, each its own lane; a block sums a column's partials), the slot
+    // so a column longer than 32 entries is split into chunks of 16 entries, each its own lane; a block sums a column's partials), the slot
     // every virtual row writes (an output row, or 2^31 | index of a partial), and the (row, first partial) list of the split rows
     struct Transposed {
       uint32_t *vptr = nullptr, *indices = nullptr, *data = nullptr, *vout = nullptr, *hrow = nullptr, *hstart = nullptr;
@@ -321,7 +321,7 @@ struct Global {
   std::atomic<uint32_t> hist_grid{0};             // env NMX_TUNE_HIST_GRID / option hist_grid
   std::atomic<uint32_t> hist_bs{0};               // env NMX_TUNE_HIST_BS / option hist_bs: threads per block of k_hist_hi (0: as k_part_hi)
   std::atomic<uint32_t> horner_order{1};          // option horner_order: 1 = tiles of k_horner_scan by start-order ticket, 0 = by block id
-  std::atomic<uint32_t> host_split{2};            // option host_split: a call with HOST scalars over >= host_split_min_n pairs of a single-device key is cut into this many pieces whose uploads overlap the previous piece's MSM (0 / 1: off)
+  std::atomic<uint32_t> host_split{255};           // option host_split: a call with HOST scalars over >= host_split_min_n pairs of a single-device key is cut into this many pieces whose uploads overlap the previous piece's MSM (0 / 1: off)
   std::atomic<size_t> host_split_min_n{(size_t)1 << 19};
   std::atomic<uint32_t> sc_fused_sum{1};          // option sc_fused_sum: 1 = a sum-check round is ONE launch (the last block sums the partials, k_sc_pass); 0 = pass + final-sum launch
   std::atomic<uint32_t> sc_host_tail{6};          // option sc_host_tail: the sum-check provers finish on the host once the tables hold <= 2^this elements (0: only the final values come over; max 8)

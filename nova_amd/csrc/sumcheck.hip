@@ -456,7 +456,10 @@ static void bind_eq_sums_t(Ctx& c, const void* A, const void* B, const void* C, 
   using F = Fp<FID>;
   const bool mont = flags & NMX_SCALARS_MONT;
   const uint32_t hq = (uint32_t)(len / 4);
-  const uint32_t want = (hq + 256 * 4 - 1) / (256 * 4);
+  // four indices per lane at 2^24 (the LDS tree per block is then a small share); below 2^20 indices ONE per lane: a pass is a
+  // latency chain of ~10 products per index and four of them in a row made every size from 2^10 to 2^18 take 45-59 us
+  const uint32_t per = hq <= (1u << 20) ? 1u : 4u;
+  const uint32_t want = (hq + 256 * per - 1) / (256 * per);
   const uint32_t blocks = want < 1 ? 1 : (want > 4096 ? 4096 : want);
   auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
   arena_reserve(c, pad((size_t)blocks * 64) + 64 + 512);

@@ -127,7 +127,7 @@ def test_host_scalar_calls_cut_into_overlapping_pieces(nmx):
     try:
         assert L.nmx_set_option(b"host_split_min_n", 8192) == 0
         assert L.nmx_set_option(b"host_split", 17) == _lib.E_ARG
-        for k in (2, 0, 3, 4, 7, 1):
+        for k in (2, 0, 3, 4, 7, 1, 255):
             assert L.nmx_set_option(b"host_split", k) == 0
             got = g.vartime_multiscalar_mul(sc, ck)
             assert (got.xy, int(got.is_inf)) == exp, k
@@ -148,6 +148,6 @@ def test_host_scalar_calls_cut_into_overlapping_pieces(nmx):
         got = g.vartime_multiscalar_mul(sc, ck)                # and the library is fine afterwards
         assert (got.xy, int(got.is_inf)) == exp
     finally:
-        assert L.nmx_set_option(b"host_split", 2) == 0
+        assert L.nmx_set_option(b"host_split", 255) == 0
         assert L.nmx_set_option(b"host_split_min_n", 1 << 19) == 0
     ck.close()
