@@ -373,7 +373,8 @@ int nmx_sumcheck_plain_sums(int field, int kind, const void* A, const void* B, c
 /* ---- Spartan's sum-check provers, ONE call each (BASELINE.json configs[4]; src/spartan/snark.rs:113-260) -------------------
  * A sum-check round is a streaming pass whose size halves every round, followed by a challenge only the host's transcript can
  * produce; at 2^20 the passes are ~0.1 ms and the rest is per-round latency.  So the round LOOP lives behind the boundary: the
- * tables (HBM-resident, NMX_SCALARS_DEVICE required) are bound in place, the bind of a round is fused with the next round's
+ * tables (HBM-resident with NMX_SCALARS_DEVICE -- the intended form; host arrays otherwise: uploaded for the call, the host
+ * copies left untouched) are bound in place, the bind of a round is fused with the next round's
  * sums, results reach the host through a polled mailbox in pinned memory, rounds that fit one block are one launch, and the
  * O(1) algebra of a round (derive_from_claim_deg2/1, UniPoly::from_evals_deg3/2, evaluate, EqSumCheckInstance::bound --
  * src/spartan/sumcheck.rs:680-753, 1226-1231, polys/univariate.rs:90-149) runs in the library.  The one thing that stays on the

@@ -192,4 +192,91 @@ template <int CURVE> struct CommitmentEngine {
 };
 
 }  // namespace provider
+
+// Spartan's sum-check provers (src/spartan/sumcheck.rs) over the C ABI's one-call-per-prover entry points.  `Transcript` is the
+// caller's: any type with `Scalar round(const std::vector<Scalar>& unipoly_coeffs)` -- what the reference writes as
+// `transcript.absorb(b"p", &poly); transcript.squeeze(b"c")` (sumcheck.rs:224-227, 481-484, 315-318).  Tables are host vectors here
+// (uploaded for the call; hosts that keep their vectors in HBM call the C entry points with NMX_SCALARS_DEVICE).
+namespace spartan {
+using provider::Scalar;
+using provider::check;
+
+struct SumcheckProof {                              // what SumcheckProof::new(compressed_polys) is built from, plus r and the claims
+  std::vector<std::vector<Scalar>> polys;           // per round: UniPoly coefficients, constant term first
+  std::vector<Scalar> r;                            // the challenges
+  std::vector<Scalar> claims;                       // final evaluations (poly_A[0], ...)
+};
+namespace detail {
+template <class Transcript> int round_cb(void* ctx, const uint8_t* coeffs32, size_t n, uint8_t* out) {
+  try {
+    std::vector<Scalar> co(n);
+    for (size_t i = 0; i < n; i++) std::copy(coeffs32 + 32 * i, coeffs32 + 32 * i + 32, co[i].begin());
+    const Scalar r = static_cast<Transcript*>(ctx)->round(co);
+    std::copy(r.begin(), r.end(), out);
+    return 0;
+  } catch (...) {
+    return 1;  // never let an exception cross the C frame: the call fails with NMX_E_ARG
+  }
+}
+inline SumcheckProof unpack(size_t rounds, size_t nco, size_t nclaims, const std::vector<uint8_t>& p, const std::vector<uint8_t>& r,
+                            const std::vector<uint8_t>& c) {
+  SumcheckProof out;
+  out.polys.assign(rounds, std::vector<Scalar>(nco));
+  out.r.resize(rounds), out.claims.resize(nclaims);
+  for (size_t j = 0; j < rounds; j++) {
+    for (size_t i = 0; i < nco; i++) std::copy(p.begin() + 32 * (nco * j + i), p.begin() + 32 * (nco * j + i) + 32, out.polys[j][i].begin());
+    std::copy(r.begin() + 32 * j, r.begin() + 32 * j + 32, out.r[j].begin());
+  }
+  for (size_t i = 0; i < nclaims; i++) std::copy(c.begin() + 32 * i, c.begin() + 32 * i + 32, out.claims[i].begin());
+  return out;
+}
+}  // namespace detail
+
+template <int FIELD> struct Sumcheck {
+  // SumcheckProof::prove_cubic_with_three_inputs (sumcheck.rs:446-507)
+  template <class Transcript>
+  static SumcheckProof prove_cubic_with_three_inputs(const Scalar& claim, const std::vector<Scalar>& taus, const std::vector<Scalar>& A,
+                                                     const std::vector<Scalar>& B, const std::vector<Scalar>& C, Transcript& tr, bool mont = false) {
+    const size_t l = taus.size();
+    if (A.size() != (size_t)1 << l || B.size() != A.size() || C.size() != A.size()) throw std::invalid_argument("tables must hold 2^taus.len() elements");
+    std::vector<uint8_t> p(128 * l + 1), r(32 * l + 1), c(96);
+    check(nmx_sumcheck_prove_cubic_with_three_inputs(FIELD, claim.data(), taus.data(), l, const_cast<Scalar*>(A.data()), const_cast<Scalar*>(B.data()),
+                                                     const_cast<Scalar*>(C.data()), mont ? NMX_SCALARS_MONT : 0u, &detail::round_cb<Transcript>, &tr,
+                                                     p.data(), r.data(), c.data()));
+    return detail::unpack(l, 4, 3, p, r, c);
+  }
+  // SumcheckProof::prove_quad_prod (sumcheck.rs:199-249)
+  template <class Transcript>
+  static SumcheckProof prove_quad_prod(const Scalar& claim, size_t num_rounds, const std::vector<Scalar>& A, const std::vector<Scalar>& B,
+                                       Transcript& tr, bool mont = false) {
+    if (A.size() != (size_t)1 << num_rounds || B.size() != A.size()) throw std::invalid_argument("tables must hold 2^num_rounds elements");
+    std::vector<uint8_t> p(96 * num_rounds + 1), r(32 * num_rounds + 1), c(64);
+    check(nmx_sumcheck_prove_quad_prod(FIELD, claim.data(), num_rounds, const_cast<Scalar*>(A.data()), const_cast<Scalar*>(B.data()),
+                                       mont ? NMX_SCALARS_MONT : 0u, &detail::round_cb<Transcript>, &tr, p.data(), r.data(), c.data()));
+    return detail::unpack(num_rounds, 3, 2, p, r, c);
+  }
+  // SumcheckProof::prove_batch_eval (sumcheck.rs:251-353)
+  template <class Transcript>
+  static SumcheckProof prove_batch_eval(const std::vector<Scalar>& claims, const std::vector<std::vector<Scalar>>& polys,
+                                        const std::vector<std::vector<Scalar>>& eq_points, const std::vector<Scalar>& coeffs, Transcript& tr,
+                                        bool mont = false) {
+    const size_t k = polys.size();
+    if (claims.size() != k || eq_points.size() != k || coeffs.size() != k || k == 0) throw std::invalid_argument("one claim, point and coefficient per polynomial");
+    std::vector<size_t> nr(k);
+    std::vector<void*> pp(k);
+    std::vector<const void*> qp(k);
+    size_t nmax = 0;
+    for (size_t i = 0; i < k; i++) {
+      nr[i] = eq_points[i].size();
+      if (polys[i].size() != (size_t)1 << nr[i]) throw std::invalid_argument("poly size mismatch");
+      pp[i] = const_cast<Scalar*>(polys[i].data()), qp[i] = eq_points[i].data();
+      nmax = nr[i] > nmax ? nr[i] : nmax;
+    }
+    std::vector<uint8_t> p(96 * nmax + 1), r(32 * nmax + 1), f(32 * k);
+    check(nmx_sumcheck_prove_batch_eval(FIELD, claims.data(), nr.data(), pp.data(), qp.data(), coeffs.data(), k, mont ? NMX_SCALARS_MONT : 0u,
+                                        &detail::round_cb<Transcript>, &tr, p.data(), r.data(), f.data()));
+    return detail::unpack(nmax, 3, k, p, r, f);
+  }
+};
+}  // namespace spartan
 }  // namespace nova

@@ -2442,11 +2442,27 @@ int nmx_field_concat(int field, const void* const* parts, const size_t* lens, ui
 
 // Spartan's sum-check provers as one call each (sumcheck_prove.hpp)
 static void check_sc_args(int field, size_t num_rounds, uint32_t flags, nmx_transcript_fn cb) {
+  (void)flags;
   require(field >= 0 && field < 4, NMX_E_ARG, "bad field id");
   require(cb != nullptr, NMX_E_ARG, "null transcript callback");
   require(num_rounds < 31, NMX_E_TOO_LARGE, "too many rounds");
-  require(flags & NMX_SCALARS_DEVICE, NMX_E_ARG, "the sum-check provers work on HBM-resident tables (NMX_SCALARS_DEVICE)");
 }
+// Host tables (no NMX_SCALARS_DEVICE): the reference's `&mut MultilinearPolynomial` are host Vecs, consumed by the prover; they
+// are uploaded for the call (their host copies are left as they were) -- the form a shim starts with before it keeps vectors in HBM.
+struct ScStaged {
+  std::vector<void*> dev;
+  ~ScStaged() {
+    for (void* p : dev)
+      if (p) (void)hipFree(p);
+  }
+  void* up(Ctx& c, const void* host, size_t elems) {
+    void* d = nullptr;
+    HIPCHK(hipMalloc(&d, elems * 32 ? elems * 32 : 32));
+    dev.push_back(d);
+    HIPCHK(hipMemcpyAsync(d, host, elems * 32, hipMemcpyHostToDevice, c.stream));
+    return d;
+  }
+};
 int nmx_sumcheck_prove_cubic_with_three_inputs(int field, const void* claim, const void* taus, size_t num_rounds, void* A, void* B, void* C,
                                                uint32_t flags, nmx_transcript_fn transcript, void* ctx, uint8_t* out_polys, uint8_t* out_r,
                                                uint8_t* out_claims) {
@@ -2454,6 +2470,12 @@ int nmx_sumcheck_prove_cubic_with_three_inputs(int field, const void* claim, con
     check_sc_args(field, num_rounds, flags, transcript);
     require(claim && (taus || num_rounds == 0) && A && B && C, NMX_E_ARG, "null argument");
     CtxLease L;
+    ScStaged st;
+    if (!(flags & NMX_SCALARS_DEVICE)) {
+      const size_t n = (size_t)1 << num_rounds;
+      A = st.up(*L.c, A, n), B = st.up(*L.c, B, n), C = st.up(*L.c, C, n);
+      flags |= NMX_SCALARS_DEVICE;
+    }
     fv_sumcheck_prove(*L.c, field, 3, claim, taus, num_rounds, A, B, C, flags, transcript, ctx, out_polys, out_r, out_claims);
   });
 }
@@ -2463,6 +2485,12 @@ int nmx_sumcheck_prove_quad_prod(int field, const void* claim, size_t num_rounds
     check_sc_args(field, num_rounds, flags, transcript);
     require(claim && A && B, NMX_E_ARG, "null argument");
     CtxLease L;
+    ScStaged st;
+    if (!(flags & NMX_SCALARS_DEVICE)) {
+      const size_t n = (size_t)1 << num_rounds;
+      A = st.up(*L.c, A, n), B = st.up(*L.c, B, n);
+      flags |= NMX_SCALARS_DEVICE;
+    }
     fv_sumcheck_prove(*L.c, field, 4, claim, nullptr, num_rounds, A, B, nullptr, flags, transcript, ctx, out_polys, out_r, out_claims);
   });
 }
@@ -2472,8 +2500,15 @@ int nmx_sumcheck_prove_batch_eval(int field, const void* claims, const size_t* n
   return guarded([&] {
     check_sc_args(field, 0, flags, transcript);
     require(claims && num_rounds && polys && eq_points && coeffs && k >= 1, NMX_E_ARG, "null argument");
-    for (size_t i = 0; i < k; i++) require(polys[i] && eq_points[i], NMX_E_ARG, "null polynomial / evaluation point");
+    for (size_t i = 0; i < k; i++) require(polys[i] && eq_points[i] && num_rounds[i] < 31, NMX_E_ARG, "null polynomial / evaluation point");
     CtxLease L;
+    ScStaged st;
+    std::vector<void*> staged;
+    if (!(flags & NMX_SCALARS_DEVICE)) {
+      for (size_t i = 0; i < k; i++) staged.push_back(st.up(*L.c, polys[i], (size_t)1 << num_rounds[i]));
+      polys = staged.data();
+      flags |= NMX_SCALARS_DEVICE;
+    }
     fv_sumcheck_prove_batch(*L.c, field, (const uint8_t*)claims, num_rounds, polys, (const uint8_t* const*)eq_points, (const uint8_t*)coeffs, k,
                             flags, transcript, ctx, out_polys, out_r, out_finals);
   });

@@ -412,11 +412,11 @@ def sumcheck_prove_cubic_with_three_inputs(field, claim, taus, A, B, C, transcri
     pc, nc, _d2, _c = _vec(C)
     t = _host_u8(taus, 32)
     nr = t.size // 32
-    assert dev and n == nb == nc == (1 << nr)
+    assert n == nb == nc == (1 << nr) and dev == _d1 == _d2
     cl = _chal(claim)
     polys, r, out = np.zeros(128 * max(nr, 1), np.uint8), np.zeros(32 * max(nr, 1), np.uint8), np.zeros(96, np.uint8)
     cb = as_transcript(transcript)
-    _check(L.lib().nmx_sumcheck_prove_cubic_with_three_inputs(field, cl.ctypes.data, t.ctypes.data, nr, pa, pb, pc, _flags(True, mont),
+    _check(L.lib().nmx_sumcheck_prove_cubic_with_three_inputs(field, cl.ctypes.data, t.ctypes.data, nr, pa, pb, pc, _flags(dev, mont),
                                                              cb, ctx, polys.ctypes.data, r.ctypes.data, out.ctypes.data))
     return _rows(polys, nr, 4), [x[0] for x in _rows(r, nr, 1)], _rows(out, 1, 3)[0]
 
@@ -426,11 +426,11 @@ def sumcheck_prove_quad_prod(field, claim, num_rounds, A, B, transcript, mont=Fa
     pa, n, dev, _a = _vec(A)
     pb, nb, _d1, _b = _vec(B)
     nr = num_rounds
-    assert dev and n == nb == (1 << nr)
+    assert n == nb == (1 << nr) and dev == _d1
     cl = _chal(claim)
     polys, r, out = np.zeros(96 * max(nr, 1), np.uint8), np.zeros(32 * max(nr, 1), np.uint8), np.zeros(64, np.uint8)
     cb = as_transcript(transcript)
-    _check(L.lib().nmx_sumcheck_prove_quad_prod(field, cl.ctypes.data, nr, pa, pb, _flags(True, mont), cb, ctx, polys.ctypes.data,
+    _check(L.lib().nmx_sumcheck_prove_quad_prod(field, cl.ctypes.data, nr, pa, pb, _flags(dev, mont), cb, ctx, polys.ctypes.data,
                                                r.ctypes.data, out.ctypes.data))
     return _rows(polys, nr, 3), [x[0] for x in _rows(r, nr, 1)], _rows(out, 1, 2)[0]
 
@@ -441,7 +441,8 @@ def sumcheck_prove_batch_eval(field, claims, num_rounds, polys, eq_points, coeff
     import ctypes
     k = len(polys)
     parts = [_vec(p) for p in polys]
-    assert all(pt[2] for pt in parts) and all(pt[1] == (1 << nr) for pt, nr in zip(parts, num_rounds))
+    dev = parts[0][2]
+    assert all(pt[2] == dev for pt in parts) and all(pt[1] == (1 << nr) for pt, nr in zip(parts, num_rounds))
     nmax = max(num_rounds)
     pts = [_host_u8(x, 32) for x in eq_points]
     assert all(x.size // 32 == nr for x, nr in zip(pts, num_rounds))
@@ -452,6 +453,6 @@ def sumcheck_prove_batch_eval(field, claims, num_rounds, polys, eq_points, coeff
     co = _host_u8(b"".join(coeffs) if isinstance(coeffs, (list, tuple)) else coeffs, 32)
     out_p, r, fin = np.zeros(96 * nmax, np.uint8), np.zeros(32 * nmax, np.uint8), np.zeros(32 * k, np.uint8)
     cb = as_transcript(transcript)
-    _check(L.lib().nmx_sumcheck_prove_batch_eval(field, cl.ctypes.data, nrs, pp, qp, co.ctypes.data, k, _flags(True, mont), cb, ctx,
+    _check(L.lib().nmx_sumcheck_prove_batch_eval(field, cl.ctypes.data, nrs, pp, qp, co.ctypes.data, k, _flags(dev, mont), cb, ctx,
                                                 out_p.ctypes.data, r.ctypes.data, fin.ctypes.data))
     return _rows(out_p, nmax, 3), [x[0] for x in _rows(r, nmax, 1)], [x[0] for x in _rows(fin, k, 1)]

@@ -17,6 +17,117 @@ int ref_sequential_bases(int curve, const uint8_t* gen, uint64_t k0, size_t n, u
 }
 using namespace nova::provider;
 
+// ---- Spartan's sum-check provers through the C++ mirror (nova::spartan::Sumcheck) against the oracle's restatement -----------------
+extern "C" {
+typedef int (*ref_transcript_fn)(void* ctx, const uint8_t* coeffs, size_t n_coeffs, uint8_t* challenge32);
+int ref_sumcheck_prove_cubic3(int field, const uint8_t* claim, const uint8_t* taus, size_t nr, const uint8_t* A, const uint8_t* B, const uint8_t* C,
+                              ref_transcript_fn cb, void* ctx, uint8_t* out_polys, uint8_t* out_r, uint8_t* out_claims);
+int ref_sumcheck_prove_quad_prod(int field, const uint8_t* claim, size_t nr, const uint8_t* A, const uint8_t* B, ref_transcript_fn cb, void* ctx,
+                                 uint8_t* out_polys, uint8_t* out_r, uint8_t* out_claims);
+int ref_sumcheck_prove_batch_eval(int field, const uint8_t* claims, const size_t* num_rounds, const uint8_t* const* polys,
+                                  const uint8_t* const* eq_points, const uint8_t* coeffs, size_t k, ref_transcript_fn cb, void* ctx,
+                                  uint8_t* out_polys, uint8_t* out_r, uint8_t* out_finals);
+}
+// a stand-in transcript: chained 64-bit mixing of everything absorbed, 31 bytes out (< 2^248 < every modulus)
+struct Standin {
+  uint64_t s[4] = {1, 2, 3, 4};
+  static uint64_t mix(uint64_t x) {
+    x ^= x >> 30, x *= 0xbf58476d1ce4e5b9ull, x ^= x >> 27, x *= 0x94d049bb133111ebull, x ^= x >> 31;
+    return x;
+  }
+  Scalar round(const std::vector<Scalar>& co) {
+    for (const Scalar& c : co)
+      for (int i = 0; i < 32; i += 8) {
+        uint64_t w;
+        memcpy(&w, c.data() + i, 8);
+        s[(i / 8) & 3] = mix(s[(i / 8) & 3] ^ w) + s[(i / 8 + 1) & 3];
+      }
+    Scalar r;
+    for (int i = 0; i < 4; i++) {
+      s[i] = mix(s[i] + s[(i + 3) & 3] + 0x9e3779b97f4a7c15ull);
+      memcpy(r.data() + 8 * i, &s[i], 8);
+    }
+    r[31] = 0;
+    return r;
+  }
+};
+static int standin_cb(void* ctx, const uint8_t* coeffs, size_t n, uint8_t* out) {
+  std::vector<Scalar> co(n);
+  for (size_t i = 0; i < n; i++) memcpy(co[i].data(), coeffs + 32 * i, 32);
+  const Scalar r = static_cast<Standin*>(ctx)->round(co);
+  memcpy(out, r.data(), 32);
+  return 0;
+}
+template <int FIELD> static int run_sumcheck(int topmask) {
+  using SC = nova::spartan::Sumcheck<FIELD>;
+  std::mt19937_64 rng(11);
+  auto rand_vec = [&](size_t n) {
+    std::vector<Scalar> v(n);
+    for (auto& s : v) {
+      for (int i = 0; i < 32; i += 8) {
+        uint64_t w = rng();
+        memcpy(s.data() + i, &w, 8);
+      }
+      s[31] &= topmask;
+    }
+    return v;
+  };
+  auto same = [](const nova::spartan::SumcheckProof& p, size_t nco, const std::vector<uint8_t>& polys, const std::vector<uint8_t>& r,
+                 const std::vector<uint8_t>& cl) {
+    for (size_t j = 0; j < p.polys.size(); j++) {
+      for (size_t i = 0; i < nco; i++)
+        if (memcmp(p.polys[j][i].data(), polys.data() + 32 * (nco * j + i), 32)) return false;
+      if (memcmp(p.r[j].data(), r.data() + 32 * j, 32)) return false;
+    }
+    for (size_t i = 0; i < p.claims.size(); i++)
+      if (memcmp(p.claims[i].data(), cl.data() + 32 * i, 32)) return false;
+    return true;
+  };
+  for (size_t l : {1ul, 5ul, 11ul}) {
+    const size_t n = (size_t)1 << l;
+    const auto A = rand_vec(n), B = rand_vec(n), C = rand_vec(n), taus = rand_vec(l);
+    const Scalar claim = rand_vec(1)[0];  // any claim: the prover does not check it (the verifier would)
+    {
+      Standin t1, t2;
+      const auto got = SC::prove_cubic_with_three_inputs(claim, taus, A, B, C, t1);
+      std::vector<uint8_t> p(128 * l), r(32 * l), c(96);
+      if (ref_sumcheck_prove_cubic3(FIELD, claim.data(), taus[0].data(), l, A[0].data(), B[0].data(), C[0].data(), standin_cb, &t2, p.data(), r.data(), c.data())) return 1;
+      if (got.polys.size() != l || !same(got, 4, p, r, c)) return 1;
+    }
+    {
+      Standin t1, t2;
+      const auto got = SC::prove_quad_prod(claim, l, A, B, t1);
+      std::vector<uint8_t> p(96 * l), r(32 * l), c(64);
+      if (ref_sumcheck_prove_quad_prod(FIELD, claim.data(), l, A[0].data(), B[0].data(), standin_cb, &t2, p.data(), r.data(), c.data())) return 1;
+      if (!same(got, 3, p, r, c)) return 1;
+    }
+  }
+  {  // batch_eval over polynomials of different sizes (spartan/mod.rs:377-437: W and E)
+    const std::vector<std::vector<Scalar>> polys = {rand_vec(1 << 9), rand_vec(1 << 12), rand_vec(1 << 4)}, pts = {rand_vec(9), rand_vec(12), rand_vec(4)};
+    const auto claims = rand_vec(3), coeffs = rand_vec(3);
+    Standin t1, t2;
+    const auto got = SC::prove_batch_eval(claims, polys, pts, coeffs, t1);
+    const size_t nr[3] = {9, 12, 4};
+    const uint8_t* pp[3] = {polys[0][0].data(), polys[1][0].data(), polys[2][0].data()};
+    const uint8_t* qp[3] = {pts[0][0].data(), pts[1][0].data(), pts[2][0].data()};
+    std::vector<uint8_t> p(96 * 12), r(32 * 12), f(96);
+    if (ref_sumcheck_prove_batch_eval(FIELD, claims[0].data(), nr, pp, qp, coeffs[0].data(), 3, standin_cb, &t2, p.data(), r.data(), f.data())) return 1;
+    if (got.polys.size() != 12 || !same(got, 3, p, r, f)) return 1;
+  }
+  // a transcript that throws: the call fails (NMX_E_ARG), nothing crosses the C frame
+  struct Throws {
+    Scalar round(const std::vector<Scalar>&) { throw std::runtime_error("refused"); }
+  } bad;
+  try {
+    const auto A = rand_vec(16), B = rand_vec(16);
+    SC::prove_quad_prod(A[0], 4, A, B, bad);
+    return 1;
+  } catch (const Error& e) {
+    if (e.code != NMX_E_ARG) return 1;
+  }
+  return 0;
+}
+
 template <int CURVE> static int run(const uint8_t gen[64], int topmask) {
   const size_t n = 100;
   std::vector<Affine> bases(n + 1);
@@ -134,6 +245,8 @@ int main() {
   try {
     if (run<NMX_BN254_G1>(g_bn, 0x1f)) return 1;
     if (run<NMX_PALLAS>(g_pallas, 0x3f)) return 1;
+    if (run_sumcheck<NMX_F_BN254_FR>(0x1f)) return 1;
+    if (run_sumcheck<NMX_F_PASTA_FQ>(0x3f)) return 1;
   } catch (const Error& e) {
     fprintf(stderr, "%s\n", e.what());
     return e.code == NMX_E_NO_DEVICE ? 3 : 2;

@@ -62,6 +62,15 @@ def test_cubic_with_three_inputs_small(nmx, fid, l):
     both(sp.check_cubic3, g_cubic3(), o_cubic3, fid, l, seed=300 + l)
 
 
+def test_host_tables_are_uploaded_for_the_call(nmx):
+    """Without NMX_SCALARS_DEVICE the tables are host arrays, as the reference's `&mut MultilinearPolynomial` are: same proofs."""
+    from nova_amd import fieldvec as fv
+    both(sp.check_cubic3, lambda f, c, t, A, B, C, tr: fv.sumcheck_prove_cubic_with_three_inputs(f, c, t, A.copy(), B.copy(), C.copy(), tr), o_cubic3,
+         1, 11, seed=17, brute=False)
+    both(sp.check_batch_eval, lambda f, cl, nrs, P, X, co, tr: fv.sumcheck_prove_batch_eval(f, cl, nrs, [p.copy() for p in P], X, co, tr), o_batch,
+         1, [9, 12], seed=18)
+
+
 @pytest.mark.parametrize("l", [10, 11, 12, 13, 16])
 def test_cubic_with_three_inputs_across_the_kernel_forms(nmx, l):
     """l = 10: every round in one block; 11-13: the first rounds as pass + final sum (k_eq_rows with both eq tables, then the
@@ -134,12 +143,10 @@ def test_a_failing_transcript_aborts_the_proof(nmx):
         fv.sumcheck_prove_quad_prod(1, sp.le(5), 4, dev(A), dev(B), bad)
     with pytest.raises(nova_amd.NmxError):               # a challenge >= p: from_repr would reject it
         fv.sumcheck_prove_quad_prod(1, sp.le(5), 4, dev(A), dev(B), lambda c: b"\xff" * 32)
-    # host tables are not accepted: the provers work on HBM-resident tables (straight through the C ABI)
-    from nova_amd import _lib
-    cb = fv.as_transcript(lambda c: sp.le(1))
-    rc = _lib.lib().nmx_sumcheck_prove_quad_prod(1, np.frombuffer(sp.le(5), np.uint8).ctypes.data, 4, A.ctypes.data, B.ctypes.data, 0, cb,
-                                                None, None, None, None)
-    assert rc == _lib.E_ARG
+    # host tables are accepted too (uploaded for the call, the host copies left as they were)
+    keepA = A.copy()
+    got = fv.sumcheck_prove_quad_prod(1, sp.le(5), 4, A, B, lambda c: sp.le(7))
+    assert got == fv.sumcheck_prove_quad_prod(1, sp.le(5), 4, dev(A), dev(B), lambda c: sp.le(7)) and np.array_equal(A, keepA)
     # and the library still works afterwards
     both(sp.check_quad_prod, g_quad, o_quad, 1, 4, seed=1)
 
