@@ -83,7 +83,8 @@ enum {
   NMX_E_IO = -8,           /* key file cannot be opened / read (PtauFileError::IoError)                    */
   NMX_E_FORMAT = -9,       /* key file header rejected (InvalidHead, UnsupportedVersion, InvalidNumSections,
                               InvalidPrime, InsufficientPowerForG1/G2; ptau.rs:104-151)                    */
-  NMX_E_POINT = -10        /* a loaded point is not canonical or not on the curve (PointNotOnCurve)        */
+  NMX_E_POINT = -10,       /* a loaded point is not canonical or not on the curve (PointNotOnCurve)        */
+  NMX_E_ZERO = -11         /* nmx_field_batch_invert: an element is zero (NovaError::InternalError, spartan/mod.rs:103-105) */
 };
 
 /* ---- lifetime ------------------------------------------------------------------------------------- */
@@ -331,6 +332,11 @@ int nmx_field_cross_term2(int field, const void* az, const void* bz, const void*
                           const void* u, size_t n, uint32_t flags, void* out);
 /* out = a + b : Z = Z1 + Z2 (src/r1cs/mod.rs:590-609) */
 int nmx_field_vec_add(int field, const void* a, const void* b, size_t n, uint32_t flags, void* out);
+/* batch_invert (src/spartan/mod.rs:54-118; callers: ppsnark's lookup argument src/spartan/ppsnark.rs:430, IPA src/provider/
+ * ipa_pc.rs:328): out[i] = 1 / v[i].  NMX_E_ZERO when an element is zero (the reference returns Err(NovaError::InternalError)) --
+ * nothing meaningful is written then.  Montgomery's trick level by level on the device (strided 8..32-element chunks per lane), the
+ * top <= 128 products inverted on the host.  `out` must not overlap `v`. */
+int nmx_field_batch_invert(int field, const void* v, size_t n, uint32_t flags, void* out);
 /* out[n_out] = parts[0] || parts[1] || ... || 0 ... 0 for vectors that live in HBM: Spartan's `z = [W.W, vec![U.u], U.X].concat()`
  * then `z.resize(2 * num_vars, 0)` (src/spartan/snark.rs:133, 193-196), and -- with one part -- the clones batch_eval_reduce
  * takes of W and E before it binds them (src/spartan/mod.rs:407-410).  Bit i of device_mask: parts[i] is an HBM pointer (else a

@@ -19,7 +19,7 @@ PROF_STAGES = 12
  STAT_TABLE_FALLBACKS, STAT_LAUNCH_GAP_NS, STAT_SCAN_TIMEOUTS, STAT_COUNT) = range(16)
 DEVICES_OVERSUBSCRIBE = 1
 E_ARG, E_NO_DEVICE, E_HIP, E_SCALAR_RANGE, E_SMALL_RANGE, E_HANDLE, E_TOO_LARGE = -1, -2, -3, -4, -5, -6, -7
-E_IO, E_FORMAT, E_POINT = -8, -9, -10
+E_IO, E_FORMAT, E_POINT, E_ZERO = -8, -9, -10, -11
 BITS_AUTO = 0xFFFFFFFF
 
 # nmx_transcript_fn: (ctx, round polynomial coefficients, how many, challenge out) -> 0
@@ -107,6 +107,7 @@ def lib():
     L.nmx_mle_multi_evaluate.argtypes = [i, vp, sz, sz, vp, sz, u32, vp]
     L.nmx_spmv_apply_transposed.argtypes = [u64, vp, sz, u32, vp]
     L.nmx_field_concat.argtypes = [i, vp, vp, u64, sz, sz, u32, vp]
+    L.nmx_field_batch_invert.argtypes = [i, vp, sz, u32, vp]
     L.nmx_sumcheck_prove_cubic_with_three_inputs.argtypes = [i, vp, vp, sz, vp, vp, vp, u32, TRANSCRIPT_FN, vp, vp, vp, vp]
     L.nmx_sumcheck_prove_quad_prod.argtypes = [i, vp, sz, vp, vp, u32, TRANSCRIPT_FN, vp, vp, vp, vp]
     L.nmx_sumcheck_prove_batch_eval.argtypes = [i, vp, vp, vp, vp, vp, sz, u32, TRANSCRIPT_FN, vp, vp, vp, vp]

@@ -2404,6 +2404,21 @@ int nmx_spmv_apply_transposed(uint64_t handle, const void* x, size_t x_len, uint
   });
 }
 
+int nmx_field_batch_invert(int field, const void* v, size_t n, uint32_t flags, void* out) {
+  return guarded([&] {
+    require(field >= 0 && field < 4, NMX_E_ARG, "bad field id");
+    require((v && out) || n == 0, NMX_E_ARG, "null argument");
+    require(n < (1ull << 31), NMX_E_TOO_LARGE, "vector too long");
+    if (n == 0) return;
+    if (flags & NMX_SCALARS_DEVICE) {
+      const char *a = (const char*)v, *b = (const char*)out;
+      require(!(a < b + n * 32 && b < a + n * 32), NMX_E_ARG, "nmx_field_batch_invert cannot run in place (v and out overlap)");
+    }
+    CtxLease L;
+    if (!fv_batch_invert(*L.c, field, v, n, flags, out)) throw Fail{NMX_E_ZERO, "batch_invert: an element is zero (NovaError::InternalError)"};
+  });
+}
+
 // z = [W, u, X] zero-padded (snark.rs:133, 193-196) and the clones of batch_eval_reduce (spartan/mod.rs:407-410) for vectors that
 // live in HBM: copies on the library's stream, so that they are ordered with the kernels that read them
 int nmx_field_concat(int field, const void* const* parts, const size_t* lens, uint64_t device_mask, size_t k, size_t n_out, uint32_t flags,

@@ -15,6 +15,7 @@
 // R = 2^256 Montgomery limbs) with the challenge pre-scaled once on the host; only the product az*bz needs a
 // form-dependent constant.  Results stay in HBM so the next MSM (`NMX_SCALARS_DEVICE`) reads them in place.
 #include "runtime.hpp"
+#include "host_fp4.hpp"
 
 namespace nmx {
 
@@ -123,6 +124,49 @@ template <int FID> struct EqDirect2Fn {
     Fp<FID> acc = one;
     for (uint32_t i = 0; i < ell; i++) acc = acc * (((x >> (ell - 1 - i)) & 1u) ? r[o + i] : nr[o + i]);
     st<FID>(right ? outR : outL, x, acc);
+  }
+};
+
+// batch_invert (src/spartan/mod.rs:54-118: Montgomery's trick, chunked over threads there).  Here a lane owns the STRIDED chunk
+// {c, c + T, c + 2T, ...} of K elements (T = number of chunks: consecutive lanes touch consecutive elements), a forward pass
+// leaves every element's prefix product in `out` and the chunk products in a vector that is inverted the same way one level up
+// (the last level, <= 128 products, on the host: one extended-Euclid inversion), and a backward pass per level turns prefix
+// products into inverses.  All products are taken on the stored words as they are (canonical or Montgomery): the form factor is
+// a scale the top level applies once, and every lower level inherits it through the chunk inverses.
+// Cost: 3 products per element at level 0 (the trick's minimum) + 3/K of that above it -- VALU-bound for long vectors (2^24:
+// 52 ps per element = 3.1 products at the multiplier's ~58 G/s; the 160 B per element of traffic would take 20 ps), and a chain
+// of 3K DEPENDENT products per level for short ones, which is why K shrinks with the level's size (binv_chunk).
+static constexpr uint32_t kBinvHostBelow = 128;
+static inline uint32_t binv_chunk(size_t n) { return n >= (1u << 23) ? 32 : n >= (1u << 21) ? 16 : 8; }
+template <int FID> struct BatchInvFwdFn {
+  const uint32_t* v;
+  uint32_t *prefix, *chunk_prod;
+  uint32_t n, T, K;
+  NMX_HD void operator()(uint32_t c) const {
+    Fp<FID> acc = Fp<FID>::one();
+    for (uint32_t j = 0; j < K; j++) {
+      const uint64_t i = (uint64_t)c + (uint64_t)j * T;
+      if (i >= n) break;
+      st<FID>(prefix, i, acc);
+      acc = acc * ld<FID>(v, i);
+    }
+    st<FID>(chunk_prod, c, acc);
+  }
+};
+template <int FID> struct BatchInvBwdFn {
+  const uint32_t *v, *chunk_inv;
+  uint32_t* prefix;  // in: prefix products; out: the inverses
+  uint32_t n, T, K;
+  NMX_HD void operator()(uint32_t c) const {
+    Fp<FID> acc = ld<FID>(chunk_inv, c);
+    uint32_t cnt = 0;
+    while (cnt < K && (uint64_t)c + (uint64_t)cnt * T < n) cnt++;
+    for (uint32_t j = cnt; j-- > 0;) {
+      const uint64_t i = (uint64_t)c + (uint64_t)j * T;
+      const Fp<FID> p = ld<FID>(prefix, i), w = ld<FID>(v, i);
+      st<FID>(prefix, i, acc * p);
+      acc = (acc * w).canon();
+    }
   }
 };
 
@@ -1227,6 +1271,85 @@ static void nifs_fold_t(Ctx& c, const void* w1, const void* w2, size_t n_w, cons
   timed_launch(c, f, n_w + n_e, &io);
 }
 
+// returns false when an element is zero (the reference: Err(NovaError::InternalError), spartan/mod.rs:103-105)
+template <int FID> static bool batch_invert_t(Ctx& c, const void* v, size_t n, uint32_t flags, void* out) {
+  using F = Fp<FID>;
+  using H = HostFp4<FID>;
+  const bool mont = flags & NMX_SCALARS_MONT, dev = flags & NMX_SCALARS_DEVICE;
+  auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  // level sizes: n, ceil(n / K(n)), ... down to at most kBinvHostBelow
+  std::vector<size_t> sz{n};
+  while (sz.back() > kBinvHostBelow) sz.push_back((sz.back() + binv_chunk(sz.back()) - 1) / binv_chunk(sz.back()));
+  const size_t L = sz.size() - 1;  // device levels 0 .. L - 1; level L on the host
+  size_t need = 256;
+  if (!dev) need += 2 * pad(n * 32);
+  for (size_t l = 1; l <= L; l++) need += 2 * pad(sz[l] * 32);  // products (= the level's input) and prefix / inverse arrays
+  arena_reserve(c, need);
+  size_t used = 0;
+  auto take = [&](size_t bytes) {
+    char* d = c.arena + used;
+    used += pad(bytes);
+    return (uint32_t*)d;
+  };
+  std::vector<const uint32_t*> in(L + 1);
+  std::vector<uint32_t*> res(L + 1);
+  if (dev) {
+    in[0] = (const uint32_t*)v, res[0] = (uint32_t*)out;
+  } else {
+    uint32_t* d = take(n * 32);
+    HIPCHK(hipMemcpyAsync(d, v, n * 32, hipMemcpyHostToDevice, c.stream));
+    in[0] = d, res[0] = take(n * 32);
+  }
+  for (size_t l = 1; l <= L; l++) {
+    uint32_t* prod = take(sz[l] * 32);
+    in[l] = prod, res[l] = take(sz[l] * 32);
+  }
+  const bool prof = G.profiling;
+  DeviceBackend be(c, false, prof);
+  be.mark("kernel");
+  for (size_t l = 0; l < L; l++) {
+    BatchInvFwdFn<FID> f{in[l], res[l], (uint32_t*)in[l + 1], (uint32_t)sz[l], (uint32_t)sz[l + 1], binv_chunk(sz[l])};
+    be.launch(f, (uint32_t)sz[l + 1]);
+  }
+  // top level on the host: out = Fm^2 / Y for every word Y (Fm = 1 or 2^256: the words' form; see the kernels' header)
+  const size_t nt = sz[L];
+  if (!c.pinned) HIPCHK(hipHostMalloc((void**)&c.pinned, DeviceBackend::kPinnedBytes, hipHostMallocDefault));
+  static_assert(2 * kBinvHostBelow * 32 <= DeviceBackend::kPinnedBytes, "the host level lives in the context's pinned buffer");
+  uint32_t *top = (uint32_t*)c.pinned, *topinv = top + 8 * kBinvHostBelow;
+  HIPCHK(hipMemcpyAsync(top, in[L], nt * 32, hipMemcpyDeviceToHost, c.stream));
+  stream_wait(c.stream);
+  {
+    std::vector<H> e(nt), pre(nt);
+    H acc = H::one();
+    for (size_t i = 0; i < nt; i++) {
+      if (!F::words_lt_p(top + 8 * i)) throw Fail{NMX_E_SCALAR_RANGE, "batch_invert: element >= field modulus"};
+      e[i] = H::from_canonical(top + 8 * i);  // the word as a plain value
+      pre[i] = acc;
+      acc = acc * e[i];
+    }
+    if (acc.is_zero()) return false;
+    H inv = acc.inv() * (mont ? H::pow2(512) : H::one());
+    for (size_t i = nt; i-- > 0;) {
+      (inv * pre[i]).to_canonical(topinv + 8 * i);
+      inv = inv * e[i];
+    }
+  }
+  HIPCHK(hipMemcpyAsync(res[L], topinv, nt * 32, hipMemcpyHostToDevice, c.stream));
+  for (size_t l = L; l-- > 0;) {
+    BatchInvBwdFn<FID> f{in[l], res[l + 1], res[l], (uint32_t)sz[l], (uint32_t)sz[l + 1], binv_chunk(sz[l])};
+    be.launch(f, (uint32_t)sz[l + 1]);
+  }
+  be.mark("end");
+  if (!dev) HIPCHK(hipMemcpyAsync(out, res[0], n * 32, hipMemcpyDeviceToHost, c.stream));
+  stream_wait(c.stream);
+  if (prof && be.nmarks == 2) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
+    prof_store(&ms, 1);
+  }
+  return true;
+}
+
 template <int FID>
 static void lincomb_t(Ctx& c, const void* const* vecs, const size_t* lens, size_t k, const void* s, size_t n_out,
                       uint32_t flags, void* out) {
@@ -1592,6 +1715,15 @@ void fv_nifs_fold(Ctx& c, int field, const void* w1, const void* w2, size_t n_w,
     case 1: nifs_fold_t<1>(c, w1, w2, n_w, e1, t, n_e, r, flags, w, e); break;
     case 2: nifs_fold_t<2>(c, w1, w2, n_w, e1, t, n_e, r, flags, w, e); break;
     case 3: nifs_fold_t<3>(c, w1, w2, n_w, e1, t, n_e, r, flags, w, e); break;
+    default: throw Fail{NMX_E_ARG, "bad field id"};
+  }
+}
+bool fv_batch_invert(Ctx& c, int field, const void* v, size_t n, uint32_t flags, void* out) {
+  switch (field) {
+    case 0: return batch_invert_t<0>(c, v, n, flags, out);
+    case 1: return batch_invert_t<1>(c, v, n, flags, out);
+    case 2: return batch_invert_t<2>(c, v, n, flags, out);
+    case 3: return batch_invert_t<3>(c, v, n, flags, out);
     default: throw Fail{NMX_E_ARG, "bad field id"};
   }
 }

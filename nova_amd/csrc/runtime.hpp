@@ -703,6 +703,7 @@ void fv_spmv_apply(Ctx&, int field, const uint32_t* indptr, const uint32_t* indi
                    size_t cols, const void* z, uint32_t flags, void* out);
 void fv_spmv_apply_pair(Ctx&, int field, const uint32_t* indptr, const uint32_t* indices, const uint32_t* data,
                         size_t rows, size_t cols, const void* z1, const void* z2, uint32_t flags, void* out1, void* out2);
+bool fv_batch_invert(Ctx&, int field, const void* v, size_t n, uint32_t flags, void* out);  // false: an element is zero
 void fv_lincomb(Ctx&, int field, const void* const* vecs, const size_t* lens, size_t k, const void* s, size_t n_out,
                 uint32_t flags, void* out);
 void fv_plain_sums(Ctx&, int field, int kind, const void* A, const void* B, const void* C, size_t len, uint32_t flags,

@@ -108,6 +108,14 @@ def vec_add(field, a, b, mont=False, async_=False):
     return out
 
 
+def batch_invert(field, v, mont=False):
+    """batch_invert (src/spartan/mod.rs:54-118): element-wise inverses; NmxError(E_ZERO) when an element is zero."""
+    pv, n, dev, _kv = _vec(v)
+    po, out = _out_like(dev, n, v)
+    _check(L.lib().nmx_field_batch_invert(field, pv, n, _flags(dev, mont), po))
+    return out
+
+
 def concat(field, parts, n_out=None, async_=False):
     """nmx_field_concat: an HBM-resident vector = the parts (CUDA tensors or host arrays) one after the other, zero-padded to n_out.
     Spartan's z = [W, u, X] (src/spartan/snark.rs:133, 193-196); with one part, a clone ordered on the library's stream."""

@@ -58,6 +58,7 @@ def lib():
         L.ref_lincomb_powers.argtypes = [ctypes.c_int, vp, vp, sz, vp, sz, vp]
         L.ref_mle_multi_evaluate.argtypes = [ctypes.c_int, vp, sz, sz, vp, vp]
         L.ref_spmv_transposed.argtypes = [ctypes.c_int, vp, vp, vp, sz, sz, vp, vp]
+        L.ref_batch_invert.argtypes = [ctypes.c_int, vp, sz, vp]
         L.ref_sumcheck_prove_cubic3.argtypes = [ctypes.c_int, vp, vp, sz, vp, vp, vp, TRANSCRIPT_FN, vp, vp, vp, vp]
         L.ref_sumcheck_prove_quad_prod.argtypes = [ctypes.c_int, vp, sz, vp, vp, TRANSCRIPT_FN, vp, vp, vp, vp]
         L.ref_sumcheck_prove_batch_eval.argtypes = [ctypes.c_int, vp, vp, vp, vp, vp, sz, TRANSCRIPT_FN, vp, vp, vp, vp]
@@ -383,3 +384,12 @@ def sumcheck_prove_batch_eval(fid, claims, num_rounds, polys, eq_points, coeffs,
     pb, rb, fb = out_p.tobytes(), r.tobytes(), fin.tobytes()
     return ([[pb[96 * j + 32 * i: 96 * j + 32 * i + 32] for i in range(3)] for j in range(nmax)],
             [rb[32 * j: 32 * j + 32] for j in range(nmax)], [fb[32 * i: 32 * i + 32] for i in range(k)])
+
+
+def batch_invert(fid, v, n):
+    """batch_invert (src/spartan/mod.rs:54-152): bytes of the inverses, or None when an element is zero (the reference's Err)."""
+    pv, _v = _buf(v)
+    out = np.zeros(32 * max(n, 1), dtype=np.uint8)
+    rc = lib().ref_batch_invert(fid, pv, n, out.ctypes.data)
+    assert rc in (0, 1)
+    return None if rc else out[: 32 * n].tobytes()

@@ -1283,3 +1283,21 @@ int ref_sumcheck_prove_batch_eval(int field, const uint8_t* claims, const size_t
   free(P); free(Q); free(len); free(cl); free(run); free(co); free(ev);
   return rc;
 }
+
+/* batch_invert_serial (src/spartan/mod.rs:120-152; batch_invert :54-118 is the same trick chunked over threads): Montgomery's trick;
+ * returns 1 when an element is zero (Err(NovaError::InternalError)), canonical in / out */
+int ref_batch_invert(int field, const uint8_t* v, size_t n, uint8_t* out) {
+  const field_t* F = field_by_id(field); if (!F) return -1;
+  fe* x = load_vec_mont(F, v, n);
+  fe* products = (fe*)malloc((n ? n : 1) * sizeof(fe));
+  fe acc = F->r1;
+  for (size_t i = 0; i < n; i++) { products[i] = acc; fe_mul(F, &acc, &acc, &x[i]); }
+  if (fe_is_zero(&acc)) { free(x); free(products); return 1; }
+  fe inv; fe_inv(F, &inv, &acc);
+  for (size_t i = n; i-- > 0;) {
+    fe t; fe_mul(F, &t, &products[i], &inv); fe_mul(F, &inv, &inv, &x[i]);
+    st_canon(F, out + 32 * i, &t);
+  }
+  free(x); free(products);
+  return 0;
+}

@@ -143,3 +143,19 @@ def test_oracle_multi_evaluate_known_values():
         assert [int.from_bytes(g, "little") for g in got] == [2, 5]
         got = cref.mle_multi_evaluate(fid, [z1.tobytes(), z2.tobytes()], 3, C.vec([2, 3, 4]))
         assert [int.from_bytes(g, "little") for g in got] == [20, 5]
+
+
+def test_batch_invert_oracle():
+    """batch_invert (src/spartan/mod.rs:54-152) restated in the oracle: x * x^-1 = 1 against Python integers, zero -> the reference's Err."""
+    from oracle import cref
+    for fid, p in C.FIELDS.items():
+        for n in (1, 2, 100, 5000):
+            v = C.edge_vectors(fid, n, 40 + n)
+            vi = C.ints(v)
+            if 0 in vi:
+                assert cref.batch_invert(fid, v, n) is None
+                v = C.vec([x if x else 7 for x in vi])
+                vi = C.ints(v)
+            got = C.ints(bytearray(cref.batch_invert(fid, v, n)))
+            assert got == [pow(x, -1, p) for x in vi]
+        assert cref.batch_invert(fid, C.vec([3, 0, 5]), 3) is None

@@ -583,3 +583,64 @@ def test_async_nifs_chain_is_ordered_before_the_commitment(nmx, k):
     finally:
         assert nmx.init_devices(1) == 1
         assert L.nmx_set_option(b"shard_min_n", 1 << 20) == 0
+
+
+def _nonzero(fid, n, seed):
+    v = C.edge_vectors(fid, n, seed)
+    return C.vec([x if x else 5 for x in C.ints(v)]).copy()
+
+
+@pytest.mark.parametrize("fid", range(4))
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 128, 129, 1000, 1025, 4096, 4097, 131073, 300001, (1 << 21) + 5])
+def test_batch_invert_vs_oracle(nmx, fid, n):
+    """batch_invert (src/spartan/mod.rs:54-152): host and HBM-resident vectors, every level count (n <= 128 is the host level alone;
+    ragged last chunks; 2^21 + 5 starts with 16-element chunks and continues with 8-element ones)."""
+    import torch
+    from nova_amd import fieldvec as fv
+    v = _nonzero(fid, n, 70 + n % 13)
+    want = cref.batch_invert(fid, v, n)
+    assert fv.batch_invert(fid, v).tobytes() == want
+    dv = torch.from_numpy(v.copy()).cuda()
+    got = fv.batch_invert(fid, dv)
+    assert got.is_cuda and got.cpu().numpy().tobytes() == want
+    assert dv.cpu().numpy().tobytes() == v.tobytes()  # the input is left alone
+
+
+@pytest.mark.parametrize("fid", [1, 3])
+@pytest.mark.parametrize("n", [100, 5000])
+def test_batch_invert_montgomery_layout(nmx, fid, n):
+    from nova_amd import fieldvec as fv
+    p = C.FIELDS[fid]
+    Rm = 1 << 256
+    v = _nonzero(fid, n, 3)
+    vm = C.vec([x * Rm % p for x in C.ints(v)])
+    got = fv.batch_invert(fid, vm, mont=True)
+    assert [x * pow(Rm, -1, p) % p for x in C.ints(got)] == C.ints(bytearray(cref.batch_invert(fid, v, n)))
+
+
+@pytest.mark.parametrize("n,at", [(1, 0), (77, 76), (129, 0), (5000, 4999), (200000, 123457)])
+def test_batch_invert_reports_a_zero_element(nmx, n, at):
+    """the reference returns Err(NovaError::InternalError) when any element is zero (spartan/mod.rs:103-105)"""
+    import torch
+    from nova_amd import NmxError
+    from nova_amd import _lib as L
+    from nova_amd import fieldvec as fv
+    v = _nonzero(1, n, 11)
+    v[at] = 0
+    assert cref.batch_invert(1, v, n) is None
+    for operand in (v, torch.from_numpy(v.copy()).cuda()):
+        with pytest.raises(NmxError) as e:
+            fv.batch_invert(1, operand)
+        assert e.value.code == L.E_ZERO
+    # and the library is usable afterwards
+    v[at] = 9
+    assert fv.batch_invert(1, v).tobytes() == cref.batch_invert(1, v, n)
+
+
+def test_batch_invert_rejects_in_place(nmx):
+    import torch
+    from nova_amd import _lib as L
+    from nova_amd import fieldvec as fv
+    v = torch.from_numpy(_nonzero(1, 64, 1).copy()).cuda()
+    rc = L.lib().nmx_field_batch_invert(1, v.data_ptr(), 64, L.SCALARS_DEVICE, v.data_ptr())
+    assert rc == L.E_ARG
