@@ -278,6 +278,22 @@ int nmx_msm_u64_batch_handle(uint64_t handle, const uint64_t* const* scalar_vecs
  * flags as bases / scalars and are host pointers. */
 int nmx_commit(uint64_t ck_handle, const void* v, size_t n, const void* h_xy64, const void* r,
                uint32_t flags, uint8_t* out, uint8_t* out_is_inf);
+/* A commitment that runs beside the caller's next calls.  The two MSMs of a folding step do not depend on each other:
+ * commit_T reads W2 and X, never comm_W (src/r1cs/mod.rs:590-622), and the RO that absorbed comm_W (src/nova/nifs.rs:53) is
+ * squeezed only behind comm_T (:60-63).  So `W.commit(ck)` (src/frontend/r1cs.rs:47) can be BEGUN, `S.commit_T(..)` computed,
+ * and comm_W collected before `U2.absorb_in_ro` -- on the reference side a `rayon::join`, here two calls.  Each MSM ends in a
+ * latency-bound tail (fold passes, reduce tree) that leaves most of the chip idle; side by side one's tail hides under the
+ * other's accumulation (prove_step replay, bench.py --overlap-commits: 1.41 -> 1.1-1.2 ms).
+ *   nmx_commit_begin   same arguments as nmx_commit; h_xy64 and r are copied, `v` must stay valid and unchanged until the
+ *                      ticket is finished.  The commitment is ordered behind the calling thread's NMX_ASYNC calls like a
+ *                      synchronous one would be, and runs on its own context and stream.
+ *   nmx_commit_finish  waits, writes out[64] (128 with NMX_OUT_PARTIAL) / out_is_inf and retires the ticket.  Whatever the
+ *                      commitment failed with is reported HERE (code and nmx_last_error); an unknown or already finished ticket
+ *                      is NMX_E_HANDLE.  Every ticket must be finished (nmx_shutdown waits for the ones that were not and drops
+ *                      their results).  nmx_profile_last does not describe these calls. */
+int nmx_commit_begin(uint64_t ck_handle, const void* v, size_t n, const void* h_xy64, const void* r, uint32_t flags,
+                     uint64_t* ticket);
+int nmx_commit_finish(uint64_t ticket, uint8_t* out, uint8_t* out_is_inf);
 
 /* ---- shard-resident vectors (multi-device keys) ----------------------------
  * A field vector laid out like the key it will be committed against: element i lives in the HBM of the device that holds

@@ -185,6 +185,37 @@ template <int CURVE> struct CommitmentEngine {
     p.is_inf = inf != 0;
     return p;
   }
+  // The same commitment begun now and collected later (nmx_commit_begin / nmx_commit_finish): `W.commit(ck)` beside the cross
+  // term + commit(T) that does not read it (src/r1cs/mod.rs:590-622, src/nova/nifs.rs:53-63).  `v` must outlive finish().
+  class Pending {
+    uint64_t ticket_ = 0;
+
+   public:
+    explicit Pending(uint64_t t) : ticket_(t) {}
+    Pending(Pending&& o) noexcept : ticket_(o.ticket_) { o.ticket_ = 0; }
+    Pending(const Pending&) = delete;
+    Pending& operator=(const Pending&) = delete;
+    ~Pending() {  // never leave a ticket behind: wait, drop the result
+      uint8_t xy[128], inf;
+      if (ticket_) (void)nmx_commit_finish(ticket_, xy, &inf);
+    }
+    Point finish() {
+      Point p;
+      uint8_t inf = 0;
+      const uint64_t t = ticket_;
+      ticket_ = 0;
+      check(nmx_commit_finish(t, p.xy.data(), &inf));
+      p.is_inf = inf != 0;
+      return p;
+    }
+  };
+  static Pending commit_begin(const CommitmentKey& ck, const std::vector<Scalar>& v, const Scalar& r, bool mont = false) {
+    if (ck.len() < v.size()) throw std::invalid_argument("assert!(ck.ck.len() >= v.len())");
+    uint64_t t = 0;
+    uint32_t flags = (mont ? NMX_SCALARS_MONT : 0u) | (ck.mont() ? NMX_BASES_MONT : 0u);
+    check(nmx_commit_begin(ck.handle(), v.data(), v.size(), ck.h().data(), r.data(), flags, &t));
+    return Pending(t);
+  }
   // hyperkzg.rs:593-612 with r_i = 0 (the HyperKZG prover's use)
   static std::vector<Point> batch_commit(const CommitmentKey& ck, const std::vector<std::vector<Scalar>>& v) {
     return DlogGroupExt<CURVE>::batch_vartime_multiscalar_mul(v, ck);

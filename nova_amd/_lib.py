@@ -73,6 +73,8 @@ def lib():
     L.nmx_msm_u64_batch.argtypes = [i, vp, vp, sz, vp, sz, u32, u32, vp, vp]
     L.nmx_msm_u64_batch_handle.argtypes = [u64, vp, vp, sz, u32, u32, vp, vp]
     L.nmx_commit.argtypes = [u64, vp, sz, vp, vp, u32, vp, vp]
+    L.nmx_commit_begin.argtypes = [u64, vp, sz, vp, vp, u32, ctypes.POINTER(ctypes.c_uint64)]
+    L.nmx_commit_finish.argtypes = [u64, vp, vp]
     L.nmx_point_sum.argtypes = [i, vp, sz, vp, vp]
     L.nmx_svec_alloc.argtypes = [sz, sz, ctypes.POINTER(u64)]
     L.nmx_svec_free.argtypes = [u64]

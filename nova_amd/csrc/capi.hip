@@ -1252,8 +1252,10 @@ int nmx_init(int device) {
   });
 }
 
+static void drain_pending_commits();  // nmx_commit_begin's tickets (below): shutdown waits for the commitments in flight
 int nmx_shutdown(void) {
   return guarded([&] {
+    drain_pending_commits();
     std::lock_guard<std::mutex> lk(G.mu);
     if (!G.inited) return;
     (void)hipSetDevice(G.device);
@@ -1820,10 +1822,9 @@ int nmx_msm_u64_batch(int curve, const uint64_t* const* scalar_vecs, const size_
   });
 }
 
-static void commit_impl(const BaseSet& bs, MsmCall mc, size_t n, const void* h_xy64, const void* r, uint32_t flags, uint8_t* out,
-                        uint8_t* out_is_inf) {
+static void commit_impl(CtxLease& L, const BaseSet& bs, MsmCall mc, size_t n, const void* h_xy64, const void* r, uint32_t flags,
+                        uint8_t* out, uint8_t* out_is_inf) {
   require(n <= bs.n, NMX_E_HANDLE, "ck shorter than v");  // assert!(ck.ck.len() >= v.len()), pedersen.rs:264
-  CtxLease L;
   stat_add(NMX_STAT_MSM_CALLS);
   const CurveOps& o = ops(bs.curve);
   if (bs.parts.empty()) {
@@ -1857,7 +1858,78 @@ int nmx_commit(uint64_t ck_handle, const void* v, size_t n, const void* h_xy64, 
   return guarded([&] {
     require(out && (v || n == 0) && h_xy64 && r, NMX_E_ARG, "null argument");
     auto bs = lookup(ck_handle);
-    commit_impl(*bs, field_call(v, flags), n, h_xy64, r, flags, out, out_is_inf);
+    CtxLease L;
+    commit_impl(L, *bs, field_call(v, flags), n, h_xy64, r, flags, out, out_is_inf);
+  });
+}
+
+// nmx_commit_begin / nmx_commit_finish: a commitment that runs BESIDE the caller's next calls.  The two MSMs of a folding step do
+// not depend on each other -- commit_T reads W2 and X, never comm_W (src/r1cs/mod.rs:590-622); the RO absorbs comm_W
+// (nifs.rs:53) but is squeezed only behind comm_T (:60-63) -- and each of them ends in a latency-bound tail (fold, reduce tree)
+// that leaves the chip idle: side by side, one's tail hides under the other's accumulation.  The commitment runs on a pool
+// worker with a context leased HERE (so its stream is ordered behind this thread's asynchronous calls, like any other call).
+struct PendingCommit {
+  struct Res {
+    std::array<uint8_t, 128> out{};
+    uint8_t inf = 0;
+  };
+  PoolFuture<Res> fut;
+  uint32_t flags = 0;
+};
+static std::mutex g_pend_mu;
+static std::unordered_map<uint64_t, std::shared_ptr<PendingCommit>>& pending_commits() {
+  static auto* m = new std::unordered_map<uint64_t, std::shared_ptr<PendingCommit>>();
+  return *m;
+}
+static uint64_t g_next_ticket = 1;
+static void drain_pending_commits() {
+  std::unordered_map<uint64_t, std::shared_ptr<PendingCommit>> gone;
+  {
+    std::lock_guard<std::mutex> lk(g_pend_mu);
+    gone.swap(pending_commits());
+  }
+  gone.clear();  // ~PoolFuture waits; results and errors of unfinished tickets are dropped
+}
+int nmx_commit_begin(uint64_t ck_handle, const void* v, size_t n, const void* h_xy64, const void* r, uint32_t flags, uint64_t* ticket) {
+  return guarded([&] {
+    require(ticket && (v || n == 0) && h_xy64 && r, NMX_E_ARG, "null argument");
+    BaseRef bs = lookup(ck_handle);
+    require(n <= bs->n, NMX_E_HANDLE, "ck shorter than v");
+    std::array<uint8_t, 64> hb;
+    std::array<uint8_t, 32> rb;
+    memcpy(hb.data(), h_xy64, 64);
+    memcpy(rb.data(), r, 32);
+    const MsmCall mc = field_call(v, flags);
+    auto lease = std::make_shared<CtxLease>();  // on the calling thread: behind its stream-ordered calls
+    auto pc = std::make_shared<PendingCommit>();
+    pc->flags = flags;
+    pc->fut = PoolFuture<PendingCommit::Res>([bs, mc, n, hb, rb, flags, lease]() mutable {
+      std::shared_ptr<CtxLease> L = std::move(lease);  // handed back when the job ends, whatever happens
+      HIPCHK(hipSetDevice(hip_device_of(L->c->dev)));  // (the device is per host thread)
+      PendingCommit::Res res;
+      commit_impl(*L, *bs, mc, n, hb.data(), rb.data(), flags, res.out.data(), &res.inf);
+      return res;
+    });
+    std::lock_guard<std::mutex> lk(g_pend_mu);
+    const uint64_t t = g_next_ticket++;
+    pending_commits()[t] = std::move(pc);
+    *ticket = t;
+  });
+}
+int nmx_commit_finish(uint64_t ticket, uint8_t* out, uint8_t* out_is_inf) {
+  return guarded([&] {
+    std::shared_ptr<PendingCommit> pc;
+    {
+      std::lock_guard<std::mutex> lk(g_pend_mu);
+      auto it = pending_commits().find(ticket);
+      if (it == pending_commits().end()) throw Fail{NMX_E_HANDLE, "unknown commitment ticket"};
+      pc = std::move(it->second);
+      pending_commits().erase(it);
+    }
+    const PendingCommit::Res res = pc->fut.get();  // rethrows what the commitment threw: the error is reported HERE
+    require(out != nullptr, NMX_E_ARG, "null argument");
+    memcpy(out, res.out.data(), (pc->flags & NMX_OUT_PARTIAL) ? 128 : 64);
+    if (out_is_inf) *out_is_inf = res.inf;
   });
 }
 
@@ -1993,7 +2065,8 @@ int nmx_commit_svec(uint64_t ck_handle, uint64_t svec, size_t n, const void* h_x
     require(n <= bs->n, NMX_E_HANDLE, "ck shorter than v");
     const std::vector<const void*> ptrs = svec_pointers(*v, *bs, n);
     const uint32_t fl = (flags & ~(uint32_t)NMX_SCALARS_DEVICE) | NMX_SCALARS_SHARDED;
-    commit_impl(*bs, field_call(ptrs.data(), fl), n, h_xy64, r, fl, out, out_is_inf);
+    CtxLease L;
+    commit_impl(L, *bs, field_call(ptrs.data(), fl), n, h_xy64, r, fl, out, out_is_inf);
   });
 }
 int nmx_profile_last_sharded(float* ms, int* dev, int* branch, int cap, float* combine_ms, int* rccl_ranks) {

@@ -21,6 +21,23 @@ BN254_G1, GRUMPKIN, PALLAS, VESTA = 0, 1, 2, 3
 CURVE_NAMES = {0: "bn254_g1", 1: "grumpkin", 2: "pallas", 3: "vesta"}
 
 
+class PendingCommitment:
+    """ticket of CommitmentEngine.commit_begin"""
+
+    def __init__(self, ticket, partial, keep):
+        self.ticket, self.partial, self._keep = ticket, partial, keep
+
+    def finish(self):
+        assert self.ticket, "finished already"
+        out = _Out(partial=self.partial)
+        t, self.ticket = self.ticket, 0
+        try:
+            _check(L.lib().nmx_commit_finish(t, *out.p))
+        finally:
+            self._keep = None
+        return out.get()
+
+
 class NmxError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"nmx error {code}: {msg}")
@@ -389,6 +406,19 @@ class CommitmentEngine:
         out = _Out(partial=partial)
         _check(L.lib().nmx_commit(ck.handle, sp, n, hh.ctypes.data, rr.ctypes.data, flags, *out.p))
         return out.get()
+
+    def commit_begin(self, ck, v, r=None, mont=False, partial=False):
+        """nmx_commit_begin: the commitment runs beside the caller's next calls (commit(W) beside cross term + commit(T):
+        r1cs/mod.rs:590-622 never reads comm_W); .finish() returns what commit() would have.  v must stay alive and
+        unchanged until then (the object keeps a reference)."""
+        sp, n, dev, keep = _scalar_arg(v, 32)
+        assert len(ck) >= n, "assert!(ck.ck.len() >= v.len())"
+        rr = _host_u8(bytes(32) if r is None else r, 32)
+        hh = _host_u8(ck.h, 64)
+        flags = dev | (L.SCALARS_MONT if mont else 0) | (L.BASES_MONT if ck.mont else 0) | (L.OUT_PARTIAL if partial else 0)
+        t = ctypes.c_uint64(0)
+        _check(L.lib().nmx_commit_begin(ck.handle, sp, n, hh.ctypes.data, rr.ctypes.data, flags, ctypes.byref(t)))
+        return PendingCommitment(t.value, partial, (v, keep, ck))
 
     def batch_commit(self, ck, vs, rs=None, mont=False):
         """hyperkzg.rs:593-612: batch MSM over ck[..max len], then + h*r_i each."""

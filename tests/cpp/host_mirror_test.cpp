@@ -175,6 +175,12 @@ template <int CURVE> static int run(const uint8_t gen[64], int topmask) {
   ref_commit(CURVE, sc[0].data(), bases[0].data(), n, bases[n].data(), r.data(), exp.xy.data(), &inf);
   exp.is_inf = inf;
   if (!(got == exp)) return 1;
+  {  // the same commitment begun, another one computed beside it, then collected (nmx_commit_begin / nmx_commit_finish)
+    auto pending = CommitmentEngine<CURVE>::commit_begin(ck, sc, r);
+    if (!(CommitmentEngine<CURVE>::commit(ck, sc, r) == exp)) return 1;
+    if (!(pending.finish() == exp)) return 1;
+    auto dropped = CommitmentEngine<CURVE>::commit_begin(ck, sc, r);  // its destructor retires the ticket
+  }
   // ragged batch (blitzar.rs:185-213)
   std::vector<std::vector<Scalar>> vs;
   for (size_t L : {0ul, 1ul, 37ul, 100ul}) vs.emplace_back(sc.begin(), sc.begin() + L);
