@@ -106,3 +106,25 @@ def test_spmv_2p22_rows(nmx):
     e1, e2 = cref.spmv_pair(FID, indptr, indices, data, n, z, z2)
     assert o1.cpu().numpy().tobytes() == e1 and o2.cpu().numpy().tobytes() == e2
     mat.close()
+
+
+@pytest.mark.parametrize("log2n", [22, 24])
+def test_batch_invert_full_size(nmx, log2n):
+    """batch_invert (src/spartan/mod.rs:54-152) at 2^22 (full compare with the oracle: 16- and 8-element chunk levels) and 2^24 (32-element
+    first level): the involution inv(inv(v)) == v bit for bit, and every product v[i] * inv[i] == 1 through the cross-term kernel
+    (a o b - u c with b = the inverses, u = 1, c = the all-ones vector, e = 0 must be the zero vector)."""
+    import torch
+    from nova_amd import fieldvec as fv
+    n = (1 << log2n) - (3 if log2n == 22 else 0)            # a ragged last chunk at every level for 2^22 - 3
+    v = big_vec(log2n, 5)[:n]
+    v[v.reshape(n, 32).any(axis=1) == 0] = util.int_to_le32(7)   # (no zero element)
+    dv = torch.from_numpy(np.ascontiguousarray(v)).cuda()
+    inv = fv.batch_invert(FID, dv)
+    back = fv.batch_invert(FID, inv)
+    assert torch.equal(back, dv)
+    ones = torch.from_numpy(np.tile(np.frombuffer(util.int_to_le32(1), np.uint8), (n, 1))).cuda()
+    zero = torch.zeros_like(dv)
+    t = fv.cross_term(FID, dv, inv, ones, zero, util.int_to_le32(1))
+    assert not bool(t.any())
+    if log2n == 22:
+        assert inv.cpu().numpy().tobytes() == cref.batch_invert(FID, np.ascontiguousarray(v), n)
