@@ -410,7 +410,8 @@ int nmx_sumcheck_plain_sums(int field, int kind, const void* A, const void* B, c
  * elements, 0..8) the remaining rounds run on the HOST -- a few hundred field products take the host 1-8 us, any kernel round
  * trip 20-25 us; the last device bind lands the tables in pinned memory.  Option "sc_fused_sum" (default 1): a round is one
  * launch, the block that finishes last adds the per-block partials up; 0: pass + one-block sum.  Option "sc_poll_us": how long a round's mailbox is
- * polled before the stream is synchronised instead (default 2000; 0: always synchronise).
+ * polled before the stream is synchronised instead (default 2000; 0: always synchronise).  Option "sc_side_streams" (default 1): the
+ * claims of a prove_batch_eval round are independent passes and run on one stream each; 0: all on the call's stream.
  *  - nmx_sumcheck_prove_cubic_with_three_inputs == SumcheckProof::prove_cubic_with_three_inputs (sumcheck.rs:446-507) with its
  *    EqSumCheckInstance (sumcheck.rs:593-1253; all sqrt-size eq tables built by one launch): A, B, C of 2^num_rounds elements,
  *    taus = num_rounds elements (host), 4 coefficients per round, out_claims = [A(r), B(r), C(r)].  A tau of zero (or a

@@ -169,6 +169,7 @@ static void ensure_init() {
   if (const char* t = getenv("NMX_SC_POLL_US")) G.sc_poll_us = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_SC_HOST_TAIL")) G.sc_host_tail = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_SC_FUSED_SUM")) G.sc_fused_sum = (uint32_t)atoi(t);
+  if (const char* t = getenv("NMX_SC_SIDE_STREAMS")) G.sc_side_streams = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_HORNER_TOP")) G.horner_top = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_HORNER_SUB")) G.horner_sub = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_HORNER_ORDER")) G.horner_order = atoi(t) ? 1u : 0u;
@@ -1278,6 +1279,9 @@ int nmx_shutdown(void) {
       if (c->have_ev)
         for (int i = 0; i < kMaxMarks; i++) (void)hipEventDestroy(c->ev[i]);
       if (c->async_ev) (void)hipEventDestroy(c->async_ev);
+      if (c->side_ev) (void)hipEventDestroy(c->side_ev);
+      for (hipStream_t sd : c->side)
+        if (sd) (void)hipStreamDestroy(sd);
       if (c->stream) (void)hipStreamDestroy(c->stream);
       delete c;
     }
@@ -2706,6 +2710,7 @@ int nmx_set_option(const char* name, uint32_t value) {
       G.host_split = value;
     } else if (n == "host_split_min_n") G.host_split_min_n = value;
     else if (n == "sc_fused_sum") G.sc_fused_sum = value ? 1u : 0u;
+    else if (n == "sc_side_streams") G.sc_side_streams = value ? 1u : 0u;
     else if (n == "sc_host_tail") {
       require(value <= 8, NMX_E_ARG, "sc_host_tail: log2 of the table length the host takes over, 0..8");
       G.sc_host_tail = value;

@@ -75,6 +75,10 @@ struct Ctx {
   // into, sequence word last, and the host polls -- mail = host address, mail_dev = the same bytes as the device sees them
   char *mail = nullptr, *mail_dev = nullptr;
   uint32_t mail_seq = 0;
+  // side streams of the batch prover (sumcheck_prove.hpp): the claims of a round are independent passes, one stream each
+  static constexpr int kSideStreams = 15;
+  hipStream_t side[kSideStreams] = {};
+  hipEvent_t side_ev = nullptr;
   hipEvent_t ev[kMaxMarks];
   bool have_ev = false;
   hipEvent_t async_ev = nullptr;  // behind the last NMX_ASYNC call enqueued on this context
@@ -324,6 +328,7 @@ struct Global {
   std::atomic<uint32_t> host_split{255};           // option host_split: a call with HOST scalars over >= host_split_min_n pairs of a single-device key is cut into this many pieces whose uploads overlap the previous piece's MSM (0 / 1: off)
   std::atomic<size_t> host_split_min_n{(size_t)1 << 19};
   std::atomic<uint32_t> sc_fused_sum{1};          // option sc_fused_sum: 1 = a sum-check round is ONE launch (the last block sums the partials, k_sc_pass); 0 = pass + final-sum launch
+  std::atomic<uint32_t> sc_side_streams{1};       // option sc_side_streams: the batch prover runs claim i > 0 on its own stream (0: all on the context's)
   std::atomic<uint32_t> sc_host_tail{6};          // option sc_host_tail: the sum-check provers finish on the host once the tables hold <= 2^this elements (0: only the final values come over; max 8)
   std::atomic<uint32_t> sc_poll_us{2000};         // option sc_poll_us: the sum-check provers poll a round's mailbox this long before they synchronise the stream (0: always synchronise)
   std::atomic<uint32_t> sync_spin_us{0};          // env NMX_SYNC_SPIN_US / option sync_spin_us: poll the stream this long before blocking

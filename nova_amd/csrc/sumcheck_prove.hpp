@@ -405,11 +405,31 @@ template <int FID> struct ScDev {
       }
     }
     if (!ok) {
-      stream_wait(c.stream);
+      sync_all();
       require(__atomic_load_n(host, __ATOMIC_ACQUIRE) == seq, NMX_E_HIP, "sum-check: the round's result never reached its mailbox");
     }
     if (profiling) prof.wait += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return host + 8;
+  }
+  // the context's stream and the side streams the batch prover put work on
+  void sync_all() {
+    stream_wait(c.stream);
+    for (hipStream_t sd : c.side)
+      if (sd) HIPCHK(hipStreamSynchronize(sd));
+  }
+  void sync_all_quiet() noexcept {
+    (void)hipStreamSynchronize(c.stream);
+    for (hipStream_t sd : c.side)
+      if (sd) (void)hipStreamSynchronize(sd);
+  }
+  // side stream i (created on first use), ordered behind everything on the context's stream so far
+  hipStream_t side_stream(uint32_t i) {
+    require(i < (uint32_t)Ctx::kSideStreams, NMX_E_HIP, "sum-check: side stream out of range");
+    if (!c.side[i]) HIPCHK(hipStreamCreateWithFlags(&c.side[i], hipStreamNonBlocking));
+    if (!c.side_ev) HIPCHK(hipEventCreateWithFlags(&c.side_ev, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(c.side_ev, c.stream));
+    HIPCHK(hipStreamWaitEvent(c.side[i], c.side_ev, 0));
+    return c.side[i];
   }
   void launched(uint32_t n = 1) { prof.launches += n; }
   // the transcript step, timed
@@ -516,10 +536,11 @@ template <int FID, int MODE> struct ScPass {
   uint32_t *A, *B, *C;
   uint32_t* partial;  // device scratch of this instance (kScPartialBytes)
   uint32_t slot;      // mailbox slot of the sums; tail areas slot, slot + 1, slot + 2 take the tables
+  hipStream_t stream; // the context's, or a side stream (batch prover: one per claim)
   F nk;
   static constexpr uint32_t NT = MODE == 3 ? 3u : MODE == 4 ? 2u : 1u;
   ScPass(ScDev<FID>& h_, void* a, void* b, void* cc, uint32_t* partial_, uint32_t slot_)
-      : h(h_), A((uint32_t*)a), B((uint32_t*)b), C((uint32_t*)cc), partial(partial_), slot(slot_) {
+      : h(h_), A((uint32_t*)a), B((uint32_t*)b), C((uint32_t*)cc), partial(partial_), slot(slot_), stream(h_.c.stream) {
     F fconst = F::zero();
     if (MODE == 3) {
       if (h.mont) fconst = pow2_plain<FID>(256);
@@ -532,7 +553,7 @@ template <int FID, int MODE> struct ScPass {
   // sums only over tables of `len` elements (round 1, and the high-half sum of the fallback)
   uint32_t sums(const uint32_t* a, const uint32_t* b, const uint32_t* cc, size_t len, const Tables& t) {
     const uint32_t hh = (uint32_t)(len / 2), seq = h.next_seq();
-    hipStream_t s = h.c.stream;
+    hipStream_t s = stream;
     if (hh <= kScSmallHq) {
       ScSmallArgs<FID> x{a, b, cc, nullptr, nullptr, nullptr, t.eqL, t.eqR, F::zero(), nk, t.shift, t.mask, hh, 0u, seq, h.slot_dev(slot)};
       hipLaunchKernelGGL((k_sc_small<FID, MODE>), dim3(1), dim3(256), 0, s, x);
@@ -565,7 +586,7 @@ template <int FID, int MODE> struct ScPass {
   uint32_t bind_sums(size_t len, const H& rh, const Tables& t) {
     const uint32_t hq = (uint32_t)(len / 4), seq = h.next_seq();
     const F r = rh.to_device();
-    hipStream_t s = h.c.stream;
+    hipStream_t s = stream;
     if (hq <= kScSmallHq) {
       ScSmallArgs<FID> x{A, B, C, A, B, C, t.eqL, t.eqR, r, nk, t.shift, t.mask, hq, 1u, seq, h.slot_dev(slot)};
       hipLaunchKernelGGL((k_sc_small<FID, MODE>), dim3(1), dim3(256), 0, s, x);
@@ -600,7 +621,7 @@ template <int FID, int MODE> struct ScPass {
     for (uint32_t t = 0; t < 3; t++) a.X[t] = t < NT ? X[t] : nullptr, a.host[t] = t < NT ? h.tail_dev(slot + t) : nullptr;
     a.r = rp ? rp->to_device() : F::zero();
     a.n = NT, a.half = (uint32_t)half, a.bind = rp ? 1u : 0u, a.seq = h.next_seq(), a.slot = h.slot_dev(slot);
-    hipLaunchKernelGGL((k_sc_bind_to_host<FID>), dim3(1), dim3(256), 0, h.c.stream, a);
+    hipLaunchKernelGGL((k_sc_bind_to_host<FID>), dim3(1), dim3(256), 0, stream, a);
     HIPCHK(hipGetLastError());
     h.launched();
     (void)h.wait(slot, a.seq);
@@ -619,17 +640,17 @@ template <int FID, int MODE> struct ScPass {
     const uint32_t* src[3] = {A, B, C};
     try {
       for (uint32_t i = 0; i < NT; i++) {
-        HIPCHK(hipMemcpyAsync(tmp + (size_t)i * len * 32, (const char*)src[i] + hb, hb, hipMemcpyDeviceToDevice, h.c.stream));
-        HIPCHK(hipMemcpyAsync(tmp + (size_t)i * len * 32 + hb, src[i], hb, hipMemcpyDeviceToDevice, h.c.stream));
+        HIPCHK(hipMemcpyAsync(tmp + (size_t)i * len * 32, (const char*)src[i] + hb, hb, hipMemcpyDeviceToDevice, stream));
+        HIPCHK(hipMemcpyAsync(tmp + (size_t)i * len * 32 + hb, src[i], hb, hipMemcpyDeviceToDevice, stream));
       }
       const uint32_t* ta = (const uint32_t*)tmp;
       const uint32_t seq = sums(ta, NT > 1 ? ta + 8 * len : nullptr, NT > 2 ? ta + 16 * len : nullptr, len, t);
       const H v = h.raw(h.wait(slot, seq), factors(t));
-      stream_wait(h.c.stream);
+      stream_wait(stream);
       (void)hipFree(tmp);
       return v;
     } catch (...) {
-      (void)hipStreamSynchronize(h.c.stream);
+      (void)hipStreamSynchronize(stream);
       (void)hipFree(tmp);
       throw;
     }
@@ -778,8 +799,17 @@ static void sc_prove_batch_t(Ctx& c, const uint8_t* claims_b, const size_t* num_
         off += (ScEqDev<FID>::heap_bytes((uint32_t)num_rounds[i]) + 255) & ~(size_t)255;
       }
     }
-    sc_batch_rounds<FID>(h.alg, cs, dev, cb, cb_ctx, out_polys, out_r, out_finals, &h.prof.rounds);
-    stream_wait(c.stream);
+    // the claims of a round are independent passes over their own tables: claim i > 0 runs on side stream i - 1 (ordered behind
+    // the set-up above), so a round costs one pass's latency, not k of them
+    if (G.sc_side_streams.load(std::memory_order_relaxed))
+      for (size_t i = 1; i < k; i++) dev.pass[i].stream = h.side_stream((uint32_t)(i - 1));
+    try {
+      sc_batch_rounds<FID>(h.alg, cs, dev, cb, cb_ctx, out_polys, out_r, out_finals, &h.prof.rounds);
+    } catch (...) {
+      h.sync_all_quiet();  // nothing of this call may still be running on a side stream when the tables go back to the caller
+      throw;
+    }
+    h.sync_all();
     h.finish_profile(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count());
   } catch (const ScFail& f) {
     (void)hipStreamSynchronize(c.stream);

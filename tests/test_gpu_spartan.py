@@ -178,6 +178,24 @@ def test_one_launch_rounds_and_two_launch_rounds_agree(nmx):
         assert L.nmx_set_option(b"sc_fused_sum", 1) == 0
 
 
+def test_batch_claims_on_side_streams_and_on_one_stream_agree(nmx):
+    """option sc_side_streams: the claims of a batch round are independent passes -- claim i > 0 runs on its own stream (default) or
+    all of them queue on the context's.  Up to 16 claims of mixed sizes, the fallback rounds (which allocate and copy on the claim's
+    stream), repeated calls (the streams are kept), and a cubic proof right behind on the context's stream."""
+    from nova_amd import _lib
+    L = _lib.lib()
+    p = fc.FIELDS[1]
+    try:
+        for side in (1, 0, 1):
+            assert L.nmx_set_option(b"sc_side_streams", side) == 0
+            both(sp.check_batch_eval, g_batch, o_batch, 1, [15, 13, 16], seed=71)
+            both(sp.check_batch_eval, g_batch, o_batch, 1, [9, 3, 12, 1, 10, 10, 7, 2, 11, 5, 8, 4, 6, 12, 9, 13], seed=72)
+            both(sp.check_batch_eval, g_batch, o_batch, 1, [10, 12, 8], seed=73, force={0: 0, 3: 1, 7: p - 1, 11: 0})
+            both(sp.check_cubic3, g_cubic3(), o_cubic3, 1, 12, seed=74, brute=False)
+    finally:
+        assert L.nmx_set_option(b"sc_side_streams", 1) == 0
+
+
 @pytest.mark.parametrize("tail", [0, 1, 3, 6, 8])
 def test_every_host_tail_threshold_gives_the_same_proof(nmx, tail):
     """option sc_host_tail: tables of <= 2^tail elements finish on the host (sc_host.hpp; 0 = only the final values come over).  The
