@@ -87,8 +87,20 @@ template <int FID> struct ScAlg {
     uint32_t l = 0, first_half = 0, second_half = 0, round = 1;
     std::vector<H> taus, eq0, slope, eqm1;  // eq_tau_0_a_inf (sumcheck.rs:643-652): eq(tau, 0), 2 tau - 1, eq(tau, -1)
     H eval_eq_left;
+    // 1 / (l(1) p) of round `inv_round`, computed ahead of time by prepare(): the one inversion a round needs (~5-9 us on the
+    // host) then runs while the device is busy with the round's pass instead of behind it
+    mutable H l1p_inv;
+    mutable uint32_t inv_round = 0;
+    mutable bool l1p_zero = false;
+    void prepare() const {
+      if (round > l || inv_round == round) return;
+      const H l1p = taus[round - 1] * eval_eq_left;  // eq0 + slope = tau
+      l1p_zero = l1p.is_zero();
+      l1p_inv = l1p_zero ? H::zero() : l1p.inv();
+      inv_round = round;
+    }
     void init(const ScAlg& a, const uint8_t* taus_bytes, uint32_t l_) {
-      l = l_, first_half = l / 2, second_half = l - first_half, round = 1;
+      l = l_, first_half = l / 2, second_half = l - first_half, round = 1, inv_round = 0;
       taus.resize(l), eq0.resize(l), slope.resize(l), eqm1.resize(l);
       for (uint32_t i = 0; i < l; i++) {
         taus[i] = a.in(taus_bytes + 32 * (size_t)i);
@@ -103,12 +115,13 @@ template <int FID> struct ScAlg {
     // the fallback_eval_inf_* paths (sumcheck.rs:1085-1222)
     template <class TM1> void derive(const H& t0, const H& tinf, const H& claim, bool deg1, H& s0, H& lead, H& sm1, TM1&& t_m1) const {
       const H& p = eval_eq_left;
-      const H l0p = eq0[round - 1] * p, l1p = (eq0[round - 1] + slope[round - 1]) * p;
+      const H l0p = eq0[round - 1] * p;
       s0 = l0p * t0;
       lead = deg1 ? H::zero() : slope[round - 1] * p * tinf;
       H tm1;
-      if (!l1p.is_zero()) {
-        const H t1 = (claim - s0) * l1p.inv();
+      prepare();  // (a no-op when the caller prepared this round while the device worked)
+      if (!l1p_zero) {
+        const H t1 = (claim - s0) * l1p_inv;
         tm1 = t0.dbl() - t1;
         if (!deg1) tm1 = tm1 + tinf.dbl();  // t(-1) = 2 t(inf) + 2 t(0) - t(1)
       } else {
@@ -277,6 +290,8 @@ void sc_batch_rounds(const ScAlg<FID>& alg, std::vector<ScBatchClaim<FID>>& clai
   for (const auto& c : claims) e = e + c.claim0 * ScAlg<FID>::pow2(nmax - c.num_rounds) * c.coeff;
   for (size_t i = 0; i < k; i++)
     if (claims[i].num_rounds == nmax && claims[i].host.empty()) dev.start(i);
+  for (size_t i = 0; i < k; i++)
+    if (claims[i].num_rounds == nmax) claims[i].eq.prepare();  // round 1's inversions, under the passes just enqueued
   std::vector<H> e0(k), em1(k);
   for (uint32_t round = 0; round < nmax; round++) {
     const uint32_t remaining = nmax - round;
@@ -309,6 +324,9 @@ void sc_batch_rounds(const ScAlg<FID>& alg, std::vector<ScBatchClaim<FID>>& clai
       }
     }
     e = ScAlg<FID>::poly_eval(poly, 3, r);
+    // the next round's inversions while the device runs the passes enqueued above
+    for (size_t i = 0; i < k; i++)
+      if (remaining - 1 <= claims[i].num_rounds && remaining > 1) claims[i].eq.prepare();
   }
   if (out_finals)
     for (size_t i = 0; i < k; i++) alg.out(claims[i].host[0], out_finals + 32 * i);  // every polynomial ends on the host (len 1)

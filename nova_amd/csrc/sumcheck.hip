@@ -45,7 +45,10 @@ template <int FID> __device__ __forceinline__ Fp<FID> block_sum(Fp<FID> v, uint3
 // normalised every second step (inputs canonical), a wave's sum < 64 p brought back below 2 p by one product with 1; then the
 // four wave sums through LDS.  Result valid in thread 0.  The two eight-level LDS trees it replaces in k_eq_rows were ~10 % of a
 // block's time at two rows per block.
-template <int FID, int J> __device__ __forceinline__ void block_sum_waves(Fp<FID> (&x)[J], uint32_t* lds /* >= 36 J words */) {
+// LADDER: the wave sum comes down by six conditional subtractions instead of a product with ONE (Fp::canon_below) -- for the one-block
+// and few-block passes of the provers, whose cost is their dependent chain; the streaming passes keep the product (fewer instructions)
+template <int FID, int J, bool LADDER = false>
+__device__ __forceinline__ void block_sum_waves(Fp<FID> (&x)[J], uint32_t* lds /* >= 36 J words */) {
   using F = Fp<FID>;
   const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
 #pragma unroll
@@ -56,7 +59,7 @@ template <int FID, int J> __device__ __forceinline__ void block_sum_waves(Fp<FID
       for (int i = 0; i < 9; i++) x[j].l[i] += (uint32_t)__shfl_down((int)x[j].l[i], d, 64);
       if (d == 16 || d == 4 || d == 1) x[j] = x[j].norm();
     }
-    x[j] = (x[j] * F::one()).canon4();  // lane 0: the wave's sum, < p
+    x[j] = LADDER ? x[j].template canon_below<5>() : (x[j] * F::one()).canon4();  // lane 0: the wave's sum, < p
     if (lane == 0) {
 #pragma unroll
       for (int i = 0; i < 9; i++) lds[(j * 9 + i) * 4 + wave] = x[j].l[i];
@@ -78,9 +81,10 @@ template <int FID, int J> __device__ __forceinline__ void block_sum_waves(Fp<FID
     }
   }
 }
-template <int FID> __device__ __forceinline__ void block_sum_pair(Fp<FID>& g0, Fp<FID>& g1, uint32_t* lds /* >= 72 words */) {
+template <int FID, bool LADDER = false>
+__device__ __forceinline__ void block_sum_pair(Fp<FID>& g0, Fp<FID>& g1, uint32_t* lds /* >= 72 words */) {
   Fp<FID> x[2] = {g0, g1};
-  block_sum_waves<FID, 2>(x, lds);
+  block_sum_waves<FID, 2, LADDER>(x, lds);
   if (threadIdx.x == 0) {
     g0 = x[0];
     g1 = x[1];

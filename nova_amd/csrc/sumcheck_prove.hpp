@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void k_sum_partials_mail(const uint32_t* parti
   }
 #pragma unroll
   for (int j = 0; j < J; j++) s[j] = s[j].canon();
-  block_sum_waves<FID, J>(s, lds);
+  block_sum_waves<FID, J, true>(s, lds);
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int j = 0; j < J; j++) s[j].to_words(slot + 8 + 8 * j);
@@ -109,7 +109,7 @@ template <int FID> __global__ __launch_bounds__(256) void k_bind_qp_sums(BindQpA
   }
   s0 = s0.norm().canon();
   s1 = s1.norm().canon();
-  block_sum_pair<FID>(s0, s1, lds);
+  block_sum_pair<FID, true>(s0, s1, lds);
   if (threadIdx.x == 0) {
     s0.to_words(partial + 16 * blockIdx.x);
     s1.to_words(partial + 16 * blockIdx.x + 8);
@@ -165,7 +165,7 @@ template <int FID, int MODE> __global__ __launch_bounds__(256) void k_sc_small(S
   }
   s0 = s0.norm().canon();
   s1 = s1.norm().canon();
-  block_sum_pair<FID>(s0, s1, lds);
+  block_sum_pair<FID, true>(s0, s1, lds);
   if (threadIdx.x == 0) {
     s0.to_words(a.slot + 8);
     s1.to_words(a.slot + 16);
@@ -220,7 +220,7 @@ template <int FID, int MODE> __global__ __launch_bounds__(256) void k_sc_pass(Sc
   }
   s0 = s0.norm().canon();
   s1 = s1.norm().canon();
-  block_sum_pair<FID>(s0, s1, lds);
+  block_sum_pair<FID, true>(s0, s1, lds);
   if (threadIdx.x == 0) {
     uint32_t w[16];
     s0.to_words(w), s1.to_words(w + 8);
@@ -249,7 +249,7 @@ template <int FID, int MODE> __global__ __launch_bounds__(256) void k_sc_pass(Sc
   t0 = t0.canon();
   t1 = t1.canon();
   __syncthreads();  // lds is reused
-  block_sum_pair<FID>(t0, t1, lds);
+  block_sum_pair<FID, true>(t0, t1, lds);
   if (threadIdx.x == 0) {
     __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     t0.to_words(a.slot + 8);
@@ -689,6 +689,7 @@ static void sc_prove_t(Ctx& c, const void* claim, const void* taus, size_t num_r
     } else {
       typename ScEqDev<FID>::Tables tb = MODE == 3 ? eqd.tables(1) : typename ScEqDev<FID>::Tables{nullptr, nullptr, 0, 0};
       uint32_t seq = pass.sums(pass.A, pass.B, pass.C, len, tb);
+      if (MODE == 3) eq.prepare();  // the round's inversion runs under the pass (sc_host.hpp Eq::prepare)
       for (;; j++) {
         const uint32_t* res = h.wait(0, seq);
         const H t0 = h.raw(res, pass.factors(tb)), t1 = h.raw(res + 8, pass.factors(tb));
@@ -712,6 +713,7 @@ static void sc_prove_t(Ctx& c, const void* claim, const void* taus, size_t num_r
         }
         if (MODE == 3) tb = eqd.tables(j + 1);
         seq = pass.bind_sums(len, r, tb);
+        if (MODE == 3) eq.prepare();
         len /= 2;
       }
     }

@@ -14,9 +14,17 @@ def test_host_fp4_against_python_integers(tmp_path):
     src = os.path.join(ROOT, "tests", "cpp", "host_fp4_test.cpp")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, src])
     out = subprocess.check_output([exe, "120"], text=True)
-    n = 0
+    n = ninv = nfast = 0
     for line in out.splitlines():
         kv = dict(tok.split("=") for tok in line.split())
+        if "invfid" in kv:      # the fast (31 steps at a time) and the bit-at-a-time inversion on stress values
+            p = fc.FIELDS[int(kv["invfid"])]
+            a = int(kv["a"], 16)
+            want = pow(a, -1, p) if a else 0
+            assert int(kv["inv"], 16) == want == int(kv["inv_slow"], 16), line
+            ninv += 1
+            nfast += int(kv["fast"])
+            continue
         p = fc.FIELDS[int(kv["fid"])]
         a, b = int(kv["a"], 16), int(kv["b"], 16)
         assert int(kv["mul"], 16) == a * b % p
@@ -29,3 +37,4 @@ def test_host_fp4_against_python_integers(tmp_path):
         assert int(kv["dev"], 16) == a * (1 << 261) % p == int(kv["dev_ref"], 16)
         n += 1
     assert n == 480
+    assert ninv == 4 * (1 + 80 + 3 * 174 + 2400) and nfast == ninv - 8      # the fast path converged on everything but the two zeros per field
