@@ -406,7 +406,7 @@ int nmx_sumcheck_plain_sums(int field, int kind, const void* A, const void* B, c
  * vectors' own form (NMX_SCALARS_MONT as everywhere).  A non-zero return aborts the proof (NMX_E_ARG); a challenge >= p is
  * NMX_E_SCALAR_RANGE.  Outputs (any may be NULL): out_polys = rounds x n_coeffs x 32 bytes (what SumcheckProof compresses),
  * out_r = rounds x 32 (the challenges), final evaluations as listed.  The tables' contents after a call are unspecified (partly
- * bound: the reference's are consumed too).  Once the tables hold <= 2^"sc_host_tail" elements (option, default 6 = 64
+ * bound: the reference's are consumed too).  Once the tables hold <= 2^"sc_host_tail" elements (option, default 7 = 128
  * elements, 0..8) the remaining rounds run on the HOST -- a few hundred field products take the host 1-8 us, any kernel round
  * trip 20-25 us; the last device bind lands the tables in pinned memory.  Option "sc_fused_sum" (default 1): a round is one
  * launch, the block that finishes last adds the per-block partials up; 0: pass + one-block sum.  Option "sc_poll_us": how long a round's mailbox is

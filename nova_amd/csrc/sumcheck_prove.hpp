@@ -19,7 +19,7 @@
 //     runs on the host in 4 x 64-bit Montgomery arithmetic (host_fp4.hpp, sc_host.hpp: ~1 us per round); the only thing that
 //     leaves the library is the transcript step: a callback receives the round polynomial's coefficients and returns the
 //     challenge (`transcript.absorb(b"p", &poly); transcript.squeeze(b"c")`, sumcheck.rs:224-227,481-484,315-318);
-//   * once the tables hold <= 64 elements (option sc_host_tail) the last device bind lands them in pinned memory and the
+//   * once the tables hold <= 128 elements (option sc_host_tail) the last device bind lands them in pinned memory and the
 //     remaining rounds run on the host (sc_host.hpp sc_tail_rounds): ~300 products against a 20-25 us kernel round trip.
 // All sqrt-size eq tables of an instance (poly_eq_left[k], poly_eq_right[k], sumcheck.rs:608-641) are built by one launch into a
 // heap layout (table k at offset 2^k) in the context's aux arena.

@@ -196,7 +196,7 @@ def test_batch_claims_on_side_streams_and_on_one_stream_agree(nmx):
         assert L.nmx_set_option(b"sc_side_streams", 1) == 0
 
 
-@pytest.mark.parametrize("tail", [0, 1, 3, 6, 8])
+@pytest.mark.parametrize("tail", [0, 1, 3, 6, 7, 8])
 def test_every_host_tail_threshold_gives_the_same_proof(nmx, tail):
     """option sc_host_tail: tables of <= 2^tail elements finish on the host (sc_host.hpp; 0 = only the final values come over).  The
     proof is the same wherever the hand-over happens -- including instances that fit the tail from the start and batch claims that
@@ -214,7 +214,7 @@ def test_every_host_tail_threshold_gives_the_same_proof(nmx, tail):
             both(sp.check_batch_eval, g_batch, o_batch, 1, nrs, seed=3 + sum(nrs))
         both(sp.check_batch_eval, g_batch, o_batch, 1, [5, 10], seed=901, force={0: 0, 4: 1, 9: 0})
     finally:
-        assert L.nmx_set_option(b"sc_host_tail", 6) == 0
+        assert L.nmx_set_option(b"sc_host_tail", 7) == 0
 
 
 def test_concat_builds_z_on_the_device(nmx):
