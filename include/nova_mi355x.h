@@ -411,7 +411,10 @@ int nmx_sumcheck_plain_sums(int field, int kind, const void* A, const void* B, c
  * trip 20-25 us; the last device bind lands the tables in pinned memory.  Option "sc_fused_sum" (default 1): a round is one
  * launch, the block that finishes last adds the per-block partials up; 0: pass + one-block sum.  Option "sc_poll_us": how long a round's mailbox is
  * polled before the stream is synchronised instead (default 2000; 0: always synchronise).  Option "sc_side_streams" (default 1): the
- * claims of a prove_batch_eval round are independent passes and run on one stream each; 0: all on the call's stream.
+ * claims of a prove_batch_eval round are independent passes and run on one stream each; 0: all on the call's stream.  Options
+ * "sc_host_parts" (default 1: a pass of <= 64 blocks hands every block's partial sums to the host, which adds them; 0: the last block
+ * does) and "sc_quad" (default 1: passes of <= 2^12 indices of the cubic / quad_prod provers spread an index over four lanes) shorten
+ * the dependent chain of the small rounds; results are identical either way.
  *  - nmx_sumcheck_prove_cubic_with_three_inputs == SumcheckProof::prove_cubic_with_three_inputs (sumcheck.rs:446-507) with its
  *    EqSumCheckInstance (sumcheck.rs:593-1253; all sqrt-size eq tables built by one launch): A, B, C of 2^num_rounds elements,
  *    taus = num_rounds elements (host), 4 coefficients per round, out_claims = [A(r), B(r), C(r)].  A tau of zero (or a

@@ -170,6 +170,8 @@ static void ensure_init() {
   if (const char* t = getenv("NMX_SC_HOST_TAIL")) G.sc_host_tail = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_SC_FUSED_SUM")) G.sc_fused_sum = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_SC_SIDE_STREAMS")) G.sc_side_streams = (uint32_t)atoi(t);
+  if (const char* t = getenv("NMX_SC_QUAD")) G.sc_quad = (uint32_t)atoi(t);
+  if (const char* t = getenv("NMX_SC_HOST_PARTS")) G.sc_host_parts = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_HORNER_TOP")) G.horner_top = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_HORNER_SUB")) G.horner_sub = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_HORNER_ORDER")) G.horner_order = atoi(t) ? 1u : 0u;
@@ -2711,6 +2713,8 @@ int nmx_set_option(const char* name, uint32_t value) {
     } else if (n == "host_split_min_n") G.host_split_min_n = value;
     else if (n == "sc_fused_sum") G.sc_fused_sum = value ? 1u : 0u;
     else if (n == "sc_side_streams") G.sc_side_streams = value ? 1u : 0u;
+    else if (n == "sc_quad") G.sc_quad = value ? 1u : 0u;
+    else if (n == "sc_host_parts") G.sc_host_parts = value ? 1u : 0u;
     else if (n == "sc_host_tail") {
       require(value <= 8, NMX_E_ARG, "sc_host_tail: log2 of the table length the host takes over, 0..8");
       G.sc_host_tail = value;

@@ -329,6 +329,8 @@ struct Global {
   std::atomic<size_t> host_split_min_n{(size_t)1 << 19};
   std::atomic<uint32_t> sc_fused_sum{1};          // option sc_fused_sum: 1 = a sum-check round is ONE launch (the last block sums the partials, k_sc_pass); 0 = pass + final-sum launch
   std::atomic<uint32_t> sc_side_streams{1};       // option sc_side_streams: the batch prover runs claim i > 0 on its own stream (0: all on the context's)
+  std::atomic<uint32_t> sc_host_parts{1};         // option sc_host_parts: passes of <= 64 blocks send per-block partial sums to the host, which adds them (0: last-block ticket)
+  std::atomic<uint32_t> sc_quad{1};               // option sc_quad: passes of <= 2^12 indices of the cubic / quad_prod provers run four lanes per index (0: one)
   std::atomic<uint32_t> sc_host_tail{7};          // option sc_host_tail: the sum-check provers finish on the host once the tables hold <= 2^this elements (0: only the final values come over; max 8)
   std::atomic<uint32_t> sc_poll_us{2000};         // option sc_poll_us: the sum-check provers poll a round's mailbox this long before they synchronise the stream (0: always synchronise)
   std::atomic<uint32_t> sync_spin_us{0};          // env NMX_SYNC_SPIN_US / option sync_spin_us: poll the stream this long before blocking

@@ -126,12 +126,115 @@ template <int FID> struct ScSmallArgs {
   uint32_t shift, mask, hq, bind, seq;
   uint32_t* slot;
 };
-template <int FID, int MODE> __global__ __launch_bounds__(256) void k_sc_small(ScSmallArgs<FID> a) {
+// ---- FOUR lanes per index (QUAD): the short chain --------------------------------------------------------------------------
+// A small pass is one index per thread and pure latency: 6 binds + 5 products in a row for the cubic prover (~1.2 us each at one
+// wave per SIMD), 4 + 2 for quad_prod.  With four lanes per index the binds run side by side (lane t binds table t; the fourth lane of
+// the cubic form builds the eq factor), the bound values cross the quad in shuffles, lane 0 forms the t(0) term and lane 1 the t(inf)
+// term: 2 + 1.5 + 1 products deep instead of 11 (cubic), 1 + 1 instead of 6 (quad_prod).  Every lane runs the same instructions
+// (operands are SELECTED per role, never branched on), so the quad costs one lane's time.  Only for passes of <= kScQuadMaxHq
+// indices: beyond that a pass leaves the latency regime and four lanes per index would be four times the work.
+static constexpr uint32_t kScQuadMaxHq = 1u << 12;  // (64 blocks of 64 indices: the largest pass whose partial sums the host adds up)
+template <int FID> __device__ __forceinline__ Fp<FID> sc_sel(bool c, const Fp<FID>& x, const Fp<FID>& y) {
+  Fp<FID> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = c ? x.l[i] : y.l[i];
+  return r;
+}
+template <int FID> __device__ __forceinline__ Fp<FID> sc_quad_get(const Fp<FID>& x, int src) {
+  Fp<FID> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = (uint32_t)__shfl((int)x.l[i], src, 4);
+  return r;
+}
+// one index of the cubic prover (MODE 3) on a quad; returns this lane's term (lane 0: the t(0) term, lane 1: the t(inf) term, others: zero)
+template <int FID> __device__ __forceinline__ Fp<FID> sc_index_quad3(const ScSmallArgs<FID>& a, uint32_t id, uint32_t role) {
+  using F = Fp<FID>;
+  const uint32_t* T = role == 0 ? a.A : role == 1 ? a.B : a.C;
+  uint32_t* oT = role == 0 ? a.oA : role == 1 ? a.oB : a.oC;
+  const bool tab = role < 3;
+  F y0, y1;
+  if (a.bind) {
+    // lanes 0-2: y = lo + r (hi - lo) twice; lane 3: eqL * eqR (ONE * eqR without eqL) and a product nobody reads
+    F w0 = F::zero(), w1 = F::zero(), v0 = F::zero(), v1 = F::zero(), u0 = a.r;
+    if (tab) {
+      const F x00 = ldw<FID>(T, id), x01 = ldw<FID>(T, (size_t)id + a.hq);
+      const F x10 = ldw<FID>(T, (size_t)id + 2 * (size_t)a.hq), x11 = ldw<FID>(T, (size_t)id + 3 * (size_t)a.hq);
+      w0 = x00, w1 = x01, v0 = F::sub2(x10, x00).norm(), v1 = F::sub2(x11, x01).norm();
+    } else {
+      v0 = ldw<FID>(a.eqR, a.eqL ? (id & a.mask) : id);
+      u0 = a.eqL ? ldw<FID>(a.eqL, id >> a.shift) : F::one();
+    }
+    const F m0 = u0 * v0, m1 = a.r * v1;
+    y0 = (w0 + m0).norm().canon();
+    y1 = (w1 + m1).norm().canon();
+    if (tab) {
+      y0.to_words(oT + 8 * (size_t)id);
+      y1.to_words(oT + 8 * ((size_t)id + a.hq));
+    }
+  } else {
+    if (tab) {
+      y0 = ldw<FID>(T, id), y1 = ldw<FID>(T, (size_t)id + a.hq);
+    } else {
+      y0 = ldw<FID>(a.eqR, a.eqL ? (id & a.mask) : id);
+      if (a.eqL) y0 = ldw<FID>(a.eqL, id >> a.shift) * y0;  // (one extra product on the no-bind path: the first round of a small instance only)
+      y1 = F::zero();
+    }
+  }
+  const F a0 = sc_quad_get<FID>(y0, 0), a1 = sc_quad_get<FID>(y1, 0), b0 = sc_quad_get<FID>(y0, 1), b1 = sc_quad_get<FID>(y1, 1);
+  const F c0 = sc_quad_get<FID>(y0, 2), fac = sc_quad_get<FID>(y0, 3);
+  // lane 0: a0 b0 - c0 k; lane 1: (a1 - a0)(b1 - b0) -- one instruction stream: the second product of lane 1 is 0 * nk
+  const bool first = role == 0;
+  const F x1 = sc_sel<FID>(first, a0, F::sub2(a1, a0).norm()), z1 = sc_sel<FID>(first, b0, F::sub2(b1, b0).norm());
+  const F x2 = sc_sel<FID>(first, c0, F::zero());
+  const F e = F::mul_add(x1, z1, x2, a.nk) * fac;
+  return sc_sel<FID>(role < 2, e, F::zero());
+}
+// one index of quad_prod (MODE 4) on a quad: lane t binds element (t & 1) of table (t >> 1)
+template <int FID> __device__ __forceinline__ Fp<FID> sc_index_quad4(const ScSmallArgs<FID>& a, uint32_t id, uint32_t role) {
+  using F = Fp<FID>;
+  const uint32_t* T = role < 2 ? a.A : a.B;
+  uint32_t* oT = role < 2 ? a.oA : a.oB;
+  const size_t at = (size_t)id + ((role & 1u) ? a.hq : 0u);
+  F y;
+  if (a.bind) {
+    const F lo = ldw<FID>(T, at), hi = ldw<FID>(T, at + 2 * (size_t)a.hq);
+    y = (lo + a.r * F::sub2(hi, lo).norm()).norm().canon();
+    y.to_words(oT + 8 * at);
+  } else {
+    y = ldw<FID>(T, at);
+  }
+  const F a0 = sc_quad_get<FID>(y, 0), a1 = sc_quad_get<FID>(y, 1), b0 = sc_quad_get<FID>(y, 2), b1 = sc_quad_get<FID>(y, 3);
+  const bool first = role == 0;
+  const F e = sc_sel<FID>(first, a0, F::sub2(a1, a0).norm()) * sc_sel<FID>(first, b0, F::sub2(b1, b0).norm());
+  return sc_sel<FID>(role < 2, e, F::zero());
+}
+// the quad form of a pass's index loop: quads of the grid stride over the indices; on return s0 / s1 hold this lane's share
+template <int FID, int MODE>
+__device__ __forceinline__ void sc_quad_loop(const ScSmallArgs<FID>& a, uint32_t first_quad, uint32_t quads, Fp<FID>& s0, Fp<FID>& s1) {
+  using F = Fp<FID>;
+  static_assert(MODE == 3 || MODE == 4, "quad form: the cubic and the quad_prod provers");
+  const uint32_t role = threadIdx.x & 3u;
+  F acc = F::zero();
+  uint32_t pending = 0;
+  for (uint32_t id = first_quad; id < a.hq; id += quads) {  // (the four lanes of a quad share id: the shuffles inside always see all four)
+    acc = acc + (MODE == 3 ? sc_index_quad3<FID>(a, id, role) : sc_index_quad4<FID>(a, id, role));
+    if (++pending == 6) {
+      acc = acc.norm().canon();
+      pending = 0;
+    }
+  }
+  acc = acc.norm().canon();
+  s0 = sc_sel<FID>(role == 0, acc, F::zero());
+  s1 = sc_sel<FID>(role == 1, acc, F::zero());
+}
+
+template <int FID, int MODE, bool QUAD = false> __global__ __launch_bounds__(256) void k_sc_small(ScSmallArgs<FID> a) {
   using F = Fp<FID>;
   __shared__ uint32_t lds[72];
   F s0 = F::zero(), s1 = F::zero();
   uint32_t pending = 0;
-  for (uint32_t id = threadIdx.x; id < a.hq; id += 256u) {
+  if constexpr (QUAD) sc_quad_loop<FID, MODE>(a, threadIdx.x >> 2, 64u, s0, s1);
+  for (uint32_t id = threadIdx.x; !QUAD && id < a.hq; id += 256u) {
     F a0, a1, b0 = F::zero(), b1 = F::zero(), c0 = F::zero(), c1;
     if (a.bind) {
       sc_bind2<FID>(a.A, a.oA, a.r, id, a.hq, a0, a1);
@@ -184,15 +287,22 @@ template <int FID> struct ScPassArgs {
   ScSmallArgs<FID> s;
   uint32_t* partial;  // 16 words per block
   uint32_t* ticket;
+  // A pass of at most kHostPartBlocks blocks skips the ticket and the second block sum: every block writes its two partial sums
+  // and the round's sequence number straight into pinned host memory (32 words per block: sums at 0 and 8, sequence at 16) and
+  // the HOST adds them up (ScDev::wait) -- a few dozen 256-bit additions there against ~7 us of ticket + reload + block sum +
+  // publish at the end of a kernel that is nothing but its dependent chain (timeline: profiles/r05_spartan/timeline_2p20.txt).
+  uint32_t* host_part = nullptr;
 };
-template <int FID, int MODE> __global__ __launch_bounds__(256) void k_sc_pass(ScPassArgs<FID> p) {
+static constexpr uint32_t kHostPartBlocks = 64, kHostPartWords = 32;
+template <int FID, int MODE, bool QUAD = false> __global__ __launch_bounds__(256) void k_sc_pass(ScPassArgs<FID> p) {
   using F = Fp<FID>;
   const ScSmallArgs<FID>& a = p.s;
   __shared__ uint32_t lds[72];
   __shared__ uint32_t s_last;
   F s0 = F::zero(), s1 = F::zero();
   uint32_t pending = 0;
-  for (uint32_t id = blockIdx.x * 256u + threadIdx.x; id < a.hq; id += gridDim.x * 256u) {
+  if constexpr (QUAD) sc_quad_loop<FID, MODE>(a, blockIdx.x * 64u + (threadIdx.x >> 2), gridDim.x * 64u, s0, s1);
+  for (uint32_t id = blockIdx.x * 256u + threadIdx.x; !QUAD && id < a.hq; id += gridDim.x * 256u) {
     F a0, a1, b0 = F::zero(), b1 = F::zero(), c0 = F::zero(), c1;
     sc_bind2<FID>(a.A, a.oA, a.r, id, a.hq, a0, a1);
     if (MODE >= 3) sc_bind2<FID>(a.B, a.oB, a.r, id, a.hq, b0, b1);
@@ -221,6 +331,14 @@ template <int FID, int MODE> __global__ __launch_bounds__(256) void k_sc_pass(Sc
   s0 = s0.norm().canon();
   s1 = s1.norm().canon();
   block_sum_pair<FID, true>(s0, s1, lds);
+  if (p.host_part) {  // kernel-uniform
+    if (threadIdx.x == 0) {
+      uint32_t* mine = p.host_part + kHostPartWords * (size_t)blockIdx.x;
+      s0.to_words(mine), s1.to_words(mine + 8);
+      mail_publish(mine + 16, a.seq);
+    }
+    return;
+  }
   if (threadIdx.x == 0) {
     uint32_t w[16];
     s0.to_words(w), s1.to_words(w + 8);
@@ -342,6 +460,7 @@ struct ScProf {  // wall-clock split of one prover call (profiling on): where a 
 };
 static constexpr uint32_t kTailMaxLog2 = 8, kTailMax = 1u << kTailMaxLog2;  // the longest table the tail takes over
 static constexpr size_t kMailBytes = kMailSlots * kMailSlotWords * 4, kTailSlotBytes = (size_t)kTailMax * 32;
+static constexpr size_t kPartSlotBytes = (size_t)kHostPartBlocks * kHostPartWords * 4;
 
 template <int FID> struct ScDev {
   using F = Fp<FID>;
@@ -376,7 +495,7 @@ template <int FID> struct ScDev {
   void mail_init() {
     if (c.mail) return;
     void* p = nullptr;
-    const size_t bytes = kMailBytes + kMailSlots * kTailSlotBytes;
+    const size_t bytes = kMailBytes + kMailSlots * kTailSlotBytes + kMailSlots * kPartSlotBytes;
     HIPCHK(hipHostMalloc(&p, bytes, hipHostMallocCoherent | hipHostMallocMapped));
     memset(p, 0, bytes);
     void* d = nullptr;
@@ -387,10 +506,54 @@ template <int FID> struct ScDev {
   uint32_t* slot_dev(uint32_t s) const { return (uint32_t*)c.mail_dev + (size_t)s * kMailSlotWords; }
   uint32_t* tail_dev(uint32_t s) const { return (uint32_t*)(c.mail_dev + kMailBytes + (size_t)s * kTailSlotBytes); }
   const uint32_t* tail_host(uint32_t s) const { return (const uint32_t*)(c.mail + kMailBytes + (size_t)s * kTailSlotBytes); }
+  // per-block partial sums of the host-summed passes (their own region: a sequence word must never be compared with table data)
+  uint32_t* part_dev(uint32_t s) const { return (uint32_t*)(c.mail_dev + kMailBytes + kMailSlots * kTailSlotBytes + (size_t)s * kPartSlotBytes); }
+  const uint32_t* part_host(uint32_t s) const {
+    return (const uint32_t*)(c.mail + kMailBytes + kMailSlots * kTailSlotBytes + (size_t)s * kPartSlotBytes);
+  }
   uint32_t next_seq() { return ++c.mail_seq ? c.mail_seq : ++c.mail_seq; }  // never 0 (a fresh mailbox reads 0)
   // waits until slot s carries `seq`; returns its result words.  The sequence word is polled in host memory; the stream is only
   // synchronised when the poll gives up (option sc_poll_us) or polling is off.
+  // passes whose per-block partial sums come to the host un-added (ScPassArgs::host_part): blocks expected per slot, and the sums
+  uint32_t parts[kMailSlots] = {};
+  uint32_t sumbuf[kMailSlots][16];
+  const uint32_t* wait_parts(uint32_t s, uint32_t seq, uint32_t nb) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const uint32_t* area = part_host(s);
+    const uint32_t poll_us = G.sc_poll_us.load(std::memory_order_relaxed);
+    auto arrived = [&](uint32_t b) { return __atomic_load_n(area + kHostPartWords * (size_t)b + 16, __ATOMIC_ACQUIRE) == seq; };
+    bool synced = false;
+    H a0 = H::zero(), a1 = H::zero();
+    for (uint32_t b = 0; b < nb; b++) {
+      if (!synced && !arrived(b)) {
+        bool ok = false;
+        if (poll_us) {
+          for (uint32_t spin = 0;; spin++) {
+            if (arrived(b)) {
+              ok = true;
+              break;
+            }
+            if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(poll_us)) break;
+          }
+        }
+        if (!ok) {
+          sync_all();
+          synced = true;
+        }
+      }
+      require(arrived(b), NMX_E_HIP, "sum-check: a block's partial sums never reached the host");
+      a0 = a0 + H::from_mont256(area + kHostPartWords * (size_t)b);  // canonical words: addition does not care about the form
+      a1 = a1 + H::from_mont256(area + kHostPartWords * (size_t)b + 8);
+    }
+    a0.to_mont256(sumbuf[s]), a1.to_mont256(sumbuf[s] + 8);
+    if (profiling) prof.wait += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return sumbuf[s];
+  }
   const uint32_t* wait(uint32_t s, uint32_t seq) {
+    if (const uint32_t nb = parts[s]) {
+      parts[s] = 0;
+      return wait_parts(s, seq, nb);
+    }
     const auto t0 = std::chrono::steady_clock::now();
     uint32_t* host = (uint32_t*)c.mail + (size_t)s * kMailSlotWords;
     const uint32_t poll_us = G.sc_poll_us.load(std::memory_order_relaxed);
@@ -539,6 +702,9 @@ template <int FID, int MODE> struct ScPass {
   hipStream_t stream; // the context's, or a side stream (batch prover: one per claim)
   F nk;
   static constexpr uint32_t NT = MODE == 3 ? 3u : MODE == 4 ? 2u : 1u;
+  static constexpr bool kQuadForm = MODE == 3 || MODE == 4;  // the provers whose index is a chain worth spreading over four lanes
+  static bool quad_on() { return G.sc_quad.load(std::memory_order_relaxed) != 0; }
+  static bool host_parts_on() { return G.sc_host_parts.load(std::memory_order_relaxed) != 0; }
   ScPass(ScDev<FID>& h_, void* a, void* b, void* cc, uint32_t* partial_, uint32_t slot_)
       : h(h_), A((uint32_t*)a), B((uint32_t*)b), C((uint32_t*)cc), partial(partial_), slot(slot_), stream(h_.c.stream) {
     F fconst = F::zero();
@@ -556,7 +722,8 @@ template <int FID, int MODE> struct ScPass {
     hipStream_t s = stream;
     if (hh <= kScSmallHq) {
       ScSmallArgs<FID> x{a, b, cc, nullptr, nullptr, nullptr, t.eqL, t.eqR, F::zero(), nk, t.shift, t.mask, hh, 0u, seq, h.slot_dev(slot)};
-      hipLaunchKernelGGL((k_sc_small<FID, MODE>), dim3(1), dim3(256), 0, s, x);
+      if (kQuadForm && hh <= 64 && quad_on()) hipLaunchKernelGGL((k_sc_small<FID, MODE, kQuadForm>), dim3(1), dim3(256), 0, s, x);
+      else hipLaunchKernelGGL((k_sc_small<FID, MODE>), dim3(1), dim3(256), 0, s, x);
       h.launched();
     } else {
       uint32_t blocks = sc_blocks_sums(hh, MODE == 1);
@@ -587,14 +754,28 @@ template <int FID, int MODE> struct ScPass {
     const uint32_t hq = (uint32_t)(len / 4), seq = h.next_seq();
     const F r = rh.to_device();
     hipStream_t s = stream;
-    if (hq <= kScSmallHq) {
+    const bool fused = G.sc_fused_sum.load(std::memory_order_relaxed) != 0;
+    if (kQuadForm && quad_on() && (hq <= 64 || (fused && hq <= kScQuadMaxHq))) {
+      // four lanes per index (sc_quad_loop): one block up to 64 indices, 64 indices per block beyond
+      ScSmallArgs<FID> x{A, B, C, A, B, C, t.eqL, t.eqR, r, nk, t.shift, t.mask, hq, 1u, seq, h.slot_dev(slot)};
+      if (hq <= 64) {
+        hipLaunchKernelGGL((k_sc_small<FID, MODE, kQuadForm>), dim3(1), dim3(256), 0, s, x);
+      } else {
+        const uint32_t blocks = (hq + 63) / 64;
+        ScPassArgs<FID> y{x, partial, partial + kScPartialBytes / 4 - 64};
+        if (host_parts_on() && blocks <= kHostPartBlocks) y.host_part = h.part_dev(slot), h.parts[slot] = blocks;
+        hipLaunchKernelGGL((k_sc_pass<FID, MODE, kQuadForm>), dim3(blocks), dim3(256), 0, s, y);
+      }
+      h.launched();
+    } else if (hq <= kScSmallHq) {
       ScSmallArgs<FID> x{A, B, C, A, B, C, t.eqL, t.eqR, r, nk, t.shift, t.mask, hq, 1u, seq, h.slot_dev(slot)};
       hipLaunchKernelGGL((k_sc_small<FID, MODE>), dim3(1), dim3(256), 0, s, x);
       h.launched();
-    } else if (G.sc_fused_sum.load(std::memory_order_relaxed)) {
+    } else if (fused) {
       const uint32_t blocks = sc_blocks_bind(hq);
       ScPassArgs<FID> x{ScSmallArgs<FID>{A, B, C, A, B, C, t.eqL, t.eqR, r, nk, t.shift, t.mask, hq, 1u, seq, h.slot_dev(slot)}, partial,
                         partial + kScPartialBytes / 4 - 64};  // the ticket: a zero word at the end of this instance's scratch
+      if (host_parts_on() && blocks <= kHostPartBlocks) x.host_part = h.part_dev(slot), h.parts[slot] = blocks;
       hipLaunchKernelGGL((k_sc_pass<FID, MODE>), dim3(blocks), dim3(256), 0, s, x);
       h.launched();
     } else {

@@ -178,6 +178,58 @@ def test_one_launch_rounds_and_two_launch_rounds_agree(nmx):
         assert L.nmx_set_option(b"sc_fused_sum", 1) == 0
 
 
+def test_four_lanes_per_index_and_one_lane_per_index_agree(nmx):
+    """option sc_quad: passes of <= 2^13 indices of the cubic and quad_prod provers spread an index over four lanes (binds side by side,
+    values exchanged in shuffles).  Sizes on both sides of every switch (one block up to 64 indices, 64 indices per block up to 2^13,
+    the one-lane form beyond), the no-bind first round of small instances (host tail lowered), the fallback rounds, both layouts via the
+    Montgomery test below; every proof equal to the oracle's with the option on and off."""
+    from nova_amd import _lib
+    L = _lib.lib()
+    p = fc.FIELDS[1]
+    try:
+        for quad in (1, 0, 1):
+            assert L.nmx_set_option(b"sc_quad", quad) == 0
+            for l in (8, 9, 10, 14, 15, 16):
+                both(sp.check_cubic3, g_cubic3(), o_cubic3, 1, l, seed=40 + l, brute=False)
+                both(sp.check_quad_prod, g_quad, o_quad, 1, l, seed=50 + l)
+            both(sp.check_cubic3, g_cubic3(), o_cubic3, 3, 11, seed=41, brute=False)
+            both(sp.check_quad_prod, g_quad, o_quad, 0, 11, seed=42)
+            both(sp.check_cubic3, g_cubic3(), o_cubic3, 1, 12, seed=43, force={0: 0, 3: 1, 7: p - 1, 9: 0}, brute=False)
+            both(sp.check_cubic3, g_cubic3(), o_cubic3, 1, 10, seed=44, taus=[0] * 10, brute=False)
+            assert L.nmx_set_option(b"sc_host_tail", 2) == 0
+            for l in (3, 5, 6, 7, 8):
+                both(sp.check_cubic3, g_cubic3(), o_cubic3, 1, l, seed=45 + l, brute=False)
+                both(sp.check_quad_prod, g_quad, o_quad, 1, l, seed=55 + l)
+            assert L.nmx_set_option(b"sc_host_tail", 7) == 0
+    finally:
+        assert L.nmx_set_option(b"sc_quad", 1) == 0
+        assert L.nmx_set_option(b"sc_host_tail", 7) == 0
+
+
+def test_host_added_partials_and_ticket_passes_agree(nmx):
+    """option sc_host_parts: a pass of <= 64 blocks sends every block's partial sums to the host, which adds them up (default); 0: the
+    block that draws the last ticket does.  Sizes around the 64-block limits of the one-lane (2^14 indices) and four-lane (2^12) forms,
+    all three provers, polling off (sc_poll_us = 0: the host synchronises, then reads), repeated."""
+    from nova_amd import _lib
+    L = _lib.lib()
+    try:
+        for hp, poll in ((1, 2000), (0, 2000), (1, 0), (1, 2000)):
+            assert L.nmx_set_option(b"sc_host_parts", hp) == 0
+            assert L.nmx_set_option(b"sc_poll_us", poll) == 0
+            for l in (9, 12, 14, 15, 16):
+                both(sp.check_cubic3, g_cubic3(), o_cubic3, 1, l, seed=140 + l, brute=False)
+                both(sp.check_quad_prod, g_quad, o_quad, 1, l + 1, seed=150 + l)
+            both(sp.check_batch_eval, g_batch, o_batch, 1, [16, 13, 15, 9], seed=160)
+            assert L.nmx_set_option(b"sc_quad", 0) == 0
+            both(sp.check_cubic3, g_cubic3(), o_cubic3, 1, 15, seed=161, brute=False)
+            both(sp.check_quad_prod, g_quad, o_quad, 1, 16, seed=162)
+            assert L.nmx_set_option(b"sc_quad", 1) == 0
+    finally:
+        assert L.nmx_set_option(b"sc_host_parts", 1) == 0
+        assert L.nmx_set_option(b"sc_poll_us", 2000) == 0
+        assert L.nmx_set_option(b"sc_quad", 1) == 0
+
+
 def test_batch_claims_on_side_streams_and_on_one_stream_agree(nmx):
     """option sc_side_streams: the claims of a batch round are independent passes -- claim i > 0 runs on its own stream (default) or
     all of them queue on the context's.  Up to 16 claims of mixed sizes, the fallback rounds (which allocate and copy on the claim's
