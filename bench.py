@@ -1346,7 +1346,7 @@ def spartan_replay(args, torch):
     class Gpu:
         W, E, z = dW, dE, dz
         clone = staticmethod(lambda v: fv.concat(fid, [v], async_=True))        # on the library's stream (torch's clone is not ordered with it)
-        concat_z = staticmethod(lambda: fv.concat(fid, [dW, u, x0], n_out=2 * n))
+        concat_z = staticmethod(lambda: fv.concat(fid, [dW, u, x0], n_out=2 * n, async_=True))   # consumed by stream-ordered calls only
         spmv = staticmethod(lambda j, v: mats[j].multiply_vec(v, async_=True))
         spmv_t = staticmethod(lambda j, v: mats[j].multiply_vec_transposed(v, async_=True))
         axpy = staticmethod(lambda a, b, r: fv.axpy(fid, a, b, r, async_=True))

@@ -29,6 +29,7 @@ find "$OUT/prof_spartan20" -name "*kernel_stats.csv" | head -1 | xargs -r head -
 echo "== A/B r03 vs HEAD"
 for rep in 1 2; do
   for wl in sumcheck3 quad_prod cross_term round3; do
+    # build/r03_tree: a checkout of the round-3 tree (git worktree add build/r03_tree 5613f68, built there); removed after this A/B
     (cd build/r03_tree && timeout 400 python bench.py --workload $wl --log2n 24 --steps 10 --warmup 3 --no-cpu-baseline) > "$OUT/ab_r03_${wl}_$rep.json" 2> "$OUT/ab_r03_${wl}_$rep.err"
     timeout 400 python bench.py --workload $wl --log2n 24 --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/ab_head_${wl}_$rep.json" 2> "$OUT/ab_head_${wl}_$rep.err"
   done
