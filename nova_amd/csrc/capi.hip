@@ -171,6 +171,7 @@ static void ensure_init() {
   if (const char* t = getenv("NMX_SC_FUSED_SUM")) G.sc_fused_sum = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_SC_SIDE_STREAMS")) G.sc_side_streams = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_SC_QUAD")) G.sc_quad = (uint32_t)atoi(t);
+  if (const char* t = getenv("NMX_SC_PRELAUNCH")) G.sc_prelaunch = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_SC_HOST_PARTS")) G.sc_host_parts = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_HORNER_TOP")) G.horner_top = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_HORNER_SUB")) G.horner_sub = (uint32_t)atoi(t);
@@ -1282,6 +1283,7 @@ int nmx_shutdown(void) {
         for (int i = 0; i < kMaxMarks; i++) (void)hipEventDestroy(c->ev[i]);
       if (c->async_ev) (void)hipEventDestroy(c->async_ev);
       if (c->side_ev) (void)hipEventDestroy(c->side_ev);
+      if (c->chal) (void)hipFree(c->chal);
       for (hipStream_t sd : c->side)
         if (sd) (void)hipStreamDestroy(sd);
       if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -2714,6 +2716,7 @@ int nmx_set_option(const char* name, uint32_t value) {
     else if (n == "sc_fused_sum") G.sc_fused_sum = value ? 1u : 0u;
     else if (n == "sc_side_streams") G.sc_side_streams = value ? 1u : 0u;
     else if (n == "sc_quad") G.sc_quad = value ? 1u : 0u;
+    else if (n == "sc_prelaunch") G.sc_prelaunch = value ? 1u : 0u;
     else if (n == "sc_host_parts") G.sc_host_parts = value ? 1u : 0u;
     else if (n == "sc_host_tail") {
       require(value <= 8, NMX_E_ARG, "sc_host_tail: log2 of the table length the host takes over, 0..8");

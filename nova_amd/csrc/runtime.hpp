@@ -79,6 +79,10 @@ struct Ctx {
   static constexpr int kSideStreams = 15;
   hipStream_t side[kSideStreams] = {};
   hipEvent_t side_ev = nullptr;
+  // challenge lines of the provers' pre-launched passes: uncached device memory the HOST writes through the large BAR (one 256-byte
+  // stride per mailbox slot), nullptr when the device has no large BAR (then nothing is pre-launched)
+  uint32_t* chal = nullptr;
+  bool chal_tried = false;
   hipEvent_t ev[kMaxMarks];
   bool have_ev = false;
   hipEvent_t async_ev = nullptr;  // behind the last NMX_ASYNC call enqueued on this context
@@ -329,6 +333,7 @@ struct Global {
   std::atomic<size_t> host_split_min_n{(size_t)1 << 19};
   std::atomic<uint32_t> sc_fused_sum{1};          // option sc_fused_sum: 1 = a sum-check round is ONE launch (the last block sums the partials, k_sc_pass); 0 = pass + final-sum launch
   std::atomic<uint32_t> sc_side_streams{1};       // option sc_side_streams: the batch prover runs claim i > 0 on its own stream (0: all on the context's)
+  std::atomic<uint32_t> sc_prelaunch{1};          // option sc_prelaunch: the cubic / quad_prod provers enqueue their small passes a round early; the pass takes its challenge from pinned memory (0: launched when the challenge is known)
   std::atomic<uint32_t> sc_host_parts{1};         // option sc_host_parts: passes of <= 64 blocks send per-block partial sums to the host, which adds them (0: last-block ticket)
   std::atomic<uint32_t> sc_quad{1};               // option sc_quad: passes of <= 2^12 indices of the cubic / quad_prod provers run four lanes per index (0: one)
   std::atomic<uint32_t> sc_host_tail{7};          // option sc_host_tail: the sum-check provers finish on the host once the tables hold <= 2^this elements (0: only the final values come over; max 8)

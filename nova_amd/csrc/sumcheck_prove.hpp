@@ -28,6 +28,9 @@
 // index per thread.
 #pragma once
 #include <array>
+#include <thread>
+
+#include <immintrin.h>
 
 #include "sc_host.hpp"
 
@@ -125,7 +128,43 @@ template <int FID> struct ScSmallArgs {
   Fp<FID> r, nk;
   uint32_t shift, mask, hq, bind, seq;
   uint32_t* slot;
+  // a pass enqueued BEFORE its challenge exists (ScPass::prelaunch): r is not in the arguments -- the kernel waits for the host to
+  // write it to this 64-byte line (uncached device memory written through the BAR): word 0 = chal_seq when it is there, word 1 != 0: give up, words 4..12 = r's limbs
+  const uint32_t* chal = nullptr;
+  uint32_t chal_seq = 0;
 };
+// The challenge of a pre-launched pass.  Thread 0 of every block reads the WHOLE line per poll (four 16-byte loads in flight together;
+// ten dependent word reads of pinned host memory made the first version of this 25 us slower than launching late); the host writes the
+// limbs first, fences, then the sequence word: a line read that shows the new sequence word shows the limbs.  false:
+// the host said stop, or nothing came for kChalTimeoutTicks of the 100 MHz wall clock -- the block leaves without touching the
+// tables or the mailbox (the host then fails its own wait).
+static constexpr uint64_t kChalTimeoutTicks = 200000000ull;  // 2 s
+template <int FID> __device__ __forceinline__ bool sc_challenge(const ScSmallArgs<FID>& a, Fp<FID>& r, uint32_t* s_r /* LDS, 10 words */) {
+  r = a.r;
+  if (!a.chal) return true;
+  if (threadIdx.x == 0) {
+    const uint64_t t0 = wall_clock64();
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const volatile u32x4* line = reinterpret_cast<const volatile u32x4*>(a.chal);  // (volatile: re-read every time round)
+    uint32_t ok = 0;
+    u32x4 q0, q1, q2, q3;
+    for (uint32_t spin = 0;; spin++) {
+      q0 = line[0], q1 = line[1], q2 = line[2], q3 = line[3];
+      if (q0.x == a.chal_seq) {
+        ok = q0.y == 0 ? 1u : 0u;
+        break;
+      }
+      if ((spin & 63u) == 63u && wall_clock64() - t0 > kChalTimeoutTicks) break;
+    }
+    s_r[0] = q1.x, s_r[1] = q1.y, s_r[2] = q1.z, s_r[3] = q1.w, s_r[4] = q2.x, s_r[5] = q2.y, s_r[6] = q2.z, s_r[7] = q2.w, s_r[8] = q3.x;
+    s_r[9] = ok;
+  }
+  __syncthreads();
+  if (!s_r[9]) return false;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = s_r[i];
+  return true;
+}
 // ---- FOUR lanes per index (QUAD): the short chain --------------------------------------------------------------------------
 // A small pass is one index per thread and pure latency: 6 binds + 5 products in a row for the cubic prover (~1.2 us each at one
 // wave per SIMD), 4 + 2 for quad_prod.  With four lanes per index the binds run side by side (lane t binds table t; the fourth lane of
@@ -228,10 +267,13 @@ __device__ __forceinline__ void sc_quad_loop(const ScSmallArgs<FID>& a, uint32_t
   s1 = sc_sel<FID>(role == 1, acc, F::zero());
 }
 
-template <int FID, int MODE, bool QUAD = false> __global__ __launch_bounds__(256) void k_sc_small(ScSmallArgs<FID> a) {
+template <int FID, int MODE, bool QUAD = false> __global__ __launch_bounds__(256) void k_sc_small(ScSmallArgs<FID> a_in) {
+  ScSmallArgs<FID> a = a_in;  // (a.r is filled in from the challenge line when the pass was pre-launched)
   using F = Fp<FID>;
   __shared__ uint32_t lds[72];
+  __shared__ uint32_t s_r[10];
   F s0 = F::zero(), s1 = F::zero();
+  if (!sc_challenge<FID>(a_in, a.r, s_r)) return;
   uint32_t pending = 0;
   if constexpr (QUAD) sc_quad_loop<FID, MODE>(a, threadIdx.x >> 2, 64u, s0, s1);
   for (uint32_t id = threadIdx.x; !QUAD && id < a.hq; id += 256u) {
@@ -296,10 +338,12 @@ template <int FID> struct ScPassArgs {
 static constexpr uint32_t kHostPartBlocks = 64, kHostPartWords = 32;
 template <int FID, int MODE, bool QUAD = false> __global__ __launch_bounds__(256) void k_sc_pass(ScPassArgs<FID> p) {
   using F = Fp<FID>;
-  const ScSmallArgs<FID>& a = p.s;
+  ScSmallArgs<FID> a = p.s;
   __shared__ uint32_t lds[72];
   __shared__ uint32_t s_last;
+  __shared__ uint32_t s_r[10];
   F s0 = F::zero(), s1 = F::zero();
+  if (!sc_challenge<FID>(p.s, a.r, s_r)) return;  // (no ticket, no partials: the pass never completes and the host's wait fails)
   uint32_t pending = 0;
   if constexpr (QUAD) sc_quad_loop<FID, MODE>(a, blockIdx.x * 64u + (threadIdx.x >> 2), gridDim.x * 64u, s0, s1);
   for (uint32_t id = blockIdx.x * 256u + threadIdx.x; !QUAD && id < a.hq; id += gridDim.x * 256u) {
@@ -460,7 +504,7 @@ struct ScProf {  // wall-clock split of one prover call (profiling on): where a 
 };
 static constexpr uint32_t kTailMaxLog2 = 8, kTailMax = 1u << kTailMaxLog2;  // the longest table the tail takes over
 static constexpr size_t kMailBytes = kMailSlots * kMailSlotWords * 4, kTailSlotBytes = (size_t)kTailMax * 32;
-static constexpr size_t kPartSlotBytes = (size_t)kHostPartBlocks * kHostPartWords * 4;
+static constexpr size_t kPartSlotBytes = (size_t)kHostPartBlocks * kHostPartWords * 4, kChalSlotBytes = 256;
 
 template <int FID> struct ScDev {
   using F = Fp<FID>;
@@ -506,6 +550,59 @@ template <int FID> struct ScDev {
   uint32_t* slot_dev(uint32_t s) const { return (uint32_t*)c.mail_dev + (size_t)s * kMailSlotWords; }
   uint32_t* tail_dev(uint32_t s) const { return (uint32_t*)(c.mail_dev + kMailBytes + (size_t)s * kTailSlotBytes); }
   const uint32_t* tail_host(uint32_t s) const { return (const uint32_t*)(c.mail + kMailBytes + (size_t)s * kTailSlotBytes); }
+  // challenge lines of the pre-launched passes: UNCACHED DEVICE memory that the host writes through the large BAR, so that every
+  // block of a waiting pass polls local memory (one poller over PCIe answers in 2.7 us, profiles/r05_spartan/signal_ubench.txt, but
+  // the up to 64 blocks of a pass polling pinned host memory together made a pre-launched round 5 us SLOWER than a launched one).
+  // nullptr: no large BAR (or the allocation failed) -- then nothing is pre-launched.
+  uint32_t* chal_line(uint32_t s) {
+    if (!c.chal_tried) {
+      c.chal_tried = true;
+      int large_bar = 0, cur = 0;  // (the lease made the context's device current on this thread)
+      void* p = nullptr;
+      if (hipGetDevice(&cur) == hipSuccess && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, cur) == hipSuccess && large_bar &&
+          hipExtMallocWithFlags(&p, kMailSlots * kChalSlotBytes, hipDeviceMallocUncached) == hipSuccess) {
+        if (hipMemsetAsync(p, 0, kMailSlots * kChalSlotBytes, c.stream) == hipSuccess && hipStreamSynchronize(c.stream) == hipSuccess) c.chal = (uint32_t*)p;
+        else (void)hipFree(p);
+      }
+      (void)hipGetLastError();
+    }
+    return c.chal ? c.chal + (size_t)s * (kChalSlotBytes / 4) : nullptr;
+  }
+  // the CPU's stores to BAR memory are write-combined: a fence between the payload and the sequence word, and one behind it to push it out
+  static void chal_write(uint32_t* line, const uint32_t* limbs9, uint32_t abort_word, uint32_t seq) {
+    volatile uint32_t* l = line;
+    if (limbs9)
+      for (int i = 0; i < 9; i++) l[4 + i] = limbs9[i];
+    l[1] = abort_word;
+    _mm_sfence();
+    l[0] = seq;
+    _mm_sfence();
+  }
+  // Pre-launched passes waiting for a challenge (chal_seq per slot, 0: none).  While one waits, no stream of this call may be
+  // synchronised -- the wait would sit behind a kernel that waits for THIS thread -- so the mailbox polls keep polling (up to
+  // kArmedPollSeconds, yielding) instead of giving up after sc_poll_us, and anything that must synchronise cancels them first.
+  uint32_t armed_seq[kMailSlots] = {};
+  static constexpr int kArmedPollSeconds = 4;
+  bool any_armed() const {
+    for (uint32_t q : armed_seq)
+      if (q) return true;
+    return false;
+  }
+  void cancel_armed() noexcept {
+    for (uint32_t s = 0; s < kMailSlots; s++)
+      if (armed_seq[s]) {
+        chal_write(chal_line(s), nullptr, 1u, armed_seq[s]);
+        armed_seq[s] = 0;
+      }
+  }
+  // has a poll that started at t0 gone on long enough?  (spin: the caller's iteration count, to look at the clock only now and then)
+  bool poll_over(const std::chrono::steady_clock::time_point& t0, uint32_t spin, uint32_t poll_us) const {
+    if ((spin & 1023u) != 1023u) return false;
+    const auto el = std::chrono::steady_clock::now() - t0;
+    if (!any_armed()) return el > std::chrono::microseconds(poll_us);
+    if (el > std::chrono::microseconds(poll_us)) std::this_thread::yield();
+    return el > std::chrono::seconds(kArmedPollSeconds);
+  }
   // per-block partial sums of the host-summed passes (their own region: a sequence word must never be compared with table data)
   uint32_t* part_dev(uint32_t s) const { return (uint32_t*)(c.mail_dev + kMailBytes + kMailSlots * kTailSlotBytes + (size_t)s * kPartSlotBytes); }
   const uint32_t* part_host(uint32_t s) const {
@@ -533,7 +630,7 @@ template <int FID> struct ScDev {
               ok = true;
               break;
             }
-            if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(poll_us)) break;
+            if (poll_over(t0, spin, poll_us)) break;
           }
         }
         if (!ok) {
@@ -564,7 +661,7 @@ template <int FID> struct ScDev {
           ok = true;
           break;
         }
-        if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(poll_us)) break;
+        if (poll_over(t0, spin, poll_us)) break;
       }
     }
     if (!ok) {
@@ -576,11 +673,13 @@ template <int FID> struct ScDev {
   }
   // the context's stream and the side streams the batch prover put work on
   void sync_all() {
+    cancel_armed();  // (a waiting pre-launched pass leaves at once; the proof is over if there was one)
     stream_wait(c.stream);
     for (hipStream_t sd : c.side)
       if (sd) HIPCHK(hipStreamSynchronize(sd));
   }
   void sync_all_quiet() noexcept {
+    cancel_armed();
     (void)hipStreamSynchronize(c.stream);
     for (hipStream_t sd : c.side)
       if (sd) (void)hipStreamSynchronize(sd);
@@ -749,35 +848,43 @@ template <int FID, int MODE> struct ScPass {
     HIPCHK(hipGetLastError());
     return seq;
   }
+  // one launch: bind + sums of a round (fused-sum forms).  Four lanes per index (sc_quad_loop) up to kScQuadMaxHq indices -- one
+  // block up to 64 of them, 64 per block beyond --, else one lane per index: one block up to kScSmallHq, k_sc_pass beyond; passes of
+  // <= kHostPartBlocks blocks leave the adding of their partials to the host.
+  // returns the number of blocks whose partials the host is to add for this pass (0: the sums arrive added up)
+  uint32_t launch_bind(const ScSmallArgs<FID>& x, uint32_t hq) {
+    hipStream_t s = stream;
+    uint32_t host_blocks = 0;
+    const bool fused = G.sc_fused_sum.load(std::memory_order_relaxed) != 0;
+    if (kQuadForm && quad_on() && (hq <= 64 || (fused && hq <= kScQuadMaxHq))) {
+      if (hq <= 64) {
+        hipLaunchKernelGGL((k_sc_small<FID, MODE, kQuadForm>), dim3(1), dim3(256), 0, s, x);
+      } else {
+        const uint32_t blocks = (hq + 63) / 64;
+        ScPassArgs<FID> y{x, partial, partial + kScPartialBytes / 4 - 64};
+        if (host_parts_on() && blocks <= kHostPartBlocks) y.host_part = h.part_dev(slot), host_blocks = blocks;
+        hipLaunchKernelGGL((k_sc_pass<FID, MODE, kQuadForm>), dim3(blocks), dim3(256), 0, s, y);
+      }
+    } else if (hq <= kScSmallHq) {
+      hipLaunchKernelGGL((k_sc_small<FID, MODE>), dim3(1), dim3(256), 0, s, x);
+    } else {
+      const uint32_t blocks = sc_blocks_bind(hq);
+      ScPassArgs<FID> y{x, partial, partial + kScPartialBytes / 4 - 64};  // the ticket: a zero word at the end of this instance's scratch
+      if (host_parts_on() && blocks <= kHostPartBlocks) y.host_part = h.part_dev(slot), host_blocks = blocks;
+      hipLaunchKernelGGL((k_sc_pass<FID, MODE>), dim3(blocks), dim3(256), 0, s, y);
+    }
+    HIPCHK(hipGetLastError());
+    h.launched();
+    return host_blocks;
+  }
   // bind the tables (len elements each) with r in place AND the sums of the next round over the bound halves
   uint32_t bind_sums(size_t len, const H& rh, const Tables& t) {
     const uint32_t hq = (uint32_t)(len / 4), seq = h.next_seq();
     const F r = rh.to_device();
     hipStream_t s = stream;
     const bool fused = G.sc_fused_sum.load(std::memory_order_relaxed) != 0;
-    if (kQuadForm && quad_on() && (hq <= 64 || (fused && hq <= kScQuadMaxHq))) {
-      // four lanes per index (sc_quad_loop): one block up to 64 indices, 64 indices per block beyond
-      ScSmallArgs<FID> x{A, B, C, A, B, C, t.eqL, t.eqR, r, nk, t.shift, t.mask, hq, 1u, seq, h.slot_dev(slot)};
-      if (hq <= 64) {
-        hipLaunchKernelGGL((k_sc_small<FID, MODE, kQuadForm>), dim3(1), dim3(256), 0, s, x);
-      } else {
-        const uint32_t blocks = (hq + 63) / 64;
-        ScPassArgs<FID> y{x, partial, partial + kScPartialBytes / 4 - 64};
-        if (host_parts_on() && blocks <= kHostPartBlocks) y.host_part = h.part_dev(slot), h.parts[slot] = blocks;
-        hipLaunchKernelGGL((k_sc_pass<FID, MODE, kQuadForm>), dim3(blocks), dim3(256), 0, s, y);
-      }
-      h.launched();
-    } else if (hq <= kScSmallHq) {
-      ScSmallArgs<FID> x{A, B, C, A, B, C, t.eqL, t.eqR, r, nk, t.shift, t.mask, hq, 1u, seq, h.slot_dev(slot)};
-      hipLaunchKernelGGL((k_sc_small<FID, MODE>), dim3(1), dim3(256), 0, s, x);
-      h.launched();
-    } else if (fused) {
-      const uint32_t blocks = sc_blocks_bind(hq);
-      ScPassArgs<FID> x{ScSmallArgs<FID>{A, B, C, A, B, C, t.eqL, t.eqR, r, nk, t.shift, t.mask, hq, 1u, seq, h.slot_dev(slot)}, partial,
-                        partial + kScPartialBytes / 4 - 64};  // the ticket: a zero word at the end of this instance's scratch
-      if (host_parts_on() && blocks <= kHostPartBlocks) x.host_part = h.part_dev(slot), h.parts[slot] = blocks;
-      hipLaunchKernelGGL((k_sc_pass<FID, MODE>), dim3(blocks), dim3(256), 0, s, x);
-      h.launched();
+    if (fused || hq <= kScSmallHq) {
+      h.parts[slot] = launch_bind(ScSmallArgs<FID>{A, B, C, A, B, C, t.eqL, t.eqR, r, nk, t.shift, t.mask, hq, 1u, seq, h.slot_dev(slot)}, hq);
     } else {
       const uint32_t blocks = sc_blocks_bind(hq);
       if (MODE == 4) {
@@ -793,6 +900,40 @@ template <int FID, int MODE> struct ScPass {
     }
     HIPCHK(hipGetLastError());
     return seq;
+  }
+  // ---- a pass enqueued before its challenge exists.  Between two small passes lie ~13 us (timeline_2p20.txt): the sums reach the
+  // host, algebra, transcript, LAUNCH, first wave -- the last two are 8-9 us on an idle queue.  Everything a bind + sums pass needs
+  // except r is known a round ahead (tables, sizes, the eq tables of its round, its mailbox sequence): it is enqueued behind the
+  // pass before it, starts the moment that one ends, and takes r from a line of pinned memory (sc_challenge); the host's "launch"
+  // becomes one 48-byte write.  Only passes of at most kPrelaunchMaxHq indices (<= 64 polling blocks); never when the coming
+  // round may need the fallback's extra pass on this stream (the caller checks Eq::l1p_zero) or when the caller asked for
+  // synchronising waits (sc_poll_us = 0); every pre-launched pass is sent its challenge or cancelled, and one that hears nothing
+  // leaves after 2 s.
+  static constexpr uint32_t kPrelaunchMaxHq = 1u << 14;
+  uint32_t pre_seq = 0, pre_parts = 0;  // mailbox sequence / host-added blocks of the pass in flight (h.armed_seq[slot]: its challenge sequence)
+  bool armed() const { return h.armed_seq[slot] != 0; }
+  bool can_prelaunch(size_t len) {
+    return G.sc_prelaunch.load(std::memory_order_relaxed) != 0 && G.sc_fused_sum.load(std::memory_order_relaxed) != 0 &&
+           G.sc_poll_us.load(std::memory_order_relaxed) != 0 && len / 4 >= 1 && len / 4 <= kPrelaunchMaxHq && h.chal_line(slot) != nullptr;
+  }
+  void prelaunch(size_t len, const Tables& t) {
+    const uint32_t hq = (uint32_t)(len / 4), seq = h.next_seq(), cs = h.next_seq();
+    ScSmallArgs<FID> x{A, B, C, A, B, C, t.eqL, t.eqR, F::zero(), nk, t.shift, t.mask, hq, 1u, seq, h.slot_dev(slot)};
+    x.chal = h.chal_line(slot), x.chal_seq = cs;
+    pre_parts = launch_bind(x, hq);
+    pre_seq = seq;
+    h.armed_seq[slot] = cs;
+  }
+  // the challenge for the pass in flight; returns the mailbox sequence its sums will carry
+  uint32_t send(const H& rh) {
+    const F r = rh.to_device();
+    ScDev<FID>::chal_write(h.chal_line(slot), r.l, 0u, h.armed_seq[slot]);
+    h.armed_seq[slot] = 0;
+    h.parts[slot] = pre_parts;  // (only now: until here the slot's pending result was the pass before)
+    return pre_seq;
+  }
+  ~ScPass() {
+    if (armed()) h.cancel_armed();
   }
   // the hand-over: bind with r (rp == nullptr: no bind) and land the tables of `half` elements in the tail areas; fills out[]
   void to_host(size_t half, const H* rp, std::vector<H>* out[3]) {
@@ -871,6 +1012,13 @@ static void sc_prove_t(Ctx& c, const void* claim, const void* taus, size_t num_r
       typename ScEqDev<FID>::Tables tb = MODE == 3 ? eqd.tables(1) : typename ScEqDev<FID>::Tables{nullptr, nullptr, 0, 0};
       uint32_t seq = pass.sums(pass.A, pass.B, pass.C, len, tb);
       if (MODE == 3) eq.prepare();  // the round's inversion runs under the pass (sc_host.hpp Eq::prepare)
+      // the pass of round `next_round` (it binds tables of cur_len elements) goes out a round early when it can (ScPass::prelaunch)
+      auto maybe_prelaunch = [&](size_t cur_len, uint32_t next_round) {
+        if (cur_len / 2 <= h.tail_len || !pass.can_prelaunch(cur_len)) return;  // (the hand-over is never pre-launched)
+        if (MODE == 3 && eq.l1p_zero) return;  // the round in between takes the fallback: its extra pass needs this stream free
+        pass.prelaunch(cur_len, MODE == 3 ? eqd.tables(next_round) : typename ScEqDev<FID>::Tables{nullptr, nullptr, 0, 0});
+      };
+      maybe_prelaunch(len, 2);
       for (;; j++) {
         const uint32_t* res = h.wait(0, seq);
         const H t0 = h.raw(res, pass.factors(tb)), t1 = h.raw(res + 8, pass.factors(tb));
@@ -893,9 +1041,10 @@ static void sc_prove_t(Ctx& c, const void* claim, const void* taus, size_t num_r
           break;
         }
         if (MODE == 3) tb = eqd.tables(j + 1);
-        seq = pass.bind_sums(len, r, tb);
+        seq = pass.armed() ? pass.send(r) : pass.bind_sums(len, r, tb);
         if (MODE == 3) eq.prepare();
         len /= 2;
+        maybe_prelaunch(len, j + 2);
       }
     }
     if (j <= l) {

@@ -206,6 +206,46 @@ def test_four_lanes_per_index_and_one_lane_per_index_agree(nmx):
         assert L.nmx_set_option(b"sc_host_tail", 7) == 0
 
 
+def test_prelaunched_passes_and_launched_passes_agree(nmx):
+    """option sc_prelaunch: a small pass of the cubic / quad_prod provers is enqueued a round early and takes its challenge from a line
+    of pinned memory (default), or is launched once the challenge is known.  Sizes around the limits (pre-launch from 2^14 indices per
+    pass down, the four-lane form from 2^12, one block from 64, the host tail at 128 elements), the fallback rounds (never pre-launched
+    over), host-added and ticket partials -- and a transcript that fails while a pre-launched pass is waiting: the pass is cancelled,
+    the call reports the failure, the next proofs are right."""
+    import nova_amd
+    from nova_amd import _lib, fieldvec as fv
+    L = _lib.lib()
+    p = fc.FIELDS[1]
+    try:
+        for n_pass, pre in enumerate((1, 0, 1)):
+            assert L.nmx_set_option(b"sc_prelaunch", pre) == 0
+            for l in ((8, 9, 10, 13, 16) if n_pass < 2 else (13,)):
+                both(sp.check_cubic3, g_cubic3(), o_cubic3, 1, l, seed=80 + l, brute=False)
+                both(sp.check_quad_prod, g_quad, o_quad, 1, l + 1, seed=90 + l)
+            both(sp.check_cubic3, g_cubic3(), o_cubic3, 1, 12, seed=82, force={0: 0, 3: 1, 7: p - 1, 9: 0}, brute=False)
+            both(sp.check_cubic3, g_cubic3(), o_cubic3, 1, 11, seed=83, taus=[0] * 11, brute=False)
+            assert L.nmx_set_option(b"sc_host_parts", 0) == 0
+            both(sp.check_cubic3, g_cubic3(), o_cubic3, 1, 14, seed=84, brute=False)
+            assert L.nmx_set_option(b"sc_host_parts", 1) == 0
+        # a transcript that gives up in round 4 of a 2^13 instance: the next pass is waiting for its challenge by then
+        A, B = fc.rand_vec(1, 1 << 13, 1), fc.rand_vec(1, 1 << 13, 2)
+        calls = []
+
+        def gives_up(_coeffs):
+            calls.append(1)
+            if len(calls) == 4:
+                raise RuntimeError("transcript refused")
+            return sp.le(7 + len(calls))
+        with pytest.raises(nova_amd.NmxError):
+            fv.sumcheck_prove_quad_prod(1, sp.le(5), 13, dev(A), dev(B), gives_up)
+        assert len(calls) == 4
+        both(sp.check_quad_prod, g_quad, o_quad, 1, 13, seed=85)
+        both(sp.check_cubic3, g_cubic3(), o_cubic3, 1, 13, seed=86, brute=False)
+    finally:
+        assert L.nmx_set_option(b"sc_prelaunch", 1) == 0
+        assert L.nmx_set_option(b"sc_host_parts", 1) == 0
+
+
 def test_host_added_partials_and_ticket_passes_agree(nmx):
     """option sc_host_parts: a pass of <= 64 blocks sends every block's partial sums to the host, which adds them up (default); 0: the
     block that draws the last ticket does.  Sizes around the 64-block limits of the one-lane (2^14 indices) and four-lane (2^12) forms,
