@@ -360,3 +360,55 @@ def test_spartan_prove_replay_matches_the_oracle(nmx):
     assert all(out["proof_verifies"].values())
     assert out["config"]["rounds"] == [12, 13, 12]
     assert set(out["provers"]) == {"sumcheck_outer", "sumcheck_inner", "sumcheck_batch"}
+
+
+def test_provers_and_commitments_from_several_threads(nmx):
+    """Six host threads at once -- cubic, quad_prod and batch provers (each leases its own context: mailbox, side streams, challenge
+    lines of its pre-launched passes), begun commitments and synchronous ones on the same GPU.  Every result equals what the same call
+    gives alone (expected values computed first, single-threaded, through the oracle)."""
+    import threading
+    import nova_amd
+    from oracle import pyref as R
+    from tests import util
+    c = R.BN254_G1
+    n = 6000
+    bases = cref.sequential_bases(c, 21, n).copy()
+    ck = nmx.CommitmentKey.from_host(c.cid, bases)
+    ce = nmx.CommitmentEngine(c.cid)
+    v = util.random_scalars(c.cid, n, seed=9)
+    want_com = (lambda r: (r.xy, int(r.is_inf)))(ce.commit(ck, v))
+    jobs = [
+        (sp.check_cubic3, g_cubic3(), o_cubic3, (1, 12), dict(seed=201, brute=False)),
+        (sp.check_cubic3, g_cubic3(), o_cubic3, (3, 10), dict(seed=202, brute=False)),
+        (sp.check_quad_prod, g_quad, o_quad, (1, 14), dict(seed=203)),
+        (sp.check_quad_prod, g_quad, o_quad, (0, 11), dict(seed=204)),
+        (sp.check_batch_eval, g_batch, o_batch, (1, [12, 9, 13]), dict(seed=205)),
+    ]
+    want = [chk(o, *a, **kw) for chk, _g, o, a, kw in jobs]
+    errs = []
+
+    def prover(i):
+        try:
+            chk, g, _o, a, kw = jobs[i]
+            for _ in range(3):
+                assert chk(g, *a, **kw) == want[i], i
+        except Exception as e:   # noqa: BLE001 -- reported by the main thread
+            errs.append((i, repr(e)))
+
+    def committer():
+        try:
+            for _ in range(12):
+                t = ce.commit_begin(ck, v)
+                got = ce.commit(ck, v)
+                assert (got.xy, int(got.is_inf)) == want_com
+                got = t.finish()
+                assert (got.xy, int(got.is_inf)) == want_com
+        except Exception as e:   # noqa: BLE001
+            errs.append(("commit", repr(e)))
+    ths = [threading.Thread(target=prover, args=(i,)) for i in range(len(jobs))] + [threading.Thread(target=committer)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    ck.close()
