@@ -774,6 +774,30 @@ def extras(out, args, torch, L, ck, host_scalars, dev_scalars):
     }
     L.nmx_cache_clear()
     del bm, sm
+    # (2b) the scalar sets of the reference's own bench (benches/commit.rs:33-110: u1, u10, u16, u32, u64 beside `random`; SURVEY.md 8(d)
+    # config 2) through the same call, HBM-resident field scalars, each checked against the oracle at full size
+    try:
+        sets = {}
+        ok_all = True
+        keyb = ck.read(0, n)
+        prep = cref.Prepared(cid, keyb, n)
+        cref.set_threads(effective_cpus())
+        for kind in ("u1", "u10", "u16", "u32", "u64"):
+            hs = util.scalar_set(cid, n, kind, seed=util.SEED + 77)
+            ds = torch.from_numpy(hs).cuda()
+            ms, r = med_ms(lambda: g.vartime_multiscalar_mul(ds, ck))
+            okk = (r.xy, int(r.is_inf)) == prep.msm(hs, n)
+            ok_all = ok_all and okk
+            sets[kind] = {"ms": round(ms, 4), "value": n / (ms * 1e-3), "gpu_matches_cpu": okk}
+            del ds
+        sets["random"] = {"ms": round(out["ms_per_step"], 4), "value": out["value"]}
+        sets["what"] = ("commit(ck, v) with r = 0 at 2^20 for the scalar distributions of benches/commit.rs (values of 1 / 10 / 16 / 32 / 64 bits stored as "
+                        "field scalars, as the reference's bench does), key and scalars resident in HBM, median of 5")
+        sets["all_match_cpu"] = ok_all
+        out["commit_rs_sets"] = sets
+        del prep, keyb
+    except Exception as e:                                 # never lose the headline to an auxiliary block
+        out["commit_rs_sets"] = {"error": repr(e)}
     # (3) N = 1 anchor of the configs[2] curve: 2^24 pairs on one GPU (c = 20 tables, 13 GiB)
     try:
         n24 = 1 << 24
