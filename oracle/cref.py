@@ -59,6 +59,7 @@ def lib():
         L.ref_mle_multi_evaluate.argtypes = [ctypes.c_int, vp, sz, sz, vp, vp]
         L.ref_spmv_transposed.argtypes = [ctypes.c_int, vp, vp, vp, sz, sz, vp, vp]
         L.ref_batch_invert.argtypes = [ctypes.c_int, vp, sz, vp]
+        L.ref_unipoly_from_evals.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]
         L.ref_sumcheck_prove_cubic3.argtypes = [ctypes.c_int, vp, vp, sz, vp, vp, vp, TRANSCRIPT_FN, vp, vp, vp, vp]
         L.ref_sumcheck_prove_quad_prod.argtypes = [ctypes.c_int, vp, sz, vp, vp, TRANSCRIPT_FN, vp, vp, vp, vp]
         L.ref_sumcheck_prove_batch_eval.argtypes = [ctypes.c_int, vp, vp, vp, vp, vp, sz, TRANSCRIPT_FN, vp, vp, vp, vp]
@@ -393,3 +394,15 @@ def batch_invert(fid, v, n):
     rc = lib().ref_batch_invert(fid, pv, n, out.ctypes.data)
     assert rc in (0, 1)
     return None if rc else out[: 32 * n].tobytes()
+
+
+def unipoly_from_evals(fid, evals, at):
+    """UniPoly::from_evals_deg2 / _deg3 + evaluate (src/spartan/polys/univariate.rs:90-113, 140-149) on integers: -> (coefficients, value at `at`)."""
+    deg = len(evals) - 1
+    ev = b"".join(int(x).to_bytes(32, "little") for x in evals)
+    pe, _e = _buf(ev)
+    pa, _a = _buf(int(at).to_bytes(32, "little"))
+    co, val = np.zeros(32 * (deg + 1), dtype=np.uint8), np.zeros(32, dtype=np.uint8)
+    assert lib().ref_unipoly_from_evals(fid, deg, pe, pa, co.ctypes.data, val.ctypes.data) == 0
+    cb = co.tobytes()
+    return [int.from_bytes(cb[32 * i: 32 * i + 32], "little") for i in range(deg + 1)], int.from_bytes(val.tobytes(), "little")

@@ -1002,6 +1002,35 @@ static void unipoly_eval(const field_t* F, fe* out, const fe* coeffs, size_t n, 
   for (size_t i = 1; i < n; i++) { fe_mul(F, &t, &power, &coeffs[i]); fe_add(F, &eval, &eval, &t); fe_mul(F, &power, &power, r); }
   *out = eval;
 }
+static fe two_inv(const field_t* F) { fe two, r; fe_from_u64(F, &two, 2); fe_inv(F, &r, &two); return r; }
+/* UniPoly::from_evals_deg2 (src/spartan/polys/univariate.rs:90-99): evals = [f(0), f(1), quadratic coefficient] -> [c, b, a] */
+static void unipoly_from_evals_deg2(const field_t* F, const fe* e0, const fe* e1, const fe* a, fe co[3]) {
+  co[0] = *e0; co[2] = *a;
+  fe_sub(F, &co[1], e1, a); fe_sub(F, &co[1], &co[1], e0);       /* b = f(1) - a - c */
+}
+/* UniPoly::from_evals_deg3 (univariate.rs:103-113): evals = [f(0), f(1), cubic coefficient, f(-1)] -> [d, c, b, a] */
+static void unipoly_from_evals_deg3(const field_t* F, const fe* e0, const fe* e1, const fe* a, const fe* em1, fe co[4]) {
+  const fe tinv = two_inv(F);
+  fe t;
+  co[0] = *e0; co[3] = *a;
+  fe_add(F, &t, e1, em1); fe_mul(F, &co[2], &t, &tinv); fe_sub(F, &co[2], &co[2], e0);          /* b = (f(1) + f(-1)) / 2 - d */
+  fe_sub(F, &co[1], e1, a); fe_sub(F, &co[1], &co[1], e0); fe_sub(F, &co[1], &co[1], &co[2]);   /* c = f(1) - a - d - b */
+}
+/* test hook for the reference's known answers (univariate.rs:284-355: 2x^2+3x+1 from [1, 6, 2]; x^3+2x^2+3x+1 from [1, 7, 1, -1]):
+ * evals = deg + 1 canonical elements in the order the constructors take them; coefficients (deg + 1) and the value at `at` out */
+int ref_unipoly_from_evals(int field, int deg, const uint8_t* evals, const uint8_t* at, uint8_t* out_coeffs, uint8_t* out_value) {
+  const field_t* F = field_by_id(field); if (!F || (deg != 2 && deg != 3)) return -1;
+  fe* e = load_vec_mont(F, evals, (size_t)deg + 1);
+  fe* x = load_vec_mont(F, at, 1);
+  fe co[4], v;
+  if (deg == 2) unipoly_from_evals_deg2(F, &e[0], &e[1], &e[2], co);
+  else unipoly_from_evals_deg3(F, &e[0], &e[1], &e[2], &e[3], co);
+  unipoly_eval(F, &v, co, (size_t)deg + 1, &x[0]);
+  for (int i = 0; i <= deg; i++) st_canon(F, out_coeffs + 32 * i, &co[i]);
+  st_canon(F, out_value, &v);
+  free(e); free(x);
+  return 0;
+}
 /* transcript round trip: coefficients out (canonical), challenge in */
 static int ask_challenge(const field_t* F, ref_transcript_fn cb, void* ctx, const fe* coeffs, size_t n, fe* r, uint8_t* polys_out,
                          uint8_t* r_out) {
@@ -1145,7 +1174,6 @@ static void eq_eval_points(const field_t* F, const eq_inst* q, int mode, const f
   }
   fe_mul(F, s_m1, eqm1, p); fe_mul(F, s_m1, s_m1, &tm1);
 }
-static fe two_inv(const field_t* F) { fe two, r; fe_from_u64(F, &two, 2); fe_inv(F, &r, &two); return r; }
 
 /* SumcheckProof::prove_cubic_with_three_inputs (src/spartan/sumcheck.rs:446-507).  A, B, C: 2^num_rounds canonical elements each
  * (not modified: the reference binds its own copies in place).  out_polys: num_rounds x 4 coefficients (UniPoly, constant term
@@ -1157,16 +1185,13 @@ int ref_sumcheck_prove_cubic3(int field, const uint8_t* claim, const uint8_t* ta
   fe *a = load_vec_mont(F, A, len), *b = load_vec_mont(F, B, len), *c = load_vec_mont(F, C, len);
   eq_inst* q = eq_new(F, taus, num_rounds);
   fe claim_per_round; ld_mont(F, &claim_per_round, claim);
-  const fe tinv = two_inv(F);
   int rc = 0;
   for (size_t j = 0; j < num_rounds && rc == 0; j++) {
     fe s0, lead, sm1, s1;
     eq_eval_points(F, q, 3, a, b, c, len, &claim_per_round, &s0, &lead, &sm1);
     fe_sub(F, &s1, &claim_per_round, &s0);                     /* evals = [s0, claim - s0, lead, s(-1)] */
-    fe co[4], t;                                               /* UniPoly::from_evals_deg3 (univariate.rs:103-113) */
-    co[0] = s0; co[3] = lead;
-    fe_add(F, &t, &s1, &sm1); fe_mul(F, &co[2], &t, &tinv); fe_sub(F, &co[2], &co[2], &s0);      /* b = (s1 + s(-1)) / 2 - d */
-    fe_sub(F, &co[1], &s1, &lead); fe_sub(F, &co[1], &co[1], &s0); fe_sub(F, &co[1], &co[1], &co[2]);
+    fe co[4];
+    unipoly_from_evals_deg3(F, &s0, &s1, &lead, &sm1, co);
     fe r;
     rc = ask_challenge(F, cb, ctx, co, 4, &r, out_polys ? out_polys + 128 * j : NULL, out_r ? out_r + 32 * j : NULL);
     if (rc) break;
@@ -1208,9 +1233,9 @@ int ref_sumcheck_prove_quad_prod(int field, const uint8_t* claim, size_t num_rou
     }
     fe e0, bc; memset(&e0, 0, sizeof e0); memset(&bc, 0, sizeof bc);
     for (int t = 0; t < T; t++) { fe_add(F, &e0, &e0, &part[2 * t]); fe_add(F, &bc, &bc, &part[2 * t + 1]); }
-    fe co[3], s1;                                              /* from_evals_deg2([e0, claim - e0, bc]) (univariate.rs:90-99) */
+    fe co[3], s1;                                              /* from_evals_deg2([e0, claim - e0, bc]) */
     fe_sub(F, &s1, &claim_per_round, &e0);
-    co[0] = e0; co[2] = bc; fe_sub(F, &co[1], &s1, &bc); fe_sub(F, &co[1], &co[1], &e0);
+    unipoly_from_evals_deg2(F, &e0, &s1, &bc, co);
     fe r;
     rc = ask_challenge(F, cb, ctx, co, 3, &r, out_polys ? out_polys + 96 * j : NULL, out_r ? out_r + 32 * j : NULL);
     if (rc) break;
@@ -1259,7 +1284,8 @@ int ref_sumcheck_prove_batch_eval(int field, const uint8_t* claims, const size_t
     for (size_t i = 0; i < k; i++) { fe_mul(F, &t, &ev[i][0], &co[i]); fe_add(F, &c0, &c0, &t); fe_mul(F, &t, &ev[i][2], &co[i]); fe_add(F, &cm1, &cm1, &t); }
     fe_sub(F, &c1, &e, &c0);
     fe_add(F, &qc, &c1, &cm1); fe_dbl(F, &t, &c0); fe_sub(F, &qc, &qc, &t); fe_mul(F, &qc, &qc, &tinv);   /* (S(1) + S(-1) - 2 S(0)) / 2 */
-    fe poly[3]; poly[0] = c0; poly[2] = qc; fe_sub(F, &poly[1], &c1, &qc); fe_sub(F, &poly[1], &poly[1], &c0);
+    fe poly[3];
+    unipoly_from_evals_deg2(F, &c0, &c1, &qc, poly);
     fe r;
     rc = ask_challenge(F, cb, ctx, poly, 3, &r, out_polys ? out_polys + 96 * round : NULL, out_r ? out_r + 32 * round : NULL);
     if (rc) break;

@@ -70,6 +70,20 @@ int batch(int mont, const uint8_t* claims, const size_t* num_rounds, const uint8
 }
 }  // namespace
 
+// UniPoly::from_evals_deg2 / _deg3 + evaluate as the product's host algebra spells them (ScAlg): evals = [f(0), f(1), leading coefficient(, f(-1))]
+// canonical in, coefficients and the value at `at` canonical out -- for the reference's known answers (univariate.rs:284-355)
+template <int FID> int unipoly(int deg, const uint8_t* evals, const uint8_t* at, uint8_t* out_coeffs, uint8_t* out_value) {
+  using H = HostFp4<FID>;
+  ScAlg<FID> alg(false);
+  H e[4], co[4];
+  for (int i = 0; i <= deg; i++) e[i] = alg.in(evals + 32 * i);
+  const H claim = e[0] + e[1];  // the provers pass the round's claim f(0) + f(1), not f(1)
+  if (deg == 2) ScAlg<FID>::from_evals_deg2(e[0], claim, e[2], co);
+  else ScAlg<FID>::from_evals_deg3(e[0], claim, e[2], e[3], co);
+  for (int i = 0; i <= deg; i++) alg.out(co[i], out_coeffs + 32 * i);
+  alg.out(ScAlg<FID>::poly_eval(co, (uint32_t)deg + 1, alg.in(at)), out_value);
+  return 0;
+}
 #define DISPATCH(call)        \
   switch (field) {            \
     case 0: return call(0);   \
@@ -80,6 +94,12 @@ int batch(int mont, const uint8_t* claims, const size_t* num_rounds, const uint8
   }
 
 extern "C" {
+int hsc_unipoly_from_evals(int field, int deg, const uint8_t* evals, const uint8_t* at, uint8_t* out_coeffs, uint8_t* out_value) {
+  if (deg != 2 && deg != 3) return -1;
+#define CALL(F) (unipoly<F>(deg, evals, at, out_coeffs, out_value))
+  DISPATCH(CALL)
+#undef CALL
+}
 int hsc_prove_cubic3(int field, int mont, const uint8_t* claim, const uint8_t* taus, size_t nr, const uint8_t* A, const uint8_t* B,
                      const uint8_t* C, TranscriptFn cb, void* ctx, uint8_t* out_polys, uint8_t* out_r, uint8_t* out_claims) {
 #define CALL(F) (prove<F, 3>(mont, claim, taus, nr, A, B, C, cb, ctx, out_polys, out_r, out_claims))

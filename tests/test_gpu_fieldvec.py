@@ -591,10 +591,11 @@ def _nonzero(fid, n, seed):
 
 
 @pytest.mark.parametrize("fid", range(4))
-@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 128, 129, 1000, 1025, 4096, 4097, 131073, 300001, (1 << 21) + 5])
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 128, 129, 1000, 1025, 4096, 4097, (1 << 15) + 5, 131073, 300001, (1 << 21) + 5])
 def test_batch_invert_vs_oracle(nmx, fid, n):
     """batch_invert (src/spartan/mod.rs:54-152): host and HBM-resident vectors, every level count (n <= 128 is the host level alone;
-    ragged last chunks; 2^21 + 5 starts with 16-element chunks and continues with 8-element ones)."""
+    ragged last chunks; 2^15 + 5 is the size of the reference's own test_batch_invert, spartan/mod.rs:547-559; 2^21 + 5 starts with
+    16-element chunks and continues with 8-element ones)."""
     import torch
     from nova_amd import fieldvec as fv
     v = _nonzero(fid, n, 70 + n % 13)

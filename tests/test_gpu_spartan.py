@@ -412,3 +412,15 @@ def test_provers_and_commitments_from_several_threads(nmx):
         t.join()
     assert not errs, errs
     ck.close()
+
+
+def test_quad_prod_round_polynomial_is_the_references_known_answer(nmx):
+    """src/spartan/polys/univariate.rs:284-300 through the HIP prover: A = [1, 2], B = [1, 3], claim 7 -> the round polynomial 2x^2 + 3x + 1;
+    the same instance embedded in the top variable of a 2^10 table (zeros elsewhere) so that the DEVICE computes that first round."""
+    for l in (1, 10):
+        n = 1 << l
+        A, B = [0] * n, [0] * n
+        A[0], A[n // 2], B[0], B[n // 2] = 1, 2, 1, 3
+        tr = sp.StandInTranscript(fc.FIELDS[1])
+        polys, _r, _c = g_quad(1, sp.le(7), l, fc.vec(A), fc.vec(B), tr)
+        assert [int.from_bytes(c, "little") for c in polys[0]] == [1, 3, 2]

@@ -136,3 +136,34 @@ def test_batch(fid, nrs):
     assert sp.check_batch_eval(h_batch, fid, nrs, seed=800 + sum(nrs)) == sp.check_batch_eval(o_batch, fid, nrs, seed=800 + sum(nrs))
     force = {0: 0, max(nrs) - 1: 1}
     assert sp.check_batch_eval(h_batch, fid, nrs, seed=5, force=force) == sp.check_batch_eval(o_batch, fid, nrs, seed=5, force=force)
+
+
+@pytest.mark.parametrize("fid", [0, 1, 2, 3])
+def test_unipoly_known_answers_of_the_reference(fid):
+    """src/spartan/polys/univariate.rs:284-355: from_evals_deg2([1, 6, 2]) = 2x^2 + 3x + 1 (value 28 at 3); from_evals_deg3([1, 7, 1, -1]) =
+    x^3 + 2x^2 + 3x + 1 (value 109 at 4) -- through the oracle's constructors and through the product's host algebra (ScAlg)."""
+    p = fc.FIELDS[fid]
+
+    def host(evals, at):
+        deg = len(evals) - 1
+        pe, _e = _buf(b"".join(int(x).to_bytes(32, "little") for x in evals))
+        pa, _a = _buf(int(at).to_bytes(32, "little"))
+        co, val = np.zeros(32 * (deg + 1), np.uint8), np.zeros(32, np.uint8)
+        assert hsc().hsc_unipoly_from_evals(fid, deg, ctypes.c_void_p(pe), ctypes.c_void_p(pa), ctypes.c_void_p(co.ctypes.data),
+                                            ctypes.c_void_p(val.ctypes.data)) == 0
+        cb = co.tobytes()
+        return [int.from_bytes(cb[32 * i: 32 * i + 32], "little") for i in range(deg + 1)], int.from_bytes(val.tobytes(), "little")
+    for f in (cref.unipoly_from_evals, lambda _fid, ev, at: host(ev, at)):
+        assert f(fid, [1, 6, 2], 3) == ([1, 3, 2], 28)
+        assert f(fid, [1, 7, 1, p - 1], 4) == ([1, 3, 2, 1], 109)
+        assert f(fid, [1, 6, 2], 0)[1] == 1 and f(fid, [1, 6, 2], 1)[1] == 6            # eval_at_zero / eval_at_one
+        assert f(fid, [1, 7, 1, p - 1], p - 1)[1] == p - 1                                # f(-1) = -1
+
+
+def test_quad_prod_round_polynomial_is_the_references_known_answer():
+    """The same quadratic through the PROVERS: A = [1, 2], B = [1, 3] has e0 = 1, e1 = 6, quadratic coefficient (2 - 1)(3 - 1) = 2 and claim 7 --
+    the one round polynomial must be [1, 3, 2] (univariate.rs:284-300)."""
+    for prove in (o_quad, h_quad):
+        tr = sp.StandInTranscript(fc.FIELDS[1])
+        polys, _r, _c = prove(1, sp.le(7), 1, fc.vec([1, 2]), fc.vec([1, 3]), tr)
+        assert [int.from_bytes(c, "little") for c in polys[0]] == [1, 3, 2]
