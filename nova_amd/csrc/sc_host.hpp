@@ -278,6 +278,9 @@ template <int FID> struct ScBatchClaim {
 //   H    t_m1(size_t i)                        the fallback's third sum t(-1) over claim i's current table
 //   void bind(size_t i, const H& r)            bind claim i's table with r and enqueue the next round's sums -- or, when the
 //                                              bound table fits the tail, bring it to the host: then claims[i].host is filled
+//   void ahead(size_t i)                       called once per round for every claim whose polynomial is still on the device, after its
+//                                              eq instance has moved on to the coming round and prepared it (Eq::l1p_zero is valid): the
+//                                              device may get the pass AFTER the pending one under way (sumcheck_prove.hpp prelaunch)
 // out_finals (k x 32 bytes, the vectors' own form) = poly_finals.
 template <int FID, class DEV>
 void sc_batch_rounds(const ScAlg<FID>& alg, std::vector<ScBatchClaim<FID>>& claims, DEV& dev, TranscriptFn cb, void* cb_ctx,
@@ -326,7 +329,10 @@ void sc_batch_rounds(const ScAlg<FID>& alg, std::vector<ScBatchClaim<FID>>& clai
     e = ScAlg<FID>::poly_eval(poly, 3, r);
     // the next round's inversions while the device runs the passes enqueued above
     for (size_t i = 0; i < k; i++)
-      if (remaining - 1 <= claims[i].num_rounds && remaining > 1) claims[i].eq.prepare();
+      if (remaining - 1 <= claims[i].num_rounds && remaining > 1) {
+        claims[i].eq.prepare();
+        if (claims[i].host.empty()) dev.ahead(i);  // (the device may enqueue the pass after the pending one now: its challenge comes later)
+      }
   }
   if (out_finals)
     for (size_t i = 0; i < k; i++) alg.out(claims[i].host[0], out_finals + 32 * i);  // every polynomial ends on the host (len 1)

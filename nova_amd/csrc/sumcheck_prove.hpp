@@ -1087,11 +1087,23 @@ template <int FID> struct ScBatchDev {
     if (len[i] / 2 <= h.tail_len) {
       std::vector<H>* out[3] = {&claims[i].host, nullptr, nullptr};
       pass[i].to_host(len[i] / 2, &r, out);
+    } else if (pass[i].armed()) {  // enqueued a round ago (ahead): all it lacks is r
+      seq[i] = pass[i].send(r);
+      tb[i] = tb_next[i];
     } else {
       tb[i] = eqd[i].tables(claims[i].eq.round + 1);
       seq[i] = pass[i].bind_sums(len[i], r, tb[i]);
     }
     len[i] /= 2;
+  }
+  // the pass that will bind claim i's table (len[i] elements now) goes out before its challenge exists (ScPass::prelaunch), unless it is
+  // the hand-over or the coming round takes the fallback (whose extra pass needs the claim's stream)
+  std::vector<typename ScEqDev<FID>::Tables> tb_next;
+  void ahead(size_t i) {
+    if (len[i] / 2 <= h.tail_len || claims[i].eq.l1p_zero || !pass[i].can_prelaunch(len[i])) return;
+    if (tb_next.size() < pass.size()) tb_next.resize(pass.size());
+    tb_next[i] = eqd[i].tables(claims[i].eq.round + 1);
+    pass[i].prelaunch(len[i], tb_next[i]);
   }
 };
 template <int FID>

@@ -46,6 +46,7 @@ template <int FID> struct NoDev {
   H t0(size_t) { throw ScFail{9, "device hook called in a host-only run"}; }
   H t_m1(size_t) { throw ScFail{9, "device hook called in a host-only run"}; }
   void bind(size_t, const H&) { throw ScFail{9, "device hook called in a host-only run"}; }
+  void ahead(size_t) { throw ScFail{9, "device hook called in a host-only run"}; }
 };
 template <int FID>
 int batch(int mont, const uint8_t* claims, const size_t* num_rounds, const uint8_t* const* polys, const uint8_t* const* eq_points,

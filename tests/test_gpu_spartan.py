@@ -224,6 +224,11 @@ def test_prelaunched_passes_and_launched_passes_agree(nmx):
                 both(sp.check_quad_prod, g_quad, o_quad, 1, l + 1, seed=90 + l)
             both(sp.check_cubic3, g_cubic3(), o_cubic3, 1, 12, seed=82, force={0: 0, 3: 1, 7: p - 1, 9: 0}, brute=False)
             both(sp.check_cubic3, g_cubic3(), o_cubic3, 1, 11, seed=83, taus=[0] * 11, brute=False)
+            both(sp.check_batch_eval, g_batch, o_batch, 1, [14, 11, 16, 9], seed=87)
+            both(sp.check_batch_eval, g_batch, o_batch, 1, [10, 12, 8], seed=88, force={0: 0, 3: 1, 7: p - 1, 11: 0})
+            assert L.nmx_set_option(b"sc_side_streams", 0) == 0
+            both(sp.check_batch_eval, g_batch, o_batch, 1, [13, 15], seed=89)
+            assert L.nmx_set_option(b"sc_side_streams", 1) == 0
             assert L.nmx_set_option(b"sc_host_parts", 0) == 0
             both(sp.check_cubic3, g_cubic3(), o_cubic3, 1, 14, seed=84, brute=False)
             assert L.nmx_set_option(b"sc_host_parts", 1) == 0
@@ -244,6 +249,7 @@ def test_prelaunched_passes_and_launched_passes_agree(nmx):
     finally:
         assert L.nmx_set_option(b"sc_prelaunch", 1) == 0
         assert L.nmx_set_option(b"sc_host_parts", 1) == 0
+        assert L.nmx_set_option(b"sc_side_streams", 1) == 0
 
 
 def test_host_added_partials_and_ticket_passes_agree(nmx):
