@@ -415,7 +415,7 @@ int nmx_sumcheck_plain_sums(int field, int kind, const void* A, const void* B, c
  * "sc_host_parts" (default 1: a pass of <= 64 blocks hands every block's partial sums to the host, which adds them; 0: the last block
  * does) and "sc_quad" (default 1: passes of <= 2^12 indices of the cubic / quad_prod provers spread an index over four lanes) shorten
  * the dependent chain of the small rounds; "sc_prelaunch" (default 1; needs a large-BAR device and sc_poll_us != 0) enqueues the
- * small passes of the cubic / quad_prod provers a round early -- the pass waits on the device for its challenge, which the host
+ * provers' small passes a round early -- the pass waits on the device for its challenge, which the host
  * writes through the BAR -- taking the launch latency off those rounds; results are identical either way.
  *  - nmx_sumcheck_prove_cubic_with_three_inputs == SumcheckProof::prove_cubic_with_three_inputs (sumcheck.rs:446-507) with its
  *    EqSumCheckInstance (sumcheck.rs:593-1253; all sqrt-size eq tables built by one launch): A, B, C of 2^num_rounds elements,
