@@ -129,13 +129,15 @@ template <int FID> struct ScSmallArgs {
   uint32_t shift, mask, hq, bind, seq;
   uint32_t* slot;
   // a pass enqueued BEFORE its challenge exists (ScPass::prelaunch): r is not in the arguments -- the kernel waits for the host to
-  // write it to this 64-byte line (uncached device memory written through the BAR): word 0 = chal_seq when it is there, word 1 != 0: give up, words 4..12 = r's limbs
+  // write it to this 64-byte line (uncached device memory written through the BAR): four 16-byte pieces, each led by chal_seq --
+  // {seq, l0, l1, l2} {seq, l3, l4, l5} {seq, l6, l7, l8} {seq, give-up flag, 0, 0} -- so a piece is either the old one or the new one whole
   const uint32_t* chal = nullptr;
   uint32_t chal_seq = 0;
 };
 // The challenge of a pre-launched pass.  Thread 0 of every block reads the WHOLE line per poll (four 16-byte loads in flight together;
-// ten dependent word reads of pinned host memory made the first version of this 25 us slower than launching late); the host writes the
-// limbs first, fences, then the sequence word: a line read that shows the new sequence word shows the limbs.  false:
+// ten dependent word reads of pinned host memory made the first version of this 25 us slower than launching late).  The host stores
+// the line as four 16-byte pieces that each begin with the sequence word; the pass goes ahead when all four show it -- no ordering
+// between the pieces is assumed, only that a 16-byte store and a 16-byte load are not torn.  false:
 // the host said stop, or nothing came for kChalTimeoutTicks of the 100 MHz wall clock -- the block leaves without touching the
 // tables or the mailbox (the host then fails its own wait).
 static constexpr uint64_t kChalTimeoutTicks = 200000000ull;  // 2 s
@@ -150,13 +152,13 @@ template <int FID> __device__ __forceinline__ bool sc_challenge(const ScSmallArg
     u32x4 q0, q1, q2, q3;
     for (uint32_t spin = 0;; spin++) {
       q0 = line[0], q1 = line[1], q2 = line[2], q3 = line[3];
-      if (q0.x == a.chal_seq) {
-        ok = q0.y == 0 ? 1u : 0u;
+      if (q0.x == a.chal_seq && q1.x == a.chal_seq && q2.x == a.chal_seq && q3.x == a.chal_seq) {  // every 16-byte piece is the new one
+        ok = q3.y == 0 ? 1u : 0u;
         break;
       }
       if ((spin & 63u) == 63u && wall_clock64() - t0 > kChalTimeoutTicks) break;
     }
-    s_r[0] = q1.x, s_r[1] = q1.y, s_r[2] = q1.z, s_r[3] = q1.w, s_r[4] = q2.x, s_r[5] = q2.y, s_r[6] = q2.z, s_r[7] = q2.w, s_r[8] = q3.x;
+    s_r[0] = q0.y, s_r[1] = q0.z, s_r[2] = q0.w, s_r[3] = q1.y, s_r[4] = q1.z, s_r[5] = q1.w, s_r[6] = q2.y, s_r[7] = q2.z, s_r[8] = q2.w;
     s_r[9] = ok;
   }
   __syncthreads();
@@ -570,13 +572,14 @@ template <int FID> struct ScDev {
   }
   // the CPU's stores to BAR memory are write-combined: a fence between the payload and the sequence word, and one behind it to push it out
   static void chal_write(uint32_t* line, const uint32_t* limbs9, uint32_t abort_word, uint32_t seq) {
-    volatile uint32_t* l = line;
-    if (limbs9)
-      for (int i = 0; i < 9; i++) l[4 + i] = limbs9[i];
-    l[1] = abort_word;
-    _mm_sfence();
-    l[0] = seq;
-    _mm_sfence();
+    static const uint32_t zero9[9] = {0};
+    const uint32_t* l = limbs9 ? limbs9 : zero9;
+    __m128i* q = reinterpret_cast<__m128i*>(line);  // (256-byte aligned)
+    _mm_stream_si128(q + 0, _mm_set_epi32((int)l[2], (int)l[1], (int)l[0], (int)seq));
+    _mm_stream_si128(q + 1, _mm_set_epi32((int)l[5], (int)l[4], (int)l[3], (int)seq));
+    _mm_stream_si128(q + 2, _mm_set_epi32((int)l[8], (int)l[7], (int)l[6], (int)seq));
+    _mm_stream_si128(q + 3, _mm_set_epi32(0, 0, (int)abort_word, (int)seq));
+    _mm_sfence();  // push the write-combining buffer out
   }
   // Pre-launched passes waiting for a challenge (chal_seq per slot, 0: none).  While one waits, no stream of this call may be
   // synchronised -- the wait would sit behind a kernel that waits for THIS thread -- so the mailbox polls keep polling (up to
