@@ -1926,6 +1926,7 @@ int nmx_commit_begin(uint64_t ck_handle, const void* v, size_t n, const void* h_
 }
 int nmx_commit_finish(uint64_t ticket, uint8_t* out, uint8_t* out_is_inf) {
   return guarded([&] {
+    require(out != nullptr, NMX_E_ARG, "null argument");  // (before the ticket is touched: it stays valid)
     std::shared_ptr<PendingCommit> pc;
     {
       std::lock_guard<std::mutex> lk(g_pend_mu);
@@ -1935,7 +1936,6 @@ int nmx_commit_finish(uint64_t ticket, uint8_t* out, uint8_t* out_is_inf) {
       pending_commits().erase(it);
     }
     const PendingCommit::Res res = pc->fut.get();  // rethrows what the commitment threw: the error is reported HERE
-    require(out != nullptr, NMX_E_ARG, "null argument");
     memcpy(out, res.out.data(), (pc->flags & NMX_OUT_PARTIAL) ? 128 : 64);
     if (out_is_inf) *out_is_inf = res.inf;
   });

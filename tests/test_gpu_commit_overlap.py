@@ -60,6 +60,7 @@ def test_finish_reports_the_commitments_error_and_tickets_retire(nmx):
     t = ce.commit_begin(ck, v)
     tk = t.ticket
     want = _pt(ce.commit(ck, v))
+    assert L.lib().nmx_commit_finish(tk, None, None) == L.E_ARG          # a bad call leaves the ticket alone
     assert _pt(t.finish()) == want
     assert L.lib().nmx_commit_finish(tk, out.ctypes.data, inf.ctypes.data) == L.E_HANDLE      # retired
     tk2 = ctypes.c_uint64(0)
