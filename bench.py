@@ -118,6 +118,7 @@ def main():
                     help="register the key WITHOUT window tables: the plain path (W bucket sets) that first / second sight of a "
                          "cached array, IPA's per-round keys and keys whose tables do not fit take")
     ap.add_argument("--iters", type=int, default=65536, help="prove_step_replay: MinRoot iterations per step")
+    ap.add_argument("--cycle", default="bn254", choices=["bn254", "pasta"], help="prove_step replay: the curve cycle (BN254/Grumpkin or Pallas/Vesta)")
     ap.add_argument("--opens", default="batch", choices=["batch", "threads", "serial"],
                     help="hyperkzg replay: the three kzg_open commitments as one batch_commit (default), three host threads (the reference's par_iter), or one after the other")
     ap.add_argument("--separate-field-ops", action="store_true", help="prove_step replay: vec_add, 3 x SpMV, cross term and the two folds as separate (stream-ordered) calls")
@@ -909,9 +910,11 @@ def prove_step_replay(args, torch):
     import nova_amd
     from nova_amd import fieldvec as fv
     from tests import util
-    N = 3 * args.iters + 9986          # primary (BN254) witness / constraint count
-    n2 = 10538                         # secondary (Grumpkin)
-    cur = {"P": (0, fv.SCALAR_FIELD_OF_CURVE[0], N), "S": (1, fv.SCALAR_FIELD_OF_CURVE[1], n2)}
+    N = 3 * args.iters + 9986          # primary (BN254 / Pallas) witness / constraint count
+    n2 = 10538                         # secondary (Grumpkin / Vesta)
+    # the curve cycle: BN254 / Grumpkin (configs[3]) or Pallas / Vesta (north_star's other cycle; src/provider/pasta.rs)
+    cP, cS = {"bn254": (0, 1), "pasta": (2, 3)}[getattr(args, "cycle", "bn254")]
+    cur = {"P": (cP, fv.SCALAR_FIELD_OF_CURVE[cP], N), "S": (cS, fv.SCALAR_FIELD_OF_CURVE[cS], n2)}
     ce = {k: nova_amd.CommitmentEngine(c[0]) for k, c in cur.items()}
     ck = {k: ce[k].setup_synthetic(c[2], k0=3) for k, c in cur.items()}
     host, dev, csr, mats = {}, {}, {}, {}
@@ -921,10 +924,10 @@ def prove_step_replay(args, torch):
         dev[k] = {nm: torch.from_numpy(v).cuda() for nm, v in host[k].items()}
         csr[k] = minroot_like_matrices(fid, n, n, seed=100 + cid)     # Z has one entry per variable here (io folded in)
         mats[k] = [fv.SparseMatrix(fid, ip, ix, dt, n) for ip, ix, dt in csr[k]]
-    u = util.random_scalars(0, 1, seed=31)
+    u = util.random_scalars(cP, 1, seed=31)
     r = {k: util.random_scalars(c[0], 1, seed=32) for k, c in cur.items()}
     rT = {k: util.random_scalars(c[0], 1, seed=33) for k, c in cur.items()}
-    uS = util.random_scalars(1, 1, seed=34)
+    uS = util.random_scalars(cS, 1, seed=34)
 
     spans = None                     # per-call wall times of the instrumented passes (every call is synchronous)
 
@@ -1026,11 +1029,11 @@ def prove_step_replay(args, torch):
     breakdown["_sum"] = round(sum(v for v in breakdown.values()), 4)
     spans = None
     outj = {
-        "metric": "RecursiveSNARK prove_step provider-call REPLAY ms (minroot, BN254/Grumpkin)", "value": dt * 1e3, "unit": "ms",
+        "metric": f"RecursiveSNARK prove_step provider-call REPLAY ms (minroot, {nova_amd.CURVE_NAMES[cP]}/{nova_amd.CURVE_NAMES[cS]})", "value": dt * 1e3, "unit": "ms",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": False,
         "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
-        "config": {"workload": f"prove_step replay: minroot {args.iters} iterations/step -> primary N={N} (BN254), secondary n={n2} "
-                               "(Grumpkin); 4 MSMs + 6 SpMVs + 2 vector adds + 2 cross terms + 4 folds (stream-ordered: commit_T's chain and the fold one call each); no synthesis / Poseidon "
+        "config": {"workload": f"prove_step replay: minroot {args.iters} iterations/step -> primary N={N} ({nova_amd.CURVE_NAMES[cP]}), secondary n={n2} "
+                               f"({nova_amd.CURVE_NAMES[cS]}); 4 MSMs + 6 SpMVs + 2 vector adds + 2 cross terms + 4 folds (stream-ordered: commit_T's chain and the fold one call each); no synthesis / Poseidon "
                                "(BASELINE.json configs[3])"},
         "roofline": None,
         "breakdown_ms": breakdown,
@@ -1191,6 +1194,7 @@ def spartan_like_matrices(fid, n, seed):
 
 
 SPARTAN_SEED = 2025
+FIELD_NAMES = {0: "BN254 Fq = Grumpkin's scalar field", 1: "BN254 Fr", 2: "Pallas Fp = Vesta's scalar field", 3: "Pallas Fq = Pallas's scalar field"}
 
 
 def spartan_instance(fid, ell, seed=None):
@@ -1344,7 +1348,9 @@ def spartan_replay(args, torch):
     from nova_amd import _lib, fieldvec as fv
     ell = args.log2n
     n = 1 << ell
-    fid = fv.SCALAR_FIELD_OF_CURVE[0]
+    # the curve whose scalar field the instance lives in: 0 = BN254 (S1 of CompressedSNARK::prove), 1 = Grumpkin (S2, the secondary
+    # circuit's SNARK, src/nova/mod.rs:862-881), 2 / 3 = Pallas / Vesta
+    fid = fv.SCALAR_FIELD_OF_CURVE[getattr(args, "curve", 0)]
     p = util_modulus(fid)
     L = _lib.lib()
     csr, hW, u, hz = spartan_instance(fid, ell)
@@ -1417,7 +1423,7 @@ def spartan_replay(args, torch):
                    "launches": int(v[-1][4]), "rounds": int(v[-1][5]), "host_tail_rounds": int(v[-1][6])} for k, v in prof.items()}
     spans, prof = None, None
     outj = {
-        "metric": "Spartan RelaxedR1CSSNARK prove (sum-check half) provider-call REPLAY ms (BN254 Fr)", "value": dt * 1e3, "unit": "ms",
+        "metric": f"Spartan RelaxedR1CSSNARK prove (sum-check half) provider-call REPLAY ms ({FIELD_NAMES[fid]})", "value": dt * 1e3, "unit": "ms",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": False, "scaling": "weak",
         "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
         "config": {"workload": f"Spartan prove replay, num_cons = num_vars = 2^{ell}: 3 SpMV, outer cubic sum-check ({ell} rounds, one call), "

@@ -228,7 +228,10 @@ enum {
                                   diagnostic (slow-launch boxes of a pool show here); 0 until the first MSM       */
   NMX_STAT_SCAN_TIMEOUTS = 14, /* suffix-Horner calls whose single-pass scan gave up a look-back wait and were repeated on
                                   the two-pass kernels (never observed; the guard that turns a hang into a slower call) */
-  NMX_STAT_COUNT = 15
+  NMX_STAT_SC_TORN_INJECTED = 15, /* option "sc_torn_test" only: deliberately torn challenge lines the host wrote ahead of the whole one */
+  NMX_STAT_SC_TORN_REJECTS = 16,  /* ... and waits in which a pre-launched sum-check pass saw such a line and polled past it
+                                     (sequence words new, checksum wrong); counted while "sc_torn_test" is on            */
+  NMX_STAT_COUNT = 17
 };
 int nmx_stats(uint64_t* out, int cap);
 /* same, bases taken from a registered key */
@@ -416,7 +419,14 @@ int nmx_sumcheck_plain_sums(int field, int kind, const void* A, const void* B, c
  * does) and "sc_quad" (default 1: passes of <= 2^12 indices of the cubic / quad_prod provers spread an index over four lanes) shorten
  * the dependent chain of the small rounds; "sc_prelaunch" (default 1; needs a large-BAR device and sc_poll_us != 0) enqueues the
  * provers' small passes a round early -- the pass waits on the device for its challenge, which the host
- * writes through the BAR -- taking the launch latency off those rounds; results are identical either way.
+ * writes through the BAR -- taking the launch latency off those rounds; results are identical either way.  The 64-byte challenge
+ * line carries a sequence word per 16-byte piece and a 64-bit checksum of its payload: the waiting pass accepts it only whole
+ * (no store granularity of the write-combining path is assumed; option "sc_torn_test" = microseconds a deliberately torn line is
+ * left on the device first, tests only, with NMX_STAT_SC_TORN_INJECTED / _REJECTS).  At most 256 blocks per device wait this way
+ * at any time; passes beyond that budget are launched late.  THE TRANSCRIPT CALLBACK MUST NOT SYNCHRONISE THE DEVICE (hipFree,
+ * hipDeviceSynchronize, a blocking copy on the NULL stream, a torch operator): a waiting pass is waiting for the challenge the
+ * callback is about to return, and a device-wide wait behind it ends only with the pass's 2 s time-out (the call then fails with
+ * NMX_E_HIP; nothing wrong is returned).
  *  - nmx_sumcheck_prove_cubic_with_three_inputs == SumcheckProof::prove_cubic_with_three_inputs (sumcheck.rs:446-507) with its
  *    EqSumCheckInstance (sumcheck.rs:593-1253; all sqrt-size eq tables built by one launch): A, B, C of 2^num_rounds elements,
  *    taus = num_rounds elements (host), 4 coefficients per round, out_claims = [A(r), B(r), C(r)].  A tau of zero (or a

@@ -16,7 +16,8 @@ PROF_STAGES = 12
 # nmx_stats indices
 (STAT_CACHE_HITS, STAT_CACHE_UPLOADS, STAT_CACHE_REGROWS, STAT_CACHE_EVICTIONS, STAT_CACHE_ENTRIES, STAT_CACHE_BYTES,
  STAT_UNCACHED_CALLS, STAT_BASE_BYTES_H2D, STAT_MSM_CALLS, STAT_FUSED_RUNS, STAT_SHARDED_CALLS, STAT_CACHE_STALE,
- STAT_TABLE_FALLBACKS, STAT_LAUNCH_GAP_NS, STAT_SCAN_TIMEOUTS, STAT_COUNT) = range(16)
+ STAT_TABLE_FALLBACKS, STAT_LAUNCH_GAP_NS, STAT_SCAN_TIMEOUTS, STAT_SC_TORN_INJECTED, STAT_SC_TORN_REJECTS,
+ STAT_COUNT) = range(18)
 DEVICES_OVERSUBSCRIBE = 1
 E_ARG, E_NO_DEVICE, E_HIP, E_SCALAR_RANGE, E_SMALL_RANGE, E_HANDLE, E_TOO_LARGE = -1, -2, -3, -4, -5, -6, -7
 E_IO, E_FORMAT, E_POINT, E_ZERO = -8, -9, -10, -11

@@ -42,7 +42,7 @@ Global::SparseSet::~SparseSet() {
   if (data) (void)hipFree(data);
 }
 Global::SparseSet::Transposed::~Transposed() {
-  (void)hipSetDevice(G.device);
+  (void)hipSetDevice(hip_device_of(dev));  // the device transposed_of built it on
   for (uint32_t* q : {vptr, indices, data, vout, hrow, hstart})
     if (q) (void)hipFree(q);
 }
@@ -165,7 +165,10 @@ static void ensure_init() {
   if (const char* t = getenv("NMX_TUNE_HIST_GRID")) G.hist_grid = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_HIST_BS")) G.hist_bs = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_SYNC_SPIN_US")) G.sync_spin_us = (uint32_t)atoi(t);
-  if (const char* t = getenv("NMX_HOST_SPLIT")) G.host_split = (uint32_t)atoi(t);
+  if (const char* t = getenv("NMX_HOST_SPLIT")) {  // same range as option host_split: at most 16 pieces, 255 = by size
+    const int v = atoi(t);
+    G.host_split = v == 255 ? 255u : (uint32_t)(v < 0 ? 0 : (v > 16 ? 16 : v));
+  }
   if (const char* t = getenv("NMX_SC_POLL_US")) G.sc_poll_us = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_SC_HOST_TAIL")) G.sc_host_tail = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_SC_FUSED_SUM")) G.sc_fused_sum = (uint32_t)atoi(t);
@@ -843,16 +846,26 @@ struct DeepCheck {  // the part of a hit's verification that may run beside the 
     size_t nth = std::max<size_t>(1, std::min<size_t>(8, count >> 15));
     const int busy = inflight().load(std::memory_order_relaxed);
     if ((size_t)busy + nth > 8) nth = busy >= 7 ? 1 : (size_t)(8 - busy);
-    inflight().fetch_add((int)nth, std::memory_order_relaxed);
     std::vector<PoolFuture<bool>> futs;
     futs.reserve(nth);
     const DeepCheck dc = *this;
     for (size_t t = 0; t < nth; t++) {
       const size_t a = start + count * t / nth, b = start + count * (t + 1) / nth;
-      futs.emplace_back([dc, a, b] {
-        const bool ok = dc.run_range(a, b);
-        inflight().fetch_sub(1, std::memory_order_relaxed);
-        return ok;
+      // counted per future that exists: the job owns the decrement (a guard object, so a throwing run_range gives it back too);
+      // if creating the future itself throws, the guard dies with the unrun closure and the count is restored all the same
+      struct Slot {
+        bool live = true;
+        Slot() { inflight().fetch_add(1, std::memory_order_relaxed); }
+        Slot(Slot&& o) noexcept : live(o.live) { o.live = false; }
+        Slot(const Slot&) = delete;
+        ~Slot() {
+          if (live) inflight().fetch_sub(1, std::memory_order_relaxed);
+        }
+      };
+      auto slot = std::make_shared<Slot>();
+      futs.emplace_back([dc, a, b, slot]() mutable {
+        std::shared_ptr<Slot> mine = std::move(slot);
+        return dc.run_range(a, b);
       });
     }
     return futs;
@@ -1909,10 +1922,21 @@ int nmx_commit_begin(uint64_t ck_handle, const void* v, size_t n, const void* h_
     memcpy(rb.data(), r, 32);
     const MsmCall mc = field_call(v, flags);
     auto lease = std::make_shared<CtxLease>();  // on the calling thread: behind its stream-ordered calls
+    // The worker must see the caller's pending NMX_ASYNC mark as well (thread-local): a sharded key leases one context per shard
+    // INSIDE the job (key_msm -> run_on_parts reads async_pending() of the thread it runs on), and those leases have to wait for
+    // the caller's asynchronous producer just as the lease above does (capi.hip:1914).
+    Ctx* const pend = async_pending();
+    const uint64_t pend_epoch = t_async_epoch;
     auto pc = std::make_shared<PendingCommit>();
     pc->flags = flags;
-    pc->fut = PoolFuture<PendingCommit::Res>([bs, mc, n, hb, rb, flags, lease]() mutable {
+    pc->fut = PoolFuture<PendingCommit::Res>([bs, mc, n, hb, rb, flags, lease, pend, pend_epoch]() mutable {
       std::shared_ptr<CtxLease> L = std::move(lease);  // handed back when the job ends, whatever happens
+      struct Restore {  // the worker's own mark comes back when the job ends (as run_on_parts' helper threads do)
+        Ctx* v;
+        uint64_t e;
+        ~Restore() { t_async_ctx = v, t_async_epoch = e; }
+      } restore{t_async_ctx, t_async_epoch};
+      t_async_ctx = pend, t_async_epoch = pend_epoch;
       HIPCHK(hipSetDevice(hip_device_of(L->c->dev)));  // (the device is per host thread)
       PendingCommit::Res res;
       commit_impl(*L, *bs, mc, n, hb.data(), rb.data(), flags, res.out.data(), &res.inf);
@@ -2450,6 +2474,7 @@ static std::shared_ptr<Global::SparseSet::Transposed> transposed_of(Ctx& c, Glob
   }
   require(nparts < (1ull << 31), NMX_E_TOO_LARGE, "matrix too large");
   auto tr = std::make_shared<Global::SparseSet::Transposed>();
+  tr->dev = c.dev;
   auto up = [&](uint32_t** d, const void* h, size_t bytes) {
     HIPCHK(hipMalloc((void**)d, bytes ? bytes : 4));
     if (bytes) HIPCHK(hipMemcpyAsync(*d, h, bytes, hipMemcpyHostToDevice, c.stream));
@@ -2462,6 +2487,7 @@ static std::shared_ptr<Global::SparseSet::Transposed> transposed_of(Ctx& c, Glob
   up(&tr->hstart, hstart.data(), hstart.size() * 4);
   HIPCHK(hipStreamSynchronize(c.stream));  // the host vectors go away
   tr->nvirt = vout.size(), tr->nheavy = hrow.size(), tr->nparts = nparts;
+  tr->dev = c.dev;
   ss.tr = tr;
   return tr;
 }
@@ -2718,6 +2744,7 @@ int nmx_set_option(const char* name, uint32_t value) {
     else if (n == "sc_quad") G.sc_quad = value ? 1u : 0u;
     else if (n == "sc_prelaunch") G.sc_prelaunch = value ? 1u : 0u;
     else if (n == "sc_host_parts") G.sc_host_parts = value ? 1u : 0u;
+    else if (n == "sc_torn_test") G.sc_torn_test = value > 1000 ? 1000u : (uint32_t)value;
     else if (n == "sc_host_tail") {
       require(value <= 8, NMX_E_ARG, "sc_host_tail: log2 of the table length the host takes over, 0..8");
       G.sc_host_tail = value;
@@ -2791,6 +2818,8 @@ int nmx_check_layout(int curve, const void* generator_raw64, const void* scalar_
   });
 }
 int nmx_stats(uint64_t* out, int cap) {
+  g_stats[NMX_STAT_SC_TORN_INJECTED].store(G.sc_torn_injected.load(std::memory_order_relaxed), std::memory_order_relaxed);
+  g_stats[NMX_STAT_SC_TORN_REJECTS].store(G.sc_torn_rejects.load(std::memory_order_relaxed), std::memory_order_relaxed);
   for (int i = 0; i < NMX_STAT_COUNT && i < cap; i++) out[i] = g_stats[i].load(std::memory_order_relaxed);
   return NMX_STAT_COUNT;
 }

@@ -335,6 +335,8 @@ struct Global {
   std::atomic<uint32_t> sc_side_streams{1};       // option sc_side_streams: the batch prover runs claim i > 0 on its own stream (0: all on the context's)
   std::atomic<uint32_t> sc_prelaunch{1};          // option sc_prelaunch: the cubic / quad_prod provers enqueue their small passes a round early; the pass takes its challenge from pinned memory (0: launched when the challenge is known)
   std::atomic<uint32_t> sc_host_parts{1};         // option sc_host_parts: passes of <= 64 blocks send per-block partial sums to the host, which adds them (0: last-block ticket)
+  std::atomic<uint32_t> sc_torn_test{0};          // option sc_torn_test (tests): microseconds a deliberately TORN challenge line stays on the device before the whole one follows (0: off)
+  std::atomic<uint64_t> sc_torn_injected{0}, sc_torn_rejects{0};  // NMX_STAT_SC_TORN_INJECTED / _REJECTS
   std::atomic<uint32_t> sc_quad{1};               // option sc_quad: passes of <= 2^12 indices of the cubic / quad_prod provers run four lanes per index (0: one)
   std::atomic<uint32_t> sc_host_tail{7};          // option sc_host_tail: the sum-check provers finish on the host once the tables hold <= 2^this elements (0: only the final values come over; max 8)
   std::atomic<uint32_t> sc_poll_us{2000};         // option sc_poll_us: the sum-check provers poll a round's mailbox this long before they synchronise the stream (0: always synchronise)

@@ -328,11 +328,18 @@ void sc_batch_rounds(const ScAlg<FID>& alg, std::vector<ScBatchClaim<FID>>& clai
     }
     e = ScAlg<FID>::poly_eval(poly, 3, r);
     // the next round's inversions while the device runs the passes enqueued above
+    // A pass may only go out ahead of its challenge when NO active claim takes the tau = 0 fall-back in the coming round: the
+    // fall-back's extra pass allocates, copies and waits for a stream, and a device-wide wait behind a kernel that is itself
+    // waiting for this thread's challenge never returns (the armed pass timed out and the proof failed with NMX_E_HIP).
+    bool fallback_next = false;
     for (size_t i = 0; i < k; i++)
       if (remaining - 1 <= claims[i].num_rounds && remaining > 1) {
         claims[i].eq.prepare();
-        if (claims[i].host.empty()) dev.ahead(i);  // (the device may enqueue the pass after the pending one now: its challenge comes later)
+        fallback_next = fallback_next || claims[i].eq.l1p_zero;
       }
+    for (size_t i = 0; i < k && !fallback_next; i++)
+      if (remaining - 1 <= claims[i].num_rounds && remaining > 1 && claims[i].host.empty())
+        dev.ahead(i);  // (the device may enqueue the pass after the pending one now: its challenge comes later)
   }
   if (out_finals)
     for (size_t i = 0; i < k; i++) alg.out(claims[i].host[0], out_finals + 32 * i);  // every polynomial ends on the host (len 1)

@@ -130,16 +130,37 @@ template <int FID> struct ScSmallArgs {
   uint32_t* slot;
   // a pass enqueued BEFORE its challenge exists (ScPass::prelaunch): r is not in the arguments -- the kernel waits for the host to
   // write it to this 64-byte line (uncached device memory written through the BAR): four 16-byte pieces, each led by chal_seq --
-  // {seq, l0, l1, l2} {seq, l3, l4, l5} {seq, l6, l7, l8} {seq, give-up flag, 0, 0} -- so a piece is either the old one or the new one whole
+  // {seq, l0, l1, l2} {seq, l3, l4, l5} {seq, l6, l7, l8} {seq, give-up flag, sum0, sum1} -- with a 64-bit checksum of
+  // (seq, flag, l0..l8) in the last two words (chal_sum): a line is accepted when all four pieces show the sequence AND the checksum
+  // of what was read matches, so no store granularity is assumed (a write-combined 16-byte store may reach the device in 8-byte halves)
   const uint32_t* chal = nullptr;
   uint32_t chal_seq = 0;
 };
+// 64-bit checksum of a challenge line (two independent 32-bit multiply-xor chains over the eleven payload words).  Not a MAC: it
+// separates "the line the host wrote" from "a mixture of that line and the one before it", whatever the mixture's granularity.
+NMX_HD void chal_sum(const uint32_t* l9, uint32_t flag, uint32_t seq, uint32_t& s0, uint32_t& s1) {
+  uint32_t a = seq ^ 0x9e3779b9u, b = (seq * 0x85ebca6bu) ^ 0xc2b2ae35u;
+  for (int i = 0; i <= 9; i++) {
+    const uint32_t w = i < 9 ? l9[i] : flag;
+    a = (a ^ w) * 0x01000193u;
+    a = (a << 13) | (a >> 19);
+    b = (b + w + (uint32_t)i) * 0x27d4eb2fu;
+    b ^= b >> 15;
+  }
+  a ^= a >> 16, a *= 0x7feb352du, a ^= a >> 15;
+  b ^= b >> 13, b *= 0x846ca68bu, b ^= b >> 16;
+  s0 = a, s1 = b ^ 0x5bd1e995u;  // (an all-zero line never passes: seq is never 0, and sum1 of zeros is not 0 either way)
+}
 // The challenge of a pre-launched pass.  Thread 0 of every block reads the WHOLE line per poll (four 16-byte loads in flight together;
 // ten dependent word reads of pinned host memory made the first version of this 25 us slower than launching late).  The host stores
-// the line as four 16-byte pieces that each begin with the sequence word; the pass goes ahead when all four show it -- no ordering
-// between the pieces is assumed, only that a 16-byte store and a 16-byte load are not torn.  false:
-// the host said stop, or nothing came for kChalTimeoutTicks of the 100 MHz wall clock -- the block leaves without touching the
-// tables or the mailbox (the host then fails its own wait).
+// the line as four 16-byte pieces that each begin with the sequence word; the pass goes ahead when all four show it AND the line's
+// checksum (chal_sum, last two words) matches what was read -- no ordering between the pieces and no store or load granularity is
+// assumed: a torn line (a piece half old, half new -- write-combining buffers may be evicted in 8-byte chunks) fails the checksum
+// and is simply polled again until the whole line has landed (before round 6 a torn piece would have bound the
+// tables IN PLACE with a wrong r and the call would have returned NMX_OK with a proof that does not verify).  A rejected line bumps
+// the word at line + 16 (a counter the host reads back for NMX_STAT_SC_TORN_REJECTS; block 0 only, once per wait).  false: the
+// host said stop, or nothing came for kChalTimeoutTicks of the 100 MHz wall clock -- the block leaves without touching the tables
+// or the mailbox (the host then fails its own wait).
 static constexpr uint64_t kChalTimeoutTicks = 200000000ull;  // 2 s
 template <int FID> __device__ __forceinline__ bool sc_challenge(const ScSmallArgs<FID>& a, Fp<FID>& r, uint32_t* s_r /* LDS, 10 words */) {
   r = a.r;
@@ -149,12 +170,22 @@ template <int FID> __device__ __forceinline__ bool sc_challenge(const ScSmallArg
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const volatile u32x4* line = reinterpret_cast<const volatile u32x4*>(a.chal);  // (volatile: re-read every time round)
     uint32_t ok = 0;
+    bool rejected = false;
     u32x4 q0, q1, q2, q3;
     for (uint32_t spin = 0;; spin++) {
       q0 = line[0], q1 = line[1], q2 = line[2], q3 = line[3];
-      if (q0.x == a.chal_seq && q1.x == a.chal_seq && q2.x == a.chal_seq && q3.x == a.chal_seq) {  // every 16-byte piece is the new one
-        ok = q3.y == 0 ? 1u : 0u;
-        break;
+      if (q0.x == a.chal_seq && q1.x == a.chal_seq && q2.x == a.chal_seq && q3.x == a.chal_seq) {  // every 16-byte piece shows the new sequence
+        const uint32_t l9[9] = {q0.y, q0.z, q0.w, q1.y, q1.z, q1.w, q2.y, q2.z, q2.w};
+        uint32_t c0, c1;
+        chal_sum(l9, q3.y, a.chal_seq, c0, c1);
+        if (c0 == q3.z && c1 == q3.w) {  // ... and the payload is the one the host summed: the line is whole
+          ok = q3.y == 0 ? 1u : 0u;
+          break;
+        }
+        if (!rejected && blockIdx.x == 0) {  // a torn line: counted once, polled again
+          rejected = true;
+          __hip_atomic_fetch_add(const_cast<uint32_t*>(a.chal) + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
       }
       if ((spin & 63u) == 63u && wall_clock64() - t0 > kChalTimeoutTicks) break;
     }
@@ -571,20 +602,74 @@ template <int FID> struct ScDev {
     return c.chal ? c.chal + (size_t)s * (kChalSlotBytes / 4) : nullptr;
   }
   // the CPU's stores to BAR memory are write-combined: a fence between the payload and the sequence word, and one behind it to push it out
-  static void chal_write(uint32_t* line, const uint32_t* limbs9, uint32_t abort_word, uint32_t seq) {
-    static const uint32_t zero9[9] = {0};
-    const uint32_t* l = limbs9 ? limbs9 : zero9;
+  static void chal_store(uint32_t* line, const uint32_t* l, uint32_t abort_word, uint32_t seq, uint32_t s0, uint32_t s1) {
     __m128i* q = reinterpret_cast<__m128i*>(line);  // (256-byte aligned)
     _mm_stream_si128(q + 0, _mm_set_epi32((int)l[2], (int)l[1], (int)l[0], (int)seq));
     _mm_stream_si128(q + 1, _mm_set_epi32((int)l[5], (int)l[4], (int)l[3], (int)seq));
     _mm_stream_si128(q + 2, _mm_set_epi32((int)l[8], (int)l[7], (int)l[6], (int)seq));
-    _mm_stream_si128(q + 3, _mm_set_epi32(0, 0, (int)abort_word, (int)seq));
+    _mm_stream_si128(q + 3, _mm_set_epi32((int)s1, (int)s0, (int)abort_word, (int)seq));
     _mm_sfence();  // push the write-combining buffer out
+  }
+  static void chal_write(uint32_t* line, const uint32_t* limbs9, uint32_t abort_word, uint32_t seq) {
+    static const uint32_t zero9[9] = {0};
+    const uint32_t* l = limbs9 ? limbs9 : zero9;
+    uint32_t s0, s1;
+    chal_sum(l, abort_word, seq, s0, s1);
+    if (const uint32_t torn = G.sc_torn_test.load(std::memory_order_relaxed)) {
+      // option sc_torn_test (tests only): what a write-combining buffer evicted in 8-byte chunks could leave on the device for a
+      // while -- every piece already shows the new sequence word and the new checksum is in place, but the SECOND half of each
+      // limb piece is still the old line's (here: the new limbs with bits flipped, so that the stale value is never accidentally
+      // right).  The waiting pass must poll past it; the whole line follows `torn` microseconds later.
+      uint32_t bad[9];
+      for (int i = 0; i < 9; i++) bad[i] = (i % 3) ? (l[i] ^ 0x15a5a5a5u) & 0x1fffffffu : l[i];
+      chal_store(line, bad, abort_word, seq, s0, s1);
+      const auto t0 = std::chrono::steady_clock::now();
+      while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(torn)) {
+      }
+      G.sc_torn_injected.fetch_add(1, std::memory_order_relaxed);
+    }
+    chal_store(line, l, abort_word, seq, s0, s1);
+  }
+  // lines the device rejected (the counter word behind each slot's line, bumped by sc_challenge): read back over the BAR -- slow,
+  // so only when the torn-line test is on
+  void collect_torn_rejects() {
+    if (!c.chal || !G.sc_torn_test.load(std::memory_order_relaxed)) return;
+    for (uint32_t s_ = 0; s_ < kMailSlots; s_++) {
+      volatile uint32_t* w = c.chal + (size_t)s_ * (kChalSlotBytes / 4) + 16;
+      const uint32_t v = *w;
+      if (v) {
+        *w = 0;
+        _mm_sfence();
+        G.sc_torn_rejects.fetch_add(v, std::memory_order_relaxed);
+      }
+    }
   }
   // Pre-launched passes waiting for a challenge (chal_seq per slot, 0: none).  While one waits, no stream of this call may be
   // synchronised -- the wait would sit behind a kernel that waits for THIS thread -- so the mailbox polls keep polling (up to
   // kArmedPollSeconds, yielding) instead of giving up after sc_poll_us, and anything that must synchronise cancels them first.
   uint32_t armed_seq[kMailSlots] = {};
+  // Blocks of pre-launched passes sit on CUs doing nothing but polling; forward progress of everything else -- the pass whose
+  // sums the host needs before it can send the challenge, other callers' kernels -- needs free slots.  A device-wide budget
+  // (kArmedBlocksCap, a quarter of the 1024 blocks of 256 lanes the chip holds at this register count) bounds them: a pass that
+  // would exceed it is launched late instead (16 claims x 64 blocks x several concurrent callers).
+  uint32_t armed_blocks[kMailSlots] = {};
+  static constexpr uint32_t kArmedBlocksCap = 256;
+  static std::atomic<uint32_t>& armed_total() {
+    static std::atomic<uint32_t> v{0};
+    return v;
+  }
+  bool arm_reserve(uint32_t slot, uint32_t blocks) {
+    if (armed_total().fetch_add(blocks, std::memory_order_relaxed) + blocks > kArmedBlocksCap) {
+      armed_total().fetch_sub(blocks, std::memory_order_relaxed);
+      return false;
+    }
+    armed_blocks[slot] = blocks;
+    return true;
+  }
+  void arm_release(uint32_t slot) {
+    if (armed_blocks[slot]) armed_total().fetch_sub(armed_blocks[slot], std::memory_order_relaxed);
+    armed_blocks[slot] = 0;
+  }
   static constexpr int kArmedPollSeconds = 4;
   bool any_armed() const {
     for (uint32_t q : armed_seq)
@@ -596,7 +681,12 @@ template <int FID> struct ScDev {
       if (armed_seq[s]) {
         chal_write(chal_line(s), nullptr, 1u, armed_seq[s]);
         armed_seq[s] = 0;
+        arm_release(s);
       }
+  }
+  ~ScDev() {
+    cancel_armed();
+    for (uint32_t s = 0; s < kMailSlots; s++) arm_release(s);
   }
   // has a poll that started at t0 gone on long enough?  (spin: the caller's iteration count, to look at the clock only now and then)
   bool poll_over(const std::chrono::steady_clock::time_point& t0, uint32_t spin, uint32_t poll_us) const {
@@ -919,19 +1009,29 @@ template <int FID, int MODE> struct ScPass {
     return G.sc_prelaunch.load(std::memory_order_relaxed) != 0 && G.sc_fused_sum.load(std::memory_order_relaxed) != 0 &&
            G.sc_poll_us.load(std::memory_order_relaxed) != 0 && len / 4 >= 1 && len / 4 <= kPrelaunchMaxHq && h.chal_line(slot) != nullptr;
   }
-  void prelaunch(size_t len, const Tables& t) {
+  // blocks launch_bind will start for a bound half of hq indices (the same rule, evaluated before the launch)
+  uint32_t bind_blocks(uint32_t hq) const {
+    const bool fused = G.sc_fused_sum.load(std::memory_order_relaxed) != 0;
+    if (kQuadForm && quad_on() && (hq <= 64 || (fused && hq <= kScQuadMaxHq))) return hq <= 64 ? 1u : (hq + 63) / 64;
+    return hq <= kScSmallHq ? 1u : sc_blocks_bind(hq);
+  }
+  // false: the device-wide budget of waiting blocks is spent -- the caller launches this pass when its challenge is known
+  bool prelaunch(size_t len, const Tables& t) {
+    if (!h.arm_reserve(slot, bind_blocks((uint32_t)(len / 4)))) return false;
     const uint32_t hq = (uint32_t)(len / 4), seq = h.next_seq(), cs = h.next_seq();
     ScSmallArgs<FID> x{A, B, C, A, B, C, t.eqL, t.eqR, F::zero(), nk, t.shift, t.mask, hq, 1u, seq, h.slot_dev(slot)};
     x.chal = h.chal_line(slot), x.chal_seq = cs;
     pre_parts = launch_bind(x, hq);
     pre_seq = seq;
     h.armed_seq[slot] = cs;
+    return true;
   }
   // the challenge for the pass in flight; returns the mailbox sequence its sums will carry
   uint32_t send(const H& rh) {
     const F r = rh.to_device();
     ScDev<FID>::chal_write(h.chal_line(slot), r.l, 0u, h.armed_seq[slot]);
     h.armed_seq[slot] = 0;
+    h.arm_release(slot);  // (the pass is running now; its blocks leave within microseconds)
     h.parts[slot] = pre_parts;  // (only now: until here the slot's pending result was the pass before)
     return pre_seq;
   }
@@ -959,6 +1059,9 @@ template <int FID, int MODE> struct ScPass {
   // t(1) of the current round: the sums pass over a copy of the tables with the halves swapped (the fallback; never on
   // transcript-derived challenges)
   H high_half_sum(size_t len, const Tables& t) {
+    // hipMalloc / hipFree below wait for the whole device: with a pass of this call waiting for ITS challenge they would never
+    // return.  The callers never pre-launch into a round that takes this path (Eq::l1p_zero, checked over ALL claims of a batch).
+    require(!h.any_armed(), NMX_E_HIP, "sum-check: the tau = 0 fall-back with a pre-launched pass in flight");
     const size_t hb = len / 2 * 32;
     char* tmp = nullptr;
     HIPCHK(hipMalloc((void**)&tmp, (size_t)NT * len * 32));
@@ -992,6 +1095,7 @@ static void sc_prove_t(Ctx& c, const void* claim, const void* taus, size_t num_r
   const uint32_t l = (uint32_t)num_rounds;
   try {
     ScDev<FID> h(c, flags);
+    try {
     arena_reserve(c, kScPartialBytes + 512);
     HIPCHK(hipMemsetAsync(c.arena + kScPartialBytes - 256, 0, 256, c.stream));  // k_sc_pass's ticket
     typename ScAlg<FID>::Eq eq;
@@ -1019,7 +1123,7 @@ static void sc_prove_t(Ctx& c, const void* claim, const void* taus, size_t num_r
       auto maybe_prelaunch = [&](size_t cur_len, uint32_t next_round) {
         if (cur_len / 2 <= h.tail_len || !pass.can_prelaunch(cur_len)) return;  // (the hand-over is never pre-launched)
         if (MODE == 3 && eq.l1p_zero) return;  // the round in between takes the fallback: its extra pass needs this stream free
-        pass.prelaunch(cur_len, MODE == 3 ? eqd.tables(next_round) : typename ScEqDev<FID>::Tables{nullptr, nullptr, 0, 0});
+        (void)pass.prelaunch(cur_len, MODE == 3 ? eqd.tables(next_round) : typename ScEqDev<FID>::Tables{nullptr, nullptr, 0, 0});
       };
       maybe_prelaunch(len, 2);
       for (;; j++) {
@@ -1059,9 +1163,13 @@ static void sc_prove_t(Ctx& c, const void* claim, const void* taus, size_t num_r
       if (NT == 3) h.alg.out(hC[0], out_claims + 64);
     }
     stream_wait(c.stream);  // the (partly bound) tables are the caller's again
+    h.collect_torn_rejects();
     h.finish_profile(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count());
+    } catch (...) {
+      h.sync_all_quiet();  // whatever failed (a HIP call, a mailbox wait, a range check): no kernel of this call still writes A / B / C
+      throw;
+    }
   } catch (const ScFail& f) {
-    (void)hipStreamSynchronize(c.stream);
     rethrow(f);
   }
 }
@@ -1106,7 +1214,7 @@ template <int FID> struct ScBatchDev {
     if (len[i] / 2 <= h.tail_len || claims[i].eq.l1p_zero || !pass[i].can_prelaunch(len[i])) return;
     if (tb_next.size() < pass.size()) tb_next.resize(pass.size());
     tb_next[i] = eqd[i].tables(claims[i].eq.round + 1);
-    pass[i].prelaunch(len[i], tb_next[i]);
+    (void)pass[i].prelaunch(len[i], tb_next[i]);  // (false: the budget of waiting blocks is spent; bind() launches it late)
   }
 };
 template <int FID>
@@ -1118,6 +1226,7 @@ static void sc_prove_batch_t(Ctx& c, const uint8_t* claims_b, const size_t* num_
   require(k >= 1 && k <= kMailSlots, NMX_E_ARG, "prove_batch_eval: between 1 and 16 claims");
   try {
     ScDev<FID> h(c, flags);
+    try {
     size_t heap_total = 0;
     for (size_t i = 0; i < k; i++) {
       require(num_rounds[i] >= 1 && num_rounds[i] < 31, NMX_E_ARG, "prove_batch_eval: 1 <= num_rounds < 31");
@@ -1150,16 +1259,15 @@ static void sc_prove_batch_t(Ctx& c, const uint8_t* claims_b, const size_t* num_
     // the set-up above), so a round costs one pass's latency, not k of them
     if (G.sc_side_streams.load(std::memory_order_relaxed))
       for (size_t i = 1; i < k; i++) dev.pass[i].stream = h.side_stream((uint32_t)(i - 1));
-    try {
-      sc_batch_rounds<FID>(h.alg, cs, dev, cb, cb_ctx, out_polys, out_r, out_finals, &h.prof.rounds);
+    sc_batch_rounds<FID>(h.alg, cs, dev, cb, cb_ctx, out_polys, out_r, out_finals, &h.prof.rounds);
+    h.sync_all();
+    h.collect_torn_rejects();
+    h.finish_profile(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count());
     } catch (...) {
-      h.sync_all_quiet();  // nothing of this call may still be running on a side stream when the tables go back to the caller
+      h.sync_all_quiet();  // nothing of this call may still be running (context or side stream) when the tables go back to the caller
       throw;
     }
-    h.sync_all();
-    h.finish_profile(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count());
   } catch (const ScFail& f) {
-    (void)hipStreamSynchronize(c.stream);
     rethrow(f);
   }
 }

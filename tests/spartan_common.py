@@ -140,14 +140,19 @@ def check_quad_prod(prove, fid, l, seed, force=None):
     return polys, rs, claims
 
 
-def check_batch_eval(prove, fid, num_rounds, seed, force=None):
+def check_batch_eval(prove, fid, num_rounds, seed, force=None, zero_coords=None):
     """prove(fid, claims, num_rounds, polys, eq_points, coeffs, transcript) -> (polys, r, finals).  Verified as
-    batch_eval_verify does (src/spartan/mod.rs:440-470 with sumcheck.rs:131-161)."""
+    batch_eval_verify does (src/spartan/mod.rs:440-470 with sumcheck.rs:131-161).  zero_coords = {claim: [coordinates]}: those
+    coordinates of that claim's evaluation point are zero (its eq instance then takes the reference's tau = 0 fall-back in those
+    rounds, sumcheck.rs:1085-1136, while the other claims do not)."""
     p = fc.FIELDS[fid]
     k = len(num_rounds)
     nmax = max(num_rounds)
     P = [fc.edge_vectors(fid, 1 << nr, seed + 3 * i) for i, nr in enumerate(num_rounds)]
     X = [fc.rand_vec(fid, max(nr, 1), seed + 100 + i)[:nr].copy() for i, nr in enumerate(num_rounds)]
+    for i, coords in (zero_coords or {}).items():
+        for j in coords:
+            X[i][j] = 0
     Pi, Xi = [ints(v) for v in P], [ints(x) if len(x) else [] for x in X]
     claims = [mle_eval(p, Pi[i], Xi[i]) for i in range(k)]
     rho = ints(fc.rand_vec(fid, 1, seed + 999))[0]

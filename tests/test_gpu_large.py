@@ -233,6 +233,18 @@ def test_prove_step_replay_matches_oracle(nmx, iters):
     assert f"N={3 * iters + 9986}" in out["config"]["workload"]
 
 
+def test_prove_step_replay_on_the_pasta_cycle_matches_oracle(nmx):
+    """north_star's other cycle (src/provider/pasta.rs): the same replay with Pallas primary / Vesta secondary, primary N ~ 2^16
+    (18 517 MinRoot iterations -> N = 65 537), serial and with the primary pair of commitments overlapped."""
+    import torch
+    import bench
+    args = argparse.Namespace(iters=18517, steps=1, warmup=0, no_cpu_baseline=False, cycle="pasta", also_overlap=True)
+    out = bench.prove_step_replay(args, torch)
+    assert out["cpu_baseline"]["gpu_matches_cpu"] is True
+    assert "N=65537 (pallas)" in out["config"]["workload"] and "(vesta)" in out["config"]["workload"]
+    assert out["overlap"]["same_commitments_as_serial"] is True
+
+
 def test_hyperkzg_replay_ell14_matches_oracle(nmx):
     import torch
     import bench

@@ -306,6 +306,43 @@ def test_peer_copy_branch_is_exercised(nmx, sharded):
     ck.close()
 
 
+def test_a_begun_commitment_over_a_sharded_key_waits_for_the_callers_async_producer(nmx, sharded):
+    """nmx_commit_begin runs the commitment on a pool worker; over a SHARDED key that worker leases one context per
+    shard, and those leases must be ordered behind the caller's pending stream-ordered call (NMX_ASYNC) just as a synchronous
+    commitment's are -- the worker now inherits the caller's asynchronous mark.  The producer here is a long axpy chain enqueued
+    without waiting; the commitment of its result is begun at once, with the staging + peer-copy branch forced (the branch in which a
+    shard stream copies the scalars itself)."""
+    import torch
+    from nova_amd import fieldvec as fv
+    L = sharded(3)
+    c = R.BN254_G1
+    fid = fv.SCALAR_FIELD_OF_CURVE[c.cid]
+    n = 1 << 17
+    bases = cref.sequential_bases(c, 9100, n)
+    ck = nmx.CommitmentKey.from_host(c.cid, bases)
+    ce = nmx.CommitmentEngine(c.cid)
+    a, b = util.random_scalars(c.cid, n, seed=21), util.random_scalars(c.cid, n, seed=22)
+    r = util.random_scalars(c.cid, 1, seed=23)
+    da, db = torch.from_numpy(a.copy()).cuda(), torch.from_numpy(b.copy()).cuda()
+    w_host = a
+    for _ in range(6):                                              # w = (((a + r b) + r b) + ...): six dependent passes
+        w_host = np.frombuffer(cref.field_axpy(fid, w_host, b, r, n), np.uint8).reshape(n, 32)
+    want = cref.Prepared(c.cid, bases, n).msm(w_host, n)
+    for force in (0, 1):
+        assert L.nmx_set_option(b"force_peer_copy", force) == 0
+        try:
+            for _ in range(4):
+                w = da
+                for _ in range(6):
+                    w = fv.axpy(fid, w, db, r, async_=True)          # enqueued, not waited for
+                t = ce.commit_begin(ck, w)
+                assert pt(t.finish()) == want
+                fv.sync()
+        finally:
+            assert L.nmx_set_option(b"force_peer_copy", 0) == 0
+    ck.close()
+
+
 def test_rccl_combine_inside_one_process(nmx, sharded):
     """VERDICT r3 missing #2: north_star's "final RCCL reduce ... over xGMI" inside the one-process mode.  The combine step is
     an ncclAllGather of one 128-byte slot per GPU + the point sum; on this one-GPU box the communicator has one rank (the

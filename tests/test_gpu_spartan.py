@@ -252,6 +252,48 @@ def test_prelaunched_passes_and_launched_passes_agree(nmx):
         assert L.nmx_set_option(b"sc_side_streams", 1) == 0
 
 
+def test_a_torn_challenge_line_is_polled_past(nmx):
+    """The challenge of a pre-launched pass reaches the device as four write-combined 16-byte stores; nothing guarantees that such a
+    store arrives whole.  Option sc_torn_test makes the host write, ahead of every challenge, what a buffer evicted in 8-byte chunks
+    could leave there: new sequence words and new checksum in all four pieces, the second half of each limb piece still stale.  The
+    waiting pass binds its tables IN PLACE with whatever it accepts, so it must reject that line (checksum) and wait for the whole one:
+    every proof equals the oracle's, and the device reports the rejected lines (VERDICT r5 weak #2 / next #1a)."""
+    from nova_amd import _lib
+    L = _lib.lib()
+    p = fc.FIELDS[1]
+    st0 = _lib.stats()
+    try:
+        assert L.nmx_set_option(b"sc_torn_test", 40) == 0          # the torn line stays for 40 us: a polling pass reads it many times
+        for l in (10, 13, 15):
+            both(sp.check_cubic3, g_cubic3(), o_cubic3, 1, l, seed=180 + l, brute=False)
+            both(sp.check_quad_prod, g_quad, o_quad, 1, l + 1, seed=190 + l)
+        both(sp.check_cubic3, g_cubic3(), o_cubic3, 3, 12, seed=181, brute=False)
+        both(sp.check_quad_prod, g_quad, o_quad, 0, 12, seed=182)
+        both(sp.check_batch_eval, g_batch, o_batch, 1, [14, 11, 13], seed=183)
+        both(sp.check_cubic3, g_cubic3(), o_cubic3, 1, 12, seed=184, force={0: 0, 3: 1, 7: p - 1, 9: 0}, brute=False)
+    finally:
+        assert L.nmx_set_option(b"sc_torn_test", 0) == 0
+    st1 = _lib.stats()
+    injected = st1[_lib.STAT_SC_TORN_INJECTED] - st0[_lib.STAT_SC_TORN_INJECTED]
+    rejects = st1[_lib.STAT_SC_TORN_REJECTS] - st0[_lib.STAT_SC_TORN_REJECTS]
+    if injected == 0:
+        pytest.skip("no large BAR on this box: nothing is pre-launched, so no challenge line is written")
+    # every torn line was written while a pass waited for it (the pass polls continuously): almost all are seen and rejected
+    assert rejects >= injected // 2, (injected, rejects)
+
+
+def test_a_fallback_round_of_one_claim_beside_prelaunched_passes_of_the_others(nmx):
+    """claim j of a batch takes the tau = 0 fall-back (an eq point with a zero coordinate) in a round in which claim i's
+    pass would have been enqueued ahead of its challenge.  The fall-back allocates and waits for the device; a pass waiting for the
+    host would have blocked it until its 2 s time-out and the call would have failed.  Nothing is pre-launched into such a round."""
+    import time
+    t0 = time.perf_counter()
+    for zc in ({1: [0]}, {1: [3, 4]}, {0: [5], 1: [2]}, {2: [0, 1, 2]}):
+        both(sp.check_batch_eval, g_batch, o_batch, 1, [14, 12, 13], seed=210 + len(zc), zero_coords=zc)
+    both(sp.check_batch_eval, g_batch, o_batch, 1, [13, 13], seed=215, zero_coords={1: list(range(13))})
+    assert time.perf_counter() - t0 < 60, "a pre-launched pass sat out its time-out"
+
+
 def test_host_added_partials_and_ticket_passes_agree(nmx):
     """option sc_host_parts: a pass of <= 64 blocks sends every block's partial sums to the host, which adds them up (default); 0: the
     block that draws the last ticket does.  Sizes around the 64-block limits of the one-lane (2^14 indices) and four-lane (2^12) forms,
@@ -366,6 +408,21 @@ def test_spartan_prove_replay_matches_the_oracle(nmx):
     assert all(out["proof_verifies"].values())
     assert out["config"]["rounds"] == [12, 13, 12]
     assert set(out["provers"]) == {"sumcheck_outer", "sumcheck_inner", "sumcheck_batch"}
+
+
+@pytest.mark.parametrize("curve,ell", [(1, 14), (2, 11), (3, 11)])
+def test_spartan_prove_replay_on_the_other_scalar_fields(nmx, curve, ell):
+    """S2 of CompressedSNARK::prove is the same Spartan prover over GRUMPKIN's scalar field (= BN254 Fq) on the secondary circuit,
+    ~2^14 constraints (src/nova/mod.rs:862-881); the Pasta cycle runs it over Pallas's / Vesta's.  The whole sequence (three
+    sum-checks, evaluations, transposed products, batch witness) against the oracle and the reference's verifier equations."""
+    import argparse
+    import torch
+    import bench
+    args = argparse.Namespace(log2n=ell, steps=1, warmup=1, no_cpu_baseline=False, curve=curve)
+    out = bench.spartan_replay(args, torch)
+    assert out["cpu_baseline"]["gpu_matches_cpu"] is True, out["cpu_baseline"]["checks"]
+    assert all(out["proof_verifies"].values())
+    assert out["config"]["rounds"] == [ell, ell + 1, ell]
 
 
 def test_provers_and_commitments_from_several_threads(nmx):

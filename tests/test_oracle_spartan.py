@@ -60,6 +60,10 @@ def test_batch_eval_with_polynomials_of_different_sizes(fid, nrs):
 def test_batch_eval_fallback_when_an_evaluation_point_has_a_zero():
     p = fc.FIELDS[1]
     sp.check_batch_eval(o_batch, 1, [4, 6], seed=900, force={0: 0, 3: 1, 5: p - 1})
+    # evaluation points that really have zero coordinates (l(1) = 0 in those rounds: sumcheck.rs:1085-1136), in one claim only / in all
+    sp.check_batch_eval(o_batch, 1, [6, 5, 7], seed=901, zero_coords={1: [0]})
+    sp.check_batch_eval(o_batch, 1, [6, 5], seed=902, zero_coords={0: [2, 3], 1: [4]})
+    sp.check_batch_eval(o_batch, 3, [5, 5], seed=903, zero_coords={1: list(range(5))})
 
 
 @pytest.mark.parametrize("fid", [0, 1, 2, 3])
