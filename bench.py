@@ -118,6 +118,7 @@ def main():
                     help="register the key WITHOUT window tables: the plain path (W bucket sets) that first / second sight of a "
                          "cached array, IPA's per-round keys and keys whose tables do not fit take")
     ap.add_argument("--iters", type=int, default=65536, help="prove_step_replay: MinRoot iterations per step")
+    ap.add_argument("--log2n-secondary", type=int, default=None, help="compressed_snark_replay: log2 of the secondary circuit's size (default min(14, log2n))")
     ap.add_argument("--cycle", default="bn254", choices=["bn254", "pasta"], help="prove_step replay: the curve cycle (BN254/Grumpkin or Pallas/Vesta)")
     ap.add_argument("--opens", default="batch", choices=["batch", "threads", "serial"],
                     help="hyperkzg replay: the three kzg_open commitments as one batch_commit (default), three host threads (the reference's par_iter), or one after the other")
@@ -126,7 +127,7 @@ def main():
                     help="prove_step replay: commit(W) begun (nmx_commit_begin) beside the cross term + commit(T) it does not depend on "
                          "(1: the primary pair inside one prove_step; 2: also the secondary pair, across the step boundary)")
     ap.add_argument("--sync-field-ops", action="store_true", help="prove_step replay: every field-vector call waits for its kernel (round 3's form)")
-    ap.add_argument("--workload", default="msm", choices=["msm", "axpy", "cross_term", "bind", "sumcheck3", "round3", "quad_prod", "lincomb8", "horner", "mle_eval", "spmv", "prove_step_replay", "hyperkzg_replay", "spartan_replay"],
+    ap.add_argument("--workload", default="msm", choices=["msm", "axpy", "cross_term", "bind", "sumcheck3", "round3", "quad_prod", "lincomb8", "horner", "mle_eval", "spmv", "prove_step_replay", "hyperkzg_replay", "spartan_replay", "compressed_snark_replay"],
                     help="msm = the headline (default); the others time one HBM-bound field-vector kernel of "
                          "SURVEY.md 8(f) at 2^log2n elements per GPU")
     args = ap.parse_args()
@@ -179,6 +180,9 @@ def main():
     if args.workload == "spartan_replay":
         assert world == 1
         return emit(spartan_replay(args, torch), False, dist)
+    if args.workload == "compressed_snark_replay":
+        assert world == 1
+        return emit(compressed_snark_replay(args, torch), False, dist)
     if args.workload != "msm":
         return field_workload(args, world, rank, L, torch, dist)
 
@@ -827,7 +831,7 @@ def extras(out, args, torch, L, ck, host_scalars, dev_scalars):
     out["prove_step_replay_ms"] = {"ms": round(ps["value"], 4), "iters_per_step": 65536, "cpu_ms": round(ps["cpu_baseline"]["value"], 2),
                                    "cpu_cores": ps["cpu_baseline"]["cores"], "gpu_matches_cpu": ps["cpu_baseline"]["gpu_matches_cpu"],
                                    "breakdown_ms": ps.get("breakdown_ms"), "overlap": ps.get("overlap"),
-                                   "what": ps["config"]["workload"]}
+                                   "trait_only": ps.get("trait_only"), "what": ps["config"]["workload"]}
     # (5) configs[4]: HyperKZG prove replay at n = 2^20
     a3 = argparse.Namespace(**vars(args))
     a3.log2n, a3.steps, a3.warmup = 20, 3, 1
@@ -842,6 +846,19 @@ def extras(out, args, torch, L, ck, host_scalars, dev_scalars):
                                     "breakdown_ms": sr["breakdown_ms"], "provers": sr["provers"], "what": sr["config"]["workload"]}
     except Exception as e:                                 # never lose the headline to an auxiliary block
         out["spartan_replay_ms"] = {"error": repr(e)}
+    # (5c) configs[4] as ONE chained sequence: CompressedSNARK::prove (folds -> Spartan -> HyperKZG on the batched witness in HBM)
+    try:
+        a5 = argparse.Namespace(**vars(args))
+        a5.log2n, a5.steps, a5.warmup, a5.log2n_secondary = 20, 3, 1, 14
+        cs = compressed_snark_replay(a5, torch)
+        out["compressed_snark_replay_ms"] = {"ms": round(cs["value"], 3), "log2n": 20, "log2n_secondary": 14,
+                                             "cpu_ms": round(cs["cpu_baseline"]["value"], 1), "cpu_cores": cs["cpu_baseline"]["cores"],
+                                             "gpu_matches_cpu": cs["cpu_baseline"]["gpu_matches_cpu"], "groups_ms": cs["groups_ms"],
+                                             "breakdown_ms": cs["breakdown_ms"], "proof_verifies": all(cs["proof_verifies"].values()),
+                                             "trait_only": {k: v for k, v in cs["trait_only"].items() if k != "per_call_ms"},
+                                             "what": cs["config"]["workload"]}
+    except Exception as e:                                 # never lose the headline to an auxiliary block
+        out["compressed_snark_replay_ms"] = {"error": repr(e)}
     # (6) the field-vector kernels' rooflines (north_star: >= 40 % of HBM is about THESE kernels)
     try:
         out["fieldvec"] = fieldvec_block(args, torch, L)
@@ -1049,7 +1066,7 @@ def prove_step_replay(args, torch):
         keys = {k: ck[k].read(0, cur[k][2]) for k in cur}
         prep = {k: cref.Prepared(cur[k][0], keys[k], cur[k][2]) for k in cur}
         t1 = time.perf_counter()
-        exp = []
+        exp, tlog = [], {}
         for k, uu in (("S", uS), ("P", u)):
             cid, fid, n = cur[k]
             h = host[k]
@@ -1061,12 +1078,18 @@ def prove_step_replay(args, torch):
             cref.field_axpy(fid, h["E1"], T, r[k], n)
             comW = prep[k].msm(h["W"], n)
             exp.append((comT, comW))
+            tlog[k] = (cid, keys[k], [("commit", [np.frombuffer(T, np.uint8).reshape(n, 32)], None), ("commit", [h["W"]], [comW])], prep[k])
         t_cpu = time.perf_counter() - t1
         ok = [(res[0].xy, int(res[0].is_inf)) == exp[0][0], (res[1].xy, int(res[1].is_inf)) == exp[1][1],
               (res[2].xy, int(res[2].is_inf)) == exp[1][0], (res[3].xy, int(res[3].is_inf)) == exp[0][1]]
         outj["cpu_baseline"] = {"value": t_cpu * 1e3, "unit": "ms", "cores": threads, "kind": "port",
                                 "sample": "the same call sequence once through oracle/nova_ref.c (commit re-loads the key "
-                                          "each call, as a fresh Vec<Affine> would not)", "gpu_matches_cpu": all(ok)}
+                                          "each call, as a fresh Vec<Affine> would not)", "serial_parts": CPU_SERIAL_PARTS,
+                                "gpu_matches_cpu": all(ok)}
+        # what the step costs the provider when Nova calls it UNCHANGED (only the DlogGroupExt override wired in): the four MSMs
+        # in slice form over host scalars -- 206 594 / 10 538 of them at the default size --, everything else on the reference's CPU
+        if getattr(args, "trait_only", True):
+            outj["trait_only"] = trait_only_msms(tlog)
     for k in ck:
         ck[k].close()
         for m in mats[k]:
@@ -1210,15 +1233,26 @@ def spartan_instance(fid, ell, seed=None):
     return csr, hW, u, hz
 
 
-def spartan_sequence(be, ell, p, u, call=lambda name, fn: fn()):
+def spartan_sequence(be, ell, p, u, call=lambda name, fn: fn(), inst=None, tr=None):
     """The provider calls of `RelaxedR1CSSNARK::prove` up to the evaluation argument, in the reference's order
-    (src/spartan/snark.rs:133-233), against a provider `be` (the HIP path or the oracle behind one interface)."""
+    (src/spartan/snark.rs:133-233), against a provider `be` (the HIP path or the oracle behind one interface).
+    inst = (W, E, X): the instance's vectors where they are (the chained replay hands over a folded witness that never left HBM);
+    default: the provider's own be.W / be.E / be.concat_z().  tr: a transcript already under way."""
     from tests import standin
     le = lambda v: int(v).to_bytes(32, "little")
     num = lambda b: int.from_bytes(bytes(b), "little")
-    tr = standin.Transcript(seed=SPARTAN_SEED)
+    tr = tr or standin.Transcript(seed=SPARTAN_SEED)
     tau = [tr.squeeze() for _ in range(ell)]                                  # snark.rs:141-143
-    zc = call("z_concat", lambda: be.concat_z())                              # :133, :193-196
+    if inst is not None:
+        class _View:                                                          # the same provider, looking at the instance handed in
+            W, E = inst[0], inst[1]
+
+            def __getattr__(self, name):
+                return getattr(be_, name)
+        be_, be = be, _View()
+        zc = call("z_concat", lambda: be_.concat_z(inst[0], u, inst[2]))      # :133, :193-196
+    else:
+        zc = call("z_concat", lambda: be.concat_z())                          # :133, :193-196
     Az, Bz, Cz = (call("spmv_x3", lambda j=j: be.spmv(j, zc)) for j in range(3))        # :146
     uCzE = call("uCz_E", lambda: be.axpy(be.E, Cz, u))                        # :147-149
     outer = call("sumcheck_outer", lambda: be.cubic3(le(0), b"".join(tau), Az, Bz, uCzE, tr))     # :158-165
@@ -1245,7 +1279,7 @@ def spartan_sequence(be, ell, p, u, call=lambda name, fn: fn()):
     w_joint = call("batch_witness", lambda: be.lincomb([be.W, be.E], c))       # spartan/mod.rs:429
     # (the batched witness stays where it is -- it is EE::prove's input; the caller brings it to the host outside the timed region)
     return {"outer": outer, "inner": inner, "batch": batch, "evaluations": (claim_Cz, eval_E, eval_W), "batch_witness": w_joint,
-            "tau": tau, "r": r, "rho": rho}
+            "tau": tau, "r": r, "rho": rho, "c": c}
 
 
 def spartan_verify(p, u, res):
@@ -1453,6 +1487,414 @@ def spartan_replay(args, torch):
     for m in mats:
         m.close()
     return outj
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[4] as ONE sequence: CompressedSNARK::prove (src/nova/mod.rs:793-881)
+# ---------------------------------------------------------------------------------------------------------------------------
+class CsnarkSide:
+    """Host data of one side (one curve of the cycle) of the chained replay: the padded shape (num_cons = num_vars = 2^ell,
+    z = [W | u | X | 0...] of 2^(ell+1) entries), the running relaxed instance (W1, E1, u1, X1) -- SATISFIED: E1 = Az1 o Bz1 - u1 Cz1,
+    built by `fill_E1` with the provider's own kernels --, the randomness of sample_random_instance_witness (W2, u2, X2;
+    src/r1cs/mod.rs:786-800 draws it from OsRng on the host: data, not provider work) and the blinds."""
+
+    def __init__(self, cid, ell, seed):
+        from nova_amd import fieldvec as fv
+        from tests import util
+        self.cid, self.ell, self.n = cid, ell, 1 << ell
+        self.fid = fv.SCALAR_FIELD_OF_CURVE[cid]
+        self.p = util_modulus(self.fid)
+        self.csr = spartan_like_matrices(self.fid, self.n, seed=seed)
+        rs = lambda k, sd: util.random_scalars(cid, k, seed=seed + sd)
+        self.W1, self.W2 = rs(self.n, 1), rs(self.n, 2)          # a running witness after many folds is full-width
+        self.u1, self.X1, self.u2, self.X2 = rs(1, 3), rs(1, 4), rs(1, 5), rs(1, 6)
+        self.r_W, self.r_E, self.r_T = rs(1, 7), rs(1, 8), rs(1, 9)
+        self.E1 = None
+
+    def z(self, W, u, X):
+        hz = np.zeros((2 * self.n, 32), np.uint8)
+        hz[:self.n], hz[self.n], hz[self.n + 1] = W, u[0], X[0]
+        return hz
+
+
+class GpuProvider:
+    """The HIP path behind the replay sequences' provider interface: every vector resident in HBM, the field calls stream-ordered
+    (NMX_ASYNC) where nothing on the host looks at their result before the next synchronous call."""
+
+    def __init__(self, torch, side, ck):
+        import nova_amd
+        from nova_amd import _lib, fieldvec as fv
+        self.t, self.fv, self._lib, self.s, self.ck = torch, fv, _lib, side, ck
+        self.fid, self.n = side.fid, side.n
+        self.ce = nova_amd.CommitmentEngine(side.cid)
+        self.mats = [fv.SparseMatrix(side.fid, ip, ix, dt, 2 * side.n) for ip, ix, dt in side.csr]
+        up = lambda v: torch.from_numpy(np.ascontiguousarray(v)).cuda()
+        self.W1, self.W2 = up(side.W1), up(side.W2)
+        self.zeros = torch.zeros((side.n, 32), dtype=torch.uint8, device="cuda")
+        if side.E1 is None:                                      # the running instance is satisfied: E1 = Az1 o Bz1 - u1 Cz1
+            dE1 = fv.r1cs_cross_term(self.mats[0], self.mats[1], self.mats[2], up(side.z(side.W1, side.u1, side.X1)), None, self.zeros, side.u1)
+            side.E1 = dE1.cpu().numpy()
+        self.E1 = up(side.E1)
+
+    def close(self):
+        for m in self.mats:
+            m.close()
+
+    pt = staticmethod(lambda c: (c.xy, int(c.is_inf)))
+
+    def concat_z(self, W, u, X):
+        return self.fv.concat(self.fid, [W, u, X], n_out=2 * self.n, async_=True)
+
+    def cross_term0(self, z, u):                                 # AZ o BZ - u CZ (sample_random_instance_witness, r1cs/mod.rs:803-812)
+        return self.fv.r1cs_cross_term(self.mats[0], self.mats[1], self.mats[2], z, None, self.zeros, u, async_=True)
+
+    def commit(self, v, r=None):
+        return self.pt(self.ce.commit(self.ck, v, r))
+
+    def batch_commit(self, vs):
+        return [self.pt(c) for c in self.ce.batch_commit(self.ck, vs)]
+
+    def vec_add(self, a, b):
+        return self.fv.vec_add(self.fid, a, b, async_=True)
+
+    def spmv(self, j, v):
+        return self.mats[j].multiply_vec(v, async_=True)
+
+    def spmv_t(self, j, v):
+        return self.mats[j].multiply_vec_transposed(v, async_=True)
+
+    def cross_term2(self, az, bz, cz, e1, e2, u):
+        return self.fv.cross_term2(self.fid, az, bz, cz, e1, e2, u, async_=True)
+
+    def axpy(self, a, b, r):
+        return self.fv.axpy(self.fid, a, b, r, async_=True)
+
+    def axpy2(self, a, b, c, r):
+        return self.fv.axpy2(self.fid, a, b, c, r, async_=True)
+
+    def clone(self, v):
+        return self.fv.concat(self.fid, [v], async_=True)
+
+    def multi_evaluate(self, zs, r):
+        return self.fv.mle_multi_evaluate(self.fid, zs, r)
+
+    def evaluate(self, z, r):
+        return self.fv.mle_evaluate(self.fid, z, r)
+
+    def eq_evals(self, r):
+        return self.fv.eq_evals_from_points(self.fid, r, device=True)
+
+    def lincomb(self, vs, s):
+        return self.fv.lincomb_powers(self.fid, vs, s)
+
+    def fold_pairs(self, v, x):
+        return self.fv.fold_pairs(self.fid, v, x, async_=True)
+
+    def poly_eval_multi(self, polys, us):
+        return self.fv.poly_eval_multi(self.fid, polys, us)
+
+    def div_by_monomial(self, B, u):
+        return self.fv.div_by_monomial(self.fid, B, u).contiguous()
+
+    def host(self, v):
+        return v.cpu().numpy().tobytes()
+
+    def cubic3(self, claim, taus, A, B, C, tr):
+        return self.fv.sumcheck_prove_cubic_with_three_inputs(self.fid, claim, taus, A, B, C, tr.fn(self._lib.TRANSCRIPT_FN), ctx=tr.ctx)
+
+    def quad(self, claim, nr, A, B, tr):
+        return self.fv.sumcheck_prove_quad_prod(self.fid, claim, nr, A, B, tr.fn(self._lib.TRANSCRIPT_FN), ctx=tr.ctx)
+
+    def batch(self, claims, nrs, polys, pts, coeffs, tr):
+        return self.fv.sumcheck_prove_batch_eval(self.fid, claims, nrs, polys, pts, coeffs, tr.fn(self._lib.TRANSCRIPT_FN), ctx=tr.ctx)
+
+
+class CpuProvider(SpartanCpu):
+    """the oracle behind the same interface (the checker / cpu_baseline leg).  `msm_log`: every commitment's (kind, host vectors) in
+    call order -- what Nova hands to DlogGroupExt when the provider is wired in through the trait alone (trait_only)."""
+
+    def __init__(self, side, key, h):
+        super().__init__(side.fid, side.csr, side.n, None, None, None)
+        from oracle import cref
+        self.s, self.key, self.h = side, key, h
+        self.prep = cref.Prepared(side.cid, key, len(key))
+        self.zeros = np.zeros((side.n, 32), np.uint8)
+        if side.E1 is None:                                      # (CPU-only runs: the satisfied running instance through the oracle)
+            side.E1 = self.cross_term0(side.z(side.W1, side.u1, side.X1), side.u1)
+        self.W1, self.W2, self.E1 = side.W1, side.W2, side.E1
+        self.msm_log = []
+
+    def concat_z(self, W, u, X):
+        return self.s.z(W, u, X)
+
+    def cross_term0(self, z, u):
+        az, bz, cz = (self.spmv(j, z) for j in range(3))
+        return self._np(self.cref.field_cross_term(self.fid, az, bz, cz, self.zeros, u, self.n), self.n)
+
+    def commit(self, v, r=None):
+        v = np.ascontiguousarray(v)
+        if r is None or bytes(r) == bytes(32):
+            out = self.prep.msm(v, len(v))
+            self.msm_log.append(("commit", [v], [out]))
+            return out
+        self.msm_log.append(("commit", [v], None))             # (the unblinded MSM the trait call returns: computed by trait_only_msms, untimed)
+        return self.cref.commit(self.s.cid, v, self.key, len(v), self.h, r)
+
+    def batch_commit(self, vs):
+        vs = [np.ascontiguousarray(v) for v in vs]
+        out = [self.prep.msm(v, len(v)) for v in vs]
+        self.msm_log.append(("batch", vs, out))
+        return out
+
+    def vec_add(self, a, b):
+        from tests import util
+        return self._np(self.cref.field_axpy(self.fid, a, b, util.int_to_le32(1), len(a)), len(a))
+
+    def cross_term2(self, az, bz, cz, e1, e2, u):
+        return self._np(self.cref.field_cross_term2(self.fid, az, bz, cz, e1, e2, u, self.n), self.n)
+
+    def lincomb(self, vs, s):
+        m = max(len(v) for v in vs)
+        return self._np(self.cref.lincomb_powers(self.fid, [np.ascontiguousarray(v).tobytes() for v in vs], s, m), m)
+
+    def fold_pairs(self, v, x):
+        m = len(v) // 2
+        return self._np(self.cref.field_bind(self.fid, v, 0, 1, 2, x, m), m)
+
+    def poly_eval_multi(self, polys, us):
+        return [[self.cref.suffix_horner(self.fid, f, len(f), u)[:32] for u in us] for f in polys]
+
+    def div_by_monomial(self, B, u):
+        return np.ascontiguousarray(self._np(self.cref.suffix_horner(self.fid, B, len(B), u), len(B))[1:])
+
+
+def relaxed_fold_sequence(be, side, tr, call):
+    """sample_random_instance_witness (src/r1cs/mod.rs:786-830) + NIFSRelaxed::prove (src/nova/nifs.rs:118-175: commit_T_relaxed,
+    src/r1cs/mod.rs:629-661; fold_relaxed, :1070-1107) on the running instance of `side`: what CompressedSNARK::prove runs once per
+    curve before the SNARKs (src/nova/mod.rs:812-845).  Returns the folded (W, E, u, X) -- W and E stay where the provider keeps
+    them -- and the three commitments."""
+    le = lambda v: int(v).to_bytes(32, "little")
+    num = lambda b: int.from_bytes(bytes(b), "little")
+    p = side.p
+    z2 = call("rand.z", lambda: be.concat_z(be.W2, side.u2, side.X2))
+    E2 = call("rand.E", lambda: be.cross_term0(z2, side.u2))                              # r1cs/mod.rs:803-812
+    cW2 = call("rand.commit_W", lambda: be.commit(be.W2, side.r_W))                       # :815-818 (rayon::join)
+    cE2 = call("rand.commit_E", lambda: be.commit(E2, side.r_E))
+    z1 = call("fold.z", lambda: be.concat_z(be.W1, side.u1, side.X1))                     # commit_T_relaxed :638-639
+    Z = call("fold.vec_add", lambda: be.vec_add(z1, z2))                                  # :643-647
+    u12 = np.frombuffer(le((num(side.u1) + num(side.u2)) % p), np.uint8).reshape(1, 32)   # :648
+    AZ, BZ, CZ = (call("fold.spmv_x3", lambda j=j: be.spmv(j, Z)) for j in range(3))      # :650
+    T = call("fold.cross_term2", lambda: be.cross_term2(AZ, BZ, CZ, be.E1, E2, u12))      # :652-659
+    cT = call("fold.commit_T", lambda: be.commit(T, side.r_T))                            # :661
+    for c in (cW2, cE2, cT):                                                              # nifs.rs:147-160 (the RO; here the stand-in)
+        tr.absorb(c[0])
+    r = tr.squeeze()
+    W = call("fold.W", lambda: be.axpy(be.W1, be.W2, r))                                  # fold_relaxed :1082-1086
+    E = call("fold.E", lambda: be.axpy2(be.E1, T, E2, r))                                 # :1087-1092  E1 + r T + r^2 E2
+    rr = num(r)
+    u = np.frombuffer(le((num(side.u1) + rr * num(side.u2)) % p), np.uint8).reshape(1, 32)
+    X = np.frombuffer(le((num(side.X1) + rr * num(side.X2)) % p), np.uint8).reshape(1, 32)
+    return {"W": W, "E": E, "u": u, "X": X, "r": r, "commitments": [cW2, cE2, cT], "keep": (z1, z2, Z, AZ, BZ, CZ, T, E2)}
+
+
+def hyperkzg_sequence(be, ell, p, hat_P, point, tr, call):
+    """EE::prove of HyperKZG (src/provider/hyperkzg.rs:926-1116) on a polynomial that is already where the provider keeps its
+    vectors: ell - 1 pair folds (:1085-1095), batch_commit (:1100), r from the commitments (:1105), u = [r, -r, r^2] (:1106),
+    the v matrix (:1049-1056), q from it (:1058), B (:1059), three openings (:1062-1065; here one batch_commit of the quotients)."""
+    le = lambda v: int(v).to_bytes(32, "little")
+    num = lambda b: int.from_bytes(bytes(b), "little")
+    polys, cur = [hat_P], hat_P
+    for i in range(ell - 1):
+        cur = call("ee.fold_pairs", lambda c=cur, i=i: be.fold_pairs(c, point[ell - i - 1]))
+        polys.append(cur)
+    coms = call("ee.batch_commit", lambda: be.batch_commit(polys[1:]))
+    for c in coms:
+        tr.absorb(c[0])
+    r = num(tr.squeeze())
+    us = np.frombuffer(le(r) + le((p - r) % p) + le(r * r % p), np.uint8).reshape(3, 32)
+    evals = call("ee.evals", lambda: be.poly_eval_multi(polys, us))
+    tr.absorb(b"".join(b"".join(row) for row in evals))
+    q = tr.squeeze()
+    B = call("ee.batch_poly", lambda: be.lincomb(polys, q))
+    hs = [call("ee.div_x3", lambda j=j: be.div_by_monomial(B, us[j:j + 1])) for j in range(3)]
+    opens = call("ee.commit_opens", lambda: be.batch_commit(hs))
+    return {"com": coms, "v": evals, "w": opens}
+
+
+def compressed_snark_sequence(beP, beS, sideP, sideS, call=lambda name, fn: fn()):
+    """The provider-side work of CompressedSNARK::prove (src/nova/mod.rs:793-881) in the reference's order:
+      secondary: sample_random_instance_witness + NIFSRelaxed::prove          (:812-826)
+      primary:   sample_random_instance_witness + NIFSRelaxed::prove          (:829-843)
+      S1::prove on the primary = RelaxedR1CSSNARK::prove (src/spartan/snark.rs:113-260): the sum-check sequence, whose batched
+                 witness W + c E (spartan/mod.rs:429) is the polynomial EE::prove folds and opens (snark.rs:236-244)
+      S2::prove on the secondary: the sum-check sequence (its evaluation argument is IPA, src/provider/ipa_pc.rs -- not replayed)
+    NOT replayed: NIFS::prove of (:797-809) -- the prove_step replay's secondary fold --, the RO / Keccak transcripts (one stand-in
+    per SNARK and one per fold), derandomize (:846-861: two scalar products of h per side), S1 || S2 (rayon::join: serial here)."""
+    from tests import standin
+    cp = lambda tag: (lambda nm, fn: call(f"{tag}.{nm}", fn))      # spans are kept per side: P = primary, S = secondary
+    out = {}
+    for tag, be, side in (("S", beS, sideS), ("P", beP, sideP)):
+        out[f"fold_{tag}"] = relaxed_fold_sequence(be, side, standin.Transcript(seed=SPARTAN_SEED + 1), cp(tag))
+    for tag, be, side in (("P", beP, sideP), ("S", beS, sideS)):
+        f = out[f"fold_{tag}"]
+        tr = standin.Transcript(seed=SPARTAN_SEED)
+        sp = spartan_sequence(be, side.ell, side.p, f["u"], cp(tag), inst=(f["W"], f["E"], f["X"]), tr=tr)
+        out[f"spartan_{tag}"] = sp
+        if tag == "P":                                            # snark.rs:236-244: batched_w.p, batched_u.x = the batch sum-check's r
+            out["ee_P"] = hyperkzg_sequence(be, side.ell, side.p, sp["batch_witness"], sp["batch"][1], tr, cp(tag))
+    return out
+
+
+def csnark_digest(res, host):
+    """what the two legs must agree on, byte for byte"""
+    d = {}
+    for tag in ("S", "P"):
+        f, sp = res[f"fold_{tag}"], res[f"spartan_{tag}"]
+        d[f"fold_{tag}.commitments"] = f["commitments"]
+        d[f"fold_{tag}.r"] = f["r"]
+        for k in ("outer", "inner", "batch", "evaluations"):
+            d[f"spartan_{tag}.{k}"] = sp[k]
+        d[f"spartan_{tag}.batch_witness"] = host[tag](sp["batch_witness"])
+    d["ee_P"] = res["ee_P"]
+    return d
+
+
+def compressed_snark_replay(args, torch):
+    """REPLAY of CompressedSNARK::prove as ONE chained sequence (BASELINE.json configs[4]; see compressed_snark_sequence): primary
+    BN254 at num_cons = 2^log2n, secondary Grumpkin at 2^log2n_secondary (default 14, the augmented circuit's size), every vector
+    resident in HBM from the folds to the openings -- the folded witness is the Spartan instance, Spartan's batched witness is
+    the polynomial HyperKZG folds and opens.  Checked against oracle/nova_ref.c run in the same order (every commitment, round
+    polynomial, evaluation, the batched witnesses, the evaluation argument) and the reference's verifier equations on both Spartan
+    proofs.  `trait_only`: the MSM calls of the same sequence in the form Nova makes them when ONLY the DlogGroupExt override of
+    INTEGRATION.md section 2 is applied (slice-form nmx_msm / nmx_msm_batch, host scalars, bases through the slice cache; the field
+    work stays on the reference's CPU and is not timed here).  A replay, not `prove`: the Rust reference cannot be built here."""
+    import nova_amd
+    from nova_amd import _lib
+    L = _lib.lib()
+    ellP, ellS = args.log2n, getattr(args, "log2n_secondary", None) or min(14, args.log2n)
+    cP, cS = {"bn254": (0, 1), "pasta": (2, 3)}[getattr(args, "cycle", "bn254")]
+    sides = {"P": CsnarkSide(cP, ellP, seed=900 + ellP), "S": CsnarkSide(cS, ellS, seed=950 + ellS)}
+    cks = {k: nova_amd.CommitmentEngine(sd.cid).setup_synthetic(sd.n, k0=7) for k, sd in sides.items()}
+    gpu = {k: GpuProvider(torch, sd, cks[k]) for k, sd in sides.items()}
+    spans = None
+
+    def call(name, fn):
+        if spans is None:
+            return fn()
+        t = time.perf_counter()
+        v = fn()
+        spans.setdefault(name, []).append(time.perf_counter() - t)
+        return v
+
+    run = lambda: compressed_snark_sequence(gpu["P"], gpu["S"], sides["P"], sides["S"], call)
+    for _ in range(args.warmup):
+        run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    spans = {}
+    passes = 3
+    for _ in range(passes):
+        run()
+    breakdown = {k: round(sum(v) / passes * 1e3, 4) for k, v in sorted(spans.items())}
+    breakdown["_sum"] = round(sum(breakdown.values()), 4)
+    groups = {}
+    for k, v in breakdown.items():
+        if k == "_sum":
+            continue
+        side, nm = k.split(".", 1)
+        g = "fold" if nm.startswith(("rand.", "fold.")) else "ee" if nm.startswith("ee.") else "spartan"
+        groups[f"{side}.{g}"] = round(groups.get(f"{side}.{g}", 0.0) + v, 4)
+    spans = None
+    verifies = {}
+    for tag in ("P", "S"):
+        for k, v in spartan_verify(sides[tag].p, res[f"fold_{tag}"]["u"], res[f"spartan_{tag}"]).items():
+            verifies[f"{tag}.{k}"] = v
+    outj = {
+        "metric": "CompressedSNARK prove provider-call REPLAY ms (one chained sequence)", "value": dt * 1e3, "unit": "ms", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": False, "scaling": "weak",
+        "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+        "config": {"workload": f"CompressedSNARK::prove replay ({nova_amd.CURVE_NAMES[cP]} primary 2^{ellP}, {nova_amd.CURVE_NAMES[cS]} secondary 2^{ellS}): per side "
+                               "random instance (3 SpMV + 2 commitments) + relaxed fold (3 SpMV, five-input cross term, commit T, two folds); Spartan "
+                               "sum-check sequence on both folded instances; HyperKZG EE::prove on the primary's batched witness where it lies in HBM "
+                               "(BASELINE.json configs[4]); stand-in transcripts; no IPA argument on the secondary"},
+        "roofline": None, "breakdown_ms": breakdown, "groups_ms": groups, "proof_verifies": verifies,
+    }
+    if not args.no_cpu_baseline:
+        from oracle import cref
+        threads = effective_cpus()
+        cref.set_threads(threads)
+        keys = {k: cks[k].read(0, sides[k].n) for k in sides}
+        cpu = {k: CpuProvider(sides[k], keys[k], cks[k].h) for k in sides}
+        t1 = time.perf_counter()
+        exp = compressed_snark_sequence(cpu["P"], cpu["S"], sides["P"], sides["S"])
+        t_cpu = time.perf_counter() - t1
+        dg = csnark_digest(res, {k: gpu[k].host for k in gpu})
+        de = csnark_digest(exp, {k: cpu[k].host for k in cpu})
+        checks = {k: dg[k] == de[k] for k in dg}
+        checks.update(verifies)
+        outj["cpu_baseline"] = {"value": t_cpu * 1e3, "unit": "ms", "cores": threads, "kind": "port",
+                                "sample": "the same chained sequence once through oracle/nova_ref.c",
+                                "serial_parts": CPU_SERIAL_PARTS, "gpu_matches_cpu": all(checks.values()), "checks": checks}
+        # the unchanged-caller form: every commitment of the sequence as the trait's slice-form call, host scalars and host bases
+        outj["trait_only"] = trait_only_msms({k: (sides[k].cid, keys[k], cpu[k].msm_log, cpu[k].prep) for k in sides})
+    for k in gpu:
+        gpu[k].close()
+        cks[k].close()
+    return outj
+
+
+CPU_SERIAL_PARTS = []   # the oracle functions of the replays that run on ONE host thread (filled in as the oracle gains OpenMP)
+
+
+def trait_only_msms(logs, reps=5):
+    """The commitments of a replayed sequence as Nova issues them through `DlogGroupExt` ALONE (only the
+    trait override applied, nothing in r1cs/mod.rs / nifs.rs / snark.rs patched): `vartime_multiscalar_mul(&[Scalar], &ck[..n])` =
+    nmx_msm and `batch_vartime_multiscalar_mul` = nmx_msm_batch over pageable HOST scalars and the caller's HOST base array (resident
+    through the slice cache after first sight, window tables from the third use on, content re-verified on every call).  The field
+    work between the commitments stays on the reference's CPU; what is timed is the sum of the provider calls.
+    logs: {side: (curve, host base array, [(kind, [host vectors], expected results or None)] in call order, oracle key)}."""
+    import nova_amd
+    from nova_amd import _lib
+    _lib.lib().nmx_cache_clear()
+    groups = {k: nova_amd.DlogGroup(v[0]) for k, v in logs.items()}
+
+    def one_pass(record, results):
+        t_all = 0.0
+        for k, (cid, bases, log, _prep) in logs.items():
+            for i, (kind, vs, _exp) in enumerate(log):
+                t = time.perf_counter()
+                if kind == "commit":
+                    got = [groups[k].vartime_multiscalar_mul(vs[0], bases[:len(vs[0])])]
+                else:
+                    got = groups[k].batch_vartime_multiscalar_mul(vs, bases[:max(len(v) for v in vs)])
+                d = time.perf_counter() - t
+                t_all += d
+                if record is not None:
+                    lens = ",".join(str(len(v)) for v in vs[:3]) + (",.." if len(vs) > 3 else "")
+                    record.setdefault(f"{k}.{i}.{kind}[{lens}]", []).append(d)
+                    results[(k, i)] = [(g.xy, int(g.is_inf)) for g in got]
+        return t_all
+    for _ in range(4):                                        # first sight, second use, tables at the third, one warm pass
+        one_pass(None, None)
+    rec, results, total = {}, {}, []
+    for _ in range(reps):
+        total.append(one_pass(rec, results))
+    ok = True
+    for k, (cid, bases, log, prep) in logs.items():           # against the oracle (blinded commitments: their unblinded MSM, computed here)
+        for i, (kind, vs, exp) in enumerate(log):
+            exp = exp if exp is not None else [prep.msm(v, len(v)) for v in vs]
+            ok = ok and results[(k, i)] == exp
+    st = _lib.stats()
+    return {"ms": round(float(np.median(total)) * 1e3, 4), "calls": sum(len(v[2]) for v in logs.values()),
+            "gpu_matches_cpu": ok,
+            "per_call_ms": {k: round(float(np.median(v)) * 1e3, 4) for k, v in rec.items()},
+            "cache": {"uploads": st[_lib.STAT_CACHE_UPLOADS], "hits": st[_lib.STAT_CACHE_HITS], "stale": st[_lib.STAT_CACHE_STALE]},
+            "what": "sum of the sequence's MSM provider calls in slice form (nmx_msm / nmx_msm_batch): pageable host scalars, host bases via the "
+                    "slice cache (content verified every call); the field work between them is the reference's own CPU code and is not timed"}
 
 
 def effective_cpus():

@@ -276,3 +276,29 @@ def test_montgomery_layout_key_commit_2p16(nmx):
     got = nmx.DlogGroup(c.cid).vartime_multiscalar_mul(mont(sc, c.r), ck, mont=True)
     assert as_pair(got) == cref.msm(c.cid, sc, bases[:n], n)
     ck.close()
+
+
+@pytest.mark.parametrize("cycle,ell,ell2", [("bn254", 14, 12), ("pasta", 11, 10)])
+def test_compressed_snark_replay_matches_oracle(nmx, cycle, ell, ell2):
+    """BASELINE.json configs[4] as ONE chained sequence (bench.py compressed_snark_replay; CompressedSNARK::prove,
+    src/nova/mod.rs:793-881): random instance + relaxed fold per side, Spartan on both folded instances, HyperKZG's EE::prove on the
+    primary's batched witness where it lies in HBM -- every commitment, round polynomial, evaluation, batched witness and the
+    evaluation argument against the oracle run in the same order; both Spartan proofs pass the reference's verifier equations; and
+    the same commitments once more in the trait-only form (slice-form calls over host scalars and host bases)."""
+    import torch
+    import bench
+    args = argparse.Namespace(log2n=ell, log2n_secondary=ell2, steps=1, warmup=1, no_cpu_baseline=False, cycle=cycle)
+    out = bench.compressed_snark_replay(args, torch)
+    assert out["cpu_baseline"]["gpu_matches_cpu"] is True, out["cpu_baseline"]["checks"]
+    assert all(out["proof_verifies"].values()) and len(out["proof_verifies"]) == 6
+    assert out["trait_only"]["gpu_matches_cpu"] is True and out["trait_only"]["calls"] == 8
+    assert {"P.fold", "P.spartan", "P.ee", "S.fold", "S.spartan"} == set(out["groups_ms"])
+
+
+def test_prove_step_trait_only_form_matches_oracle(nmx):
+    """prove_step with ONLY the DlogGroupExt override applied: the step's four MSMs as slice-form calls over host scalars."""
+    import torch
+    import bench
+    args = argparse.Namespace(iters=1024, steps=1, warmup=0, no_cpu_baseline=False)
+    out = bench.prove_step_replay(args, torch)
+    assert out["trait_only"]["gpu_matches_cpu"] is True and out["trait_only"]["calls"] == 4

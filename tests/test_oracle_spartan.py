@@ -108,3 +108,40 @@ def test_the_replayed_prove_sequence_verifies_on_the_oracle(ell):
     bad[0, 0] ^= 1
     res = bench.spartan_sequence(bench.SpartanCpu(fid, csr, n, hW, bad, hz), ell, p, u)
     assert not bench.spartan_verify(p, u, res)["proof_verifies_outer"]
+
+
+def test_compressed_snark_sequence_through_the_oracle_alone():
+    """bench.py's compressed_snark_sequence (CompressedSNARK::prove, src/nova/mod.rs:793-881, as provider calls) with the oracle on
+    both sides: the relaxed fold of a satisfied running instance with a sampled random instance (src/r1cs/mod.rs:786-830, 629-661,
+    1070-1107) is satisfied again -- both Spartan proofs over the FOLDED instances pass the reference's verifier equations -- and the
+    evaluation argument's openings are consistent: B(u_j) recomputed from the v matrix equals the quotient identity's value."""
+    import bench
+    from oracle import pyref as R
+    sides = {"P": bench.CsnarkSide(0, 6, seed=906), "S": bench.CsnarkSide(1, 5, seed=955)}
+    keys = {k: cref.sequential_bases([R.BN254_G1, R.GRUMPKIN][sd.cid], 7, sd.n + 1) for k, sd in sides.items()}
+    cpu = {k: bench.CpuProvider(sides[k], keys[k][:sides[k].n], keys[k][sides[k].n].tobytes()) for k in sides}
+    res = bench.compressed_snark_sequence(cpu["P"], cpu["S"], sides["P"], sides["S"])
+    for tag in ("P", "S"):
+        assert all(bench.spartan_verify(sides[tag].p, res[f"fold_{tag}"]["u"], res[f"spartan_{tag}"]).values()), tag
+    # every commitment of the sequence was logged for the trait-only form: per side 3 in the fold; the primary adds batch_commit + openings
+    assert [k for k, _v, _e in cpu["S"].msm_log] == ["commit"] * 3
+    assert [k for k, _v, _e in cpu["P"].msm_log] == ["commit"] * 3 + ["batch", "batch"]
+    # HyperKZG's v matrix obeys the verifier's recurrence between consecutive folded polynomials (hyperkzg.rs:1180-1215): with
+    # u = [r, -r, r^2] and x = point[ell - i - 1],  r P_{i+1}(r^2) = r (1 - x) P_even(r^2) + x r P_odd(r^2),  where
+    # P_even(r^2) = (v[i][0] + v[i][1]) / 2 and r P_odd(r^2) = (v[i][0] - v[i][1]) / 2.  r itself is not part of the output; the
+    # last folded polynomial is linear, f(X) = c0 + c1 X, so r = (f(r^2) - c0) / (c1 r).
+    p = sides["P"].p
+    num = lambda b: int.from_bytes(bytes(b), "little")
+    v = [[num(c) for c in row] for row in res["ee_P"]["v"]]
+    x = [num(c) for c in res["spartan_P"]["batch"][1]]
+    ell = sides["P"].ell
+    assert len(v) == ell and len(res["ee_P"]["com"]) == ell - 1 and len(res["ee_P"]["w"]) == 3
+    two_inv = pow(2, -1, p)
+    c0 = (v[ell - 1][0] + v[ell - 1][1]) * two_inv % p
+    c1r = (v[ell - 1][0] - v[ell - 1][1]) * two_inv % p
+    r = (v[ell - 1][2] - c0) * pow(c1r, -1, p) % p
+    for i in range(ell - 1):
+        xi = x[ell - i - 1]
+        even = (v[i][0] + v[i][1]) * two_inv % p
+        odd_r = (v[i][0] - v[i][1]) * two_inv % p
+        assert r * v[i + 1][2] % p == (r * (1 - xi) % p * even + xi * odd_r) % p, i
