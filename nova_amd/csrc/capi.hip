@@ -176,6 +176,7 @@ static void ensure_init() {
   if (const char* t = getenv("NMX_SC_QUAD")) G.sc_quad = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_SC_PRELAUNCH")) G.sc_prelaunch = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_SC_HOST_PARTS")) G.sc_host_parts = (uint32_t)atoi(t);
+  if (const char* t = getenv("NMX_SC_RESIDENT")) G.sc_resident = atoi(t) ? 1u : 0u;
   if (const char* t = getenv("NMX_TUNE_HORNER_TOP")) G.horner_top = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_HORNER_SUB")) G.horner_sub = (uint32_t)atoi(t);
   if (const char* t = getenv("NMX_TUNE_HORNER_ORDER")) G.horner_order = atoi(t) ? 1u : 0u;
@@ -2744,6 +2745,7 @@ int nmx_set_option(const char* name, uint32_t value) {
     else if (n == "sc_quad") G.sc_quad = value ? 1u : 0u;
     else if (n == "sc_prelaunch") G.sc_prelaunch = value ? 1u : 0u;
     else if (n == "sc_host_parts") G.sc_host_parts = value ? 1u : 0u;
+    else if (n == "sc_resident") G.sc_resident = value ? 1u : 0u;
     else if (n == "sc_torn_test") G.sc_torn_test = value > 1000 ? 1000u : (uint32_t)value;
     else if (n == "sc_host_tail") {
       require(value <= 8, NMX_E_ARG, "sc_host_tail: log2 of the table length the host takes over, 0..8");

@@ -335,6 +335,7 @@ struct Global {
   std::atomic<uint32_t> sc_side_streams{1};       // option sc_side_streams: the batch prover runs claim i > 0 on its own stream (0: all on the context's)
   std::atomic<uint32_t> sc_prelaunch{1};          // option sc_prelaunch: the cubic / quad_prod provers enqueue their small passes a round early; the pass takes its challenge from pinned memory (0: launched when the challenge is known)
   std::atomic<uint32_t> sc_host_parts{1};         // option sc_host_parts: passes of <= 64 blocks send per-block partial sums to the host, which adds them (0: last-block ticket)
+  std::atomic<uint32_t> sc_resident{1};           // option sc_resident: from tables of <= 2^14 elements every remaining device round of a sum-check prover runs inside ONE resident kernel (k_sc_resident) that waits for each challenge on the device (0: a pass per round)
   std::atomic<uint32_t> sc_torn_test{0};          // option sc_torn_test (tests): microseconds a deliberately TORN challenge line stays on the device before the whole one follows (0: off)
   std::atomic<uint64_t> sc_torn_injected{0}, sc_torn_rejects{0};  // NMX_STAT_SC_TORN_INJECTED / _REJECTS
   std::atomic<uint32_t> sc_quad{1};               // option sc_quad: passes of <= 2^12 indices of the cubic / quad_prod provers run four lanes per index (0: one)

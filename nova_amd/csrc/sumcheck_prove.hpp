@@ -162,6 +162,7 @@ NMX_HD void chal_sum(const uint32_t* l9, uint32_t flag, uint32_t seq, uint32_t& 
 // host said stop, or nothing came for kChalTimeoutTicks of the 100 MHz wall clock -- the block leaves without touching the tables
 // or the mailbox (the host then fails its own wait).
 static constexpr uint64_t kChalTimeoutTicks = 200000000ull;  // 2 s
+static constexpr uint32_t kChalLineWords = 32;               // a slot's second challenge line (128 bytes on; each line: 16 words + its reject counter)
 template <int FID> __device__ __forceinline__ bool sc_challenge(const ScSmallArgs<FID>& a, Fp<FID>& r, uint32_t* s_r /* LDS, 10 words */) {
   r = a.r;
   if (!a.chal) return true;
@@ -453,6 +454,143 @@ template <int FID, int MODE, bool QUAD = false> __global__ __launch_bounds__(256
   }
 }
 
+// ---- SEVERAL rounds inside one resident kernel (round 6; option sc_resident) ---------------------------------------------------
+// From tables of kResidentMaxLen elements down, a round's pass is a few dozen blocks for a few microseconds; what a round COSTS is
+// everything around the pass -- kernel start and end, the queue's dispatch, a fresh poll set-up -- ~25-30 us per round against ~10 us
+// of dependent work (profiles/r05_spartan/timeline_2p20.txt: run 15-17 us, gap 9-13 us).  This kernel is launched ONCE (a round
+// ahead, like a pre-launched pass) and stays for every remaining device round of the prover:
+//     wait for the round's challenge (the checksummed BAR line of sc_challenge)  ->  bind the tables in place  ->  next round's sums
+//     ->  per-block partial sums + sequence word into pinned host memory (the host adds them: ScPassArgs::host_part)  ->  wait again
+// and ends with the hand-over: the last bind lands the tables in the host's tail area (k_sc_bind_to_host's work).  A block stays as
+// long as a pass still needs it (pass i has hq0 >> i indices: 64 per block in the four-lane form, 256 in the one-lane form) and leaves
+// after its last one.  The HOST is the grid barrier between two rounds: it sends challenge i + 1 only when every block of pass i has
+// published -- each block publishes behind an agent-scope release of ALL its lanes' table stores and a system-scope fence, and
+// invalidates its L1 (agent-scope acquire) after every challenge, so the tables another block bound in the round before are read
+// from L2.  Cancelling (abort word on the line), the 2 s time-out and the device-wide budget of waiting blocks are sc_challenge's /
+// ScDev's; a round that needs the tau = 0 fall-back cancels the kernel first and continues on launched passes.
+template <int FID> struct ScResArgs {
+  uint32_t *A, *B, *C;
+  const uint32_t *heapL, *heapR;                    // eq heaps (ScEqDev layout); MODE 4: unused
+  uint32_t first_half, second_half, l, round0;      // pass i is the bind of round round0 + i (its sums are round round0 + i + 1's)
+  Fp<FID> nk;
+  uint32_t len0, passes, tail;  // tables hold len0 elements at entry; `passes` bind + sums passes; tail: one more bind lands the tables on the host
+  uint32_t seq0, cs0;           // pass i publishes with sequence seq0 + i and takes its challenge with sequence cs0 + i
+  // TWO challenge lines (kChalLineWords apart), pass i polls line i & 1: the host names the line of pass i + 1 as the one to cancel the
+  // moment it has sent challenge i (ScPass::res_send), and a cancellation written there must not overwrite a challenge that some
+  // block has not read yet -- with one line, a fall-back in ANOTHER claim of a batch cancelled this claim's kernel by overwriting
+  // the challenge it was about to read: the pass never ran and the host's wait for its sums failed
+  const uint32_t* chal;
+  uint32_t* host_part;          // kHostPartWords per block
+  uint32_t* slot;               // mailbox slot of the hand-over
+  uint32_t* host_tab[3];        // tail areas (pinned)
+  uint32_t ntab;
+};
+template <int FID> __device__ __forceinline__ void sc_res_tables(const ScResArgs<FID>& a, uint32_t rnd, ScSmallArgs<FID>& x) {
+  if (rnd < a.first_half) {  // ScEqDev::tables
+    x.eqL = a.heapL + 8 * ((size_t)1 << (a.first_half - rnd));
+    x.eqR = a.heapR + 8 * ((size_t)1 << a.second_half);
+    x.shift = a.second_half;
+    x.mask = a.second_half >= 32 ? 0xffffffffu : ((1u << a.second_half) - 1u);
+  } else {
+    x.eqL = nullptr;
+    x.eqR = a.heapR + 8 * ((size_t)1 << (a.l - rnd));
+    x.shift = 0, x.mask = 0xffffffffu;
+  }
+}
+// the one-lane index loop of a bind + sums pass (k_sc_pass's body)
+template <int FID, int MODE>
+__device__ __forceinline__ void sc_lane_loop(const ScSmallArgs<FID>& a, uint32_t first, uint32_t stride, Fp<FID>& s0, Fp<FID>& s1) {
+  using F = Fp<FID>;
+  uint32_t pending = 0;
+  for (uint32_t id = first; id < a.hq; id += stride) {
+    F a0, a1, b0 = F::zero(), b1 = F::zero(), c0 = F::zero(), c1;
+    sc_bind2<FID>(a.A, a.oA, a.r, id, a.hq, a0, a1);
+    if (MODE >= 3) sc_bind2<FID>(a.B, a.oB, a.r, id, a.hq, b0, b1);
+    if (MODE == 3) sc_bind2<FID>(a.C, a.oC, a.r, id, a.hq, c0, c1);
+    if (MODE == 4) {
+      s0 = s0 + a0 * b0;
+      s1 = s1 + F::sub2(a1, a0).norm() * F::sub2(b1, b0).norm();
+    } else {
+      F fac = ldw<FID>(a.eqR, a.eqL ? (id & a.mask) : id);
+      if (a.eqL) fac = ldw<FID>(a.eqL, id >> a.shift) * fac;
+      if (MODE == 1) {
+        s0 = s0 + a0 * fac;
+      } else {
+        const F e0 = F::mul_add(a0, b0, c0, a.nk);
+        const F q = F::sub2(a1, a0).norm() * F::sub2(b1, b0).norm();
+        s0 = s0 + e0 * fac;
+        s1 = s1 + q * fac;
+      }
+    }
+    if (++pending == 6) {
+      s0 = s0.norm().canon();
+      s1 = s1.norm().canon();
+      pending = 0;
+    }
+  }
+  s0 = s0.norm().canon();
+  s1 = s1.norm().canon();
+}
+static constexpr uint32_t kResidentMaxLen = 1u << 14;  // tables of at most this many elements at entry (first pass: 2^12 indices)
+template <int FID, int MODE, bool QUAD> __host__ __device__ inline uint32_t sc_res_blocks(uint32_t hq) {
+  const uint32_t per = QUAD ? 64u : 256u;
+  return hq <= per ? 1u : (hq + per - 1) / per;
+}
+template <int FID, int MODE, bool QUAD> __global__ __launch_bounds__(256) void k_sc_resident(ScResArgs<FID> p) {
+  using F = Fp<FID>;
+  __shared__ uint32_t lds[72];
+  __shared__ uint32_t s_r[10];
+  constexpr uint32_t per = QUAD ? 64u : 256u;
+  ScSmallArgs<FID> a;
+  a.A = p.A, a.B = p.B, a.C = p.C, a.oA = p.A, a.oB = p.B, a.oC = p.C;
+  a.eqL = a.eqR = nullptr, a.shift = 0, a.mask = 0xffffffffu;
+  a.r = F::zero(), a.nk = p.nk, a.bind = 1u, a.seq = 0, a.slot = nullptr;
+  a.chal = p.chal;
+  uint32_t len = p.len0;
+  for (uint32_t i = 0; i < p.passes; i++, len >>= 1) {
+    a.hq = len >> 2;
+    const uint32_t nb = sc_res_blocks<FID, MODE, QUAD>(a.hq);
+    if (blockIdx.x >= nb) return;  // (block-uniform; nb only shrinks: this block is not needed again)
+    a.chal_seq = p.cs0 + i;
+    a.chal = p.chal + ((i & 1u) ? kChalLineWords : 0u);  // two lines, used in turn (see ScResArgs::chal)
+    if (MODE != 4) sc_res_tables<FID>(p, p.round0 + i + 1, a);  // the sums of this pass are the NEXT round's: its eq tables
+    F r;
+    if (!sc_challenge<FID>(a, r, s_r)) return;
+    a.r = r;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the tables other blocks bound in the round before: not from this CU's L1
+    F s0 = F::zero(), s1 = F::zero();
+    if constexpr (QUAD) sc_quad_loop<FID, MODE>(a, blockIdx.x * per + (threadIdx.x >> 2), nb * per, s0, s1);
+    else sc_lane_loop<FID, MODE>(a, blockIdx.x * per + threadIdx.x, nb * per, s0, s1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // every lane's table stores, before the block says "done"
+    block_sum_pair<FID, true>(s0, s1, lds);
+    if (threadIdx.x == 0) {
+      uint32_t* mine = p.host_part + kHostPartWords * (size_t)blockIdx.x;
+      s0.to_words(mine), s1.to_words(mine + 8);
+      mail_publish(mine + 16, p.seq0 + i);
+    }
+  }
+  if (!p.tail || blockIdx.x != 0) return;
+  // the hand-over (k_sc_bind_to_host): tables of `len` elements bound to len / 2, landed in the tail areas
+  a.chal_seq = p.cs0 + p.passes;
+  a.chal = p.chal + ((p.passes & 1u) ? kChalLineWords : 0u);
+  F r;
+  if (!sc_challenge<FID>(a, r, s_r)) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  const uint32_t half = len >> 1;
+  uint32_t* X[3] = {p.A, p.B, p.C};
+  for (uint32_t id = threadIdx.x; id < half; id += 256u) {
+    for (uint32_t t = 0; t < p.ntab; t++) {
+      const F x0 = ldw<FID>(X[t], id), x1 = ldw<FID>(X[t], (size_t)id + half);
+      const F y = (x0 + r * F::sub2(x1, x0).norm()).norm().canon();
+      y.to_words(X[t] + 8 * (size_t)id);
+      y.to_words(p.host_tab[t] + 8 * (size_t)id);
+    }
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) mail_publish(p.slot, p.seq0 + p.passes);
+}
+
 // ---- the bind that hands the tables to the host: bound values (or, bind = 0, the tables as they are) into pinned memory ------
 // The tail rounds run on the host (sc_host.hpp); with half == 1 this is the LAST bind and the values are the final claims
 // (poly_A[0], ..., sumcheck.rs:241-248, 499-506).
@@ -634,20 +772,22 @@ template <int FID> struct ScDev {
   // so only when the torn-line test is on
   void collect_torn_rejects() {
     if (!c.chal || !G.sc_torn_test.load(std::memory_order_relaxed)) return;
-    for (uint32_t s_ = 0; s_ < kMailSlots; s_++) {
-      volatile uint32_t* w = c.chal + (size_t)s_ * (kChalSlotBytes / 4) + 16;
-      const uint32_t v = *w;
-      if (v) {
-        *w = 0;
-        _mm_sfence();
-        G.sc_torn_rejects.fetch_add(v, std::memory_order_relaxed);
+    for (uint32_t s_ = 0; s_ < kMailSlots; s_++)
+      for (uint32_t line = 0; line < 2; line++) {
+        volatile uint32_t* w = c.chal + (size_t)s_ * (kChalSlotBytes / 4) + line * kChalLineWords + 16;
+        const uint32_t v = *w;
+        if (v) {
+          *w = 0;
+          _mm_sfence();
+          G.sc_torn_rejects.fetch_add(v, std::memory_order_relaxed);
+        }
       }
-    }
   }
   // Pre-launched passes waiting for a challenge (chal_seq per slot, 0: none).  While one waits, no stream of this call may be
   // synchronised -- the wait would sit behind a kernel that waits for THIS thread -- so the mailbox polls keep polling (up to
   // kArmedPollSeconds, yielding) instead of giving up after sc_poll_us, and anything that must synchronise cancels them first.
   uint32_t armed_seq[kMailSlots] = {};
+  uint32_t armed_line[kMailSlots] = {};  // word offset of the line the waiting pass polls (0, or kChalLineWords: the resident kernel's odd passes)
   // Blocks of pre-launched passes sit on CUs doing nothing but polling; forward progress of everything else -- the pass whose
   // sums the host needs before it can send the challenge, other callers' kernels -- needs free slots.  A device-wide budget
   // (kArmedBlocksCap, a quarter of the 1024 blocks of 256 lanes the chip holds at this register count) bounds them: a pass that
@@ -679,8 +819,9 @@ template <int FID> struct ScDev {
   void cancel_armed() noexcept {
     for (uint32_t s = 0; s < kMailSlots; s++)
       if (armed_seq[s]) {
-        chal_write(chal_line(s), nullptr, 1u, armed_seq[s]);
+        chal_write(chal_line(s) + armed_line[s], nullptr, 1u, armed_seq[s]);
         armed_seq[s] = 0;
+        armed_line[s] = 0;
         arm_release(s);
       }
   }
@@ -702,6 +843,13 @@ template <int FID> struct ScDev {
     return (const uint32_t*)(c.mail + kMailBytes + kMailSlots * kTailSlotBytes + (size_t)s * kPartSlotBytes);
   }
   uint32_t next_seq() { return ++c.mail_seq ? c.mail_seq : ++c.mail_seq; }  // never 0 (a fresh mailbox reads 0)
+  // k consecutive sequence numbers, none of them 0 (the resident kernel counts its passes up from a base)
+  uint32_t reserve_seq(uint32_t k) {
+    if (c.mail_seq > 0xffffffffu - k - 1u) c.mail_seq = 0;
+    const uint32_t base = c.mail_seq + 1u;
+    c.mail_seq += k;
+    return base;
+  }
   // waits until slot s carries `seq`; returns its result words.  The sequence word is polled in host memory; the stream is only
   // synchronised when the poll gives up (option sc_poll_us) or polling is off.
   // passes whose per-block partial sums come to the host un-added (ScPassArgs::host_part): blocks expected per slot, and the sums
@@ -731,7 +879,12 @@ template <int FID> struct ScDev {
           synced = true;
         }
       }
-      require(arrived(b), NMX_E_HIP, "sum-check: a block's partial sums never reached the host");
+      if (!arrived(b)) {
+        char msg[200];
+        snprintf(msg, sizeof msg, "sum-check: a block's partial sums never reached the host (slot %u, block %u of %u, sequence %u, found %u)", s, b, nb, seq,
+                 __atomic_load_n(area + kHostPartWords * (size_t)b + 16, __ATOMIC_ACQUIRE));
+        throw Fail{NMX_E_HIP, msg};
+      }
       a0 = a0 + H::from_mont256(area + kHostPartWords * (size_t)b);  // canonical words: addition does not care about the form
       a1 = a1 + H::from_mont256(area + kHostPartWords * (size_t)b + 8);
     }
@@ -1024,6 +1177,7 @@ template <int FID, int MODE> struct ScPass {
     pre_parts = launch_bind(x, hq);
     pre_seq = seq;
     h.armed_seq[slot] = cs;
+    h.armed_line[slot] = 0;
     return true;
   }
   // the challenge for the pass in flight; returns the mailbox sequence its sums will carry
@@ -1034,6 +1188,76 @@ template <int FID, int MODE> struct ScPass {
     h.arm_release(slot);  // (the pass is running now; its blocks leave within microseconds)
     h.parts[slot] = pre_parts;  // (only now: until here the slot's pending result was the pass before)
     return pre_seq;
+  }
+  // ---- every remaining device round in ONE resident kernel (k_sc_resident; option sc_resident) -----------------------------------
+  // Launched a round ahead like a pre-launched pass, from tables of <= kResidentMaxLen elements; the host's part of a round shrinks
+  // to: add the blocks' partial sums, algebra, transcript, one 64-byte write.  res_next = the pass whose challenge goes out next
+  // (== res_passes: the hand-over's).  h.armed_seq[slot] always holds the challenge sequence the kernel is waiting for, so
+  // ScDev::cancel_armed (any failure, any fall-back) ends it.
+  static constexpr bool kResQuad = kQuadForm;
+  bool res_on = false;
+  bool res_allowed = true;  // false: this pass shares its stream with other claims' passes (a resident kernel would hold them up for good)
+  uint32_t res_seq0 = 0, res_cs0 = 0, res_next = 0, res_passes = 0;
+  size_t res_len0 = 0;
+  bool res_active() const { return res_on && h.armed_seq[slot] != 0; }
+  bool can_resident(size_t len) {
+    if (!res_allowed || !G.sc_resident.load(std::memory_order_relaxed) || len > kResidentMaxLen || len / 2 <= h.tail_len || len < 4) return false;
+    if (kResQuad && !quad_on()) return false;  // (the four-lane form is the cubic / quad_prod provers' small-pass form; off: launched passes)
+    return G.sc_fused_sum.load(std::memory_order_relaxed) != 0 && G.sc_poll_us.load(std::memory_order_relaxed) != 0 &&
+           host_parts_on() && slot + NT <= kMailSlots && h.chal_line(slot) != nullptr;
+  }
+  // round0: the round whose challenge the first pass binds with.  eqd: the instance's eq heaps (MODE 4: nullptr)
+  bool start_resident(size_t len, uint32_t round0, const ScEqDev<FID>* eqd) {
+    uint32_t passes = 0;
+    for (size_t l_ = len; l_ / 2 > h.tail_len; l_ /= 2) passes++;
+    const uint32_t blocks = sc_res_blocks<FID, MODE, kResQuad>((uint32_t)(len / 4));
+    if (passes == 0 || blocks > kHostPartBlocks || !h.arm_reserve(slot, blocks)) return false;
+    ScResArgs<FID> a;
+    a.A = A, a.B = B, a.C = C;
+    a.heapL = eqd ? eqd->heapL : nullptr, a.heapR = eqd ? eqd->heapR : nullptr;
+    a.first_half = eqd ? eqd->first_half : 0, a.second_half = eqd ? eqd->second_half : 0, a.l = eqd ? eqd->l : 0, a.round0 = round0;
+    a.nk = nk;
+    a.len0 = (uint32_t)len, a.passes = passes, a.tail = 1u;
+    a.seq0 = res_seq0 = h.reserve_seq(passes + 1), a.cs0 = res_cs0 = h.reserve_seq(passes + 1);
+    a.chal = h.chal_line(slot);
+    a.host_part = h.part_dev(slot);
+    a.slot = h.slot_dev(slot);
+    for (uint32_t t = 0; t < 3; t++) a.host_tab[t] = t < NT ? h.tail_dev(slot + t) : nullptr;
+    a.ntab = NT;
+    hipLaunchKernelGGL((k_sc_resident<FID, MODE, kResQuad>), dim3(blocks), dim3(256), 0, stream, a);
+    HIPCHK(hipGetLastError());
+    h.launched();
+    res_on = true, res_next = 0, res_passes = passes, res_len0 = len;
+    h.armed_seq[slot] = res_cs0;
+    h.armed_line[slot] = 0;
+    return true;
+  }
+  // the challenge of the next bind + sums pass; returns the mailbox sequence its partial sums carry
+  uint32_t res_send(const H& rh) {
+    const F r = rh.to_device();
+    const uint32_t i = res_next++;
+    h.armed_seq[slot] = res_cs0 + i + 1;  // what the kernel waits for once this pass is through, and where: a cancel names that line
+    h.armed_line[slot] = ((i + 1) & 1u) ? kChalLineWords : 0u;
+    ScDev<FID>::chal_write(h.chal_line(slot) + ((i & 1u) ? kChalLineWords : 0u), r.l, 0u, res_cs0 + i);
+    h.parts[slot] = sc_res_blocks<FID, MODE, kResQuad>((uint32_t)((res_len0 >> i) / 4));
+    return res_seq0 + i;
+  }
+  // the last challenge: the kernel binds once more and lands the tables of `half` elements in the tail areas
+  void res_to_host(size_t half, const H& rh, std::vector<H>* out[3]) {
+    require(res_next == res_passes && half == (res_len0 >> res_passes) / 2, NMX_E_HIP, "sum-check: resident kernel out of step");
+    const F r = rh.to_device();
+    h.armed_seq[slot] = 0;
+    h.armed_line[slot] = 0;
+    h.arm_release(slot);
+    res_on = false;
+    ScDev<FID>::chal_write(h.chal_line(slot) + ((res_passes & 1u) ? kChalLineWords : 0u), r.l, 0u, res_cs0 + res_passes);
+    h.parts[slot] = 0;
+    (void)h.wait(slot, res_seq0 + res_passes);
+    for (uint32_t t = 0; t < NT; t++) {
+      const uint32_t* src = h.tail_host(slot + t);
+      out[t]->resize(half);
+      for (size_t i = 0; i < half; i++) (*out[t])[i] = h.stored(src + 8 * i);
+    }
   }
   ~ScPass() {
     if (armed()) h.cancel_armed();
@@ -1121,8 +1345,10 @@ static void sc_prove_t(Ctx& c, const void* claim, const void* taus, size_t num_r
       if (MODE == 3) eq.prepare();  // the round's inversion runs under the pass (sc_host.hpp Eq::prepare)
       // the pass of round `next_round` (it binds tables of cur_len elements) goes out a round early when it can (ScPass::prelaunch)
       auto maybe_prelaunch = [&](size_t cur_len, uint32_t next_round) {
-        if (cur_len / 2 <= h.tail_len || !pass.can_prelaunch(cur_len)) return;  // (the hand-over is never pre-launched)
+        if (pass.res_active()) return;  // the resident kernel has this pass (and all after it)
         if (MODE == 3 && eq.l1p_zero) return;  // the round in between takes the fallback: its extra pass needs this stream free
+        if (pass.can_resident(cur_len) && pass.start_resident(cur_len, next_round - 1, MODE == 3 ? &eqd : nullptr)) return;
+        if (cur_len / 2 <= h.tail_len || !pass.can_prelaunch(cur_len)) return;  // (the hand-over is never pre-launched)
         (void)pass.prelaunch(cur_len, MODE == 3 ? eqd.tables(next_round) : typename ScEqDev<FID>::Tables{nullptr, nullptr, 0, 0});
       };
       maybe_prelaunch(len, 2);
@@ -1132,7 +1358,10 @@ static void sc_prove_t(Ctx& c, const void* claim, const void* taus, size_t num_r
         H co[4];
         if (MODE == 3) {
           H s0, lead, sm1;
-          eq.derive(t0, t1, cl, false, s0, lead, sm1, [&] { return t0.dbl() + t1.dbl() - pass.high_half_sum(len, tb); });
+          eq.derive(t0, t1, cl, false, s0, lead, sm1, [&] {
+            h.cancel_armed();  // (a resident kernel waiting for the next challenge leaves: the fall-back's extra pass synchronises)
+            return t0.dbl() + t1.dbl() - pass.high_half_sum(len, tb);
+          });
           ScAlg<FID>::from_evals_deg3(s0, cl, lead, sm1, co);
         } else {
           ScAlg<FID>::from_evals_deg2(t0, cl, t1, co);
@@ -1142,13 +1371,14 @@ static void sc_prove_t(Ctx& c, const void* claim, const void* taus, size_t num_r
         if (MODE == 3) eq.bound(r);
         h.prof.rounds++;
         if (len / 2 <= h.tail_len) {  // the bound tables go to the host: the remaining rounds (none if they are the final values) run there
-          pass.to_host(len / 2, &r, tabs);
+          if (pass.res_active()) pass.res_to_host(len / 2, r, tabs);
+          else pass.to_host(len / 2, &r, tabs);
           len /= 2;
           j++;
           break;
         }
         if (MODE == 3) tb = eqd.tables(j + 1);
-        seq = pass.armed() ? pass.send(r) : pass.bind_sums(len, r, tb);
+        seq = pass.res_active() ? pass.res_send(r) : pass.armed() ? pass.send(r) : pass.bind_sums(len, r, tb);
         if (MODE == 3) eq.prepare();
         len /= 2;
         maybe_prelaunch(len, j + 2);
@@ -1193,11 +1423,18 @@ template <int FID> struct ScBatchDev {
     seq[i] = pass[i].sums(pass[i].A, nullptr, nullptr, len[i], tb[i]);
   }
   H t0(size_t i) { return last_t0[i] = h.raw(h.wait((uint32_t)i, seq[i]), pass[i].factors(tb[i])); }
-  H t_m1(size_t i) { return last_t0[i].dbl() - pass[i].high_half_sum(len[i], tb[i]); }  // t(-1) = 2 t(0) - t(1)
+  H t_m1(size_t i) {  // t(-1) = 2 t(0) - t(1)
+    h.cancel_armed();  // every claim's waiting pass / resident kernel leaves: the fall-back's extra pass waits for the whole device
+    return last_t0[i].dbl() - pass[i].high_half_sum(len[i], tb[i]);
+  }
   void bind(size_t i, const H& r) {
     if (len[i] / 2 <= h.tail_len) {
       std::vector<H>* out[3] = {&claims[i].host, nullptr, nullptr};
-      pass[i].to_host(len[i] / 2, &r, out);
+      if (pass[i].res_active()) pass[i].res_to_host(len[i] / 2, r, out);
+      else pass[i].to_host(len[i] / 2, &r, out);
+    } else if (pass[i].res_active()) {  // the claim's resident kernel: the challenge is all a round needs
+      seq[i] = pass[i].res_send(r);
+      tb[i] = eqd[i].tables(claims[i].eq.round + 1);
     } else if (pass[i].armed()) {  // enqueued a round ago (ahead): all it lacks is r
       seq[i] = pass[i].send(r);
       tb[i] = tb_next[i];
@@ -1211,7 +1448,9 @@ template <int FID> struct ScBatchDev {
   // the hand-over or the coming round takes the fallback (whose extra pass needs the claim's stream)
   std::vector<typename ScEqDev<FID>::Tables> tb_next;
   void ahead(size_t i) {
-    if (len[i] / 2 <= h.tail_len || claims[i].eq.l1p_zero || !pass[i].can_prelaunch(len[i])) return;
+    if (pass[i].res_active() || claims[i].eq.l1p_zero) return;
+    if (pass[i].can_resident(len[i]) && pass[i].start_resident(len[i], claims[i].eq.round, &eqd[i])) return;
+    if (len[i] / 2 <= h.tail_len || !pass[i].can_prelaunch(len[i])) return;
     if (tb_next.size() < pass.size()) tb_next.resize(pass.size());
     tb_next[i] = eqd[i].tables(claims[i].eq.round + 1);
     (void)pass[i].prelaunch(len[i], tb_next[i]);  // (false: the budget of waiting blocks is spent; bind() launches it late)
@@ -1259,6 +1498,14 @@ static void sc_prove_batch_t(Ctx& c, const uint8_t* claims_b, const size_t* num_
     // the set-up above), so a round costs one pass's latency, not k of them
     if (G.sc_side_streams.load(std::memory_order_relaxed))
       for (size_t i = 1; i < k; i++) dev.pass[i].stream = h.side_stream((uint32_t)(i - 1));
+    // A kernel that stays for several rounds must never sit in front of a pass the round's challenge depends on.  With one claim that
+    // cannot happen (the kernel's only counterpart is this thread).  With several it can even on separate HIP streams: the runtime
+    // maps streams onto a handful of hardware queues, two "independent" streams may share one, and claim A's resident kernel then holds
+    // up claim B's pass, whose sums the host needs before it can send A's challenge -- measured: every batch of four claims stalled
+    // until the 4 s poll limit (gpurun_out/r6d).  Batches of several claims therefore keep one pass per round (pre-launched a round
+    // ahead: passes are enqueued in dependency order, which is safe on a shared queue).
+    if (k > 1)
+      for (size_t i = 0; i < k; i++) dev.pass[i].res_allowed = false;
     sc_batch_rounds<FID>(h.alg, cs, dev, cb, cb_ctx, out_polys, out_r, out_finals, &h.prof.rounds);
     h.sync_all();
     h.collect_torn_rejects();

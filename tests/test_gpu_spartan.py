@@ -252,6 +252,71 @@ def test_prelaunched_passes_and_launched_passes_agree(nmx):
         assert L.nmx_set_option(b"sc_side_streams", 1) == 0
 
 
+def test_resident_rounds_and_a_pass_per_round_agree(nmx):
+    """option sc_resident: from tables of <= 2^14 elements every remaining device round of a prover runs inside ONE resident kernel
+    (k_sc_resident: wait for the challenge on the device, bind, next sums, partials to the host, wait again; the hand-over at the end)
+    instead of one pass per round.  Sizes on both sides of the entry (2^14 elements), instances that are resident from their first
+    bind, every host-tail threshold (the kernel ends with the hand-over: 1 .. 256 elements), all four fields, batch claims of mixed
+    sizes (each its own resident kernel; more claims than the budget of waiting blocks allows), forced challenges that send a round
+    into the tau = 0 fall-back while a resident kernel is waiting (it is cancelled, the proof goes on on launched passes), a
+    transcript that fails mid-way, the torn-line injection -- every proof equal to the oracle's, with the option on and off."""
+    import nova_amd
+    from nova_amd import _lib, fieldvec as fv
+    L = _lib.lib()
+    p = fc.FIELDS[1]
+    try:
+        for res in (1, 0, 1):
+            assert L.nmx_set_option(b"sc_resident", res) == 0
+            for l in (9, 10, 13, 14, 15, 17):
+                both(sp.check_cubic3, g_cubic3(), o_cubic3, 1, l, seed=240 + l, brute=False)
+                both(sp.check_quad_prod, g_quad, o_quad, 1, l + 1, seed=250 + l)
+            for fid in (0, 2, 3):
+                both(sp.check_cubic3, g_cubic3(), o_cubic3, fid, 12, seed=260 + fid, brute=False)
+                both(sp.check_quad_prod, g_quad, o_quad, fid, 13, seed=265 + fid)
+            both(sp.check_batch_eval, g_batch, o_batch, 1, [14, 11, 16, 9], seed=270)
+            both(sp.check_batch_eval, g_batch, o_batch, 3, [13, 13], seed=271)
+            both(sp.check_batch_eval, g_batch, o_batch, 1, [12, 9, 14, 10, 13, 11, 12, 10, 9, 14, 13, 12], seed=272)   # 12 claims: the budget runs out
+            # fall-back rounds while resident kernels wait: forced challenges (cubic), zero coordinates (one claim of a batch)
+            both(sp.check_cubic3, g_cubic3(), o_cubic3, 1, 13, seed=273, force={0: 0, 3: 1, 7: p - 1, 9: 0}, brute=False)
+            both(sp.check_cubic3, g_cubic3(), o_cubic3, 1, 12, seed=274, taus=[0] * 12, brute=False)
+            base = fc.ints(fc.rand_vec(1, 14, 56))
+            base[9] = 0
+            both(sp.check_cubic3, g_cubic3(), o_cubic3, 1, 14, seed=275, taus=base, brute=False)
+            both(sp.check_batch_eval, g_batch, o_batch, 1, [14, 12, 13], seed=276, zero_coords={1: [6], 2: [10]})
+            both(sp.check_batch_eval, g_batch, o_batch, 1, [10, 12, 8], seed=277, force={0: 0, 3: 1, 7: p - 1, 11: 0})
+            for tail in (0, 1, 4, 8):
+                assert L.nmx_set_option(b"sc_host_tail", tail) == 0
+                both(sp.check_cubic3, g_cubic3(), o_cubic3, 1, 11, seed=280 + tail, brute=False)
+                both(sp.check_quad_prod, g_quad, o_quad, 1, 10, seed=285 + tail)
+                both(sp.check_batch_eval, g_batch, o_batch, 1, [11, 6, 9], seed=290 + tail)
+            assert L.nmx_set_option(b"sc_host_tail", 7) == 0
+            assert L.nmx_set_option(b"sc_torn_test", 25) == 0
+            both(sp.check_cubic3, g_cubic3(), o_cubic3, 1, 14, seed=295, brute=False)
+            both(sp.check_batch_eval, g_batch, o_batch, 1, [13, 12], seed=296)
+            assert L.nmx_set_option(b"sc_torn_test", 0) == 0
+            assert L.nmx_set_option(b"sc_side_streams", 0) == 0
+            both(sp.check_batch_eval, g_batch, o_batch, 1, [13, 14], seed=297)
+            assert L.nmx_set_option(b"sc_side_streams", 1) == 0
+        # a transcript that gives up while the resident kernel waits for its next challenge
+        A, B = fc.rand_vec(1, 1 << 13, 1), fc.rand_vec(1, 1 << 13, 2)
+        calls = []
+
+        def gives_up(_coeffs):
+            calls.append(1)
+            if len(calls) == 4:
+                raise RuntimeError("transcript refused")
+            return sp.le(7 + len(calls))
+        with pytest.raises(nova_amd.NmxError):
+            fv.sumcheck_prove_quad_prod(1, sp.le(5), 13, dev(A), dev(B), gives_up)
+        assert len(calls) == 4
+        both(sp.check_quad_prod, g_quad, o_quad, 1, 13, seed=298)
+    finally:
+        assert L.nmx_set_option(b"sc_resident", 1) == 0
+        assert L.nmx_set_option(b"sc_host_tail", 7) == 0
+        assert L.nmx_set_option(b"sc_torn_test", 0) == 0
+        assert L.nmx_set_option(b"sc_side_streams", 1) == 0
+
+
 def test_a_torn_challenge_line_is_polled_past(nmx):
     """The challenge of a pre-launched pass reaches the device as four write-combined 16-byte stores; nothing guarantees that such a
     store arrives whole.  Option sc_torn_test makes the host write, ahead of every challenge, what a buffer evicted in 8-byte chunks
