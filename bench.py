@@ -65,20 +65,37 @@ def madds_per_launch(n, args):
     return n * (-(-(bits + 1) // table_window_bits(n, args)))
 
 
+PMC_R6 = os.path.join("profiles", "r06_msm", "pmc.json")   # scripts/gpu_r6_pmc.sh on the round-6 build
+PMC_R6_KERNEL = "k_launch<AccumSegFn<0, 1> >"
+
+
+def _pmc_accum():
+    """(entry, source) of the accumulate kernel in the newest committed PMC summary."""
+    try:
+        return json.load(open(os.path.join(ROOT, PMC_R6)))[PMC_R6_KERNEL], PMC_R6
+    except (OSError, KeyError, ValueError):
+        pass
+    for rnd in ("r04_msm_2p20", "r03_msm_2p20", "r02_msm_2p20", "r01_msm_2p20"):
+        try:
+            path = os.path.join("profiles", rnd, "pmc_traffic.json")
+            return json.load(open(os.path.join(ROOT, path)))["accum"], path
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
 def pmc_valu(args, world):
     """VALU wave-instructions per accumulate launch from the committed PMC summary (same configuration rule as
-    pmc_traffic): the basis of roofline.valu_issue."""
+    pmc_traffic): the basis of roofline.valu_issue.  Returns (instructions, effective clock GHz of the profiled pass, source)."""
     if not (world == 1 and args.curve == 0 and args.log2n == 20 and args.dist == "random" and not args.window_bits):
         return None
-    try:
-        for rnd in ("r04_msm_2p20", "r03_msm_2p20"):
-            path = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
-            if os.path.exists(path):
-                d = json.load(open(path))["accum"]
-                return d["SQ_INSTS_VALU"], d.get("effective_clock_GHz")
+    d, src = _pmc_accum()
+    if not d or "SQ_INSTS_VALU" not in d:
         return None
-    except (OSError, KeyError, ValueError):
-        return None
+    clock = d.get("effective_clock_GHz")
+    if clock is None and d.get("GRBM_GUI_ACTIVE") and d.get("us"):
+        clock = d["GRBM_GUI_ACTIVE"] / 8 / (d["us"] * 1e3)      # cycles per XCD / ns
+    return d["SQ_INSTS_VALU"], clock, src
 
 
 def pmc_traffic(args, world):
@@ -86,13 +103,11 @@ def pmc_traffic(args, world):
     collected on (BN254, 2^20, random scalars, one GPU); everything else reports null."""
     if not (world == 1 and args.curve == 0 and args.log2n == 20 and args.dist == "random" and not args.window_bits):
         return None
-    for rnd in ("r04_msm_2p20", "r03_msm_2p20", "r02_msm_2p20", "r01_msm_2p20"):
-        try:
-            d = json.load(open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")))["accum"]
-            return d["hbm_read_bytes_corrected"] + d["hbm_write_bytes"]
-        except (OSError, KeyError, ValueError):
-            continue
-    return None
+    d, _src = _pmc_accum()
+    try:
+        return d["hbm_read_bytes_corrected"] + d["hbm_write_bytes"]
+    except (KeyError, TypeError):
+        return None
 
 
 def main():
@@ -311,7 +326,7 @@ def main():
             # (every VOP3 instruction at full rate, 2.4 GHz): no instruction mix can exceed it, so frac <= 1 by construction.
             # Under this kernel the chip clocks to its power budget (effective clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel time of
             # the profiled pass, ~2.06 GHz): at THAT clock the issue ports are ~99 % busy.
-            insts, gui = pv
+            insts, gui, pmc_src = pv
             lane_ops = insts * 64
             ach = lane_ops / (accum_ms * 1e-3) / 1e12
             out["roofline"]["valu_issue"] = {
@@ -319,7 +334,7 @@ def main():
                 "achieved_T_lane_ops_per_s": ach,
                 "peak_T_lane_ops_per_s": VALU_PEAK_T,
                 "frac": ach / VALU_PEAK_T,
-                "source": "profiles/r04_msm_2p20/pmc_traffic.json (rocprofv3 --pmc SQ_INSTS_VALU, separate pass) / accum-kernel time of this run",
+                "source": f"{pmc_src} (rocprofv3 --pmc SQ_INSTS_VALU, separate pass) / accum-kernel time of this run",
             }
             if gui:   # GRBM_GUI_ACTIVE / 8 XCDs / the kernel's duration in the same counter pass
                 out["roofline"]["valu_issue"]["effective_clock_GHz_profiled_pass"] = round(gui, 2)
@@ -1195,8 +1210,9 @@ def hyperkzg_replay(args, torch, ck=None):
         ok = ([(c.xy, int(c.is_inf)) for c in coms] == ecoms and evals == eevals
               and [(c.xy, int(c.is_inf)) for c in opens] == eopens)
         outj["cpu_baseline"] = {"value": t_cpu * 1e3, "unit": "ms", "cores": threads, "kind": "port",
-                                "sample": "the same call sequence once through oracle/nova_ref.c (Horner / division passes are "
-                                          "single-threaded there)", "gpu_matches_cpu": ok}
+                                "sample": "the same call sequence once through oracle/nova_ref.c (OpenMP wherever the reference uses rayon; "
+                                          "the division passes chunked as hyperkzg.rs:961-999)", "serial_parts": CPU_SERIAL_PARTS,
+                                "gpu_matches_cpu": ok}
     if own_ck:
         ck.close()
     return outj
@@ -1481,8 +1497,8 @@ def spartan_replay(args, torch):
         checks = {k: res[k] == exp[k] for k in ("outer", "inner", "batch", "evaluations", "batch_witness")}
         checks.update(outj["proof_verifies"])
         outj["cpu_baseline"] = {"value": t_cpu * 1e3, "unit": "ms", "cores": threads, "kind": "port",
-                                "sample": "the same call sequence once through oracle/nova_ref.c (OpenMP over the N-scaling sums; the "
-                                          "transposed product, evaluations and batch witness are single-threaded there)",
+                                "sample": "the same call sequence once through oracle/nova_ref.c (OpenMP wherever the reference uses rayon)",
+                                "serial_parts": CPU_SERIAL_PARTS,
                                 "gpu_matches_cpu": all(checks.values()), "checks": checks}
     for m in mats:
         m.close()
@@ -1847,7 +1863,11 @@ def compressed_snark_replay(args, torch):
     return outj
 
 
-CPU_SERIAL_PARTS = []   # the oracle functions of the replays that run on ONE host thread (filled in as the oracle gains OpenMP)
+# what of the oracle's side of a replay still runs on ONE host thread (round 6: the transposed product, evaluations, eq tables, batch
+# witness, Horner / division passes and the pair product went OpenMP, as the reference's rayon code is: spartan/mod.rs:497-533,
+# polys/multilinear.rs:98-180, polys/eq.rs:54-73, hyperkzg.rs:961-999)
+CPU_SERIAL_PARTS = ["the transcript callback and the O(1) algebra of a sum-check round", "the integer counting sort inside the transposed product",
+                    "vectors shorter than 4 096 elements (sum-check tables of the late rounds, eq tables of the short side)"]
 
 
 def trait_only_msms(logs, reps=5):

@@ -795,14 +795,16 @@ int ref_eq_evals(int field, const uint8_t* r, size_t ell, uint8_t* out) {
   size_t size = 1;
   for (size_t j = ell; j-- > 0;) {           /* for r in r.iter().rev() */
     fe rr; ld_mont(F, &rr, r + 32 * j);
-    for (size_t i = 0; i < size; i++) {
+#pragma omp parallel for num_threads(nthreads()) if (size >= 4096)   /* zip_with_for_each!(par_iter_mut, ..), eq.rs:64-67 */
+    for (long i = 0; i < (long)size; i++) {
       fe y; fe_mul(F, &y, &ev[i], &rr);       /* *y = *x * r */
       ev[i + size] = y;
       fe_sub(F, &ev[i], &ev[i], &y);          /* *x -= *y */
     }
     size *= 2;
   }
-  for (size_t i = 0; i < n; i++) st_canon(F, out + 32 * i, &ev[i]);
+#pragma omp parallel for num_threads(nthreads()) if (n >= 4096)
+  for (long i = 0; i < (long)n; i++) st_canon(F, out + 32 * i, &ev[i]);
   free(ev);
   return 0;
 }
@@ -813,16 +815,19 @@ int ref_mle_evaluate(int field, const uint8_t* z, size_t ell, const uint8_t* r, 
   uint8_t* el = (uint8_t*)malloc(32 * n_left); uint8_t* er = (uint8_t*)malloc(32 * n_right);
   ref_eq_evals(field, r, s_left, el); ref_eq_evals(field, r + 32 * s_left, s_right, er);
   fe acc; memset(&acc, 0, sizeof acc);
-  for (size_t i = 0; i < n_left; i++) {
+  fe* terms = (fe*)malloc(n_left * sizeof(fe));
+#pragma omp parallel for num_threads(nthreads()) if (n_left * n_right >= 4096)   /* (0..n_left).into_par_iter(), multilinear.rs:110-120 */
+  for (long i = 0; i < (long)n_left; i++) {
     fe red; memset(&red, 0, sizeof red);
     for (size_t j = 0; j < n_right; j++) {
-      fe zz, e, t; ld_mont(F, &zz, z + 32 * (i * n_right + j)); ld_mont(F, &e, er + 32 * j);
+      fe zz, e, t; ld_mont(F, &zz, z + 32 * ((size_t)i * n_right + j)); ld_mont(F, &e, er + 32 * j);
       fe_mul(F, &t, &zz, &e); fe_add(F, &red, &red, &t);
     }
-    fe e, t; ld_mont(F, &e, el + 32 * i); fe_mul(F, &t, &e, &red); fe_add(F, &acc, &acc, &t);
+    fe e; ld_mont(F, &e, el + 32 * i); fe_mul(F, &terms[i], &e, &red);
   }
+  for (size_t i = 0; i < n_left; i++) fe_add(F, &acc, &acc, &terms[i]);   /* (field addition is exact: any order gives the same element) */
   st_canon(F, out32, &acc);
-  free(el); free(er);
+  free(el); free(er); free(terms);
   return 0;
 }
 /* SparseMatrix::multiply_vec (src/r1cs/sparse.rs:201-229), CSR with usize indices */
@@ -844,7 +849,8 @@ int ref_spmv(int field, const uint64_t* indptr, const uint64_t* indices, const u
 int ref_spmv_pair(int field, const uint64_t* indptr, const uint64_t* indices, const uint8_t* data, size_t rows,
                   const uint8_t* z1, const uint8_t* z2, uint8_t* out1, uint8_t* out2) {
   const field_t* F = field_by_id(field); if (!F) return -1;
-  for (size_t rw = 0; rw < rows; rw++) {
+#pragma omp parallel for num_threads(nthreads())
+  for (long rw = 0; rw < (long)rows; rw++) {
     fe a1, a2; memset(&a1, 0, sizeof a1); memset(&a2, 0, sizeof a2);
     for (uint64_t k = indptr[rw]; k < indptr[rw + 1]; k++) {
       fe d, v, t; ld_mont(F, &d, data + 32 * k);
@@ -897,13 +903,16 @@ int ref_lincomb_powers(int field, const uint8_t* const* vecs, const size_t* lens
   fe* acc = (fe*)calloc(n_out ? n_out : 1, sizeof(fe));
   fe pw = F->r1;
   for (size_t j = 0; j < k; j++) {
-    for (size_t i = 0; i < lens[j]; i++) {
+    const size_t lj = lens[j];
+#pragma omp parallel for num_threads(nthreads()) if (lj >= 4096)   /* par chunks / par_iter_mut, spartan/mod.rs:170-277 */
+    for (long i = 0; i < (long)lj; i++) {
       fe v, t; ld_mont(F, &v, vecs[j] + 32 * i);
       fe_mul(F, &t, &pw, &v); fe_add(F, &acc[i], &acc[i], &t);
     }
     fe_mul(F, &pw, &pw, &sm);
   }
-  for (size_t i = 0; i < n_out; i++) st_canon(F, out + 32 * i, &acc[i]);
+#pragma omp parallel for num_threads(nthreads()) if (n_out >= 4096)
+  for (long i = 0; i < (long)n_out; i++) st_canon(F, out + 32 * i, &acc[i]);
   free(acc);
   return 0;
 }
@@ -917,11 +926,12 @@ int ref_mle_multi_evaluate(int field, const uint8_t* const* zs, size_t k, size_t
   uint8_t* el = (uint8_t*)malloc(32 * n_left); uint8_t* er = (uint8_t*)malloc(32 * n_right);
   ref_eq_evals(field, r, s_left, el); ref_eq_evals(field, r + 32 * s_left, s_right, er);
   fe* red = (fe*)calloc(n_left * k, sizeof(fe));
-  for (size_t i = 0; i < n_left; i++)
+#pragma omp parallel for num_threads(nthreads()) if (n_left * n_right >= 4096)   /* all_reduced.par_chunks_mut(k), multilinear.rs:152-163 */
+  for (long i = 0; i < (long)n_left; i++)
     for (size_t j = 0; j < n_right; j++) {
       fe e; ld_mont(F, &e, er + 32 * j);
       for (size_t p = 0; p < k; p++) {
-        fe zz, t; ld_mont(F, &zz, zs[p] + 32 * (i * n_right + j));
+        fe zz, t; ld_mont(F, &zz, zs[p] + 32 * ((size_t)i * n_right + j));
         fe_mul(F, &t, &zz, &e); fe_add(F, &red[i * k + p], &red[i * k + p], &t);
       }
     }
@@ -941,11 +951,48 @@ int ref_mle_multi_evaluate(int field, const uint8_t* const* zs, size_t k, size_t
 int ref_poly_suffix_horner(int field, const uint8_t* f, size_t n, const uint8_t* u, uint8_t* out) {
   const field_t* F = field_by_id(field); if (!F) return -1;
   fe uu, acc; ld_mont(F, &uu, u); memset(&acc, 0, sizeof acc);
-  for (size_t i = n; i-- > 0;) {
-    fe fi; ld_mont(F, &fi, f + 32 * i);
-    fe_mul(F, &acc, &acc, &uu); fe_add(F, &acc, &acc, &fi);   /* acc = acc * u + fi */
-    st_canon(F, out + 32 * i, &acc);
+  const size_t T = (size_t)nthreads();
+  if (n < 8192 || T < 2) {
+    for (size_t i = n; i-- > 0;) {
+      fe fi; ld_mont(F, &fi, f + 32 * i);
+      fe_mul(F, &acc, &acc, &uu); fe_add(F, &acc, &acc, &fi);   /* acc = acc * u + fi */
+      st_canon(F, out + 32 * i, &acc);
+    }
+    return 0;
   }
+  /* Chunked as the reference's div_by_monomial is (hyperkzg.rs:961-999: per-chunk Horner, chunk heads chained with u^chunk, a second
+   * pass adds the carry): chunk c = [c L, min(n, (c + 1) L)); local[i] = sum_{k >= i, k in chunk} f[k] u^(k - i); the value entering
+   * chunk c from the right is carry[c] = out[(c + 1) L]; out[i] = local[i] + carry[c] u^(end_c - i).  Same elements as the serial pass. */
+  const size_t L = (n + T - 1) / T, C = (n + L - 1) / L;
+  fe* loc = (fe*)malloc(n * sizeof(fe));
+  fe* carry = (fe*)calloc(C + 1, sizeof(fe));
+#pragma omp parallel for num_threads(nthreads()) schedule(static, 1)
+  for (long c = 0; c < (long)C; c++) {
+    const size_t lo = (size_t)c * L, hi = lo + L < n ? lo + L : n;
+    fe a; memset(&a, 0, sizeof a);
+    for (size_t i = hi; i-- > lo;) {
+      fe fi; ld_mont(F, &fi, f + 32 * i);
+      fe_mul(F, &a, &a, &uu); fe_add(F, &a, &a, &fi);
+      loc[i] = a;
+    }
+  }
+  for (size_t c = C; c-- > 0;) {   /* carry[c] = out[(c + 1) L] = local head of chunk c + 1 + carry[c + 1] u^len(c + 1) */
+    if (c + 1 >= C) continue;      /* (the last chunk has nothing to its right: carry stays zero) */
+    const size_t lo = (c + 1) * L, hi = lo + L < n ? lo + L : n;
+    fe pw = F->r1, t;
+    for (size_t i = lo; i < hi; i++) fe_mul(F, &pw, &pw, &uu);
+    fe_mul(F, &t, &carry[c + 1], &pw); fe_add(F, &carry[c], &loc[lo], &t);
+  }
+#pragma omp parallel for num_threads(nthreads()) schedule(static, 1)
+  for (long c = 0; c < (long)C; c++) {
+    const size_t lo = (size_t)c * L, hi = lo + L < n ? lo + L : n;
+    fe pw = carry[c];                          /* carry u^(hi - i), built from the right end of the chunk */
+    for (size_t i = hi; i-- > lo;) {
+      fe v; fe_mul(F, &pw, &pw, &uu); fe_add(F, &v, &loc[i], &pw);
+      st_canon(F, out + 32 * i, &v);
+    }
+  }
+  free(loc); free(carry);
   return 0;
 }
 
@@ -964,16 +1011,44 @@ typedef int (*ref_transcript_fn)(void* ctx, const uint8_t* coeffs, size_t n_coef
 int ref_spmv_transposed(int field, const uint64_t* indptr, const uint64_t* indices, const uint8_t* data, size_t rows, size_t cols,
                         const uint8_t* rx, uint8_t* out) {
   const field_t* F = field_by_id(field); if (!F) return -1;
-  fe* acc = (fe*)calloc(cols ? cols : 1, sizeof(fe));
-  for (size_t rw = 0; rw < rows; rw++) {
-    fe x; ld_mont(F, &x, rx + 32 * rw);
-    for (uint64_t k = indptr[rw]; k < indptr[rw + 1]; k++) {
-      fe d, t; ld_mont(F, &d, data + 32 * k);
-      fe_mul(F, &t, &x, &d); fe_add(F, &acc[indices[k]], &acc[indices[k]], &t);
+  const size_t nnz = (size_t)indptr[rows];
+  if (nnz < 8192 || nthreads() < 2) {   /* the reference's loop as written (one matrix on one thread) */
+    fe* acc = (fe*)calloc(cols ? cols : 1, sizeof(fe));
+    for (size_t rw = 0; rw < rows; rw++) {
+      fe x; ld_mont(F, &x, rx + 32 * rw);
+      for (uint64_t k = indptr[rw]; k < indptr[rw + 1]; k++) {
+        fe d, t; ld_mont(F, &d, data + 32 * k);
+        fe_mul(F, &t, &x, &d); fe_add(F, &acc[indices[k]], &acc[indices[k]], &t);
+      }
     }
+    for (size_t i = 0; i < cols; i++) st_canon(F, out + 32 * i, &acc[i]);
+    free(acc);
+    return 0;
   }
-  for (size_t i = 0; i < cols; i++) st_canon(F, out + 32 * i, &acc[i]);
-  free(acc);
+  /* The reference runs this loop on one thread per matrix, the three matrices side by side (rayon::join, spartan/mod.rs:513-531).
+   * The oracle is called once per matrix, so to stay a fair baseline it spreads ONE matrix over the cores instead: entries grouped
+   * by column (a counting sort over the indices: integers only, one thread), then the columns in parallel.  Same sums (field
+   * addition is exact in any order). */
+  uint32_t* start = (uint32_t*)calloc(cols + 2, sizeof(uint32_t));
+  for (size_t k = 0; k < nnz; k++) start[indices[k] + 2]++;
+  for (size_t c = 0; c < cols; c++) start[c + 2] += start[c + 1];
+  uint32_t* ent = (uint32_t*)malloc((nnz ? nnz : 1) * sizeof(uint32_t));  /* entry ids grouped by column */
+  uint32_t* row_of = (uint32_t*)malloc((nnz ? nnz : 1) * sizeof(uint32_t));
+  for (size_t rw = 0; rw < rows; rw++)
+    for (uint64_t k = indptr[rw]; k < indptr[rw + 1]; k++) {
+      const uint32_t q = start[indices[k] + 1]++;
+      ent[q] = (uint32_t)k; row_of[q] = (uint32_t)rw;
+    }
+#pragma omp parallel for num_threads(nthreads()) schedule(dynamic, 1024)
+  for (long c = 0; c < (long)cols; c++) {
+    fe a; memset(&a, 0, sizeof a);
+    for (uint32_t q = start[c]; q < start[c + 1]; q++) {
+      fe x, d, t; ld_mont(F, &x, rx + 32 * (size_t)row_of[q]); ld_mont(F, &d, data + 32 * (size_t)ent[q]);
+      fe_mul(F, &t, &x, &d); fe_add(F, &a, &a, &t);
+    }
+    st_canon(F, out + 32 * c, &a);
+  }
+  free(start); free(ent); free(row_of);
   return 0;
 }
 

@@ -159,3 +159,37 @@ def test_batch_invert_oracle():
             got = C.ints(bytearray(cref.batch_invert(fid, v, n)))
             assert got == [pow(x, -1, p) for x in vi]
         assert cref.batch_invert(fid, C.vec([3, 0, 5]), 3) is None
+
+
+def test_parallel_paths_of_the_oracle_equal_its_serial_paths():
+    """Round 6: the oracle's transposed product, evaluations, eq tables, batch witness and Horner / division pass run OpenMP above a size
+    threshold (the reference's rayon code does: spartan/mod.rs:497-533, polys/multilinear.rs:98-180, hyperkzg.rs:961-999).  With one thread
+    every one of them takes its serial loop -- the restatement line for line; with several the chunked / column-grouped form: same
+    bytes, at sizes on both sides of the thresholds and with ragged chunk ends."""
+    from tests import spartan_common as sp
+    fid = 1
+    keep = cref.get_threads()
+    try:
+        outs = []
+        for th in (1, 5):
+            cref.set_threads(th)
+            o = []
+            for n in (8191, 8192, 20011):
+                f = C.rand_vec(fid, n, 50 + n)
+                u = C.rand_vec(fid, 1, 51 + n)
+                o.append(cref.suffix_horner(fid, f, n, u))
+            ell = 14
+            z = C.rand_vec(fid, 1 << ell, 60)
+            r = C.rand_vec(fid, ell, 61)
+            o.append(cref.mle_evaluate(fid, z, ell, r))
+            o.append(b"".join(cref.mle_multi_evaluate(fid, [z.tobytes(), C.rand_vec(fid, 1 << ell, 62).tobytes()], ell, r)))
+            o.append(cref.eq_evals(fid, r, ell))
+            o.append(cref.lincomb_powers(fid, [z.tobytes(), C.rand_vec(fid, 5000, 63).tobytes()], u, 1 << ell))
+            ip, ix, dt = sp.heavy_column_csr(fid, 6000, 2500, 7, heavy_cols=(0, 2499))
+            x = C.rand_vec(fid, 6000, 64)
+            o.append(cref.spmv_transposed(fid, ip, ix, dt, 6000, 2500, x))
+            o.append(b"".join(cref.spmv_pair(fid, ip, ix, dt, 6000, C.rand_vec(fid, 2500, 65), C.rand_vec(fid, 2500, 66))))
+            outs.append(o)
+        assert outs[0] == outs[1]
+    finally:
+        cref.set_threads(keep)
