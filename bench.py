@@ -141,6 +141,7 @@ def main():
     ap.add_argument("--overlap-commits", type=int, default=0, choices=[0, 1, 2],
                     help="prove_step replay: commit(W) begun (nmx_commit_begin) beside the cross term + commit(T) it does not depend on "
                          "(1: the primary pair inside one prove_step; 2: also the secondary pair, across the step boundary)")
+    ap.add_argument("--separate-spmv", action="store_true", help="spartan replay: the three (transposed) products as three calls instead of nmx_spmv_apply_many")
     ap.add_argument("--sync-field-ops", action="store_true", help="prove_step replay: every field-vector call waits for its kernel (round 3's form)")
     ap.add_argument("--workload", default="msm", choices=["msm", "axpy", "cross_term", "bind", "sumcheck3", "round3", "quad_prod", "lincomb8", "horner", "mle_eval", "spmv", "prove_step_replay", "hyperkzg_replay", "spartan_replay", "compressed_snark_replay"],
                     help="msm = the headline (default); the others time one HBM-bound field-vector kernel of "
@@ -1269,7 +1270,10 @@ def spartan_sequence(be, ell, p, u, call=lambda name, fn: fn(), inst=None, tr=No
         zc = call("z_concat", lambda: be_.concat_z(inst[0], u, inst[2]))      # :133, :193-196
     else:
         zc = call("z_concat", lambda: be.concat_z())                          # :133, :193-196
-    Az, Bz, Cz = (call("spmv_x3", lambda j=j: be.spmv(j, zc)) for j in range(3))        # :146
+    if hasattr(be, "spmv_all"):                                               # S.multiply_vec(&z) is ONE reference function (r1cs/mod.rs:407-471)
+        Az, Bz, Cz = call("spmv_x3", lambda: be.spmv_all(zc))                  # :146
+    else:
+        Az, Bz, Cz = (call("spmv_x3", lambda j=j: be.spmv(j, zc)) for j in range(3))
     uCzE = call("uCz_E", lambda: be.axpy(be.E, Cz, u))                        # :147-149
     outer = call("sumcheck_outer", lambda: be.cubic3(le(0), b"".join(tau), Az, Bz, uCzE, tr))     # :158-165
     r_x = outer[1]
@@ -1280,7 +1284,10 @@ def spartan_sequence(be, ell, p, u, call=lambda name, fn: fn(), inst=None, tr=No
     rr = num(r)
     claim_inner = (num(claim_Az) + rr * num(claim_Bz) + rr * rr * num(claim_Cz)) % p
     evals_rx = call("eq_evals", lambda: be.eq_evals(b"".join(r_x)))            # :182
-    eA, eB, eC = (call("spmv_T_x3", lambda j=j: be.spmv_t(j, evals_rx)) for j in range(3))   # :184
+    if hasattr(be, "spmv_t_all"):                                              # compute_eval_table_sparse (spartan/mod.rs:497-533) likewise
+        eA, eB, eC = call("spmv_T_x3", lambda: be.spmv_t_all(evals_rx))        # :184
+    else:
+        eA, eB, eC = (call("spmv_T_x3", lambda j=j: be.spmv_t(j, evals_rx)) for j in range(3))
     ABC = call("poly_ABC", lambda: be.axpy2(eA, eB, eC, r))                    # :188-190
     inner = call("sumcheck_inner", lambda: be.quad(le(claim_inner), ell + 1, ABC, zc, tr))   # :199-205
     r_y = inner[1]
@@ -1429,6 +1436,9 @@ def spartan_replay(args, torch):
         concat_z = staticmethod(lambda: fv.concat(fid, [dW, u, x0], n_out=2 * n, async_=True))   # consumed by stream-ordered calls only
         spmv = staticmethod(lambda j, v: mats[j].multiply_vec(v, async_=True))
         spmv_t = staticmethod(lambda j, v: mats[j].multiply_vec_transposed(v, async_=True))
+        if not getattr(args, "separate_spmv", False):
+            spmv_all = staticmethod(lambda v: fv.multiply_vec_many(mats, v, async_=True))
+            spmv_t_all = staticmethod(lambda v: fv.multiply_vec_many(mats, v, transposed=True, async_=True))
         axpy = staticmethod(lambda a, b, r: fv.axpy(fid, a, b, r, async_=True))
         axpy2 = staticmethod(lambda a, b, c, r: fv.axpy2(fid, a, b, c, r, async_=True))
         multi_evaluate = staticmethod(lambda zs, r: fv.mle_multi_evaluate(fid, zs, r))
@@ -1579,6 +1589,12 @@ class GpuProvider:
     def spmv_t(self, j, v):
         return self.mats[j].multiply_vec_transposed(v, async_=True)
 
+    def spmv_all(self, v):
+        return self.fv.multiply_vec_many(self.mats, v, async_=True)
+
+    def spmv_t_all(self, v):
+        return self.fv.multiply_vec_many(self.mats, v, transposed=True, async_=True)
+
     def cross_term2(self, az, bz, cz, e1, e2, u):
         return self.fv.cross_term2(self.fid, az, bz, cz, e1, e2, u, async_=True)
 
@@ -1699,7 +1715,10 @@ def relaxed_fold_sequence(be, side, tr, call):
     z1 = call("fold.z", lambda: be.concat_z(be.W1, side.u1, side.X1))                     # commit_T_relaxed :638-639
     Z = call("fold.vec_add", lambda: be.vec_add(z1, z2))                                  # :643-647
     u12 = np.frombuffer(le((num(side.u1) + num(side.u2)) % p), np.uint8).reshape(1, 32)   # :648
-    AZ, BZ, CZ = (call("fold.spmv_x3", lambda j=j: be.spmv(j, Z)) for j in range(3))      # :650
+    if hasattr(be, "spmv_all"):
+        AZ, BZ, CZ = call("fold.spmv_x3", lambda: be.spmv_all(Z))                         # :650 (one reference function: multiply_vec)
+    else:
+        AZ, BZ, CZ = (call("fold.spmv_x3", lambda j=j: be.spmv(j, Z)) for j in range(3))
     T = call("fold.cross_term2", lambda: be.cross_term2(AZ, BZ, CZ, be.E1, E2, u12))      # :652-659
     cT = call("fold.commit_T", lambda: be.commit(T, side.r_T))                            # :661
     for c in (cW2, cE2, cT):                                                              # nifs.rs:147-160 (the RO; here the stand-in)

@@ -499,6 +499,14 @@ int nmx_spmv_apply_transposed(uint64_t handle, const void* x, size_t x_len, uint
 /* (M*z1, M*z2) in one pass over the matrix: PrecomputedSparseMatrix::multiply_vec_pair (src/r1cs/sparse.rs:215-229) */
 int nmx_spmv_apply_pair(uint64_t handle, const void* z1, const void* z2, size_t z_len, uint32_t flags, void* out1,
                         void* out2);
+/* k matrices of one shape family against ONE vector in one call (round 6):
+ *   transposed = 0: outs[i] = M_i * x          -- R1CSShape::multiply_vec (src/r1cs/mod.rs:407-471: A z, B z, C z under rayon::join)
+ *   transposed = 1: outs[i] = M_i^T * x        -- compute_eval_table_sparse (src/spartan/mod.rs:497-533: the three tables, rayon::join)
+ * With NMX_SCALARS_DEVICE the products run side by side (matrix 0 on the call's stream, the others on side streams that start behind
+ * it and that it continues behind): they are latency-bound gathers, three in flight take little longer than one; NMX_ASYNC as for the
+ * single-matrix calls.  Host operands: one matrix after the other.  1 <= k <= 8, all matrices over the same field. */
+int nmx_spmv_apply_many(const uint64_t* handles, size_t k, int transposed, const void* x, size_t x_len, uint32_t flags,
+                        void* const* outs);
 
 /* ---- measurement ------------------------------------------------------------------------------------
  * With profiling on, every MSM brackets its stages with hipEvents on the stream the kernels run on;

@@ -2343,7 +2343,8 @@ int nmx_mle_evaluate(int field, const void* z, size_t len, const void* r, size_t
     require(ell < 31 && len == ((size_t)1 << ell), NMX_E_ARG, "assert_eq!(r.len(), self.get_num_vars())");
     CtxLease L;
     EvalScratch es(*L.c, field, r, ell, len, flags);
-    es.evaluate(*L.c, field, z, len, flags, out32);
+    if ((flags & NMX_SCALARS_DEVICE) && ell >= 1) fv_mle_multi_eval(*L.c, field, &z, 1, len, es.eqL, es.eqR, (uint32_t)es.s_right, flags, out32);
+    else es.evaluate(*L.c, field, z, len, flags, out32);
   });
 }
 
@@ -2357,6 +2358,11 @@ int nmx_mle_multi_evaluate(int field, const void* const* zs, size_t k, size_t le
     CtxLease L;
     // the two sqrt-size eq tables are built once and shared by all k polynomials (multilinear.rs:141-147)
     EvalScratch es(*L.c, field, r, ell, len, flags);
+    if ((flags & NMX_SCALARS_DEVICE) && ell >= 1) {  // resident polynomials: all passes enqueued at once, results through the mailbox
+      for (size_t j = 0; j < k; j += 16)
+        fv_mle_multi_eval(*L.c, field, zs + j, k - j < 16 ? k - j : 16, len, es.eqL, es.eqR, (uint32_t)es.s_right, flags, out + 32 * j);
+      return;
+    }
     for (size_t j = 0; j < k; j++) es.evaluate(*L.c, field, zs[j], len, flags, out + 32 * j);
   });
 }
@@ -2509,6 +2515,49 @@ int nmx_spmv_apply_transposed(uint64_t handle, const void* x, size_t x_len, uint
     auto tr = transposed_of(*L.c, ss);
     fv_spmv_apply_transposed(*L.c, ss.field, tr->vptr, tr->indices, tr->data, tr->vout, tr->hrow, tr->hstart, tr->nvirt, tr->nheavy,
                              tr->nparts, ss.rows, ss.cols, x, flags, out);
+  });
+}
+
+int nmx_spmv_apply_many(const uint64_t* handles, size_t k, int transposed, const void* x, size_t x_len, uint32_t flags, void* const* outs) {
+  return guarded([&] {
+    require(handles && x && outs && k >= 1 && k <= 8, NMX_E_ARG, "bad argument (1 .. 8 matrices)");
+    std::vector<std::shared_ptr<Global::SparseSet>> sp(k);
+    {
+      std::lock_guard<std::mutex> lk(G.mu);
+      for (size_t i = 0; i < k; i++) {
+        auto it = G.sparse.find(handles[i]);
+        if (it == G.sparse.end()) throw Fail{NMX_E_HANDLE, "unknown matrix handle"};
+        sp[i] = it->second;
+      }
+    }
+    for (size_t i = 0; i < k; i++) {
+      require(outs[i], NMX_E_ARG, "null output");
+      require(sp[i]->field == sp[0]->field, NMX_E_ARG, "matrices over different fields");
+      require(x_len == (transposed ? sp[i]->rows : sp[i]->cols), NMX_E_ARG, "invalid shape");
+    }
+    if (!(flags & NMX_SCALARS_DEVICE)) {  // host operands: one matrix after the other through the single-matrix paths
+      for (size_t i = 0; i < k; i++) {
+        const int rc = transposed ? nmx_spmv_apply_transposed(handles[i], x, x_len, flags, outs[i]) : nmx_spmv_apply(handles[i], x, x_len, flags, outs[i]);
+        if (rc) throw Fail{rc, nmx_last_error()};
+      }
+      return;
+    }
+    CtxLease L;
+    std::vector<std::shared_ptr<Global::SparseSet::Transposed>> tr(k);
+    std::vector<SpmvManyItem> items(k);
+    for (size_t i = 0; i < k; i++) {
+      Global::SparseSet& ss = *sp[i];
+      SpmvManyItem& m = items[i];
+      m.rows = ss.rows, m.cols = ss.cols, m.out = outs[i];
+      if (transposed) {
+        tr[i] = transposed_of(*L.c, ss);
+        m.vptr = tr[i]->vptr, m.tix = tr[i]->indices, m.tdata = tr[i]->data, m.vout = tr[i]->vout, m.hrow = tr[i]->hrow, m.hstart = tr[i]->hstart;
+        m.nvirt = tr[i]->nvirt, m.nheavy = tr[i]->nheavy, m.nparts = tr[i]->nparts;
+      } else {
+        m.indptr = ss.indptr, m.indices = ss.indices, m.data = ss.data;
+      }
+    }
+    fv_spmv_many(*L.c, sp[0]->field, items.data(), k, transposed != 0, x, flags);
   });
 }
 

@@ -1688,6 +1688,80 @@ void fv_spmv_apply_transposed(Ctx& c, int field, const uint32_t* vptr, const uin
   }
 }
 
+// R1CSShape::multiply_vec (src/r1cs/mod.rs:407-471: A z, B z, C z side by side under rayon::join) and compute_eval_table_sparse
+// (src/spartan/mod.rs:497-533: the three transposed products, rayon::join again) as ONE call over HBM-resident vectors: matrix 0 on
+// the context's stream, the others on its side streams -- these products are gathers of 32-byte elements, bound by latency (a 2^20-row
+// transposed product: 80 us for 143 MB), so three of them in flight together take little longer than one.  The side streams start
+// behind everything enqueued on the context's stream so far and the context's stream continues behind all of them: to the caller
+// the call is stream-ordered like any other (NMX_ASYNC allowed).
+template <int FID> static void spmv_many_t(Ctx& c, const SpmvManyItem* it, size_t k, bool transposed, const void* x, uint32_t flags) {
+  const bool async = (flags & NMX_ASYNC) != 0;
+  auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  size_t need = 256;
+  std::vector<size_t> off(k, 0);
+  if (transposed)
+    for (size_t i = 0; i < k; i++) {
+      off[i] = need;
+      need += pad((it[i].nparts ? it[i].nparts : 1) * 32);
+    }
+  arena_reserve(c, need);
+  require(k >= 1 && k - 1 <= (size_t)Ctx::kSideStreams, NMX_E_ARG, "too many matrices in one call");
+  if (!c.side_ev) HIPCHK(hipEventCreateWithFlags(&c.side_ev, hipEventDisableTiming));
+  if (k > 1) HIPCHK(hipEventRecord(c.side_ev, c.stream));
+  std::vector<hipEvent_t> done(k, nullptr);
+  try {
+    for (size_t i = 0; i < k; i++) {
+      hipStream_t st = c.stream;
+      if (i > 0) {
+        if (!c.side[i - 1]) HIPCHK(hipStreamCreateWithFlags(&c.side[i - 1], hipStreamNonBlocking));
+        st = c.side[i - 1];
+        HIPCHK(hipStreamWaitEvent(st, c.side_ev, 0));
+      }
+      const SpmvManyItem& m = it[i];
+      if (transposed) {
+        uint32_t* partial = (uint32_t*)(c.arena + off[i]);
+        SpmvSegFn<FID> f{m.vptr, m.tix, m.tdata, (const uint32_t*)x, m.vout, (uint32_t*)m.out, partial,
+                         m.rows <= ((size_t)1 << kSpmvColBits) ? (1u << kSpmvColBits) - 1u : 0xffffffffu};
+        if (m.nvirt) hipLaunchKernelGGL((k_launch<SpmvSegFn<FID>>), dim3((uint32_t)((m.nvirt + 255) / 256)), dim3(256), 0, st, f, (uint32_t)m.nvirt);
+        if (m.nheavy) hipLaunchKernelGGL((k_spmv_heavy<FID>), dim3((uint32_t)m.nheavy), dim3(256), 0, st, m.hrow, m.hstart, (const uint32_t*)partial, (uint32_t*)m.out);
+      } else {
+        SpmvFn<FID> f{m.indptr, m.indices, m.data, (const uint32_t*)x, (uint32_t*)m.out,
+                      m.cols <= ((size_t)1 << kSpmvColBits) ? (1u << kSpmvColBits) - 1u : 0xffffffffu};
+        if (m.rows) hipLaunchKernelGGL((k_launch<SpmvFn<FID>>), dim3((uint32_t)((m.rows + 255) / 256)), dim3(256), 0, st, f, (uint32_t)m.rows);
+      }
+      HIPCHK(hipGetLastError());
+      if (i > 0) {
+        HIPCHK(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+        HIPCHK(hipEventRecord(done[i], st));
+        HIPCHK(hipStreamWaitEvent(c.stream, done[i], 0));
+      }
+    }
+  } catch (...) {
+    for (size_t i = 1; i < k; i++)
+      if (c.side[i - 1]) (void)hipStreamSynchronize(c.side[i - 1]);
+    (void)hipStreamSynchronize(c.stream);
+    for (hipEvent_t e : done)
+      if (e) (void)hipEventDestroy(e);
+    throw;
+  }
+  for (hipEvent_t e : done)
+    if (e) (void)hipEventDestroy(e);  // (a recorded event may be destroyed: the waits already enqueued keep what they need)
+  if (async) {
+    async_mark(c);
+    return;
+  }
+  stream_wait(c.stream);
+}
+void fv_spmv_many(Ctx& c, int field, const SpmvManyItem* items, size_t k, bool transposed, const void* x, uint32_t flags) {
+  switch (field) {
+    case 0: spmv_many_t<0>(c, items, k, transposed, x, flags); break;
+    case 1: spmv_many_t<1>(c, items, k, transposed, x, flags); break;
+    case 2: spmv_many_t<2>(c, items, k, transposed, x, flags); break;
+    case 3: spmv_many_t<3>(c, items, k, transposed, x, flags); break;
+    default: throw Fail{NMX_E_ARG, "bad field id"};
+  }
+}
+
 void fv_spmv_apply_pair(Ctx& c, int field, const uint32_t* indptr, const uint32_t* indices, const uint32_t* data,
                         size_t rows, size_t cols, const void* z1, const void* z2, uint32_t flags, void* out1, void* out2) {
   switch (field) {

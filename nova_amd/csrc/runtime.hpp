@@ -728,6 +728,15 @@ void fv_eval_multi(Ctx&, int field, const void* const* polys, const size_t* lens
 void fv_bind_eq_sums(Ctx&, int field, int mode, const void* A, const void* B, const void* C, size_t len, const void* r,
                      const void* eqL, size_t nL, const void* eqR, size_t nR, uint32_t shift, uint32_t flags, void* oA,
                      void* oB, void* oC, uint8_t* out);  // sumcheck.hip
+struct SpmvManyItem {  // one matrix of nmx_spmv_apply_many (fieldvec.hip spmv_many_t)
+  const uint32_t *indptr = nullptr, *indices = nullptr, *data = nullptr;                                                  // CSR (forward)
+  const uint32_t *vptr = nullptr, *tix = nullptr, *tdata = nullptr, *vout = nullptr, *hrow = nullptr, *hstart = nullptr;  // M^T in virtual rows
+  size_t nvirt = 0, nheavy = 0, nparts = 0, rows = 0, cols = 0;
+  void* out = nullptr;
+};
+void fv_spmv_many(Ctx&, int field, const SpmvManyItem* items, size_t k, bool transposed, const void* x, uint32_t flags);
+void fv_mle_multi_eval(Ctx&, int field, const void* const* zs, size_t k, size_t len, const uint32_t* eqL, const uint32_t* eqR, uint32_t s_right,
+                       uint32_t flags, uint8_t* out);  // sumcheck_prove.hpp: HBM-resident polynomials, results through the mailbox
 void fv_eq_sums(Ctx&, int field, int mode, const void* A, const void* B, const void* C, size_t len, const void* eqL,
                 size_t nL, const void* eqR, size_t nR, uint32_t shift, uint32_t flags, uint8_t* out);  // sumcheck.hip
 void fv_spmv_apply_transposed(Ctx&, int field, const uint32_t* vptr, const uint32_t* indices, const uint32_t* data, const uint32_t* vout,

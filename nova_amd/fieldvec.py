@@ -349,6 +349,19 @@ class SparseMatrix:
             self.handle = 0
 
 
+def multiply_vec_many(mats, x, transposed=False, mont=False, async_=False):
+    """nmx_spmv_apply_many: [M x for M in mats] (R1CSShape::multiply_vec, src/r1cs/mod.rs:407-471) or, transposed, [M^T x ...]
+    (compute_eval_table_sparse, src/spartan/mod.rs:497-533) in one call; HBM-resident x: the products run side by side."""
+    import ctypes
+    px, n, dev, _kx = _vec(x)
+    k = len(mats)
+    hs = (ctypes.c_uint64 * k)(*[m.handle for m in mats])
+    outs = [_out_like(dev, m.cols if transposed else m.rows, x) for m in mats]
+    ptrs = (ctypes.c_void_p * k)(*[o[0] for o in outs])
+    _check(L.lib().nmx_spmv_apply_many(hs, k, 1 if transposed else 0, px, n, _flags(dev, mont, async_), ptrs))
+    return [o[1] for o in outs]
+
+
 def suffix_horner(field, f, u, mont=False):
     """out[i] = sum_{k>=i} f[k] u^(k-i): out[0] = poly_eval(f, u) (hyperkzg.rs:1011-1020), out[1:] = the quotient of
     div_by_monomial(f, u) (hyperkzg.rs:961-999)."""

@@ -552,3 +552,34 @@ def test_quad_prod_round_polynomial_is_the_references_known_answer(nmx):
         tr = sp.StandInTranscript(fc.FIELDS[1])
         polys, _r, _c = g_quad(1, sp.le(7), l, fc.vec(A), fc.vec(B), tr)
         assert [int.from_bytes(c, "little") for c in polys[0]] == [1, 3, 2]
+
+
+@pytest.mark.parametrize("fid", [0, 1, 2, 3])
+def test_three_products_in_one_call(nmx, fid):
+    """nmx_spmv_apply_many: R1CSShape::multiply_vec (A z, B z, C z; src/r1cs/mod.rs:407-471) and compute_eval_table_sparse (the three
+    transposed products; src/spartan/mod.rs:497-533) as one call each, the matrices side by side on side streams -- against the oracle
+    per matrix, HBM-resident (synchronous and stream-ordered), host operands, repeated (the side streams are reused), with a heavy
+    column in one matrix only, and followed at once by a stream-ordered consumer of the results."""
+    from nova_amd import fieldvec as fv
+    rows, cols = 9000, 5000
+    csr = [sp.heavy_column_csr(fid, rows, cols, 11 + j, heavy_cols=(0, cols - 1) if j == 1 else ()) for j in range(3)]
+    mats = [fv.SparseMatrix(fid, ip, ix, dt, cols) for ip, ix, dt in csr]
+    z, x = fc.edge_vectors(fid, cols, 31), fc.edge_vectors(fid, rows, 32)
+    want_f = [cref.spmv(fid, ip, ix, dt, rows, z) for ip, ix, dt in csr]
+    want_t = [cref.spmv_transposed(fid, ip, ix, dt, rows, cols, x) for ip, ix, dt in csr]
+    dz, dx = dev(z), dev(x)
+    for _ in range(3):
+        assert [o.cpu().numpy().tobytes() for o in fv.multiply_vec_many(mats, dz)] == want_f
+        assert [o.cpu().numpy().tobytes() for o in fv.multiply_vec_many(mats, dx, transposed=True)] == want_t
+    outs = fv.multiply_vec_many(mats, dz, async_=True)
+    s = fv.axpy(fid, outs[0], outs[2], fc.rand_vec(fid, 1, 5), async_=True)          # a consumer on the call's stream
+    outs_t = fv.multiply_vec_many(mats[:2], dx, transposed=True, async_=True)
+    fv.sync()
+    assert [o.cpu().numpy().tobytes() for o in outs] == want_f
+    assert [o.cpu().numpy().tobytes() for o in outs_t] == want_t[:2]
+    assert s.cpu().numpy().tobytes() == cref.field_axpy(fid, np.frombuffer(want_f[0], np.uint8).reshape(rows, 32),
+                                                         np.frombuffer(want_f[2], np.uint8).reshape(rows, 32), fc.rand_vec(fid, 1, 5), rows)
+    assert [o.tobytes() for o in fv.multiply_vec_many(mats, z)] == want_f              # host operands
+    assert [o.tobytes() for o in fv.multiply_vec_many(mats, x, transposed=True)] == want_t
+    for m in mats:
+        m.close()
