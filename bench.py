@@ -1580,6 +1580,13 @@ class GpuProvider:
     def batch_commit(self, vs):
         return [self.pt(c) for c in self.ce.batch_commit(self.ck, vs)]
 
+    def commit_pair(self, a, b):
+        """two independent commitments (rayon::join on the reference side): the first begun with nmx_commit_begin, the second
+        synchronous beside it -- one's latency-bound tail under the other's accumulation"""
+        t = self.ce.commit_begin(self.ck, a[0], a[1])
+        second = self.pt(self.ce.commit(self.ck, b[0], b[1]))
+        return self.pt(t.finish()), second
+
     def vec_add(self, a, b):
         return self.fv.vec_add(self.fid, a, b, async_=True)
 
@@ -1710,8 +1717,12 @@ def relaxed_fold_sequence(be, side, tr, call):
     p = side.p
     z2 = call("rand.z", lambda: be.concat_z(be.W2, side.u2, side.X2))
     E2 = call("rand.E", lambda: be.cross_term0(z2, side.u2))                              # r1cs/mod.rs:803-812
-    cW2 = call("rand.commit_W", lambda: be.commit(be.W2, side.r_W))                       # :815-818 (rayon::join)
-    cE2 = call("rand.commit_E", lambda: be.commit(E2, side.r_E))
+    # :815-818 `rayon::join(|| commit(W), || commit(E))`: two threads on the reference side; a provider that can takes them side by side
+    if hasattr(be, "commit_pair"):
+        cW2, cE2 = call("rand.commit_W_E", lambda: be.commit_pair((be.W2, side.r_W), (E2, side.r_E)))
+    else:
+        cW2 = call("rand.commit_W", lambda: be.commit(be.W2, side.r_W))
+        cE2 = call("rand.commit_E", lambda: be.commit(E2, side.r_E))
     z1 = call("fold.z", lambda: be.concat_z(be.W1, side.u1, side.X1))                     # commit_T_relaxed :638-639
     Z = call("fold.vec_add", lambda: be.vec_add(z1, z2))                                  # :643-647
     u12 = np.frombuffer(le((num(side.u1) + num(side.u2)) % p), np.uint8).reshape(1, 32)   # :648
@@ -1876,10 +1887,113 @@ def compressed_snark_replay(args, torch):
                                 "serial_parts": CPU_SERIAL_PARTS, "gpu_matches_cpu": all(checks.values()), "checks": checks}
         # the unchanged-caller form: every commitment of the sequence as the trait's slice-form call, host scalars and host bases
         outj["trait_only"] = trait_only_msms({k: (sides[k].cid, keys[k], cpu[k].msm_log, cpu[k].prep) for k in sides})
+        if not getattr(args, "no_cpp_driver", False):
+            for k in gpu:                                  # (the driver registers its own keys and matrices: give the HBM back first)
+                gpu[k].close()
+                cks[k].close()
+            gpu = {}
+            outj["cpp_driver"] = cpp_chained_replay(sides, exp, {k: cpu[k].host for k in cpu}, args.steps, args.warmup)
     for k in gpu:
         gpu[k].close()
         cks[k].close()
     return outj
+
+
+CPP_DRIVER_SRC = os.path.join(ROOT, "bench", "csnark_replay.cpp")
+CPP_DRIVER_BIN = os.path.join(ROOT, "bench", "csnark_replay.bin")
+
+
+def build_cpp_driver(force=False):
+    """g++ bench/csnark_replay.cpp (the chained replay driven from C++ through include/nova_mi355x.hpp): host code only, links the
+    product library, the HIP runtime (device buffers) and the stand-in transcript.  Built by __graft_entry__.build() so that the
+    binary travels to the GPU box."""
+    import subprocess
+    from tests import standin
+    standin.build()
+    deps = [CPP_DRIVER_SRC, os.path.join(ROOT, "include", "nova_mi355x.hpp"), os.path.join(ROOT, "include", "nova_mi355x.h")]
+    if force or not os.path.exists(CPP_DRIVER_BIN) or os.path.getmtime(CPP_DRIVER_BIN) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", CPP_DRIVER_BIN, CPP_DRIVER_SRC,
+                               "-L" + os.path.join(ROOT, "nova_amd"), "-lnova_mi355x", "-L" + os.path.join(ROOT, "tests", "standin"),
+                               "-lstandin_transcript", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,$ORIGIN/../nova_amd",
+                               "-Wl,-rpath,$ORIGIN/../tests/standin", "-Wl,-rpath,/opt/rocm/lib"])
+    return CPP_DRIVER_BIN
+
+
+def _write_records(path, recs):
+    import struct
+    with open(path, "wb") as f:
+        for name, data in recs.items():
+            b = bytes(data)
+            nb = name.encode()
+            f.write(struct.pack("<I", len(nb)) + nb + struct.pack("<Q", len(b)) + b)
+
+
+def _read_records(path):
+    import struct
+    out = {}
+    with open(path, "rb") as f:
+        buf = f.read()
+    i = 0
+    while i < len(buf):
+        (nl,) = struct.unpack_from("<I", buf, i)
+        name = buf[i + 4:i + 4 + nl].decode()
+        (nb,) = struct.unpack_from("<Q", buf, i + 4 + nl)
+        i += 12 + nl
+        out[name] = buf[i:i + nb]
+        i += nb
+    return out
+
+
+def cpp_chained_replay(sides, exp, cpu_host, steps, warmup, k0=7):
+    """The same chained sequence driven from C++ (bench/csnark_replay.cpp through include/nova_mi355x.hpp) on the same instance: its
+    wall time per sequence, and every output compared with the oracle's run `exp` (csnark_digest)."""
+    import struct
+    import subprocess
+    import tempfile
+    recs = {}
+    for tag, sd in sides.items():
+        recs[f"{tag}.meta"] = np.array([sd.cid, sd.fid, sd.ell, k0], np.uint64).tobytes()
+        for j, (ip, ix, dt) in enumerate(sd.csr):
+            recs[f"{tag}.ip{j}"] = np.ascontiguousarray(ip, np.uint64).tobytes()
+            recs[f"{tag}.ix{j}"] = np.ascontiguousarray(ix, np.uint64).tobytes()
+            recs[f"{tag}.dt{j}"] = np.ascontiguousarray(dt).tobytes()
+        for nm in ("W1", "W2", "E1", "u1", "X1", "u2", "X2", "r_W", "r_E", "r_T"):
+            recs[f"{tag}.{nm}"] = np.ascontiguousarray(getattr(sd, nm)).tobytes()
+    with tempfile.TemporaryDirectory() as td:
+        fin, fout = os.path.join(td, "instance.bin"), os.path.join(td, "out.bin")
+        _write_records(fin, recs)
+        r = subprocess.run([build_cpp_driver(), fin, fout, str(steps), str(warmup)], capture_output=True, text=True)
+        if r.returncode != 0:
+            return {"error": f"rc {r.returncode}: {r.stderr[-300:]}"}
+        got = _read_records(fout)
+    pts = lambda b: [(bytes(b[65 * i:65 * i + 64]), int(b[65 * i + 64])) for i in range(len(b) // 65)]
+    flat = lambda b: [bytes(b[32 * i:32 * i + 32]) for i in range(len(b) // 32)]
+    rows = lambda b, w: [flat(b[32 * w * j:32 * w * (j + 1)]) for j in range(len(b) // (32 * w))]
+    dg = {}
+    for tag in ("S", "P"):
+        dg[f"fold_{tag}.commitments"] = [pts(got[f"{tag}.fold.{k}"])[0] for k in ("cW2", "cE2", "cT")]
+        dg[f"fold_{tag}.r"] = bytes(got[f"{tag}.fold.r"])
+        for k, w in (("outer", 4), ("inner", 3), ("batch", 3)):
+            dg[f"spartan_{tag}.{k}"] = (rows(got[f"{tag}.spartan.{k}.polys"], w), flat(got[f"{tag}.spartan.{k}.r"]), flat(got[f"{tag}.spartan.{k}.claims"]))
+        dg[f"spartan_{tag}.evaluations"] = flat(got[f"{tag}.spartan.evaluations"])
+        dg[f"spartan_{tag}.batch_witness"] = bytes(got[f"{tag}.spartan.batch_witness"])
+    v = flat(got["P.ee.v"])
+    dg["ee_P"] = {"com": pts(got["P.ee.com"]), "v": [v[3 * i:3 * i + 3] for i in range(len(v) // 3)], "w": pts(got["P.ee.w"])}
+    de = csnark_digest(exp, cpu_host)
+
+    def plain(x):                                       # one shape on both sides: nested lists of bytes / ints
+        if isinstance(x, (bytes, bytearray, memoryview, np.ndarray)):
+            return bytes(x)
+        if isinstance(x, dict):
+            return {k: plain(val) for k, val in x.items()}
+        if isinstance(x, (list, tuple)):
+            return [plain(val) for val in x]
+        return int(x) if isinstance(x, (int, np.integer)) else x
+    checks = {k: plain(dg[k]) == plain(de[k]) for k in de}
+    return {"ms": round(struct.unpack("<d", got["ms_per_sequence"])[0], 4), "steps": steps, "gpu_matches_cpu": all(checks.values()),
+            "failed": [k for k, ok in checks.items() if not ok],
+            "what": "bench/csnark_replay.cpp: the same provider calls in the same order through include/nova_mi355x.hpp (namespace resident), "
+                    "device buffers allocated once, no Python between the calls"}
 
 
 # what of the oracle's side of a replay still runs on ONE host thread (round 6: the transposed product, evaluations, eq tables, batch

@@ -67,6 +67,13 @@ class CommitmentKey {
                                      k.h_.data()));
     return k;
   }
+  // synthetic key P_i = (k0 + i) G built on the device, h = P_n (benchmarks and replays: nmx_bases_generate)
+  static CommitmentKey generate(int curve, size_t n, uint64_t k0 = 1, bool precompute = true) {
+    CommitmentKey k(curve, n, Affine{});
+    check(nmx_bases_generate(curve, k0, n + 1, precompute ? NMX_BASES_PRECOMPUTE : 0u, &k.handle_));
+    check(nmx_bases_read(k.handle_, n, 1, k.h_.data()));
+    return k;
+  }
   CommitmentKey(CommitmentKey&& o) noexcept : curve_(o.curve_), n_(o.n_), h_(o.h_), mont_(o.mont_), handle_(o.handle_) {
     o.handle_ = 0;
   }
@@ -310,4 +317,120 @@ template <int FIELD> struct Sumcheck {
   }
 };
 }  // namespace spartan
+
+// Hosts that keep their vectors in HBM between provider calls (INTEGRATION.md sections 2b-2e: the patched r1cs/mod.rs, nifs.rs,
+// snark.rs): the same operations over device pointers.  Thin by design -- each function is one C call with NMX_SCALARS_DEVICE (and
+// NMX_ASYNC where the host does not look at the result before its next synchronous call); allocation is the host's business
+// (hipMalloc, a pool, torch).  `n` counts 32-byte elements.  Used by bench/csnark_replay.cpp (the chained CompressedSNARK::prove replay).
+namespace resident {
+using provider::Affine;
+using provider::check;
+using provider::CommitmentKey;
+using provider::Point;
+using provider::Scalar;
+constexpr uint32_t kDev = NMX_SCALARS_DEVICE, kAsync = NMX_SCALARS_DEVICE | NMX_ASYNC;
+
+inline Point commit(const CommitmentKey& ck, const void* v, size_t n, const Scalar& r) {  // CE::commit (pedersen.rs:263-270, hyperkzg.rs:584-591)
+  Point p;
+  uint8_t inf = 0;
+  check(nmx_commit(ck.handle(), v, n, ck.h().data(), r.data(), kDev, p.xy.data(), &inf));
+  p.is_inf = inf != 0;
+  return p;
+}
+inline uint64_t commit_begin(const CommitmentKey& ck, const void* v, size_t n, const Scalar& r) {  // one arm of a rayon::join of two commits
+  uint64_t t = 0;
+  check(nmx_commit_begin(ck.handle(), v, n, ck.h().data(), r.data(), kDev, &t));
+  return t;
+}
+inline Point commit_finish(uint64_t ticket) {
+  Point p;
+  uint8_t inf = 0;
+  check(nmx_commit_finish(ticket, p.xy.data(), &inf));
+  p.is_inf = inf != 0;
+  return p;
+}
+inline std::vector<Point> batch_commit(const CommitmentKey& ck, const std::vector<const void*>& vs, const std::vector<size_t>& lens) {  // hyperkzg.rs:593-612, r_i = 0
+  const size_t k = vs.size();
+  std::vector<uint8_t> xy(64 * (k ? k : 1)), inf(k ? k : 1);
+  check(nmx_msm_batch_handle(ck.handle(), vs.data(), lens.data(), k, kDev, xy.data(), inf.data()));
+  std::vector<Point> out(k);
+  for (size_t i = 0; i < k; i++) {
+    std::copy(xy.begin() + 64 * i, xy.begin() + 64 * i + 64, out[i].xy.begin());
+    out[i].is_inf = inf[i] != 0;
+  }
+  return out;
+}
+// z = [W | u | X | 0 ...] (snark.rs:133, r1cs/mod.rs:638-639)
+inline void concat_z(int field, const void* W, size_t n, const Scalar& u, const Scalar& X, size_t n_out, void* out) {
+  const void* parts[3] = {W, u.data(), X.data()};
+  const size_t lens[3] = {n, 1, 1};
+  check(nmx_field_concat(field, parts, lens, 1u, 3, n_out, kAsync, out));
+}
+inline void clone(int field, const void* v, size_t n, void* out) {
+  const void* parts[1] = {v};
+  const size_t lens[1] = {n};
+  check(nmx_field_concat(field, parts, lens, 1u, 1, n, kAsync, out));
+}
+inline void vec_add(int field, const void* a, const void* b, size_t n, void* out) { check(nmx_field_vec_add(field, a, b, n, kAsync, out)); }
+inline void axpy(int field, const void* a, const void* b, const Scalar& r, size_t n, void* out) { check(nmx_field_axpy(field, a, b, r.data(), n, kAsync, out)); }
+inline void axpy2(int field, const void* a, const void* b, const void* c, const Scalar& r, size_t n, void* out) {
+  check(nmx_field_axpy2(field, a, b, c, r.data(), n, kAsync, out));
+}
+inline void cross_term2(int field, const void* az, const void* bz, const void* cz, const void* e1, const void* e2, const Scalar& u, size_t n, void* out) {
+  check(nmx_field_cross_term2(field, az, bz, cz, e1, e2, u.data(), n, kAsync, out));
+}
+// R1CSShape::multiply_vec / compute_eval_table_sparse: the three products in one call
+inline void multiply_vec3(const uint64_t mats[3], bool transposed, const void* x, size_t x_len, void* const outs[3]) {
+  check(nmx_spmv_apply_many(mats, 3, transposed ? 1 : 0, x, x_len, kAsync, outs));
+}
+// AZ o BZ - u CZ - E over Z = z (sample_random_instance_witness with E = 0, r1cs/mod.rs:803-812)
+inline void r1cs_cross_term(const uint64_t mats[3], const void* z, size_t z_len, const void* e, const Scalar& u, void* out) {
+  check(nmx_r1cs_cross_term(mats[0], mats[1], mats[2], z, nullptr, z_len, e, u.data(), kAsync, out));
+}
+inline Scalar mle_evaluate(int field, const void* z, size_t len, const std::vector<Scalar>& r) {
+  Scalar out;
+  check(nmx_mle_evaluate(field, z, len, r.data(), r.size(), kDev, out.data()));
+  return out;
+}
+inline std::vector<Scalar> mle_multi_evaluate(int field, const std::vector<const void*>& zs, size_t len, const std::vector<Scalar>& r) {
+  std::vector<Scalar> out(zs.size());
+  check(nmx_mle_multi_evaluate(field, zs.data(), zs.size(), len, r.data(), r.size(), kDev, out[0].data()));
+  return out;
+}
+inline void eq_evals(int field, const std::vector<Scalar>& r, void* out) { check(nmx_eq_evals_from_points(field, r.data(), r.size(), kDev, out)); }
+inline void lincomb_powers(int field, const std::vector<const void*>& vs, const std::vector<size_t>& lens, const Scalar& s, size_t n_out, void* out) {
+  check(nmx_field_lincomb_powers(field, vs.data(), lens.data(), vs.size(), s.data(), n_out, kDev, out));
+}
+inline void fold_pairs(int field, const void* p, size_t len, const Scalar& x, void* out) { check(nmx_poly_fold_pairs(field, p, len, x.data(), kAsync, out)); }
+inline void suffix_horner(int field, const void* f, size_t n, const Scalar& u, void* out) { check(nmx_poly_suffix_horner(field, f, n, u.data(), kDev, out)); }
+inline std::vector<Scalar> poly_eval_multi(int field, const std::vector<const void*>& polys, const std::vector<size_t>& lens, const std::vector<Scalar>& pts) {
+  std::vector<Scalar> out(polys.size() * pts.size());
+  check(nmx_poly_eval_multi(field, polys.data(), lens.data(), polys.size(), pts.data(), pts.size(), kDev, out[0].data()));
+  return out;
+}
+// the sum-check provers over HBM-resident tables (bound in place); `cb` / `ctx`: nmx_transcript_fn and its state
+struct Proof {
+  std::vector<uint8_t> polys, r, claims;
+};
+inline Proof prove_cubic(int field, const Scalar& claim, const std::vector<Scalar>& taus, void* A, void* B, void* C, nmx_transcript_fn cb, void* ctx) {
+  const size_t l = taus.size();
+  Proof p{std::vector<uint8_t>(128 * l), std::vector<uint8_t>(32 * l), std::vector<uint8_t>(96)};
+  check(nmx_sumcheck_prove_cubic_with_three_inputs(field, claim.data(), taus.data(), l, A, B, C, kDev, cb, ctx, p.polys.data(), p.r.data(), p.claims.data()));
+  return p;
+}
+inline Proof prove_quad(int field, const Scalar& claim, size_t l, void* A, void* B, nmx_transcript_fn cb, void* ctx) {
+  Proof p{std::vector<uint8_t>(96 * l), std::vector<uint8_t>(32 * l), std::vector<uint8_t>(64)};
+  check(nmx_sumcheck_prove_quad_prod(field, claim.data(), l, A, B, kDev, cb, ctx, p.polys.data(), p.r.data(), p.claims.data()));
+  return p;
+}
+inline Proof prove_batch(int field, const std::vector<Scalar>& claims, const std::vector<size_t>& nr, const std::vector<void*>& polys,
+                         const std::vector<const void*>& points, const std::vector<Scalar>& coeffs, nmx_transcript_fn cb, void* ctx) {
+  size_t nmax = 0;
+  for (size_t v : nr) nmax = v > nmax ? v : nmax;
+  Proof p{std::vector<uint8_t>(96 * nmax), std::vector<uint8_t>(32 * nmax), std::vector<uint8_t>(32 * claims.size())};
+  check(nmx_sumcheck_prove_batch_eval(field, claims.data(), nr.data(), polys.data(), points.data(), coeffs.data(), claims.size(), kDev, cb, ctx,
+                                      p.polys.data(), p.r.data(), p.claims.data()));
+  return p;
+}
+}  // namespace resident
 }  // namespace nova

@@ -292,6 +292,8 @@ def test_compressed_snark_replay_matches_oracle(nmx, cycle, ell, ell2):
     assert out["cpu_baseline"]["gpu_matches_cpu"] is True, out["cpu_baseline"]["checks"]
     assert all(out["proof_verifies"].values()) and len(out["proof_verifies"]) == 6
     assert out["trait_only"]["gpu_matches_cpu"] is True and out["trait_only"]["calls"] == 8
+    # the same sequence driven from C++ through include/nova_mi355x.hpp (bench/csnark_replay.cpp), against the same oracle run
+    assert out["cpp_driver"].get("gpu_matches_cpu") is True, out["cpp_driver"]
     assert {"P.fold", "P.spartan", "P.ee", "S.fold", "S.spartan"} == set(out["groups_ms"])
 
 
