@@ -872,6 +872,7 @@ def extras(out, args, torch, L, ck, host_scalars, dev_scalars):
                                              "gpu_matches_cpu": cs["cpu_baseline"]["gpu_matches_cpu"], "groups_ms": cs["groups_ms"],
                                              "breakdown_ms": cs["breakdown_ms"], "proof_verifies": all(cs["proof_verifies"].values()),
                                              "trait_only": {k: v for k, v in cs["trait_only"].items() if k != "per_call_ms"},
+                                             "cpp_driver": {k: v for k, v in (cs.get("cpp_driver") or {}).items() if k != "what"},
                                              "what": cs["config"]["workload"]}
     except Exception as e:                                 # never lose the headline to an auxiliary block
         out["compressed_snark_replay_ms"] = {"error": repr(e)}

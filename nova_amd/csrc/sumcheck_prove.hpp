@@ -1535,13 +1535,23 @@ static void mle_multi_eval_t(Ctx& c, const void* const* zs, size_t k, size_t len
     std::vector<ScPass<FID, 1>> pass;
     pass.reserve(k);
     std::vector<uint32_t> seq(k);
+    const bool prof = G.profiling;
+    DeviceBackend be(c, false, prof);
+    be.mark("passes");
     for (size_t j = 0; j < k; j++) {
       pass.emplace_back(h, const_cast<void*>(zs[j]), nullptr, nullptr, (uint32_t*)(c.arena + j * kScPartialBytes), (uint32_t)j);
       seq[j] = pass[j].sums(pass[j].A, nullptr, nullptr, 2 * len, t);  // the mode-1 sum over "half" = len
     }
+    be.mark("end");
     for (size_t j = 0; j < k; j++) {
       const H v = h.raw(h.wait((uint32_t)j, seq[j]), 3);  // three stored factors: z, eqL, eqR
       h.alg.out(v, out + 32 * j);
+    }
+    if (prof && be.nmarks == 2) {  // kernel time of the k passes + final sums (hipEvents on the call's stream), as the single-pass path reports it
+      float ms = 0;
+      HIPCHK(hipEventSynchronize(c.ev[1]));
+      HIPCHK(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
+      prof_store(&ms, 1);
     }
   } catch (...) {
     h.sync_all_quiet();
