@@ -480,6 +480,7 @@ template <int FID> struct ScResArgs {
   // block has not read yet -- with one line, a fall-back in ANOTHER claim of a batch cancelled this claim's kernel by overwriting
   // the challenge it was about to read: the pass never ran and the host's wait for its sums failed
   const uint32_t* chal;
+  uint32_t line0;               // the line of pass 0 (0 / 1): the slot's lines alternate across EVERYTHING that waits on them, pre-launched passes included
   uint32_t* host_part;          // kHostPartWords per block
   uint32_t* slot;               // mailbox slot of the hand-over
   uint32_t* host_tab[3];        // tail areas (pinned)
@@ -552,7 +553,7 @@ template <int FID, int MODE, bool QUAD> __global__ __launch_bounds__(256) void k
     const uint32_t nb = sc_res_blocks<FID, MODE, QUAD>(a.hq);
     if (blockIdx.x >= nb) return;  // (block-uniform; nb only shrinks: this block is not needed again)
     a.chal_seq = p.cs0 + i;
-    a.chal = p.chal + ((i & 1u) ? kChalLineWords : 0u);  // two lines, used in turn (see ScResArgs::chal)
+    a.chal = p.chal + (((i + p.line0) & 1u) ? kChalLineWords : 0u);  // two lines, used in turn (see ScResArgs::chal)
     if (MODE != 4) sc_res_tables<FID>(p, p.round0 + i + 1, a);  // the sums of this pass are the NEXT round's: its eq tables
     F r;
     if (!sc_challenge<FID>(a, r, s_r)) return;
@@ -572,7 +573,7 @@ template <int FID, int MODE, bool QUAD> __global__ __launch_bounds__(256) void k
   if (!p.tail || blockIdx.x != 0) return;
   // the hand-over (k_sc_bind_to_host): tables of `len` elements bound to len / 2, landed in the tail areas
   a.chal_seq = p.cs0 + p.passes;
-  a.chal = p.chal + ((p.passes & 1u) ? kChalLineWords : 0u);
+  a.chal = p.chal + (((p.passes + p.line0) & 1u) ? kChalLineWords : 0u);
   F r;
   if (!sc_challenge<FID>(a, r, s_r)) return;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -787,7 +788,16 @@ template <int FID> struct ScDev {
   // synchronised -- the wait would sit behind a kernel that waits for THIS thread -- so the mailbox polls keep polling (up to
   // kArmedPollSeconds, yielding) instead of giving up after sc_poll_us, and anything that must synchronise cancels them first.
   uint32_t armed_seq[kMailSlots] = {};
-  uint32_t armed_line[kMailSlots] = {};  // word offset of the line the waiting pass polls (0, or kChalLineWords: the resident kernel's odd passes)
+  uint32_t armed_line[kMailSlots] = {};  // word offset of the line the waiting pass polls (0 or kChalLineWords)
+  // A slot's two lines are used in turn by everything that waits on them -- pre-launched passes and the passes of a resident kernel
+  // alike: whatever is armed polls the line that the pass before it did NOT use, so a cancellation (written to the armed line) can
+  // never overwrite a challenge that an earlier pass has been sent but has not read yet.  next_line[s]: the line the next waiter takes.
+  uint32_t next_line[kMailSlots] = {};
+  uint32_t take_line(uint32_t s) {
+    const uint32_t l = next_line[s];
+    next_line[s] ^= 1u;
+    return l;
+  }
   // Blocks of pre-launched passes sit on CUs doing nothing but polling; forward progress of everything else -- the pass whose
   // sums the host needs before it can send the challenge, other callers' kernels -- needs free slots.  A device-wide budget
   // (kArmedBlocksCap, a quarter of the 1024 blocks of 256 lanes the chip holds at this register count) bounds them: a pass that
@@ -1156,7 +1166,7 @@ template <int FID, int MODE> struct ScPass {
   // synchronising waits (sc_poll_us = 0); every pre-launched pass is sent its challenge or cancelled, and one that hears nothing
   // leaves after 2 s.
   static constexpr uint32_t kPrelaunchMaxHq = 1u << 14;
-  uint32_t pre_seq = 0, pre_parts = 0;  // mailbox sequence / host-added blocks of the pass in flight (h.armed_seq[slot]: its challenge sequence)
+  uint32_t pre_seq = 0, pre_parts = 0, pre_line = 0;  // mailbox sequence / host-added blocks / challenge line of the pass in flight (h.armed_seq[slot]: its challenge sequence)
   bool armed() const { return h.armed_seq[slot] != 0; }
   bool can_prelaunch(size_t len) {
     return G.sc_prelaunch.load(std::memory_order_relaxed) != 0 && G.sc_fused_sum.load(std::memory_order_relaxed) != 0 &&
@@ -1173,18 +1183,20 @@ template <int FID, int MODE> struct ScPass {
     if (!h.arm_reserve(slot, bind_blocks((uint32_t)(len / 4)))) return false;
     const uint32_t hq = (uint32_t)(len / 4), seq = h.next_seq(), cs = h.next_seq();
     ScSmallArgs<FID> x{A, B, C, A, B, C, t.eqL, t.eqR, F::zero(), nk, t.shift, t.mask, hq, 1u, seq, h.slot_dev(slot)};
-    x.chal = h.chal_line(slot), x.chal_seq = cs;
+    pre_line = h.take_line(slot) ? kChalLineWords : 0u;
+    x.chal = h.chal_line(slot) + pre_line, x.chal_seq = cs;
     pre_parts = launch_bind(x, hq);
     pre_seq = seq;
     h.armed_seq[slot] = cs;
-    h.armed_line[slot] = 0;
+    h.armed_line[slot] = pre_line;
     return true;
   }
   // the challenge for the pass in flight; returns the mailbox sequence its sums will carry
   uint32_t send(const H& rh) {
     const F r = rh.to_device();
-    ScDev<FID>::chal_write(h.chal_line(slot), r.l, 0u, h.armed_seq[slot]);
+    ScDev<FID>::chal_write(h.chal_line(slot) + pre_line, r.l, 0u, h.armed_seq[slot]);
     h.armed_seq[slot] = 0;
+    h.armed_line[slot] = 0;
     h.arm_release(slot);  // (the pass is running now; its blocks leave within microseconds)
     h.parts[slot] = pre_parts;  // (only now: until here the slot's pending result was the pass before)
     return pre_seq;
@@ -1197,7 +1209,8 @@ template <int FID, int MODE> struct ScPass {
   static constexpr bool kResQuad = kQuadForm;
   bool res_on = false;
   bool res_allowed = true;  // false: this pass shares its stream with other claims' passes (a resident kernel would hold them up for good)
-  uint32_t res_seq0 = 0, res_cs0 = 0, res_next = 0, res_passes = 0;
+  uint32_t res_seq0 = 0, res_cs0 = 0, res_next = 0, res_passes = 0, res_line0 = 0;
+  uint32_t res_line(uint32_t i) const { return ((i + res_line0) & 1u) ? kChalLineWords : 0u; }  // word offset of pass i's line
   size_t res_len0 = 0;
   bool res_active() const { return res_on && h.armed_seq[slot] != 0; }
   bool can_resident(size_t len) {
@@ -1220,6 +1233,8 @@ template <int FID, int MODE> struct ScPass {
     a.len0 = (uint32_t)len, a.passes = passes, a.tail = 1u;
     a.seq0 = res_seq0 = h.reserve_seq(passes + 1), a.cs0 = res_cs0 = h.reserve_seq(passes + 1);
     a.chal = h.chal_line(slot);
+    a.line0 = res_line0 = h.take_line(slot);
+    if (passes & 1u) (void)h.take_line(slot);  // passes + 1 waits in all, the hand-over's on line (line0 + passes) & 1: the next waiter takes the other one
     a.host_part = h.part_dev(slot);
     a.slot = h.slot_dev(slot);
     for (uint32_t t = 0; t < 3; t++) a.host_tab[t] = t < NT ? h.tail_dev(slot + t) : nullptr;
@@ -1229,7 +1244,7 @@ template <int FID, int MODE> struct ScPass {
     h.launched();
     res_on = true, res_next = 0, res_passes = passes, res_len0 = len;
     h.armed_seq[slot] = res_cs0;
-    h.armed_line[slot] = 0;
+    h.armed_line[slot] = res_line(0);
     return true;
   }
   // the challenge of the next bind + sums pass; returns the mailbox sequence its partial sums carry
@@ -1237,8 +1252,8 @@ template <int FID, int MODE> struct ScPass {
     const F r = rh.to_device();
     const uint32_t i = res_next++;
     h.armed_seq[slot] = res_cs0 + i + 1;  // what the kernel waits for once this pass is through, and where: a cancel names that line
-    h.armed_line[slot] = ((i + 1) & 1u) ? kChalLineWords : 0u;
-    ScDev<FID>::chal_write(h.chal_line(slot) + ((i & 1u) ? kChalLineWords : 0u), r.l, 0u, res_cs0 + i);
+    h.armed_line[slot] = res_line(i + 1);
+    ScDev<FID>::chal_write(h.chal_line(slot) + res_line(i), r.l, 0u, res_cs0 + i);
     h.parts[slot] = sc_res_blocks<FID, MODE, kResQuad>((uint32_t)((res_len0 >> i) / 4));
     return res_seq0 + i;
   }
@@ -1250,7 +1265,7 @@ template <int FID, int MODE> struct ScPass {
     h.armed_line[slot] = 0;
     h.arm_release(slot);
     res_on = false;
-    ScDev<FID>::chal_write(h.chal_line(slot) + ((res_passes & 1u) ? kChalLineWords : 0u), r.l, 0u, res_cs0 + res_passes);
+    ScDev<FID>::chal_write(h.chal_line(slot) + res_line(res_passes), r.l, 0u, res_cs0 + res_passes);
     h.parts[slot] = 0;
     (void)h.wait(slot, res_seq0 + res_passes);
     for (uint32_t t = 0; t < NT; t++) {
