@@ -1991,7 +1991,9 @@ def cpp_chained_replay(sides, exp, cpu_host, steps, warmup, k0=7):
             return [plain(val) for val in x]
         return int(x) if isinstance(x, (int, np.integer)) else x
     checks = {k: plain(dg[k]) == plain(de[k]) for k in de}
+    grp = struct.unpack("<5d", got["ms_per_group"])
     return {"ms": round(struct.unpack("<d", got["ms_per_sequence"])[0], 4), "steps": steps, "gpu_matches_cpu": all(checks.values()),
+            "groups_ms": dict(zip(("S.fold", "P.fold", "P.spartan", "P.ee", "S.spartan"), (round(g, 4) for g in grp))),
             "failed": [k for k, ok in checks.items() if not ok],
             "what": "bench/csnark_replay.cpp: the same provider calls in the same order through include/nova_mi355x.hpp (namespace resident), "
                     "device buffers allocated once, no Python between the calls"}

@@ -162,6 +162,8 @@ struct Side {
   Scalar u1, X1, u2, X2, rW, rE, rT;
   // scratch, allocated once
   Dev z1, z2, Z, AZ, BZ, CZ, E2, T, W, E, zc, Az, Bz, Cz, uCzE, erx, eA, eB, eC, ABC, Wc, Ec, wj, chain, Bp, hs[3], hq;
+  std::vector<Scalar> ee_point;  // handed from the sum-check sequence to EE::prove
+  uint8_t ee_tr[48];
   // results of the last run
   std::map<std::string, Blob> out;
   void put(const std::string& k, const void* d, size_t b) { out[tag + "." + k] = Blob((const uint8_t*)d, (const uint8_t*)d + b); }
@@ -291,9 +293,16 @@ static void spartan_prove(Side& s, const Scalar& u, const Scalar& X, bool with_e
   uint8_t evs[96];
   memcpy(evs, ev[0].data(), 32), memcpy(evs + 32, ev[1].data(), 32), memcpy(evs + 64, eval_W.data(), 32);
   s.put("spartan.evaluations", evs, 96);
-  if (!with_ee) return;
-  // ---- EE::prove: hat_P = the batched witness, point = the batch sum-check's r (snark.rs:236-244)
-  const std::vector<Scalar> point = scalars_of(batch.r);
+  (void)with_ee;
+  s.ee_point = scalars_of(batch.r);   // EE::prove: hat_P = the batched witness, point = the batch sum-check's r (snark.rs:236-244)
+  memcpy(s.ee_tr, tr.state, sizeof s.ee_tr);
+}
+static void ee_prove(Side& s) {
+  const int f = s.fid;
+  const size_t n = s.n, ell = s.ell;
+  Transcript tr(0);
+  memcpy(tr.state, s.ee_tr, sizeof s.ee_tr);  // the SNARK's transcript goes on (snark.rs:236: `&mut transcript`)
+  const std::vector<Scalar>& point = s.ee_point;
   std::vector<const void*> polys{s.wj.p};
   std::vector<size_t> lens{n};
   char* cur = (char*)s.chain.p;
@@ -337,15 +346,34 @@ int main(int argc, char** argv) {
     const auto in = read_records(argv[1]);
     Side P, S;
     load_side(P, in, "P"), load_side(S, in, "S");
+    // wall time per group, summed over the timed steps: fold S, fold P, Spartan P, EE P, Spartan S (every group ends in a synchronous
+    // call -- a commitment, an evaluation, the batched witness -- so its work is complete when its clock stops)
+    double grp[5] = {0, 0, 0, 0, 0};
+    bool timing = false;
+    auto lap = [&](int g, std::chrono::steady_clock::time_point& t) {
+      const auto now = std::chrono::steady_clock::now();
+      if (timing) grp[g] += std::chrono::duration<double, std::milli>(now - t).count();
+      t = now;
+    };
     auto run = [&] {
       Scalar uS, XS, uP, XP;
+      auto t = std::chrono::steady_clock::now();
       relaxed_fold(S, uS, XS);            // nova/mod.rs:812-826
-      relaxed_fold(P, uP, XP);            // :829-843
-      spartan_prove(P, uP, XP, true);           // S1::prove (:863-871)
-      spartan_prove(S, uS, XS, false);          // S2::prove (:872-880; its IPA argument is not replayed)
       provider::check(nmx_sync());
+      lap(0, t);
+      relaxed_fold(P, uP, XP);            // :829-843
+      provider::check(nmx_sync());
+      lap(1, t);
+      spartan_prove(P, uP, XP, false);    // S1::prove (:863-871): the sum-check sequence ...
+      lap(2, t);
+      ee_prove(P);                        // ... and EE::prove on its batched witness (snark.rs:236-244)
+      lap(3, t);
+      spartan_prove(S, uS, XS, false);    // S2::prove (:872-880; its IPA argument is not replayed)
+      provider::check(nmx_sync());
+      lap(4, t);
     };
     for (int i = 0; i < warmup; i++) run();
+    timing = true;
     HIPOK(hipDeviceSynchronize());
     const auto t0 = std::chrono::steady_clock::now();
     for (int i = 0; i < steps; i++) run();
@@ -354,6 +382,8 @@ int main(int argc, char** argv) {
     FILE* f = fopen(argv[2], "wb");
     if (!f) return 2;
     write_record(f, "ms_per_sequence", &ms, 8);
+    for (double& g : grp) g /= (steps > 0 ? steps : 1);
+    write_record(f, "ms_per_group", grp, sizeof grp);  // fold S, fold P, Spartan P, EE P, Spartan S
     for (Side* s : {&P, &S}) {
       for (const auto& kv : s->out) write_record(f, kv.first, kv.second.data(), kv.second.size());
       const Blob wj = s->wj.download();

@@ -87,51 +87,74 @@ template <int FID> struct ScAlg {
     uint32_t l = 0, first_half = 0, second_half = 0, round = 1;
     std::vector<H> taus, eq0, slope, eqm1;  // eq_tau_0_a_inf (sumcheck.rs:643-652): eq(tau, 0), 2 tau - 1, eq(tau, -1)
     H eval_eq_left;
-    // 1 / (l(1) p) of round `inv_round`, computed ahead of time by prepare(): the one inversion a round needs (~5-9 us on the
-    // host) then runs while the device is busy with the round's pass instead of behind it
-    mutable H l1p_inv;
-    mutable uint32_t inv_round = 0;
-    mutable bool l1p_zero = false;
+    // derive_from_claim divides by l(1) p = tau_j x eval_eq_left once per round (sumcheck.rs:680-753).  Rounds 1-5 of this project did
+    // that inversion on the host every round (~3 us each, prepared under the device's pass where there was one: at small tables and in
+    // the batch prover -- two claims, short passes -- it was on the critical path: ~120 us of a 2^20 batch proof).  Round 6 tracks the
+    // INNER claim instead: the round polynomial is s_j(X) = p_j eq(tau_j, X) t_j(X) with p_j = eval_eq_left, and the claim of round j
+    // is s_{j-1}(r_{j-1}) = p_j t_{j-1}(r_{j-1}); so with T_j := t_{j-1}(r_{j-1}) (T_1 = the caller's claim, p_1 = 1)
+    //     (1 - tau_j) t_j(0) + tau_j t_j(1) = T_j     =>     t_j(1) = (T_j - (1 - tau_j) t_j(0)) / tau_j
+    // -- a division by tau_j alone, known before the first round: ONE inversion per instance (Montgomery's trick over all taus), none
+    // per round.  The same field elements as (claim - l(0) p t(0)) / (l(1) p) whenever p != 0 (claim = p T exactly); when a challenge
+    // has zeroed p every s_j is the zero polynomial whatever t(1) is, so the reference's fall-back for that case (a third sum) is not
+    // needed for the same output.  tau_j = 0 still takes the fall-back (t(1) is then not determined by the claim).
+    std::vector<H> tau_inv;  // 1 / tau_i; zero where tau_i = 0
+    mutable H T;             // T_round (valid from round 2 on: set by bound())
+    mutable H lt0, lt1, ltinf;  // t(0), t(1), t(inf) of the round derive() last ran for
+    mutable bool l1p_zero = false;  // the coming round takes the fall-back (tau_round = 0)
     void prepare() const {
-      if (round > l || inv_round == round) return;
-      const H l1p = taus[round - 1] * eval_eq_left;  // eq0 + slope = tau
-      l1p_zero = l1p.is_zero();
-      l1p_inv = l1p_zero ? H::zero() : l1p.inv();
-      inv_round = round;
+      if (round > l) return;
+      l1p_zero = taus[round - 1].is_zero();
     }
     void init(const ScAlg& a, const uint8_t* taus_bytes, uint32_t l_) {
-      l = l_, first_half = l / 2, second_half = l - first_half, round = 1, inv_round = 0;
-      taus.resize(l), eq0.resize(l), slope.resize(l), eqm1.resize(l);
+      l = l_, first_half = l / 2, second_half = l - first_half, round = 1;
+      taus.resize(l), eq0.resize(l), slope.resize(l), eqm1.resize(l), tau_inv.assign(l, H::zero());
       for (uint32_t i = 0; i < l; i++) {
         taus[i] = a.in(taus_bytes + 32 * (size_t)i);
         eq0[i] = H::one() - taus[i];
         slope[i] = taus[i] - eq0[i];
         eqm1[i] = eq0[i] - slope[i];
       }
+      // all 1 / tau_i from one inversion: prefix products of the non-zero taus, invert the last, walk back
+      std::vector<H> pre(l);
+      H acc = H::one();
+      for (uint32_t i = 0; i < l; i++) {
+        pre[i] = acc;
+        if (!taus[i].is_zero()) acc = acc * taus[i];
+      }
+      H inv = acc.inv();  // (acc is a product of non-zero elements, or ONE)
+      for (uint32_t i = l; i-- > 0;) {
+        if (taus[i].is_zero()) continue;
+        tau_inv[i] = inv * pre[i];
+        inv = inv * taus[i];
+      }
       eval_eq_left = H::one();
     }
     // derive_from_claim_deg2 / _deg1 (sumcheck.rs:680-753): (s(0), cubic coefficient, s(-1)) from t(0), t(inf) and the claim;
-    // t_m1() supplies t(-1) when l(1) p = 0 (tau = 0, or a challenge that zeroed eval_eq_left): the third N-scaling sum of
-    // the fallback_eval_inf_* paths (sumcheck.rs:1085-1222)
+    // t_m1() supplies t(-1) when tau = 0: the third N-scaling sum of the fallback_eval_inf_* paths (sumcheck.rs:1085-1222)
     template <class TM1> void derive(const H& t0, const H& tinf, const H& claim, bool deg1, H& s0, H& lead, H& sm1, TM1&& t_m1) const {
       const H& p = eval_eq_left;
       const H l0p = eq0[round - 1] * p;
       s0 = l0p * t0;
       lead = deg1 ? H::zero() : slope[round - 1] * p * tinf;
-      H tm1;
-      prepare();  // (a no-op when the caller prepared this round while the device worked)
+      H tm1, t1;
+      prepare();
       if (!l1p_zero) {
-        const H t1 = (claim - s0) * l1p_inv;
+        const H& Tj = round == 1 ? claim : T;  // (p_1 = 1: the caller's claim IS the inner claim)
+        t1 = (Tj - eq0[round - 1] * t0) * tau_inv[round - 1];
         tm1 = t0.dbl() - t1;
         if (!deg1) tm1 = tm1 + tinf.dbl();  // t(-1) = 2 t(inf) + 2 t(0) - t(1)
       } else {
         tm1 = t_m1();
+        t1 = t0.dbl() - tm1;
+        if (!deg1) t1 = t1 + tinf.dbl();
       }
+      lt0 = t0, lt1 = t1, ltinf = deg1 ? H::zero() : tinf;
       sm1 = eqm1[round - 1] * p * tm1;
     }
     void bound(const H& r) {  // sumcheck.rs:1226-1231
       const H& tau = taus[round - 1];
       eval_eq_left = eval_eq_left * (H::one() - tau - r + (r * tau).dbl());
+      T = lt0 + r * ((lt1 - lt0 - ltinf) + r * ltinf);  // t_round(r): the next round's inner claim
       round++;
     }
     // eq over the variables still free in round `rnd` (1-based): taus[rnd .. l), most significant first -- what
