@@ -24,9 +24,13 @@
  * running sum; windows combined by c doublings); `best_msm()` below restates that.  Any correct MSM returns the
  * same group element, so the internal strategy affects the baseline's speed only.
  *
- * Parity pinning: the reference stores no MSM output vectors (its tests assert msm == naive sum at run time:
- * msm.rs:722-821, curve_property_tests.rs:180-218, blitzar.rs:48-214).  This file is pinned against
- * oracle/pyref.py (big-int definition) on that same test matrix in tests/test_oracle.py.
+ * PARITY UNPINNED at reference-output level: this oracle has never met an output of the reference itself (no Rust toolchain in the
+ * image, probed again 2026-09-30; no C / C++ reference sources to build into oracle/_ref), and the reference stores no MSM output
+ * vectors (its tests assert msm == naive sum at run time: msm.rs:722-821, curve_property_tests.rs:180-218, blitzar.rs:48-214).
+ * What pins it instead: oracle/pyref.py (big-int definition) on that same test matrix (tests/test_oracle.py), the public EIP-196
+ * vectors and the SymPy-computed vectors of all four curves (tests/golden/public_kats.json, sympy_kats.json), and -- for the
+ * field-vector and sum-check rows -- every known answer the reference's own tests hold (tests/golden/field_kats.json, with their
+ * source lines) plus the reference's verifier equations on every replayed proof.
  *
  * Threading: OpenMP, one chunk per thread + final sum -- the decomposition the reference uses with rayon
  * (`par_chunks(len / num_threads)` + `reduce(identity, +)`, msm.rs:520-526,564-571,664-673).
