@@ -77,3 +77,33 @@ def edge_vectors(fid, n, seed):
         if i < n:
             v[(7 * i + seed) % n] = util.int_to_le32(x)
     return v
+
+
+def mixed_coefficient_case(fid):
+    """the reference's mixed-coefficient SpMV fixture (src/r1cs/sparse.rs:486-520) as CSR over field `fid`, with the dense integer products
+    of tests/golden/field_kats.json reduced mod p: (indptr, indices, data, cols, z, z2, out, out2)"""
+    k = KATS["spmv_mixed_coefficients"]
+    p = FIELDS[fid]
+    rows, cols = k["rows"], k["cols"]
+    ent = sorted(tuple(e) for e in k["entries"])
+    indptr = [0] * (rows + 1)
+    for r, _c, _v in ent:
+        indptr[r + 1] += 1
+    for r in range(rows):
+        indptr[r + 1] += indptr[r]
+    return (np.array(indptr, np.uint64), np.array([c for _r, c, _v in ent], np.uint64), vec([v % p for _r, _c, v in ent]), cols, vec(k["z"]), vec(k["z2"]),
+            [x % p for x in k["out_int"]], [x % p for x in k["out2_int"]])
+
+
+def check_kats3(mle_multi_evaluate, spmv, spmv_pair):
+    """round 6's additions to the golden file: mle_multi_evaluate(fid, [z_vec...], r_vec) -> list of 32-byte values;
+    spmv(fid, indptr, indices, data_vec, cols, z_vec) -> bytes; spmv_pair(fid, indptr, indices, data_vec, cols, z1, z2) -> (bytes, bytes)"""
+    for fid in FIELDS:
+        for case in KATS["mle_multi_evaluate_known_values"]["cases"]:
+            got = mle_multi_evaluate(fid, [vec(z) for z in case["zs"]], vec(case["point"]))
+            assert [int.from_bytes(bytes(g), "little") for g in got] == case["evals"]
+        ip, ix, dt, cols, z, z2, out, out2 = mixed_coefficient_case(fid)
+        assert ints(np.frombuffer(to_bytes(spmv(fid, ip, ix, dt, cols, z)), np.uint8)) == out
+        assert ints(np.frombuffer(to_bytes(spmv(fid, ip, ix, dt, cols, z2)), np.uint8)) == out2
+        a, b = spmv_pair(fid, ip, ix, dt, cols, z, z2)
+        assert ints(np.frombuffer(to_bytes(a), np.uint8)) == out and ints(np.frombuffer(to_bytes(b), np.uint8)) == out2

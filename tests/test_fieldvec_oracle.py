@@ -61,6 +61,14 @@ def test_oracle_kats_eq_mle_spmv():
                   lambda fid, ip, ix, d, cols, z: cref.spmv(fid, ip, ix, d, len(ip) - 1, z))
 
 
+def test_oracle_kats_multi_evaluate_and_the_mixed_coefficient_matrix():
+    """round 6's additions to tests/golden/field_kats.json: multi_evaluate_with's known values (multilinear.rs:456-485) and the reference's
+    mixed-coefficient SpMV fixture (sparse.rs:486-544: +1, -1, small, small negative, general, an empty row) against the dense product."""
+    C.check_kats3(lambda fid, zs, r: cref.mle_multi_evaluate(fid, [z.tobytes() for z in zs], len(r), r),
+                  lambda fid, ip, ix, d, cols, z: cref.spmv(fid, ip, ix, d, len(ip) - 1, z),
+                  lambda fid, ip, ix, d, cols, z1, z2: cref.spmv_pair(fid, ip, ix, d, len(ip) - 1, z1, z2))
+
+
 @pytest.mark.parametrize("fid", range(4))
 def test_oracle_eq_mle_spmv_vs_definition(fid):
     p = C.FIELDS[fid]

@@ -132,6 +132,47 @@ def test_reference_kats_eq_mle_spmv(nmx):
     C.check_kats2(lambda fid, r: fv.eq_evals_from_points(fid, r), lambda fid, z, r: fv.mle_evaluate(fid, z, r), spmv)
 
 
+def test_reference_kats_multi_evaluate_and_the_mixed_coefficient_matrix(nmx):
+    """multi_evaluate_with's known values (multilinear.rs:456-485) and the reference's mixed-coefficient SpMV fixture (sparse.rs:486-544)
+    through the C ABI: host operands and HBM-resident ones (the mailbox path of the evaluations), multiply_vec, multiply_vec_pair, the
+    many-matrix call and -- against the dense product of the transposed fixture -- the transposed product."""
+    import torch
+    from nova_amd import fieldvec as fv
+    dev = lambda x: torch.from_numpy(np.ascontiguousarray(x).copy()).cuda()
+
+    def spmv(fid, ip, ix, d, cols, z):
+        m = fv.SparseMatrix(fid, ip, ix, d, cols)
+        out = m.multiply_vec(z)
+        assert m.multiply_vec(dev(z)).cpu().numpy().tobytes() == out.tobytes()
+        assert fv.multiply_vec_many([m, m], dev(z))[1].cpu().numpy().tobytes() == out.tobytes()
+        m.close()
+        return out
+
+    def spmv_pair(fid, ip, ix, d, cols, z1, z2):
+        m = fv.SparseMatrix(fid, ip, ix, d, cols)
+        out = m.multiply_vec_pair(z1, z2)
+        m.close()
+        return out
+
+    def multi(fid, zs, r):
+        host = fv.mle_multi_evaluate(fid, zs, r)
+        assert fv.mle_multi_evaluate(fid, [dev(z) for z in zs], r) == host
+        assert [fv.mle_evaluate(fid, dev(z), r) for z in zs] == host
+        return host
+    C.check_kats3(multi, spmv, spmv_pair)
+    for fid in C.FIELDS:                                     # M^T x on the same fixture: out[c] = sum_r M[r][c] x[r] (spartan/mod.rs:506-512)
+        ip, ix, dt, cols, _z, _z2, _o, _o2 = C.mixed_coefficient_case(fid)
+        k, p = C.KATS["spmv_mixed_coefficients"], C.FIELDS[fid]
+        x = [3, 1, 4, 1, 5]
+        want = [0] * cols
+        for r, c, v in k["entries"]:
+            want[c] = (want[c] + v * x[r]) % p
+        m = fv.SparseMatrix(fid, ip, ix, dt, cols)
+        assert C.ints(m.multiply_vec_transposed(C.vec(x))) == want
+        assert C.ints(m.multiply_vec_transposed(dev(C.vec(x))).cpu().numpy()) == want
+        m.close()
+
+
 @pytest.mark.parametrize("fid", range(4))
 def test_eq_mle_spmv_vs_oracle(nmx, fid):
     import torch
