@@ -141,6 +141,7 @@ def main():
     ap.add_argument("--overlap-commits", type=int, default=0, choices=[0, 1, 2],
                     help="prove_step replay: commit(W) begun (nmx_commit_begin) beside the cross term + commit(T) it does not depend on "
                          "(1: the primary pair inside one prove_step; 2: also the secondary pair, across the step boundary)")
+    ap.add_argument("--separate-folds", action="store_true", help="hyperkzg replay: the ell - 1 pair folds as ell - 1 calls instead of nmx_poly_fold_chain")
     ap.add_argument("--separate-spmv", action="store_true", help="spartan replay: the three (transposed) products as three calls instead of nmx_spmv_apply_many")
     ap.add_argument("--sync-field-ops", action="store_true", help="prove_step replay: every field-vector call waits for its kernel (round 3's form)")
     ap.add_argument("--workload", default="msm", choices=["msm", "axpy", "cross_term", "bind", "sumcheck3", "round3", "quad_prod", "lincomb8", "horner", "mle_eval", "spmv", "prove_step_replay", "hyperkzg_replay", "spartan_replay", "compressed_snark_replay"],
@@ -1143,10 +1144,13 @@ def hyperkzg_replay(args, torch, ck=None):
     dP = torch.from_numpy(hP).cuda()
 
     def step():
-        polys, cur = [dP], dP
-        for i in range(ell - 1):   # stream-ordered: the host looks at none of the folded polynomials before they are committed
-            cur = fv.fold_pairs(fid, cur, xs[ell - i - 1], async_=not getattr(args, "sync_field_ops", False))
-            polys.append(cur)
+        if getattr(args, "separate_folds", False) or getattr(args, "sync_field_ops", False):
+            polys, cur = [dP], dP
+            for i in range(ell - 1):   # stream-ordered: the host looks at none of the folded polynomials before they are committed
+                cur = fv.fold_pairs(fid, cur, xs[ell - i - 1], async_=not getattr(args, "sync_field_ops", False))
+                polys.append(cur)
+        else:                          # the fold loop as ONE call (nmx_poly_fold_chain: the short folds inside one block)
+            polys = [dP] + fv.fold_chain(fid, dP, np.ascontiguousarray(xs[::-1][:ell - 1]), async_=True)
         coms = ce.batch_commit(ck, polys[1:])
         evals = fv.poly_eval_multi(fid, polys, us)   # the whole v matrix (hyperkzg.rs:1049-1056) in one launch
         B = fv.lincomb_powers(fid, polys, qs[0])     # B = sum_i q^i f_i (kzg_compute_batch_polynomial, hyperkzg.rs:1028-1040)
@@ -1630,6 +1634,9 @@ class GpuProvider:
     def fold_pairs(self, v, x):
         return self.fv.fold_pairs(self.fid, v, x, async_=True)
 
+    def fold_chain(self, v, xs):
+        return self.fv.fold_chain(self.fid, v, xs, async_=True)
+
     def poly_eval_multi(self, polys, us):
         return self.fv.poly_eval_multi(self.fid, polys, us)
 
@@ -1750,10 +1757,14 @@ def hyperkzg_sequence(be, ell, p, hat_P, point, tr, call):
     the v matrix (:1049-1056), q from it (:1058), B (:1059), three openings (:1062-1065; here one batch_commit of the quotients)."""
     le = lambda v: int(v).to_bytes(32, "little")
     num = lambda b: int.from_bytes(bytes(b), "little")
-    polys, cur = [hat_P], hat_P
-    for i in range(ell - 1):
-        cur = call("ee.fold_pairs", lambda c=cur, i=i: be.fold_pairs(c, point[ell - i - 1]))
-        polys.append(cur)
+    if hasattr(be, "fold_chain") and ell > 1:                                   # the whole loop :1085-1095 as one call
+        xs = b"".join(bytes(point[ell - i - 1]) for i in range(ell - 1))
+        polys = [hat_P] + list(call("ee.fold_pairs", lambda: be.fold_chain(hat_P, xs)))
+    else:
+        polys, cur = [hat_P], hat_P
+        for i in range(ell - 1):
+            cur = call("ee.fold_pairs", lambda c=cur, i=i: be.fold_pairs(c, point[ell - i - 1]))
+            polys.append(cur)
     coms = call("ee.batch_commit", lambda: be.batch_commit(polys[1:]))
     for c in coms:
         tr.absorb(c[0])

@@ -308,12 +308,16 @@ static void ee_prove(Side& s) {
   char* cur = (char*)s.chain.p;
   const void* prev = s.wj.p;
   size_t len = n;
+  std::vector<Scalar> xs;
+  std::vector<void*> fold_out;
   for (size_t i = 0; i + 1 < ell; i++) {
-    R::fold_pairs(f, prev, len, point[ell - i - 1], cur);
     len /= 2;
+    xs.push_back(point[ell - i - 1]), fold_out.push_back(cur);
     polys.push_back(cur), lens.push_back(len);
-    prev = cur, cur += len * 32;
+    cur += len * 32;
   }
+  (void)prev;
+  if (!xs.empty()) R::fold_chain(f, s.wj.p, n, xs, fold_out);  // the loop hyperkzg.rs:1085-1095 as one call
   const std::vector<provider::Point> com = R::batch_commit(*s.ck, std::vector<const void*>(polys.begin() + 1, polys.end()), std::vector<size_t>(lens.begin() + 1, lens.end()));
   for (const provider::Point& q : com) tr.absorb(q.xy.data(), 64);
   const U256 er = from_scalar(tr.squeeze());

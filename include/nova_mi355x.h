@@ -368,6 +368,12 @@ int nmx_field_concat(int field, const void* const* parts, const size_t* lens, ui
 int nmx_mle_bind_top(int field, const void* z, size_t len, const void* r, uint32_t flags, void* out);
 /* HyperKZG fold step (src/provider/hyperkzg.rs:1085-1095): out[j] = p[2j] + x*(p[2j+1] - p[2j]), j < len/2 */
 int nmx_poly_fold_pairs(int field, const void* p, size_t len, const void* x, uint32_t flags, void* out);
+/* The whole fold loop of HyperKZG's prove (src/provider/hyperkzg.rs:1085-1095) as one call (round 6): outs[0] = fold(p, xs[0]) of len / 2
+ * elements, outs[i] = fold(outs[i - 1], xs[i]) of len >> (i + 1), i < k <= log2(len); the reference runs it with k = ell - 1 and
+ * xs[i] = point[ell - i - 1].  len a power of two; xs: k x 32 bytes on the host; outs: k distinct vectors, none of them p.  With
+ * NMX_SCALARS_DEVICE the folds of more than 2048 inputs are one launch each and all the shorter ones run in ONE block (each reading
+ * its predecessor's output from LDS); NMX_ASYNC as for nmx_poly_fold_pairs.  Same results, fold by fold, as k single calls. */
+int nmx_poly_fold_chain(int field, const void* p, size_t len, const void* xs, size_t k, uint32_t flags, void* const* outs);
 
 /* The N-scaling sums of one eq-factored sum-check round (src/spartan/sumcheck.rs:900-1075), over id in [0, len/2)
  * with x0 = X[id], x1 = X[id + len/2] and factor = eqL[id >> shift] * eqR[id & (2^shift - 1)] (first-half rounds,

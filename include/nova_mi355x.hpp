@@ -402,6 +402,10 @@ inline void lincomb_powers(int field, const std::vector<const void*>& vs, const 
   check(nmx_field_lincomb_powers(field, vs.data(), lens.data(), vs.size(), s.data(), n_out, kDev, out));
 }
 inline void fold_pairs(int field, const void* p, size_t len, const Scalar& x, void* out) { check(nmx_poly_fold_pairs(field, p, len, x.data(), kAsync, out)); }
+// the fold loop of hyperkzg.rs:1085-1095 in one call: outs[i] = fold(outs[i - 1] or p, xs[i])
+inline void fold_chain(int field, const void* p, size_t len, const std::vector<Scalar>& xs, const std::vector<void*>& outs) {
+  check(nmx_poly_fold_chain(field, p, len, xs.data(), xs.size(), kAsync, outs.data()));
+}
 inline void suffix_horner(int field, const void* f, size_t n, const Scalar& u, void* out) { check(nmx_poly_suffix_horner(field, f, n, u.data(), kDev, out)); }
 inline std::vector<Scalar> poly_eval_multi(int field, const std::vector<const void*>& polys, const std::vector<size_t>& lens, const std::vector<Scalar>& pts) {
   std::vector<Scalar> out(polys.size() * pts.size());

@@ -103,6 +103,7 @@ def lib():
     L.nmx_r1cs_cross_term.argtypes = [u64, u64, u64, vp, vp, sz, vp, vp, u32, vp]
     L.nmx_nifs_fold.argtypes = [i, vp, vp, sz, vp, vp, sz, vp, u32, vp, vp]
     L.nmx_spmv_apply_pair.argtypes = [u64, vp, vp, sz, u32, vp, vp]
+    L.nmx_poly_fold_chain.argtypes = [ctypes.c_int, vp, sz, vp, sz, u32, vp]
     L.nmx_spmv_apply_many.argtypes = [vp, sz, ctypes.c_int, vp, sz, u32, vp]
     L.nmx_sumcheck_plain_sums.argtypes = [i, i, vp, vp, vp, sz, u32, vp]
     L.nmx_poly_eval_multi.argtypes = [i, vp, vp, sz, vp, sz, u32, vp]

@@ -2189,6 +2189,27 @@ int nmx_poly_fold_pairs(int field, const void* p, size_t len, const void* x, uin
   });
 }
 
+int nmx_poly_fold_chain(int field, const void* p, size_t len, const void* xs, size_t k, uint32_t flags, void* const* outs) {
+  return guarded([&] {
+    require(p && (xs || k == 0) && (outs || k == 0), NMX_E_ARG, "null argument");
+    require(field >= 0 && field < 4, NMX_E_ARG, "bad field id");
+    require(len >= 2 && (len & (len - 1)) == 0 && len < (1ull << 32), NMX_E_ARG, "len must be a power of two >= 2");
+    require(k >= 1 && (len >> k) >= 1, NMX_E_ARG, "at most log2(len) folds");
+    for (size_t i = 0; i < k; i++) require(outs[i] && outs[i] != p, NMX_E_ARG, "null output, or a fold in place");
+    if (!(flags & NMX_SCALARS_DEVICE)) {  // host vectors: fold by fold through the single-fold path
+      const void* cur = p;
+      for (size_t i = 0; i < k; i++) {
+        const int rc = nmx_poly_fold_pairs(field, cur, len >> i, (const uint8_t*)xs + 32 * i, flags, outs[i]);
+        if (rc) throw Fail{rc, nmx_last_error()};
+        cur = outs[i];
+      }
+      return;
+    }
+    CtxLease L;
+    fv_fold_chain(*L.c, field, p, len, xs, k, flags, outs);
+  });
+}
+
 int nmx_sumcheck_eq_sums(int field, int mode, const void* A, const void* B, const void* C, size_t len, const void* eqL,
                          size_t n_eqL, const void* eqR, size_t n_eqR, uint32_t shift, uint32_t flags, uint8_t* out64) {
   return guarded([&] {

@@ -1454,23 +1454,27 @@ template <int FID> static void horner_dev(Ctx& c, const uint32_t* f, uint32_t n,
 // the single-pass kernel (k_horner_scan): per-lane constants + tile states from one small launch, then the scan itself
 // -> false if a wave of the scan gave up waiting (never observed; the caller then runs the two-pass kernels)
 static constexpr uint32_t kScanSpinLimit = 1u << 22;  // polls of >= 0.5 us each: seconds, against waits of microseconds
-template <int FID> static bool horner_scan_t(Ctx& c, const void* f, size_t n, const Fp<FID>& u0, bool dev, void* out) {
+template <int FID> static bool horner_scan_t(Ctx& c, const void* f, size_t n, const Fp<FID>& u0, const HostFp4<FID>& hu, bool dev, void* out) {
   using F = Fp<FID>;
+  using H = HostFp4<FID>;
   // sub-tiles per wave: the look-backs are paid once per tile, so long inputs take 2 (from 2^21 coefficients) or 4 (from 2^22);
   // short ones keep 1: more tiles in flight (profiles/r03_fieldvec/horner_scan.txt)
   uint32_t J = G.horner_sub;
   if (J != 1 && J != 2 && J != 4) J = n >= (1u << 22) ? 4u : (n >= (1u << 21) ? 2u : 1u);
   const size_t tile = (size_t)J * kScanSub;
   const uint32_t nt = (uint32_t)((n + tile - 1) / tile), ng = (nt + kScanGroup - 1) / kScanGroup;
-  F u8 = u0;
-  for (int i = 0; i < 3; i++) u8 = u8.sqr().canon();
-  F uS = u8;
-  for (int i = 0; i < 6; i++) uS = uS.sqr().canon();
-  F uT = uS;
-  for (uint32_t q = J; q > 1; q >>= 1) uT = uT.sqr().canon();
-  F uG = uT;
-  for (int i = 0; i < 6; i++) uG = uG.sqr().canon();
-  const F v8 = u8.inv();  // u != 0 (checked by the caller)
+  // the scan's five constants: ~17 squarings and one inversion, in 4 x 64-bit host arithmetic (HostFp4; the portable build of the
+  // device form took ~10 us per call here -- three calls per HyperKZG prove)
+  H h8 = hu;
+  for (int i = 0; i < 3; i++) h8 = h8 * h8;
+  H hS = h8;
+  for (int i = 0; i < 6; i++) hS = hS * hS;
+  H hT = hS;
+  for (uint32_t q = J; q > 1; q >>= 1) hT = hT * hT;
+  H hG = hT;
+  for (int i = 0; i < 6; i++) hG = hG * hG;
+  const F u8 = h8.to_device(), uS = hS.to_device(), uT = hT.to_device(), uG = hG.to_device();
+  const F v8 = h8.inv().to_device();  // u != 0 (checked by the caller)
   const size_t nflags = (size_t)nt + 2 * (size_t)ng + 1;  // tile states, group tickets, group states, the start-order counter
   arena_reserve(c, HornerArena::pad(kScanTblN * 36) + HornerArena::pad(nflags * 4) + HornerArena::pad((size_t)nt * 36) +
                        2 * HornerArena::pad((size_t)ng * 36) + (dev ? 0 : 2 * HornerArena::pad(n * 32)) + 256);
@@ -1526,7 +1530,8 @@ static void horner_t(Ctx& c, const void* f, size_t n, const void* u, uint32_t fl
   if (n >= kScanMin && n < (1ull << 32) && G.horner_top == 0) {
     const F us = challenge<FID>(u, flags & NMX_SCALARS_MONT);
     if (!us.is_zero_limbs()) {  // u = 0: out = f, left to the chunk kernels below
-      if (horner_scan_t<FID>(c, f, n, us, dev, out)) return;
+      const HostFp4<FID> hu = (flags & NMX_SCALARS_MONT) ? HostFp4<FID>::from_mont256(u) : HostFp4<FID>::from_canonical(u);
+      if (horner_scan_t<FID>(c, f, n, us, hu, dev, out)) return;
     }
   }
 
@@ -1839,6 +1844,90 @@ void fv_cross_term2(Ctx& c, int field, const void* az, const void* bz, const voi
 void fv_vec_add(Ctx& c, int field, const void* a, const void* b, size_t n, uint32_t flags, void* out) {
   FIELD_SWITCH(field, vec_add(c, a, b, n, flags, out));
 }
+// ---- HyperKZG's fold loop as one call (round 6) ---------------------------------------------------------------------------
+// `for i in 0..ell-1 { Pi[j] = x[ell-i-1] * (P[2j+1] - P[2j]) + P[2j] }` (src/provider/hyperkzg.rs:1085-1095): ell - 1 folds, each
+// half as long as the one before -- as separate calls 19 launches at 2^20, of which the last dozen move a few KiB each and cost a
+// launch (~10 us of queue time, ~5 us of host time) apiece.  Folds of more than kFoldChainLen inputs stay one launch each
+// (BindTopFn); the rest run in ONE block: the first reads its input from HBM, every later one reads the previous output from
+// LDS; every output is also written to its own HBM vector (they are what batch_commit commits to).
+static constexpr uint32_t kFoldChainLen = 2048, kFoldChainMax = 12;
+template <int FID> struct FoldChainArgs {
+  const uint32_t* in;
+  uint32_t* out[kFoldChainMax];
+  Fp<FID> x[kFoldChainMax];  // challenges, internal form
+  uint32_t len, k;           // input length (<= kFoldChainLen, even), folds (len >> k >= 1)
+};
+template <int FID> __global__ __launch_bounds__(1024) void k_fold_chain(FoldChainArgs<FID> a) {
+  using F = Fp<FID>;
+  constexpr uint32_t N0 = kFoldChainLen / 2, N1 = kFoldChainLen / 4;
+  __shared__ uint32_t buf0[8 * N0], buf1[8 * N1];  // [word][element]: outputs of the even / odd folds
+  const uint32_t t = threadIdx.x;
+  uint32_t n_out = a.len >> 1;
+  for (uint32_t i = 0; i < a.k; i++, n_out >>= 1) {
+    uint32_t* dst = (i & 1u) ? buf1 : buf0;
+    const uint32_t* src = (i & 1u) ? buf0 : buf1;
+    const uint32_t dn = (i & 1u) ? N1 : N0, sn = (i & 1u) ? N0 : N1;
+    for (uint32_t j = t; j < n_out; j += 1024u) {
+      F lo, hi;
+      if (i == 0) {
+        lo = ld<FID>(a.in, 2 * (size_t)j), hi = ld<FID>(a.in, 2 * (size_t)j + 1);
+      } else {
+        uint32_t wl[8], wh[8];
+#pragma unroll
+        for (int w = 0; w < 8; w++) wl[w] = src[w * sn + 2 * j], wh[w] = src[w * sn + 2 * j + 1];
+        lo = F::from_words(wl), hi = F::from_words(wh);
+      }
+      const F y = (lo + a.x[i] * F::sub2(hi, lo).norm()).norm().canon();
+      uint32_t w8[8];
+      y.to_words(w8);
+#pragma unroll
+      for (int w = 0; w < 8; w++) {
+        a.out[i][8 * (size_t)j + w] = w8[w];
+        if (i + 1 < a.k) dst[w * dn + j] = w8[w];
+      }
+    }
+    __syncthreads();
+  }
+}
+template <int FID>
+static void fold_chain_t(Ctx& c, const void* p, size_t len, const void* xs, size_t k, uint32_t flags, void* const* outs) {
+  using F = Fp<FID>;
+  const bool mont = flags & NMX_SCALARS_MONT, async = (flags & NMX_ASYNC) != 0;
+  DeviceBackend be(c, false, false);
+  const uint32_t* cur = (const uint32_t*)p;
+  size_t cur_len = len, i = 0;
+  for (; i < k && cur_len > kFoldChainLen; i++, cur_len /= 2) {
+    BindTopFn<FID> f{cur, cur + 8, (uint32_t*)outs[i], challenge<FID>((const uint8_t*)xs + 32 * i, mont), 2u};
+    be.launch(f, (uint32_t)(cur_len / 2));
+    cur = (const uint32_t*)outs[i];
+  }
+  if (i < k) {
+    FoldChainArgs<FID> a;
+    a.in = cur, a.len = (uint32_t)cur_len, a.k = (uint32_t)(k - i);
+    require(a.k <= kFoldChainMax, NMX_E_ARG, "fold chain: more folds than the input has halvings");
+    for (uint32_t q = 0; q < kFoldChainMax; q++) {
+      a.out[q] = q < a.k ? (uint32_t*)outs[i + q] : nullptr;
+      a.x[q] = q < a.k ? challenge<FID>((const uint8_t*)xs + 32 * (i + q), mont) : F::zero();
+    }
+    hipLaunchKernelGGL((k_fold_chain<FID>), dim3(1), dim3(1024), 0, c.stream, a);
+    HIPCHK(hipGetLastError());
+  }
+  if (async) {
+    async_mark(c);
+    return;
+  }
+  stream_wait(c.stream);
+}
+void fv_fold_chain(Ctx& c, int field, const void* p, size_t len, const void* xs, size_t k, uint32_t flags, void* const* outs) {
+  switch (field) {
+    case 0: fold_chain_t<0>(c, p, len, xs, k, flags, outs); break;
+    case 1: fold_chain_t<1>(c, p, len, xs, k, flags, outs); break;
+    case 2: fold_chain_t<2>(c, p, len, xs, k, flags, outs); break;
+    case 3: fold_chain_t<3>(c, p, len, xs, k, flags, outs); break;
+    default: throw Fail{NMX_E_ARG, "bad field id"};
+  }
+}
+
 void fv_bind(Ctx& c, int field, const void* z, size_t z_len, size_t lo_off, size_t hi_off, size_t stride,
              const void* r, size_t n_out, uint32_t flags, void* out) {
   FIELD_SWITCH(field, bind(c, z, z_len, lo_off, hi_off, stride, r, n_out, flags, out));

@@ -728,6 +728,7 @@ void fv_eval_multi(Ctx&, int field, const void* const* polys, const size_t* lens
 void fv_bind_eq_sums(Ctx&, int field, int mode, const void* A, const void* B, const void* C, size_t len, const void* r,
                      const void* eqL, size_t nL, const void* eqR, size_t nR, uint32_t shift, uint32_t flags, void* oA,
                      void* oB, void* oC, uint8_t* out);  // sumcheck.hip
+void fv_fold_chain(Ctx&, int field, const void* p, size_t len, const void* xs, size_t k, uint32_t flags, void* const* outs);  // fieldvec.hip
 struct SpmvManyItem {  // one matrix of nmx_spmv_apply_many (fieldvec.hip spmv_many_t)
   const uint32_t *indptr = nullptr, *indices = nullptr, *data = nullptr;                                                  // CSR (forward)
   const uint32_t *vptr = nullptr, *tix = nullptr, *tdata = nullptr, *vout = nullptr, *hrow = nullptr, *hstart = nullptr;  // M^T in virtual rows

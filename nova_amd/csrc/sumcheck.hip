@@ -14,6 +14,7 @@
 // second one-block launch.  Vectors are processed in the form they arrive in (canonical or R = 2^256 Montgomery):
 // every term carries the same power of the form factor, fixed by one constant multiplication on the host.
 #include "runtime.hpp"
+#include "host_fp4.hpp"
 
 namespace nmx {
 
@@ -642,34 +643,46 @@ static void eval_multi_t(Ctx& c, const void* const* polys, const size_t* lens, s
       desc[i].f = (const uint32_t*)d;
     }
   }
-  // tables on the host: a few hundred multiplications per point
+  // tables on the host: ~280 multiplications per point, in 4 x 64-bit Montgomery arithmetic (HostFp4: ~25 ns a product; the
+  // portable build of the device's 9 x 29-bit form costs ~250 ns -- 0.2 ms of table building in front of a 30-60 us kernel,
+  // which is what a HyperKZG prove's evaluation matrix cost until round 6)
+  using H = HostFp4<FID>;
   std::vector<uint32_t> hpts(8 * m), h16(8 * 256 * m), h4096(8 * 20 * m);
   for (size_t j = 0; j < m; j++) {
-    const F u = challenge_internal<FID>((const uint8_t*)points + 32 * j, mont);
-    u.to_words(hpts.data() + 8 * j);
-    F u16 = u;
-    for (int q = 0; q < 4; q++) u16 = u16.sqr().canon();   // u^16
-    F pw = F::one();
+    const uint8_t* pj = (const uint8_t*)points + 32 * j;
+    (void)challenge_internal<FID>(pj, mont);               // (the range check: a point >= p is NMX_E_SCALAR_RANGE)
+    const H u = mont ? H::from_mont256(pj) : H::from_canonical(pj);
+    u.to_device().to_words(hpts.data() + 8 * j);
+    H u16 = u;
+    for (int q = 0; q < 4; q++) u16 = u16 * u16;           // u^16
+    H pw = H::one();
     for (int t = 0; t < 256; t++) {
-      pw.canon().to_words(h16.data() + 8 * (j * 256 + t));
-      pw = (pw * u16).canon();
+      pw.to_device().to_words(h16.data() + 8 * (j * 256 + t));
+      pw = pw * u16;
     }
-    F big = pw;  // u^(16 * 256) = u^4096
+    H big = pw;  // u^(16 * 256) = u^4096
     for (int sft = 0; sft < 20; sft++) {
-      big.canon().to_words(h4096.data() + 8 * (j * 20 + sft));
-      big = big.sqr().canon();
+      big.to_device().to_words(h4096.data() + 8 * (j * 20 + sft));
+      big = big * big;
     }
   }
-  EvalPoly* d_desc = (EvalPoly*)take(k * sizeof(EvalPoly));
-  uint32_t* d_pts = (uint32_t*)take(m * 32);
-  uint32_t* d_16 = (uint32_t*)take(m * 256 * 32);
-  uint32_t* d_4096 = (uint32_t*)take(m * 20 * 32);
+  // descriptors and the three tables travel as ONE host-to-device copy (they sit back to back in the arena; four copies from
+  // pageable memory were four staged transfers of 10-20 us each in front of a 30 us kernel)
+  const size_t o_desc = 0, o_pts = o_desc + pad(k * sizeof(EvalPoly)), o_16 = o_pts + pad(m * 32), o_4096 = o_16 + pad(m * 256 * 32),
+               up_bytes = o_4096 + pad(m * 20 * 32);
+  char* d_up = take(up_bytes);
+  EvalPoly* d_desc = (EvalPoly*)(d_up + o_desc);
+  uint32_t* d_pts = (uint32_t*)(d_up + o_pts);
+  uint32_t* d_16 = (uint32_t*)(d_up + o_16);
+  uint32_t* d_4096 = (uint32_t*)(d_up + o_4096);
   uint32_t* d_part = (uint32_t*)take((size_t)blocks * kEvalMaxPts * 32);
   uint32_t* d_out = (uint32_t*)take(k * m * 32);
-  HIPCHK(hipMemcpyAsync(d_desc, desc.data(), k * sizeof(EvalPoly), hipMemcpyHostToDevice, c.stream));
-  HIPCHK(hipMemcpyAsync(d_pts, hpts.data(), m * 32, hipMemcpyHostToDevice, c.stream));
-  HIPCHK(hipMemcpyAsync(d_16, h16.data(), m * 256 * 32, hipMemcpyHostToDevice, c.stream));
-  HIPCHK(hipMemcpyAsync(d_4096, h4096.data(), m * 20 * 32, hipMemcpyHostToDevice, c.stream));
+  std::vector<char> up(up_bytes, 0);
+  memcpy(up.data() + o_desc, desc.data(), k * sizeof(EvalPoly));
+  memcpy(up.data() + o_pts, hpts.data(), m * 32);
+  memcpy(up.data() + o_16, h16.data(), m * 256 * 32);
+  memcpy(up.data() + o_4096, h4096.data(), m * 20 * 32);
+  HIPCHK(hipMemcpyAsync(d_up, up.data(), up_bytes, hipMemcpyHostToDevice, c.stream));
   const bool prof = G.profiling;
   DeviceBackend be(c, false, prof);
   be.mark("k");

@@ -156,6 +156,19 @@ def fold_pairs(field, p, x, mont=False, async_=False):
     return out
 
 
+def fold_chain(field, p, xs, mont=False, async_=False):
+    """nmx_poly_fold_chain: HyperKZG's fold loop (hyperkzg.rs:1085-1095) in one call -- [fold(p, xs[0]), fold(that, xs[1]), ...]."""
+    import ctypes
+    pp, n, dev, _kp = _vec(p)
+    xx = _host_u8(xs, 32)
+    k = xx.size // 32
+    assert n >= 2 and n & (n - 1) == 0 and (n >> k) >= 1
+    outs = [_out_like(dev, n >> (i + 1), p) for i in range(k)]
+    ptrs = (ctypes.c_void_p * k)(*[o[0] for o in outs])
+    _check(L.lib().nmx_poly_fold_chain(field, pp, n, xx.ctypes.data, k, _flags(dev, mont, async_), ptrs))
+    return [o[1] for o in outs]
+
+
 def sumcheck_eq_sums(field, mode, A, B, C, eq_right, eq_left=None, shift=0, mont=False):
     """(t_0, t_inf) of EqSumCheckInstance::evaluation_points_{quadratic_with_one_input (mode 1),
     cubic_with_two_inputs (2), cubic_with_three_inputs (3)} (src/spartan/sumcheck.rs:900-1075) as two 32-byte field

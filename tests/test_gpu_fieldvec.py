@@ -686,3 +686,33 @@ def test_batch_invert_rejects_in_place(nmx):
     v = torch.from_numpy(_nonzero(1, 64, 1).copy()).cuda()
     rc = L.lib().nmx_field_batch_invert(1, v.data_ptr(), 64, L.SCALARS_DEVICE, v.data_ptr())
     assert rc == L.E_ARG
+
+
+@pytest.mark.parametrize("fid", range(4))
+def test_fold_chain_equals_fold_by_fold(nmx, fid):
+    """nmx_poly_fold_chain (the loop of hyperkzg.rs:1085-1095 as one call: long folds one launch each, the folds of <= 2048 inputs inside
+    one block through LDS) against the oracle's pair fold applied fold by fold -- lengths on both sides of the 2048-input switch, the
+    full chain down to 2 elements and a partial one, HBM-resident (synchronous and stream-ordered) and host operands, and the reference's
+    known answers (tests/golden/field_kats.json hyperkzg_fold_eval) through the chain."""
+    import torch
+    from nova_amd import fieldvec as fv
+    for ell, k in ((1, 1), (2, 1), (2, 2), (6, 5), (11, 10), (12, 11), (13, 12), (13, 4), (15, 14), (16, 3)):
+        n = 1 << ell
+        P = C.edge_vectors(fid, n, 70 + ell)
+        xs = C.rand_vec(fid, k, 71 + ell)
+        want, cur = [], P
+        for i in range(k):
+            m = len(cur) // 2
+            cur = np.frombuffer(cref.field_bind(fid, cur, 0, 1, 2, xs[i:i + 1], m), np.uint8).reshape(m, 32)
+            want.append(cur.tobytes())
+        d = torch.from_numpy(P.copy()).cuda()
+        assert [o.cpu().numpy().tobytes() for o in fv.fold_chain(fid, d, xs)] == want
+        outs = fv.fold_chain(fid, d, xs, async_=True)
+        fv.sync()
+        assert [o.cpu().numpy().tobytes() for o in outs] == want
+        assert [o.tobytes() for o in fv.fold_chain(fid, P, xs)] == want                   # host vectors
+        assert d.cpu().numpy().tobytes() == P.tobytes()                                    # the input is left alone
+    for case in C.KATS["hyperkzg_fold_eval"]["cases"]:                                     # evaluation = the chain's last element
+        poly, pt = C.vec(case["poly"]), C.vec(list(reversed(case["point"])))
+        out = fv.fold_chain(fid, torch.from_numpy(poly.copy()).cuda(), pt)
+        assert C.ints(out[-1].cpu().numpy()) == [case["eval"]]
