@@ -42,3 +42,18 @@ def test_cpp_mirror_on_gpu(tmp_path):
         (tmp_path / f"curve{c.cid}.key").write_bytes(K.write_pedersen_key(c, pts[100], pts))
     r = subprocess.run([b], capture_output=True, text=True, env=dict(os.environ, NMX_TEST_KEYDIR=str(tmp_path)))
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+
+
+def test_cpp_chained_replay_driver_builds_and_refuses_without_gpu(tmp_path):
+    """bench/csnark_replay.cpp (the chained CompressedSNARK::prove replay through include/nova_mi355x.hpp's `resident` functions) compiles
+    with g++ against the product library and, like everything in the product path, stops with NMX_E_NO_DEVICE when there is no GPU
+    (exit 3) -- no CPU fall-back.  On the GPU box it is exercised by tests/test_gpu_large.py::test_compressed_snark_replay_matches_oracle."""
+    import bench
+    from nova_amd import _lib
+    b = bench.build_cpp_driver()
+    assert os.path.exists(b)
+    if _lib.lib().nmx_device_count() > 0:
+        pytest.skip("a HIP device is visible")
+    r = subprocess.run([b, os.devnull, str(tmp_path / "out.bin"), "1", "0"], capture_output=True, text=True)
+    assert r.returncode == 3, (r.returncode, r.stderr)
+    assert "no HIP device" in r.stderr

@@ -583,3 +583,47 @@ def test_three_products_in_one_call(nmx, fid):
     assert [o.tobytes() for o in fv.multiply_vec_many(mats, x, transposed=True)] == want_t
     for m in mats:
         m.close()
+
+
+def test_evaluations_and_many_products_from_several_threads(nmx):
+    """Round 6's mailbox evaluations (more polynomials than mailbox slots in one call) and the many-matrix product from four host threads
+    at once, beside a prover: every call leases its own context (mailbox, side streams); results equal the single-threaded ones."""
+    import threading
+    import torch
+    from nova_amd import fieldvec as fv
+    fid, ell = 1, 12
+    n = 1 << ell
+    zs = [fc.edge_vectors(fid, n, 300 + i) for i in range(19)]           # 19 > 16 mailbox slots: two passes inside one call
+    r = fc.rand_vec(fid, ell, 320)
+    want_ev = cref.mle_multi_evaluate(fid, [z.tobytes() for z in zs], ell, r)
+    dz = [dev(z) for z in zs]
+    assert fv.mle_multi_evaluate(fid, dz, r) == want_ev
+    csr = [sp.heavy_column_csr(fid, 3000, 2000, 330 + j, heavy_cols=(0,)) for j in range(3)]
+    mats = [fv.SparseMatrix(fid, ip, ix, dt, 2000) for ip, ix, dt in csr]
+    x = fc.edge_vectors(fid, 3000, 340)
+    want_t = [cref.spmv_transposed(fid, ip, ix, dt, 3000, 2000, x) for ip, ix, dt in csr]
+    dx = dev(x)
+    want_q = sp.check_quad_prod(o_quad, fid, 13, seed=350)
+    errs = []
+
+    def work(i):
+        try:
+            for _ in range(6):
+                if i == 0:
+                    assert fv.mle_multi_evaluate(fid, dz, r) == want_ev
+                elif i == 1:
+                    assert [o.cpu().numpy().tobytes() for o in fv.multiply_vec_many(mats, dx, transposed=True)] == want_t
+                elif i == 2:
+                    assert [fv.mle_evaluate(fid, z, r) for z in dz[:5]] == want_ev[:5]
+                else:
+                    assert sp.check_quad_prod(g_quad, fid, 13, seed=350) == want_q
+        except Exception as e:   # noqa: BLE001 -- reported by the main thread
+            errs.append((i, repr(e)))
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    for m in mats:
+        m.close()
