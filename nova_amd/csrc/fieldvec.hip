@@ -1896,6 +1896,7 @@ static void fold_chain_t(Ctx& c, const void* p, size_t len, const void* xs, size
   DeviceBackend be(c, false, false);
   const uint32_t* cur = (const uint32_t*)p;
   size_t cur_len = len, i = 0;
+  try {
   for (; i < k && cur_len > kFoldChainLen; i++, cur_len /= 2) {
     BindTopFn<FID> f{cur, cur + 8, (uint32_t*)outs[i], challenge<FID>((const uint8_t*)xs + 32 * i, mont), 2u};
     be.launch(f, (uint32_t)(cur_len / 2));
@@ -1911,6 +1912,10 @@ static void fold_chain_t(Ctx& c, const void* p, size_t len, const void* xs, size
     }
     hipLaunchKernelGGL((k_fold_chain<FID>), dim3(1), dim3(1024), 0, c.stream, a);
     HIPCHK(hipGetLastError());
+  }
+  } catch (...) {
+    (void)hipStreamSynchronize(c.stream);  // (a challenge out of range, a failed launch: nothing of this call still writes into outs)
+    throw;
   }
   if (async) {
     async_mark(c);
