@@ -716,3 +716,52 @@ def test_fold_chain_equals_fold_by_fold(nmx, fid):
         poly, pt = C.vec(case["poly"]), C.vec(list(reversed(case["point"])))
         out = fv.fold_chain(fid, torch.from_numpy(poly.copy()).cuda(), pt)
         assert C.ints(out[-1].cpu().numpy()) == [case["eval"]]
+
+
+@pytest.mark.parametrize("fid", [1, 2])
+def test_montgomery_layout_through_the_round6_paths(nmx, fid):
+    """halo2curves' in-memory layout (R = 2^256 Montgomery limbs, NMX_SCALARS_MONT) through the entry points and code paths round 6 added:
+    evaluations of HBM-resident polynomials (the mailbox path), the fold chain, the many-matrix product (forward and transposed), the
+    suffix Horner scan with its host-built constants, the evaluation matrix with its host-built tables -- each equal to the canonical
+    computation converted in and out."""
+    import torch
+    from nova_amd import fieldvec as fv
+    p = C.FIELDS[fid]
+    Rm = 1 << 256
+    to_m = lambda v: C.vec([x * Rm % p for x in C.ints(v)])
+    un_m = lambda b: b"".join(int(x * pow(Rm, -1, p) % p).to_bytes(32, "little") for x in C.ints(np.frombuffer(bytes(b), np.uint8)))
+    dev = lambda v: torch.from_numpy(np.ascontiguousarray(v).copy()).cuda()
+    ell = 11
+    n = 1 << ell
+    zs = [C.edge_vectors(fid, n, 400 + i) for i in range(3)]
+    r = C.rand_vec(fid, ell, 410)
+    want = cref.mle_multi_evaluate(fid, [z.tobytes() for z in zs], ell, r)
+    got = fv.mle_multi_evaluate(fid, [dev(to_m(z)) for z in zs], to_m(r), mont=True)
+    assert [un_m(g) for g in got] == want
+    assert un_m(fv.mle_evaluate(fid, dev(to_m(zs[0])), to_m(r), mont=True)) == want[0]
+    # fold chain: 2^13 -> 2 (across the one-block switch)
+    P = C.edge_vectors(fid, 1 << 13, 420)
+    xs = C.rand_vec(fid, 12, 421)
+    cur, want_f = P, []
+    for i in range(12):
+        m = len(cur) // 2
+        cur = np.frombuffer(cref.field_bind(fid, cur, 0, 1, 2, xs[i:i + 1], m), np.uint8).reshape(m, 32)
+        want_f.append(cur.tobytes())
+    assert [un_m(o.cpu().numpy().tobytes()) for o in fv.fold_chain(fid, dev(to_m(P)), to_m(xs), mont=True)] == want_f
+    # the many-matrix product, both directions (matrix registered from Montgomery coefficients)
+    ip, ix, dt = C.random_csr(fid, 700, 500, 430)
+    mats = [fv.SparseMatrix(fid, ip, ix, to_m(dt), 500, mont=True) for _ in range(2)]
+    z, x = C.edge_vectors(fid, 500, 431), C.edge_vectors(fid, 700, 432)
+    assert [un_m(o.cpu().numpy().tobytes()) for o in fv.multiply_vec_many(mats, dev(to_m(z)), mont=True)] == [cref.spmv(fid, ip, ix, dt, 700, z)] * 2
+    got_t = [un_m(o.cpu().numpy().tobytes()) for o in fv.multiply_vec_many(mats, dev(to_m(x)), transposed=True, mont=True)]
+    assert got_t == [cref.spmv_transposed(fid, ip, ix, dt, 700, 500, x)] * 2
+    for m_ in mats:
+        m_.close()
+    # suffix Horner (single-pass scan from 1024 coefficients on) and the evaluation matrix
+    f = C.edge_vectors(fid, 40000, 440)
+    u = C.rand_vec(fid, 1, 441)
+    assert un_m(fv.suffix_horner(fid, dev(to_m(f)), to_m(u), mont=True).cpu().numpy().tobytes()) == cref.suffix_horner(fid, f, 40000, u)
+    polys = [C.edge_vectors(fid, m_, 450 + m_) for m_ in (40000, 4097, 2)]
+    pts = C.rand_vec(fid, 3, 451)
+    got = fv.poly_eval_multi(fid, [dev(to_m(q)) for q in polys], to_m(pts), mont=True)
+    assert [[un_m(v) for v in row] for row in got] == [[cref.suffix_horner(fid, q, len(q), pts[j:j + 1])[:32] for j in range(3)] for q in polys]
