@@ -141,6 +141,7 @@ def main():
     ap.add_argument("--overlap-commits", type=int, default=0, choices=[0, 1, 2],
                     help="prove_step replay: commit(W) begun (nmx_commit_begin) beside the cross term + commit(T) it does not depend on "
                          "(1: the primary pair inside one prove_step; 2: also the secondary pair, across the step boundary)")
+    ap.add_argument("--serial-snarks", action="store_true", help="compressed_snark_replay: S1::prove and S2::prove one after the other instead of side by side (rayon::join)")
     ap.add_argument("--separate-folds", action="store_true", help="hyperkzg replay: the ell - 1 pair folds as ell - 1 calls instead of nmx_poly_fold_chain")
     ap.add_argument("--separate-spmv", action="store_true", help="spartan replay: the three (transposed) products as three calls instead of nmx_spmv_apply_many")
     ap.add_argument("--sync-field-ops", action="store_true", help="prove_step replay: every field-vector call waits for its kernel (round 3's form)")
@@ -873,7 +874,7 @@ def extras(out, args, torch, L, ck, host_scalars, dev_scalars):
                                              "gpu_matches_cpu": cs["cpu_baseline"]["gpu_matches_cpu"], "groups_ms": cs["groups_ms"],
                                              "breakdown_ms": cs["breakdown_ms"], "proof_verifies": all(cs["proof_verifies"].values()),
                                              "trait_only": {k: v for k, v in cs["trait_only"].items() if k != "per_call_ms"},
-                                             "cpp_driver": {k: v for k, v in (cs.get("cpp_driver") or {}).items() if k != "what"},
+                                             "cpp_driver": {k: v for k, v in (cs.get("cpp_driver") or {}).items() if k not in ("what", "per_step_ms")},
                                              "what": cs["config"]["workload"]}
     except Exception as e:                                 # never lose the headline to an auxiliary block
         out["compressed_snark_replay_ms"] = {"error": repr(e)}
@@ -1779,7 +1780,7 @@ def hyperkzg_sequence(be, ell, p, hat_P, point, tr, call):
     return {"com": coms, "v": evals, "w": opens}
 
 
-def compressed_snark_sequence(beP, beS, sideP, sideS, call=lambda name, fn: fn()):
+def compressed_snark_sequence(beP, beS, sideP, sideS, call=lambda name, fn: fn(), parallel_snarks=False):
     """The provider-side work of CompressedSNARK::prove (src/nova/mod.rs:793-881) in the reference's order:
       secondary: sample_random_instance_witness + NIFSRelaxed::prove          (:812-826)
       primary:   sample_random_instance_witness + NIFSRelaxed::prove          (:829-843)
@@ -1787,19 +1788,40 @@ def compressed_snark_sequence(beP, beS, sideP, sideS, call=lambda name, fn: fn()
                  witness W + c E (spartan/mod.rs:429) is the polynomial EE::prove folds and opens (snark.rs:236-244)
       S2::prove on the secondary: the sum-check sequence (its evaluation argument is IPA, src/provider/ipa_pc.rs -- not replayed)
     NOT replayed: NIFS::prove of (:797-809) -- the prove_step replay's secondary fold --, the RO / Keccak transcripts (one stand-in
-    per SNARK and one per fold), derandomize (:846-861: two scalar products of h per side), S1 || S2 (rayon::join: serial here)."""
+    per SNARK and one per fold), derandomize (:846-861: two scalar products of h per side).  parallel_snarks: S1::prove and S2::prove side
+    by side on two host threads, as the reference's `rayon::join` at :862-881 runs them (every provider call leases its own context and
+    stream); False: one after the other (the oracle's leg: its OpenMP loops already use every core)."""
     from tests import standin
     cp = lambda tag: (lambda nm, fn: call(f"{tag}.{nm}", fn))      # spans are kept per side: P = primary, S = secondary
     out = {}
     for tag, be, side in (("S", beS, sideS), ("P", beP, sideP)):
         out[f"fold_{tag}"] = relaxed_fold_sequence(be, side, standin.Transcript(seed=SPARTAN_SEED + 1), cp(tag))
-    for tag, be, side in (("P", beP, sideP), ("S", beS, sideS)):
+    def snark(tag, be, side):
         f = out[f"fold_{tag}"]
         tr = standin.Transcript(seed=SPARTAN_SEED)
         sp = spartan_sequence(be, side.ell, side.p, f["u"], cp(tag), inst=(f["W"], f["E"], f["X"]), tr=tr)
         out[f"spartan_{tag}"] = sp
         if tag == "P":                                            # snark.rs:236-244: batched_w.p, batched_u.x = the batch sum-check's r
             out["ee_P"] = hyperkzg_sequence(be, side.ell, side.p, sp["batch_witness"], sp["batch"][1], tr, cp(tag))
+    if not parallel_snarks:
+        snark("P", beP, sideP)
+        snark("S", beS, sideS)
+        return out
+    failed = []
+
+    def second():
+        try:
+            snark("S", beS, sideS)
+        except Exception as e:   # noqa: BLE001 -- re-raised on the calling thread
+            failed.append(e)
+    t = threading.Thread(target=second)
+    t.start()
+    try:
+        snark("P", beP, sideP)
+    finally:
+        t.join()
+    if failed:
+        raise failed[0]
     return out
 
 
@@ -1844,7 +1866,8 @@ def compressed_snark_replay(args, torch):
         spans.setdefault(name, []).append(time.perf_counter() - t)
         return v
 
-    run = lambda: compressed_snark_sequence(gpu["P"], gpu["S"], sides["P"], sides["S"], call)
+    par = not getattr(args, "serial_snarks", False)
+    run = lambda: compressed_snark_sequence(gpu["P"], gpu["S"], sides["P"], sides["S"], call, parallel_snarks=par)
     for _ in range(args.warmup):
         run()
     torch.cuda.synchronize()
@@ -1878,7 +1901,9 @@ def compressed_snark_replay(args, torch):
         "config": {"workload": f"CompressedSNARK::prove replay ({nova_amd.CURVE_NAMES[cP]} primary 2^{ellP}, {nova_amd.CURVE_NAMES[cS]} secondary 2^{ellS}): per side "
                                "random instance (3 SpMV + 2 commitments) + relaxed fold (3 SpMV, five-input cross term, commit T, two folds); Spartan "
                                "sum-check sequence on both folded instances; HyperKZG EE::prove on the primary's batched witness where it lies in HBM "
-                               "(BASELINE.json configs[4]); stand-in transcripts; no IPA argument on the secondary"},
+                               "(BASELINE.json configs[4]); stand-in transcripts; no IPA argument on the secondary; S1 and S2 "
+                               + ("side by side on two host threads (rayon::join, nova/mod.rs:862-881)" if par else "one after the other"),
+                   "parallel_snarks": par},
         "roofline": None, "breakdown_ms": breakdown, "groups_ms": groups, "proof_verifies": verifies,
     }
     if not args.no_cpu_baseline:
@@ -1904,7 +1929,7 @@ def compressed_snark_replay(args, torch):
                 gpu[k].close()
                 cks[k].close()
             gpu = {}
-            outj["cpp_driver"] = cpp_chained_replay(sides, exp, {k: cpu[k].host for k in cpu}, args.steps, args.warmup)
+            outj["cpp_driver"] = cpp_chained_replay(sides, exp, {k: cpu[k].host for k in cpu}, args.steps, args.warmup, serial_snarks=not par)
     for k in gpu:
         gpu[k].close()
         cks[k].close()
@@ -1926,7 +1951,7 @@ def build_cpp_driver(force=False):
     if force or not os.path.exists(CPP_DRIVER_BIN) or os.path.getmtime(CPP_DRIVER_BIN) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", CPP_DRIVER_BIN, CPP_DRIVER_SRC,
                                "-L" + os.path.join(ROOT, "nova_amd"), "-lnova_mi355x", "-L" + os.path.join(ROOT, "tests", "standin"),
-                               "-lstandin_transcript", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,$ORIGIN/../nova_amd",
+                               "-lstandin_transcript", "-L/opt/rocm/lib", "-lamdhip64", "-lpthread", "-Wl,-rpath,$ORIGIN/../nova_amd",
                                "-Wl,-rpath,$ORIGIN/../tests/standin", "-Wl,-rpath,/opt/rocm/lib"])
     return CPP_DRIVER_BIN
 
@@ -1956,7 +1981,7 @@ def _read_records(path):
     return out
 
 
-def cpp_chained_replay(sides, exp, cpu_host, steps, warmup, k0=7):
+def cpp_chained_replay(sides, exp, cpu_host, steps, warmup, k0=7, serial_snarks=False):
     """The same chained sequence driven from C++ (bench/csnark_replay.cpp through include/nova_mi355x.hpp) on the same instance: its
     wall time per sequence, and every output compared with the oracle's run `exp` (csnark_digest)."""
     import struct
@@ -1974,7 +1999,8 @@ def cpp_chained_replay(sides, exp, cpu_host, steps, warmup, k0=7):
     with tempfile.TemporaryDirectory() as td:
         fin, fout = os.path.join(td, "instance.bin"), os.path.join(td, "out.bin")
         _write_records(fin, recs)
-        r = subprocess.run([build_cpp_driver(), fin, fout, str(steps), str(warmup)], capture_output=True, text=True)
+        # (at least three untimed sequences: contexts the worker threads lease for the first time still grow their workspaces then)
+        r = subprocess.run([build_cpp_driver(), fin, fout, str(steps), str(max(warmup, 3)), "1" if serial_snarks else "0"], capture_output=True, text=True)
         if r.returncode != 0:
             return {"error": f"rc {r.returncode}: {r.stderr[-300:]}"}
         got = _read_records(fout)
@@ -2003,7 +2029,9 @@ def cpp_chained_replay(sides, exp, cpu_host, steps, warmup, k0=7):
         return int(x) if isinstance(x, (int, np.integer)) else x
     checks = {k: plain(dg[k]) == plain(de[k]) for k in de}
     grp = struct.unpack("<5d", got["ms_per_group"])
+    per_step = struct.unpack(f"<{len(got['ms_per_step']) // 8}d", got["ms_per_step"])
     return {"ms": round(struct.unpack("<d", got["ms_per_sequence"])[0], 4), "steps": steps, "gpu_matches_cpu": all(checks.values()),
+            "median_ms": round(float(np.median(per_step)), 4), "per_step_ms": [round(x, 3) for x in per_step],
             "groups_ms": dict(zip(("S.fold", "P.fold", "P.spartan", "P.ee", "S.spartan"), (round(g, 4) for g in grp))),
             "failed": [k for k, ok in checks.items() if not ok],
             "what": "bench/csnark_replay.cpp: the same provider calls in the same order through include/nova_mi355x.hpp (namespace resident), "

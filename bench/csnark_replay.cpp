@@ -4,7 +4,7 @@
 // instance (matrices, running instance, the sampled randomness, blinds) to a file, runs this program, reads back every commitment,
 // round polynomial, evaluation and the batched witnesses, and compares them with the oracle's run: this program only TIMES and
 // REPORTS -- the checker stays where it is.
-//   csnark_replay <instance file> <output file> <steps> <warmup>
+//   csnark_replay <instance file> <output file> <steps> <warmup> [serial_snarks]
 // File format (both ways): records  u32 name_len | name | u64 bytes | data.
 #include <hip/hip_runtime_api.h>
 
@@ -12,8 +12,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <map>
 #include <string>
+#include <thread>
 
 #include "../include/nova_mi355x.hpp"
 
@@ -345,6 +347,7 @@ int main(int argc, char** argv) {
     return 2;
   }
   const int steps = atoi(argv[3]), warmup = atoi(argv[4]);
+  const bool serial_snarks = argc > 5 && atoi(argv[5]) != 0;
   try {
     provider::check(nmx_init(0));
     const auto in = read_records(argv[1]);
@@ -368,24 +371,54 @@ int main(int argc, char** argv) {
       relaxed_fold(P, uP, XP);            // :829-843
       provider::check(nmx_sync());
       lap(1, t);
-      spartan_prove(P, uP, XP, false);    // S1::prove (:863-871): the sum-check sequence ...
-      lap(2, t);
-      ee_prove(P);                        // ... and EE::prove on its batched witness (snark.rs:236-244)
-      lap(3, t);
-      spartan_prove(S, uS, XS, false);    // S2::prove (:872-880; its IPA argument is not replayed)
-      provider::check(nmx_sync());
-      lap(4, t);
+      if (serial_snarks) {
+        spartan_prove(P, uP, XP, false);  // S1::prove (:863-871): the sum-check sequence ...
+        lap(2, t);
+        ee_prove(P);                      // ... and EE::prove on its batched witness (snark.rs:236-244)
+        lap(3, t);
+        spartan_prove(S, uS, XS, false);  // S2::prove (:872-880; its IPA argument is not replayed)
+        provider::check(nmx_sync());
+        lap(4, t);
+      } else {                            // rayon::join(S1::prove, S2::prove), nova/mod.rs:862-881: S2 on a second host thread
+        std::exception_ptr err;
+        std::thread th([&] {
+          try {
+            spartan_prove(S, uS, XS, false);
+            provider::check(nmx_sync());
+          } catch (...) {
+            err = std::current_exception();
+          }
+        });
+        try {
+          spartan_prove(P, uP, XP, false);
+          lap(2, t);
+          ee_prove(P);
+          lap(3, t);
+        } catch (...) {
+          th.join();
+          throw;
+        }
+        th.join();
+        if (err) std::rethrow_exception(err);
+        lap(4, t);                        // (what S2 still needed after S1 was done)
+      }
     };
     for (int i = 0; i < warmup; i++) run();
     timing = true;
     HIPOK(hipDeviceSynchronize());
     const auto t0 = std::chrono::steady_clock::now();
-    for (int i = 0; i < steps; i++) run();
+    std::vector<double> step_ms;
+    for (int i = 0; i < steps; i++) {
+      const auto ts = std::chrono::steady_clock::now();
+      run();
+      step_ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts).count());
+    }
     HIPOK(hipDeviceSynchronize());
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / (steps > 0 ? steps : 1);
     FILE* f = fopen(argv[2], "wb");
     if (!f) return 2;
     write_record(f, "ms_per_sequence", &ms, 8);
+    write_record(f, "ms_per_step", step_ms.data(), step_ms.size() * 8);  // every timed sequence on its own
     for (double& g : grp) g /= (steps > 0 ? steps : 1);
     write_record(f, "ms_per_group", grp, sizeof grp);  // fold S, fold P, Spartan P, EE P, Spartan S
     for (Side* s : {&P, &S}) {
