@@ -452,6 +452,33 @@ int nmx_sumcheck_prove_quad_prod(int field, const void* claim, size_t num_rounds
 int nmx_sumcheck_prove_batch_eval(int field, const void* claims, const size_t* num_rounds, void* const* polys,
                                   const void* const* eq_points, const void* coeffs, size_t k, uint32_t flags,
                                   nmx_transcript_fn transcript, void* ctx, uint8_t* out_polys, uint8_t* out_r, uint8_t* out_finals);
+/* ---- inner-product argument (the evaluation engine of the secondary curve) -----------------------------------------------------
+ * InnerProductArgument::prove (src/provider/ipa_pc.rs:174-281), reached through EvaluationEngine::prove (:69-82) -- the evaluation
+ * argument of S2 in CompressedSNARK::prove (src/nova/mod.rs:862-881; Grumpkin / Pallas / Vesta engines, src/provider/mod.rs:38-148).
+ * One call runs every round: c_L, c_R (inner_product, :84-90, :207-208), L = commit(ck_R.combine(ck_c), a_L || c_L, 0) and
+ * R = commit(ck_L.combine(ck_c), a_R || c_R, 0) (:213-232), the folds of a and b (:237-247).  The reference also folds the key each
+ * round -- ck.fold(r^-1, r), n/2 two-point MSMs (src/provider/pedersen.rs:484-497) -- and commits against the folded halves; this
+ * library never folds it: round k's L and R are MSMs over the REGISTERED key with scalars a_k[i] * S_k[m] (S_k = the 2^k products of
+ * the earlier r_t^(+-1)), one fused two-vector run over the key's window tables.  Same group elements, so the same L, R, challenges
+ * and a_hat as the reference's loop (checked against the oracle's key-folding restatement and the reference's verifier,
+ * ipa_pc.rs:286-390, in tests/).
+ *   ck_handle   the Pedersen key (CommitmentKey::ck), registered; the first n points are used (`ck.split_at(U.b_vec.len())`, :183);
+ *               n > its length: NMX_E_HANDLE
+ *   ck_c_xy64   host, 64 bytes: the ALREADY SCALED one-point key `ck_c.scale(&r)` (:190-191; the caller's transcript squeezed that r
+ *               after absorbing the instance), in the form NMX_BASES_MONT names
+ *   a, b        W.a_vec and U.b_vec: n elements each, n a power of two (2^ell evaluations); host, or HBM with NMX_SCALARS_DEVICE;
+ *               canonical, or Montgomery limbs with NMX_SCALARS_MONT (then r and a_hat are Montgomery too).  Not modified.
+ *   transcript  called once per round with L and R (affine canonical x || y like every result of this library, and whether each is
+ *               the identity): absorb(b"L", &L); absorb(b"R", &R); squeeze(b"r") (:231-234); writes r and returns 0.  Non-zero:
+ *               NMX_E_ARG; r >= modulus: NMX_E_SCALAR_RANGE; r = 0: NMX_E_ZERO (`r.invert().unwrap()` panics, :235).
+ *   out_L, out_R  log2(n) points of 64 bytes each (L_vec, R_vec; canonical x || y); out_is_inf (may be null): 2 log2(n) bytes, [2k] = L_k is the identity,
+ *               [2k + 1] = R_k;  out_a_hat: 32 bytes (a_vec[0] after the last fold, :271).  n = 1: no round, a_hat = a[0].
+ * Flags: NMX_SCALARS_MONT, NMX_SCALARS_DEVICE, NMX_BASES_MONT; anything else NMX_E_ARG.  On an error the outputs written so far are
+ * unspecified and nothing of the call still runs. */
+typedef int (*nmx_ipa_transcript_fn)(void* ctx, const uint8_t* L_xy64, int L_is_inf, const uint8_t* R_xy64, int R_is_inf,
+                                     uint8_t* r32_out);
+int nmx_ipa_prove(uint64_t ck_handle, const void* ck_c_xy64, const void* a, const void* b, size_t n, uint32_t flags,
+                  nmx_ipa_transcript_fn transcript, void* ctx, uint8_t* out_L, uint8_t* out_R, uint8_t* out_is_inf, uint8_t* out_a_hat);
 /* PolyEvalWitness::batch / batch_diff_size (src/spartan/mod.rs:165-277): out[i] = sum_j s^j * vecs[j][i], i < n_out,
  * vectors shorter than n_out read as zero-padded; every lens[j] <= n_out.  `vecs`, `lens`, `s` are host arrays; the
  * vectors themselves and `out` follow NMX_SCALARS_DEVICE. */

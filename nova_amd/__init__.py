@@ -8,5 +8,5 @@ tests and bench.py; it never computes a group operation itself.
 from . import _lib  # noqa: F401
 from .provider import (  # noqa: F401
     BN254_G1, GRUMPKIN, PALLAS, VESTA, CURVE_NAMES, Commitment, CommitmentEngine, CommitmentKey, DlogGroup,
-    NmxError, ShardedVector, init_devices, shard_plan, svec_map,
+    NmxError, ShardedVector, init_devices, ipa_prove, shard_plan, svec_map,
 )

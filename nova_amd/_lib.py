@@ -26,6 +26,9 @@ BITS_AUTO = 0xFFFFFFFF
 # nmx_transcript_fn: (ctx, round polynomial coefficients, how many, challenge out) -> 0
 TRANSCRIPT_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_size_t,
                                  ctypes.POINTER(ctypes.c_uint8))
+# nmx_ipa_transcript_fn: (ctx, L xy64, L is the identity, R xy64, R is the identity, challenge out) -> 0
+IPA_TRANSCRIPT_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_int,
+                                     ctypes.POINTER(ctypes.c_uint8), ctypes.c_int, ctypes.POINTER(ctypes.c_uint8))
 
 _lib = None
 
@@ -116,6 +119,7 @@ def lib():
     L.nmx_sumcheck_prove_cubic_with_three_inputs.argtypes = [i, vp, vp, sz, vp, vp, vp, u32, TRANSCRIPT_FN, vp, vp, vp, vp]
     L.nmx_sumcheck_prove_quad_prod.argtypes = [i, vp, sz, vp, vp, u32, TRANSCRIPT_FN, vp, vp, vp, vp]
     L.nmx_sumcheck_prove_batch_eval.argtypes = [i, vp, vp, vp, vp, vp, sz, u32, TRANSCRIPT_FN, vp, vp, vp, vp]
+    L.nmx_ipa_prove.argtypes = [u64, vp, vp, vp, sz, u32, IPA_TRANSCRIPT_FN, vp, vp, vp, vp, vp]
     L.nmx_set_profiling.argtypes = [i]
     L.nmx_profile_last.argtypes = [ctypes.POINTER(ctypes.c_float), i]
     L.nmx_set_window_bits.argtypes = [u32]

@@ -2707,6 +2707,109 @@ int nmx_sumcheck_prove_batch_eval(int field, const void* claims, const size_t* n
   });
 }
 
+// InnerProductArgument::prove (src/provider/ipa_pc.rs:174-281) as one call.  The commitment key is never folded (ipa.hpp): every
+// round's L and R are one fused two-vector commitment over the registered key, whose window tables are the ones every other
+// commitment of that curve uses.  Per round: k_ipa_expand (+ the one-block partial sum) -> 64 bytes to the host (c_L, c_R) ->
+// commit_batch (the blinding terms c_L * ck_c, c_R * ck_c on pool threads under the MSM) -> the transcript callback -> k_ipa_fold.
+int nmx_ipa_prove(uint64_t ck_handle, const void* ck_c_xy64, const void* a, const void* b, size_t n, uint32_t flags,
+                  nmx_ipa_transcript_fn transcript, void* ctx, uint8_t* out_L, uint8_t* out_R, uint8_t* out_is_inf, uint8_t* out_a_hat) {
+  return guarded([&] {
+    require(transcript != nullptr, NMX_E_ARG, "null transcript callback");
+    require(ck_c_xy64 && a && b && out_a_hat, NMX_E_ARG, "null argument");
+    require(!(flags & ~(uint32_t)(NMX_SCALARS_MONT | NMX_SCALARS_DEVICE | NMX_BASES_MONT)), NMX_E_ARG, "unsupported flag");
+    require(n >= 1 && (n & (n - 1)) == 0, NMX_E_ARG, "n must be a power of two");  // U.b_vec.len().ilog2() rounds (ipa_pc.rs:262)
+    require(n < ((size_t)1 << 31), NMX_E_TOO_LARGE, "vector too long");
+    size_t rounds = 0;
+    while (((size_t)1 << rounds) < n) rounds++;
+    require(rounds == 0 || (out_L && out_R), NMX_E_ARG, "null argument");
+    auto bs = lookup(ck_handle);
+    require(n <= bs->n, NMX_E_HANDLE, "ck shorter than the vectors");  // ck.split_at(U.b_vec.len()) would panic (ipa_pc.rs:183)
+    const CurveOps& o = ops(bs->curve);
+    const int field = o.scalar_field;
+    const bool dev = (flags & NMX_SCALARS_DEVICE) != 0;
+    const uint32_t sflags = flags & NMX_SCALARS_MONT;
+    CtxLease L;
+    Ctx& c = *L.c;
+    if (rounds == 0) {  // a_hat = a_vec[0], no round (:268-272)
+      if (dev) {
+        HIPCHK(hipMemcpyAsync(out_a_hat, a, 32, hipMemcpyDeviceToHost, c.stream));
+        stream_wait(c.stream);
+      } else {
+        memcpy(out_a_hat, a, 32);
+      }
+      return;
+    }
+    // the call's device state, outside the arena the MSMs re-carve: [a b staged] a_w b_w vL vR S0 S1 partial dout
+    auto pad = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t half = pad((n / 2) * 32), full = pad(n * 32), pb = pad(fv_ipa_partial_bytes(n));
+    const size_t total = (dev ? 0 : 2 * full) + 2 * half + 2 * full + 2 * half + pb + 256;
+    struct Own {
+      void* p = nullptr;
+      ~Own() {
+        if (p) (void)hipFree(p);
+      }
+    } own;
+    char* base;
+    if (total <= ((size_t)64 << 20)) {
+      aux_reserve(c, total);
+      base = c.aux;
+    } else {
+      HIPCHK(hipMalloc(&own.p, total));
+      base = (char*)own.p;
+    }
+    size_t used = 0;
+    auto carve = [&](size_t bytes) {
+      char* q = base + used;
+      used += bytes;
+      return (uint32_t*)q;
+    };
+    const uint32_t *a_cur, *b_cur;
+    if (dev) {
+      a_cur = (const uint32_t*)a, b_cur = (const uint32_t*)b;
+    } else {
+      uint32_t *sa = carve(full), *sb = carve(full);
+      HIPCHK(hipMemcpyAsync(sa, a, n * 32, hipMemcpyHostToDevice, c.stream));
+      HIPCHK(hipMemcpyAsync(sb, b, n * 32, hipMemcpyHostToDevice, c.stream));
+      a_cur = sa, b_cur = sb;
+    }
+    uint32_t *a_w = carve(half), *b_w = carve(half), *vL = carve(full), *vR = carve(full);
+    uint32_t* S[2] = {carve(half), carve(half)};
+    uint32_t *partial = carve(pb), *dout = carve(256);
+    try {
+      fv_ipa_one(c, field, S[0]);
+      const bool sharded = !bs->parts.empty();
+      const BaseSet& key = sharded ? *bs : prefix_or_key(*bs, 0, n);
+      size_t len = n;
+      for (size_t k = 0; k < rounds; k++, len /= 2) {
+        uint8_t cs[64], pts[128], infs[2] = {0, 0};
+        fv_ipa_expand(c, field, a_cur, b_cur, S[k & 1], n, len, sflags, vL, vR, partial, dout, cs);
+        const uint32_t mflags = (flags & (NMX_SCALARS_MONT | NMX_BASES_MONT)) | NMX_SCALARS_DEVICE;
+        if (!sharded) {
+          const BatchItem items[2] = {{vL, n}, {vR, n}};
+          stat_add(NMX_STAT_MSM_CALLS, 2);
+          o.commit_batch(c, key, items, 2, field_call(nullptr, mflags), ck_c_xy64, cs, mflags, pts, infs);
+        } else {  // a key over several devices: two sharded commitments (the vectors sit on the primary device)
+          commit_impl(L, *bs, field_call(vL, mflags), n, ck_c_xy64, cs, mflags, pts, infs);
+          commit_impl(L, *bs, field_call(vR, mflags), n, ck_c_xy64, cs + 32, mflags, pts + 64, infs + 1);
+        }
+        memcpy(out_L + 64 * k, pts, 64);
+        memcpy(out_R + 64 * k, pts + 64, 64);
+        if (out_is_inf) out_is_inf[2 * k] = infs[0], out_is_inf[2 * k + 1] = infs[1];
+        uint8_t r[32], rinv[32];
+        require(transcript(ctx, pts, infs[0], pts + 64, infs[1], r) == 0, NMX_E_ARG, "the transcript callback failed");
+        require(fv_ipa_invert(field, r, sflags, rinv), NMX_E_ZERO, "a round challenge is zero");  // r.invert().unwrap() (:235)
+        fv_ipa_fold(c, field, a_cur, b_cur, len, r, rinv, sflags, a_w, b_w, S[k & 1], (size_t)1 << k, S[(k + 1) & 1]);
+        a_cur = a_w, b_cur = b_w;  // from here on in place: lane i reads elements i and i + h, writes element i
+      }
+      HIPCHK(hipMemcpyAsync(out_a_hat, a_cur, 32, hipMemcpyDeviceToHost, c.stream));
+      stream_wait(c.stream);
+    } catch (...) {
+      (void)hipStreamSynchronize(c.stream);  // nothing of this call still reads the caller's vectors
+      throw;
+    }
+  });
+}
+
 int nmx_r1cs_cross_term(uint64_t hA, uint64_t hB, uint64_t hC, const void* z1, const void* z2, size_t z_len, const void* e,
                         const void* u, uint32_t flags, void* out) {
   return guarded([&] {

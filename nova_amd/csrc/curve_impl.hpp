@@ -554,6 +554,40 @@ template <int CID> struct CurveImpl {
     if (any) acc.add(hr.get());
     write_result<CID>(acc, flags, out, inf);
   }
+  static void commit_batch(Ctx& c, const BaseSet& bs, const BatchItem* items, size_t k, const MsmCall& shared, const void* h_xy64,
+                           const uint8_t* rs32, uint32_t flags, uint8_t* out, uint8_t* inf) {
+    std::vector<PoolFuture<XYZZ<BF>>> hr(k);
+    std::vector<uint8_t> any(k, 0);
+    for (size_t j = 0; j < k; j++) {  // every range check before anything is launched
+      uint32_t rw[8];
+      memcpy(rw, rs32 + 32 * j, 32);
+      require(Fp<SF>::words_lt_p(rw), NMX_E_SCALAR_RANGE, "blinding scalar >= field modulus");
+      for (int i = 0; i < 8; i++) any[j] |= rw[i] ? 1 : 0;
+      require(items[j].n <= bs.n, NMX_E_HANDLE, "ck shorter than v");
+    }
+    std::array<uint8_t, 64> hb;
+    memcpy(hb.data(), h_xy64, 64);
+    for (size_t j = 0; j < k; j++) {
+      if (!any[j]) continue;
+      std::array<uint8_t, 32> rb;
+      memcpy(rb.data(), rs32 + 32 * j, 32);
+      hr[j] = PoolFuture<XYZZ<BF>>([hb, rb, flags] { return blind_point(hb.data(), rb.data(), flags); });
+    }
+    std::vector<XYZZ<BF>> r(k, XYZZ<BF>::identity());
+    if (k >= 2 && batch_limit_for<CID>(bs) >= k) {
+      run_msm_batch<CID>(c, bs, 0, items, k, shared, r.data());  // a failure unwinds through hr's destructors, which wait
+    } else {
+      for (size_t j = 0; j < k; j++) {
+        MsmCall mc = shared;
+        mc.scalars = items[j].scalars;
+        r[j] = run_msm_key<CID>(c, bs, 0, items[j].n, mc);
+      }
+    }
+    for (size_t j = 0; j < k; j++) {
+      if (any[j]) r[j].add(hr[j].get());
+      write_result<CID>(r[j], flags, out + 64 * j, inf ? inf + j : nullptr);
+    }
+  }
   static void upload(Ctx& c, BaseSet& bs, const void* src, uint32_t flags, const BaseFill* fill) {
     upload_bases<CID>(c, bs, src, flags, fill);
   }
@@ -620,7 +654,7 @@ template <int CID> struct CurveImpl {
   }
   static CurveOps ops() {
     return CurveOps{&msm_key, &msm_key_batch, &batch_limit, &commit, &upload, &check_point_host, FpParams<BF>::PW,
-                    &generate, &internal_to_canonical, &point_sum, &blind_term, &check_layout, &table_bytes};
+                    &generate, &internal_to_canonical, &point_sum, &blind_term, &check_layout, &table_bytes, &commit_batch, SF};
   }
 };
 

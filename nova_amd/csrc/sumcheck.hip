@@ -882,3 +882,4 @@ void fv_eq_sums(Ctx& c, int field, int mode, const void* A, const void* B, const
 }  // namespace nmx
 
 #include "sumcheck_prove.hpp"
+#include "ipa.hpp"

@@ -476,3 +476,43 @@ class CommitmentEngine:
         small = self.group.vartime_multiscalar_mul_small(v_u64, ck, partial=True)
         blind = self.commit(ck, np.zeros((0, 32), np.uint8), r, mont, partial=True)
         return self.group.point_sum([small.xy, blind.xy])
+
+
+def as_ipa_transcript(fn):
+    """fn(L_xy64: bytes, L_is_identity: bool, R_xy64: bytes, R_is_identity: bool) -> 32-byte challenge, wrapped as
+    nmx_ipa_transcript_fn.  The transcript is the caller's: `absorb(b"L", &L); absorb(b"R", &R); squeeze(b"r")`
+    (src/provider/ipa_pc.rs:231-234)."""
+    if isinstance(fn, L.IPA_TRANSCRIPT_FN):
+        return fn
+
+    def cb(_ctx, Lp, Li, Rp, Ri, out):
+        try:
+            ch = fn(bytes(Lp[:64]), bool(Li), bytes(Rp[:64]), bool(Ri))
+            ctypes.memmove(out, ch, 32)
+            return 0
+        except Exception:                   # an exception must not cross the C frame: the call fails with NMX_E_ARG
+            import traceback
+            traceback.print_exc()
+            return 1
+    return L.IPA_TRANSCRIPT_FN(cb)
+
+
+def ipa_prove(ck, ck_c_xy64, a, b, transcript, mont=False, ctx=None):
+    """InnerProductArgument::prove (src/provider/ipa_pc.rs:174-281) over a registered Pedersen key: `ck` a CommitmentKey (its first
+    len(a) points are used), `ck_c_xy64` the already scaled one-point key `ck_c.scale(&r)`, a / b the witness and the instance's
+    vector (host arrays or CUDA tensors, len a power of two).  Returns (L_vec, R_vec as 64-byte strings, [(L is identity, R is
+    identity)], a_hat as 32 bytes).  The key is never folded (nova_amd/csrc/ipa.hpp)."""
+    pa, n, deva, _ka = _scalar_arg(a, 32)
+    pb, nb, devb, _kb = _scalar_arg(b, 32)
+    assert n == nb and deva == devb, "InvalidInputLength (ipa_pc.rs:185-187) / both vectors on the same side"
+    rounds = max(n.bit_length() - 1, 0)
+    u = _host_u8(ck_c_xy64, 64)
+    oL, oR = np.zeros(64 * max(rounds, 1), np.uint8), np.zeros(64 * max(rounds, 1), np.uint8)
+    oi, ah = np.zeros(2 * max(rounds, 1), np.uint8), np.zeros(32, np.uint8)
+    flags = deva | (L.SCALARS_MONT if mont else 0) | (L.BASES_MONT if ck.mont else 0)
+    cb = as_ipa_transcript(transcript)
+    _check(L.lib().nmx_ipa_prove(ck.handle, u.ctypes.data, pa, pb, n, flags, cb, ctx, oL.ctypes.data, oR.ctypes.data, oi.ctypes.data,
+                                 ah.ctypes.data))
+    Lb, Rb = oL.tobytes(), oR.tobytes()
+    return ([Lb[64 * j: 64 * j + 64] for j in range(rounds)], [Rb[64 * j: 64 * j + 64] for j in range(rounds)],
+            [(bool(oi[2 * j]), bool(oi[2 * j + 1])) for j in range(rounds)], ah.tobytes())

@@ -11,6 +11,9 @@ import numpy as np
 # the transcript's side of a sum-check round: (ctx, round polynomial coefficients, how many, challenge out) -> 0
 TRANSCRIPT_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_size_t,
                                  ctypes.POINTER(ctypes.c_uint8))
+# the transcript's side of an inner-product-argument round: (ctx, L xy64, L is the identity, R xy64, R is the identity, challenge out) -> 0
+IPA_TRANSCRIPT_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_int,
+                                     ctypes.POINTER(ctypes.c_uint8), ctypes.c_int, ctypes.POINTER(ctypes.c_uint8))
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libnova_ref.so")
@@ -63,6 +66,7 @@ def lib():
         L.ref_sumcheck_prove_cubic3.argtypes = [ctypes.c_int, vp, vp, sz, vp, vp, vp, TRANSCRIPT_FN, vp, vp, vp, vp]
         L.ref_sumcheck_prove_quad_prod.argtypes = [ctypes.c_int, vp, sz, vp, vp, TRANSCRIPT_FN, vp, vp, vp, vp]
         L.ref_sumcheck_prove_batch_eval.argtypes = [ctypes.c_int, vp, vp, vp, vp, vp, sz, TRANSCRIPT_FN, vp, vp, vp, vp]
+        L.ref_ipa_prove.argtypes = [ctypes.c_int, vp, vp, vp, vp, sz, IPA_TRANSCRIPT_FN, vp, vp, vp, vp, vp]
         _lib = L
     return _lib
 
@@ -317,6 +321,40 @@ def spmv_transposed(fid, indptr, indices, data, rows, cols, rx):
     rc = lib().ref_spmv_transposed(fid, ip.ctypes.data, ix.ctypes.data, pd, rows, cols, px, out.ctypes.data)
     assert rc == 0
     return out[: 32 * cols].tobytes()
+
+
+def make_ipa_transcript(fn):
+    """Wrap fn(L_xy64: bytes, L_is_inf: bool, R_xy64: bytes, R_is_inf: bool) -> 32-byte challenge as the C callback of the
+    inner-product argument (the same callback type serves the product's nmx_ipa_prove)."""
+    def cb(_ctx, L, Li, R, Ri, out):
+        try:
+            ch = fn(bytes(L[:64]), bool(Li), bytes(R[:64]), bool(Ri))
+            ctypes.memmove(out, ch, 32)
+            return 0
+        except Exception:          # never let an exception cross the C frame
+            import traceback
+            traceback.print_exc()
+            return 1
+    return IPA_TRANSCRIPT_FN(cb)
+
+
+def ipa_prove(cid, ck, ck_c, a, b, n, transcript, ctx=None):
+    """InnerProductArgument::prove (src/provider/ipa_pc.rs:174-281) with the key fold of pedersen.rs:484-497: ck = n points
+    (xy64), ck_c = the scaled one-point key, a / b = n canonical scalars.  Returns (L [rounds] xy64, R [rounds] xy64,
+    infs [rounds][2], a_hat) or raises ValueError(code)."""
+    rounds = max(n.bit_length() - 1, 0)
+    ps = [_buf(x) for x in (ck, ck_c, a, b)]
+    oL = np.zeros(64 * max(rounds, 1), np.uint8)
+    oR = np.zeros(64 * max(rounds, 1), np.uint8)
+    oi = np.zeros(2 * max(rounds, 1), np.uint8)
+    ah = np.zeros(32, np.uint8)
+    rc = lib().ref_ipa_prove(cid, ps[0][0], ps[1][0], ps[2][0], ps[3][0], n, transcript, ctx, oL.ctypes.data, oR.ctypes.data,
+                             oi.ctypes.data, ah.ctypes.data)
+    if rc != 0:
+        raise ValueError(rc)
+    Lb, Rb = oL.tobytes(), oR.tobytes()
+    return ([Lb[64 * j: 64 * j + 64] for j in range(rounds)], [Rb[64 * j: 64 * j + 64] for j in range(rounds)],
+            [(bool(oi[2 * j]), bool(oi[2 * j + 1])) for j in range(rounds)], ah.tobytes())
 
 
 def make_transcript(fn):

@@ -1406,3 +1406,80 @@ int ref_batch_invert(int field, const uint8_t* v, size_t n, uint8_t* out) {
   free(x); free(products);
   return 0;
 }
+
+/* ------------------------------------------------------------------ inner-product argument ---------------------
+ * InnerProductArgument::prove (src/provider/ipa_pc.rs:174-281) behind EvaluationEngine::prove (:69-82; S2 of CompressedSNARK::prove
+ * on the secondary curve, src/nova/mod.rs:862-881), restated step by step INCLUDING the key fold the HIP path avoids:
+ *   per round (prove_inner, :195-251):  (ck_L, ck_R) = ck.split_at(n/2)                      pedersen.rs:457-468
+ *     c_L = <a[..n/2], b[n/2..]>, c_R = <a[n/2..], b[..n/2]>                                  inner_product, :84-90
+ *     L = commit(ck_R.combine(ck_c), a[..n/2] || c_L, 0), R = commit(ck_L.combine(ck_c), a[n/2..] || c_R, 0)   :213-232
+ *     r = transcript(L, R); a' = a_L r + r^-1 a_R; b' = b_L r^-1 + r b_R                       :234-249
+ *     ck' = ck.fold(r^-1, r): ck'[i] = msm([r^-1, r], [ck_L[i], ck_R[i]]).affine()             pedersen.rs:484-497
+ *   result: L_vec, R_vec, a_hat = a[0]                                                         :268-272
+ * `ck_c` is the ALREADY SCALED one-point key (ck_c.scale(&r), :190-191: the caller's transcript produced that r); the callback
+ * absorbs L and R and squeezes the round's r (:231-234), returning it canonical.  n must be a power of two (the evaluation engine
+ * passes 2^ell evaluations).  Returns -1 on bad arguments, -11 if a challenge is zero (`r.invert().unwrap()` panics). */
+typedef int (*ref_ipa_transcript_fn)(void* ctx, const uint8_t* L_xy64, int L_is_inf, const uint8_t* R_xy64, int R_is_inf, uint8_t* r32);
+int ref_ipa_prove(int curve, const uint8_t* ck_xy64, const uint8_t* ck_c_xy64, const uint8_t* a_le32, const uint8_t* b_le32, size_t n,
+                  ref_ipa_transcript_fn cb, void* ctx, uint8_t* out_L, uint8_t* out_R, uint8_t* out_inf, uint8_t* out_a_hat) {
+  if (curve < 0 || curve > 3 || n == 0 || (n & (n - 1))) return -1;
+  const curve_t* C = &CURVES[curve];
+  const field_t* S = C->scalar;
+  for (size_t i = 0; i < n; i++) {
+    fe s; memcpy(&s, a_le32 + 32 * i, 32); if (fe_geq(&s, &S->p)) return -4;
+    memcpy(&s, b_le32 + 32 * i, 32); if (fe_geq(&s, &S->p)) return -4;
+  }
+  aff* ck = (aff*)malloc(sizeof(aff) * (n + 1));       /* Montgomery coordinates, as a host Vec<Affine> */
+  aff* key = (aff*)malloc(sizeof(aff) * (n / 2 + 2));  /* ck_R.combine(ck_c) / ck_L.combine(ck_c) */
+  fe* a = load_vec_mont(S, a_le32, n);
+  fe* b = load_vec_mont(S, b_le32, n);
+  fe* v = (fe*)malloc(sizeof(fe) * (n / 2 + 2));       /* canonical scalars of one commitment */
+  load_bases(C, ck_xy64, n, ck);
+  aff ckc; load_bases(C, ck_c_xy64, 1, &ckc);
+  int rc = 0;
+  size_t round = 0;
+  for (size_t len = n; len > 1 && rc == 0; len /= 2, round++) {
+    const size_t h = len / 2;
+    fe cL, cR; memset(&cL, 0, sizeof cL); memset(&cR, 0, sizeof cR);
+    for (size_t i = 0; i < h; i++) {
+      fe t; fe_mul(S, &t, &a[i], &b[h + i]); fe_add(S, &cL, &cL, &t);
+      fe_mul(S, &t, &a[h + i], &b[i]); fe_add(S, &cR, &cR, &t);
+    }
+    xyzz acc;
+    uint8_t Lb[64], Rb[64], Li = 0, Ri = 0, ch[32];
+    /* L: bases ck_R || ck_c, scalars a_L || c_L; the blinding term is h * 0 (commit(.., &Scalar::ZERO)) */
+    memcpy(key, ck + h, sizeof(aff) * h); key[h] = ckc;
+    for (size_t i = 0; i < h; i++) fe_from_mont(S, &v[i], &a[i]);
+    fe_from_mont(S, &v[h], &cL);
+    msm_full(C, v, key, h + 1, &acc); store_point(C, &acc, Lb, &Li);
+    memcpy(key, ck, sizeof(aff) * h); key[h] = ckc;
+    for (size_t i = 0; i < h; i++) fe_from_mont(S, &v[i], &a[h + i]);
+    fe_from_mont(S, &v[h], &cR);
+    msm_full(C, v, key, h + 1, &acc); store_point(C, &acc, Rb, &Ri);
+    memcpy(out_L + 64 * round, Lb, 64); memcpy(out_R + 64 * round, Rb, 64);
+    if (out_inf) { out_inf[2 * round] = Li; out_inf[2 * round + 1] = Ri; }
+    if (cb(ctx, Lb, Li, Rb, Ri, ch) != 0) { rc = -1; break; }
+    fe rr; memcpy(&rr, ch, 32);
+    if (fe_geq(&rr, &S->p)) { rc = -4; break; }
+    if (fe_is_zero(&rr)) { rc = -11; break; }
+    fe r, rinv; fe_to_mont(S, &r, &rr); fe_inv(S, &rinv, &r);
+#pragma omp parallel for num_threads(nthreads())
+    for (long i = 0; i < (long)h; i++) {
+      fe t, u;
+      fe_mul(S, &t, &a[i], &r); fe_mul(S, &u, &rinv, &a[h + i]); fe_add(S, &a[i], &t, &u);
+      fe_mul(S, &t, &b[i], &rinv); fe_mul(S, &u, &r, &b[h + i]); fe_add(S, &b[i], &t, &u);
+    }
+    /* ck.fold(&r_inverse, &r): one two-point MSM per pair, result normalised to affine (pedersen.rs:488-494) */
+    fe w[2]; fe_from_mont(S, &w[0], &rinv); fe_from_mont(S, &w[1], &r);
+#pragma omp parallel for num_threads(nthreads()) schedule(dynamic, 16)
+    for (long i = 0; i < (long)h; i++) {
+      aff two[2] = {ck[i], ck[h + i]};
+      xyzz t; msm_full(C, w, two, 2, &t);
+      aff o; xyzz_to_affine(C->base, &o, &t);
+      ck[i] = o;   /* ck[i] is read by iteration i only; ck[h + i] is never written in this loop */
+    }
+  }
+  if (rc == 0) st_canon(S, out_a_hat, &a[0]);
+  free(ck); free(key); free(a); free(b); free(v);
+  return rc;
+}

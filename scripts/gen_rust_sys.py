@@ -38,6 +38,8 @@ def rust_type(ctype):
     t = re.sub(r"\s+", " ", ctype.strip())
     if t == "nmx_transcript_fn":
         return "NmxTranscriptFn"
+    if t == "nmx_ipa_transcript_fn":
+        return "NmxIpaTranscriptFn"
     toks = re.findall(r"const|\*|[A-Za-z_][A-Za-z0-9_]*", t)
     # C declarator, left to right: [const] base [const] { * [const] }
     i, base_const = 0, False
@@ -141,6 +143,9 @@ def generate():
           "/// One sum-check round: `coeffs32` = `n_coeffs` field elements of 32 bytes (the compressed round polynomial), the callback",
           "/// absorbs them, squeezes the challenge into `challenge32_out` and returns 0.  It must not synchronise the device.",
           "pub type NmxTranscriptFn = unsafe extern \"C\" fn(ctx: *mut c_void, coeffs32: *const u8, n_coeffs: usize, challenge32_out: *mut u8) -> c_int;",
+          "/// One round of the inner-product argument: absorb L and R (affine canonical x || y, and whether each is the identity), squeeze r.",
+          "pub type NmxIpaTranscriptFn = unsafe extern \"C\" fn(ctx: *mut c_void, l_xy64: *const u8, l_is_inf: c_int, r_xy64: *const u8, r_is_inf: c_int,",
+          "                                                     r32_out: *mut u8) -> c_int;",
           "",
           "#[link(name = \"nova_mi355x\")]",
           "extern \"C\" {"]

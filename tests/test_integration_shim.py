@@ -36,7 +36,7 @@ def c_class(t):
         return "void"
     if "*" in t:
         return "ptr"
-    if t.startswith("nmx_transcript_fn"):
+    if t.startswith("nmx_transcript_fn") or t.startswith("nmx_ipa_transcript_fn"):
         return "fnptr"
     t = re.sub(r"^const ", "", t)
     t = re.sub(r"\b[A-Za-z_][A-Za-z0-9_]*$", "", t).strip() if " " in t else t   # drop the parameter name
@@ -47,7 +47,7 @@ def rust_class(t):
     t = t.strip()
     if t.startswith("*const") or t.startswith("*mut"):
         return "ptr"
-    if t.startswith("NmxTranscriptFn") or t.startswith("Option<NmxTranscriptFn") or "extern \"C\" fn" in t:
+    if t.startswith(("NmxTranscriptFn", "NmxIpaTranscriptFn", "Option<NmxTranscriptFn")) or "extern \"C\" fn" in t:
         return "fnptr"
     return {"c_int": "i32", "i32": "i32", "u32": "u32", "u64": "u64", "usize": "usize", "c_uint": "u32"}[t]
 
@@ -105,7 +105,7 @@ def rust_calls(text):
 def test_header_prototypes_parse():
     protos = header_protos()
     src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
-    names = set(re.findall(r"\b(nmx_[a-z0-9_]+)\s*\(", src)) - {"nmx_transcript_fn"}
+    names = set(re.findall(r"\b(nmx_[a-z0-9_]+)\s*\(", src)) - {"nmx_transcript_fn", "nmx_ipa_transcript_fn"}
     assert names <= set(protos), sorted(names - set(protos))
     assert protos["nmx_init"] == ("i32", ["i32"])
     assert protos["nmx_last_error"] == ("ptr", [])

@@ -145,3 +145,4 @@ def to_mont_bases(cid, xy64):
     rows = np.ascontiguousarray(xy64).reshape(-1, 64)
     out = b"".join(R.fe_to_le32((int.from_bytes(bytes(row[j:j + 32]), "little") << 256) % p) for row in rows for j in (0, 32))
     return np.frombuffer(out, np.uint8).reshape(-1, 64).copy()
+
