@@ -1567,6 +1567,7 @@ class GpuProvider:
             dE1 = fv.r1cs_cross_term(self.mats[0], self.mats[1], self.mats[2], up(side.z(side.W1, side.u1, side.X1)), None, self.zeros, side.u1)
             side.E1 = dE1.cpu().numpy()
         self.E1 = up(side.E1)
+        self.ipa_u = self.ipa_generator()
 
     def close(self):
         for m in self.mats:
@@ -1638,6 +1639,24 @@ class GpuProvider:
     def fold_chain(self, v, xs):
         return self.fv.fold_chain(self.fid, v, xs, async_=True)
 
+    def ipa_generator(self):
+        """ck_c = CE::setup(b"ipa", 1) (src/provider/ipa_pc.rs:50): one more generator, made where the keys are made"""
+        import nova_amd
+        k = nova_amd.CommitmentKey.generate(self.s.cid, 1, k0=IPA_GENERATOR_K0)
+        u = k.read(0, 1).tobytes()
+        k.close()
+        return u
+
+    def scale_point(self, U, r):
+        """ck_c.scale(&r) (ipa_pc.rs:190-191; pedersen.rs:499-506): one point times one scalar = a commitment to nothing with h = U"""
+        import nova_amd
+        view = nova_amd.CommitmentKey(self.s.cid, self.ck.handle, self.ck.n, U)
+        return self.ce.commit(view, np.zeros((0, 32), np.uint8), r).xy
+
+    def ipa(self, ckc, a, b, tr):
+        import nova_amd
+        return nova_amd.ipa_prove(self.ck, ckc, a, b, tr.fn_ipa(self._lib.IPA_TRANSCRIPT_FN), ctx=tr.ctx)
+
     def poly_eval_multi(self, polys, us):
         return self.fv.poly_eval_multi(self.fid, polys, us)
 
@@ -1671,6 +1690,7 @@ class CpuProvider(SpartanCpu):
             side.E1 = self.cross_term0(side.z(side.W1, side.u1, side.X1), side.u1)
         self.W1, self.W2, self.E1 = side.W1, side.W2, side.E1
         self.msm_log = []
+        self.ipa_u = self.ipa_generator()
 
     def concat_z(self, W, u, X):
         return self.s.z(W, u, X)
@@ -1714,6 +1734,20 @@ class CpuProvider(SpartanCpu):
 
     def div_by_monomial(self, B, u):
         return np.ascontiguousarray(self._np(self.cref.suffix_horner(self.fid, B, len(B), u), len(B))[1:])
+
+    def ipa_generator(self):
+        from oracle import pyref
+        return self.cref.sequential_bases(pyref.CURVES_BY_ID[self.s.cid], IPA_GENERATOR_K0, 1).tobytes()
+
+    def scale_point(self, U, r):
+        out, _inf = self.cref.commit(self.s.cid, np.zeros((0, 32), np.uint8), self.key, 0, U, r)
+        return bytes(out)
+
+    def ipa(self, ckc, a, b, tr):
+        """InnerProductArgument::prove with the key fold of pedersen.rs:484-497 (oracle/nova_ref.c ref_ipa_prove)"""
+        n = len(a)
+        return self.cref.ipa_prove(self.s.cid, self.key[:n], ckc, np.ascontiguousarray(a), np.ascontiguousarray(b), n,
+                                   tr.fn_ipa(self.cref.IPA_TRANSCRIPT_FN), ctx=tr.ctx)
 
 
 def relaxed_fold_sequence(be, side, tr, call):
@@ -1780,13 +1814,31 @@ def hyperkzg_sequence(be, ell, p, hat_P, point, tr, call):
     return {"com": coms, "v": evals, "w": opens}
 
 
+IPA_GENERATOR_K0 = 424243
+
+
+def ipa_sequence(be, ell, poly, point, tr, call):
+    """EE::prove of the inner-product engine (src/provider/ipa_pc.rs:69-82 -> InnerProductArgument::prove :174-281) on a polynomial that
+    is already where the provider keeps its vectors: b = EqPolynomial::new(point).evals() (:78), r from the transcript (:186-190),
+    ck_c.scale(&r) (:191), then the log n rounds -- c_L, c_R, the commitments L and R, the folds of a and b; the reference also folds the
+    key (pedersen.rs:484-497: 2 n scalar multiplications per proof), the HIP path commits against the registered key instead
+    (nova_amd/csrc/ipa.hpp) and the oracle does what the reference does."""
+    b = call("ee.eq_evals", lambda: be.eq_evals(b"".join(bytes(x) for x in point)))
+    r0 = tr.squeeze()
+    state = bytes(tr.state.raw)                                    # (what a verifier's transcript holds here: tests replay the rounds from it)
+    ckc = call("ee.scale_ck_c", lambda: be.scale_point(be.ipa_u, r0))
+    Ls, Rs, infs, a_hat = call("ee.ipa", lambda: be.ipa(ckc, poly, b, tr))
+    return {"ck_c": bytes(ckc), "L": Ls, "R": Rs, "inf": infs, "a_hat": a_hat, "tr_state": state}
+
+
 def compressed_snark_sequence(beP, beS, sideP, sideS, call=lambda name, fn: fn(), parallel_snarks=False):
     """The provider-side work of CompressedSNARK::prove (src/nova/mod.rs:793-881) in the reference's order:
       secondary: sample_random_instance_witness + NIFSRelaxed::prove          (:812-826)
       primary:   sample_random_instance_witness + NIFSRelaxed::prove          (:829-843)
       S1::prove on the primary = RelaxedR1CSSNARK::prove (src/spartan/snark.rs:113-260): the sum-check sequence, whose batched
                  witness W + c E (spartan/mod.rs:429) is the polynomial EE::prove folds and opens (snark.rs:236-244)
-      S2::prove on the secondary: the sum-check sequence (its evaluation argument is IPA, src/provider/ipa_pc.rs -- not replayed)
+      S2::prove on the secondary: the sum-check sequence, then ITS evaluation argument on its batched witness -- the inner-product
+                 argument (src/provider/ipa_pc.rs:69-82, 174-281; ipa_sequence)
     NOT replayed: NIFS::prove of (:797-809) -- the prove_step replay's secondary fold --, the RO / Keccak transcripts (one stand-in
     per SNARK and one per fold), derandomize (:846-861: two scalar products of h per side).  parallel_snarks: S1::prove and S2::prove side
     by side on two host threads, as the reference's `rayon::join` at :862-881 runs them (every provider call leases its own context and
@@ -1803,6 +1855,8 @@ def compressed_snark_sequence(beP, beS, sideP, sideS, call=lambda name, fn: fn()
         out[f"spartan_{tag}"] = sp
         if tag == "P":                                            # snark.rs:236-244: batched_w.p, batched_u.x = the batch sum-check's r
             out["ee_P"] = hyperkzg_sequence(be, side.ell, side.p, sp["batch_witness"], sp["batch"][1], tr, cp(tag))
+        else:
+            out["ee_S"] = ipa_sequence(be, side.ell, sp["batch_witness"], sp["batch"][1], tr, cp(tag))
     if not parallel_snarks:
         snark("P", beP, sideP)
         snark("S", beS, sideS)
@@ -1836,6 +1890,7 @@ def csnark_digest(res, host):
             d[f"spartan_{tag}.{k}"] = sp[k]
         d[f"spartan_{tag}.batch_witness"] = host[tag](sp["batch_witness"])
     d["ee_P"] = res["ee_P"]
+    d["ee_S"] = res["ee_S"]
     return d
 
 
@@ -1901,7 +1956,7 @@ def compressed_snark_replay(args, torch):
         "config": {"workload": f"CompressedSNARK::prove replay ({nova_amd.CURVE_NAMES[cP]} primary 2^{ellP}, {nova_amd.CURVE_NAMES[cS]} secondary 2^{ellS}): per side "
                                "random instance (3 SpMV + 2 commitments) + relaxed fold (3 SpMV, five-input cross term, commit T, two folds); Spartan "
                                "sum-check sequence on both folded instances; HyperKZG EE::prove on the primary's batched witness where it lies in HBM "
-                               "(BASELINE.json configs[4]); stand-in transcripts; no IPA argument on the secondary; S1 and S2 "
+                               "(BASELINE.json configs[4]) and the inner-product argument on the secondary's; stand-in transcripts; S1 and S2 "
                                + ("side by side on two host threads (rayon::join, nova/mod.rs:862-881)" if par else "one after the other"),
                    "parallel_snarks": par},
         "roofline": None, "breakdown_ms": breakdown, "groups_ms": groups, "proof_verifies": verifies,
@@ -2017,6 +2072,11 @@ def cpp_chained_replay(sides, exp, cpu_host, steps, warmup, k0=7, serial_snarks=
         dg[f"spartan_{tag}.batch_witness"] = bytes(got[f"{tag}.spartan.batch_witness"])
     v = flat(got["P.ee.v"])
     dg["ee_P"] = {"com": pts(got["P.ee.com"]), "v": [v[3 * i:3 * i + 3] for i in range(len(v) // 3)], "w": pts(got["P.ee.w"])}
+    eS = {k: bytes(got[f"S.ee.{k}"]) for k in ("ck_c", "L", "R", "inf", "a_hat", "tr_state")}
+    dg["ee_S"] = {"ck_c": eS["ck_c"], "L": [eS["L"][64 * i:64 * i + 64] for i in range(len(eS["L"]) // 64)],
+                  "R": [eS["R"][64 * i:64 * i + 64] for i in range(len(eS["R"]) // 64)],
+                  "inf": [[eS["inf"][2 * i], eS["inf"][2 * i + 1]] for i in range(len(eS["inf"]) // 2)], "a_hat": eS["a_hat"],
+                  "tr_state": eS["tr_state"]}
     de = csnark_digest(exp, cpu_host)
 
     def plain(x):                                       # one shape on both sides: nested lists of bytes / ints
@@ -2028,11 +2088,11 @@ def cpp_chained_replay(sides, exp, cpu_host, steps, warmup, k0=7, serial_snarks=
             return [plain(val) for val in x]
         return int(x) if isinstance(x, (int, np.integer)) else x
     checks = {k: plain(dg[k]) == plain(de[k]) for k in de}
-    grp = struct.unpack("<5d", got["ms_per_group"])
+    grp = struct.unpack("<6d", got["ms_per_group"])
     per_step = struct.unpack(f"<{len(got['ms_per_step']) // 8}d", got["ms_per_step"])
     return {"ms": round(struct.unpack("<d", got["ms_per_sequence"])[0], 4), "steps": steps, "gpu_matches_cpu": all(checks.values()),
             "median_ms": round(float(np.median(per_step)), 4), "per_step_ms": [round(x, 3) for x in per_step],
-            "groups_ms": dict(zip(("S.fold", "P.fold", "P.spartan", "P.ee", "S.spartan"), (round(g, 4) for g in grp))),
+            "groups_ms": dict(zip(("S.fold", "P.fold", "P.spartan", "P.ee", "S.spartan" if serial_snarks else "S.after_P", "S.ee"), (round(g, 4) for g in grp))),
             "failed": [k for k, ok in checks.items() if not ok],
             "what": "bench/csnark_replay.cpp: the same provider calls in the same order through include/nova_mi355x.hpp (namespace resident), "
                     "device buffers allocated once, no Python between the calls"}

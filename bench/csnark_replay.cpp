@@ -24,6 +24,7 @@ void standin_init(void* t, uint64_t seed);
 void standin_absorb(void* t, const uint8_t* data, size_t n);
 void standin_squeeze(void* t, uint8_t out[32]);
 int standin_transcript(void* ctx, const uint8_t* coeffs, size_t n_coeffs, uint8_t* challenge32);
+int standin_ipa_transcript(void* ctx, const uint8_t* L_xy64, int L_is_inf, const uint8_t* R_xy64, int R_is_inf, uint8_t* r32);
 }
 using namespace nova;
 using provider::Scalar;
@@ -164,6 +165,7 @@ struct Side {
   Scalar u1, X1, u2, X2, rW, rE, rT;
   // scratch, allocated once
   Dev z1, z2, Z, AZ, BZ, CZ, E2, T, W, E, zc, Az, Bz, Cz, uCzE, erx, eA, eB, eC, ABC, Wc, Ec, wj, chain, Bp, hs[3], hq;
+  provider::Affine ipa_u{};      // ck_c = CE::setup(b"ipa", 1) (ipa_pc.rs:50)
   std::vector<Scalar> ee_point;  // handed from the sum-check sequence to EE::prove
   uint8_t ee_tr[48];
   // results of the last run
@@ -210,6 +212,7 @@ static void load_side(Side& s, const std::map<std::string, Blob>& in, const std:
   for (Dev* d : {&s.z1, &s.z2, &s.Z, &s.zc, &s.eA, &s.eB, &s.eC, &s.ABC}) d->alloc(2 * n);
   for (Dev* d : {&s.AZ, &s.BZ, &s.CZ, &s.E2, &s.T, &s.W, &s.E, &s.Az, &s.Bz, &s.Cz, &s.uCzE, &s.erx, &s.Wc, &s.Ec, &s.wj, &s.chain, &s.Bp, &s.hq}) d->alloc(n);
   for (Dev& d : s.hs) d.alloc(n);
+  s.ipa_u = provider::CommitmentKey::generate(s.cid, 0, 424243).h();  // bench.IPA_GENERATOR_K0
 }
 
 // sample_random_instance_witness + NIFSRelaxed::prove (bench.py relaxed_fold_sequence; r1cs/mod.rs:786-830, 629-661, 1070-1107)
@@ -341,6 +344,22 @@ static void ee_prove(Side& s) {
   s.put("ee.com", cb.data(), cb.size()), s.put("ee.v", v[0].data(), 32 * v.size()), s.put("ee.w", wb.data(), wb.size());
 }
 
+// EE::prove of the inner-product engine on the secondary's batched witness (bench.py ipa_sequence; ipa_pc.rs:69-82, 174-281)
+static void ee_ipa(Side& s) {
+  const int f = s.fid;
+  const size_t n = s.n;
+  Transcript tr(0);
+  memcpy(tr.state, s.ee_tr, sizeof s.ee_tr);  // the SNARK's transcript goes on (snark.rs:236: `&mut transcript`)
+  R::eq_evals(f, s.ee_point, s.erx.p);        // b = EqPolynomial::new(point).evals() (:78)
+  const Scalar r0 = tr.squeeze();
+  s.put("ee.tr_state", tr.state, sizeof tr.state);
+  const provider::Affine ckc = R::scale_point(*s.ck, s.ipa_u, r0);  // ck_c.scale(&r) (:190-191)
+  const R::IpaProof pr = R::ipa_prove(*s.ck, ckc, s.wj.p, s.erx.p, n, &standin_ipa_transcript, tr.state);
+  s.put("ee.ck_c", ckc.data(), 64);
+  s.put("ee.L", pr.L.data(), pr.L.size()), s.put("ee.R", pr.R.data(), pr.R.size()), s.put("ee.inf", pr.inf.data(), pr.inf.size());
+  s.put("ee.a_hat", pr.a_hat.data(), 32);
+}
+
 int main(int argc, char** argv) {
   if (argc < 5) {
     fprintf(stderr, "usage: %s <instance> <output> <steps> <warmup>\n", argv[0]);
@@ -355,7 +374,7 @@ int main(int argc, char** argv) {
     load_side(P, in, "P"), load_side(S, in, "S");
     // wall time per group, summed over the timed steps: fold S, fold P, Spartan P, EE P, Spartan S (every group ends in a synchronous
     // call -- a commitment, an evaluation, the batched witness -- so its work is complete when its clock stops)
-    double grp[5] = {0, 0, 0, 0, 0};
+    double grp[6] = {0, 0, 0, 0, 0, 0};
     bool timing = false;
     auto lap = [&](int g, std::chrono::steady_clock::time_point& t) {
       const auto now = std::chrono::steady_clock::now();
@@ -376,15 +395,18 @@ int main(int argc, char** argv) {
         lap(2, t);
         ee_prove(P);                      // ... and EE::prove on its batched witness (snark.rs:236-244)
         lap(3, t);
-        spartan_prove(S, uS, XS, false);  // S2::prove (:872-880; its IPA argument is not replayed)
+        spartan_prove(S, uS, XS, false);  // S2::prove (:872-880) ...
         provider::check(nmx_sync());
         lap(4, t);
+        ee_ipa(S);                        // ... and its evaluation argument, the inner-product argument
+        lap(5, t);
       } else {                            // rayon::join(S1::prove, S2::prove), nova/mod.rs:862-881: S2 on a second host thread
         std::exception_ptr err;
         std::thread th([&] {
           try {
             spartan_prove(S, uS, XS, false);
             provider::check(nmx_sync());
+            ee_ipa(S);
           } catch (...) {
             err = std::current_exception();
           }
@@ -420,7 +442,7 @@ int main(int argc, char** argv) {
     write_record(f, "ms_per_sequence", &ms, 8);
     write_record(f, "ms_per_step", step_ms.data(), step_ms.size() * 8);  // every timed sequence on its own
     for (double& g : grp) g /= (steps > 0 ? steps : 1);
-    write_record(f, "ms_per_group", grp, sizeof grp);  // fold S, fold P, Spartan P, EE P, Spartan S
+    write_record(f, "ms_per_group", grp, sizeof grp);  // fold S, fold P, Spartan P, EE P, Spartan S (parallel: what S2 still needed), EE S (serial only)
     for (Side* s : {&P, &S}) {
       for (const auto& kv : s->out) write_record(f, kv.first, kv.second.data(), kv.second.size());
       const Blob wj = s->wj.download();

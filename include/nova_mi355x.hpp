@@ -436,5 +436,26 @@ inline Proof prove_batch(int field, const std::vector<Scalar>& claims, const std
                                       p.polys.data(), p.r.data(), p.claims.data()));
   return p;
 }
+// ck_c.scale(&r) (src/provider/ipa_pc.rs:190-191, pedersen.rs:499-506): one point times one scalar -- a commitment to the empty
+// vector with h = the point
+inline Affine scale_point(const CommitmentKey& ck, const Affine& h, const Scalar& r) {
+  Affine out{};
+  uint8_t inf = 0;
+  check(nmx_commit(ck.handle(), nullptr, 0, h.data(), r.data(), 0, out.data(), &inf));
+  return out;
+}
+// InnerProductArgument::prove (src/provider/ipa_pc.rs:174-281) over HBM-resident a, b; `ck_c` already scaled (scale_point)
+struct IpaProof {
+  std::vector<uint8_t> L, R, inf;  // log2 n points of 64 bytes each; inf[2k] / inf[2k + 1]: L_k / R_k is the identity
+  Scalar a_hat{};
+};
+inline IpaProof ipa_prove(const CommitmentKey& ck, const Affine& ck_c, const void* a, const void* b, size_t n, nmx_ipa_transcript_fn cb, void* ctx) {
+  size_t rounds = 0;
+  while (((size_t)1 << rounds) < n) rounds++;
+  IpaProof p{std::vector<uint8_t>(64 * (rounds ? rounds : 1)), std::vector<uint8_t>(64 * (rounds ? rounds : 1)), std::vector<uint8_t>(2 * (rounds ? rounds : 1)), {}};
+  check(nmx_ipa_prove(ck.handle(), ck_c.data(), a, b, n, kDev, cb, ctx, p.L.data(), p.R.data(), p.inf.data(), p.a_hat.data()));
+  p.L.resize(64 * rounds), p.R.resize(64 * rounds), p.inf.resize(2 * rounds);
+  return p;
+}
 }  // namespace resident
 }  // namespace nova

@@ -4,9 +4,9 @@ set -u
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r6ipa
 mkdir -p "$OUT"
 timeout 1200 python -m pytest tests/test_gpu_ipa.py -x -q 2>&1 | tail -5 | tee "$OUT/pytest.txt"
-python scripts/gpu_r6_ipa.py 10 12 14 16 17 2>&1 | grep -v amdgpu.ids | tee "$OUT/timing.txt"
+python scripts/archive/gpu_r6_ipa.py 10 12 14 16 17 2>&1 | grep -v amdgpu.ids | tee "$OUT/timing.txt"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d /tmp/ipa_trace -- python $GRAFT_REPO_ROOT/scripts/gpu_r6_ipa.py 14 > /tmp/ipa_trace.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/ipa_trace -- python $GRAFT_REPO_ROOT/scripts/archive/gpu_r6_ipa.py 14 > /tmp/ipa_trace.log 2>&1
 f=$(find /tmp/ipa_trace -name "*kernel_trace.csv" | head -1)
 python - "$f" <<'PY' | tee "$OUT/timeline_2p14.txt"
 import csv, sys

@@ -39,6 +39,10 @@ class Transcript:
     def fn(self, proto):
         return proto(("standin_transcript", lib()))
 
+    def fn_ipa(self, proto):
+        """the inner-product argument's round callback (nmx_ipa_transcript_fn / the oracle's) on the same state"""
+        return proto(("standin_ipa_transcript", lib()))
+
     def absorb(self, data):
         b = bytes(data)
         lib().standin_absorb(self.state, b, len(b))

@@ -43,3 +43,14 @@ int standin_transcript(void* ctx, const uint8_t* coeffs, size_t n_coeffs, uint8_
   standin_squeeze(t, challenge32);
   return 0;
 }
+/* nmx_ipa_transcript_fn / ref_ipa_transcript_fn: absorb(b"L", &L); absorb(b"R", &R); squeeze(b"r") (src/provider/ipa_pc.rs:231-234) */
+int standin_ipa_transcript(void* ctx, const uint8_t* L_xy64, int L_is_inf, const uint8_t* R_xy64, int R_is_inf, uint8_t* r32) {
+  standin_t* t = (standin_t*)ctx;
+  const uint8_t flags[8] = {(uint8_t)(L_is_inf != 0), (uint8_t)(R_is_inf != 0), 0, 0, 0, 0, 0, 0};
+  standin_absorb(t, L_xy64, 64);
+  standin_absorb(t, R_xy64, 64);
+  standin_absorb(t, flags, 8);
+  standin_squeeze(t, r32);
+  r32[0] |= 1; /* never zero: the reference unwraps the inverse (:235) */
+  return 0;
+}

@@ -282,8 +282,8 @@ def test_montgomery_layout_key_commit_2p16(nmx):
 def test_compressed_snark_replay_matches_oracle(nmx, cycle, ell, ell2):
     """BASELINE.json configs[4] as ONE chained sequence (bench.py compressed_snark_replay; CompressedSNARK::prove,
     src/nova/mod.rs:793-881): random instance + relaxed fold per side, Spartan on both folded instances, HyperKZG's EE::prove on the
-    primary's batched witness where it lies in HBM -- every commitment, round polynomial, evaluation, batched witness and the
-    evaluation argument against the oracle run in the same order; both Spartan proofs pass the reference's verifier equations; and
+    primary's batched witness where it lies in HBM, the inner-product argument on the secondary's -- every commitment, round polynomial,
+    evaluation, batched witness and both evaluation arguments against the oracle run in the same order; both Spartan proofs pass the reference's verifier equations; and
     the same commitments once more in the trait-only form (slice-form calls over host scalars and host bases)."""
     import torch
     import bench
@@ -294,7 +294,9 @@ def test_compressed_snark_replay_matches_oracle(nmx, cycle, ell, ell2):
     assert out["trait_only"]["gpu_matches_cpu"] is True and out["trait_only"]["calls"] == 8
     # the same sequence driven from C++ through include/nova_mi355x.hpp (bench/csnark_replay.cpp), against the same oracle run
     assert out["cpp_driver"].get("gpu_matches_cpu") is True, out["cpp_driver"]
-    assert {"P.fold", "P.spartan", "P.ee", "S.fold", "S.spartan"} == set(out["groups_ms"])
+    assert {"P.fold", "P.spartan", "P.ee", "S.fold", "S.spartan", "S.ee"} == set(out["groups_ms"])
+    # the secondary's evaluation argument (the inner-product argument) is part of what was compared, from Python and from C++
+    assert out["cpu_baseline"]["checks"]["ee_S"] is True and "ee_S" not in out["cpp_driver"]["failed"]
 
 
 def test_prove_step_trait_only_form_matches_oracle(nmx):

@@ -145,3 +145,28 @@ def test_compressed_snark_sequence_through_the_oracle_alone():
         even = (v[i][0] + v[i][1]) * two_inv % p
         odd_r = (v[i][0] - v[i][1]) * two_inv % p
         assert r * v[i + 1][2] % p == (r * (1 - xi) % p * even + xi * odd_r) % p, i
+    # the secondary's evaluation argument: the IPA proof over the batched witness passes the reference's verifier (ipa_pc.rs:286-390)
+    # with b = eq(point) and the challenges replayed from the same stand-in transcript state
+    from tests import ipa_common as ic
+    from tests import standin
+    S, ee = sides["S"], res["ee_S"]
+    curve = R.GRUMPKIN
+    a = cpu["S"].host(res["spartan_S"]["batch_witness"])
+    point = b"".join(bytes(c) for c in res["spartan_S"]["batch"][1])
+    b = cref.eq_evals(S.fid, point, S.ell)
+    assert len(ee["L"]) == len(ee["R"]) == S.ell
+    # the round challenges, as the verifier gets them: its transcript, in the state the prover's was in, absorbs every (L, R)
+    import ctypes
+    tr = standin.Transcript(seed=1)
+    ctypes.memmove(tr.state, ee["tr_state"], 48)
+    rs = []
+    for L, Rr, (Li, Ri) in zip(ee["L"], ee["R"], ee["inf"]):
+        out = (ctypes.c_uint8 * 32)()
+        standin.lib().standin_ipa_transcript(tr.ctx, (ctypes.c_uint8 * 64)(*L), int(Li), (ctypes.c_uint8 * 64)(*Rr), int(Ri), out)
+        rs.append(int.from_bytes(bytes(out), "little"))
+    ckc = np.frombuffer(ee["ck_c"], np.uint8).copy()
+    key = np.ascontiguousarray(keys["S"][:S.n])
+    av, bv = np.frombuffer(a, np.uint8).reshape(-1, 32).copy(), np.frombuffer(b, np.uint8).reshape(-1, 32).copy()
+    assert ic.verify(curve, key, ckc, av, bv, S.n, ee["L"], ee["R"], ee["inf"], ee["a_hat"], rs)
+    bad = ic.le((int.from_bytes(ee["a_hat"], "little") + 1) % curve.r)
+    assert not ic.verify(curve, key, ckc, av, bv, S.n, ee["L"], ee["R"], ee["inf"], bad, rs)
