@@ -2739,14 +2739,16 @@ int nmx_ipa_prove(uint64_t ck_handle, const void* ck_c_xy64, const void* a, cons
       }
       return;
     }
-    // the call's device state, outside the arena the MSMs re-carve: [a b staged] a_w b_w vL vR S0 S1 partial dout
+    // the call's device state, outside the arena the MSMs re-carve: [a b staged] A0 A1 B0 B1 vL vR S0 S1 dout
     auto pad = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t half = pad((n / 2) * 32), full = pad(n * 32), pb = pad(fv_ipa_partial_bytes(n));
-    const size_t total = (dev ? 0 : 2 * full) + 2 * half + 2 * full + 2 * half + pb + 256;
+    const size_t half = pad((n / 2) * 32), full = pad(n * 32);
+    const size_t total = (dev ? 0 : 2 * full) + 4 * half + 2 * full + 2 * half + 256;
     struct Own {
       void* p = nullptr;
+      hipEvent_t ev = nullptr;
       ~Own() {
         if (p) (void)hipFree(p);
+        if (ev) (void)hipEventDestroy(ev);
       }
     } own;
     char* base;
@@ -2757,6 +2759,7 @@ int nmx_ipa_prove(uint64_t ck_handle, const void* ck_c_xy64, const void* a, cons
       HIPCHK(hipMalloc(&own.p, total));
       base = (char*)own.p;
     }
+    HIPCHK(hipEventCreateWithFlags(&own.ev, hipEventDisableTiming));
     size_t used = 0;
     auto carve = [&](size_t bytes) {
       char* q = base + used;
@@ -2772,37 +2775,50 @@ int nmx_ipa_prove(uint64_t ck_handle, const void* ck_c_xy64, const void* a, cons
       HIPCHK(hipMemcpyAsync(sb, b, n * 32, hipMemcpyHostToDevice, c.stream));
       a_cur = sa, b_cur = sb;
     }
-    uint32_t *a_w = carve(half), *b_w = carve(half), *vL = carve(full), *vR = carve(full);
+    uint32_t* A[2] = {carve(half), carve(half)};
+    uint32_t* B[2] = {carve(half), carve(half)};
+    uint32_t *vL = carve(full), *vR = carve(full);
     uint32_t* S[2] = {carve(half), carve(half)};
-    uint32_t *partial = carve(pb), *dout = carve(256);
+    uint32_t* dout = carve(256);
     try {
-      fv_ipa_one(c, field, S[0]);
       const bool sharded = !bs->parts.empty();
       const BaseSet& key = sharded ? *bs : prefix_or_key(*bs, 0, n);
+      const uint32_t mflags = (flags & (NMX_SCALARS_MONT | NMX_BASES_MONT)) | NMX_SCALARS_DEVICE;
+      const int hip_dev = hip_device_of(c.dev);
+      uint8_t r[32], rinv[32];
       size_t len = n;
+      fv_ipa_one(c, field, S[0]);  // S_0 = [1]
       for (size_t k = 0; k < rounds; k++, len /= 2) {
-        uint8_t cs[64], pts[128], infs[2] = {0, 0};
-        fv_ipa_expand(c, field, a_cur, b_cur, S[k & 1], n, len, sflags, vL, vR, partial, dout, cs);
-        const uint32_t mflags = (flags & (NMX_SCALARS_MONT | NMX_BASES_MONT)) | NMX_SCALARS_DEVICE;
+        // round k's launch folds with round k - 1's challenge on the way: vectors and table ping-pong between two buffers
+        const uint32_t* partial_host = nullptr;
+        fv_ipa_round(c, field, a_cur, b_cur, S[(k + 1) & 1], A[k & 1], B[k & 1], S[k & 1], n, len, k ? r : nullptr, k ? rinv : nullptr, sflags, vL,
+                     vR, own.ev, &partial_host);
+        if (k) a_cur = A[k & 1], b_cur = B[k & 1];
+        // c_L, c_R reach the host on the pool threads that need them (the blinding terms), once the launch above has completed
+        const hipEvent_t ev = own.ev;
+        const std::function<void(size_t, uint8_t*)> late = [=](size_t j, uint8_t* out32) {
+          HIPCHK(hipSetDevice(hip_dev));
+          HIPCHK(hipEventSynchronize(ev));
+          fv_ipa_scalar(field, partial_host, n, (int)j, sflags, out32);
+        };
+        uint8_t pts[128], infs[2] = {0, 0};
         if (!sharded) {
           const BatchItem items[2] = {{vL, n}, {vR, n}};
           stat_add(NMX_STAT_MSM_CALLS, 2);
-          o.commit_batch(c, key, items, 2, field_call(nullptr, mflags), ck_c_xy64, cs, mflags, pts, infs);
+          o.commit_batch(c, key, items, 2, field_call(nullptr, mflags), ck_c_xy64, nullptr, &late, mflags, pts, infs);
         } else {  // a key over several devices: two sharded commitments (the vectors sit on the primary device)
+          uint8_t cs[64];
+          late(0, cs), late(1, cs + 32);
           commit_impl(L, *bs, field_call(vL, mflags), n, ck_c_xy64, cs, mflags, pts, infs);
           commit_impl(L, *bs, field_call(vR, mflags), n, ck_c_xy64, cs + 32, mflags, pts + 64, infs + 1);
         }
         memcpy(out_L + 64 * k, pts, 64);
         memcpy(out_R + 64 * k, pts + 64, 64);
         if (out_is_inf) out_is_inf[2 * k] = infs[0], out_is_inf[2 * k + 1] = infs[1];
-        uint8_t r[32], rinv[32];
         require(transcript(ctx, pts, infs[0], pts + 64, infs[1], r) == 0, NMX_E_ARG, "the transcript callback failed");
         require(fv_ipa_invert(field, r, sflags, rinv), NMX_E_ZERO, "a round challenge is zero");  // r.invert().unwrap() (:235)
-        fv_ipa_fold(c, field, a_cur, b_cur, len, r, rinv, sflags, a_w, b_w, S[k & 1], (size_t)1 << k, S[(k + 1) & 1]);
-        a_cur = a_w, b_cur = b_w;  // from here on in place: lane i reads elements i and i + h, writes element i
       }
-      HIPCHK(hipMemcpyAsync(out_a_hat, a_cur, 32, hipMemcpyDeviceToHost, c.stream));
-      stream_wait(c.stream);
+      fv_ipa_last(c, field, a_cur, r, rinv, sflags, dout, out_a_hat);  // the last round's vector has two elements
     } catch (...) {
       (void)hipStreamSynchronize(c.stream);  // nothing of this call still reads the caller's vectors
       throw;

@@ -555,23 +555,31 @@ template <int CID> struct CurveImpl {
     write_result<CID>(acc, flags, out, inf);
   }
   static void commit_batch(Ctx& c, const BaseSet& bs, const BatchItem* items, size_t k, const MsmCall& shared, const void* h_xy64,
-                           const uint8_t* rs32, uint32_t flags, uint8_t* out, uint8_t* inf) {
+                           const uint8_t* rs32, const std::function<void(size_t, uint8_t*)>* late, uint32_t flags, uint8_t* out,
+                           uint8_t* inf) {
     std::vector<PoolFuture<XYZZ<BF>>> hr(k);
-    std::vector<uint8_t> any(k, 0);
     for (size_t j = 0; j < k; j++) {  // every range check before anything is launched
+      require(items[j].n <= bs.n, NMX_E_HANDLE, "ck shorter than v");
+      if (late) continue;
       uint32_t rw[8];
       memcpy(rw, rs32 + 32 * j, 32);
       require(Fp<SF>::words_lt_p(rw), NMX_E_SCALAR_RANGE, "blinding scalar >= field modulus");
-      for (int i = 0; i < 8; i++) any[j] |= rw[i] ? 1 : 0;
-      require(items[j].n <= bs.n, NMX_E_HANDLE, "ck shorter than v");
     }
     std::array<uint8_t, 64> hb;
     memcpy(hb.data(), h_xy64, 64);
     for (size_t j = 0; j < k; j++) {
-      if (!any[j]) continue;
-      std::array<uint8_t, 32> rb;
-      memcpy(rb.data(), rs32 + 32 * j, 32);
-      hr[j] = PoolFuture<XYZZ<BF>>([hb, rb, flags] { return blind_point(hb.data(), rb.data(), flags); });
+      if (late) {
+        const std::function<void(size_t, uint8_t*)> get = *late;
+        hr[j] = PoolFuture<XYZZ<BF>>([hb, get, j, flags] {
+          uint8_t rb[32];
+          get(j, rb);
+          return blind_point(hb.data(), rb, flags);
+        });
+      } else {
+        std::array<uint8_t, 32> rb;
+        memcpy(rb.data(), rs32 + 32 * j, 32);
+        hr[j] = PoolFuture<XYZZ<BF>>([hb, rb, flags] { return blind_point(hb.data(), rb.data(), flags); });
+      }
     }
     std::vector<XYZZ<BF>> r(k, XYZZ<BF>::identity());
     if (k >= 2 && batch_limit_for<CID>(bs) >= k) {
@@ -584,7 +592,7 @@ template <int CID> struct CurveImpl {
       }
     }
     for (size_t j = 0; j < k; j++) {
-      if (any[j]) r[j].add(hr[j].get());
+      r[j].add(hr[j].get());  // (h * 0 is the identity)
       write_result<CID>(r[j], flags, out + 64 * j, inf ? inf + j : nullptr);
     }
   }

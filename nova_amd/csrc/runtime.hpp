@@ -694,8 +694,10 @@ struct CurveOps {
   // out[j] = msm(items[j]) + h * rs[j] for k vectors over one key: ONE fused pipeline run when the key's tables take k bucket sets
   // (batch_limit), one run per vector otherwise; the k blinding terms on pool threads under the device work (as `commit`).
   // rs32: k scalars in the ABI form of `flags`, host.  The two commitments of an inner-product-argument round (ipa_pc.rs:213-232).
+  // late: when set, the scalars are not known yet -- (*late)(j, out32) blocks until scalar j is and writes it (called on the pool
+  // thread that computes blinding term j, under the device work); rs32 is ignored then.
   void (*commit_batch)(Ctx&, const BaseSet&, const BatchItem* items, size_t k, const MsmCall& shared, const void* h_xy64,
-                       const uint8_t* rs32, uint32_t flags, uint8_t* out64, uint8_t* inf);
+                       const uint8_t* rs32, const std::function<void(size_t, uint8_t*)>* late, uint32_t flags, uint8_t* out64, uint8_t* inf);
   int scalar_field;  // field id (NMX_F_*) of the curve's scalars
 };
 // field-vector kernels (fieldvec.hip)
@@ -727,14 +729,15 @@ void fv_spmv_apply_pair(Ctx&, int field, const uint32_t* indptr, const uint32_t*
 bool fv_batch_invert(Ctx&, int field, const void* v, size_t n, uint32_t flags, void* out);  // false: an element is zero
 void fv_lincomb(Ctx&, int field, const void* const* vecs, const size_t* lens, size_t k, const void* s, size_t n_out,
                 uint32_t flags, void* out);
-// inner-product argument, field side (ipa.hpp): all pointers device words, `partial` >= fv_ipa_partial_bytes(n), `dout` 64 bytes
-void fv_ipa_expand(Ctx&, int field, const uint32_t* a, const uint32_t* b, const uint32_t* S, size_t n, size_t len, uint32_t flags,
-                   uint32_t* vL, uint32_t* vR, uint32_t* partial, uint32_t* dout, uint8_t* out_c64);
-void fv_ipa_fold(Ctx&, int field, const uint32_t* a, const uint32_t* b, size_t len, const void* r, const void* rinv, uint32_t flags,
-                 uint32_t* a_out, uint32_t* b_out, const uint32_t* S, size_t s_len, uint32_t* S_out);
+// inner-product argument, field side (ipa.hpp): device words; `done` is recorded behind the round's kernel, whose block partials land in
+// pinned host memory at *partial_host (the context's mailbox) -- fv_ipa_scalar adds them up on whatever thread waited for `done`
+void fv_ipa_round(Ctx&, int field, const uint32_t* a, const uint32_t* b, const uint32_t* S, uint32_t* a_out, uint32_t* b_out, uint32_t* S_out,
+                  size_t n, size_t len, const void* r_prev, const void* rinv_prev, uint32_t flags, uint32_t* vL, uint32_t* vR, hipEvent_t done,
+                  const uint32_t** partial_host);
+void fv_ipa_scalar(int field, const uint32_t* partial_host, size_t n, int which, uint32_t flags, uint8_t* out32);
+void fv_ipa_last(Ctx&, int field, const uint32_t* a, const void* r, const void* rinv, uint32_t flags, uint32_t* dout, uint8_t* out32);
 void fv_ipa_one(Ctx&, int field, uint32_t* S);
 bool fv_ipa_invert(int field, const void* r, uint32_t flags, void* out);
-size_t fv_ipa_partial_bytes(size_t n);
 void fv_plain_sums(Ctx&, int field, int kind, const void* A, const void* B, const void* C, size_t len, uint32_t flags,
                    uint8_t* out);  // sumcheck.hip
 void fv_eval_multi(Ctx&, int field, const void* const* polys, const size_t* lens, size_t k, const void* points, size_t m,
