@@ -478,3 +478,29 @@ def test_eight_way_config3_shape(nmx, sharded):
     assert pt(g.point_sum(parts)) == exp
     sv.close()
     ck.close()
+
+
+@pytest.mark.parametrize("k", [2, 3])
+def test_inner_product_argument_over_a_sharded_key(nmx, sharded, k):
+    """nmx_ipa_prove when the Pedersen key lies across several devices: every round's L and R are two sharded commitments (the expanded
+    vectors sit on the primary device, each shard pulls its piece) -- same proof as the oracle's key-folding restatement, and it passes
+    the reference's verifier (ipa_pc.rs:286-390)."""
+    from nova_amd import _lib
+    from tests import ipa_common as ic
+    sharded(k)
+    curve, n = R.GRUMPKIN, 2048
+    before = _lib.stats()[_lib.STAT_SHARDED_CALLS]
+
+    def gpu(ck, ckc, a, b, m, tr):
+        import torch
+        K = nmx.CommitmentKey.from_host(curve.cid, ck)
+        out = nmx.ipa_prove(K, ckc, torch.from_numpy(a.copy()).cuda(), torch.from_numpy(b.copy()).cuda(), tr)
+        K.close()
+        return out
+
+    def oracle(ck, ckc, a, b, m, tr):
+        return cref.ipa_prove(curve.cid, ck, ckc, a, b, m, cref.make_ipa_transcript(tr))
+    got, tg = ic.check_ipa(gpu, curve, n, seed=12)
+    want, tw = ic.check_ipa(oracle, curve, n, seed=12)
+    assert got == want and tg.rs == tw.rs
+    assert _lib.stats()[_lib.STAT_SHARDED_CALLS] >= before + 2 * 11
