@@ -387,7 +387,7 @@ static void run_msm_batch(Ctx& c, const BaseSet& bs, size_t offset, const BatchI
   require(bs.pre_W && k >= 1 && k <= 256 && !shared.u64_mode && !shared.gather_host && !shared.all_ones, NMX_E_ARG,
           "fused batch: unsupported call");
   const uint32_t sbits = FpParams<SF>::BITS;
-  std::vector<uint32_t> off(k + 1);
+  std::vector<uint32_t> off(k + 1), desc;
   std::vector<const uint32_t*> ptrs(k);
   uint64_t total_n = 0, lens_hash = 0x243f6a8885a308d3ull;
   for (size_t j = 0; j < k; j++) {
@@ -435,8 +435,10 @@ static void run_msm_batch(Ctx& c, const BaseSet& bs, size_t offset, const BatchI
   for (int attempt = 0; attempt < 2; attempt++) try {
   for (int pass = (c.shape_key == shape_key && c.shape_bytes <= c.cap) ? 1 : 0; pass < 2; pass++) {
     DeviceBackend be(c, pass == 0, prof);
-    uint32_t* d_off = be.alloc<uint32_t>(k + 1);
-    const uint32_t** d_ptr = be.alloc<const uint32_t*>(k);
+    // offsets and vector pointers in ONE allocation and one copy: [k + 1 offsets, padded to 8 bytes][k pointers]
+    const size_t off_words = (k + 2) & ~(size_t)1;
+    uint32_t* d_off = be.alloc<uint32_t>(off_words + 2 * k);
+    const uint32_t** d_ptr = (const uint32_t**)(d_off + off_words);
     for (size_t j = 0; j < k; j++) {
       if (shared.scalars_device) {
         ptrs[j] = (const uint32_t*)items[j].scalars;
@@ -447,9 +449,11 @@ static void run_msm_batch(Ctx& c, const BaseSet& bs, size_t offset, const BatchI
           HIPCHK(hipMemcpyAsync(d_s, items[j].scalars, items[j].n * 32, hipMemcpyHostToDevice, c.stream));
       }
     }
-    if (pass == 1) {  // (pageable sources: the copies are staged before the call returns; both vectors outlive the sync)
-      HIPCHK(hipMemcpyAsync(d_off, off.data(), (k + 1) * 4, hipMemcpyHostToDevice, c.stream));
-      HIPCHK(hipMemcpyAsync(d_ptr, ptrs.data(), k * sizeof(void*), hipMemcpyHostToDevice, c.stream));
+    if (pass == 1) {  // (a pageable source: the copy is staged before the call returns; `desc` outlives the sync)
+      desc.assign(off_words + 2 * k, 0);
+      memcpy(desc.data(), off.data(), (k + 1) * 4);
+      memcpy(desc.data() + off_words, ptrs.data(), k * sizeof(void*));
+      HIPCHK(hipMemcpyAsync(d_off, desc.data(), desc.size() * 4, hipMemcpyHostToDevice, c.stream));
     }
     a.batch_off = d_off;
     a.batch_vec = d_ptr;

@@ -167,7 +167,8 @@ MsmShape msm_pipeline(BE& be, const MsmArgs& a, uint32_t scalar_bits, XYZZW* wsu
   TaskRec* extra = be.template alloc<TaskRec>(seg ? 1 : extra_cap);
   XYZZW* buckets = be.template alloc<XYZZW>(sh.nbuckets);
   XYZZW* partials = be.template alloc<XYZZW>(seg ? 1 : extra_cap);
-  be.memset0(start, nzero * sizeof(uint32_t));
+  // (the whole 256-byte-padded allocation: a size that is not a multiple of the fill kernel's vector width costs a second dispatch)
+  be.memset0(start, (nzero * sizeof(uint32_t) + 255) & ~(size_t)255);
 
   DigitSrc<SFID> src;
   src.scalars = a.scalars;

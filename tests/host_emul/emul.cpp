@@ -30,7 +30,7 @@ struct HostEmulBackend {
     for (void* p : blocks) free(p);
   }
   template <class T> T* alloc(size_t count) {
-    void* p = calloc(count ? count : 1, sizeof(T));
+    void* p = calloc(((count ? count : 1) * sizeof(T) + 255) & ~(size_t)255, 1);  // padded to 256 bytes like the device arena (the pipeline clears whole allocations)
     blocks.push_back(p);
     return (T*)p;
   }
