@@ -145,7 +145,7 @@ def main():
     ap.add_argument("--separate-folds", action="store_true", help="hyperkzg replay: the ell - 1 pair folds as ell - 1 calls instead of nmx_poly_fold_chain")
     ap.add_argument("--separate-spmv", action="store_true", help="spartan replay: the three (transposed) products as three calls instead of nmx_spmv_apply_many")
     ap.add_argument("--sync-field-ops", action="store_true", help="prove_step replay: every field-vector call waits for its kernel (round 3's form)")
-    ap.add_argument("--workload", default="msm", choices=["msm", "axpy", "cross_term", "bind", "sumcheck3", "round3", "quad_prod", "lincomb8", "horner", "mle_eval", "spmv", "prove_step_replay", "hyperkzg_replay", "spartan_replay", "compressed_snark_replay"],
+    ap.add_argument("--workload", default="msm", choices=["msm", "axpy", "cross_term", "bind", "sumcheck3", "round3", "quad_prod", "lincomb8", "horner", "mle_eval", "spmv", "prove_step_replay", "hyperkzg_replay", "spartan_replay", "compressed_snark_replay", "ipa_replay"],
                     help="msm = the headline (default); the others time one HBM-bound field-vector kernel of "
                          "SURVEY.md 8(f) at 2^log2n elements per GPU")
     args = ap.parse_args()
@@ -201,6 +201,9 @@ def main():
     if args.workload == "compressed_snark_replay":
         assert world == 1
         return emit(compressed_snark_replay(args, torch), False, dist)
+    if args.workload == "ipa_replay":
+        assert world == 1
+        return emit(ipa_replay(args, torch), False, dist)
     if args.workload != "msm":
         return field_workload(args, world, rank, L, torch, dist)
 
@@ -878,6 +881,16 @@ def extras(out, args, torch, L, ck, host_scalars, dev_scalars):
                                              "what": cs["config"]["workload"]}
     except Exception as e:                                 # never lose the headline to an auxiliary block
         out["compressed_snark_replay_ms"] = {"error": repr(e)}
+    # (5d) the secondary's evaluation argument on its own: the inner-product argument at 2^14
+    try:
+        a6 = argparse.Namespace(**vars(args))
+        a6.log2n, a6.steps, a6.warmup = 14, 5, 2
+        ir = ipa_replay(a6, torch)
+        out["ipa_prove_ms"] = {"ms": round(ir["value"], 3), "log2n": 14, "ms_per_round": ir["ms_per_round"], "cpu_ms": round(ir["cpu_baseline"]["value"], 1),
+                               "cpu_cores": ir["cpu_baseline"]["cores"], "gpu_matches_cpu": ir["cpu_baseline"]["gpu_matches_cpu"],
+                               "checks": ir["cpu_baseline"]["checks"], "what": ir["config"]["workload"]}
+    except Exception as e:                                 # never lose the headline to an auxiliary block
+        out["ipa_prove_ms"] = {"error": repr(e)}
     # (6) the field-vector kernels' rooflines (north_star: >= 40 % of HBM is about THESE kernels)
     try:
         out["fieldvec"] = fieldvec_block(args, torch, L)
@@ -1815,6 +1828,72 @@ def hyperkzg_sequence(be, ell, p, hat_P, point, tr, call):
 
 
 IPA_GENERATOR_K0 = 424243
+
+
+def ipa_replay(args, torch):
+    """The inner-product argument alone (EvaluationEngine::prove of the Pedersen / IPA engines, src/provider/ipa_pc.rs:69-82, 174-281) at
+    n = 2^log2n on the secondary curve of the cycle (Grumpkin; --cycle pasta: Vesta): a and b resident in HBM, the registered key with its
+    window tables, the native stand-in transcript.  The HIP path never folds the key (nova_amd/csrc/ipa.hpp); the oracle's leg folds it as
+    the reference does (pedersen.rs:484-497).  Checked: every L, R and a_hat equal, and the proof against the reference's verifier
+    equation (tests/ipa_common.py) when n <= 2^14."""
+    import nova_amd
+    from nova_amd import _lib
+    from tests import standin, util
+    ell = args.log2n if args.log2n and args.log2n <= 20 else 14
+    n = 1 << ell
+    cid = {"bn254": 1, "pasta": 3}[getattr(args, "cycle", "bn254")]
+    ce = nova_amd.CommitmentEngine(cid)
+    ck = ce.setup_synthetic(n, k0=7)
+    gk = nova_amd.CommitmentKey.generate(cid, 1, k0=IPA_GENERATOR_K0)
+    U = gk.read(0, 1).tobytes()
+    gk.close()
+    ha, hb, r0 = util.random_scalars(cid, n, seed=61), util.random_scalars(cid, n, seed=62), util.random_scalars(cid, 1, seed=63)
+    da, db = torch.from_numpy(ha).cuda(), torch.from_numpy(hb).cuda()
+    ckc = ce.commit(nova_amd.CommitmentKey(cid, ck.handle, ck.n, U), np.zeros((0, 32), np.uint8), r0).xy
+
+    def run():
+        tr = standin.Transcript(seed=SPARTAN_SEED)
+        return nova_amd.ipa_prove(ck, ckc, da, db, tr.fn_ipa(_lib.IPA_TRANSCRIPT_FN), ctx=tr.ctx)
+    for _ in range(args.warmup):
+        run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    outj = {"metric": "InnerProductArgument::prove ms (one evaluation argument)", "value": dt * 1e3, "unit": "ms", "n_gpus": 1, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE,
+            "data": "synthetic", "ms_per_round": round(dt * 1e3 / max(ell, 1), 4),
+            "config": {"workload": f"InnerProductArgument::prove ({nova_amd.CURVE_NAMES[cid]}, n = 2^{ell}, {ell} rounds): per round one launch for the folds of "
+                                   "the previous round, the expanded scalar vectors and the inner products, then ONE fused two-vector MSM over the "
+                                   "registered key (the key is never folded); stand-in transcript"},
+            "roofline": None}
+    if not args.no_cpu_baseline:
+        from oracle import cref, pyref
+        threads = effective_cpus()
+        cref.set_threads(threads)
+        key = ck.read(0, n)
+        t1 = time.perf_counter()
+        tr = standin.Transcript(seed=SPARTAN_SEED)
+        exp = cref.ipa_prove(cid, key, np.frombuffer(bytes(ckc), np.uint8).copy(), ha, hb, n, tr.fn_ipa(cref.IPA_TRANSCRIPT_FN), ctx=tr.ctx)
+        t_cpu = time.perf_counter() - t1
+        checks = {"proof": tuple(res) == tuple(exp)}
+        if ell <= 14:
+            import ctypes
+            from tests import ipa_common as ic
+            tv, rs = standin.Transcript(seed=SPARTAN_SEED), []
+            for Lp, Rp, (Li, Ri) in zip(res[0], res[1], res[2]):
+                o = (ctypes.c_uint8 * 32)()
+                standin.lib().standin_ipa_transcript(tv.ctx, (ctypes.c_uint8 * 64)(*Lp), int(Li), (ctypes.c_uint8 * 64)(*Rp), int(Ri), o)
+                rs.append(int.from_bytes(bytes(o), "little"))
+            checks["reference_verifier"] = bool(ic.verify(pyref.CURVES_BY_ID[cid], key, np.frombuffer(bytes(ckc), np.uint8).copy(), ha, hb, n,
+                                                          res[0], res[1], res[2], res[3], rs))
+        outj["cpu_baseline"] = {"value": t_cpu * 1e3, "unit": "ms", "cores": threads, "kind": "port",
+                                "sample": "the same argument once through oracle/nova_ref.c, key fold included (2 n scalar multiplications)",
+                                "gpu_matches_cpu": all(checks.values()), "checks": checks}
+    ck.close()
+    return outj
 
 
 def ipa_sequence(be, ell, poly, point, tr, call):

@@ -128,3 +128,13 @@ def test_errors(nmx):
     want = cref.ipa_prove(curve.cid, ck, ckc, a, b, n, cref.make_ipa_transcript(ic.IpaTranscript(curve.r)))
     assert (Ls, Rs, infs, ah) == want
     K.close(), short.close()
+
+
+@pytest.mark.parametrize("cycle", ["bn254", "pasta"])
+def test_bench_workload(nmx, cycle):
+    """bench.py --workload ipa_replay (also the `ipa_prove_ms` block of the default line): equal to the oracle, accepted by the verifier"""
+    import argparse
+    import torch
+    import bench
+    out = bench.ipa_replay(argparse.Namespace(log2n=10, steps=2, warmup=1, no_cpu_baseline=False, cycle=cycle), torch)
+    assert out["cpu_baseline"]["gpu_matches_cpu"] is True and out["cpu_baseline"]["checks"] == {"proof": True, "reference_verifier": True}
