@@ -318,6 +318,55 @@ template <int FIELD> struct Sumcheck {
 };
 }  // namespace spartan
 
+// The inner-product argument (src/provider/ipa_pc.rs:174-281) over the C ABI's one call.  `Transcript` is the caller's: any type with
+// `Scalar round(const Point& L, const Point& R)` -- `transcript.absorb(b"L", &L); transcript.absorb(b"R", &R); transcript.squeeze(b"r")`
+// (:231-234).  Host vectors here (uploaded for the call); `ck_c` is the already scaled one-point key (`ck_c.scale(&r)`, :190-191).
+namespace ipa {
+using provider::Affine;
+using provider::check;
+using provider::CommitmentKey;
+using provider::Point;
+using provider::Scalar;
+
+struct InnerProductArgument {  // L_vec, R_vec, a_hat (:157-162)
+  std::vector<Point> L_vec, R_vec;
+  Scalar a_hat{};
+};
+namespace detail {
+template <class Transcript> int round_cb(void* ctx, const uint8_t* L, int L_inf, const uint8_t* R, int R_inf, uint8_t* out) {
+  try {
+    Point l, r;
+    std::copy(L, L + 64, l.xy.begin()), std::copy(R, R + 64, r.xy.begin());
+    l.is_inf = L_inf != 0, r.is_inf = R_inf != 0;
+    const Scalar c = static_cast<Transcript*>(ctx)->round(l, r);
+    std::copy(c.begin(), c.end(), out);
+    return 0;
+  } catch (...) {
+    return 1;  // never let an exception cross the C frame: the call fails with NMX_E_ARG
+  }
+}
+}  // namespace detail
+template <class Transcript>
+InnerProductArgument prove(const CommitmentKey& ck, const Affine& ck_c, const std::vector<Scalar>& a_vec, const std::vector<Scalar>& b_vec,
+                           Transcript& tr, bool mont = false) {
+  if (a_vec.size() != b_vec.size() || a_vec.empty()) throw std::invalid_argument("InvalidInputLength (ipa_pc.rs:185-187)");
+  const size_t n = a_vec.size();
+  size_t rounds = 0;
+  while (((size_t)1 << rounds) < n) rounds++;
+  std::vector<uint8_t> L(64 * rounds + 1), R(64 * rounds + 1), inf(2 * rounds + 1);
+  InnerProductArgument out;
+  check(nmx_ipa_prove(ck.handle(), ck_c.data(), a_vec.data(), b_vec.data(), n, mont ? NMX_SCALARS_MONT : 0u, &detail::round_cb<Transcript>, &tr,
+                      L.data(), R.data(), inf.data(), out.a_hat.data()));
+  out.L_vec.resize(rounds), out.R_vec.resize(rounds);
+  for (size_t k = 0; k < rounds; k++) {
+    std::copy(L.begin() + 64 * k, L.begin() + 64 * k + 64, out.L_vec[k].xy.begin());
+    std::copy(R.begin() + 64 * k, R.begin() + 64 * k + 64, out.R_vec[k].xy.begin());
+    out.L_vec[k].is_inf = inf[2 * k] != 0, out.R_vec[k].is_inf = inf[2 * k + 1] != 0;
+  }
+  return out;
+}
+}  // namespace ipa
+
 // Hosts that keep their vectors in HBM between provider calls (INTEGRATION.md sections 2b-2e: the patched r1cs/mod.rs, nifs.rs,
 // snark.rs): the same operations over device pointers.  Thin by design -- each function is one C call with NMX_SCALARS_DEVICE (and
 // NMX_ASYNC where the host does not look at the result before its next synchronous call); allocation is the host's business

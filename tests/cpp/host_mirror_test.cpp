@@ -128,6 +128,71 @@ template <int FIELD> static int run_sumcheck(int topmask) {
   return 0;
 }
 
+// ---- the inner-product argument through the C++ mirror (nova::ipa::prove) against the oracle's key-folding restatement ---------------
+extern "C" {
+typedef int (*ref_ipa_transcript_fn)(void* ctx, const uint8_t* L_xy64, int L_is_inf, const uint8_t* R_xy64, int R_is_inf, uint8_t* r32);
+int ref_ipa_prove(int curve, const uint8_t* ck_xy64, const uint8_t* ck_c_xy64, const uint8_t* a_le32, const uint8_t* b_le32, size_t n,
+                  ref_ipa_transcript_fn cb, void* ctx, uint8_t* out_L, uint8_t* out_R, uint8_t* out_inf, uint8_t* out_a_hat);
+}
+struct IpaStandin {  // absorb L and R, squeeze r: the sum-check stand-in over the points' words
+  Standin st;
+  Scalar round(const Point& L, const Point& R) {
+    std::vector<Scalar> co(4);
+    memcpy(co[0].data(), L.xy.data(), 32), memcpy(co[1].data(), L.xy.data() + 32, 32);
+    memcpy(co[2].data(), R.xy.data(), 32), memcpy(co[3].data(), R.xy.data() + 32, 32);
+    Scalar r = st.round(co);
+    r[0] |= 1;  // never zero
+    return r;
+  }
+};
+static int ipa_standin_cb(void* ctx, const uint8_t* L, int Li, const uint8_t* R, int Ri, uint8_t* out) {
+  Point l, r;
+  memcpy(l.xy.data(), L, 64), memcpy(r.xy.data(), R, 64);
+  l.is_inf = Li != 0, r.is_inf = Ri != 0;
+  const Scalar c = static_cast<IpaStandin*>(ctx)->round(l, r);
+  memcpy(out, c.data(), 32);
+  return 0;
+}
+template <int CURVE> static int run_ipa(const uint8_t gen[64], int topmask) {
+  std::mt19937_64 rng(11);
+  for (size_t n : {1ul, 2ul, 64ul, 512ul}) {
+    std::vector<Affine> bases(n + 1);
+    ref_sequential_bases(CURVE, gen, 4242, n + 1, bases[0].data());
+    std::vector<Scalar> a(n), b(n);
+    for (auto* v : {&a, &b})
+      for (auto& s : *v) {
+        for (int i = 0; i < 32; i += 8) {
+          uint64_t w = rng();
+          memcpy(s.data() + i, &w, 8);
+        }
+        s[31] &= topmask;
+      }
+    CommitmentKey ck(CURVE, std::vector<Affine>(bases.begin(), bases.begin() + n), bases[n]);
+    const Affine ck_c = bases[n];  // (any point of the group serves as the scaled one-point key)
+    IpaStandin t1, t2;
+    const auto got = nova::ipa::prove(ck, ck_c, a, b, t1);
+    size_t rounds = 0;
+    while (((size_t)1 << rounds) < n) rounds++;
+    std::vector<uint8_t> L(64 * rounds + 1), R(64 * rounds + 1), inf(2 * rounds + 1);
+    Scalar a_hat;
+    if (ref_ipa_prove(CURVE, bases[0].data(), ck_c.data(), a[0].data(), b[0].data(), n, ipa_standin_cb, &t2, L.data(), R.data(), inf.data(), a_hat.data()))
+      return 1;
+    if (got.L_vec.size() != rounds || got.R_vec.size() != rounds || !(got.a_hat == a_hat)) return 1;
+    for (size_t k = 0; k < rounds; k++) {
+      if (memcmp(got.L_vec[k].xy.data(), L.data() + 64 * k, 64) || memcmp(got.R_vec[k].xy.data(), R.data() + 64 * k, 64)) return 1;
+      if (got.L_vec[k].is_inf != (inf[2 * k] != 0) || got.R_vec[k].is_inf != (inf[2 * k + 1] != 0)) return 1;
+    }
+  }
+  try {  // InvalidInputLength
+    CommitmentKey ck(CURVE, std::vector<Affine>(4), Affine{});
+    IpaStandin t;
+    nova::ipa::prove(ck, Affine{}, std::vector<Scalar>(4), std::vector<Scalar>(3), t);
+    return 1;
+  } catch (const std::invalid_argument&) {
+  }
+  return 0;
+}
+
 template <int CURVE> static int run(const uint8_t gen[64], int topmask) {
   const size_t n = 100;
   std::vector<Affine> bases(n + 1);
@@ -253,6 +318,8 @@ int main() {
     if (run<NMX_PALLAS>(g_pallas, 0x3f)) return 1;
     if (run_sumcheck<NMX_F_BN254_FR>(0x1f)) return 1;
     if (run_sumcheck<NMX_F_PASTA_FQ>(0x3f)) return 1;
+    if (run_ipa<NMX_BN254_G1>(g_bn, 0x1f)) return 1;
+    if (run_ipa<NMX_PALLAS>(g_pallas, 0x3f)) return 1;
   } catch (const Error& e) {
     fprintf(stderr, "%s\n", e.what());
     return e.code == NMX_E_NO_DEVICE ? 3 : 2;
