@@ -306,3 +306,23 @@ def test_prove_step_trait_only_form_matches_oracle(nmx):
     args = argparse.Namespace(iters=1024, steps=1, warmup=0, no_cpu_baseline=False)
     out = bench.prove_step_replay(args, torch)
     assert out["trait_only"]["gpu_matches_cpu"] is True and out["trait_only"]["calls"] == 4
+
+
+def test_inner_product_argument_2p19(nmx):
+    """nmx_ipa_prove at a size whose device state no longer fits the context's small arena (its own allocation, capi.hip) and whose
+    key carries c = 16 tables: equal to the oracle's key-folding restatement round by round (same stand-in transcript)."""
+    import torch
+    from nova_amd import _lib
+    from oracle import cref
+    from oracle import pyref as R
+    from tests import standin, util
+    curve, n = R.GRUMPKIN, 1 << 19
+    ck = nmx.CommitmentKey.generate(curve.cid, n, k0=11)
+    key = ck.read(0, n)
+    a, b = util.random_scalars(curve.cid, n, seed=5), util.random_scalars(curve.cid, n, seed=6)
+    ckc = cref.sequential_bases(curve, 31337, 1).copy()
+    t1, t2 = standin.Transcript(seed=3), standin.Transcript(seed=3)
+    got = nmx.ipa_prove(ck, ckc, torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), t1.fn_ipa(_lib.IPA_TRANSCRIPT_FN), ctx=t1.ctx)
+    want = cref.ipa_prove(curve.cid, key, ckc, a, b, n, t2.fn_ipa(cref.IPA_TRANSCRIPT_FN), ctx=t2.ctx)
+    assert tuple(got) == tuple(want) and len(got[0]) == 19
+    ck.close()
