@@ -1,6 +1,6 @@
 // ipa.hpp -- the field side of the inner-product argument (InnerProductArgument::prove, /root/reference/src/provider/ipa_pc.rs:174-281;
 // EvaluationEngine::prove :69-82 = the evaluation argument of S2 in CompressedSNARK::prove, src/nova/mod.rs:862-881), included by
-// sumcheck.hip (it uses that file's block sums and the partial-sum launch).
+// sumcheck.hip (it uses that file's block sums and challenge conversion, and the provers' pinned mailbox of sumcheck_prove.hpp).
 //
 // The reference folds the commitment key every round -- ck' = ck.fold(r^-1, r): n/2 two-point MSMs (pedersen.rs:484-497), 2n scalar
 // multiplications per proof -- and commits the round's L and R against the folded halves.  Here the key is never folded.  With
