@@ -326,3 +326,27 @@ def test_inner_product_argument_2p19(nmx):
     want = cref.ipa_prove(curve.cid, key, ckc, a, b, n, t2.fn_ipa(cref.IPA_TRANSCRIPT_FN), ctx=t2.ctx)
     assert tuple(got) == tuple(want) and len(got[0]) == 19
     ck.close()
+
+
+@pytest.mark.parametrize("cid,lgk", [(0, 20), (1, 18), (0, 22)], ids=["bn254-2p20-c17", "grumpkin-2p18-c16", "bn254-2p22-c20+prefix"])
+def test_inner_product_argument_over_prefixes_of_large_keys(nmx, cid, lgk):
+    """nmx_ipa_prove over the first n points of a long registered key, whatever tables it carries: the fused two-vector run on c = 17 and
+    c = 16 tables, the narrow prefix tables of a c = 20 key (or one MSM per vector where nothing fuses) -- equal to the oracle's
+    key-folding restatement."""
+    import torch
+    from nova_amd import _lib
+    from oracle import cref
+    from oracle import pyref as R
+    from tests import standin, util
+    curve = R.CURVES_BY_ID[cid]
+    ck = nmx.CommitmentKey.generate(cid, 1 << lgk, k0=3)
+    ckc = cref.sequential_bases(curve, 31337, 1).copy()
+    for lg in (3, 12, 15):
+        n = 1 << lg
+        key = ck.read(0, n)
+        a, b = util.random_scalars(cid, n, seed=5), util.random_scalars(cid, n, seed=6)
+        t1, t2 = standin.Transcript(seed=3), standin.Transcript(seed=3)
+        got = nmx.ipa_prove(ck, ckc, torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), t1.fn_ipa(_lib.IPA_TRANSCRIPT_FN), ctx=t1.ctx)
+        want = cref.ipa_prove(cid, key, ckc, a, b, n, t2.fn_ipa(cref.IPA_TRANSCRIPT_FN), ctx=t2.ctx)
+        assert tuple(got) == tuple(want), (lgk, lg)
+    ck.close()
