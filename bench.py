@@ -870,7 +870,7 @@ def extras(out, args, torch, L, ck, host_scalars, dev_scalars):
     # (5c) configs[4] as ONE chained sequence: CompressedSNARK::prove (folds -> Spartan -> HyperKZG on the batched witness in HBM)
     try:
         a5 = argparse.Namespace(**vars(args))
-        a5.log2n, a5.steps, a5.warmup, a5.log2n_secondary = 20, 3, 1, 14
+        a5.log2n, a5.steps, a5.warmup, a5.log2n_secondary = 20, 5, 3, 14
         cs = compressed_snark_replay(a5, torch)
         out["compressed_snark_replay_ms"] = {"ms": round(cs["value"], 3), "log2n": 20, "log2n_secondary": 14,
                                              "cpu_ms": round(cs["cpu_baseline"]["value"], 1), "cpu_cores": cs["cpu_baseline"]["cores"],
