@@ -103,3 +103,22 @@ def test_layout_selfcheck_min_n_and_stats_are_host_side(L):
     st = _lib.stats()
     assert len(st) == _lib.STAT_COUNT and all(v >= 0 for v in st)
     assert L.nmx_check_layout(9, gen, s, 1) == _lib.E_ARG
+
+
+def test_ipa_prove_argument_checks_are_host_side(L):
+    """nmx_ipa_prove refuses bad arguments before it touches a device or a key: null callback / null vectors / unknown flags / n not a
+    power of two -> NMX_E_ARG; an unknown key handle -> NMX_E_HANDLE (InnerProductArgument::prove, ipa_pc.rs:174-188)."""
+    from nova_amd import _lib
+    z = np.zeros(64, np.uint8)
+    cb = _lib.IPA_TRANSCRIPT_FN(lambda *a: 0)
+    null_cb = ctypes.cast(None, _lib.IPA_TRANSCRIPT_FN)
+    p = z.ctypes.data
+    assert L.nmx_ipa_prove(1, p, p, p, 2, 0, null_cb, None, p, p, None, p) == _lib.E_ARG
+    assert L.nmx_ipa_prove(1, None, p, p, 2, 0, cb, None, p, p, None, p) == _lib.E_ARG
+    assert L.nmx_ipa_prove(1, p, None, p, 2, 0, cb, None, p, p, None, p) == _lib.E_ARG
+    assert L.nmx_ipa_prove(1, p, p, p, 2, 1 << 9, cb, None, p, p, None, p) == _lib.E_ARG          # NMX_ASYNC is not a flag of this call
+    assert L.nmx_ipa_prove(1, p, p, p, 6, 0, cb, None, p, p, None, p) == _lib.E_ARG
+    assert L.nmx_ipa_prove(1, p, p, p, 0, 0, cb, None, p, p, None, p) == _lib.E_ARG
+    assert L.nmx_ipa_prove(1, p, p, p, 4, 0, cb, None, None, p, None, p) == _lib.E_ARG            # rounds > 0 need out_L / out_R
+    assert L.nmx_ipa_prove(0xdeadbeef, p, p, p, 4, 0, cb, None, p, p, None, p) == _lib.E_HANDLE
+

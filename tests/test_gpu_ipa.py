@@ -138,3 +138,22 @@ def test_bench_workload(nmx, cycle):
     import bench
     out = bench.ipa_replay(argparse.Namespace(log2n=10, steps=2, warmup=1, no_cpu_baseline=False, cycle=cycle), torch)
     assert out["cpu_baseline"]["gpu_matches_cpu"] is True and out["cpu_baseline"]["checks"] == {"proof": True, "reference_verifier": True}
+
+
+def test_raw_abi_without_the_identity_flags(nmx):
+    """out_is_inf may be null (the shim that only wants the points); the call is otherwise the same"""
+    import ctypes
+    from nova_amd import _lib
+    from tests import standin
+    curve, n = R.GRUMPKIN, 32
+    ck, ckc, a, b = ic.make_instance(curve, n, 4)
+    K = nmx.CommitmentKey.from_host(curve.cid, ck)
+    t1, t2 = standin.Transcript(seed=2), standin.Transcript(seed=2)
+    oL, oR, ah = np.zeros(64 * 5, np.uint8), np.zeros(64 * 5, np.uint8), np.zeros(32, np.uint8)
+    rc = _lib.lib().nmx_ipa_prove(K.handle, ckc.ctypes.data, a.ctypes.data, b.ctypes.data, n, 0, t1.fn_ipa(_lib.IPA_TRANSCRIPT_FN), t1.ctx,
+                                  oL.ctypes.data, oR.ctypes.data, None, ah.ctypes.data)
+    assert rc == 0
+    Ls, Rs, infs, want_ah = cref.ipa_prove(curve.cid, ck, ckc, a, b, n, t2.fn_ipa(cref.IPA_TRANSCRIPT_FN), ctx=t2.ctx)
+    assert oL.tobytes() == b"".join(Ls) and oR.tobytes() == b"".join(Rs) and ah.tobytes() == want_ah
+    K.close()
+
